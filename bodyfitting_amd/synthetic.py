@@ -1,0 +1,455 @@
+"""Seeded synthetic SMPL-shaped body models and multi-view fitting problems.
+
+No SMPL / SMPL-X model files, GMM prior or datasets exist in the build or GPU
+containers (reference README.md:18 asks the user to download them), so every
+test, golden fixture and bench input is generated here, with the real tensor
+shapes the reference consumes:
+
+  * body model tensors as smplx==0.1.13 stores them (called through reference
+    models/smpl.py:56-83): v_template[NV,3], shapedirs[NV,3,NB],
+    posedirs[9(NJ-1),3NV], J_regressor[NJ,NV] (dense), lbs_weights[NV,NJ],
+    parents[NJ], plus J_regressor_extra[9,NV] (reference models/smpl.py:62-64),
+    the 21 VertexJointSelector ids and the 49-entry joint map
+    (reference constants.py:13-89);
+  * the GMM pose prior dict {means[8,69], covars[8,69,69], weights[8]} that
+    reference smplify/prior.py:127-133 unpickles from data/gmm_08.pkl;
+  * a ring of calibrated cameras (recipe follows reference utils/renderer.py:7-25,
+    expressed directly in the OpenCV convention the loss assumes), OpenPose-25
+    keypoints with confidences, and an HMR-like initial estimate.
+
+Everything is numpy + ``numpy.random.default_rng(seed)`` so it is bit-stable on
+the build box and on the GPU box (same image).  Seeds: 0 for the model,
+``1000 + f`` for frame ``f``.
+"""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+# kinematic trees (smplx 0.1.13 semantics)
+SMPL_PARENTS = np.array(
+    [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21],
+    dtype=np.int32)
+
+SMPLX_PARENTS = np.array(
+    [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19,
+     15, 15, 15,
+     20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35, 20, 37, 38,
+     21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50, 21, 52, 53], dtype=np.int32)
+
+# rest-pose joint locations of the capsule humanoid (metres, y up, +x = body left)
+_SMPL_REST = np.array([
+    [0.000, 0.000, 0.000],    # 0 pelvis
+    [0.070, -0.090, 0.000],   # 1 L hip
+    [-0.070, -0.090, 0.000],  # 2 R hip
+    [0.000, 0.110, -0.020],   # 3 spine1
+    [0.100, -0.480, 0.000],   # 4 L knee
+    [-0.100, -0.480, 0.000],  # 5 R knee
+    [0.000, 0.250, 0.000],    # 6 spine2
+    [0.090, -0.900, -0.030],  # 7 L ankle
+    [-0.090, -0.900, -0.030],  # 8 R ankle
+    [0.000, 0.310, 0.020],    # 9 spine3
+    [0.110, -0.960, 0.090],   # 10 L foot
+    [-0.110, -0.960, 0.090],  # 11 R foot
+    [0.000, 0.520, -0.020],   # 12 neck
+    [0.080, 0.420, 0.000],    # 13 L collar
+    [-0.080, 0.420, 0.000],   # 14 R collar
+    [0.000, 0.610, 0.030],    # 15 head
+    [0.190, 0.450, 0.000],    # 16 L shoulder
+    [-0.190, 0.450, 0.000],   # 17 R shoulder
+    [0.450, 0.450, 0.000],    # 18 L elbow
+    [-0.450, 0.450, 0.000],   # 19 R elbow
+    [0.700, 0.450, 0.000],    # 20 L wrist
+    [-0.700, 0.450, 0.000],   # 21 R wrist
+    [0.790, 0.450, 0.000],    # 22 L hand
+    [-0.790, 0.450, 0.000],   # 23 R hand
+], dtype=np.float64)
+
+# limb radius per child joint (the tube p->j hangs off joint p)
+_SMPL_RADIUS = np.array([
+    0.0, 0.085, 0.085, 0.120, 0.070, 0.070, 0.125, 0.050, 0.050, 0.125, 0.040, 0.040,
+    0.055, 0.070, 0.070, 0.095, 0.055, 0.055, 0.045, 0.045, 0.035, 0.035, 0.030, 0.030])
+
+# JOINT_MAP of the reference, evaluated over JOINT_NAMES (constants.py:13-89)
+SMPL_JOINT_MAP = np.array(
+    [24, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
+     8, 5, 45, 46, 4, 7, 21, 19, 17, 16, 18, 20, 47, 48, 49, 50, 51, 52, 53, 24, 26, 25, 28, 27],
+    dtype=np.int32)
+
+
+def _smplx_rest():
+    """55-joint rest skeleton: the SMPL body (22 joints) + jaw/eyes + 2x15 finger joints."""
+    rest = np.zeros((55, 3))
+    rest[:22] = _SMPL_REST[:22]
+    rest[22] = [0.000, 0.560, 0.060]    # jaw
+    rest[23] = [0.030, 0.640, 0.090]    # left eye
+    rest[24] = [-0.030, 0.640, 0.090]   # right eye
+    radius = np.zeros(55)
+    radius[:22] = _SMPL_RADIUS[:22]
+    radius[22:25] = [0.035, 0.012, 0.012]
+    # five fingers x three phalanges per hand, fanned out from the wrist
+    for side, wrist, base in ((1.0, 20, 25), (-1.0, 21, 40)):
+        for f in range(5):
+            spread = (f - 2) * 0.018
+            for k in range(3):
+                j = base + 3 * f + k
+                rest[j] = rest[wrist] + [side * (0.085 + 0.028 * k), -0.004 * f, spread]
+                radius[j] = 0.008
+    return rest, radius
+
+
+def _ring_counts(weights, total, minimum=2):
+    """Integer ring counts per bone, at least `minimum` each, summing to `total`."""
+    w = np.asarray(weights, dtype=np.float64)
+    raw = w / w.sum() * total
+    counts = np.maximum(minimum, np.floor(raw).astype(np.int64))
+    # hand out / take back the remainder deterministically by largest fractional part
+    order = np.argsort(-(raw - np.floor(raw)), kind="stable")
+    i = 0
+    while counts.sum() < total:
+        counts[order[i % len(order)]] += 1
+        i += 1
+    i = 0
+    big = np.argsort(-counts, kind="stable")
+    while counts.sum() > total:
+        if counts[big[i % len(big)]] > minimum:
+            counts[big[i % len(big)]] -= 1
+        i += 1
+    return counts
+
+
+def _tube_mesh(rest, parents, radius, nv, seg):
+    """Vertices on rings around every bone p->j, faces between adjacent rings."""
+    nj = len(parents)
+    assert nv % seg == 0
+    bones = [(int(parents[j]), j) for j in range(1, nj)]
+    length = np.array([np.linalg.norm(rest[j] - rest[p]) for p, j in bones])
+    weight = np.maximum(length, 0.04) * np.maximum(radius[1:], 0.01) ** 0.5
+    rings = _ring_counts(weight, nv // seg)
+    verts, faces, bone_of, t_of = [], [], [], []
+    base = 0
+    ang = np.arange(seg) * (2.0 * np.pi / seg)
+    for b, (p, j) in enumerate(bones):
+        axis = rest[j] - rest[p]
+        ln = np.linalg.norm(axis)
+        axis = axis / ln
+        helper = np.array([0.0, 0.0, 1.0]) if abs(axis[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
+        e1 = np.cross(axis, helper)
+        e1 /= np.linalg.norm(e1)
+        e2 = np.cross(axis, e1)
+        nr = int(rings[b])
+        for k in range(nr):
+            t = (k + 0.5) / nr
+            # slightly bulging tube, rotated a little per ring so faces are not co-planar strips
+            r = radius[j] * (1.0 + 0.25 * np.sin(np.pi * t))
+            a = ang + 0.31 * k
+            ring = rest[p] + axis * (t * ln) + r * (np.cos(a)[:, None] * e1 + np.sin(a)[:, None] * e2)
+            verts.append(ring)
+            bone_of += [b] * seg
+            t_of += [t] * seg
+            if k + 1 < nr:
+                lo = base + k * seg
+                hi = lo + seg
+                for s in range(seg):
+                    s1 = (s + 1) % seg
+                    faces.append([lo + s, lo + s1, hi + s])
+                    faces.append([lo + s1, hi + s1, hi + s])
+        base += nr * seg
+    verts = np.concatenate(verts, 0)
+    assert verts.shape[0] == nv
+    return verts, np.asarray(faces, dtype=np.int32), np.asarray(bone_of), np.asarray(t_of), bones
+
+
+def _nearest_vertex(verts, target, taken):
+    d = np.linalg.norm(verts - np.asarray(target)[None], axis=1)
+    for idx in np.argsort(d, kind="stable"):
+        if int(idx) not in taken:
+            taken.add(int(idx))
+            return int(idx)
+    raise RuntimeError("no free vertex")
+
+
+def make_gmm(seed=0, n_comp=8, dim=69):
+    """GMM prior dict with the keys reference smplify/prior.py:130-133 reads."""
+    rng = np.random.default_rng(seed + 7)
+    means = rng.normal(0.0, 0.2, size=(n_comp, dim))
+    covars = np.empty((n_comp, dim, dim))
+    for m in range(n_comp):
+        a = rng.normal(0.0, 1.0, size=(dim, dim))
+        covars[m] = a @ a.T * 0.01 + 0.5 * np.eye(dim)
+    weights = rng.uniform(0.5, 1.5, size=n_comp)
+    weights /= weights.sum()
+    return {"means": means, "covars": covars, "weights": weights}
+
+
+def gmm_buffers(gmm):
+    """The three buffers the merged GMM NLL uses (reference smplify/prior.py:143-160).
+
+    Returns float32 ``means[M,D]``, ``precisions[M,D,D]`` and ``nll_weights[M]`` computed in
+    float64 and rounded once, exactly as the reference constructor does.
+    """
+    means = np.asarray(gmm["means"], dtype=np.float32)
+    covs32 = np.asarray(gmm["covars"], dtype=np.float32)
+    precisions = np.stack([np.linalg.inv(c) for c in covs32]).astype(np.float32)
+    sqrdets = np.array([np.sqrt(np.linalg.det(c)) for c in gmm["covars"]])
+    const = (2.0 * np.pi) ** (69 / 2.0)
+    nll_weights = np.asarray(gmm["weights"] / (const * (sqrdets / sqrdets.min())))
+    return means, precisions, nll_weights.astype(np.float32)
+
+
+def make_model(model_type="smpl", seed=0, nv=None):
+    """Synthetic body model with the tensor layout of smplx 0.1.13."""
+    rng = np.random.default_rng(seed)
+    if model_type == "smpl":
+        parents, rest, radius = SMPL_PARENTS, _SMPL_REST.copy(), _SMPL_RADIUS
+        nv = 6890 if nv is None else nv
+        seg = 10
+        nb = 10
+    elif model_type == "smplx":
+        parents = SMPLX_PARENTS
+        rest, radius = _smplx_rest()
+        nv = 10475 if nv is None else nv
+        seg = 5
+        nb = 20  # 10 betas + 10 expression
+    else:
+        raise ValueError(f"unknown model type {model_type!r}")
+    nj = len(parents)
+    while nv % seg:
+        seg -= 1
+    verts, faces, bone_of, t_of, bones = _tube_mesh(rest, parents, radius, nv, seg)
+    verts = verts + rng.normal(0.0, 0.0015, size=verts.shape)
+
+    # skinning weights: 4 non-zeros per row (bone owner, child, grand-parent, one stray joint)
+    lbs = np.zeros((nv, nj))
+    stray = rng.integers(0, nj, size=nv)
+    stray_w = rng.uniform(0.0, 0.04, size=nv)
+    for v in range(nv):
+        p, j = bones[bone_of[v]]
+        t = t_of[v]
+        gp = int(parents[p]) if parents[p] >= 0 else p
+        w_child = 0.02 + 0.5 * max(0.0, (t - 0.6) / 0.4) ** 2
+        w_gp = 0.02 + 0.5 * max(0.0, (0.4 - t) / 0.4) ** 2 if gp != p else 0.0
+        lbs[v, j] += w_child
+        lbs[v, gp] += w_gp
+        lbs[v, stray[v]] += stray_w[v]
+        lbs[v, p] += 1.0 - w_child - w_gp - stray_w[v]
+    lbs /= lbs.sum(1, keepdims=True)
+
+    # joint regressor: mean of the 32 template vertices nearest to each rest joint (dense storage)
+    jreg = np.zeros((nj, nv))
+    for j in range(nj):
+        near = np.argsort(np.linalg.norm(verts - rest[j][None], axis=1), kind="stable")[:32]
+        jreg[j, near] = 1.0 / 32.0
+
+    # shape directions: smooth affine deformations about the pelvis + a little per-vertex noise
+    centre = verts.mean(0)
+    shapedirs = np.empty((nv, 3, nb))
+    for l in range(nb):
+        a = rng.normal(0.0, 0.012, size=(3, 3))
+        a[np.diag_indices(3)] += rng.normal(0.0, 0.02, size=3)
+        shapedirs[:, :, l] = (verts - centre) @ a.T
+    shapedirs += rng.normal(0.0, 0.0008, size=shapedirs.shape)
+
+    posedirs = rng.normal(0.0, 0.001, size=(9 * (nj - 1), 3 * nv))
+
+    out = {
+        "model_type": model_type,
+        "v_template": verts.astype(np.float32),
+        "shapedirs": shapedirs.astype(np.float32),
+        "posedirs": posedirs.astype(np.float32),
+        "J_regressor": jreg.astype(np.float32),
+        "lbs_weights": lbs.astype(np.float32),
+        "parents": parents.copy(),
+        "faces": faces,
+    }
+
+    taken = set()
+    if model_type == "smpl":
+        head, lfoot, rfoot, lhand, rhand = rest[15], rest[10], rest[11], rest[22], rest[23]
+        targets = [
+            head + [0.0, 0.02, 0.11],                                  # nose
+            head + [-0.035, 0.05, 0.09], head + [0.035, 0.05, 0.09],   # reye, leye
+            head + [-0.09, 0.03, 0.0], head + [0.09, 0.03, 0.0],       # rear, lear
+            lfoot + [0.02, -0.03, 0.06], lfoot + [0.05, -0.03, 0.03], rest[7] + [0.0, -0.06, -0.05],
+            rfoot + [-0.02, -0.03, 0.06], rfoot + [-0.05, -0.03, 0.03], rest[8] + [0.0, -0.06, -0.05],
+        ]
+        for f in range(5):
+            targets.append(lhand + [0.05, 0.0, (f - 2) * 0.015])
+        for f in range(5):
+            targets.append(rhand + [-0.05, 0.0, (f - 2) * 0.015])
+        out["selector_ids"] = np.array([_nearest_vertex(verts, t, taken) for t in targets], dtype=np.int32)
+        out["joint_map"] = SMPL_JOINT_MAP.copy()
+        # 9 extra + 17 h36m regressors: sparse random rows (reference models/smpl.py:62-64)
+        for name, rows in (("J_regressor_extra", 9), ("J_regressor_h36m", 17)):
+            reg = np.zeros((rows, nv))
+            for r in range(rows):
+                ids = rng.choice(nv, size=16, replace=False)
+                w = rng.uniform(0.2, 1.0, size=16)
+                reg[r, ids] = w / w.sum()
+            out[name] = reg.astype(np.float32)
+    else:
+        _add_smplx_extras(out, rng, verts, faces, rest, taken)
+    return out
+
+
+def _add_smplx_extras(out, rng, verts, faces, rest, taken):
+    """SMPL-X only pieces: hand PCA, pose mean, expression split, landmarks."""
+    nv = verts.shape[0]
+    head = rest[15]
+    targets = [
+        head + [0.0, 0.02, 0.11], head + [-0.035, 0.05, 0.09], head + [0.035, 0.05, 0.09],
+        head + [-0.09, 0.03, 0.0], head + [0.09, 0.03, 0.0],
+        rest[10] + [0.02, -0.03, 0.06], rest[10] + [0.05, -0.03, 0.03], rest[7] + [0.0, -0.06, -0.05],
+        rest[11] + [-0.02, -0.03, 0.06], rest[11] + [-0.05, -0.03, 0.03], rest[8] + [0.0, -0.06, -0.05],
+    ]
+    for base, side in ((25, 1.0), (40, -1.0)):
+        for f in range(5):
+            targets.append(rest[base + 3 * f + 2] + [side * 0.02, 0.0, 0.0])
+    out["selector_ids"] = np.array([_nearest_vertex(verts, t, taken) for t in targets], dtype=np.int32)
+    # hand PCA (6 comps, smplify.py:121-122) and the non-flat hand mean that sits in pose_mean
+    out["left_hand_components"] = rng.normal(0.0, 0.3, size=(6, 45)).astype(np.float32)
+    out["right_hand_components"] = rng.normal(0.0, 0.3, size=(6, 45)).astype(np.float32)
+    pose_mean = np.zeros(165)
+    pose_mean[75:120] = rng.normal(0.0, 0.1, size=45)
+    pose_mean[120:165] = rng.normal(0.0, 0.1, size=45)
+    out["pose_mean"] = pose_mean.astype(np.float32)
+    # 51 static + 79x17 dynamic contour landmarks as (face id, barycentric) pairs
+    head_faces = np.where(np.linalg.norm(verts[faces].mean(1) - head[None], axis=1) < 0.16)[0]
+    if len(head_faces) < 68:
+        head_faces = np.arange(len(faces))
+
+    def bary(n):
+        b = rng.uniform(0.1, 1.0, size=(n, 3))
+        return (b / b.sum(1, keepdims=True)).astype(np.float32)
+
+    out["lmk_faces_idx"] = rng.choice(head_faces, size=51).astype(np.int32)
+    out["lmk_bary_coords"] = bary(51)
+    out["dynamic_lmk_faces_idx"] = rng.choice(head_faces, size=(79, 17)).astype(np.int32)
+    out["dynamic_lmk_bary_coords"] = bary(79 * 17).reshape(79, 17, 3)
+    out["neck_kin_chain"] = np.array([12, 9, 6, 3, 0], dtype=np.int32)
+    # reference models/utils.py:75-94 with use_hands, use_face, use_face_contour -> 135 joints
+    body = [55, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65]
+    lhand = [20, 37, 38, 39, 66, 25, 26, 27, 67, 28, 29, 30, 68, 34, 35, 36, 69, 31, 32, 33, 70]
+    rhand = [21, 52, 53, 54, 71, 40, 41, 42, 72, 43, 44, 45, 73, 49, 50, 51, 74, 46, 47, 48, 75]
+    out["joint_map"] = np.array(body + lhand + rhand + list(range(76, 127 + 17)), dtype=np.int32)
+
+
+def model_digest(model):
+    """Short content hash of the float tensors, stored next to goldens to catch generator drift."""
+    h = hashlib.sha256()
+    for key in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+        h.update(np.ascontiguousarray(model[key]).tobytes())
+    return h.hexdigest()[:16]
+
+
+# ----------------------------------------------------------------------------------------------
+# cameras and per-frame problems
+# ----------------------------------------------------------------------------------------------
+
+def ring_cameras(n_views=48, radius=3.2, centre=(0.0, 0.0, 0.0), imsize=512, focal=512.0):
+    """`n_views` cameras equally spaced in yaw on a ring, looking at `centre`.
+
+    Returns (c2ws list of [4,4] float32, Ks list of [3,3] float32) the way
+    apps/genebody_fitting.py:134-140 hands them to BodyFitting (camera-to-world `RT`, pixel K).
+    Camera axes follow OpenCV: x right, y down, z forward.
+    """
+    centre = np.asarray(centre, dtype=np.float64)
+    c2ws, Ks = [], []
+    for theta in np.linspace(0.0, 2.0 * np.pi, n_views + 1)[:-1]:
+        pos = centre + radius * np.array([np.cos(theta), 0.0, -np.sin(theta)])
+        fwd = centre - pos
+        fwd /= np.linalg.norm(fwd)
+        down = np.array([0.0, -1.0, 0.0])
+        right = np.cross(down, fwd)
+        right /= np.linalg.norm(right)
+        down = np.cross(fwd, right)
+        c2w = np.eye(4)
+        c2w[:3, 0], c2w[:3, 1], c2w[:3, 2], c2w[:3, 3] = right, down, fwd, pos
+        c2ws.append(c2w.astype(np.float32))
+        Ks.append(np.array([[focal, 0, imsize / 2], [0, focal, imsize / 2], [0, 0, 1]], dtype=np.float32))
+    return c2ws, Ks
+
+
+def _rodrigues64(rvec):
+    a = np.linalg.norm(rvec)
+    if a < 1e-12:
+        return np.eye(3)
+    k = rvec / a
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+
+
+def smpl_joints64(model, betas, full_pose):
+    """float64 posed model for *data synthesis* only (GT keypoints); not an oracle.
+
+    Returns (vertices[NV,3], joints45[NJ+21,3]).
+    """
+    vt = model["v_template"].astype(np.float64)
+    sd = model["shapedirs"].astype(np.float64)
+    nb = min(sd.shape[2], len(betas))
+    v_shaped = vt + sd[:, :, :nb] @ np.asarray(betas, dtype=np.float64)[:nb]
+    J = model["J_regressor"].astype(np.float64) @ v_shaped
+    nj = len(model["parents"])
+    R = np.stack([_rodrigues64(r) for r in np.asarray(full_pose, dtype=np.float64).reshape(nj, 3)])
+    feat = (R[1:] - np.eye(3)[None]).reshape(-1)
+    v_posed = v_shaped + (feat @ model["posedirs"].astype(np.float64)).reshape(-1, 3)
+    G = np.zeros((nj, 4, 4))
+    for i in range(nj):
+        T = np.eye(4)
+        T[:3, :3] = R[i]
+        p = int(model["parents"][i])
+        T[:3, 3] = J[i] if p < 0 else J[i] - J[p]
+        G[i] = T if p < 0 else G[p] @ T
+    A = G.copy()
+    for i in range(nj):
+        A[i, :3, 3] -= G[i, :3, :3] @ J[i]
+    Tv = np.einsum("vj,jab->vab", model["lbs_weights"].astype(np.float64), A)
+    verts = np.einsum("vab,vb->va", Tv[:, :3, :3], v_posed) + Tv[:, :3, 3]
+    joints = np.concatenate([G[:, :3, 3], verts[model["selector_ids"]]], 0)
+    return verts, joints
+
+
+def make_problem(model, frame=0, n_views=48, imsize=512, constant_scale=0.3, pose_noise=0.1,
+                 drop=0.05, missing_views=()):
+    """One synthetic SMPL frame: cameras, OpenPose-25 keypoints, HMR-like init.
+
+    keypoints[v] is ``{'pose': float32[25,3]}`` (x, y, confidence) like utils/io_utils.py:138-183
+    returns, or None for a view listed in `missing_views` (loss.py:157 skips those).
+    """
+    assert model["model_type"] == "smpl"
+    rng = np.random.default_rng(1000 + frame)
+    betas_gt = rng.normal(0.0, 0.5, size=10)
+    pose_gt = rng.normal(0.0, 0.2, size=72)
+    pose_gt[:3] = [0.0, rng.uniform(-np.pi, np.pi), 0.0]
+    pose_gt[:3] += rng.normal(0.0, 0.1, size=3)
+    transl_gt = rng.normal(0.0, 0.05, size=3)
+    scale_gt = rng.uniform(0.9, 1.1) / constant_scale
+
+    _, joints = smpl_joints64(model, betas_gt, pose_gt)
+    op25 = joints[model["joint_map"][:25]]
+    world = (op25 + transl_gt) * scale_gt * constant_scale
+
+    c2ws, Ks = ring_cameras(n_views, imsize=imsize, focal=float(imsize),
+                            centre=(world.mean(0) * [1, 1, 1]).tolist())
+    keypoints = []
+    for v in range(n_views):
+        w2c = np.linalg.inv(c2ws[v].astype(np.float64))
+        cam = world @ w2c[:3, :3].T + w2c[:3, 3]
+        uvw = cam @ Ks[v].astype(np.float64).T
+        uv = uvw[:, :2] / uvw[:, 2:3] + rng.normal(0.0, 1.0, size=(25, 2))
+        conf = rng.uniform(0.5, 1.0, size=25)
+        conf[rng.uniform(size=25) < drop] = 0.0
+        kp = np.concatenate([uv, conf[:, None]], 1).astype(np.float32)
+        kp[conf == 0.0, :2] = 0.0
+        keypoints.append(None if v in missing_views else {"pose": kp})
+
+    init_pose = (pose_gt + rng.normal(0.0, pose_noise, size=72)).astype(np.float32)
+    init_betas = np.zeros(10, dtype=np.float32)
+    return {
+        "c2ws": c2ws, "Ks": Ks, "keypoints": keypoints, "imsize": imsize,
+        "use_frames": list(range(n_views)),
+        "init_betas": init_betas[None], "init_pose": init_pose[None],
+        "gt": {"betas": betas_gt, "pose": pose_gt, "transl": transl_gt, "scale": scale_gt},
+        "constant_scale": constant_scale,
+    }

@@ -1,0 +1,206 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference on torch CPU.
+
+TEST INFRASTRUCTURE ONLY - runs in the build container, where /root/reference exists; it is never
+executed on the GPU box (nothing there may read /root/reference).  The committed .npz files hold
+data only: seeds / small inputs and the reference's outputs.
+
+What is imported from /root/reference, untouched: smplify/smplify.py (SMPLify.__call__ loop),
+smplify/loss.py, smplify/prior.py, models/smpl.py, config.py, constants.py.
+What is stubbed (absent third-party modules that the hot path imports but never executes for
+smpl_type='smpl', keypoint-only): cv2, torchgeometry, mesh_grid, trimesh, imageio, neural_renderer,
+torchvision, scipy.misc.face, utils.camera (raises on numpy>=1.24, camera.py:90-92).
+What is stood in: `smplx` (oracle/smplx_standin) - see its docstring for the parity consequence.
+
+Usage:  python oracle/gen_golden.py            (writes tests/golden/)
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import sys
+import tempfile
+import time
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFERENCE = "/root/reference"
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def _stub(name, **attrs):
+    mod = types.ModuleType(name)
+    mod.__dict__.update(attrs)
+    sys.modules[name] = mod
+    return mod
+
+
+def install_reference_imports():
+    """Make `import smplify.smplify` from /root/reference work in this container."""
+    import torch
+
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "oracle", "smplx_standin"))
+    sys.path.insert(0, REFERENCE)
+    _stub("cv2")
+    _stub("torchgeometry", angle_axis_to_rotation_matrix=None)
+    _stub("mesh_grid", insert_grid_surface=None, cumsum=None, search_nearest_point=None,
+          search_inside_mesh=None, search_intersect=None, search_nearest_point_backward=None)
+    _stub("trimesh")
+    _stub("imageio")
+    _stub("neural_renderer")
+    tv = _stub("torchvision")
+    tv.models = _stub("torchvision.models")
+    tv.models.resnet = _stub("torchvision.models.resnet")
+    tv.transforms = _stub("torchvision.transforms", Normalize=None)
+    import scipy.misc
+    if not hasattr(scipy.misc, "face"):
+        scipy.misc.face = None
+    _stub("utils.camera")            # real module body raises on numpy >= 1.24
+    try:
+        import matplotlib  # noqa: F401  (smplify.py:2 imports matplotlib.dviread)
+    except ImportError:
+        mpl = _stub("matplotlib")
+        mpl.dviread = _stub("matplotlib.dviread")
+    torch.set_num_threads(1)
+
+
+def write_data_dir(tmp, model, gmm):
+    """The files the reference opens relative to CWD (config.py:1-2, prior.py:124-128)."""
+    os.makedirs(os.path.join(tmp, "data"), exist_ok=True)
+    np.save(os.path.join(tmp, "data", "J_regressor_extra.npy"), model["J_regressor_extra"])
+    np.save(os.path.join(tmp, "data", "J_regressor_h36m.npy"), model["J_regressor_h36m"])
+    with open(os.path.join(tmp, "data", "gmm_08.pkl"), "wb") as f:
+        pickle.dump(gmm, f)
+
+
+def run_reference_fit(problem, num_iters, snapshots=()):
+    """Run reference SMPLify.__call__ (smplify.py:84-250) and capture parameter snapshots.
+
+    Snapshots are taken by wrapping torch.optim.Adam.step - the reference code itself is untouched."""
+    import torch
+    from smplify.smplify import SMPLify
+
+    snaps = {}
+    orig_step = torch.optim.Adam.step
+    counter = {"n": 0}
+
+    def step(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        counter["n"] += 1
+        if counter["n"] in snapshots:
+            g = self.param_groups
+            snaps[counter["n"]] = {
+                "global_transl": g[0]["params"][0].detach().numpy()[0].copy(),
+                "scale": g[1]["params"][0].detach().numpy()[0].copy(),
+                "pose": g[2]["params"][0].detach().numpy()[0].copy(),
+                "betas": g[3]["params"][0].detach().numpy()[0].copy(),
+                "global_orient": g[4]["params"][0].detach().numpy()[0].copy(),
+            }
+        return r
+
+    torch.optim.Adam.step = step
+    try:
+        fitter = SMPLify(smpl_type="smpl", num_iters=num_iters, gender="neutral",
+                         device=torch.device("cpu"), debug=False)
+        net_output = (torch.from_numpy(problem["init_betas"].copy()),
+                      torch.from_numpy(problem["init_pose"].copy()))
+        t0 = time.perf_counter()
+        res = fitter(net_output, problem["c2ws"], problem["Ks"], problem["keypoints"], None,
+                     use_frames=problem["use_frames"], imsize=problem["imsize"])
+        wall = time.perf_counter() - t0
+    finally:
+        torch.optim.Adam.step = orig_step
+    return res, snaps, wall
+
+
+def reference_loss_terms(model, gmm, problem, params):
+    """reference multiview_keypoint_loss (loss.py:139-230) + autograd gradient at `params`, fp32."""
+    import torch
+    from models.smpl import SMPL
+    from smplify.loss import multiview_keypoint_loss
+    from smplify.prior import MaxMixturePrior
+    import config
+
+    prior = MaxMixturePrior(prior_folder="data", num_gaussians=8, dtype=torch.float32)
+    smpl = SMPL(config.SMPL_MODEL_DIR, batch_size=1, gender="neutral", create_transl=True)
+    p = {k: torch.tensor(np.asarray(v, np.float32).reshape(1, -1), requires_grad=True) for k, v in params.items()}
+    out = smpl(global_orient=p["global_orient"], body_pose=p["pose"], betas=p["betas"], return_full_pose=True)
+    c = problem["constant_scale"]
+    mj = (out.joints + p["global_transl"]) * p["scale"] * c
+    bv = (out.vertices + p["global_transl"]) * p["scale"] * c
+    w2cs = torch.inverse(torch.from_numpy(np.array(problem["c2ws"])).float())
+    loss, terms = multiview_keypoint_loss(w2cs, problem["Ks"], problem["keypoints"], mj, p["pose"], p["betas"],
+                                          problem["use_frames"], prior, imsize=problem["imsize"])
+    loss.backward()
+    return (float(loss), {k: float(np.asarray(v).reshape(-1)[0]) for k, v in terms.items()},
+            {k: v.grad.numpy()[0].copy() for k, v in p.items()}, mj.detach().numpy()[0], bv.detach().numpy()[0])
+
+
+def flat_snaps(snaps):
+    out = {}
+    for k, d in snaps.items():
+        for name, v in d.items():
+            out[f"it{k}_{name}"] = v
+    return out
+
+
+def main():
+    install_reference_imports()
+    import smplx
+    from bodyfitting_amd import synthetic as S
+
+    os.makedirs(GOLDEN, exist_ok=True)
+    model = S.make_model("smpl", seed=0)
+    gmm = S.make_gmm(seed=0)
+    smplx.MODEL_REGISTRY["smpl"] = model
+    digest = S.model_digest(model)
+    tmp = tempfile.mkdtemp(prefix="bf_golden_")
+    write_data_dir(tmp, model, gmm)
+    os.chdir(tmp)
+
+    meta = dict(model_seed=0, model_digest=digest)
+
+    # ---- config 1: 1 frame, 1 view, 50 iters (plumbing) ------------------------------------
+    prob = S.make_problem(model, frame=0, n_views=1)
+    res, snaps, wall = run_reference_fit(prob, 50, snapshots=(1, 10, 50))
+    np.savez_compressed(os.path.join(GOLDEN, "cfg1_1view_50it.npz"), frame=0, n_views=1, num_iters=50,
+                        wall_s=wall, joints=res["joints"], full_pose=res["full_pose"],
+                        vertices_sample=res["vertices"][::53], final_global_transl=res["global_transl"],
+                        **flat_snaps(snaps), **meta)
+    print("cfg1", wall, "s")
+
+    # ---- config 2: 1 frame, 48 views, 100 iters ---------------------------------------------
+    for frame in (0, 1, 2, 3):
+        prob = S.make_problem(model, frame=frame, n_views=48)
+        res, snaps, wall = run_reference_fit(prob, 100, snapshots=(1, 2, 10, 50, 100))
+        np.savez_compressed(os.path.join(GOLDEN, f"cfg2_48view_100it_f{frame}.npz"), frame=frame, n_views=48,
+                            num_iters=100, wall_s=wall, joints=res["joints"], full_pose=res["full_pose"],
+                            vertices_sample=res["vertices"][::53], final_global_transl=res["global_transl"],
+                            **flat_snaps(snaps), **meta)
+        print("cfg2 frame", frame, wall, "s")
+
+    # ---- ragged input: views without a detection (loss.py:157 skip, :197 divisor) ------------
+    prob = S.make_problem(model, frame=5, n_views=8, missing_views=(2, 5))
+    res, snaps, wall = run_reference_fit(prob, 20, snapshots=(1, 20))
+    np.savez_compressed(os.path.join(GOLDEN, "ragged_8view_20it.npz"), frame=5, n_views=8, num_iters=20,
+                        missing_views=np.array([2, 5]), joints=res["joints"],
+                        vertices_sample=res["vertices"][::53], **flat_snaps(snaps), **meta)
+
+    # ---- one loss / gradient evaluation (loss.py:219-224 dict + autograd grads) ---------------
+    prob = S.make_problem(model, frame=0, n_views=48)
+    params = {"global_transl": np.array([0.02, -0.01, 0.03]), "scale": np.array([1.1]),
+              "pose": prob["init_pose"][0, 3:], "betas": np.linspace(-0.5, 0.5, 10),
+              "global_orient": prob["init_pose"][0, :3]}
+    loss, terms, grads, mj, bv = reference_loss_terms(model, gmm, prob, params)
+    np.savez_compressed(os.path.join(GOLDEN, "loss_terms_f0.npz"), frame=0, n_views=48, loss=loss,
+                        joints=mj, vertices_sample=bv[::53],
+                        **{f"term_{k}": v for k, v in terms.items()},
+                        **{f"param_{k}": np.asarray(v, np.float32) for k, v in params.items()},
+                        **{f"grad_{k}": v for k, v in grads.items()}, **meta)
+    print("loss terms", loss, terms)
+
+
+if __name__ == "__main__":
+    main()
