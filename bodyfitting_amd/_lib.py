@@ -1,0 +1,105 @@
+"""ctypes binding of libbodyfit.so (include/bodyfit.h).  No fallback: without the HIP library the
+product path raises - there is deliberately no CPU implementation behind this ABI."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbodyfit.so")
+
+
+class BodyfitError(RuntimeError):
+    pass
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [
+        ("n_verts", C.c_int32), ("n_joints", C.c_int32), ("n_betas", C.c_int32),
+        ("v_template", C.POINTER(C.c_float)), ("shapedirs", C.POINTER(C.c_float)),
+        ("posedirs", C.POINTER(C.c_float)), ("j_regressor", C.POINTER(C.c_float)),
+        ("lbs_weights", C.POINTER(C.c_float)), ("parents", C.POINTER(C.c_int32)),
+        ("n_selector", C.c_int32), ("selector_ids", C.POINTER(C.c_int32)),
+        ("n_extra", C.c_int32), ("j_regressor_extra", C.POINTER(C.c_float)),
+        ("n_joint_map", C.c_int32), ("joint_map", C.POINTER(C.c_int32)),
+        ("n_loss_joints", C.c_int32),
+        ("gmm_components", C.c_int32), ("gmm_dim", C.c_int32),
+        ("gmm_means", C.POINTER(C.c_float)), ("gmm_precisions", C.POINTER(C.c_float)),
+        ("gmm_nll_weights", C.POINTER(C.c_float)),
+    ]
+
+
+class Hyper(C.Structure):
+    _fields_ = [(n, C.c_float) for n in (
+        "sigma", "pose_prior_weight", "angle_prior_weight", "shape_prior_weight", "constant_scale",
+        "imsize", "lr", "lr_transl_scale", "adam_beta1", "adam_beta2", "adam_eps")]
+
+
+FIT_DEFAULT, FIT_DENSE, FIT_NO_VERTICES = 0, 1, 2
+
+# every entry point include/bodyfit.h declares: name -> (restype, argtypes)
+_FP = C.POINTER(C.c_float)
+_IP = C.POINTER(C.c_int32)
+_VP = C.c_void_p
+SIGNATURES = {
+    "bf_last_error": (C.c_char_p, []),
+    "bf_version": (C.c_char_p, []),
+    "bf_device_count": (C.c_int, []),
+    "bf_hyper_default": (None, [C.POINTER(Hyper)]),
+    "bf_model_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_VP)]),
+    "bf_model_destroy": (None, [_VP]),
+    "bf_model_n_params": (C.c_int, [_VP]),
+    "bf_smpl_forward": (C.c_int, [_VP, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "bf_batch_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "bf_batch_destroy": (None, [_VP]),
+    "bf_batch_set_cameras": (C.c_int, [_VP, _FP, _FP]),
+    "bf_batch_set_keypoints": (C.c_int, [_VP, _FP, _IP]),
+    "bf_batch_set_init": (C.c_int, [_VP, _FP, _FP]),
+    "bf_batch_set_params": (C.c_int, [_VP, _FP]),
+    "bf_batch_get_params": (C.c_int, [_VP, _FP]),
+    "bf_fit": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper), C.c_uint32]),
+    "bf_loss_grad": (C.c_int, [_VP, C.POINTER(Hyper), _FP, _FP]),
+    "bf_batch_sync": (C.c_int, [_VP]),
+    "bf_batch_get_result": (C.c_int, [_VP, _FP, _FP, _FP, _FP]),
+    "bf_batch_export_params_dev": (C.c_int, [_VP, _VP]),
+    "bf_batch_last_timing": (C.c_int, [_VP, _FP]),
+}
+
+_lib = None
+
+
+def load():
+    """Return the loaded library; raise BodyfitError (never fall back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BodyfitError(
+            f"{LIB_PATH} is missing - build it with `make -C bodyfitting_amd/csrc` (or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise BodyfitError(f"could not load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    lib.bf_batch_debug_dump.restype = C.c_int
+    lib.bf_batch_debug_dump.argtypes = [_VP, _FP, C.c_int]
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().bf_last_error().decode("utf-8", "replace")
+        raise BodyfitError(f"{what or 'libbodyfit'} failed ({rc}): {msg}")
+
+
+def fptr(a):
+    return a.ctypes.data_as(_FP) if a is not None else None
+
+
+def iptr(a):
+    return a.ctypes.data_as(_IP) if a is not None else None

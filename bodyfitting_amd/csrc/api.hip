@@ -1,0 +1,611 @@
+// Host side of libbodyfit: the C ABI of include/bodyfit.h over the gfx950 kernels.
+#include "../../include/bodyfit.h"
+#include "bf_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" __global__ void bf_fit_kernel(FitTab, FrameIO, HyperDev, int, int, const float *, int);
+extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *);
+extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *);
+extern "C" __global__ void bf_joints_kernel(MeshTab, const float *, const float *, float *, float *);
+extern "C" size_t bf_fit_smem_bytes(int, int, int, int, int, int, int, int);
+extern "C" size_t bf_mesh_smem_bytes(int, int, int);
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(BF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &h) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess) return e;
+        return h.empty() ? hipSuccess : hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+struct bf_model {
+    int device = 0;
+    int nv = 0, nj = 0, nb = 0, npf = 0, ns = 0, nl = 0, np = 0, n_levels = 0;
+    int n_selector = 0, n_extra = 0, n_joint_map = 0;
+    FitTab fit{};
+    MeshTab mesh{};
+    size_t fit_smem = 0, mesh_smem = 0;
+    DevBuf<float> v_template, shapedirs, posedirs, lbs_weights, j_extra;
+    DevBuf<int> selector_ids, joint_map;
+    DevBuf<int> parents, level_start, level_joints, child_start, child_list, lj_kind, lj_index;
+    DevBuf<float> Jt, Jd, Jdrel, sel_vt, sel_sd, sel_pd, sel_w, g_means, g_psym, g_logw;
+};
+
+struct bf_batch {
+    bf_model *m = nullptr;
+    int F = 0, V = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    bool timed = false;
+    int steps_done = 0;
+    bf_hyper adam_hyper{};
+    int adam_cap = 0;
+    DevBuf<float> proj, keypoints, params, adam_m, adam_v, grads, terms, state, vraw, vout, joints, adam_tab, debug;
+    DevBuf<int> ndiv;
+    bool have_result = false;
+};
+
+extern "C" {
+
+const char *bf_last_error(void) { return g_err.c_str(); }
+const char *bf_version(void) { return "bodyfit-mi355x 0.1 (gfx950)"; }
+
+int bf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void bf_hyper_default(bf_hyper *h) {
+    if (!h) return;
+    h->sigma = 100.f;
+    h->pose_prior_weight = 4.78f;
+    h->angle_prior_weight = 15.2f;
+    h->shape_prior_weight = 5.f;
+    h->constant_scale = 0.3f;
+    h->imsize = 512.f;
+    h->lr = 1e-2f;
+    h->lr_transl_scale = 0.1f;
+    h->adam_beta1 = 0.9f;
+    h->adam_beta2 = 0.999f;
+    h->adam_eps = 1e-8f;
+}
+
+int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
+    if (!d || !out) return fail(BF_ERR_INVALID, "bf_model_create: null argument");
+    *out = nullptr;
+    if (bf_device_count() <= device || device < 0) return fail(BF_ERR_NO_DEVICE, "bf_model_create: no such HIP device");
+    if (d->n_verts <= 0 || d->n_joints < 2 || d->n_joints > 64 || d->n_betas <= 0 || d->n_betas > 12)
+        return fail(BF_ERR_UNSUPPORTED, "bf_model_create: need 2..64 joints and 1..12 betas");
+    if (d->gmm_components != BF_GMM_M || d->gmm_dim != BF_GMM_D)
+        return fail(BF_ERR_UNSUPPORTED, "bf_model_create: the GMM prior must be 8 components x 69 dims");
+    if (d->n_loss_joints <= 0 || d->n_loss_joints > 32 || d->n_loss_joints > d->n_joint_map)
+        return fail(BF_ERR_UNSUPPORTED, "bf_model_create: 1..32 loss joints supported");
+    if (d->n_extra > 32 || d->n_joints + d->n_selector + d->n_extra > 128)
+        return fail(BF_ERR_UNSUPPORTED, "bf_model_create: too many auxiliary joints");
+    const int nv = d->n_verts, nj = d->n_joints, nb = d->n_betas, npf = 9 * (nj - 1);
+    if (d->parents[0] != -1) return fail(BF_ERR_INVALID, "bf_model_create: parents[0] must be -1");
+    for (int j = 1; j < nj; ++j)
+        if (d->parents[j] < 0 || d->parents[j] >= j) return fail(BF_ERR_INVALID, "bf_model_create: parents[i] must be in [0,i)");
+    for (int i = 0; i < d->n_selector; ++i)
+        if (d->selector_ids[i] < 0 || d->selector_ids[i] >= nv) return fail(BF_ERR_INVALID, "bf_model_create: selector id out of range");
+    const int n_all = nj + d->n_selector + d->n_extra;
+    for (int i = 0; i < d->n_joint_map; ++i)
+        if (d->joint_map[i] < 0 || d->joint_map[i] >= n_all) return fail(BF_ERR_INVALID, "bf_model_create: joint_map entry out of range");
+    HIP_TRY(hipSetDevice(device));
+
+    auto *m = new bf_model();
+    m->device = device;
+    m->nv = nv; m->nj = nj; m->nb = nb; m->npf = npf;
+    m->n_selector = d->n_selector; m->n_extra = d->n_extra; m->n_joint_map = d->n_joint_map;
+    m->nl = d->n_loss_joints;
+    m->np = 3 + 1 + 3 * (nj - 1) + nb + 3;
+
+    // ---- kinematic tree: depth levels and children lists ----------------------------------
+    std::vector<int> parents(d->parents, d->parents + nj), depth(nj, 0);
+    int n_levels = 1;
+    for (int j = 1; j < nj; ++j) { depth[j] = depth[parents[j]] + 1; n_levels = std::max(n_levels, depth[j] + 1); }
+    std::vector<int> level_start(n_levels + 1, 0), level_joints;
+    for (int l = 0; l < n_levels; ++l) {
+        level_start[l] = (int)level_joints.size();
+        for (int j = 0; j < nj; ++j) if (depth[j] == l) level_joints.push_back(j);
+    }
+    level_start[n_levels] = (int)level_joints.size();
+    std::vector<int> child_start(nj + 1, 0), child_list;
+    for (int p = 0; p < nj; ++p) {
+        child_start[p] = (int)child_list.size();
+        for (int j = 1; j < nj; ++j) if (parents[j] == p) child_list.push_back(j);
+    }
+    child_start[nj] = (int)child_list.size();
+    m->n_levels = n_levels;
+
+    // ---- loss joints -> chain joint or selector-vertex slot (loss.py:163, models/smpl.py:75) ----
+    std::vector<int> lj_kind(m->nl), lj_index(m->nl), sel;
+    for (int k = 0; k < m->nl; ++k) {
+        int s = d->joint_map[k];
+        if (s < nj) { lj_kind[k] = 0; lj_index[k] = s; }
+        else if (s < nj + d->n_selector) {
+            int vid = d->selector_ids[s - nj];
+            auto it = std::find(sel.begin(), sel.end(), vid);
+            if (it == sel.end()) { sel.push_back(vid); it = sel.end() - 1; }
+            lj_kind[k] = 1; lj_index[k] = (int)(it - sel.begin());
+        } else {
+            delete m;
+            return fail(BF_ERR_UNSUPPORTED, "bf_model_create: a loss joint maps to an extra-regressor joint");
+        }
+    }
+    const int ns = (int)sel.size();
+    m->ns = ns;
+
+    // ---- pre-contracted joint regressor (float64 accumulate, rounded once) --------------------
+    std::vector<float> Jt(nj * 3), Jd((size_t)nj * 3 * nb), Jdrel((size_t)nj * 3 * nb);
+    {
+        std::vector<double> acc((size_t)3 + 3 * nb);
+        std::vector<double> Jd64((size_t)nj * 3 * nb);
+        for (int j = 0; j < nj; ++j) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            const float *row = d->j_regressor + (size_t)j * nv;
+            for (int v = 0; v < nv; ++v) {
+                double w = row[v];
+                if (w == 0.0) continue;
+                for (int k = 0; k < 3; ++k) {
+                    acc[k] += w * d->v_template[(size_t)v * 3 + k];
+                    const float *sd = d->shapedirs + ((size_t)v * 3 + k) * nb;
+                    for (int l = 0; l < nb; ++l) acc[3 + k * nb + l] += w * sd[l];
+                }
+            }
+            for (int k = 0; k < 3; ++k) {
+                Jt[j * 3 + k] = (float)acc[k];
+                for (int l = 0; l < nb; ++l) {
+                    Jd64[((size_t)j * 3 + k) * nb + l] = acc[3 + k * nb + l];
+                    Jd[((size_t)j * 3 + k) * nb + l] = (float)acc[3 + k * nb + l];
+                }
+            }
+        }
+        for (int j = 0; j < nj; ++j)
+            for (int e = 0; e < 3 * nb; ++e) {
+                double v = Jd64[(size_t)j * 3 * nb + e];
+                if (j > 0) v -= Jd64[(size_t)parents[j] * 3 * nb + e];
+                Jdrel[(size_t)j * 3 * nb + e] = (float)v;
+            }
+    }
+    // ---- selector-vertex slices of the model ----------------------------------------------------
+    std::vector<float> sel_vt(ns * 3), sel_sd((size_t)ns * 3 * nb), sel_pd((size_t)npf * ns * 3), sel_w((size_t)ns * nj);
+    for (int s = 0; s < ns; ++s) {
+        int v = sel[s];
+        for (int k = 0; k < 3; ++k) {
+            sel_vt[s * 3 + k] = d->v_template[(size_t)v * 3 + k];
+            for (int l = 0; l < nb; ++l) sel_sd[((size_t)s * 3 + k) * nb + l] = d->shapedirs[((size_t)v * 3 + k) * nb + l];
+            for (int p = 0; p < npf; ++p) sel_pd[(size_t)p * ns * 3 + s * 3 + k] = d->posedirs[(size_t)p * 3 * nv + 3 * v + k];
+        }
+        for (int j = 0; j < nj; ++j) sel_w[(size_t)s * nj + j] = d->lbs_weights[(size_t)v * nj + j];
+    }
+    // ---- GMM: symmetrised precisions and -log of the merged weights (prior.py:188-189) ---------
+    const int M = BF_GMM_M, D = BF_GMM_D;
+    std::vector<float> psym((size_t)M * D * D), logw(M), means(d->gmm_means, d->gmm_means + (size_t)M * D);
+    for (int c = 0; c < M; ++c) {
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j)
+                psym[((size_t)c * D + i) * D + j] = (float)(0.5 * ((double)d->gmm_precisions[((size_t)c * D + i) * D + j] +
+                                                                   (double)d->gmm_precisions[((size_t)c * D + j) * D + i]));
+        logw[c] = (float)(-std::log((double)d->gmm_nll_weights[c]));
+    }
+
+    bool okay = true;
+    auto up_f = [&](DevBuf<float> &b, const float *src, size_t n) {
+        std::vector<float> h(src, src + n);
+        okay = okay && b.upload(h) == hipSuccess;
+    };
+    auto up_vf = [&](DevBuf<float> &b, const std::vector<float> &h) { okay = okay && b.upload(h) == hipSuccess; };
+    auto up_vi = [&](DevBuf<int> &b, const std::vector<int> &h) { okay = okay && b.upload(h) == hipSuccess; };
+    up_f(m->v_template, d->v_template, (size_t)nv * 3);
+    up_f(m->shapedirs, d->shapedirs, (size_t)nv * 3 * nb);
+    up_f(m->posedirs, d->posedirs, (size_t)npf * 3 * nv);
+    up_f(m->lbs_weights, d->lbs_weights, (size_t)nv * nj);
+    up_f(m->j_extra, d->j_regressor_extra, (size_t)d->n_extra * nv);
+    up_vi(m->selector_ids, std::vector<int>(d->selector_ids, d->selector_ids + d->n_selector));
+    up_vi(m->joint_map, std::vector<int>(d->joint_map, d->joint_map + d->n_joint_map));
+    up_vi(m->parents, parents); up_vi(m->level_start, level_start); up_vi(m->level_joints, level_joints);
+    up_vi(m->child_start, child_start); up_vi(m->child_list, child_list);
+    up_vi(m->lj_kind, lj_kind); up_vi(m->lj_index, lj_index);
+    up_vf(m->Jt, Jt); up_vf(m->Jd, Jd); up_vf(m->Jdrel, Jdrel);
+    up_vf(m->sel_vt, sel_vt); up_vf(m->sel_sd, sel_sd); up_vf(m->sel_pd, sel_pd); up_vf(m->sel_w, sel_w);
+    up_vf(m->g_means, means); up_vf(m->g_psym, psym); up_vf(m->g_logw, logw);
+    if (!okay) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation / upload failed"); }
+
+    FitTab &T = m->fit;
+    T.nj = nj; T.nb = nb; T.npf = npf; T.ns = ns; T.nl = m->nl; T.np = m->np; T.n_levels = n_levels;
+    T.nbp = 3 * (nj - 1);
+    T.off_pose = 4; T.off_beta = 4 + 3 * (nj - 1); T.off_orient = T.off_beta + nb;
+    T.parents = m->parents.p; T.level_start = m->level_start.p; T.level_joints = m->level_joints.p;
+    T.child_start = m->child_start.p; T.child_list = m->child_list.p;
+    T.lj_kind = m->lj_kind.p; T.lj_index = m->lj_index.p;
+    T.Jt = m->Jt.p; T.Jd = m->Jd.p; T.Jdrel = m->Jdrel.p;
+    T.sel_vt = m->sel_vt.p; T.sel_sd = m->sel_sd.p; T.sel_pd = m->sel_pd.p; T.sel_w = m->sel_w.p;
+    T.g_means = m->g_means.p; T.g_psym = m->g_psym.p; T.g_logw = m->g_logw.p;
+    MeshTab &Q = m->mesh;
+    Q.nv = nv; Q.nj = nj; Q.nb = nb; Q.npf = npf;
+    Q.n_selector = d->n_selector; Q.n_extra = d->n_extra; Q.n_joint_map = d->n_joint_map;
+    Q.v_template = m->v_template.p; Q.shapedirs = m->shapedirs.p; Q.posedirs = m->posedirs.p;
+    Q.lbs_weights = m->lbs_weights.p; Q.j_extra = m->j_extra.p;
+    Q.selector_ids = m->selector_ids.p; Q.joint_map = m->joint_map.p;
+    m->mesh_smem = bf_mesh_smem_bytes(nj, npf, nb);
+    *out = m;
+    return BF_OK;
+}
+
+void bf_model_destroy(bf_model *m) { delete m; }
+int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
+
+static int launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *joints,
+                       float *joints_ori, hipStream_t stream) {
+    dim3 grid((m->nv + BF_MESH_TILE - 1) / BF_MESH_TILE, n);
+    hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, m->mesh,
+                       state_dev, vraw, vout);
+    HIP_TRY(hipGetLastError());
+    if (joints || joints_ori) {
+        hipLaunchKernelGGL(bf_joints_kernel, dim3(n), dim3(256), 0, stream, m->mesh, state_dev, (const float *)vraw,
+                           joints, joints_ori);
+        HIP_TRY(hipGetLastError());
+    }
+    return BF_OK;
+}
+
+int bf_smpl_forward(bf_model *m, int n, const float *betas, const float *global_orient, const float *body_pose,
+                    float *vertices, float *joints, float *joints_ori) {
+    if (!m || n <= 0 || !betas || !global_orient || !body_pose) return fail(BF_ERR_INVALID, "bf_smpl_forward: bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    const int nj = m->nj, nb = m->nb, nv = m->nv;
+    const size_t stride = bf_state_stride(nj, m->npf, nb);
+    DevBuf<float> d_beta, d_or, d_bp, d_state, d_vraw, d_j, d_jo;
+    HIP_TRY(d_beta.upload(std::vector<float>(betas, betas + (size_t)n * nb)));
+    HIP_TRY(d_or.upload(std::vector<float>(global_orient, global_orient + (size_t)n * 3)));
+    HIP_TRY(d_bp.upload(std::vector<float>(body_pose, body_pose + (size_t)n * 3 * (nj - 1))));
+    HIP_TRY(d_state.alloc((size_t)n * stride));
+    HIP_TRY(d_vraw.alloc((size_t)n * nv * 3));
+    HIP_TRY(d_j.alloc((size_t)n * m->n_joint_map * 3));
+    HIP_TRY(d_jo.alloc((size_t)n * (nj + m->n_selector) * 3));
+    hipLaunchKernelGGL(bf_pose_state_kernel, dim3(n), dim3(128), 0, 0, m->fit, (const float *)d_beta.p,
+                       (const float *)d_or.p, (const float *)d_bp.p, (const float *)nullptr, d_state.p);
+    HIP_TRY(hipGetLastError());
+    int rc = launch_mesh(m, n, d_state.p, d_vraw.p, nullptr, d_j.p, d_jo.p, 0);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (vertices) HIP_TRY(hipMemcpy(vertices, d_vraw.p, (size_t)n * nv * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (joints) HIP_TRY(hipMemcpy(joints, d_j.p, d_j.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (joints_ori) HIP_TRY(hipMemcpy(joints_ori, d_jo.p, d_jo.n * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
+    if (!m || !out || n_frames <= 0 || n_views <= 0) return fail(BF_ERR_INVALID, "bf_batch_create: bad argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(m->device));
+    size_t smem = bf_fit_smem_bytes(m->nj, m->nb, m->npf, m->ns, m->nl, m->np, n_views, m->n_levels);
+    if (smem > 160 * 1024) return fail(BF_ERR_UNSUPPORTED, "bf_batch_create: too many views for one workgroup's LDS");
+    auto *b = new bf_batch();
+    b->m = m; b->F = n_frames; b->V = n_views;
+    const size_t F = n_frames, np = m->np;
+    bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 3; ++i) ok = ok && hipEventCreate(&b->ev[i]) == hipSuccess;
+    ok = ok && b->proj.alloc(F * n_views * 12) == hipSuccess;
+    ok = ok && b->keypoints.alloc(F * n_views * m->nl * 3) == hipSuccess;
+    ok = ok && b->ndiv.upload(std::vector<int>(F, n_views)) == hipSuccess;
+    ok = ok && b->params.alloc(F * np) == hipSuccess && b->adam_m.alloc(F * np) == hipSuccess;
+    ok = ok && b->adam_v.alloc(F * np) == hipSuccess && b->grads.alloc(F * np) == hipSuccess;
+    ok = ok && b->terms.alloc(F * 4) == hipSuccess;
+    ok = ok && b->state.alloc(F * bf_state_stride(m->nj, m->npf, m->nb)) == hipSuccess;
+    ok = ok && b->vraw.alloc(F * m->nv * 3) == hipSuccess && b->vout.alloc(F * m->nv * 3) == hipSuccess;
+    ok = ok && b->joints.alloc(F * m->n_joint_map * 3) == hipSuccess;
+    ok = ok && b->debug.alloc(8192) == hipSuccess;
+    if (ok) {
+        ok = hipMemset(b->adam_m.p, 0, F * np * sizeof(float)) == hipSuccess &&
+             hipMemset(b->adam_v.p, 0, F * np * sizeof(float)) == hipSuccess &&
+             hipMemset(b->params.p, 0, F * np * sizeof(float)) == hipSuccess &&
+             hipMemset(b->keypoints.p, 0, b->keypoints.n * sizeof(float)) == hipSuccess &&
+             hipMemset(b->debug.p, 0, 8192 * sizeof(float)) == hipSuccess;
+    }
+    if (ok && smem > 64 * 1024)
+        ok = hipFuncSetAttribute((const void *)bf_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
+    if (!ok) { bf_batch_destroy(b); return fail(BF_ERR_HIP, "bf_batch_create: device allocation failed"); }
+    m->fit_smem = smem;
+    *out = b;
+    return BF_OK;
+}
+
+void bf_batch_destroy(bf_batch *b) {
+    if (!b) return;
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    delete b;
+}
+
+// general 4x4 inverse, Gauss-Jordan with partial pivoting, in double
+static bool invert4(const float *src, double *inv) {
+    double a[4][8];
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) { a[r][c] = src[r * 4 + c]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return false;
+        if (piv != c) for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[c][k]);
+        double d = a[c][c];
+        for (int k = 0; k < 8; ++k) a[c][k] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            double f = a[r][c];
+            if (f != 0.0) for (int k = 0; k < 8; ++k) a[r][k] -= f * a[c][k];
+        }
+    }
+    for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) inv[r * 4 + c] = a[r][4 + c];
+    return true;
+}
+
+int bf_batch_set_cameras(bf_batch *b, const float *c2w, const float *K) {
+    if (!b || !c2w || !K) return fail(BF_ERR_INVALID, "bf_batch_set_cameras: null argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    const size_t n = (size_t)b->F * b->V;
+    std::vector<float> proj(n * 12);
+    for (size_t i = 0; i < n; ++i) {
+        double w2c[16];
+        if (!invert4(c2w + i * 16, w2c)) return fail(BF_ERR_INVALID, "bf_batch_set_cameras: singular c2w");
+        const float *k = K + i * 9;
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c)
+                proj[i * 12 + r * 4 + c] =
+                    (float)((double)k[r * 3] * w2c[c] + (double)k[r * 3 + 1] * w2c[4 + c] + (double)k[r * 3 + 2] * w2c[8 + c]);
+    }
+    HIP_TRY(hipMemcpy(b->proj.p, proj.data(), proj.size() * sizeof(float), hipMemcpyHostToDevice));
+    return BF_OK;
+}
+
+int bf_batch_set_keypoints(bf_batch *b, const float *keypoints, const int32_t *n_use_frames) {
+    if (!b || !keypoints) return fail(BF_ERR_INVALID, "bf_batch_set_keypoints: null argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipMemcpy(b->keypoints.p, keypoints, b->keypoints.n * sizeof(float), hipMemcpyHostToDevice));
+    std::vector<int> nd(b->F, b->V);
+    if (n_use_frames)
+        for (int f = 0; f < b->F; ++f) {
+            if (n_use_frames[f] <= 0) return fail(BF_ERR_INVALID, "bf_batch_set_keypoints: n_use_frames must be positive");
+            nd[f] = n_use_frames[f];
+        }
+    HIP_TRY(hipMemcpy(b->ndiv.p, nd.data(), nd.size() * sizeof(int), hipMemcpyHostToDevice));
+    return BF_OK;
+}
+
+static int reset_adam(bf_batch *b) {
+    HIP_TRY(hipMemset(b->adam_m.p, 0, b->adam_m.n * sizeof(float)));
+    HIP_TRY(hipMemset(b->adam_v.p, 0, b->adam_v.n * sizeof(float)));
+    b->steps_done = 0;
+    b->have_result = false;
+    return BF_OK;
+}
+
+int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_pose) {
+    if (!b || !init_betas || !init_pose) return fail(BF_ERR_INVALID, "bf_batch_set_init: null argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    const bf_model *m = b->m;
+    const int np = m->np, nj = m->nj, nb = m->nb;
+    std::vector<float> p((size_t)b->F * np, 0.f);
+    for (int f = 0; f < b->F; ++f) {
+        float *q = p.data() + (size_t)f * np;
+        q[3] = 1.0f;                                                             // body_scale = 1, transl = 0
+        std::memcpy(q + m->fit.off_pose, init_pose + (size_t)f * 3 * nj + 3, sizeof(float) * 3 * (nj - 1));
+        std::memcpy(q + m->fit.off_beta, init_betas + (size_t)f * nb, sizeof(float) * nb);
+        std::memcpy(q + m->fit.off_orient, init_pose + (size_t)f * 3 * nj, sizeof(float) * 3);
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(b->params.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
+    return reset_adam(b);
+}
+
+int bf_batch_set_params(bf_batch *b, const float *params) {
+    if (!b || !params) return fail(BF_ERR_INVALID, "bf_batch_set_params: null argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(b->params.p, params, b->params.n * sizeof(float), hipMemcpyHostToDevice));
+    return reset_adam(b);
+}
+
+int bf_batch_get_params(bf_batch *b, float *params) {
+    if (!b || !params) return fail(BF_ERR_INVALID, "bf_batch_get_params: null argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(params, b->params.p, b->params.n * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+static HyperDev to_dev(const bf_hyper &h) {
+    HyperDev d;
+    d.sigma2 = h.sigma * h.sigma;
+    d.w_pose = h.pose_prior_weight * h.pose_prior_weight;
+    d.w_angle = h.angle_prior_weight * h.angle_prior_weight;
+    d.w_shape = h.shape_prior_weight * h.shape_prior_weight;
+    d.cscale = h.constant_scale;
+    d.coeff = h.imsize / 1024.0f;
+    d.beta1 = h.adam_beta1; d.beta2 = h.adam_beta2; d.eps = h.adam_eps;
+    return d;
+}
+
+// torch.optim.Adam evaluates the bias corrections in python floats (double): SURVEY.md 10C
+static int ensure_adam_tab(bf_batch *b, const bf_hyper &h, int upto) {
+    bool same = b->adam_cap >= upto && b->adam_hyper.lr == h.lr && b->adam_hyper.lr_transl_scale == h.lr_transl_scale &&
+                b->adam_hyper.adam_beta1 == h.adam_beta1 && b->adam_hyper.adam_beta2 == h.adam_beta2;
+    if (same) return BF_OK;
+    int cap = std::max(upto, 1024);
+    std::vector<float> tab((size_t)cap * 3);
+    const double b1 = (double)h.adam_beta1, b2 = (double)h.adam_beta2;
+    for (int t = 1; t <= cap; ++t) {
+        double bc1 = 1.0 - std::pow(b1, t), bc2 = 1.0 - std::pow(b2, t);
+        tab[(size_t)(t - 1) * 3 + 0] = (float)((double)h.lr_transl_scale / bc1);
+        tab[(size_t)(t - 1) * 3 + 1] = (float)((double)h.lr / bc1);
+        tab[(size_t)(t - 1) * 3 + 2] = (float)std::sqrt(bc2);
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (b->adam_tab.p) { (void)hipFree(b->adam_tab.p); b->adam_tab.p = nullptr; }
+    HIP_TRY(b->adam_tab.upload(tab));
+    b->adam_cap = cap;
+    b->adam_hyper = h;
+    return BF_OK;
+}
+
+static FrameIO frame_io(bf_batch *b, bool want_grads) {
+    FrameIO io;
+    io.n_frames = b->F; io.n_views = b->V;
+    io.proj = b->proj.p; io.keypoints = b->keypoints.p; io.ndiv = b->ndiv.p;
+    io.params = b->params.p; io.adam_m = b->adam_m.p; io.adam_v = b->adam_v.p;
+    io.grads = want_grads ? b->grads.p : nullptr;
+    io.terms = b->terms.p; io.state = b->state.p;
+    io.debug = b->debug.p;
+    return io;
+}
+
+int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
+    if (!b || n_iters <= 0) return fail(BF_ERR_INVALID, "bf_fit: bad argument");
+    bf_model *m = b->m;
+    HIP_TRY(hipSetDevice(m->device));
+    bf_hyper h;
+    if (hyper) h = *hyper; else bf_hyper_default(&h);
+    int rc = ensure_adam_tab(b, h, b->steps_done + n_iters);
+    if (rc) return rc;
+    HyperDev hd = to_dev(h);
+    FrameIO io = frame_io(b, false);
+    const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES);
+    HIP_TRY(hipEventRecord(b->ev[0], b->stream));
+    if (!dense) {
+        hipLaunchKernelGGL(bf_fit_kernel, dim3(b->F), dim3(BF_FIT_THREADS), m->fit_smem, b->stream, m->fit, io, hd,
+                           n_iters, 0, (const float *)b->adam_tab.p, b->steps_done);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+        if (want_v) {
+            rc = launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->joints.p, nullptr, b->stream);
+            if (rc) return rc;
+        }
+    } else {
+        // reference-literal schedule: every iteration evaluates the whole mesh (smplify.py:179-190)
+        for (int it = 0; it < n_iters; ++it) {
+            hipLaunchKernelGGL(bf_fit_kernel, dim3(b->F), dim3(BF_FIT_THREADS), m->fit_smem, b->stream, m->fit, io, hd,
+                               1, 0, (const float *)b->adam_tab.p, b->steps_done + it);
+            HIP_TRY(hipGetLastError());
+            rc = launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->joints.p, nullptr, b->stream);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+    }
+    HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+    b->steps_done += n_iters;
+    b->timed = true;
+    b->have_result = want_v || dense;
+    return BF_OK;
+}
+
+int bf_loss_grad(bf_batch *b, const bf_hyper *hyper, float *terms, float *grads) {
+    if (!b) return fail(BF_ERR_INVALID, "bf_loss_grad: null batch");
+    bf_model *m = b->m;
+    HIP_TRY(hipSetDevice(m->device));
+    bf_hyper h;
+    if (hyper) h = *hyper; else bf_hyper_default(&h);
+    int rc = ensure_adam_tab(b, h, 1);
+    if (rc) return rc;
+    HyperDev hd = to_dev(h);
+    FrameIO io = frame_io(b, true);
+    hipLaunchKernelGGL(bf_fit_kernel, dim3(b->F), dim3(BF_FIT_THREADS), m->fit_smem, b->stream, m->fit, io, hd, 1, 1,
+                       (const float *)b->adam_tab.p, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (terms) HIP_TRY(hipMemcpy(terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (grads) HIP_TRY(hipMemcpy(grads, b->grads.p, b->grads.n * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+int bf_batch_sync(bf_batch *b) {
+    if (!b) return fail(BF_ERR_INVALID, "bf_batch_sync: null batch");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return BF_OK;
+}
+
+int bf_batch_get_result(bf_batch *b, float *vertices, float *joints, float *full_pose, float *loss_terms) {
+    if (!b) return fail(BF_ERR_INVALID, "bf_batch_get_result: null batch");
+    const bf_model *m = b->m;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if ((vertices || joints) && !b->have_result)
+        return fail(BF_ERR_INVALID, "bf_batch_get_result: no mesh was evaluated (BF_FIT_NO_VERTICES or no bf_fit yet)");
+    if (vertices) HIP_TRY(hipMemcpy(vertices, b->vout.p, b->vout.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (joints) HIP_TRY(hipMemcpy(joints, b->joints.p, b->joints.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (loss_terms) HIP_TRY(hipMemcpy(loss_terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (full_pose) {
+        const size_t stride = bf_state_stride(m->nj, m->npf, m->nb);
+        std::vector<float> st((size_t)b->F * stride);
+        HIP_TRY(hipMemcpy(st.data(), b->state.p, st.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int f = 0; f < b->F; ++f) {
+            StateView v = bf_state_view(st.data() + (size_t)f * stride, m->nj, m->npf, m->nb);
+            std::memcpy(full_pose + (size_t)f * 3 * m->nj, v.theta, sizeof(float) * 3 * m->nj);
+        }
+    }
+    return BF_OK;
+}
+
+int bf_batch_export_params_dev(bf_batch *b, void *dst_dev) {
+    if (!b || !dst_dev) return fail(BF_ERR_INVALID, "bf_batch_export_params_dev: null argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipMemcpyAsync(dst_dev, b->params.p, b->params.n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return BF_OK;
+}
+
+int bf_batch_last_timing(bf_batch *b, float ms[3]) {
+    if (!b || !ms) return fail(BF_ERR_INVALID, "bf_batch_last_timing: null argument");
+    if (!b->timed) return fail(BF_ERR_INVALID, "bf_batch_last_timing: no bf_fit recorded yet");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipEventSynchronize(b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[0], b->ev[0], b->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&ms[1], b->ev[1], b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], b->ev[0], b->ev[2]));
+    return BF_OK;
+}
+
+/* test hook: the first-iteration intermediates of frame 0 dumped by the last kernel launch */
+int bf_batch_debug_dump(bf_batch *b, float *dst, int n) {
+    if (!b || !dst || n <= 0 || n > 8192) return fail(BF_ERR_INVALID, "bf_batch_debug_dump: bad argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(dst, b->debug.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+// Internal layouts shared by the HIP kernels and the host side of libbodyfit (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define BF_GMM_M 8          // reference hard-codes num_gaussians=8 (smplify/smplify.py:47)
+#define BF_GMM_D 69         // and a 69-dof body pose (smplify/prior.py:154)
+#define BF_GMM_LD 72        // padded row length of the d / y vectors in LDS
+#define BF_FIT_THREADS 256  // one workgroup (4 wave64) per frame
+#define BF_VSUB 8           // view sub-slots in the projection phase (256 / 32)
+#define BF_KP_ROUNDS 6      // keypoints cached in registers for V <= 8*6 = 48 views
+#define BF_MESH_TILE 32     // vertices per workgroup of the full-mesh forward
+#define BF_MESH_RG 8        // pose-feature row groups per workgroup (split-K inside the workgroup)
+
+// Model-level tables of the fit, all resident in HBM for the life of the model.
+struct FitTab {
+    int nj, nb, npf, ns, nl, np;     // joints, betas, pose features 9(nj-1), selector verts, loss joints, params
+    int n_levels;                    // depth of the kinematic tree
+    int nbp;                         // optimised body-pose dofs (69 SMPL); the GMM sees them zero-padded to 69
+    int off_pose, off_beta, off_orient;
+    const int *parents;              // [nj]
+    const int *level_start;          // [n_levels+1]  joints sorted by depth
+    const int *level_joints;         // [nj]
+    const int *child_start;          // [nj+1]        CSR children lists
+    const int *child_list;           // [nj-1]
+    const int *lj_kind;              // [nl] 0 = chain joint, 1 = selector vertex slot
+    const int *lj_index;             // [nl]
+    const float *Jt;                 // [nj*3]        J_regressor v_template
+    const float *Jd;                 // [nj*3][nb]    J_regressor shapedirs
+    const float *Jdrel;              // [nj*3][nb]    Jd[j] - Jd[parent(j)]   (Jd[0] for the root)
+    const float *sel_vt;             // [ns*3]
+    const float *sel_sd;             // [ns*3][nb]
+    const float *sel_pd;             // [npf][ns*3]   posedirs columns of the selector vertices
+    const float *sel_w;              // [ns][nj]
+    const float *g_means;            // [M][D]
+    const float *g_psym;             // [M][D][D]     0.5 (P + P^T)
+    const float *g_logw;             // [M]           -log(nll_weights)
+};
+
+// Full model tensors for the dense mesh kernels.
+struct MeshTab {
+    int nv, nj, nb, npf;
+    int n_selector, n_extra, n_joint_map;
+    const float *v_template;         // [nv*3]
+    const float *shapedirs;          // [nv*3][nb]
+    const float *posedirs;           // [npf][3nv]
+    const float *lbs_weights;        // [nv][nj]
+    const float *j_extra;            // [n_extra][nv]
+    const int *selector_ids;         // [n_selector]
+    const int *joint_map;            // [n_joint_map]
+};
+
+// Per-frame pose state handed from the fit / pose-prep kernel to the mesh kernel.
+// layout per frame (floats): GR[nj*9] At[nj*3] Gt[nj*3] feat[npf] theta[nj*3] beta[nb] t[3] s c
+__host__ __device__ inline int bf_state_stride(int nj, int npf, int nb) {
+    return nj * 9 + nj * 3 + nj * 3 + npf + nj * 3 + nb + 3 + 2;
+}
+struct StateView {
+    float *GR, *At, *Gt, *feat, *theta, *beta, *t, *sc;   // sc[0] = body_scale, sc[1] = constant_scale
+};
+__host__ __device__ inline StateView bf_state_view(float *base, int nj, int npf, int nb) {
+    StateView s;
+    s.GR = base;
+    s.At = s.GR + nj * 9;
+    s.Gt = s.At + nj * 3;
+    s.feat = s.Gt + nj * 3;
+    s.theta = s.feat + npf;
+    s.beta = s.theta + nj * 3;
+    s.t = s.beta + nb;
+    s.sc = s.t + 3;
+    return s;
+}
+
+struct FrameIO {
+    int n_frames, n_views;
+    const float *proj;        // [F][V][12]   K [R|t], world -> pixel
+    const float *keypoints;   // [F][V][nl][3]
+    const int *ndiv;          // [F]
+    float *params;            // [F][np]
+    float *adam_m;            // [F][np]
+    float *adam_v;            // [F][np]
+    float *grads;             // [F][np]       (grad-only mode)
+    float *terms;             // [F][4]
+    float *state;             // [F][state_stride]
+    float *debug;             // optional dump of the first iteration's intermediates
+};
+
+struct HyperDev {
+    float sigma2, w_pose, w_angle, w_shape, cscale, coeff;
+    float beta1, beta2, eps;
+};

@@ -1,0 +1,213 @@
+// Full-mesh SMPL forward for gfx950: the HBM-bound part of the path.
+//
+//   bf_pose_state_kernel  theta, beta -> per-frame pose state (chain matrices A_j, pose feature)
+//   bf_mesh_kernel        streams posedirs / shapedirs / lbs_weights once and emits all NV vertices
+//   bf_joints_kernel      chain + selector + extra-regressor joints, gathered by joint_map
+//
+// Reference being replaced: smplx 0.1.13 `lbs()` as called from models/smpl.py:69-83 and
+// smplify/smplify.py:179-190; per frame-iteration it streams
+// posedirs 17,114,760 B + shapedirs 826,800 B + lbs_weights 661,440 B + v_template 82,680 B.
+//
+// Layout: posedirs is [P, 3NV] row-major, i.e. for one pose-feature row consecutive lanes read
+// consecutive (vertex, xyz) columns - already coalesced.  A workgroup owns a tile of 32 vertices
+// (96 columns) and splits the P rows over 8 row groups (split-K inside the workgroup, reduced through
+// LDS), so the grid is ceil(NV/32) = 216 workgroups of 12 waves: every load of a wave is
+// independent, the whole 17 MB matrix is in flight at once and all 256 CUs have work.  The 24 chain
+// matrices (1.1 KB) and the 207-float pose feature sit in LDS.
+#include "bf_internal.h"
+
+namespace {
+__device__ inline void m_rodrigues(float tx, float ty, float tz, float *R) {
+    float ux = tx + 1e-8f, uy = ty + 1e-8f, uz = tz + 1e-8f;
+    float a = sqrtf(ux * ux + uy * uy + uz * uz);
+    float nx = tx / a, ny = ty / a, nz = tz / a;
+    float s = sinf(a), c = cosf(a), oc = 1.0f - c;
+    R[0] = 1.0f + oc * (-nz * nz - ny * ny);
+    R[1] = s * (-nz) + oc * (nx * ny);
+    R[2] = s * ny + oc * (nx * nz);
+    R[3] = s * nz + oc * (nx * ny);
+    R[4] = 1.0f + oc * (-nz * nz - nx * nx);
+    R[5] = s * (-nx) + oc * (ny * nz);
+    R[6] = s * (-ny) + oc * (nx * nz);
+    R[7] = s * nx + oc * (ny * nz);
+    R[8] = 1.0f + oc * (-ny * ny - nx * nx);
+}
+__device__ inline float m_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+}  // namespace
+
+// One 128-thread workgroup per parameter set.  betas[n][nb], orient[n][3], body_pose[n][3(nj-1)];
+// transl / scale are taken as (0,0,0) / 1 / 1 when `sim` is null, else sim[n][5] = t, s, c.
+extern "C" __global__ void __launch_bounds__(128)
+bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__restrict__ orient,
+                     const float *__restrict__ body_pose, const float *__restrict__ sim, float *state) {
+    __shared__ float R[64 * 9], J[64 * 3], GR[64 * 9], Gt[64 * 3];
+    const int tid = threadIdx.x, nt = 128, f = blockIdx.x;
+    const int nj = T.nj, nb = T.nb, npf = T.npf;
+    const float *beta = betas + (size_t)f * nb;
+    StateView st = bf_state_view(state + (size_t)f * bf_state_stride(nj, npf, nb), nj, npf, nb);
+    if (tid < nj) {
+        const float *th = tid == 0 ? orient + (size_t)f * 3 : body_pose + (size_t)f * 3 * (nj - 1) + 3 * (tid - 1);
+        m_rodrigues(th[0], th[1], th[2], R + tid * 9);
+        st.theta[tid * 3] = th[0]; st.theta[tid * 3 + 1] = th[1]; st.theta[tid * 3 + 2] = th[2];
+    }
+    for (int i = tid; i < nj * 3; i += nt) {
+        float acc = 0.f;
+        for (int l = 0; l < nb; ++l) acc += T.Jd[i * nb + l] * beta[l];
+        J[i] = T.Jt[i] + acc;
+    }
+    __syncthreads();
+    if (tid < 9) GR[tid] = R[tid];
+    if (tid >= 64 && tid < 67) Gt[tid - 64] = J[tid - 64];
+    __syncthreads();
+    for (int lev = 1; lev < T.n_levels; ++lev) {
+        int ls = T.level_start[lev], cnt = (T.level_start[lev + 1] - ls) * 3;
+        for (int idx = tid; idx < cnt; idx += nt) {
+            int i = T.level_joints[ls + idx / 3], r = idx % 3, p = T.parents[i];
+            float g0 = GR[p * 9 + r * 3], g1 = GR[p * 9 + r * 3 + 1], g2 = GR[p * 9 + r * 3 + 2];
+            const float *Ri = R + i * 9;
+            GR[i * 9 + r * 3 + 0] = g0 * Ri[0] + g1 * Ri[3] + g2 * Ri[6];
+            GR[i * 9 + r * 3 + 1] = g0 * Ri[1] + g1 * Ri[4] + g2 * Ri[7];
+            GR[i * 9 + r * 3 + 2] = g0 * Ri[2] + g1 * Ri[5] + g2 * Ri[8];
+            float r0 = J[i * 3] - J[p * 3], r1 = J[i * 3 + 1] - J[p * 3 + 1], r2 = J[i * 3 + 2] - J[p * 3 + 2];
+            Gt[i * 3 + r] = g0 * r0 + g1 * r1 + g2 * r2 + Gt[p * 3 + r];
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nj * 9; i += nt) st.GR[i] = GR[i];
+    for (int i = tid; i < nj * 3; i += nt) {
+        int j = i / 3, a = i % 3;
+        const float *g = GR + j * 9 + a * 3;
+        st.At[i] = Gt[i] - (g[0] * J[j * 3] + g[1] * J[j * 3 + 1] + g[2] * J[j * 3 + 2]);
+        st.Gt[i] = Gt[i];
+    }
+    for (int p = tid; p < npf; p += nt) {
+        int j = 1 + p / 9, e = p % 9;
+        st.feat[p] = R[j * 9 + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+    }
+    if (tid < nb) st.beta[tid] = beta[tid];
+    if (tid < 3) st.t[tid] = sim ? sim[(size_t)f * 5 + tid] : 0.f;
+    if (tid == 3) { st.sc[0] = sim ? sim[(size_t)f * 5 + 3] : 1.f; st.sc[1] = sim ? sim[(size_t)f * 5 + 4] : 1.f; }
+}
+
+// grid (ceil(NV/32), F), block 96 x 8.  vraw = model-space vertices (lbs output), vout = (v + t) s c.
+extern "C" __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
+bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ vraw, float *__restrict__ vout) {
+    constexpr int COLS = BF_MESH_TILE * 3;
+    extern __shared__ __align__(16) float sm[];
+    const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
+    float *s_feat = sm;                         // [npf]
+    float *s_A = s_feat + ((npf + 3) & ~3);     // [nj][12]  rows of (GR | At)
+    float *s_red = s_A + nj * 12;               // [RG][COLS]
+    float *s_vp = s_red + BF_MESH_RG * COLS;    // [COLS]
+    float *s_beta = s_vp + COLS;                // [nb] + t[3] + sc[2]
+    const int tid = threadIdx.x, nt = COLS * BF_MESH_RG;
+    const int col = tid % COLS, rg = tid / COLS;
+    const int frame = blockIdx.y;
+    StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
+    const int ncols = 3 * nv;
+    const int gcol = blockIdx.x * COLS + col;
+    const bool ok = gcol < ncols;
+
+    // issue this thread's slice of the posedirs stream first: every load is independent
+    const int rows = (npf + BF_MESH_RG - 1) / BF_MESH_RG;
+    const int p0 = rg * rows, p1 = min(npf, p0 + rows);
+    const float *pd = M.posedirs + (size_t)p0 * ncols + (ok ? gcol : 0);
+    float acc = 0.f;
+    for (int i = tid; i < npf; i += nt) s_feat[i] = st.feat[i];
+    for (int i = tid; i < nj * 12; i += nt) {
+        int j = i / 12, e = i % 12, a = e / 4, b = e % 4;
+        s_A[i] = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
+    }
+    if (tid < nb + 5) s_beta[tid] = st.beta[tid];   // beta, t, sc are contiguous in the state record
+    __syncthreads();
+#pragma unroll 13
+    for (int p = p0; p < p1; ++p) {
+        acc += s_feat[p] * pd[0];
+        pd += ncols;
+    }
+    s_red[rg * COLS + col] = acc;
+    __syncthreads();
+    if (rg == 0) {
+        float off = 0.f;
+#pragma unroll
+        for (int q = 0; q < BF_MESH_RG; ++q) off += s_red[q * COLS + col];
+        float vs = 0.f;
+        if (ok) {
+            const float *sd = M.shapedirs + (size_t)gcol * nb;
+            float a2 = 0.f;
+            for (int l = 0; l < nb; ++l) a2 += sd[l] * s_beta[l];
+            vs = M.v_template[gcol] + a2;
+        }
+        s_vp[col] = vs + off;
+    }
+    __syncthreads();
+    if (rg == 0 && ok) {
+        int vl = col / 3, k = col % 3, v = blockIdx.x * BF_MESH_TILE + vl;
+        const float *w = M.lbs_weights + (size_t)v * nj;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, tt = 0.f;
+        for (int j = 0; j < nj; ++j) {
+            float wj = w[j];
+            const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
+            t0 += wj * a.x; t1 += wj * a.y; t2 += wj * a.z; tt += wj * a.w;
+        }
+        float r = t0 * s_vp[vl * 3] + t1 * s_vp[vl * 3 + 1] + t2 * s_vp[vl * 3 + 2] + tt;
+        size_t o = (size_t)frame * ncols + gcol;
+        if (vraw) vraw[o] = r;
+        if (vout) vout[o] = (r + s_beta[nb + k]) * s_beta[nb + 3] * s_beta[nb + 4];
+    }
+}
+
+extern "C" size_t bf_mesh_smem_bytes(int nj, int npf, int nb) {
+    constexpr int COLS = BF_MESH_TILE * 3;
+    return sizeof(float) * (((npf + 3) & ~3) + nj * 12 + BF_MESH_RG * COLS + COLS + nb + 8);
+}
+
+// One 256-thread workgroup per frame.  joints_ori = cat(chain joints, selector vertices) and
+// joints = cat(joints_ori, J_regressor_extra vraw)[joint_map] (models/smpl.py:72-75), both with the
+// similarity of smplify.py:189 applied.
+extern "C" __global__ void __launch_bounds__(256)
+bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__restrict__ vraw,
+                 float *__restrict__ joints, float *__restrict__ joints_ori) {
+    __shared__ float s_part[4][32 * 3];
+    __shared__ float s_all[(64 + 32 + 32) * 3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frame = blockIdx.x;
+    const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv, ne = M.n_extra, nsel = M.n_selector;
+    StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
+    const float *vr = vraw + (size_t)frame * nv * 3;
+    const float t0 = st.t[0], t1 = st.t[1], t2 = st.t[2], sc = st.sc[0] * st.sc[1];
+    // extra regressors: each thread strides over the vertices, then a fixed-order block reduction
+    for (int e = 0; e < ne; ++e) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        const float *row = M.j_extra + (size_t)e * nv;
+        for (int v = tid; v < nv; v += 256) {
+            float w = row[v];
+            a0 += w * vr[v * 3]; a1 += w * vr[v * 3 + 1]; a2 += w * vr[v * 3 + 2];
+        }
+        a0 = m_wave_sum(a0); a1 = m_wave_sum(a1); a2 = m_wave_sum(a2);
+        if (lane == 0) { s_part[wave][e * 3] = a0; s_part[wave][e * 3 + 1] = a1; s_part[wave][e * 3 + 2] = a2; }
+    }
+    __syncthreads();
+    const int n_ori = nj + nsel;
+    for (int i = tid; i < (n_ori + ne) * 3; i += 256) {
+        int j = i / 3, k = i % 3;
+        float x;
+        if (j < nj) x = st.Gt[j * 3 + k];
+        else if (j < n_ori) x = vr[(size_t)M.selector_ids[j - nj] * 3 + k];
+        else {
+            int e = (j - n_ori) * 3 + k;
+            x = s_part[0][e] + s_part[1][e] + s_part[2][e] + s_part[3][e];
+        }
+        float tk = k == 0 ? t0 : (k == 1 ? t1 : t2);
+        s_all[i] = (x + tk) * sc;
+    }
+    __syncthreads();
+    if (joints_ori)
+        for (int i = tid; i < n_ori * 3; i += 256) joints_ori[(size_t)frame * n_ori * 3 + i] = s_all[i];
+    if (joints)
+        for (int i = tid; i < M.n_joint_map * 3; i += 256)
+            joints[(size_t)frame * M.n_joint_map * 3 + i] = s_all[M.joint_map[i / 3] * 3 + i % 3];
+}

@@ -1,0 +1,214 @@
+"""Thin numpy-level wrappers over the C ABI: `DeviceModel` (bf_model) and `FrameBatch` (bf_batch).
+
+Host code is plain Python + numpy + ctypes; PyTorch is not involved on this path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .synthetic import gmm_buffers
+
+N_LOSS_JOINTS = 25   # SKELETON_LENGTH, reference smplify/loss.py:17
+
+
+def _f32(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a), dtype=np.int32)
+
+
+class DeviceModel:
+    """Body model + GMM prior uploaded once to one GPU (replaces the per-frame construction at
+    reference smplify/body_fitting.py:82 -> smplify/smplify.py:46-56)."""
+
+    def __init__(self, model, gmm, device=0):
+        lib = _lib.load()
+        self._lib = lib
+        self.model_type = model.get("model_type", "smpl")
+        means, prec, nllw = gmm_buffers(gmm) if isinstance(gmm, dict) else gmm
+        keep = {
+            "v_template": _f32(model["v_template"]), "shapedirs": _f32(model["shapedirs"]),
+            "posedirs": _f32(model["posedirs"]), "j_regressor": _f32(model["J_regressor"]),
+            "lbs_weights": _f32(model["lbs_weights"]), "parents": _i32(model["parents"]),
+            "selector_ids": _i32(model["selector_ids"]),
+            "j_regressor_extra": _f32(model["J_regressor_extra"]), "joint_map": _i32(model["joint_map"]),
+            "gmm_means": _f32(means), "gmm_precisions": _f32(prec), "gmm_nll_weights": _f32(nllw),
+        }
+        self.n_verts, self.n_joints = keep["lbs_weights"].shape
+        self.n_betas = keep["shapedirs"].shape[2]
+        self.n_selector = len(keep["selector_ids"])
+        self.n_joint_map = len(keep["joint_map"])
+        self.faces = _i32(model["faces"]) if "faces" in model else None
+        if keep["posedirs"].shape != (9 * (self.n_joints - 1), 3 * self.n_verts):
+            raise ValueError("posedirs must be [9(NJ-1), 3NV] as smplx stores it")
+        d = _lib.ModelDesc()
+        d.n_verts, d.n_joints, d.n_betas = self.n_verts, self.n_joints, self.n_betas
+        for name in ("v_template", "shapedirs", "posedirs", "j_regressor", "lbs_weights", "j_regressor_extra",
+                     "gmm_means", "gmm_precisions", "gmm_nll_weights"):
+            setattr(d, name, _lib.fptr(keep[name]))
+        for name in ("parents", "selector_ids", "joint_map"):
+            setattr(d, name, _lib.iptr(keep[name]))
+        d.n_selector, d.n_extra = self.n_selector, keep["j_regressor_extra"].shape[0]
+        d.n_joint_map, d.n_loss_joints = self.n_joint_map, N_LOSS_JOINTS
+        d.gmm_components, d.gmm_dim = keep["gmm_means"].shape
+        self._h = C.c_void_p()
+        _lib.check(lib.bf_model_create(C.byref(d), int(device), C.byref(self._h)), "bf_model_create")
+        self.device = int(device)
+        self.n_params = lib.bf_model_n_params(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bf_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, betas, global_orient, body_pose):
+        """models.smpl.SMPL.forward (reference models/smpl.py:69-83): -> vertices, joints49, joints45."""
+        betas = _f32(betas, (-1, self.n_betas))
+        n = betas.shape[0]
+        orient = _f32(global_orient, (n, 3))
+        pose = _f32(body_pose, (n, 3 * (self.n_joints - 1)))
+        verts = np.empty((n, self.n_verts, 3), np.float32)
+        joints = np.empty((n, self.n_joint_map, 3), np.float32)
+        jori = np.empty((n, self.n_joints + self.n_selector, 3), np.float32)
+        _lib.check(self._lib.bf_smpl_forward(self._h, n, _lib.fptr(betas), _lib.fptr(orient), _lib.fptr(pose),
+                                             _lib.fptr(verts), _lib.fptr(joints), _lib.fptr(jori)), "bf_smpl_forward")
+        return verts, joints, jori
+
+
+def make_hyper(**kw):
+    h = _lib.Hyper()
+    _lib.load().bf_hyper_default(C.byref(h))
+    for k, v in kw.items():
+        if not hasattr(h, k):
+            raise TypeError(f"unknown hyper-parameter {k!r}")
+        setattr(h, k, float(v))
+    return h
+
+
+class FrameBatch:
+    """F independent frames x V views resident on the model's GPU."""
+
+    def __init__(self, dev_model: DeviceModel, n_frames, n_views):
+        self._lib = dev_model._lib
+        self.model = dev_model
+        self.F, self.V = int(n_frames), int(n_views)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.bf_batch_create(dev_model._h, self.F, self.V, C.byref(self._h)), "bf_batch_create")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bf_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- inputs ------------------------------------------------------------------------------
+    def set_cameras(self, c2ws, Ks):
+        c2w = _f32(c2ws, (self.F, self.V, 4, 4))
+        K = _f32(Ks, (self.F, self.V, 3, 3))
+        _lib.check(self._lib.bf_batch_set_cameras(self._h, _lib.fptr(c2w), _lib.fptr(K)), "bf_batch_set_cameras")
+
+    def set_keypoints(self, keypoints, n_use_frames=None):
+        kp = _f32(keypoints, (self.F, self.V, N_LOSS_JOINTS, 3))
+        nd = None if n_use_frames is None else _i32(np.broadcast_to(np.asarray(n_use_frames), (self.F,)))
+        _lib.check(self._lib.bf_batch_set_keypoints(self._h, _lib.fptr(kp), _lib.iptr(nd)), "bf_batch_set_keypoints")
+
+    def set_init(self, init_betas, init_pose):
+        b = _f32(init_betas, (self.F, self.model.n_betas))
+        p = _f32(init_pose, (self.F, 3 * self.model.n_joints))
+        _lib.check(self._lib.bf_batch_set_init(self._h, _lib.fptr(b), _lib.fptr(p)), "bf_batch_set_init")
+
+    def set_params(self, params):
+        p = _f32(params, (self.F, self.model.n_params))
+        _lib.check(self._lib.bf_batch_set_params(self._h, _lib.fptr(p)), "bf_batch_set_params")
+
+    # -- compute -----------------------------------------------------------------------------
+    def fit(self, n_iters, hyper=None, flags=_lib.FIT_DEFAULT):
+        hp = C.byref(hyper) if hyper is not None else None
+        _lib.check(self._lib.bf_fit(self._h, int(n_iters), hp, int(flags)), "bf_fit")
+
+    def sync(self):
+        _lib.check(self._lib.bf_batch_sync(self._h), "bf_batch_sync")
+
+    def loss_grad(self, hyper=None):
+        terms = np.empty((self.F, 4), np.float32)
+        grads = np.empty((self.F, self.model.n_params), np.float32)
+        hp = C.byref(hyper) if hyper is not None else None
+        _lib.check(self._lib.bf_loss_grad(self._h, hp, _lib.fptr(terms), _lib.fptr(grads)), "bf_loss_grad")
+        return terms, grads
+
+    # -- outputs -----------------------------------------------------------------------------
+    def get_params(self):
+        p = np.empty((self.F, self.model.n_params), np.float32)
+        _lib.check(self._lib.bf_batch_get_params(self._h, _lib.fptr(p)), "bf_batch_get_params")
+        return p
+
+    def get_result(self, vertices=True):
+        m = self.model
+        verts = np.empty((self.F, m.n_verts, 3), np.float32) if vertices else None
+        joints = np.empty((self.F, m.n_joint_map, 3), np.float32) if vertices else None
+        full_pose = np.empty((self.F, 3 * m.n_joints), np.float32)
+        terms = np.empty((self.F, 4), np.float32)
+        _lib.check(self._lib.bf_batch_get_result(self._h, _lib.fptr(verts), _lib.fptr(joints), _lib.fptr(full_pose),
+                                                 _lib.fptr(terms)), "bf_batch_get_result")
+        return verts, joints, full_pose, terms
+
+    def export_params_dev(self, dev_ptr):
+        _lib.check(self._lib.bf_batch_export_params_dev(self._h, C.c_void_p(int(dev_ptr))), "bf_batch_export_params_dev")
+
+    def last_timing(self):
+        ms = np.zeros(3, np.float32)
+        _lib.check(self._lib.bf_batch_last_timing(self._h, _lib.fptr(ms)), "bf_batch_last_timing")
+        return {"fit_ms": float(ms[0]), "mesh_ms": float(ms[1]), "total_ms": float(ms[2])}
+
+    def debug_dump(self, n):
+        out = np.zeros(n, np.float32)
+        _lib.check(self._lib.bf_batch_debug_dump(self._h, _lib.fptr(out), int(n)), "bf_batch_debug_dump")
+        return out
+
+
+def split_params(packed, n_joints=24, n_betas=10):
+    """packed[...,86] in optimiser order (reference smplify.py:167-171) -> dict of named blocks."""
+    p = np.asarray(packed)
+    nbp = 3 * (n_joints - 1)
+    return {"global_transl": p[..., 0:3], "scale": p[..., 3:4], "pose": p[..., 4:4 + nbp],
+            "betas": p[..., 4 + nbp:4 + nbp + n_betas], "global_orient": p[..., 4 + nbp + n_betas:4 + nbp + n_betas + 3]}
+
+
+def pack_params(d):
+    return np.concatenate([np.asarray(d[k], dtype=np.float32).reshape(-1) for k in
+                           ("global_transl", "scale", "pose", "betas", "global_orient")]).astype(np.float32)
+
+
+def pack_problem(problems):
+    """list of synthetic.make_problem dicts -> (c2w[F,V,4,4], K[F,V,3,3], kp[F,V,25,3], ndiv[F], betas, pose)."""
+    F, V = len(problems), len(problems[0]["c2ws"])
+    c2w = np.stack([np.stack(p["c2ws"]) for p in problems]).astype(np.float32)
+    K = np.stack([np.stack(p["Ks"]) for p in problems]).astype(np.float32)
+    kp = np.zeros((F, V, N_LOSS_JOINTS, 3), np.float32)
+    for f, p in enumerate(problems):
+        for v, k in enumerate(p["keypoints"]):
+            if k is not None:                      # None view: confidence 0 everywhere (loss.py:157)
+                kp[f, v] = k["pose"]
+    ndiv = np.array([len(p["use_frames"]) for p in problems], np.int32)
+    betas = np.concatenate([p["init_betas"] for p in problems]).astype(np.float32)
+    pose = np.concatenate([p["init_pose"] for p in problems]).astype(np.float32)
+    return c2w, K, kp, ndiv, betas, pose

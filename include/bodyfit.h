@@ -1,0 +1,148 @@
+/*
+ * libbodyfit - MI355X-native multi-view SMPLify inner loop, C ABI.
+ *
+ * The reference (generalizable-neural-performer/bodyfitting) has no C/plugin API for this path;
+ * its boundary is Python (`smplify.smplify.SMPLify`, `smplify.body_fitting.BodyFitting`,
+ * `models.smpl.SMPL`).  This header is the native surface the build's Python mirror of those
+ * classes (bodyfitting_amd/smplify.py, smpl.py) binds through ctypes.  Each entry point names the
+ * reference code it replaces.
+ *
+ * Conventions: every function returns 0 on success and a negative bf_status otherwise;
+ * bf_last_error() gives the message for the calling thread.  All pointers are HOST pointers to
+ * caller-owned, C-contiguous buffers unless the name ends in `_dev`.  Device memory is owned by the
+ * library behind the opaque handles.  One handle is used by one host thread at a time.  Work is
+ * queued on the batch's own HIP stream; nothing blocks except bf_batch_sync and the getters.
+ * All floating point is fp32 (the reference's dtype); indices are int32.
+ */
+#ifndef BODYFIT_H
+#define BODYFIT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum bf_status {
+    BF_OK = 0,
+    BF_ERR_INVALID = -1,      /* bad argument / inconsistent sizes */
+    BF_ERR_HIP = -2,          /* a HIP runtime call failed (message has the hipError string) */
+    BF_ERR_UNSUPPORTED = -3,  /* size outside what the kernels were built for */
+    BF_ERR_NO_DEVICE = -4     /* no usable gfx950 device */
+} bf_status;
+
+typedef struct bf_model bf_model;   /* body model + GMM prior resident on one device */
+typedef struct bf_batch bf_batch;   /* F independent frames being fitted against one model */
+
+/*
+ * Body model tensors exactly as smplx==0.1.13 stores them and reference models/smpl.py:56-66 extends
+ * them, plus the buffers of MaxMixturePrior (reference smplify/prior.py:143-160).
+ */
+typedef struct bf_model_desc {
+    int32_t n_verts;               /* NV: 6890 (SMPL) */
+    int32_t n_joints;              /* NJ: 24 */
+    int32_t n_betas;               /* NB: 10 */
+    const float *v_template;       /* [NV,3] */
+    const float *shapedirs;        /* [NV,3,NB] */
+    const float *posedirs;         /* [9(NJ-1), 3NV]  row p = pose-feature element, col = 3v+k */
+    const float *j_regressor;      /* [NJ,NV] dense */
+    const float *lbs_weights;      /* [NV,NJ] dense */
+    const int32_t *parents;        /* [NJ], parents[0] = -1, parents[i] < i */
+    int32_t n_selector;            /* 21: VertexJointSelector vertex ids appended after the chain joints */
+    const int32_t *selector_ids;   /* [n_selector] */
+    int32_t n_extra;               /* 9: rows of J_regressor_extra (models/smpl.py:62-64,72) */
+    const float *j_regressor_extra;/* [n_extra,NV] dense */
+    int32_t n_joint_map;           /* 49: output joints = cat(chain, selector, extra)[joint_map] */
+    const int32_t *joint_map;      /* [n_joint_map] (models/smpl.py:61,75) */
+    int32_t n_loss_joints;         /* 25: SKELETON_LENGTH, the leading joints that enter the loss (loss.py:17,163) */
+    int32_t gmm_components;        /* 8 */
+    int32_t gmm_dim;               /* 69 */
+    const float *gmm_means;        /* [M,D] */
+    const float *gmm_precisions;   /* [M,D,D] = inv(covars) */
+    const float *gmm_nll_weights;  /* [M] (prior.py:153-160) */
+} bf_model_desc;
+
+/* Loss weights and optimiser constants; bf_hyper_default() fills the reference's literals. */
+typedef struct bf_hyper {
+    float sigma;               /* 100   loss.py:139 */
+    float pose_prior_weight;   /* 4.78  loss.py:141 */
+    float angle_prior_weight;  /* 15.2  loss.py:140 */
+    float shape_prior_weight;  /* 5     loss.py:140 */
+    float constant_scale;      /* 0.3   smplify.py:160 */
+    float imsize;              /* 512   scale_coeff = imsize/1024, loss.py:155 */
+    float lr;                  /* 1e-2  smplify.py:174 */
+    float lr_transl_scale;     /* 0.1   smplify.py:167-168 */
+    float adam_beta1;          /* 0.9 */
+    float adam_beta2;          /* 0.999 */
+    float adam_eps;            /* 1e-8 */
+} bf_hyper;
+
+/* bf_fit flags */
+#define BF_FIT_DEFAULT      0u
+#define BF_FIT_DENSE        1u   /* evaluate the full mesh every iteration, like the reference does
+                                    (smplify.py:179-190), instead of only the vertices that carry
+                                    gradient; same results, used for measurement */
+#define BF_FIT_NO_VERTICES  2u   /* skip the final full-mesh evaluation (parameters only) */
+
+const char *bf_last_error(void);
+const char *bf_version(void);
+int bf_device_count(void);
+void bf_hyper_default(bf_hyper *h);
+
+/* Replaces the per-frame model + prior construction of SMPLify.__init__ (smplify.py:46-56): the
+ * tensors are uploaded once per process, and the model-level tables of the fit are derived. */
+int bf_model_create(const bf_model_desc *desc, int device, bf_model **out);
+void bf_model_destroy(bf_model *m);
+/* number of optimised scalars per frame: 86 for SMPL, laid out in the reference's optimiser order
+ * (smplify.py:167-171): global_transl[3] body_scale[1] body_pose[69] betas[10] global_orient[3] */
+int bf_model_n_params(const bf_model *m);
+
+/* models.smpl.SMPL.forward (models/smpl.py:69-83) for `n` parameter sets:
+ * betas[n,NB], global_orient[n,3], body_pose[n,3(NJ-1)] ->
+ * vertices[n,NV,3], joints[n,n_joint_map,3], joints_ori[n,NJ+n_selector,3] (either output may be NULL) */
+int bf_smpl_forward(bf_model *m, int n, const float *betas, const float *global_orient,
+                    const float *body_pose, float *vertices, float *joints, float *joints_ori);
+
+/* One batch = F frames that SMPLify.__call__ (smplify.py:84-250) would process one after another
+ * (apps/genebody_fitting.py:183-192), each with V calibrated views. */
+int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out);
+void bf_batch_destroy(bf_batch *b);
+
+/* c2w[F,V,4,4], K[F,V,3,3]: what the caller passes as `c2ws`, `Ks` (smplify.py:84); inverted to
+ * world-to-camera here (smplify.py:131-135). */
+int bf_batch_set_cameras(bf_batch *b, const float *c2w, const float *K);
+/* keypoints[F,V,n_loss_joints,3] = (x, y, confidence): keypoints[i]['pose'] of loss.py:160.  A view
+ * without a detection (None, loss.py:157) is passed with all confidences 0.  n_use_frames[F] is the
+ * divisor len(use_frames) of loss.py:197 (NULL -> V). */
+int bf_batch_set_keypoints(bf_batch *b, const float *keypoints, const int32_t *n_use_frames);
+/* init_betas[F,NB], init_pose[F,3NJ] = net_output of smplify.py:103; transl=0, scale=1 (:126-128) */
+int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_pose);
+/* direct access to the packed optimised scalars [F,n_params] (for stage-level tests / warm starts) */
+int bf_batch_set_params(bf_batch *b, const float *params);
+int bf_batch_get_params(bf_batch *b, float *params);
+
+/* The optimisation loop smplify.py:177-213: n_iters Adam steps on every frame.  Asynchronous. */
+int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags);
+/* One evaluation of multiview_keypoint_loss (loss.py:139-230) and its gradient at the current
+ * parameters, no update: terms[F,4] = reprojection, pose_prior, angle_prior, shape_prior
+ * (loss.py:219-224); grads[F,n_params]. */
+int bf_loss_grad(bf_batch *b, const bf_hyper *hyper, float *terms, float *grads);
+int bf_batch_sync(bf_batch *b);
+
+/* rtn_dict of smplify.py:216-226 after bf_fit (any pointer may be NULL):
+ * vertices[F,NV,3], joints[F,n_joint_map,3], full_pose[F,3NJ] come from the LAST forward pass
+ * (parameters before the final step, as in the reference); the stepped parameters come from
+ * bf_batch_get_params.  loss_terms[F,4] are those of the last evaluated iteration. */
+int bf_batch_get_result(bf_batch *b, float *vertices, float *joints, float *full_pose, float *loss_terms);
+/* packed [F,n_params] stepped parameters copied into a DEVICE buffer (e.g. the send buffer of the
+ * final RCCL all-gather when frames are sharded over GPUs) */
+int bf_batch_export_params_dev(bf_batch *b, void *dst_dev);
+
+/* Device time of the kernels of the last bf_fit on this batch, from HIP events on the batch's
+ * stream: ms[0] = fit loop, ms[1] = final full-mesh forward, ms[2] = whole call. */
+int bf_batch_last_timing(bf_batch *b, float ms[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BODYFIT_H */

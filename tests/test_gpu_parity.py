@@ -1,0 +1,175 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the reference goldens.
+
+Tolerances: the north star asks for fitted beta / theta / transl within 1e-4 abs of the reference
+PyTorch CPU path after 100 iterations; stage-level quantities are held tighter (fp32 round-off).
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from bodyfitting_amd import synthetic as S
+from bodyfitting_amd import native as N
+from oracle import analytic as A
+from oracle import smplify_oracle as O
+
+pytestmark = pytest.mark.gpu
+PARAMS = ("global_transl", "scale", "pose", "betas", "global_orient")
+FIT_TOL = 1e-4
+
+
+def _batch(dev_model, problems):
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem(problems)
+    b = N.FrameBatch(dev_model, len(problems), c2w.shape[1])
+    b.set_cameras(c2w, K)
+    b.set_keypoints(kp, ndiv)
+    b.set_init(betas, pose)
+    return b
+
+
+def test_smpl_forward_matches_oracle(dev_model, smpl_model):
+    """models.smpl.SMPL.forward: vertices[6890,3], joints[49,3], joints_ori[45,3] (fp32 round-off)."""
+    rng = np.random.default_rng(3)
+    n = 3
+    betas = rng.normal(0, 0.7, (n, 10)).astype(np.float32)
+    orient = rng.normal(0, 0.8, (n, 3)).astype(np.float32)
+    pose = rng.normal(0, 0.3, (n, 69)).astype(np.float32)
+    pose[1] = 0.0
+    orient[1] = 0.0                      # identity pose: the Rodrigues singular point
+    verts, joints, jori = dev_model.forward(betas, orient, pose)
+    m = O.to_torch_model(smpl_model, torch.float64)
+    ref = O.smpl_forward(m, torch.tensor(betas, dtype=torch.float64), torch.tensor(orient, dtype=torch.float64),
+                         torch.tensor(pose, dtype=torch.float64))
+    np.testing.assert_allclose(verts, ref["vertices"].numpy(), atol=3e-6)
+    np.testing.assert_allclose(joints, ref["joints"].numpy(), atol=3e-6)
+    np.testing.assert_allclose(jori, ref["joints_ori"].numpy(), atol=3e-6)
+    # known answer: identity pose => v_template + S beta
+    shaped = smpl_model["v_template"] + smpl_model["shapedirs"] @ betas[1]
+    np.testing.assert_allclose(verts[1], shaped, atol=2e-6)
+
+
+def test_loss_terms_and_gradient(dev_model, smpl_model, gmm_bufs):
+    """bf_loss_grad vs the reference's loss dict / autograd gradient (golden) and the fp64 oracle."""
+    g = load_golden("loss_terms_f0.npz")
+    prob = S.make_problem(smpl_model, frame=0, n_views=48)
+    b = _batch(dev_model, [prob])
+    params = {k: g[f"param_{k}"] for k in PARAMS}
+    b.set_params(N.pack_params(params)[None])
+    terms, grads = b.loss_grad()
+    names = ("reprojection_loss", "pose_prior_loss", "angle_prior_loss", "shape_prior_loss")
+    for i, n in enumerate(names):
+        assert terms[0, i] == pytest.approx(float(g[f"term_{n}"]), rel=2e-6)
+    got = N.split_params(grads[0])
+    _, _, g64, _, _ = O.loss_and_grad(smpl_model, gmm_bufs, prob, {k: v.astype(np.float64) for k, v in params.items()})
+    for k in PARAMS:
+        scale = np.abs(g64[k]).max()
+        np.testing.assert_allclose(got[k], g64[k], atol=5e-6 * scale, err_msg=k)
+        np.testing.assert_allclose(got[k], g[f"grad_{k}"], atol=5e-6 * scale, err_msg=k)
+    b.close()
+
+
+def test_gradient_at_zero_pose(dev_model, smpl_model, gmm_bufs):
+    """theta = 0 sits on the Rodrigues singular point (angle = ||1e-8||)."""
+    prob = S.make_problem(smpl_model, frame=2, n_views=5, missing_views=(1, 3))
+    b = _batch(dev_model, [prob])
+    params = {"global_transl": np.array([0.02, -0.01, 0.03]), "scale": np.array([1.1]), "pose": np.zeros(69),
+              "betas": np.linspace(-0.5, 0.5, 10), "global_orient": np.zeros(3)}
+    b.set_params(N.pack_params(params)[None])
+    terms, grads = b.loss_grad()
+    loss, t64, g64, _, _ = O.loss_and_grad(smpl_model, gmm_bufs, prob, params)
+    assert float(terms.sum()) == pytest.approx(loss, rel=2e-6)
+    got = N.split_params(grads[0])
+    for k in PARAMS:
+        np.testing.assert_allclose(got[k], g64[k], atol=1e-5 * np.abs(g64[k]).max(), err_msg=k)
+    b.close()
+
+
+@pytest.mark.parametrize("frame", [0, 1, 2, 3])
+def test_cfg2_fit_matches_reference(dev_model, smpl_model, frame):
+    """BASELINE config 2 (1 frame, 48 views, 100 iters): fitted parameters vs the reference goldens."""
+    g = load_golden(f"cfg2_48view_100it_f{frame}.npz")
+    prob = S.make_problem(smpl_model, frame=frame, n_views=48)
+    b = _batch(dev_model, [prob])
+    done = 0
+    for k in (1, 2, 10, 50, 100):
+        b.fit(k - done)
+        done = k
+        got = N.split_params(b.get_params()[0])
+        for n in PARAMS:
+            np.testing.assert_allclose(got[n], g[f"it{k}_{n}"], rtol=0, atol=FIT_TOL, err_msg=f"it{k} {n}")
+    verts, joints, full_pose, terms = b.get_result()
+    np.testing.assert_allclose(joints[0], g["joints"], atol=FIT_TOL)
+    np.testing.assert_allclose(verts[0][::53], g["vertices_sample"], atol=FIT_TOL)
+    np.testing.assert_allclose(full_pose[0], g["full_pose"], atol=FIT_TOL)
+    p = N.split_params(b.get_params()[0])
+    np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=FIT_TOL)
+    b.close()
+
+
+def test_cfg1_one_view(dev_model, smpl_model):
+    g = load_golden("cfg1_1view_50it.npz")
+    prob = S.make_problem(smpl_model, frame=0, n_views=1)
+    b = _batch(dev_model, [prob])
+    b.fit(50)
+    got = N.split_params(b.get_params()[0])
+    for n in PARAMS:
+        np.testing.assert_allclose(got[n], g[f"it50_{n}"], rtol=0, atol=FIT_TOL, err_msg=n)
+    b.close()
+
+
+def test_ragged_views(dev_model, smpl_model):
+    """None keypoint views: skipped, but still counted in the divisor (loss.py:157,197)."""
+    g = load_golden("ragged_8view_20it.npz")
+    prob = S.make_problem(smpl_model, frame=5, n_views=8, missing_views=tuple(g["missing_views"]))
+    b = _batch(dev_model, [prob])
+    b.fit(20)
+    got = N.split_params(b.get_params()[0])
+    for n in PARAMS:
+        np.testing.assert_allclose(got[n], g[f"it20_{n}"], rtol=0, atol=FIT_TOL, err_msg=n)
+    b.close()
+
+
+def test_batch_frames_are_independent(dev_model, smpl_model):
+    """config 4 in miniature: a batch gives exactly what each frame gives alone, in any order."""
+    probs = [S.make_problem(smpl_model, frame=f, n_views=48) for f in (0, 1, 2, 3)]
+    b = _batch(dev_model, probs)
+    b.fit(100)
+    together = b.get_params()
+    b.close()
+    for i, f in enumerate((0, 1, 2, 3)):
+        g = load_golden(f"cfg2_48view_100it_f{f}.npz")
+        got = N.split_params(together[i])
+        for n in PARAMS:
+            np.testing.assert_allclose(got[n], g[f"it100_{n}"], rtol=0, atol=FIT_TOL)
+    b2 = _batch(dev_model, probs[::-1])
+    b2.fit(100)
+    np.testing.assert_array_equal(b2.get_params()[::-1], together)   # bit-identical: deterministic reductions
+    b2.close()
+
+
+def test_dense_schedule_gives_same_fit(dev_model, smpl_model):
+    """BF_FIT_DENSE evaluates the full mesh every iteration like the reference; same parameters."""
+    from bodyfitting_amd import _lib
+    prob = S.make_problem(smpl_model, frame=1, n_views=48)
+    a, b = _batch(dev_model, [prob]), _batch(dev_model, [prob])
+    a.fit(30)
+    b.fit(30, flags=_lib.FIT_DENSE)
+    np.testing.assert_array_equal(a.get_params(), b.get_params())
+    va, ja, _, _ = a.get_result()
+    vb, jb, _, _ = b.get_result()
+    np.testing.assert_array_equal(va, vb)
+    np.testing.assert_array_equal(ja, jb)
+    a.close()
+    b.close()
+
+
+def test_fit_is_resumable(dev_model, smpl_model):
+    """100 steps in one launch == 37 + 63 steps in two launches (Adam state carried in HBM)."""
+    prob = S.make_problem(smpl_model, frame=2, n_views=48)
+    a, b = _batch(dev_model, [prob]), _batch(dev_model, [prob])
+    a.fit(100)
+    b.fit(37)
+    b.fit(63)
+    np.testing.assert_array_equal(a.get_params(), b.get_params())
+    a.close()
+    b.close()
