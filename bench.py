@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""frames fitted / sec on synthetic 48-view SMPL (6890 v), 100 Adam iterations (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one complete fit of this rank's frames: re-arm the batch on the device, 100 iterations
+of reference smplify/smplify.py:177-213, the final full-mesh forward, the joints, and the copy of
+parameters / vertices / joints into pinned host memory (the rtn_dict of smplify.py:216-226).
+Inputs (cameras, keypoints, initial estimate, model) are already resident in HBM when the timed
+region starts.  N=1 default workload = BASELINE config 2 (1 frame per GPU per step); frames are
+independent, so for N>1 every rank fits its own frames (weak scaling, no data-path collective) and
+the packed parameters are all-gathered over RCCL once per step.
+
+PyTorch appears here only for torch.distributed (barrier, RCCL all-gather) and - in the clearly
+separated `cpu_baseline` leg - to execute the oracle; the measured path is numpy + ctypes + HIP.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from bodyfitting_amd import _lib, native as N, synthetic as S   # noqa: E402
+
+# algorithmic bytes per frame-iteration of the SMPL forward the reference
+# evaluates every iteration (posedirs + shapedirs + lbs_weights + J_regressor + J_regressor_extra +
+# v_template, each streamed once).
+BYTES_PER_FRAME_ITER = 17_114_760 + 826_800 + 661_440 + 661_440 + 248_040 + 82_680   # 19,595,160
+# what ONE launch of the full-mesh kernel must read + write per frame (no J_regressor: pre-contracted)
+BYTES_MESH_LAUNCH = 17_114_760 + 826_800 + 661_440 + 82_680 + 2 * 82_680
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--frames-per-gpu", type=int, default=1, help="1 = BASELINE config 2; 32 = config 4's per-GPU shard")
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--views", type=int, default=48)
+    ap.add_argument("--dense", action="store_true", help="full mesh every iteration (reference-literal schedule)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (dense schedule, batched shards)")
+    ap.add_argument("--cpu-frames", type=int, default=3)
+    return ap.parse_args()
+
+
+def build_batch(dev, model, frames, n_views):
+    probs = [S.make_problem(model, frame=f, n_views=n_views) for f in frames]
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem(probs)
+    b = N.FrameBatch(dev, len(frames), n_views)
+    b.set_cameras(c2w, K)
+    b.set_keypoints(kp, ndiv)
+    b.set_init(betas, pose)
+    return b, probs
+
+
+def run_steps(batch, steps, iters, flags, after_step=None):
+    for _ in range(steps):
+        batch.reset()
+        batch.fit(iters, flags=flags)
+        if after_step is not None:
+            after_step()
+    batch.sync()
+
+
+def timed_leg(batch, steps, warmup, iters, flags, barrier=lambda: None, after_step=None):
+    run_steps(batch, warmup, iters, flags, after_step)
+    batch.timing_reset()
+    barrier()
+    batch.sync()
+    t0 = time.perf_counter()
+    run_steps(batch, steps, iters, flags, after_step)
+    barrier()
+    t1 = time.perf_counter()
+    return t1 - t0, batch.timing_sum()
+
+
+def cpu_baseline(model, gmm, n_frames, n_views, iters):
+    """The oracle (torch-CPU restatement of the reference loop: same ops, autograd, Adam) timed on
+    this host; 1 thread, which is the faster setting for this dispatch-bound loop."""
+    import torch
+    from oracle import smplify_oracle as O
+    torch.set_num_threads(1)
+    gb = S.gmm_buffers(gmm)
+    probs = [S.make_problem(model, frame=f, n_views=n_views) for f in range(n_frames)]
+    O.fit(model, gb, probs[0], 2)                      # warm the allocator / op caches
+    t0 = time.perf_counter()
+    for p in probs:
+        O.fit(model, gb, p, iters)
+    dt = time.perf_counter() - t0
+    return {"value": n_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"{n_frames} frames x {n_views} views x {iters} iters, oracle/smplify_oracle.py (torch "
+                      f"{torch.__version__} CPU, autograd + Adam), {dt:.1f} s"}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes, or None."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    gather = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if a.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    model, gmm = S.make_model("smpl", seed=0), S.make_gmm(seed=0)
+    dev = N.DeviceModel(model, gmm, device=local)
+    F = a.frames_per_gpu
+    frames = list(range(rank * F, rank * F + F))          # distinct frames on every rank
+    batch, _ = build_batch(dev, model, frames, a.views)
+    flags = _lib.FIT_FETCH | (_lib.FIT_DENSE if a.dense else 0)
+
+    barrier = (lambda: None)
+    after = None
+    if world > 1:
+        import torch
+        send = torch.empty(F * dev.n_params, dtype=torch.float32, device=f"cuda:{local}")
+        recv = torch.empty(world * F * dev.n_params, dtype=torch.float32, device=f"cuda:{local}")
+
+        def barrier():
+            dist.barrier()
+            torch.cuda.synchronize()
+
+        def after():          # the one collective of the path: final gather of the fitted parameters
+            batch.export_params_dev(send.data_ptr())
+            dist.all_gather_into_tensor(recv, send)
+        gather = recv
+
+    wall, ev = timed_leg(batch, a.steps, a.warmup, a.iters, flags, barrier, after)
+    if world > 1:
+        import torch
+        torch.cuda.synchronize()
+        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+
+    # sanity: the timed path really produced a fit (and the gather really carried every rank's frames)
+    p = N.split_params(batch.get_params()[0])
+    assert np.isfinite(batch.get_params()).all() and abs(float(p["scale"][0]) - 1.0) > 1e-3
+    if gather is not None:
+        allp = gather.cpu().numpy().reshape(world, F, dev.n_params)
+        assert np.array_equal(allp[rank], batch.get_params())
+
+    total_frames = world * F * a.steps
+    value = total_frames / wall
+    fit_ms = ev["fit_ms"] / max(ev["calls"], 1)
+    mesh_ms = ev["mesh_ms"] / max(ev["calls"], 1)
+    traffic = pmc_traffic()
+    out = {
+        "metric": "frames fitted/sec (100 iters, 48 views, SMPL 6890v)",
+        "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (f"{F} frame(s) per GPU per step x {a.views} views x {a.iters} Adam iters, SMPL-shaped "
+                                f"synthetic model (6890 v, 24 joints), keypoint-only loss"
+                                + (" = BASELINE config 2" if F == 1 else "")
+                                + (" = BASELINE config 4 shard" if F == 32 else "")),
+                   "frames_per_gpu": F, "views": a.views, "iters": a.iters,
+                   "schedule": "dense (full mesh every iteration)" if a.dense else "sparse (gradient-carrying vertices only) + one final full mesh",
+                   "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of parameters per step" if world > 1 else "1 GPU"},
+        "roofline": {
+            "bound": "hbm", "kernel": "bf_fit_kernel" if not a.dense else "bf_fit_kernel+bf_mesh_kernel (per iteration)",
+            "achieved": BYTES_PER_FRAME_ITER * a.iters * F / (fit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": BYTES_PER_FRAME_ITER * a.iters * F / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": (traffic or {}).get("bf_fit_kernel_bytes_per_launch"),
+            "avg_launch_ms": fit_ms,
+            "algorithmic_bytes_per_launch": BYTES_PER_FRAME_ITER * a.iters * F,
+            "note": "nominal bytes = SURVEY 8(d) dense forward stream (19,595,160 B per frame-iteration) x iters x frames; "
+                    "the sparse kernel keeps its working set in LDS, see DESIGN.md",
+        },
+        "roofline_mesh": {
+            "bound": "hbm", "kernel": "bf_mesh_kernel", "achieved": BYTES_MESH_LAUNCH * F / (mesh_ms * 1e-3) / 1e9 if mesh_ms > 0 else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": BYTES_MESH_LAUNCH * F / (mesh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if mesh_ms > 0 else None,
+            "traffic": (traffic or {}).get("bf_mesh_kernel_bytes_per_launch"), "avg_launch_ms": mesh_ms,
+            "algorithmic_bytes_per_launch": BYTES_MESH_LAUNCH * F,
+        },
+        "device_ms_per_step": {k: ev[k] / max(ev["calls"], 1) for k in ("fit_ms", "mesh_ms", "tail_ms", "total_ms")},
+    }
+
+    if rank == 0 and world == 1 and not a.no_extra:
+        extra = {}
+        # the reference-literal schedule on the same workload
+        if not a.dense:
+            w, e = timed_leg(batch, max(4, a.steps // 5), 2, a.iters, _lib.FIT_FETCH | _lib.FIT_DENSE)
+            n = max(4, a.steps // 5)
+            extra["dense_schedule"] = {"value": F * n / w, "unit": "frames/s", "ms_per_step": w / n * 1e3,
+                                       "device_fit_ms": e["fit_ms"] / e["calls"]}
+        # config 4's per-GPU shard and a CU-filling batch: frames are independent workgroups
+        for fb in (32, 256, 1024):
+            if fb == F:
+                continue
+            bb, _ = build_batch(dev, model, list(range(fb)), a.views)
+            n = 10
+            w, e = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH)
+            extra[f"batch_{fb}_frames"] = {"value": fb * n / w, "unit": "frames/s", "ms_per_step": w / n * 1e3,
+                                           "device_fit_ms": e["fit_ms"] / e["calls"], "device_mesh_ms": e["mesh_ms"] / e["calls"]}
+            bb.close()
+        out["extra"] = extra
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(model, gmm, a.cpu_frames, a.views, a.iters)
+    batch.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,7 +35,7 @@ class Hyper(C.Structure):
         "imsize", "lr", "lr_transl_scale", "adam_beta1", "adam_beta2", "adam_eps")]
 
 
-FIT_DEFAULT, FIT_DENSE, FIT_NO_VERTICES = 0, 1, 2
+FIT_DEFAULT, FIT_DENSE, FIT_NO_VERTICES, FIT_FETCH = 0, 1, 2, 4
 
 # every entry point include/bodyfit.h declares: name -> (restype, argtypes)
 _FP = C.POINTER(C.c_float)
@@ -55,6 +55,7 @@ SIGNATURES = {
     "bf_batch_set_cameras": (C.c_int, [_VP, _FP, _FP]),
     "bf_batch_set_keypoints": (C.c_int, [_VP, _FP, _IP]),
     "bf_batch_set_init": (C.c_int, [_VP, _FP, _FP]),
+    "bf_batch_reset": (C.c_int, [_VP]),
     "bf_batch_set_params": (C.c_int, [_VP, _FP]),
     "bf_batch_get_params": (C.c_int, [_VP, _FP]),
     "bf_fit": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper), C.c_uint32]),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "bf_batch_get_result": (C.c_int, [_VP, _FP, _FP, _FP, _FP]),
     "bf_batch_export_params_dev": (C.c_int, [_VP, _VP]),
     "bf_batch_last_timing": (C.c_int, [_VP, _FP]),
+    "bf_batch_timing_reset": (C.c_int, [_VP]),
+    "bf_batch_timing_sum": (C.c_int, [_VP, _FP, _IP]),
 }
 
 _lib = None

@@ -67,8 +67,14 @@ struct bf_batch {
     bf_model *m = nullptr;
     int F = 0, V = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    static constexpr int kRing = 1024;
+    std::vector<hipEvent_t> ring;   // kRing x 4 events: | fit | mesh | joints + fetch |
+    int ring_n = 0;                 // calls recorded since the last timing reset
+    hipEvent_t *ev = nullptr;       // the triple of the last call
     bool timed = false;
+    DevBuf<float> params0;          // parameters of the last set_init / set_params
+    float *h_params = nullptr, *h_vout = nullptr, *h_joints = nullptr, *h_terms = nullptr, *h_state = nullptr;
+    bool fetched = false;
     int steps_done = 0;
     bf_hyper adam_hyper{};
     int adam_cap = 0;
@@ -270,11 +276,12 @@ void bf_model_destroy(bf_model *m) { delete m; }
 int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
 
 static int launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *joints,
-                       float *joints_ori, hipStream_t stream) {
+                       float *joints_ori, hipStream_t stream, hipEvent_t after_mesh = nullptr) {
     dim3 grid((m->nv + BF_MESH_TILE - 1) / BF_MESH_TILE, n);
     hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, m->mesh,
                        state_dev, vraw, vout);
     HIP_TRY(hipGetLastError());
+    if (after_mesh) HIP_TRY(hipEventRecord(after_mesh, stream));
     if (joints || joints_ori) {
         hipLaunchKernelGGL(bf_joints_kernel, dim3(n), dim3(256), 0, stream, m->mesh, state_dev, (const float *)vraw,
                            joints, joints_ori);
@@ -319,7 +326,15 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
     b->m = m; b->F = n_frames; b->V = n_views;
     const size_t F = n_frames, np = m->np;
     bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 3; ++i) ok = ok && hipEventCreate(&b->ev[i]) == hipSuccess;
+    b->ring.assign((size_t)bf_batch::kRing * 4, nullptr);
+    for (auto &e : b->ring) ok = ok && hipEventCreate(&e) == hipSuccess;
+    b->ev = b->ring.data();
+    ok = ok && b->params0.alloc(F * np) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&b->h_params, F * np * sizeof(float)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&b->h_vout, F * m->nv * 3 * sizeof(float)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&b->h_joints, F * m->n_joint_map * 3 * sizeof(float)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&b->h_terms, F * 4 * sizeof(float)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&b->h_state, F * bf_state_stride(m->nj, m->npf, m->nb) * sizeof(float)) == hipSuccess;
     ok = ok && b->proj.alloc(F * n_views * 12) == hipSuccess;
     ok = ok && b->keypoints.alloc(F * n_views * m->nl * 3) == hipSuccess;
     ok = ok && b->ndiv.upload(std::vector<int>(F, n_views)) == hipSuccess;
@@ -348,7 +363,8 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
 void bf_batch_destroy(bf_batch *b) {
     if (!b) return;
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    for (auto &e : b->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->ring) if (e) (void)hipEventDestroy(e);
+    for (float *h : {b->h_params, b->h_vout, b->h_joints, b->h_terms, b->h_state}) if (h) (void)hipHostFree(h);
     delete b;
 }
 
@@ -407,10 +423,24 @@ int bf_batch_set_keypoints(bf_batch *b, const float *keypoints, const int32_t *n
 }
 
 static int reset_adam(bf_batch *b) {
+    HIP_TRY(hipMemcpy(b->params0.p, b->params.p, b->params.n * sizeof(float), hipMemcpyDeviceToDevice));
     HIP_TRY(hipMemset(b->adam_m.p, 0, b->adam_m.n * sizeof(float)));
     HIP_TRY(hipMemset(b->adam_v.p, 0, b->adam_v.n * sizeof(float)));
     b->steps_done = 0;
     b->have_result = false;
+    b->fetched = false;
+    return BF_OK;
+}
+
+int bf_batch_reset(bf_batch *b) {
+    if (!b) return fail(BF_ERR_INVALID, "bf_batch_reset: null batch");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipMemcpyAsync(b->params.p, b->params0.p, b->params.n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    HIP_TRY(hipMemsetAsync(b->adam_m.p, 0, b->adam_m.n * sizeof(float), b->stream));
+    HIP_TRY(hipMemsetAsync(b->adam_v.p, 0, b->adam_v.n * sizeof(float), b->stream));
+    b->steps_done = 0;
+    b->have_result = false;
+    b->fetched = false;
     return BF_OK;
 }
 
@@ -444,7 +474,8 @@ int bf_batch_get_params(bf_batch *b, float *params) {
     if (!b || !params) return fail(BF_ERR_INVALID, "bf_batch_get_params: null argument");
     HIP_TRY(hipSetDevice(b->m->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
-    HIP_TRY(hipMemcpy(params, b->params.p, b->params.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (b->fetched) std::memcpy(params, b->h_params, b->params.n * sizeof(float));
+    else HIP_TRY(hipMemcpy(params, b->params.p, b->params.n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
 }
 
@@ -504,6 +535,7 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     HyperDev hd = to_dev(h);
     FrameIO io = frame_io(b, false);
     const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES);
+    b->ev = b->ring.data() + (size_t)(b->ring_n % bf_batch::kRing) * 4;
     HIP_TRY(hipEventRecord(b->ev[0], b->stream));
     if (!dense) {
         hipLaunchKernelGGL(bf_fit_kernel, dim3(b->F), dim3(BF_FIT_THREADS), m->fit_smem, b->stream, m->fit, io, hd,
@@ -511,9 +543,9 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(b->ev[1], b->stream));
         if (want_v) {
-            rc = launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->joints.p, nullptr, b->stream);
+            rc = launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->joints.p, nullptr, b->stream, b->ev[2]);
             if (rc) return rc;
-        }
+        } else HIP_TRY(hipEventRecord(b->ev[2], b->stream));
     } else {
         // reference-literal schedule: every iteration evaluates the whole mesh (smplify.py:179-190)
         for (int it = 0; it < n_iters; ++it) {
@@ -524,8 +556,22 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
             if (rc) return rc;
         }
         HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+        HIP_TRY(hipEventRecord(b->ev[2], b->stream));
     }
-    HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+    b->fetched = false;
+    if (flags & BF_FIT_FETCH) {
+        const size_t fb = sizeof(float);
+        HIP_TRY(hipMemcpyAsync(b->h_params, b->params.p, b->params.n * fb, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->h_terms, b->terms.p, b->terms.n * fb, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->h_state, b->state.p, b->state.n * fb, hipMemcpyDeviceToHost, b->stream));
+        if (want_v || dense) {
+            HIP_TRY(hipMemcpyAsync(b->h_vout, b->vout.p, b->vout.n * fb, hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->h_joints, b->joints.p, b->joints.n * fb, hipMemcpyDeviceToHost, b->stream));
+        }
+        b->fetched = true;
+    }
+    HIP_TRY(hipEventRecord(b->ev[3], b->stream));
+    b->ring_n += 1;
     b->steps_done += n_iters;
     b->timed = true;
     b->have_result = want_v || dense;
@@ -565,13 +611,20 @@ int bf_batch_get_result(bf_batch *b, float *vertices, float *joints, float *full
     HIP_TRY(hipStreamSynchronize(b->stream));
     if ((vertices || joints) && !b->have_result)
         return fail(BF_ERR_INVALID, "bf_batch_get_result: no mesh was evaluated (BF_FIT_NO_VERTICES or no bf_fit yet)");
-    if (vertices) HIP_TRY(hipMemcpy(vertices, b->vout.p, b->vout.n * sizeof(float), hipMemcpyDeviceToHost));
-    if (joints) HIP_TRY(hipMemcpy(joints, b->joints.p, b->joints.n * sizeof(float), hipMemcpyDeviceToHost));
-    if (loss_terms) HIP_TRY(hipMemcpy(loss_terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (b->fetched) {
+        if (vertices) std::memcpy(vertices, b->h_vout, b->vout.n * sizeof(float));
+        if (joints) std::memcpy(joints, b->h_joints, b->joints.n * sizeof(float));
+        if (loss_terms) std::memcpy(loss_terms, b->h_terms, b->terms.n * sizeof(float));
+    } else {
+        if (vertices) HIP_TRY(hipMemcpy(vertices, b->vout.p, b->vout.n * sizeof(float), hipMemcpyDeviceToHost));
+        if (joints) HIP_TRY(hipMemcpy(joints, b->joints.p, b->joints.n * sizeof(float), hipMemcpyDeviceToHost));
+        if (loss_terms) HIP_TRY(hipMemcpy(loss_terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));
+    }
     if (full_pose) {
         const size_t stride = bf_state_stride(m->nj, m->npf, m->nb);
         std::vector<float> st((size_t)b->F * stride);
-        HIP_TRY(hipMemcpy(st.data(), b->state.p, st.size() * sizeof(float), hipMemcpyDeviceToHost));
+        if (b->fetched) std::memcpy(st.data(), b->h_state, st.size() * sizeof(float));
+        else HIP_TRY(hipMemcpy(st.data(), b->state.p, st.size() * sizeof(float), hipMemcpyDeviceToHost));
         for (int f = 0; f < b->F; ++f) {
             StateView v = bf_state_view(st.data() + (size_t)f * stride, m->nj, m->npf, m->nb);
             std::memcpy(full_pose + (size_t)f * 3 * m->nj, v.theta, sizeof(float) * 3 * m->nj);
@@ -588,14 +641,41 @@ int bf_batch_export_params_dev(bf_batch *b, void *dst_dev) {
     return BF_OK;
 }
 
-int bf_batch_last_timing(bf_batch *b, float ms[3]) {
+int bf_batch_last_timing(bf_batch *b, float ms[4]) {
     if (!b || !ms) return fail(BF_ERR_INVALID, "bf_batch_last_timing: null argument");
     if (!b->timed) return fail(BF_ERR_INVALID, "bf_batch_last_timing: no bf_fit recorded yet");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipEventSynchronize(b->ev[2]));
+    HIP_TRY(hipEventSynchronize(b->ev[3]));
     HIP_TRY(hipEventElapsedTime(&ms[0], b->ev[0], b->ev[1]));
     HIP_TRY(hipEventElapsedTime(&ms[1], b->ev[1], b->ev[2]));
-    HIP_TRY(hipEventElapsedTime(&ms[2], b->ev[0], b->ev[2]));
+    HIP_TRY(hipEventElapsedTime(&ms[2], b->ev[2], b->ev[3]));
+    HIP_TRY(hipEventElapsedTime(&ms[3], b->ev[0], b->ev[3]));
+    return BF_OK;
+}
+
+int bf_batch_timing_reset(bf_batch *b) {
+    if (!b) return fail(BF_ERR_INVALID, "bf_batch_timing_reset: null batch");
+    b->ring_n = 0;
+    return BF_OK;
+}
+
+int bf_batch_timing_sum(bf_batch *b, float ms[4], int32_t *n_calls) {
+    if (!b || !ms || !n_calls) return fail(BF_ERR_INVALID, "bf_batch_timing_sum: null argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    int n = std::min(b->ring_n, (int)bf_batch::kRing);
+    double acc[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; ++i) {
+        hipEvent_t *e = b->ring.data() + (size_t)i * 4;
+        float t01, t12, t23, t03;
+        HIP_TRY(hipEventElapsedTime(&t01, e[0], e[1]));
+        HIP_TRY(hipEventElapsedTime(&t12, e[1], e[2]));
+        HIP_TRY(hipEventElapsedTime(&t23, e[2], e[3]));
+        HIP_TRY(hipEventElapsedTime(&t03, e[0], e[3]));
+        acc[0] += t01; acc[1] += t12; acc[2] += t23; acc[3] += t03;
+    }
+    for (int k = 0; k < 4; ++k) ms[k] = (float)acc[k];
+    *n_calls = n;
     return BF_OK;
 }
 

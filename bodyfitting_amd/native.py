@@ -136,6 +136,10 @@ class FrameBatch:
         p = _f32(init_pose, (self.F, 3 * self.model.n_joints))
         _lib.check(self._lib.bf_batch_set_init(self._h, _lib.fptr(b), _lib.fptr(p)), "bf_batch_set_init")
 
+    def reset(self):
+        """re-arm for another fit of the same inputs (stream-ordered, no host traffic)"""
+        _lib.check(self._lib.bf_batch_reset(self._h), "bf_batch_reset")
+
     def set_params(self, params):
         p = _f32(params, (self.F, self.model.n_params))
         _lib.check(self._lib.bf_batch_set_params(self._h, _lib.fptr(p)), "bf_batch_set_params")
@@ -175,9 +179,19 @@ class FrameBatch:
         _lib.check(self._lib.bf_batch_export_params_dev(self._h, C.c_void_p(int(dev_ptr))), "bf_batch_export_params_dev")
 
     def last_timing(self):
-        ms = np.zeros(3, np.float32)
+        ms = np.zeros(4, np.float32)
         _lib.check(self._lib.bf_batch_last_timing(self._h, _lib.fptr(ms)), "bf_batch_last_timing")
-        return {"fit_ms": float(ms[0]), "mesh_ms": float(ms[1]), "total_ms": float(ms[2])}
+        return {"fit_ms": float(ms[0]), "mesh_ms": float(ms[1]), "tail_ms": float(ms[2]), "total_ms": float(ms[3])}
+
+    def timing_reset(self):
+        _lib.check(self._lib.bf_batch_timing_reset(self._h), "bf_batch_timing_reset")
+
+    def timing_sum(self):
+        ms = np.zeros(4, np.float32)
+        n = C.c_int32(0)
+        _lib.check(self._lib.bf_batch_timing_sum(self._h, _lib.fptr(ms), C.byref(n)), "bf_batch_timing_sum")
+        return {"fit_ms": float(ms[0]), "mesh_ms": float(ms[1]), "tail_ms": float(ms[2]), "total_ms": float(ms[3]),
+                "calls": int(n.value)}
 
     def debug_dump(self, n):
         out = np.zeros(n, np.float32)

@@ -83,6 +83,9 @@ typedef struct bf_hyper {
                                     (smplify.py:179-190), instead of only the vertices that carry
                                     gradient; same results, used for measurement */
 #define BF_FIT_NO_VERTICES  2u   /* skip the final full-mesh evaluation (parameters only) */
+#define BF_FIT_FETCH        4u   /* queue the device->host copies of the result into the batch's pinned
+                                    staging buffers behind the kernels (bf_batch_get_result then only
+                                    waits for them) */
 
 const char *bf_last_error(void);
 const char *bf_version(void);
@@ -117,6 +120,10 @@ int bf_batch_set_cameras(bf_batch *b, const float *c2w, const float *K);
 int bf_batch_set_keypoints(bf_batch *b, const float *keypoints, const int32_t *n_use_frames);
 /* init_betas[F,NB], init_pose[F,3NJ] = net_output of smplify.py:103; transl=0, scale=1 (:126-128) */
 int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_pose);
+/* Re-arm the batch for another fit of the same inputs without touching the host: restores the
+ * parameters of the last bf_batch_set_init / bf_batch_set_params and clears the Adam state, as
+ * stream-ordered device copies.  (The reference rebuilds everything per frame, body_fitting.py:82.) */
+int bf_batch_reset(bf_batch *b);
 /* direct access to the packed optimised scalars [F,n_params] (for stage-level tests / warm starts) */
 int bf_batch_set_params(bf_batch *b, const float *params);
 int bf_batch_get_params(bf_batch *b, float *params);
@@ -139,8 +146,13 @@ int bf_batch_get_result(bf_batch *b, float *vertices, float *joints, float *full
 int bf_batch_export_params_dev(bf_batch *b, void *dst_dev);
 
 /* Device time of the kernels of the last bf_fit on this batch, from HIP events on the batch's
- * stream: ms[0] = fit loop, ms[1] = final full-mesh forward, ms[2] = whole call. */
-int bf_batch_last_timing(bf_batch *b, float ms[3]);
+ * stream: ms[0] = fit loop kernel(s), ms[1] = final full-mesh forward kernel, ms[2] = joints kernel +
+ * result fetch, ms[3] = whole call.  (With BF_FIT_DENSE every iteration's mesh pass is inside ms[0].) */
+int bf_batch_last_timing(bf_batch *b, float ms[4]);
+/* The same, summed over every bf_fit since bf_batch_timing_reset (at most 1024 calls are kept);
+ * *n_calls receives how many were summed. */
+int bf_batch_timing_reset(bf_batch *b);
+int bf_batch_timing_sum(bf_batch *b, float ms[4], int32_t *n_calls);
 
 #ifdef __cplusplus
 }
