@@ -1,0 +1,80 @@
+"""Where body models and the GMM prior come from.
+
+The reference reads `data/smpl/*.pkl` through smplx, `data/J_regressor_extra.npy` and
+`data/gmm_08.pkl` relative to the working directory (config.py:1-6, smplify/prior.py:124-128), once
+per *frame*.  Here a model is resolved once per process and cached per (type, gender, device):
+
+  1. a dict registered with `register_model(...)` (tests, synthetic benchmarks),
+  2. an `.npz` with the smplx tensor names under `data/` (`{type}_{gender}.npz`),
+  3. otherwise a clear error - nothing is downloaded and nothing is silently replaced.
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+
+_MODELS = {}
+_GMM = {}
+_DEVICE_MODELS = {}
+
+
+def register_model(model, model_type="smpl", gender="neutral"):
+    _MODELS[(model_type, gender)] = model
+    for k in [k for k in _DEVICE_MODELS if k[:2] == (model_type, gender)]:
+        _DEVICE_MODELS.pop(k).close()
+
+
+def register_gmm(gmm):
+    _GMM["gmm"] = gmm
+    for k in list(_DEVICE_MODELS):
+        _DEVICE_MODELS.pop(k).close()
+
+
+def _load_npz_model(model_type, gender, folder="data"):
+    for name in (f"{model_type}_{gender}.npz", f"{model_type}/{model_type.upper()}_{gender.upper()}.npz"):
+        path = os.path.join(folder, name)
+        if os.path.exists(path):
+            z = np.load(path, allow_pickle=True)
+            model = {k: z[k] for k in z.files}
+            model.setdefault("model_type", model_type)
+            extra = os.path.join(folder, "J_regressor_extra.npy")       # config.py:1
+            if "J_regressor_extra" not in model and os.path.exists(extra):
+                model["J_regressor_extra"] = np.load(extra)
+            return model
+    return None
+
+
+def get_model(model_type="smpl", gender="neutral"):
+    for key in ((model_type, gender), (model_type, "neutral")):
+        if key in _MODELS:
+            return _MODELS[key]
+    model = _load_npz_model(model_type, gender)
+    if model is None:
+        raise FileNotFoundError(
+            f"no {model_type}/{gender} body model: register one with bodyfitting_amd.assets.register_model() "
+            f"or place data/{model_type}_{gender}.npz (smplx tensor names) next to the working directory")
+    _MODELS[(model_type, gender)] = model
+    return model
+
+
+def get_gmm(prior_folder="data", num_gaussians=8):
+    if "gmm" in _GMM:
+        return _GMM["gmm"]
+    path = os.path.join(prior_folder, "gmm_{:02d}.pkl".format(num_gaussians))    # prior.py:122-124
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"GMM prior {path!r} not found and none registered (assets.register_gmm)")
+    with open(path, "rb") as f:
+        gmm = pickle.load(f, encoding="latin1")
+    _GMM["gmm"] = {k: np.asarray(gmm[k]) for k in ("means", "covars", "weights")}
+    return _GMM["gmm"]
+
+
+def get_device_model(model_type="smpl", gender="neutral", device=0):
+    """The HIP-resident model, created once per (type, gender, device)."""
+    from .native import DeviceModel
+    key = (model_type, gender, int(device))
+    if key not in _DEVICE_MODELS:
+        _DEVICE_MODELS[key] = DeviceModel(get_model(model_type, gender), get_gmm(), device=device)
+    return _DEVICE_MODELS[key]

@@ -1,0 +1,51 @@
+"""File formats on either side of the loop, without cv2 / imageio / torch."""
+from __future__ import annotations
+
+import json
+import re
+
+import numpy as np
+
+
+def save_obj_mesh(mesh_path, verts, faces):
+    """utils/io_utils.py:185-192: `v %.4f %.4f %.4f`, 1-based `f %d %d %d`."""
+    with open(mesh_path, "w") as f:
+        for v in verts:
+            f.write("v %.4f %.4f %.4f\n" % (v[0], v[1], v[2]))
+        for tri in faces:
+            f.write("f %d %d %d\n" % (tri[0] + 1, tri[1] + 1, tri[2] + 1))
+
+
+def load_openpose(json_name, only_one=True):
+    """OpenPose JSON -> {'pose': [25,3], 'hand_left': [21,3], 'hand_right': [21,3], 'face': [70,3]} of
+    the highest-scoring person, or None (behaviour of utils/io_utils.py:138-183 for 2-D keypoints)."""
+    with open(json_name, "r") as fid:
+        d = json.load(fid)
+    people = d.get("people", [])
+    if not people:
+        return None
+    parsed = []
+    for person in people:
+        entry = {}
+        for key, val in person.items():
+            if "keypoints" not in key:
+                continue
+            p = np.asarray(val, dtype=np.float64).reshape(-1)
+            if p.size == 0:
+                continue
+            dim = re.findall("([2-9]d)", key)
+            dim = 2 if not dim else int(dim[-1][0])
+            if p.size % (dim + 1) != 0:
+                continue
+            p = p.reshape(-1, dim + 1)
+            if np.abs(p[:, -1]).max() <= 0:
+                continue
+            entry[key.replace("_keypoints", "").replace("_%dd" % dim, "")] = p
+        parsed.append(entry)
+    parsed = [e for e in parsed if e]
+    if not parsed:
+        return None
+    if not only_one:
+        return parsed
+    scores = [sum(p[:, -1].sum() for p in e.values()) for e in parsed]
+    return parsed[int(np.argmax(scores))]

@@ -1,0 +1,109 @@
+"""`smplify.smplify.SMPLify` of the reference (smplify/smplify.py:18-254) on the HIP path.
+
+Same constructor arguments, same `__call__` signature, same result dict (numpy arrays, batch
+dimension squeezed): vertices[NV,3], joints[49,3], pose[69], betas[10], global_orient[3], faces,
+global_transl[3] (= t*s, without the constant scale), scale[1], full_pose[72].
+
+Differences, all at the edges: the model / GMM are resolved once per process through
+`bodyfitting_amd.assets` instead of being re-read per frame; `net_output` may hold numpy arrays or
+anything with `.detach().cpu().numpy()`; `device` is a HIP device index (or a torch.device whose
+index is used).  Options whose kernels are not built yet (use_mask, use_mesh, displacement, smplx)
+raise NotImplementedError - there is no silent CPU path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import assets
+from .native import FrameBatch, make_hyper, split_params, N_LOSS_JOINTS
+
+
+def _np(x):
+    if hasattr(x, "detach"):
+        x = x.detach().cpu().numpy()
+    return np.asarray(x)
+
+
+def _device_index(device):
+    if device is None:
+        return 0
+    if isinstance(device, int):
+        return device
+    idx = getattr(device, "index", None)
+    return 0 if idx is None else int(idx)
+
+
+class SMPLify:
+    """Multi-view SMPLify.  One instance can fit any number of frames (`fit_frames`)."""
+
+    def __init__(self, smpl_type="smpl", age="adult", step_size=1e-2, batch_size=1, num_iters=600, gender="male",
+                 use_mask=False, device=0, debug=True):
+        if smpl_type != "smpl":
+            raise NotImplementedError("smpl_type='smplx' is not built yet (DESIGN.md section 7)")
+        if age != "adult":
+            raise NotImplementedError("age='kid' is out of scope (SURVEY.md 8c)")
+        self.smpl_type, self.age, self.gender = smpl_type, age, gender
+        self.use_hand_face = False
+        self.use_mask = use_mask
+        self.batch_size = batch_size
+        self.num_iters = num_iters          # step_size is ignored by the reference too (smplify.py:24,174)
+        self.debug = debug
+        self.device = _device_index(device)
+        self._dev = assets.get_device_model("smpl", gender, self.device)
+        model = assets.get_model("smpl", gender)
+        self.smpl_faces = np.asarray(model["faces"]).astype(np.int32).reshape(1, -1, 3)    # smplify.py:82
+
+    # ------------------------------------------------------------------------------------------
+    def fit_frames(self, init_betas, init_poses, c2ws, Ks, keypoints, n_use_frames=None, imsize=512,
+                   constant_scale=0.3, num_iters=None, flags=0):
+        """Fit F independent frames in one launch.
+
+        init_betas[F,10], init_poses[F,72], c2ws[F,V,4,4], Ks[F,V,3,3], keypoints[F,V,25,3]
+        (confidence 0 = no detection).  Returns a list of F result dicts."""
+        init_betas = np.asarray(init_betas, np.float32).reshape(-1, self._dev.n_betas)
+        F = init_betas.shape[0]
+        c2ws = np.asarray(c2ws, np.float32).reshape(F, -1, 4, 4)
+        V = c2ws.shape[1]
+        batch = FrameBatch(self._dev, F, V)
+        try:
+            batch.set_cameras(c2ws, Ks)
+            batch.set_keypoints(keypoints, n_use_frames)
+            batch.set_init(init_betas, init_poses)
+            hyper = make_hyper(imsize=imsize, constant_scale=constant_scale)
+            batch.fit(self.num_iters if num_iters is None else num_iters, hyper, flags | 4)
+            params = batch.get_params()
+            verts, joints, full_pose, terms = batch.get_result()
+        finally:
+            batch.close()
+        out = []
+        for f in range(F):
+            p = split_params(params[f], self._dev.n_joints, self._dev.n_betas)
+            out.append({
+                "vertices": verts[f], "joints": joints[f], "pose": p["pose"].copy(), "betas": p["betas"].copy(),
+                "global_orient": p["global_orient"].copy(), "faces": self.smpl_faces[0],
+                "global_transl": p["global_transl"] * p["scale"],                      # smplify.py:223
+                "scale": p["scale"].copy(), "full_pose": full_pose[f],
+                "loss_terms": dict(zip(("reprojection_loss", "pose_prior_loss", "angle_prior_loss", "shape_prior_loss"),
+                                       (float(t) for t in terms[f]))),
+            })
+        return out
+
+    def __call__(self, net_output, c2ws, Ks, keypoints, output_folder=None, use_mask=False, masks=None,
+                 use_frames=[0], mask_frames=[0], keyframe=6, imsize=512, use_mesh=False, meshfile=None,
+                 displacement=False):
+        if use_mask:
+            raise NotImplementedError("the silhouette loss (loss.py:85-130) is not built yet")
+        if use_mesh or displacement:
+            raise NotImplementedError("the scan closest-point loss / SMPL+D stage (smplify.py:146-156,228-247) is not built yet")
+        init_betas, init_poses = (_np(x) for x in net_output)
+        V = len(use_frames)
+        c2w = np.stack([_np(c) for c in c2ws[:V]]).astype(np.float32)
+        K = np.stack([_np(k) for k in Ks[:V]]).astype(np.float32)
+        kp = np.zeros((V, N_LOSS_JOINTS, 3), np.float32)
+        for i in range(V):
+            if keypoints[i] is not None:                                               # loss.py:157
+                kp[i] = np.asarray(keypoints[i]["pose"], np.float32)[:N_LOSS_JOINTS]
+        res = self.fit_frames(init_betas[:1], init_poses[:1], c2w[None], K[None], kp[None],
+                              n_use_frames=[V], imsize=imsize)[0]                      # divisor loss.py:197
+        res.pop("loss_terms")
+        return res

@@ -1,0 +1,70 @@
+"""The Python mirror of the reference interface: names, signatures, file outputs (no GPU needed)."""
+import inspect
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from bodyfitting_amd import io
+from bodyfitting_amd.body_fitting import BodyFitting
+from bodyfitting_amd.smplify import SMPLify
+from bodyfitting_amd.smpl import SMPL, ModelOutput
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_signatures_match_the_reference():
+    # reference smplify/smplify.py:21-31,84-86
+    assert list(inspect.signature(SMPLify.__init__).parameters)[1:] == [
+        "smpl_type", "age", "step_size", "batch_size", "num_iters", "gender", "use_mask", "device", "debug"]
+    assert list(inspect.signature(SMPLify.__call__).parameters)[1:] == [
+        "net_output", "c2ws", "Ks", "keypoints", "output_folder", "use_mask", "masks", "use_frames", "mask_frames",
+        "keyframe", "imsize", "use_mesh", "meshfile", "displacement"]
+    # reference smplify/body_fitting.py:78-80 (+ net_output, replacing the out-of-scope HMR)
+    assert list(inspect.signature(BodyFitting.__call__).parameters)[1:16] == [
+        "images", "c2ws", "Ks", "keypoints", "gender", "keyframe", "use_frames", "use_mask", "masks", "mask_frames",
+        "render_skip", "output_folder", "use_mesh", "meshfile", "disp"]
+    assert {"vertices", "joints", "full_pose", "betas", "global_orient", "body_pose", "joints_ori"} <= set(
+        ModelOutput.__dataclass_fields__)
+    assert ModelOutput(betas=np.zeros(3))["betas"].shape == (3,)
+
+
+def test_dropin_import_lines():
+    sys.path.insert(0, os.path.join(REPO, "bodyfitting_amd", "dropin"))
+    try:
+        for mod in ("smplify", "models"):
+            sys.modules.pop(mod, None)
+        from smplify.body_fitting import BodyFitting as B      # apps/genebody_fitting.py:9
+        from smplify.smplify import SMPLify as S2
+        from models.smpl import SMPL as M
+        assert B is BodyFitting and S2 is SMPLify and M is SMPL
+    finally:
+        sys.path.pop(0)
+        for mod in [m for m in sys.modules if m.split(".")[0] in ("smplify", "models")]:
+            sys.modules.pop(mod)
+
+
+def test_obj_writer_format(tmp_path):
+    verts = np.array([[0.123456, -1.0, 2.5], [1, 2, 3]], dtype=np.float32)
+    faces = np.array([[0, 1, 0]], dtype=np.int32)
+    p = tmp_path / "m.obj"
+    io.save_obj_mesh(str(p), verts, faces)
+    assert p.read_text() == "v 0.1235 -1.0000 2.5000\nv 1.0000 2.0000 3.0000\nf 1 2 1\n"
+
+
+def test_openpose_reader(tmp_path):
+    pose = np.random.default_rng(0).uniform(1, 500, (25, 3))
+    weak = pose.copy()
+    weak[:, 2] *= 0.1
+    doc = {"version": 1.3, "people": [{"person_id": [-1], "pose_keypoints_2d": weak.reshape(-1).tolist()},
+                                      {"person_id": [-1], "pose_keypoints_2d": pose.reshape(-1).tolist(),
+                                       "hand_left_keypoints_2d": [0.0] * 63, "face_keypoints_2d": []}]}
+    p = tmp_path / "kp.json"
+    p.write_text(json.dumps(doc))
+    got = io.load_openpose(str(p))
+    assert set(got) == {"pose"}                    # all-zero / empty blocks are dropped
+    np.testing.assert_allclose(got["pose"], pose)  # the higher-scoring person wins
+    p.write_text(json.dumps({"people": []}))
+    assert io.load_openpose(str(p)) is None
