@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbodyfit.so")
+# BODYFIT_LIB selects a diagnostic build (e.g. libbodyfit_stamp.so) for bring-up tools; never a different backend
+LIB_PATH = os.environ.get("BODYFIT_LIB") or os.path.join(_HERE, "libbodyfit.so")
 
 
 class BodyfitError(RuntimeError):

@@ -9,11 +9,11 @@
 #include <string>
 #include <vector>
 
-extern "C" __global__ void bf_fit_kernel(FitTab, FrameIO, HyperDev, int, int, const float *, int);
+extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *);
 extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *);
 extern "C" __global__ void bf_joints_kernel(MeshTab, const float *, const float *, float *, float *);
-extern "C" size_t bf_fit_smem_bytes(int, int, int, int, int, int, int, int);
+extern "C" size_t bf_fit_smem_bytes(int, int, int, int, int, int, int);
 extern "C" size_t bf_mesh_smem_bytes(int, int, int);
 
 namespace {
@@ -59,6 +59,9 @@ struct bf_model {
     size_t fit_smem = 0, mesh_smem = 0;
     DevBuf<float> v_template, shapedirs, posedirs, lbs_weights, j_extra;
     DevBuf<int> selector_ids, joint_map;
+    DevBuf<int> depth_d;
+    DevBuf<unsigned long long> desc_d;
+    DevBuf<float> g_plane, g_ptail;
     DevBuf<int> parents, level_start, level_joints, child_start, child_list, lj_kind, lj_index;
     DevBuf<float> Jt, Jd, Jdrel, sel_vt, sel_sd, sel_pd, sel_w, g_means, g_psym, g_logw;
 };
@@ -229,6 +232,21 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         logw[c] = (float)(-std::log((double)d->gmm_nll_weights[c]));
     }
 
+    // lane-major register images of Psym for the fit kernel (coalesced one-off load)
+    std::vector<float> plane((size_t)M * BF_GMM_LD * 64, 0.f), ptail((size_t)4 * 12 * 64, 0.f);
+    for (int c = 0; c < M; ++c)
+        for (int j = 0; j < D; ++j)
+            for (int l = 0; l < 64; ++l) plane[((size_t)c * BF_GMM_LD + j) * 64 + l] = psym[((size_t)c * D + l) * D + j];
+    for (int w = 0; w < 4; ++w)
+        for (int l = 0; l < 60; ++l) {
+            int comp = l < 30 ? 2 * w : 2 * w + 1, row = 64 + (l % 30) / 6, col = 12 * (l % 6);
+            for (int e = 0; e < 12; ++e)
+                if (col + e < D) ptail[((size_t)w * 12 + e) * 64 + l] = psym[((size_t)comp * D + row) * D + col + e];
+        }
+    int max_children = 0;
+    for (int p = 0; p < nj; ++p) max_children = std::max(max_children, child_start[p + 1] - child_start[p]);
+    if (max_children > 6) { delete m; return fail(BF_ERR_UNSUPPORTED, "bf_model_create: a joint has more than 6 children"); }
+
     bool okay = true;
     auto up_f = [&](DevBuf<float> &b, const float *src, size_t n) {
         std::vector<float> h(src, src + n);
@@ -243,6 +261,12 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     up_f(m->j_extra, d->j_regressor_extra, (size_t)d->n_extra * nv);
     up_vi(m->selector_ids, std::vector<int>(d->selector_ids, d->selector_ids + d->n_selector));
     up_vi(m->joint_map, std::vector<int>(d->joint_map, d->joint_map + d->n_joint_map));
+    {
+        std::vector<unsigned long long> desc(nj, 0ull);
+        for (int j = nj - 1; j >= 1; --j) desc[parents[j]] |= desc[j] | (1ull << j);
+        okay = okay && m->desc_d.upload(desc) == hipSuccess;
+    }
+    up_vi(m->depth_d, depth); up_vf(m->g_plane, plane); up_vf(m->g_ptail, ptail);
     up_vi(m->parents, parents); up_vi(m->level_start, level_start); up_vi(m->level_joints, level_joints);
     up_vi(m->child_start, child_start); up_vi(m->child_list, child_list);
     up_vi(m->lj_kind, lj_kind); up_vi(m->lj_index, lj_index);
@@ -255,6 +279,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     T.nj = nj; T.nb = nb; T.npf = npf; T.ns = ns; T.nl = m->nl; T.np = m->np; T.n_levels = n_levels;
     T.nbp = 3 * (nj - 1);
     T.off_pose = 4; T.off_beta = 4 + 3 * (nj - 1); T.off_orient = T.off_beta + nb;
+    T.depth = m->depth_d.p; T.desc = m->desc_d.p; T.g_plane = m->g_plane.p; T.g_ptail = m->g_ptail.p;
     T.parents = m->parents.p; T.level_start = m->level_start.p; T.level_joints = m->level_joints.p;
     T.child_start = m->child_start.p; T.child_list = m->child_list.p;
     T.lj_kind = m->lj_kind.p; T.lj_index = m->lj_index.p;
@@ -320,7 +345,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
     if (!m || !out || n_frames <= 0 || n_views <= 0) return fail(BF_ERR_INVALID, "bf_batch_create: bad argument");
     *out = nullptr;
     HIP_TRY(hipSetDevice(m->device));
-    size_t smem = bf_fit_smem_bytes(m->nj, m->nb, m->npf, m->ns, m->nl, m->np, n_views, m->n_levels);
+    size_t smem = bf_fit_smem_bytes(m->nj, m->nb, m->npf, m->ns, m->nl, m->np, n_views);
     if (smem > 160 * 1024) return fail(BF_ERR_UNSUPPORTED, "bf_batch_create: too many views for one workgroup's LDS");
     auto *b = new bf_batch();
     b->m = m; b->F = n_frames; b->V = n_views;
@@ -352,8 +377,6 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
              hipMemset(b->keypoints.p, 0, b->keypoints.n * sizeof(float)) == hipSuccess &&
              hipMemset(b->debug.p, 0, 8192 * sizeof(float)) == hipSuccess;
     }
-    if (ok && smem > 64 * 1024)
-        ok = hipFuncSetAttribute((const void *)bf_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess;
     if (!ok) { bf_batch_destroy(b); return fail(BF_ERR_HIP, "bf_batch_create: device allocation failed"); }
     m->fit_smem = smem;
     *out = b;
@@ -538,9 +561,7 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     b->ev = b->ring.data() + (size_t)(b->ring_n % bf_batch::kRing) * 4;
     HIP_TRY(hipEventRecord(b->ev[0], b->stream));
     if (!dense) {
-        hipLaunchKernelGGL(bf_fit_kernel, dim3(b->F), dim3(BF_FIT_THREADS), m->fit_smem, b->stream, m->fit, io, hd,
-                           n_iters, 0, (const float *)b->adam_tab.p, b->steps_done);
-        HIP_TRY(hipGetLastError());
+        HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_iters, 0, b->adam_tab.p, b->steps_done, m->fit_smem, b->stream));
         HIP_TRY(hipEventRecord(b->ev[1], b->stream));
         if (want_v) {
             rc = launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->joints.p, nullptr, b->stream, b->ev[2]);
@@ -549,9 +570,7 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     } else {
         // reference-literal schedule: every iteration evaluates the whole mesh (smplify.py:179-190)
         for (int it = 0; it < n_iters; ++it) {
-            hipLaunchKernelGGL(bf_fit_kernel, dim3(b->F), dim3(BF_FIT_THREADS), m->fit_smem, b->stream, m->fit, io, hd,
-                               1, 0, (const float *)b->adam_tab.p, b->steps_done + it);
-            HIP_TRY(hipGetLastError());
+            HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
             rc = launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->joints.p, nullptr, b->stream);
             if (rc) return rc;
         }
@@ -588,9 +607,7 @@ int bf_loss_grad(bf_batch *b, const bf_hyper *hyper, float *terms, float *grads)
     if (rc) return rc;
     HyperDev hd = to_dev(h);
     FrameIO io = frame_io(b, true);
-    hipLaunchKernelGGL(bf_fit_kernel, dim3(b->F), dim3(BF_FIT_THREADS), m->fit_smem, b->stream, m->fit, io, hd, 1, 1,
-                       (const float *)b->adam_tab.p, 0);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, m->fit_smem, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (terms) HIP_TRY(hipMemcpy(terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));
     if (grads) HIP_TRY(hipMemcpy(grads, b->grads.p, b->grads.n * sizeof(float), hipMemcpyDeviceToHost));

@@ -6,9 +6,9 @@
 #define BF_GMM_M 8          // reference hard-codes num_gaussians=8 (smplify/smplify.py:47)
 #define BF_GMM_D 69         // and a 69-dof body pose (smplify/prior.py:154)
 #define BF_GMM_LD 72        // padded row length of the d / y vectors in LDS
-#define BF_FIT_THREADS 256  // one workgroup (4 wave64) per frame
-#define BF_VSUB 8           // view sub-slots in the projection phase (256 / 32)
-#define BF_KP_ROUNDS 6      // keypoints cached in registers for V <= 8*6 = 48 views
+#define BF_FIT_THREADS 512  // one workgroup (8 wave64, two per SIMD) per frame
+#define BF_VSUB 16          // view sub-slots in the projection phase (512 / 32)
+#define BF_KP_ROUNDS 3      // keypoints cached in registers for V <= 16*3 = 48 views
 #define BF_MESH_TILE 32     // vertices per workgroup of the full-mesh forward
 #define BF_MESH_RG 8        // pose-feature row groups per workgroup (split-K inside the workgroup)
 
@@ -19,6 +19,8 @@ struct FitTab {
     int nbp;                         // optimised body-pose dofs (69 SMPL); the GMM sees them zero-padded to 69
     int off_pose, off_beta, off_orient;
     const int *parents;              // [nj]
+    const int *depth;                // [nj]
+    const unsigned long long *desc;  // [nj] bit k set = joint k is a strict descendant
     const int *level_start;          // [n_levels+1]  joints sorted by depth
     const int *level_joints;         // [nj]
     const int *child_start;          // [nj+1]        CSR children lists
@@ -35,6 +37,8 @@ struct FitTab {
     const float *g_means;            // [M][D]
     const float *g_psym;             // [M][D][D]     0.5 (P + P^T)
     const float *g_logw;             // [M]           -log(nll_weights)
+    const float *g_plane;            // [M][72][64]   Psym[m][row=lane][col=j] lane-major (rows 0..63), zero padded
+    const float *g_ptail;            // [4][12][64]   rows 64..68 of components (2w, 2w+1) cut into 60 twelve-column pieces
 };
 
 // Full model tensors for the dense mesh kernels.

@@ -1,57 +1,77 @@
 // Persistent per-frame SMPLify fit kernel for gfx950 (MI355X).
 //
-// One 256-thread workgroup owns one frame for ALL Adam iterations of reference
-// smplify/smplify.py:177-213: parameters, kinematic chain, gradients and Adam moments stay in LDS /
-// registers for the whole fit, the only HBM traffic is the one-off table load (~190 KB, L2 resident
-// across frames) and the final write-back.  There is no kernel boundary, no host sync and no
-// per-view host->device copy inside the loop (the reference pays 48 of those per iteration,
-// loss.py:160).
+// One 512-thread workgroup (8 wave64, two per SIMD) owns one frame for ALL Adam iterations of
+// reference smplify/smplify.py:177-213: parameters, kinematic chain, gradients and Adam moments stay
+// in LDS / registers for the whole fit; the only HBM traffic is the one-off table load (~190 KB, L2
+// resident across frames) and the final write-back.  No kernel boundary, host sync or host->device
+// copy inside the loop (the reference pays 48 keypoint copies + 4 syncs per iteration, loss.py:160,219).
 //
 // Work per iteration (keypoint-only objective, loss.py:139-230): only the first 25 of the 49 joints
-// enter the loss (loss.py:163) = 14 chain joints + 11 selector vertices, so the iteration evaluates
-//   Rodrigues x NJ (smplx quirk angle=||theta+1e-8||), J(beta) from the pre-contracted regressor,
-//   the kinematic chain level by level, LBS of the selector vertices only (their 33 posedirs
-//   columns live in LDS), 48-view projection + GMoF, the merged 8x69x69 GMM prior (precision
-//   matrices pinned in VGPRs: 2 components per wave), angle / shape priors,
-// then the hand-derived reverse sweep of all of it and the torch-semantics Adam update.
-// The derivation is oracle/analytic.py; tests hold both to torch.autograd.
+// enter the loss (loss.py:163) = 14 chain joints + 11 selector vertices, so an iteration evaluates
+// Rodrigues x NJ (smplx quirk angle=||theta+1e-8||), J(beta) from the pre-contracted regressor, the
+// kinematic chain, LBS of the selector vertices only (their 33 posedirs columns live in LDS), the
+// 48-view projection + GMoF, the merged 8x69x69 GMM prior, the angle / shape priors, the exact
+// reverse sweep of all of it, and the torch-semantics Adam update.  Derivation: oracle/analytic.py.
+//
+// The kernel is latency-bound (a dependent chain of short phases), so the design minimises the
+// number of workgroup barriers (11 per iteration) and keeps every index in registers:
+//   waves 0-2  chain specialists: wave r carries matrix row r of every joint (row r of G_i depends
+//              only on row r of G_parent), lane = joint, levels run back to back with no barrier
+//              (LDS is in-order within a wave);
+//   wave 3     shaped selector vertices, housekeeping;
+//   waves 4-7  GMM specialists: the symmetrised precision rows of components 2g, 2g+1 live in
+//              VGPRs for the whole launch; d, the mat-vec, the tail rows and the quadratic forms
+//              run inside one phase, wave-locally;
+//   all waves  pose blend partials, 48-view projection (thread = joint x view slot, keypoints in
+//              registers), reverse skinning, d(pose feature).
+// The reverse chain is flattened: with t_i = sum over subtree(i) of dL/dGt and
+// N_i = D_i GR_i^T + t_i (Gt_i - Gt_parent)^T, dL/dGR_p = (D_p GR_p^T + sum_{i in strict subtree} N_i) GR_p,
+// i.e. two subtree sums instead of one barrier per tree level.  All reductions have a fixed order.
 #include "bf_internal.h"
+
+// Diagnostic build only (-DBF_STAMP, libbodyfit_stamp.so): thread 0 stamps the shader clock after every
+// barrier of iteration 2 into io.debug[4096..]; the product library has no stamps.
+#ifdef BF_STAMP
+#define BF_SYNC() do { __syncthreads(); if (tid == 0 && it == 2 && io.debug && sidx < 96) { io.debug[4096 + sidx] = (float)(long long)(clock64() - t_iter); } ++sidx; } while (0)
+#else
+#define BF_SYNC() __syncthreads()
+#endif
+// orders this wave's LDS traffic for the compiler; the hardware executes a wave's LDS ops in order
+#define BF_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
 
 namespace {
 
 struct FitSmem {
-    float *params, *R, *rc, *J, *GR, *Gt, *At, *vs, *vp, *TR, *vsel, *part, *dXw, *dvsel, *dvp;
-    float *dGR, *dGt, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal;
+    float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
+    float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
     float *Jt, *Jd, *Jdrel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj;
-    int *parents, *level_start, *level_joints, *child_start, *child_list, *lj_kind, *lj_index;
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 
 // Carve the dynamic LDS segment; the same function sizes it on the host (base == nullptr).
 __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj, int nb, int npf, int ns,
-                                                  int nl, int np, int nviews, int n_levels) {
+                                                  int nl, int np, int nviews) {
     size_t o = 0;
     auto take = [&](int n) { float *p = base ? base + o : nullptr; o += pad4(n); return p; };
-    s.params = take(np);
+    s.pa = take(np);       s.pb = take(np);
     s.R = take(nj * 9);    s.rc = take(nj * 4);   s.J = take(nj * 3);
-    s.GR = take(nj * 9);   s.Gt = take(nj * 3);   s.At = take(nj * 3);
+    s.G = take(nj * 12);   s.At = take(nj * 3);
     s.vs = take(ns * 3);   s.vp = take(ns * 3);   s.TR = take(ns * 9);   s.vsel = take(ns * 3);
     s.part = take(BF_VSUB * 32 * 4);
-    s.dXw = take(nl * 4);  s.dvsel = take(ns * 3); s.dvp = take(ns * 3);
-    s.dGR = take(nj * 9);  s.dGt = take(nj * 3);  s.dAt = take(nj * 3);  s.dJ = take(nj * 3);
+    s.dvsel = take(ns * 3); s.dvp = take(ns * 3);
+    s.dGR = take(nj * 9);  s.dGt = take(nj * 3);  s.tt = take(nj * 3);   s.N = take(nj * 9);
+    s.dAt = take(nj * 3);  s.dJ = take(nj * 3);
     s.dR = take(nj * 9);   s.drel = take(nj * 3); s.dfeat = take(npf);   s.gth = take(nj * 3);
     s.g = take(np);
     s.gd = take(BF_GMM_M * BF_GMM_LD); s.gy = take(BF_GMM_M * BF_GMM_LD);
-    s.gq = take(BF_GMM_M);             s.gtail = take(BF_FIT_THREADS);   s.scal = take(4);
+    s.gq = take(BF_GMM_M);             s.gtail = take(256);   s.scal = take(8);
+    s.feat = take(npf);                s.vpp = take(BF_FIT_THREADS + ns * 3);
     s.Jt = take(nj * 3);   s.Jd = take(nj * 3 * nb);      s.Jdrel = take(nj * 3 * nb);
     s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * nb); s.sel_pd = take(npf * ns * 3);
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
     s.proj = take(nviews * 12);
-    s.parents = (int *)take(nj);          s.level_start = (int *)take(n_levels + 1);
-    s.level_joints = (int *)take(nj);     s.child_start = (int *)take(nj + 1);
-    s.child_list = (int *)take(nj);       s.lj_kind = (int *)take(nl);
-    s.lj_index = (int *)take(nl);
+    (void)nl;
     return o * sizeof(float);
 }
 
@@ -114,6 +134,12 @@ __device__ inline float theta_of(const float *params, const FitTab &T, int j, in
     return j == 0 ? params[T.off_orient + k] : params[T.off_pose + 3 * (j - 1) + k];
 }
 
+#define GR_(j, r, c) S.G[((j) * 3 + (r)) * 4 + (c)]
+#define GT_(j, r) S.G[((j) * 3 + (r)) * 4 + 3]
+
+}  // namespace
+
+
 __device__ inline void copy_f(float *dst, const float *src, int n, int tid, int nt) {
     for (int i = tid; i < n; i += nt) dst[i] = src[i];
 }
@@ -121,29 +147,31 @@ __device__ inline void copy_i(int *dst, const int *src, int n, int tid, int nt) 
     for (int i = tid; i < n; i += nt) dst[i] = src[i];
 }
 
-}  // namespace
 
 // mode: 0 = fit (n_iters Adam steps), 1 = one loss/gradient evaluation, no update.
-// adam_tab[it] = {lr_transl_scale / bc1, lr / bc1, sqrt(bc2)} evaluated in double on the host
-// exactly as torch's single-tensor Adam does.
-extern "C" __global__ void __launch_bounds__(BF_FIT_THREADS)
-bf_fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float *__restrict__ adam_tab,
-              int adam_t0) {
+// adam_tab[it] = {lr_transl_scale / bc1, lr / bc1, sqrt(bc2)} evaluated in double on the host exactly
+// as torch's single-tensor Adam does.  NJ/NB/NS/NL > 0 fix the sizes at compile time
+// (SMPL: 24, 10, 11, 25) so every inner loop unrolls; 0 = take them from the tables.
+template <int NJ, int NB, int NS, int NL>
+__global__ void __launch_bounds__(BF_FIT_THREADS)
+fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float *__restrict__ adam_tab, int adam_t0) {
     extern __shared__ __align__(16) float smem_raw[];
     const int tid = threadIdx.x, nt = BF_FIT_THREADS;
+    constexpr int NG = 256;                    // threads of the geometry waves (0-3)
     const int lane = tid & 63, wave = tid >> 6;
     const int frame = blockIdx.x;
-    const int nj = T.nj, nb = T.nb, npf = T.npf, ns = T.ns, nl = T.nl, np = T.np, V = io.n_views;
+    const int nj = NJ ? NJ : T.nj, nb = NB ? NB : T.nb, ns = NS ? NS : T.ns, nl = NL ? NL : T.nl;
+    const int npf = 9 * (nj - 1), np = T.np, V = io.n_views, ns3 = ns * 3, nj3 = nj * 3;
     FitSmem S;
-    fit_smem_carve(S, smem_raw, nj, nb, npf, ns, nl, np, V, T.n_levels);
+    fit_smem_carve(S, smem_raw, nj, nb, npf, ns, nl, np, V);
 
     // ---- one-off loads --------------------------------------------------------------------
-    copy_f(S.Jt, T.Jt, nj * 3, tid, nt);
-    copy_f(S.Jd, T.Jd, nj * 3 * nb, tid, nt);
-    copy_f(S.Jdrel, T.Jdrel, nj * 3 * nb, tid, nt);
-    copy_f(S.sel_vt, T.sel_vt, ns * 3, tid, nt);
-    copy_f(S.sel_sd, T.sel_sd, ns * 3 * nb, tid, nt);
-    copy_f(S.sel_pd, T.sel_pd, npf * ns * 3, tid, nt);
+    copy_f(S.Jt, T.Jt, nj3, tid, nt);
+    copy_f(S.Jd, T.Jd, nj3 * nb, tid, nt);
+    copy_f(S.Jdrel, T.Jdrel, nj3 * nb, tid, nt);
+    copy_f(S.sel_vt, T.sel_vt, ns3, tid, nt);
+    copy_f(S.sel_sd, T.sel_sd, ns3 * nb, tid, nt);
+    copy_f(S.sel_pd, T.sel_pd, npf * ns3, tid, nt);
     copy_f(S.sel_w, T.sel_w, ns * nj, tid, nt);
     for (int i = tid; i < BF_GMM_M * BF_GMM_LD; i += nt) {
         int m = i / BF_GMM_LD, j = i % BF_GMM_LD;
@@ -152,83 +180,148 @@ bf_fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const fl
         S.gy[i] = 0.f;
     }
     copy_f(S.proj, io.proj + (size_t)frame * V * 12, V * 12, tid, nt);
-    copy_i(S.parents, T.parents, nj, tid, nt);
-    copy_i(S.level_start, T.level_start, T.n_levels + 1, tid, nt);
-    copy_i(S.level_joints, T.level_joints, nj, tid, nt);
-    copy_i(S.child_start, T.child_start, nj + 1, tid, nt);
-    copy_i(S.child_list, T.child_list, nj - 1, tid, nt);
-    copy_i(S.lj_kind, T.lj_kind, nl, tid, nt);
-    copy_i(S.lj_index, T.lj_index, nl, tid, nt);
-    copy_f(S.params, io.params + (size_t)frame * np, np, tid, nt);
+    copy_f(S.pa, io.params + (size_t)frame * np, np, tid, nt);
+    float *Pcur = S.pa, *Pnext = S.pb;
 
-    // GMM precision rows pinned in registers: wave w owns components 2w and 2w+1, lane l row l;
-    // rows 64..68 of both components are cut into 60 twelve-column pieces, one per lane.
-    const int ma = 2 * wave, mb = 2 * wave + 1;
-    float Pa[BF_GMM_LD], Pb[BF_GMM_LD], Pt[12];
-    {
-        const float *ra = T.g_psym + ((size_t)ma * BF_GMM_D + lane) * BF_GMM_D;
-        const float *rb = T.g_psym + ((size_t)mb * BF_GMM_D + lane) * BF_GMM_D;
+    // chain-row role (waves 0-2): lane = joint
+    const bool cw_on = wave < 3 && lane < nj;
+    const int wj = cw_on ? lane : 0;
+    const int wp = wj > 0 ? T.parents[wj] : 0;
+    const int wd = cw_on ? T.depth[wj] : -1;
+    // (joint, row) role of the reverse sweep: tid < 3 nj
+    const bool c_on = tid < nj3;
+    const int ci = c_on ? tid / 3 : 0, cr = c_on ? tid - ci * 3 : 0;
+    const int cp = ci > 0 ? T.parents[ci] : 0;
+    const unsigned long long cmask = c_on ? T.desc[ci] : 0ull;       // strict descendants of ci
+    // loss-joint routing of this thread's joint slot
+    const int jslot = tid & 31, vsub = tid >> 5;
+    const bool j_on = jslot < nl;
+    const int lkind = j_on ? T.lj_kind[jslot] : 0, lidx = j_on ? T.lj_index[jslot] : 0;
+    const float *lsrc = lkind == 0 ? S.G + lidx * 12 + 3 : S.vsel + lidx * 3;
+    const int lstride = lkind == 0 ? 4 : 1;
+    float *ldst = (lkind == 0 ? S.dGt : S.dvsel) + lidx * 3;
+
+    // GMM role (waves 4-7): precision rows pinned in registers (lane-major host copies: coalesced)
+    const bool gw = wave >= 4;
+    const int gwi = gw ? wave - 4 : 0;
+    const int ma = 2 * gwi, mb = 2 * gwi + 1;
+    const int tpiece = lane < 60 ? lane : 59;
+    const float *tail_d = S.gd + (tpiece < 30 ? ma : mb) * BF_GMM_LD + 12 * (tpiece % 6);
+    const float logw_a = T.g_logw[ma], logw_b = T.g_logw[mb];
+    int gd_off[3], gd_src[3];                 // this lane's (component, dof) items of d = theta - mu
 #pragma unroll
-        for (int j = 0; j < BF_GMM_LD; ++j) {
-            Pa[j] = j < BF_GMM_D ? ra[j] : 0.f;
-            Pb[j] = j < BF_GMM_D ? rb[j] : 0.f;
-        }
-        int piece = lane < 60 ? lane : 59;
-        int tcomp = piece < 30 ? ma : mb, trow = 64 + (piece % 30) / 6, tcol = 12 * (piece % 6);
-        const float *rt = T.g_psym + ((size_t)tcomp * BF_GMM_D + trow) * BF_GMM_D;
-#pragma unroll
-        for (int e = 0; e < 12; ++e) Pt[e] = (lane < 60 && tcol + e < BF_GMM_D) ? rt[tcol + e] : 0.f;
+    for (int q = 0; q < 3; ++q) {
+        int i = lane + q * 64;
+        bool ok = gw && i < 2 * BF_GMM_D;
+        int c = i < BF_GMM_D ? ma : mb, j = i < BF_GMM_D ? i : i - BF_GMM_D;
+        gd_off[q] = ok ? c * BF_GMM_LD + j : -1;
+        gd_src[q] = j < T.nbp ? T.off_pose + j : -1;       // smplx pads 63 -> 69 with zeros (loss.py:207)
     }
 
     // keypoints of this thread's (joint slot, view sub-slot) pinned in registers
-    const int jslot = tid & 31, vsub = tid >> 5;
     float kx[BF_KP_ROUNDS], ky[BF_KP_ROUNDS], kc2[BF_KP_ROUNDS];
     const float *kp_frame = io.keypoints + (size_t)frame * V * nl * 3;
 #pragma unroll
     for (int r = 0; r < BF_KP_ROUNDS; ++r) {
         int v = vsub + BF_VSUB * r;
-        bool ok = v < V && jslot < nl;
+        bool ok = v < V && j_on;
         const float *k = kp_frame + ((size_t)(ok ? v : 0) * nl + (ok ? jslot : 0)) * 3;
         kx[r] = k[0]; ky[r] = k[1];
         float cf = ok ? k[2] : 0.f;
         kc2[r] = cf * cf;
     }
     const float ndiv_f = (float)io.ndiv[frame];
+    const float icoeff = 1.0f / hp.coeff;
+    const float kscale = -1.0f / (hp.coeff * ndiv_f);
+    const float s2 = hp.sigma2;
 
-    // Adam moments of parameter `tid`
+    // pose-blend role: (row slice sl, output column o of the selector vertices)
+    const int NSL = ns3 <= nt ? nt / ns3 : 1;
+    const int rows_sl = (npf + NSL - 1) / NSL;
+
+    // Adam role: parameter `tid`, its moments in registers
     float am = 0.f, av = 0.f;
     if (tid < np) { am = io.adam_m[(size_t)frame * np + tid]; av = io.adam_v[(size_t)frame * np + tid]; }
-    const float s2 = hp.sigma2;
+    float ang_sg = 0.f;                        // angle prior sign (loss.py:54-61: dofs 52, 55, 9, 12)
+    {
+        int ip = tid - T.off_pose;
+        if (tid >= T.off_pose && tid < T.off_beta) ang_sg = ip == 52 ? 1.f : ((ip == 55 || ip == 9 || ip == 12) ? -1.f : 0.f);
+    }
     __syncthreads();
 
-    for (int it = 0; it < n_iters; ++it) {
-        // ================= phase A: per-joint rotations, rest joints, shaped selector verts, GMM d
-        if (tid < nj) {
-            rodrigues_fwd(theta_of(S.params, T, tid, 0), theta_of(S.params, T, tid, 1),
-                          theta_of(S.params, T, tid, 2), S.R + tid * 9, S.rc + tid * 4);
+    // phases shared by both wave roles
+    auto pose_blend = [&]() {
+        for (int idx = tid; idx < ns3 * NSL; idx += nt) {
+        int sl = idx / ns3, o = idx - sl * ns3;
+        int p0 = sl * rows_sl, p1 = min(npf, p0 + rows_sl);
+        float acc = 0.f;
+        const float *pd = S.sel_pd + p0 * ns3 + o;
+        for (int p = p0; p < p1; ++p, pd += ns3) acc += S.feat[p] * pd[0];
+        S.vpp[idx] = acc;
+    }
+    };
+    auto project = [&]() {
+        {
+        float tX = Pcur[0], tY = Pcur[1], tZ = Pcur[2];
+        float sc = Pcur[3] * hp.cscale;
+        float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+        if (j_on) { y0 = lsrc[0] + tX; y1 = lsrc[lstride] + tY; y2 = lsrc[2 * lstride] + tZ; }
+        float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, lsum = 0.f;
+        auto one_view = [&](int v, float gx, float gy, float c2) {
+            const float4 *P = (const float4 *)(S.proj + v * 12);
+            float4 Pa4 = P[0], Pb4 = P[1], Pc4 = P[2];
+            float p0 = Pa4.x * x0 + Pa4.y * x1 + Pa4.z * x2 + Pa4.w;
+            float p1 = Pb4.x * x0 + Pb4.y * x1 + Pb4.z * x2 + Pb4.w;
+            float p2 = Pc4.x * x0 + Pc4.y * x1 + Pc4.z * x2 + Pc4.w;
+            float ip2 = 1.0f / p2;
+            float u = p0 * ip2, w = p1 * ip2;
+            float rx = (gx - u) * icoeff, ry = (gy - w) * icoeff;
+            float ix = 1.0f / (s2 + rx * rx), iy = 1.0f / (s2 + ry * ry);
+            lsum += c2 * (s2 * rx * rx * ix + s2 * ry * ry * iy);
+            float k = c2 * kscale;
+            float du = k * (2.f * s2 * s2 * rx * ix * ix), dw = k * (2.f * s2 * s2 * ry * iy * iy);
+            float q0 = du * ip2, q1 = dw * ip2, q2 = -(du * u + dw * w) * ip2;
+            g0 += Pa4.x * q0 + Pb4.x * q1 + Pc4.x * q2;
+            g1 += Pa4.y * q0 + Pb4.y * q1 + Pc4.y * q2;
+            g2 += Pa4.z * q0 + Pb4.z * q1 + Pc4.z * q2;
+        };
+#pragma unroll
+        for (int r = 0; r < BF_KP_ROUNDS; ++r) {
+            int v = vsub + BF_VSUB * r;
+            if (v < V && j_on) one_view(v, kx[r], ky[r], kc2[r]);
         }
-        for (int i = tid; i < nj * 3 + ns * 3; i += nt) {
-            const float *beta = S.params + T.off_beta;
-            if (i < nj * 3) {
-                float acc = 0.f;
-                for (int l = 0; l < nb; ++l) acc += S.Jd[i * nb + l] * beta[l];
-                S.J[i] = S.Jt[i] + acc;
-            } else {
-                int o = i - nj * 3;
-                float acc = 0.f;
-                for (int l = 0; l < nb; ++l) acc += S.sel_sd[o * nb + l] * beta[l];
-                S.vs[o] = S.sel_vt[o] + acc;
+        for (int v = vsub + BF_VSUB * BF_KP_ROUNDS; v < V; v += BF_VSUB) {   // V > 48: stream the rest
+            if (j_on) {
+                const float *k = kp_frame + ((size_t)v * nl + jslot) * 3;
+                one_view(v, k[0], k[1], k[2] * k[2]);
             }
         }
-        for (int i = tid; i < BF_GMM_M * BF_GMM_D; i += nt) {
-            int m = i / BF_GMM_D, j = i % BF_GMM_D;
-            float th = j < T.nbp ? S.params[T.off_pose + j] : 0.f;   // smplx pads 63 -> 69 with zeros (loss.py:207)
-            S.gd[m * BF_GMM_LD + j] = th - S.means[m * BF_GMM_LD + j];
-        }
-        __syncthreads();
+        float4 pr = {g0, g1, g2, lsum};
+        ((float4 *)S.part)[vsub * 32 + jslot] = pr;
+    }
+    };
 
-        // ================= phase B: GMM matvec (register-resident P), chain root
-        {
+    if (gw) {
+        // ================= GMM specialists (waves 4-7): the precision rows never leave their registers
+        float Pa[BF_GMM_LD], Pb[BF_GMM_LD], Pt[12];
+#pragma unroll
+        for (int j = 0; j < BF_GMM_LD; ++j) {
+            Pa[j] = T.g_plane[((size_t)ma * BF_GMM_LD + j) * 64 + lane];
+            Pb[j] = T.g_plane[((size_t)mb * BF_GMM_LD + j) * 64 + lane];
+        }
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Pt[e] = T.g_ptail[((size_t)gwi * 12 + e) * 64 + lane];
+        for (int it = 0; it < n_iters; ++it) {
+#ifdef BF_STAMP
+            int sidx = 0;
+            long long t_iter = clock64();
+#endif
+            // GMM, wave-local: d = theta - mu, y = Psym d (rows 0..63 per lane + 60 tail pieces), q = 0.5 d'y - log w~
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (gd_off[q] >= 0) S.gd[gd_off[q]] = (gd_src[q] >= 0 ? Pcur[gd_src[q]] : 0.f) - S.means[gd_off[q]];
+            BF_WAVE_FENCE();
             const float4 *da4 = (const float4 *)(S.gd + ma * BF_GMM_LD);
             const float4 *db4 = (const float4 *)(S.gd + mb * BF_GMM_LD);
             float ya = 0.f, yb = 0.f;
@@ -240,287 +333,288 @@ bf_fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const fl
             }
             S.gy[ma * BF_GMM_LD + lane] = ya;
             S.gy[mb * BF_GMM_LD + lane] = yb;
-            int piece = lane < 60 ? lane : 59;
-            const float *dt = S.gd + (piece < 30 ? ma : mb) * BF_GMM_LD + 12 * (piece % 6);
             float yt = 0.f;
 #pragma unroll
-            for (int e = 0; e < 12; ++e) yt += Pt[e] * dt[e];
-            S.gtail[tid] = yt;
-        }
-        if (tid < 9) S.GR[tid] = S.R[tid];
-        if (tid >= 64 && tid < 67) S.Gt[tid - 64] = S.J[tid - 64];
-        __syncthreads();
-
-        // ================= phase C: chain, level by level; GMM quadratic forms ride along level 1
-        for (int lev = 1; lev < T.n_levels; ++lev) {
-            int ls = S.level_start[lev], cnt = (S.level_start[lev + 1] - ls) * 3;
-            for (int idx = tid; idx < cnt; idx += nt) {
-                int i = S.level_joints[ls + idx / 3], r = idx % 3, p = S.parents[i];
-                float g0 = S.GR[p * 9 + r * 3], g1 = S.GR[p * 9 + r * 3 + 1], g2 = S.GR[p * 9 + r * 3 + 2];
-                const float *Ri = S.R + i * 9;
-                S.GR[i * 9 + r * 3 + 0] = g0 * Ri[0] + g1 * Ri[3] + g2 * Ri[6];
-                S.GR[i * 9 + r * 3 + 1] = g0 * Ri[1] + g1 * Ri[4] + g2 * Ri[7];
-                S.GR[i * 9 + r * 3 + 2] = g0 * Ri[2] + g1 * Ri[5] + g2 * Ri[8];
-                float r0 = S.J[i * 3] - S.J[p * 3], r1 = S.J[i * 3 + 1] - S.J[p * 3 + 1], r2 = S.J[i * 3 + 2] - S.J[p * 3 + 2];
-                S.Gt[i * 3 + r] = g0 * r0 + g1 * r1 + g2 * r2 + S.Gt[p * 3 + r];
-            }
-            if (lev == 1) {
-                // q_m = 0.5 d'Pd - log w~ for this wave's two components (prior.py:188-189)
-                float ta = 0.f, tb = 0.f;
-                if (lane < 5) {
-                    float ysa = 0.f, ysb = 0.f;
+            for (int e = 0; e < 12; ++e) yt += Pt[e] * tail_d[e];
+            S.gtail[gwi * 64 + lane] = yt;
+            BF_WAVE_FENCE();
+            float ta = S.gd[ma * BF_GMM_LD + lane] * ya, tb = S.gd[mb * BF_GMM_LD + lane] * yb;
+            if (lane < 5) {
+                float ysa = 0.f, ysb = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) {
-                        ysa += S.gtail[wave * 64 + 6 * lane + e];
-                        ysb += S.gtail[wave * 64 + 30 + 6 * lane + e];
+                for (int e = 0; e < 6; ++e) {
+                    ysa += S.gtail[gwi * 64 + 6 * lane + e];
+                    ysb += S.gtail[gwi * 64 + 30 + 6 * lane + e];
+                }
+                S.gy[ma * BF_GMM_LD + 64 + lane] = ysa;
+                S.gy[mb * BF_GMM_LD + 64 + lane] = ysb;
+                ta += S.gd[ma * BF_GMM_LD + 64 + lane] * ysa;
+                tb += S.gd[mb * BF_GMM_LD + 64 + lane] * ysb;
+            }
+            ta = wave_sum(ta);
+            tb = wave_sum(tb);
+            if (lane == 0) {
+                S.gq[ma] = 0.5f * ta + logw_a;       // prior.py:188-189
+                S.gq[mb] = 0.5f * tb + logw_b;
+            }
+            BF_SYNC();                 // A
+            pose_blend();
+            BF_SYNC();                 // B
+            BF_SYNC();                 // C
+            project();
+            BF_SYNC();                 // D
+            BF_SYNC();                 // E
+            BF_SYNC();                 // F
+            for (int p = tid - 256; p < npf; p += 256) {      // d(pose feature) = sel_pd . dvp
+                float acc = 0.f;
+                const float *row = S.sel_pd + p * ns3;
+#pragma unroll 11
+                for (int o = 0; o < ns3; ++o) acc += row[o] * S.dvp[o];
+                S.dfeat[p] = acc;
+            }
+            BF_SYNC();                 // G
+            BF_SYNC();                 // H
+            BF_SYNC();                 // I
+            BF_SYNC();                 // J
+            BF_SYNC();                 // K
+            if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
+        }
+    } else {
+    // ================= geometry waves (0-3)
+    for (int it = 0; it < n_iters; ++it) {
+#ifdef BF_STAMP
+        int sidx = 0;
+        long long t_iter = clock64();
+#endif
+        // ================= phase A: forward chain (waves 0-2) | shaped selector verts (wave 3) | GMM (waves 4-7)
+        if (wave < 3) {
+            float Ri[9], rc[3], Jj0 = 0.f, Jj1 = 0.f, Jj2 = 0.f, rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
+            float4 row = {0.f, 0.f, 0.f, 0.f};
+            if (cw_on) {
+                rodrigues_fwd(theta_of(Pcur, T, wj, 0), theta_of(Pcur, T, wj, 1), theta_of(Pcur, T, wj, 2), Ri, rc);
+                const float *beta = Pcur + T.off_beta;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+#pragma unroll
+                for (int l = 0; l < nb; ++l) {
+                    float bl = beta[l];
+                    a0 += S.Jd[(wj * 3 + 0) * nb + l] * bl; a1 += S.Jd[(wj * 3 + 1) * nb + l] * bl; a2 += S.Jd[(wj * 3 + 2) * nb + l] * bl;
+                    b0 += S.Jd[(wp * 3 + 0) * nb + l] * bl; b1 += S.Jd[(wp * 3 + 1) * nb + l] * bl; b2 += S.Jd[(wp * 3 + 2) * nb + l] * bl;
+                }
+                Jj0 = S.Jt[wj * 3] + a0; Jj1 = S.Jt[wj * 3 + 1] + a1; Jj2 = S.Jt[wj * 3 + 2] + a2;
+                rel0 = Jj0 - (S.Jt[wp * 3] + b0); rel1 = Jj1 - (S.Jt[wp * 3 + 1] + b1); rel2 = Jj2 - (S.Jt[wp * 3 + 2] + b2);
+                if (wave == 0) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
+                    S.rc[wj * 4] = rc[0]; S.rc[wj * 4 + 1] = rc[1]; S.rc[wj * 4 + 2] = rc[2];
+                    S.J[wj * 3] = Jj0; S.J[wj * 3 + 1] = Jj1; S.J[wj * 3 + 2] = Jj2;
+                    if (wj > 0) {
+                        float *f = S.feat + (wj - 1) * 9;
+                        f[0] = Ri[0] - 1.f; f[1] = Ri[1]; f[2] = Ri[2]; f[3] = Ri[3]; f[4] = Ri[4] - 1.f;
+                        f[5] = Ri[5]; f[6] = Ri[6]; f[7] = Ri[7]; f[8] = Ri[8] - 1.f;
                     }
-                    S.gy[ma * BF_GMM_LD + 64 + lane] = ysa;
-                    S.gy[mb * BF_GMM_LD + 64 + lane] = ysb;
-                    ta = S.gd[ma * BF_GMM_LD + 64 + lane] * ysa;
-                    tb = S.gd[mb * BF_GMM_LD + 64 + lane] * ysb;
                 }
-                ta += S.gd[ma * BF_GMM_LD + lane] * S.gy[ma * BF_GMM_LD + lane];
-                tb += S.gd[mb * BF_GMM_LD + lane] * S.gy[mb * BF_GMM_LD + lane];
-                ta = wave_sum(ta);
-                tb = wave_sum(tb);
-                if (lane == 0) {
-                    S.gq[ma] = 0.5f * ta + T.g_logw[ma];
-                    S.gq[mb] = 0.5f * tb + T.g_logw[mb];
+                if (wj == 0) {
+                    row.x = wave == 0 ? Ri[0] : (wave == 1 ? Ri[3] : Ri[6]);
+                    row.y = wave == 0 ? Ri[1] : (wave == 1 ? Ri[4] : Ri[7]);
+                    row.z = wave == 0 ? Ri[2] : (wave == 1 ? Ri[5] : Ri[8]);
+                    row.w = wave == 0 ? Jj0 : (wave == 1 ? Jj1 : Jj2);
+                    *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
                 }
             }
-            __syncthreads();
+            for (int lev = 1; lev < T.n_levels; ++lev) {
+                BF_WAVE_FENCE();
+                if (wd == lev) {
+                    float4 g = *(const float4 *)(S.G + (wp * 3 + wave) * 4);
+                    row.x = g.x * Ri[0] + g.y * Ri[3] + g.z * Ri[6];
+                    row.y = g.x * Ri[1] + g.y * Ri[4] + g.z * Ri[7];
+                    row.z = g.x * Ri[2] + g.y * Ri[5] + g.z * Ri[8];
+                    row.w = g.x * rel0 + g.y * rel1 + g.z * rel2 + g.w;
+                    *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
+                }
+            }
+            if (cw_on) S.At[wj * 3 + wave] = row.w - (row.x * Jj0 + row.y * Jj1 + row.z * Jj2);
+        } else {
+            const float *beta = Pcur + T.off_beta;
+            for (int o = lane; o < ns3; o += 64) {
+                float acc = 0.f;
+#pragma unroll
+                for (int l = 0; l < nb; ++l) acc += S.sel_sd[o * nb + l] * beta[l];
+                S.vs[o] = S.sel_vt[o] + acc;
+            }
+            for (int i = lane; i < nj3; i += 64) S.dGt[i] = 0.f;       // targets of phase E's routing
+            for (int i = lane; i < ns3; i += 64) S.dvsel[i] = 0.f;
         }
+        BF_SYNC();
 
-        // ================= phase D: A_j translation, pose-blended selector vertices
-        for (int i = tid; i < nj * 3; i += nt) {
-            int j = i / 3, a = i % 3;
-            const float *g = S.GR + j * 9 + a * 3;
-            S.At[i] = S.Gt[i] - (g[0] * S.J[j * 3] + g[1] * S.J[j * 3 + 1] + g[2] * S.J[j * 3 + 2]);
-        }
-        for (int base = 0; base < ns * 3 * 4; base += nt) {
-            int idx = base + tid, o = idx >> 2, sl = idx & 3;
-            bool ok = o < ns * 3;
-            float acc = 0.f;
+        // ================= phase B: pose blend of the selector vertices, partial sums over row slices
+        pose_blend();
+        BF_SYNC();
+
+        // ================= phase C: finish the pose blend; skin the selector vertices.  Lane b of a quad owns
+        // column b of row k of T_s = sum_j w_sj A_j
+        for (int base = 0; base < ns3 * 4; base += nt) {
+            int o = (base + tid) >> 2, b = tid & 3;
+            bool ok = o < ns3;
+            int sv = ok ? o / 3 : 0, k = ok ? o - sv * 3 : 0;
+            float t = 0.f, vpb = 1.f;
             if (ok) {
-                int p0 = sl * ((npf + 3) / 4), p1 = min(npf, p0 + (npf + 3) / 4);
-                for (int p = p0; p < p1; ++p) {
-                    int j = 1 + p / 9, e = p % 9;
-                    float f = S.R[j * 9 + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
-                    acc += f * S.sel_pd[p * ns * 3 + o];
+                if (b < 3) {
+                    float acc = 0.f;
+                    for (int sl = 0; sl < NSL; ++sl) acc += S.vpp[sl * ns3 + sv * 3 + b];
+                    vpb = S.vs[sv * 3 + b] + acc;
+                    if (k == 0) S.vp[sv * 3 + b] = vpb;
                 }
-            }
-            acc += __shfl_xor(acc, 1);
-            acc += __shfl_xor(acc, 2);
-            if (ok && sl == 0) S.vp[o] = S.vs[o] + acc;
-        }
-        __syncthreads();
-
-        // ================= phase E: skin the selector vertices (row k of T_s, then v_k)
-        for (int idx = tid; idx < ns * 3; idx += nt) {
-            int sv = idx / 3, k = idx % 3;
-            float t0 = 0.f, t1 = 0.f, t2 = 0.f, tt = 0.f;
-            for (int j = 0; j < nj; ++j) {
-                float w = S.sel_w[sv * nj + j];
-                t0 += w * S.GR[j * 9 + k * 3];
-                t1 += w * S.GR[j * 9 + k * 3 + 1];
-                t2 += w * S.GR[j * 9 + k * 3 + 2];
-                tt += w * S.At[j * 3 + k];
-            }
-            S.TR[sv * 9 + k * 3] = t0; S.TR[sv * 9 + k * 3 + 1] = t1; S.TR[sv * 9 + k * 3 + 2] = t2;
-            S.vsel[idx] = t0 * S.vp[sv * 3] + t1 * S.vp[sv * 3 + 1] + t2 * S.vp[sv * 3 + 2] + tt;
-        }
-        __syncthreads();
-
-        // ================= phase F: similarity, 48-view projection, GMoF and its gradient
-        {
-            float tX = S.params[0], tY = S.params[1], tZ = S.params[2];
-            float sc = S.params[3] * hp.cscale;
-            float y0 = 0.f, y1 = 0.f, y2 = 0.f;
-            if (jslot < nl) {
-                const float *src = S.lj_kind[jslot] == 0 ? S.Gt + S.lj_index[jslot] * 3 : S.vsel + S.lj_index[jslot] * 3;
-                y0 = src[0] + tX; y1 = src[1] + tY; y2 = src[2] + tZ;
-            }
-            float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
-            float g0 = 0.f, g1 = 0.f, g2 = 0.f, lsum = 0.f;
-            auto one_view = [&](int v, float gx, float gy, float c2) {
-                const float *P = S.proj + v * 12;
-                float p0 = P[0] * x0 + P[1] * x1 + P[2] * x2 + P[3];
-                float p1 = P[4] * x0 + P[5] * x1 + P[6] * x2 + P[7];
-                float p2 = P[8] * x0 + P[9] * x1 + P[10] * x2 + P[11];
-                float u = p0 / p2, w = p1 / p2;
-                float rx = (gx - u) / hp.coeff, ry = (gy - w) / hp.coeff;
-                float dx = s2 + rx * rx, dy = s2 + ry * ry;
-                lsum += c2 * (s2 * rx * rx / dx + s2 * ry * ry / dy);
-                float k = -c2 / (hp.coeff * ndiv_f);
-                float du = k * (2.f * s2 * s2 * rx / (dx * dx)), dw = k * (2.f * s2 * s2 * ry / (dy * dy));
-                float q0 = du / p2, q1 = dw / p2, q2 = -(du * u + dw * w) / p2;
-                g0 += P[0] * q0 + P[4] * q1 + P[8] * q2;
-                g1 += P[1] * q0 + P[5] * q1 + P[9] * q2;
-                g2 += P[2] * q0 + P[6] * q1 + P[10] * q2;
-            };
+                const float *w = S.sel_w + sv * nj;
+                const float *A = b < 3 ? S.G + k * 4 + b : S.At + k;
+                const int stride = b < 3 ? 12 : 3;
 #pragma unroll
-            for (int r = 0; r < BF_KP_ROUNDS; ++r) {
-                int v = vsub + BF_VSUB * r;
-                if (v < V && jslot < nl) one_view(v, kx[r], ky[r], kc2[r]);
+                for (int j = 0; j < nj; ++j) t += w[j] * A[j * stride];
+                if (b < 3) S.TR[sv * 9 + k * 3 + b] = t;
             }
-            for (int v = vsub + BF_VSUB * BF_KP_ROUNDS; v < V; v += BF_VSUB) {   // V > 48: stream the rest
-                if (jslot < nl) {
-                    const float *k = kp_frame + ((size_t)v * nl + jslot) * 3;
-                    one_view(v, k[0], k[1], k[2] * k[2]);
-                }
-            }
-            float4 pr = {g0, g1, g2, lsum};
-            ((float4 *)S.part)[vsub * 32 + jslot] = pr;
+            float contrib = ok ? t * vpb : 0.f;
+            contrib += __shfl_xor(contrib, 1);
+            contrib += __shfl_xor(contrib, 2);
+            if (ok && b == 0) S.vsel[o] = contrib;
         }
-        __syncthreads();
+        BF_SYNC();
 
-        // ================= phase G: reduce over view sub-slots; route dL/dX to its source
-        for (int i = tid; i < nj * 3; i += nt) S.dGt[i] = 0.f;
-        for (int i = tid; i < ns * 3; i += nt) S.dvsel[i] = 0.f;
-        if (tid < nl * 4) {
-            int j = tid >> 2, k = tid & 3;
-            float acc = 0.f;
+        // ================= phase D: similarity, multi-view projection, GMoF and its gradient
+        project();
+        BF_SYNC();
+
+        // ================= phase E: fixed-order reduce over the view slots; route dL/dX; d/dt, d/ds, loss value
+        if (wave < 2) {
+            // lane = (joint slot js, half h): each half sums 8 of the 16 view slots, then the halves combine
+            int js = lane & 31, h = lane >> 5;
+            float4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < BF_VSUB; ++q) acc += S.part[(q * 32 + j) * 4 + k];
-            S.dXw[tid] = acc;
-        }
-        __syncthreads();
-        if (tid < nl * 3) {
-            int j = tid / 3, k = tid % 3;
-            float dX = S.dXw[j * 4 + k] * (S.params[3] * hp.cscale);
-            float *dst = S.lj_kind[j] == 0 ? S.dGt + S.lj_index[j] * 3 + k : S.dvsel + S.lj_index[j] * 3 + k;
-            atomicAdd(dst, dX);   // LDS; sources are distinct for the reference joint maps (<= 2-way otherwise)
-        }
-        if (tid >= 128 && tid < 132) {
-            // gradients of global_transl (k<3) and body_scale (k==3), smplify.py:189
-            int k = tid - 128;
-            float acc = 0.f;
-            for (int j = 0; j < nl; ++j) {
-                if (k < 3) acc += S.dXw[j * 4 + k];
-                else {
-                    const float *src = S.lj_kind[j] == 0 ? S.Gt + S.lj_index[j] * 3 : S.vsel + S.lj_index[j] * 3;
-                    acc += S.dXw[j * 4] * (src[0] + S.params[0]) + S.dXw[j * 4 + 1] * (src[1] + S.params[1]) +
-                           S.dXw[j * 4 + 2] * (src[2] + S.params[2]);
-                }
+            for (int q = 0; q < BF_VSUB / 2; ++q) {
+                float4 p = ((const float4 *)S.part)[(h * (BF_VSUB / 2) + q) * 32 + js];
+                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
             }
-            S.g[k] = k < 3 ? acc * (S.params[3] * hp.cscale) : acc * hp.cscale;
+            a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
+            float sc = Pcur[3] * hp.cscale;
+            bool cnt = js < nl && h == 0;          // (jslot == js on both halves of waves 0 and 1)
+            if (wave == 0) {
+                if (cnt) {
+                    atomicAdd(ldst + 0, a.x * sc);   // LDS; distinct targets for the reference joint maps
+                    atomicAdd(ldst + 1, a.y * sc);
+                    atomicAdd(ldst + 2, a.z * sc);
+                }
+                float gt0 = wave_sum(cnt ? a.x : 0.f), gt1 = wave_sum(cnt ? a.y : 0.f), gt2 = wave_sum(cnt ? a.z : 0.f);
+                if (lane == 0) { S.g[0] = gt0 * sc; S.g[1] = gt1 * sc; S.g[2] = gt2 * sc; }   // d/d global_transl (smplify.py:189)
+            } else {
+                float y0 = 0.f, y1 = 0.f, y2 = 0.f;
+                if (cnt) { y0 = lsrc[0] + Pcur[0]; y1 = lsrc[lstride] + Pcur[1]; y2 = lsrc[2 * lstride] + Pcur[2]; }
+                float gs = wave_sum(cnt ? a.x * y0 + a.y * y1 + a.z * y2 : 0.f);
+                float ls = wave_sum(cnt ? a.w : 0.f);
+                if (lane == 0) { S.g[3] = gs * hp.cscale; S.scal[0] = ls; }                   // d/d body_scale; sum conf^2 rho
+            }
         }
-        if (tid == 192) {
-            float acc = 0.f;
-            for (int j = 0; j < nl; ++j) acc += S.dXw[j * 4 + 3];
-            S.scal[0] = acc;   // sum over views and joints of conf^2 rho (divided by len(use_frames) at write-out)
-        }
-        __syncthreads();
+        BF_SYNC();
 
-        // ================= phase H: reverse skinning of the selector vertices
-        for (int i = tid; i < nj * 3; i += nt) {
-            int j = i / 3, a = i % 3;
+        // ================= phase F: reverse skinning of the selector vertices
+        if (c_on) {
             float dat = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
             for (int sv = 0; sv < ns; ++sv) {
-                float wd = S.sel_w[sv * nj + j] * S.dvsel[sv * 3 + a];
-                dat += wd;
-                r0 += wd * S.vp[sv * 3]; r1 += wd * S.vp[sv * 3 + 1]; r2 += wd * S.vp[sv * 3 + 2];
+                float wd_ = S.sel_w[sv * nj + ci] * S.dvsel[sv * 3 + cr];
+                dat += wd_;
+                r0 += wd_ * S.vp[sv * 3]; r1 += wd_ * S.vp[sv * 3 + 1]; r2 += wd_ * S.vp[sv * 3 + 2];
             }
-            S.dAt[i] = dat;
-            S.dGt[i] += dat;
-            S.dGR[j * 9 + a * 3] = r0 - dat * S.J[j * 3];
-            S.dGR[j * 9 + a * 3 + 1] = r1 - dat * S.J[j * 3 + 1];
-            S.dGR[j * 9 + a * 3 + 2] = r2 - dat * S.J[j * 3 + 2];
+            S.dAt[tid] = dat;
+            S.dGt[tid] += dat;
+            S.dGR[ci * 9 + cr * 3] = r0 - dat * S.J[ci * 3];
+            S.dGR[ci * 9 + cr * 3 + 1] = r1 - dat * S.J[ci * 3 + 1];
+            S.dGR[ci * 9 + cr * 3 + 2] = r2 - dat * S.J[ci * 3 + 2];
         }
-        for (int idx = nt - 1 - tid; idx < ns * 3; idx += nt) {   // taken from the far end of the block
-            int sv = idx / 3, b = idx % 3;
+        for (int idx = NG - 1 - tid; idx < ns3; idx += NG) {   // taken from the far end of the geometry waves
+            int sv = idx / 3, b = idx - sv * 3;
             S.dvp[idx] = S.TR[sv * 9 + b] * S.dvsel[sv * 3] + S.TR[sv * 9 + 3 + b] * S.dvsel[sv * 3 + 1] +
                          S.TR[sv * 9 + 6 + b] * S.dvsel[sv * 3 + 2];
         }
-        __syncthreads();
+        BF_SYNC();
 
-        // ================= phase I: d(pose feature), direct dJ, then the chain in reverse
-        for (int p = tid; p < npf; p += nt) {
-            float acc = 0.f;
-            const float *row = S.sel_pd + p * ns * 3;
-            for (int o = 0; o < ns * 3; ++o) acc += row[o] * S.dvp[o];
-            S.dfeat[p] = acc;
+        // ================= phase G: subtree sums t_i of dL/dGt, N_i rows, direct dJ (tid < 3 nj) | d(pose feature)
+        float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f;
+        if (c_on) {
+            float ttot = S.dGt[tid];
+#pragma unroll
+            for (int k = 0; k < nj; ++k)
+                if ((cmask >> k) & 1ull) ttot += S.dGt[k * 3 + cr];
+            S.tt[tid] = ttot;
+            float d0 = S.dGR[ci * 9 + cr * 3], d1 = S.dGR[ci * 9 + cr * 3 + 1], d2 = S.dGR[ci * 9 + cr * 3 + 2];
+            dg0 = d0 * GR_(ci, 0, 0) + d1 * GR_(ci, 0, 1) + d2 * GR_(ci, 0, 2);     // row cr of D_i GR_i^T
+            dg1 = d0 * GR_(ci, 1, 0) + d1 * GR_(ci, 1, 1) + d2 * GR_(ci, 1, 2);
+            dg2 = d0 * GR_(ci, 2, 0) + d1 * GR_(ci, 2, 1) + d2 * GR_(ci, 2, 2);
+            float u0 = 0.f, u1 = 0.f, u2 = 0.f;
+            if (ci > 0) { u0 = GT_(ci, 0) - GT_(cp, 0); u1 = GT_(ci, 1) - GT_(cp, 1); u2 = GT_(ci, 2) - GT_(cp, 2); }
+            S.N[ci * 9 + cr * 3] = dg0 + ttot * u0;
+            S.N[ci * 9 + cr * 3 + 1] = dg1 + ttot * u1;
+            S.N[ci * 9 + cr * 3 + 2] = dg2 + ttot * u2;
+            S.dJ[tid] = -(GR_(ci, 0, cr) * S.dAt[ci * 3] + GR_(ci, 1, cr) * S.dAt[ci * 3 + 1] + GR_(ci, 2, cr) * S.dAt[ci * 3 + 2]);
         }
-        for (int i = nt - 1 - tid; i < nj * 3; i += nt) {
-            int j = i / 3, b = i % 3;
-            S.dJ[i] = -(S.GR[j * 9 + b] * S.dAt[j * 3] + S.GR[j * 9 + 3 + b] * S.dAt[j * 3 + 1] +
-                        S.GR[j * 9 + 6 + b] * S.dAt[j * 3 + 2]);
-        }
-        __syncthreads();
-        for (int lev = T.n_levels - 2; lev >= 0; --lev) {
-            int ls = S.level_start[lev], cnt = (S.level_start[lev + 1] - ls) * 3;
-            for (int idx = tid; idx < cnt; idx += nt) {
-                int p = S.level_joints[ls + idx / 3], r = idx % 3;
-                float a0 = S.dGR[p * 9 + r * 3], a1 = S.dGR[p * 9 + r * 3 + 1], a2 = S.dGR[p * 9 + r * 3 + 2];
-                float at = S.dGt[p * 3 + r];
-                for (int ci = S.child_start[p]; ci < S.child_start[p + 1]; ++ci) {
-                    int i = S.child_list[ci];
-                    float d0 = S.dGR[i * 9 + r * 3], d1 = S.dGR[i * 9 + r * 3 + 1], d2 = S.dGR[i * 9 + r * 3 + 2];
-                    float dt = S.dGt[i * 3 + r];
-                    const float *Ri = S.R + i * 9;
-                    a0 += d0 * Ri[0] + d1 * Ri[1] + d2 * Ri[2] + dt * (S.J[i * 3] - S.J[p * 3]);
-                    a1 += d0 * Ri[3] + d1 * Ri[4] + d2 * Ri[5] + dt * (S.J[i * 3 + 1] - S.J[p * 3 + 1]);
-                    a2 += d0 * Ri[6] + d1 * Ri[7] + d2 * Ri[8] + dt * (S.J[i * 3 + 2] - S.J[p * 3 + 2]);
-                    at += dt;
-                }
-                S.dGR[p * 9 + r * 3] = a0; S.dGR[p * 9 + r * 3 + 1] = a1; S.dGR[p * 9 + r * 3 + 2] = a2;
-                S.dGt[p * 3 + r] = at;
-            }
-            __syncthreads();
-        }
+        BF_SYNC();
 
-        // ================= phase J: dL/dR_i and dL/d(rel_i) per joint column
-        for (int idx = tid; idx < nj * 3; idx += nt) {
-            int i = idx / 3, b = idx % 3;
-            if (i == 0) {
+        // ================= phase H: dL/dGR_p (total) = (D_p GR_p^T + sum over strict subtree of N_i) GR_p, row cr
+        if (c_on) {
+#pragma unroll
+            for (int k = 0; k < nj; ++k)
+                if ((cmask >> k) & 1ull) { dg0 += S.N[k * 9 + cr * 3]; dg1 += S.N[k * 9 + cr * 3 + 1]; dg2 += S.N[k * 9 + cr * 3 + 2]; }
+            S.dGR[ci * 9 + cr * 3] = dg0 * GR_(ci, 0, 0) + dg1 * GR_(ci, 1, 0) + dg2 * GR_(ci, 2, 0);
+            S.dGR[ci * 9 + cr * 3 + 1] = dg0 * GR_(ci, 0, 1) + dg1 * GR_(ci, 1, 1) + dg2 * GR_(ci, 2, 1);
+            S.dGR[ci * 9 + cr * 3 + 2] = dg0 * GR_(ci, 0, 2) + dg1 * GR_(ci, 1, 2) + dg2 * GR_(ci, 2, 2);
+        }
+        BF_SYNC();
+
+        // ================= phase I: dL/dR_i and dL/d(rel_i) per joint column (cr plays the column b)
+        if (c_on) {
+            const int b = cr;
+            if (ci == 0) {
                 S.dR[b] = S.dGR[b]; S.dR[3 + b] = S.dGR[3 + b]; S.dR[6 + b] = S.dGR[6 + b];
-                S.drel[b] = S.dGt[b];
+                S.drel[b] = S.tt[b];
             } else {
-                int p = S.parents[i];
-                const float *Gp = S.GR + p * 9;
-                float c0 = S.dGR[i * 9 + b], c1 = S.dGR[i * 9 + 3 + b], c2 = S.dGR[i * 9 + 6 + b];
-                int pf = (i - 1) * 9;
-                S.dR[i * 9 + b] = Gp[0] * c0 + Gp[3] * c1 + Gp[6] * c2 + S.dfeat[pf + b];
-                S.dR[i * 9 + 3 + b] = Gp[1] * c0 + Gp[4] * c1 + Gp[7] * c2 + S.dfeat[pf + 3 + b];
-                S.dR[i * 9 + 6 + b] = Gp[2] * c0 + Gp[5] * c1 + Gp[8] * c2 + S.dfeat[pf + 6 + b];
-                S.drel[idx] = Gp[b] * S.dGt[i * 3] + Gp[3 + b] * S.dGt[i * 3 + 1] + Gp[6 + b] * S.dGt[i * 3 + 2];
+                float c0 = S.dGR[ci * 9 + b], c1 = S.dGR[ci * 9 + 3 + b], c2 = S.dGR[ci * 9 + 6 + b];
+                int pf = (ci - 1) * 9;
+                S.dR[ci * 9 + b] = GR_(cp, 0, 0) * c0 + GR_(cp, 1, 0) * c1 + GR_(cp, 2, 0) * c2 + S.dfeat[pf + b];
+                S.dR[ci * 9 + 3 + b] = GR_(cp, 0, 1) * c0 + GR_(cp, 1, 1) * c1 + GR_(cp, 2, 1) * c2 + S.dfeat[pf + 3 + b];
+                S.dR[ci * 9 + 6 + b] = GR_(cp, 0, 2) * c0 + GR_(cp, 1, 2) * c1 + GR_(cp, 2, 2) * c2 + S.dfeat[pf + 6 + b];
+                S.drel[tid] = GR_(cp, 0, b) * S.tt[ci * 3] + GR_(cp, 1, b) * S.tt[ci * 3 + 1] + GR_(cp, 2, b) * S.tt[ci * 3 + 2];
             }
         }
-        __syncthreads();
+        BF_SYNC();
 
-        // ================= phase K: Rodrigues reverse; geometric part of dL/dbeta
+        // ================= phase J: Rodrigues reverse (wave 0) | geometric part of dL/dbeta (waves 1-3)
         if (tid < nj) {
-            rodrigues_bwd(theta_of(S.params, T, tid, 0), theta_of(S.params, T, tid, 1),
-                          theta_of(S.params, T, tid, 2), S.rc + tid * 4, S.dR + tid * 9, S.gth + tid * 3);
+            rodrigues_bwd(theta_of(Pcur, T, tid, 0), theta_of(Pcur, T, tid, 1), theta_of(Pcur, T, tid, 2),
+                          S.rc + tid * 4, S.dR + tid * 9, S.gth + tid * 3);
         }
-        if (tid >= 64) {
+        if (wave >= 1 && wave < 4) {
             // 16 lanes per beta component: sum Jd.dJ + Jdrel.drel + sel_sd.dvp
             int q = tid - 64, l = q >> 4, sl = q & 15;
             float acc = 0.f;
             if (l < nb) {
-                for (int i = sl; i < nj * 3; i += 16) acc += S.Jd[i * nb + l] * S.dJ[i] + S.Jdrel[i * nb + l] * S.drel[i];
-                for (int o = sl; o < ns * 3; o += 16) acc += S.sel_sd[o * nb + l] * S.dvp[o];
+                for (int i = sl; i < nj3; i += 16) acc += S.Jd[i * nb + l] * S.dJ[i] + S.Jdrel[i * nb + l] * S.drel[i];
+                for (int o = sl; o < ns3; o += 16) acc += S.sel_sd[o * nb + l] * S.dvp[o];
             }
             acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
             if (l < nb && sl == 0) S.g[T.off_beta + l] = acc;
         }
-        __syncthreads();
+        BF_SYNC();
 
-        // ================= phase L: priors, gradient assembly, Adam (one parameter per thread)
+        // ================= phase K: priors, gradient assembly, Adam (one parameter per thread)
         int mstar = 0;
         float qmin = S.gq[0];
 #pragma unroll
         for (int m = 1; m < BF_GMM_M; ++m) { float q = S.gq[m]; if (q < qmin) { qmin = q; mstar = m; } }
         float grad = 0.f, pval = 0.f;
         if (tid < np) {
-            pval = S.params[tid];
+            pval = Pcur[tid];
             if (tid < 4) grad = S.g[tid];
             else if (tid < T.off_beta) {
                 int ip = tid - T.off_pose;
                 grad = S.gth[3 + ip] + hp.w_pose * S.gy[mstar * BF_GMM_LD + ip];
-                // angle prior exp(theta * sign)^2 on dofs 52, 55, 9, 12 (loss.py:54-61)
-                float sg = ip == 52 ? 1.f : ((ip == 55 || ip == 9 || ip == 12) ? -1.f : 0.f);
-                if (sg != 0.f) { float e = expf(pval * sg); grad += hp.w_angle * 2.f * e * e * sg; }
+                if (ang_sg != 0.f) { float e = expf(pval * ang_sg); grad += hp.w_angle * 2.f * e * e * ang_sg; }
             } else if (tid < T.off_orient) {
                 grad = S.g[tid] + 2.f * hp.w_shape * pval;
             } else grad = S.gth[tid - T.off_orient];
@@ -538,7 +632,7 @@ bf_fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const fl
                 const int ai[4] = {52, 55, 9, 12};
                 const float as[4] = {1.f, -1.f, -1.f, -1.f};
                 for (int k = 0; k < 4; ++k) {
-                    float th = ai[k] < T.nbp ? S.params[T.off_pose + ai[k]] : 0.f;
+                    float th = ai[k] < T.nbp ? Pcur[T.off_pose + ai[k]] : 0.f;
                     float e = expf(th * as[k]);
                     acc += e * e;
                 }
@@ -546,28 +640,25 @@ bf_fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const fl
             }
             if (tid == 128) {
                 float acc = 0.f;
-                for (int l = 0; l < nb; ++l) acc += S.params[T.off_beta + l] * S.params[T.off_beta + l];
+                for (int l = 0; l < nb; ++l) acc += Pcur[T.off_beta + l] * Pcur[T.off_beta + l];
                 io.terms[(size_t)frame * 4 + 3] = hp.w_shape * acc;
             }
             StateView st = bf_state_view(io.state + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
-            for (int i = tid; i < nj * 9; i += nt) st.GR[i] = S.GR[i];
-            for (int i = tid; i < nj * 3; i += nt) { st.At[i] = S.At[i]; st.Gt[i] = S.Gt[i]; st.theta[i] = theta_of(S.params, T, i / 3, i % 3); }
-            for (int p = tid; p < npf; p += nt) {
-                int j = 1 + p / 9, e = p % 9;
-                st.feat[p] = S.R[j * 9 + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
-            }
-            if (tid < nb) st.beta[tid] = S.params[T.off_beta + tid];
-            if (tid < 3) st.t[tid] = S.params[tid];
-            if (tid == 3) { st.sc[0] = S.params[3]; st.sc[1] = hp.cscale; }
+            for (int i = tid; i < nj * 9; i += NG) { int j = i / 9, e = i - j * 9; st.GR[i] = GR_(j, e / 3, e % 3); }
+            for (int i = tid; i < nj3; i += NG) { st.At[i] = S.At[i]; st.Gt[i] = GT_(i / 3, i % 3); st.theta[i] = theta_of(Pcur, T, i / 3, i % 3); }
+            for (int p = tid; p < npf; p += NG) st.feat[p] = S.feat[p];
+            if (tid < nb) st.beta[tid] = Pcur[T.off_beta + tid];
+            if (tid < 3) st.t[tid] = Pcur[tid];
+            if (tid == 3) { st.sc[0] = Pcur[3]; st.sc[1] = hp.cscale; }
             if (io.grads && tid < np) io.grads[(size_t)frame * np + tid] = grad;
         }
-        if (io.debug && it == 0 && frame == 0) {
+        if (io.debug && it == 0 && frame == 0 && mode == 1) {
             float *d = io.debug;
             int o = 0;
-            auto dump = [&](const float *src, int n) { for (int i = tid; i < n; i += nt) d[o + i] = src[i]; o += n; };
-            dump(S.R, nj * 9); dump(S.J, nj * 3); dump(S.GR, nj * 9); dump(S.Gt, nj * 3); dump(S.vp, ns * 3);
-            dump(S.vsel, ns * 3); dump(S.dXw, nl * 4); dump(S.dGR, nj * 9); dump(S.dGt, nj * 3); dump(S.dR, nj * 9);
-            dump(S.gth, nj * 3); dump(S.gq, BF_GMM_M); dump(S.dfeat, npf); dump(S.dJ, nj * 3); dump(S.drel, nj * 3);
+            auto dump = [&](const float *src, int n) { for (int i = tid; i < n; i += NG) d[o + i] = src[i]; o += n; };
+            dump(S.R, nj * 9); dump(S.J, nj3); dump(S.G, nj * 12); dump(S.vp, ns3);
+            dump(S.vsel, ns3); dump(S.g, 4); dump(S.dGR, nj * 9); dump(S.tt, nj3); dump(S.dR, nj * 9);
+            dump(S.gth, nj3); dump(S.gq, BF_GMM_M); dump(S.dfeat, npf); dump(S.dJ, nj3); dump(S.drel, nj3);
         }
         if (mode == 0 && tid < np) {
             // torch.optim.Adam, single-tensor path
@@ -576,21 +667,40 @@ bf_fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const fl
             av = av * hp.beta2 + (1.0f - hp.beta2) * grad * grad;
             float denom = sqrtf(av) / at[2] + hp.eps;
             float step = tid < 4 ? at[0] : at[1];
-            pval = pval - step * (am / denom);
+            Pnext[tid] = pval - step * (am / denom);
         }
-        __syncthreads();
-        if (mode == 0 && tid < np) S.params[tid] = pval;
-        __syncthreads();
+        BF_SYNC();
+        if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
+    }
+
     }
 
     if (mode == 0 && tid < np) {
-        io.params[(size_t)frame * np + tid] = S.params[tid];
+        io.params[(size_t)frame * np + tid] = Pcur[tid];
         io.adam_m[(size_t)frame * np + tid] = am;
         io.adam_v[(size_t)frame * np + tid] = av;
     }
 }
 
-extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int np, int nviews, int n_levels) {
+extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int np, int nviews) {
     FitSmem s;
-    return fit_smem_carve(s, nullptr, nj, nb, npf, ns, nl, np, nviews, n_levels);
+    return fit_smem_carve(s, nullptr, nj, nb, npf, ns, nl, np, nviews);
+}
+
+// Host-side launcher: picks the compile-time-sized instantiation for SMPL, the table-driven one otherwise.
+extern "C" hipError_t bf_fit_launch(const FitTab *T, const FrameIO *io, const HyperDev *hp, int n_iters, int mode,
+                                    const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
+    const bool smpl = T->nj == 24 && T->nb == 10 && T->ns == 11 && T->nl == 25;
+    auto k_smpl = fit_kernel<24, 10, 11, 25>;
+    auto k_any = fit_kernel<0, 0, 0, 0>;
+    auto kern = smpl ? k_smpl : k_any;
+    static size_t attr_smpl = 0, attr_any = 0;
+    size_t &have = smpl ? attr_smpl : attr_any;
+    if (smem > 64 * 1024 && smem > have) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        have = smem;
+    }
+    hipLaunchKernelGGL(kern, dim3(io->n_frames), dim3(BF_FIT_THREADS), smem, stream, *T, *io, *hp, n_iters, mode, adam_tab, adam_t0);
+    return hipGetLastError();
 }

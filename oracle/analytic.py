@@ -211,7 +211,7 @@ def loss_grad(tab, gmm_bufs, views, params, c=0.3, imsize=512):
              "global_orient": g_theta[0]}
     aux = {"joints25_world": Xw, "gmm_component": mstar, "q": q,
            # intermediates in the order csrc/fit_kernels.hip dumps them (debug hook)
-           "dump": [R, J, GR, Gt, vp, vsel, np.concatenate([dXw, np.zeros((len(dXw), 1), dt)], 1), dGR, dGt, dR,
+           "dump": [R, J, GR, Gt, vp, vsel, np.concatenate([g_t, [g_s]]), dGR, dGt, dR,
                     g_theta, q, dfeat, dJ_direct, drel_all]}
     return float(loss), {k: float(v) for k, v in terms.items()}, grads, aux
 

@@ -10,7 +10,7 @@ from bodyfitting_amd import native as N          # noqa: E402
 from bodyfitting_amd import synthetic as S       # noqa: E402
 from oracle import analytic as A                 # noqa: E402
 
-NAMES = ["R", "J", "GR", "Gt", "vp", "vsel", "dXw(+loss)", "dGR", "dGt", "dR", "gth", "q", "dfeat", "dJ", "drel"]
+NAMES = ["R", "J", "G=[GR|Gt]", "vp", "vsel", "g_t,g_s", "dGR", "dGt", "dR", "gth", "q", "dfeat", "dJ", "drel"]
 
 
 def main():
@@ -31,14 +31,14 @@ def main():
     tab, views = A.build_fit_tables(model), A.build_views(prob)
     loss, t64, g64, aux = A.loss_grad(tab, gb, views, params)
     print("terms gpu", terms[0], "oracle", list(t64.values()))
+    d = aux["dump"]
+    aux["dump"] = d[:2] + [np.concatenate([d[2], d[3][:, :, None]], 2)] + d[4:]      # kernel keeps rows [GR_r | Gt_r]
     sizes = [a.size for a in aux["dump"]]
     dump = b.debug_dump(int(sum(sizes)))
     o = 0
     for name, ref in zip(NAMES, aux["dump"]):
         got = dump[o:o + ref.size].reshape(ref.shape)
         o += ref.size
-        if name.startswith("dXw"):
-            got, ref = got[:, :3], ref[:, :3]
         err = np.abs(got - ref).max()
         print(f"{name:12s} max|ref|={np.abs(ref).max():.4e} maxerr={err:.3e} rel={err / (np.abs(ref).max() + 1e-30):.2e}")
     got = N.split_params(grads[0])

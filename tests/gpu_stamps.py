@@ -1,0 +1,23 @@
+"""Bring-up helper (not a test): per-phase cycle stamps of one fit iteration from the -DBF_STAMP build.
+    BODYFIT_LIB=bodyfitting_amd/libbodyfit_stamp.so python tests/gpu_stamps.py"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bodyfitting_amd import native as N, synthetic as S   # noqa: E402
+
+model, gmm = S.make_model("smpl"), S.make_gmm()
+dev = N.DeviceModel(model, gmm)
+c2w, K, kp, ndiv, betas, pose = N.pack_problem([S.make_problem(model, 0, 48)])
+b = N.FrameBatch(dev, 1, 48)
+b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+for rep in range(3):
+    b.reset(); b.fit(100); b.sync()
+    d = b.debug_dump(4096 + 96)[4096:]
+    n = int(np.max(np.nonzero(d)[0])) + 1 if np.any(d) else 0
+    st = d[:n]
+    print("rep", rep, "timing", b.last_timing())
+    print("  cumulative cycles after each barrier:", [int(x) for x in st])
+    print("  per-phase:", [int(x) for x in np.diff(np.concatenate([[0], st]))])
