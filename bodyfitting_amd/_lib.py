@@ -64,6 +64,12 @@ SIGNATURES = {
     "bf_batch_sync": (C.c_int, [_VP]),
     "bf_batch_get_result": (C.c_int, [_VP, _FP, _FP, _FP, _FP]),
     "bf_batch_export_params_dev": (C.c_int, [_VP, _VP]),
+    "bf_scan_create": (C.c_int, [C.c_int, C.c_int, _FP, C.c_int, _IP, C.POINTER(_VP)]),
+    "bf_scan_destroy": (None, [_VP]),
+    "bf_scan_height": (C.c_float, [_VP]),
+    "bf_scan_grid_info": (C.c_int, [_VP, _IP, _FP]),
+    "bf_scan_nearest": (C.c_int, [_VP, C.c_int, _FP, _IP, _FP, _FP]),
+    "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
     "bf_batch_last_timing": (C.c_int, [_VP, _FP]),
     "bf_batch_timing_reset": (C.c_int, [_VP]),
     "bf_batch_timing_sum": (C.c_int, [_VP, _FP, _IP]),

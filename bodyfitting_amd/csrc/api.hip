@@ -1,94 +1,19 @@
 // Host side of libbodyfit: the C ABI of include/bodyfit.h over the gfx950 kernels.
-#include "../../include/bodyfit.h"
-#include "bf_internal.h"
-
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
+#include "bf_host.h"
 
 extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
-extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *);
-extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *);
-extern "C" __global__ void bf_joints_kernel(MeshTab, const float *, const float *, float *, float *);
+extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
+extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *);
+extern "C" __global__ void bf_joints_kernel(MeshTab, const float *, const float *, const float *, float *, float *);
 extern "C" size_t bf_fit_smem_bytes(int, int, int, int, int, int, int);
 extern "C" size_t bf_mesh_smem_bytes(int, int, int);
 
-namespace {
-
-thread_local std::string g_err;
-
-int fail(int code, const std::string &msg) {
-    g_err = msg;
-    return code;
-}
-
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess)                                                                      \
-            return fail(BF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
-    } while (0)
-
-template <class T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    hipError_t alloc(size_t count) {
-        n = count;
-        return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
-    }
-    hipError_t upload(const std::vector<T> &h) {
-        hipError_t e = alloc(h.size());
-        if (e != hipSuccess) return e;
-        return h.empty() ? hipSuccess : hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
-    }
-    ~DevBuf() { if (p) (void)hipFree(p); }
-};
-
-}  // namespace
-
-struct bf_model {
-    int device = 0;
-    int nv = 0, nj = 0, nb = 0, npf = 0, ns = 0, nl = 0, np = 0, n_levels = 0;
-    int n_selector = 0, n_extra = 0, n_joint_map = 0;
-    FitTab fit{};
-    MeshTab mesh{};
-    size_t fit_smem = 0, mesh_smem = 0;
-    DevBuf<float> v_template, shapedirs, posedirs, lbs_weights, j_extra;
-    DevBuf<int> selector_ids, joint_map;
-    DevBuf<int> depth_d;
-    DevBuf<unsigned long long> desc_d;
-    DevBuf<float> g_plane, g_ptail;
-    DevBuf<int> parents, level_start, level_joints, child_start, child_list, lj_kind, lj_index;
-    DevBuf<float> Jt, Jd, Jdrel, sel_vt, sel_sd, sel_pd, sel_w, g_means, g_psym, g_logw;
-};
-
-struct bf_batch {
-    bf_model *m = nullptr;
-    int F = 0, V = 0;
-    hipStream_t stream = nullptr;
-    static constexpr int kRing = 1024;
-    std::vector<hipEvent_t> ring;   // kRing x 4 events: | fit | mesh | joints + fetch |
-    int ring_n = 0;                 // calls recorded since the last timing reset
-    hipEvent_t *ev = nullptr;       // the triple of the last call
-    bool timed = false;
-    DevBuf<float> params0;          // parameters of the last set_init / set_params
-    float *h_params = nullptr, *h_vout = nullptr, *h_joints = nullptr, *h_terms = nullptr, *h_state = nullptr;
-    bool fetched = false;
-    int steps_done = 0;
-    bf_hyper adam_hyper{};
-    int adam_cap = 0;
-    DevBuf<float> proj, keypoints, params, adam_m, adam_v, grads, terms, state, vraw, vout, joints, adam_tab, debug;
-    DevBuf<int> ndiv;
-    bool have_result = false;
-};
+std::string &bf_err_slot() { thread_local std::string e; return e; }
+int bf_fail(int code, const std::string &msg) { bf_err_slot() = msg; return code; }
 
 extern "C" {
 
-const char *bf_last_error(void) { return g_err.c_str(); }
+const char *bf_last_error(void) { return bf_err_slot().c_str(); }
 const char *bf_version(void) { return "bodyfit-mi355x 0.1 (gfx950)"; }
 
 int bf_device_count(void) {
@@ -221,6 +146,20 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         }
         for (int j = 0; j < nj; ++j) sel_w[(size_t)s * nj + j] = d->lbs_weights[(size_t)v * nj + j];
     }
+    std::vector<float> nzw((size_t)ns * BF_SEL_NNZ, 0.f);
+    std::vector<int> nzj((size_t)ns * BF_SEL_NNZ, 0);
+    int sel_nnz = 0;
+    for (int s = 0; s < ns; ++s) {
+        int c = 0;
+        for (int j = 0; j < nj; ++j) {
+            float w = sel_w[(size_t)s * nj + j];
+            if (w == 0.f) continue;
+            if (c < BF_SEL_NNZ) { nzw[(size_t)s * BF_SEL_NNZ + c] = w; nzj[(size_t)s * BF_SEL_NNZ + c] = j; }
+            ++c;
+        }
+        sel_nnz = std::max(sel_nnz, c);
+    }
+    if (sel_nnz > BF_SEL_NNZ) sel_nnz = 0;
     // ---- GMM: symmetrised precisions and -log of the merged weights (prior.py:188-189) ---------
     const int M = BF_GMM_M, D = BF_GMM_D;
     std::vector<float> psym((size_t)M * D * D), logw(M), means(d->gmm_means, d->gmm_means + (size_t)M * D);
@@ -257,6 +196,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     up_f(m->v_template, d->v_template, (size_t)nv * 3);
     up_f(m->shapedirs, d->shapedirs, (size_t)nv * 3 * nb);
     up_f(m->posedirs, d->posedirs, (size_t)npf * 3 * nv);
+    m->posedirs_host.assign(d->posedirs, d->posedirs + (size_t)npf * 3 * nv);
     up_f(m->lbs_weights, d->lbs_weights, (size_t)nv * nj);
     up_f(m->j_extra, d->j_regressor_extra, (size_t)d->n_extra * nv);
     up_vi(m->selector_ids, std::vector<int>(d->selector_ids, d->selector_ids + d->n_selector));
@@ -266,7 +206,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         for (int j = nj - 1; j >= 1; --j) desc[parents[j]] |= desc[j] | (1ull << j);
         okay = okay && m->desc_d.upload(desc) == hipSuccess;
     }
-    up_vi(m->depth_d, depth); up_vf(m->g_plane, plane); up_vf(m->g_ptail, ptail);
+    up_vi(m->depth_d, depth); up_vf(m->sel_nzw, nzw); up_vi(m->sel_nzj, nzj); up_vf(m->g_plane, plane); up_vf(m->g_ptail, ptail);
     up_vi(m->parents, parents); up_vi(m->level_start, level_start); up_vi(m->level_joints, level_joints);
     up_vi(m->child_start, child_start); up_vi(m->child_list, child_list);
     up_vi(m->lj_kind, lj_kind); up_vi(m->lj_index, lj_index);
@@ -279,6 +219,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     T.nj = nj; T.nb = nb; T.npf = npf; T.ns = ns; T.nl = m->nl; T.np = m->np; T.n_levels = n_levels;
     T.nbp = 3 * (nj - 1);
     T.off_pose = 4; T.off_beta = 4 + 3 * (nj - 1); T.off_orient = T.off_beta + nb;
+    T.sel_nnz = sel_nnz; T.sel_nzw = m->sel_nzw.p; T.sel_nzj = m->sel_nzj.p;
     T.depth = m->depth_d.p; T.desc = m->desc_d.p; T.g_plane = m->g_plane.p; T.g_ptail = m->g_ptail.p;
     T.parents = m->parents.p; T.level_start = m->level_start.p; T.level_joints = m->level_joints.p;
     T.child_start = m->child_start.p; T.child_list = m->child_list.p;
@@ -292,6 +233,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     Q.v_template = m->v_template.p; Q.shapedirs = m->shapedirs.p; Q.posedirs = m->posedirs.p;
     Q.lbs_weights = m->lbs_weights.p; Q.j_extra = m->j_extra.p;
     Q.selector_ids = m->selector_ids.p; Q.joint_map = m->joint_map.p;
+    Q.n_tiles = (nv + BF_MESH_TILE - 1) / BF_MESH_TILE;
     m->mesh_smem = bf_mesh_smem_bytes(nj, npf, nb);
     *out = m;
     return BF_OK;
@@ -300,16 +242,16 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
 void bf_model_destroy(bf_model *m) { delete m; }
 int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
 
-static int launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *joints,
-                       float *joints_ori, hipStream_t stream, hipEvent_t after_mesh = nullptr) {
-    dim3 grid((m->nv + BF_MESH_TILE - 1) / BF_MESH_TILE, n);
+int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
+                   float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed) {
+    dim3 grid(m->mesh.n_tiles, n);
     hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, m->mesh,
-                       state_dev, vraw, vout);
+                       state_dev, vraw, vout, (joints || joints_ori) ? xpart : (float *)nullptr, vposed);
     HIP_TRY(hipGetLastError());
     if (after_mesh) HIP_TRY(hipEventRecord(after_mesh, stream));
     if (joints || joints_ori) {
         hipLaunchKernelGGL(bf_joints_kernel, dim3(n), dim3(256), 0, stream, m->mesh, state_dev, (const float *)vraw,
-                           joints, joints_ori);
+                           (const float *)xpart, joints, joints_ori);
         HIP_TRY(hipGetLastError());
     }
     return BF_OK;
@@ -321,18 +263,20 @@ int bf_smpl_forward(bf_model *m, int n, const float *betas, const float *global_
     HIP_TRY(hipSetDevice(m->device));
     const int nj = m->nj, nb = m->nb, nv = m->nv;
     const size_t stride = bf_state_stride(nj, m->npf, nb);
-    DevBuf<float> d_beta, d_or, d_bp, d_state, d_vraw, d_j, d_jo;
+    DevBuf<float> d_beta, d_or, d_bp, d_state, d_vraw, d_j, d_jo, d_xp;
     HIP_TRY(d_beta.upload(std::vector<float>(betas, betas + (size_t)n * nb)));
     HIP_TRY(d_or.upload(std::vector<float>(global_orient, global_orient + (size_t)n * 3)));
     HIP_TRY(d_bp.upload(std::vector<float>(body_pose, body_pose + (size_t)n * 3 * (nj - 1))));
     HIP_TRY(d_state.alloc((size_t)n * stride));
     HIP_TRY(d_vraw.alloc((size_t)n * nv * 3));
+    HIP_TRY(d_xp.alloc((size_t)n * m->mesh.n_tiles * m->n_extra * 3));
     HIP_TRY(d_j.alloc((size_t)n * m->n_joint_map * 3));
     HIP_TRY(d_jo.alloc((size_t)n * (nj + m->n_selector) * 3));
     hipLaunchKernelGGL(bf_pose_state_kernel, dim3(n), dim3(128), 0, 0, m->fit, (const float *)d_beta.p,
-                       (const float *)d_or.p, (const float *)d_bp.p, (const float *)nullptr, d_state.p);
+                       (const float *)d_or.p, (const float *)d_bp.p, (const float *)nullptr, d_state.p,
+                       (const float *)nullptr, (const float *)nullptr, 1.0f);
     HIP_TRY(hipGetLastError());
-    int rc = launch_mesh(m, n, d_state.p, d_vraw.p, nullptr, d_j.p, d_jo.p, 0);
+    int rc = bf_launch_mesh(m, n, d_state.p, d_vraw.p, nullptr, d_xp.p, d_j.p, d_jo.p, 0, nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     if (vertices) HIP_TRY(hipMemcpy(vertices, d_vraw.p, (size_t)n * nv * 3 * sizeof(float), hipMemcpyDeviceToHost));
@@ -369,6 +313,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
     ok = ok && b->state.alloc(F * bf_state_stride(m->nj, m->npf, m->nb)) == hipSuccess;
     ok = ok && b->vraw.alloc(F * m->nv * 3) == hipSuccess && b->vout.alloc(F * m->nv * 3) == hipSuccess;
     ok = ok && b->joints.alloc(F * m->n_joint_map * 3) == hipSuccess;
+    ok = ok && b->xpart.alloc(F * m->mesh.n_tiles * std::max(m->n_extra, 1) * 3) == hipSuccess;
     ok = ok && b->debug.alloc(8192) == hipSuccess;
     if (ok) {
         ok = hipMemset(b->adam_m.p, 0, F * np * sizeof(float)) == hipSuccess &&
@@ -502,7 +447,7 @@ int bf_batch_get_params(bf_batch *b, float *params) {
     return BF_OK;
 }
 
-static HyperDev to_dev(const bf_hyper &h) {
+HyperDev bf_to_dev(const bf_hyper &h) {
     HyperDev d;
     d.sigma2 = h.sigma * h.sigma;
     d.w_pose = h.pose_prior_weight * h.pose_prior_weight;
@@ -536,7 +481,7 @@ static int ensure_adam_tab(bf_batch *b, const bf_hyper &h, int upto) {
     return BF_OK;
 }
 
-static FrameIO frame_io(bf_batch *b, bool want_grads) {
+FrameIO bf_frame_io(bf_batch *b, bool want_grads) {
     FrameIO io;
     io.n_frames = b->F; io.n_views = b->V;
     io.proj = b->proj.p; io.keypoints = b->keypoints.p; io.ndiv = b->ndiv.p;
@@ -544,6 +489,8 @@ static FrameIO frame_io(bf_batch *b, bool want_grads) {
     io.grads = want_grads ? b->grads.p : nullptr;
     io.terms = b->terms.p; io.state = b->state.p;
     io.debug = b->debug.p;
+    io.cscale = b->cscale.p;          // null unless scans are attached
+    io.ext = nullptr;
     return io;
 }
 
@@ -555,23 +502,32 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (hyper) h = *hyper; else bf_hyper_default(&h);
     int rc = ensure_adam_tab(b, h, b->steps_done + n_iters);
     if (rc) return rc;
-    HyperDev hd = to_dev(h);
-    FrameIO io = frame_io(b, false);
+    HyperDev hd = bf_to_dev(h);
+    FrameIO io = bf_frame_io(b, false);
+    if (!b->scans.empty()) flags &= ~BF_FIT_DENSE;
     const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES);
     b->ev = b->ring.data() + (size_t)(b->ring_n % bf_batch::kRing) * 4;
     HIP_TRY(hipEventRecord(b->ev[0], b->stream));
-    if (!dense) {
+    if (!b->scans.empty()) {
+        rc = bf_fit_with_scans(b, n_iters, h, hd, io);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+        if (want_v) {
+            rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, b->ev[2], nullptr);
+            if (rc) return rc;
+        } else HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+    } else if (!dense) {
         HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_iters, 0, b->adam_tab.p, b->steps_done, m->fit_smem, b->stream));
         HIP_TRY(hipEventRecord(b->ev[1], b->stream));
         if (want_v) {
-            rc = launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->joints.p, nullptr, b->stream, b->ev[2]);
+            rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, b->ev[2], nullptr);
             if (rc) return rc;
         } else HIP_TRY(hipEventRecord(b->ev[2], b->stream));
     } else {
         // reference-literal schedule: every iteration evaluates the whole mesh (smplify.py:179-190)
         for (int it = 0; it < n_iters; ++it) {
             HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
-            rc = launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->joints.p, nullptr, b->stream);
+            rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
             if (rc) return rc;
         }
         HIP_TRY(hipEventRecord(b->ev[1], b->stream));
@@ -605,8 +561,8 @@ int bf_loss_grad(bf_batch *b, const bf_hyper *hyper, float *terms, float *grads)
     if (hyper) h = *hyper; else bf_hyper_default(&h);
     int rc = ensure_adam_tab(b, h, 1);
     if (rc) return rc;
-    HyperDev hd = to_dev(h);
-    FrameIO io = frame_io(b, true);
+    HyperDev hd = bf_to_dev(h);
+    FrameIO io = bf_frame_io(b, true);
     HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, m->fit_smem, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (terms) HIP_TRY(hipMemcpy(terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));

@@ -1,0 +1,104 @@
+// Host-side private definitions shared by api.hip and scan_api.hip.
+#pragma once
+#include "../../include/bodyfit.h"
+#include "bf_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+std::string &bf_err_slot();
+int bf_fail(int code, const std::string &msg);
+#define fail bf_fail
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(BF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+    }
+    hipError_t upload(const std::vector<T> &h) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess) return e;
+        return h.empty() ? hipSuccess : hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+struct bf_model {
+    int device = 0;
+    int nv = 0, nj = 0, nb = 0, npf = 0, ns = 0, nl = 0, np = 0, n_levels = 0;
+    int n_selector = 0, n_extra = 0, n_joint_map = 0;
+    FitTab fit{};
+    MeshTab mesh{};
+    size_t fit_smem = 0, mesh_smem = 0;
+    DevBuf<float> v_template, shapedirs, posedirs, lbs_weights, j_extra;
+    DevBuf<int> selector_ids, joint_map;
+    DevBuf<int> depth_d, sel_nzj;
+    DevBuf<float> sel_nzw;
+    DevBuf<unsigned long long> desc_d;
+    DevBuf<float> g_plane, g_ptail;
+    DevBuf<int> parents, level_start, level_joints, child_start, child_list, lj_kind, lj_index;
+    DevBuf<float> Jt, Jd, Jdrel, sel_vt, sel_sd, sel_pd, sel_w, g_means, g_psym, g_logw;
+    DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass
+    std::vector<float> posedirs_host;
+    std::vector<int> faces_host;  // body-model topology (for the SMPL+D stage), optional
+};
+
+struct bf_batch {
+    bf_model *m = nullptr;
+    int F = 0, V = 0;
+    hipStream_t stream = nullptr;
+    static constexpr int kRing = 1024;
+    std::vector<hipEvent_t> ring;   // kRing x 4 events: | fit | mesh | joints + fetch |
+    int ring_n = 0;                 // calls recorded since the last timing reset
+    hipEvent_t *ev = nullptr;       // the triple of the last call
+    bool timed = false;
+    DevBuf<float> params0;          // parameters of the last set_init / set_params
+    float *h_params = nullptr, *h_vout = nullptr, *h_joints = nullptr, *h_terms = nullptr, *h_state = nullptr;
+    bool fetched = false;
+    int steps_done = 0;
+    bf_hyper adam_hyper{};
+    int adam_cap = 0;
+    DevBuf<float> proj, keypoints, params, adam_m, adam_v, grads, terms, state, vraw, vout, joints, adam_tab, debug, xpart;
+    DevBuf<int> ndiv;
+    bool have_result = false;
+    // dense vertex losses (use_mesh, smplify.py:146-156,205-206)
+    std::vector<struct bf_scan *> scans;
+    DevBuf<ScanDev> scan_dev;
+    DevBuf<float> cscale, pc_weight, pc_partial, pc_loss, dvout, vposed, cpts, ext_part, ext;
+    DevBuf<int> cface;
+    // SMPL+D stage (smplify.py:228-247)
+    DevBuf<float> disp, disp_m, disp_v, disp_base;
+    bool have_disp = false;
+};
+
+struct bf_scan {
+    int device = 0, nv = 0, nf = 0;
+    ScanDev dev{};
+    DevBuf<float> verts, face_norms;
+    DevBuf<int> faces, cell_start, cell_tris;
+};
+
+
+// shared between api.hip and scan_api.hip
+extern "C" {
+int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
+                   float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed);
+int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDev &hd, FrameIO io);
+HyperDev bf_to_dev(const bf_hyper &h);
+FrameIO bf_frame_io(bf_batch *b, bool want_grads);
+}
+extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);

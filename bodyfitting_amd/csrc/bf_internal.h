@@ -9,6 +9,7 @@
 #define BF_FIT_THREADS 512  // one workgroup (8 wave64, two per SIMD) per frame
 #define BF_VSUB 16          // view sub-slots in the projection phase (512 / 32)
 #define BF_KP_ROUNDS 3      // keypoints cached in registers for V <= 16*3 = 48 views
+#define BF_SEL_NNZ 8         // compacted skinning weights per selector vertex (real SMPL has <= 4)
 #define BF_MESH_TILE 32     // vertices per workgroup of the full-mesh forward
 #define BF_MESH_RG 8        // pose-feature row groups per workgroup (split-K inside the workgroup)
 
@@ -34,6 +35,9 @@ struct FitTab {
     const float *sel_sd;             // [ns*3][nb]
     const float *sel_pd;             // [npf][ns*3]   posedirs columns of the selector vertices
     const float *sel_w;              // [ns][nj]
+    int sel_nnz;                     // max non-zeros per row if <= BF_SEL_NNZ, else 0
+    const float *sel_nzw;            // [ns][BF_SEL_NNZ] non-zero weights in joint order, zero padded
+    const int *sel_nzj;              // [ns][BF_SEL_NNZ] their joints (padding points at joint 0)
     const float *g_means;            // [M][D]
     const float *g_psym;             // [M][D][D]     0.5 (P + P^T)
     const float *g_logw;             // [M]           -log(nll_weights)
@@ -52,6 +56,7 @@ struct MeshTab {
     const float *j_extra;            // [n_extra][nv]
     const int *selector_ids;         // [n_selector]
     const int *joint_map;            // [n_joint_map]
+    int n_tiles;                     // ceil(nv / BF_MESH_TILE)
 };
 
 // Per-frame pose state handed from the fit / pose-prep kernel to the mesh kernel.
@@ -75,6 +80,16 @@ __host__ __device__ inline StateView bf_state_view(float *base, int nj, int npf,
     return s;
 }
 
+// One scan mesh with its uniform search grid (device pointers).
+struct ScanDev {
+    int nv, nf, nx, ny, nz;
+    float ox, oy, oz, step, height;
+    const float *verts;       // [nv][3]
+    const int *faces;         // [nf][3]
+    const int *cell_start;    // [nx*ny*nz + 1], cell = (x*ny + y)*nz + z
+    const int *cell_tris;     // triangles per cell, ascending face id
+};
+
 struct FrameIO {
     int n_frames, n_views;
     const float *proj;        // [F][V][12]   K [R|t], world -> pixel
@@ -87,6 +102,8 @@ struct FrameIO {
     float *terms;             // [F][4]
     float *state;             // [F][state_stride]
     float *debug;             // optional dump of the first iteration's intermediates
+    const float *cscale;      // [F] per-frame constant scale (scan_height / 1.7, smplify.py:156) or null
+    const float *ext;         // [F][npf + nj*12 + nb + 4] gradients arriving from the dense vertex losses, or null
 };
 
 struct HyperDev {

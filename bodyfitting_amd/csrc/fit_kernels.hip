@@ -44,7 +44,8 @@ namespace {
 struct FitSmem {
     float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
-    float *Jt, *Jd, *Jdrel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj;
+    float *Jt, *Jd, *Jdrel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw;
+    int *nzj;
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
@@ -60,7 +61,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.vs = take(ns * 3);   s.vp = take(ns * 3);   s.TR = take(ns * 9);   s.vsel = take(ns * 3);
     s.part = take(BF_VSUB * 32 * 4);
     s.dvsel = take(ns * 3); s.dvp = take(ns * 3);
-    s.dGR = take(nj * 9);  s.dGt = take(nj * 3);  s.tt = take(nj * 3);   s.N = take(nj * 9);
+    s.dGR = take(nj * 9);  s.dGt = take(nj * 3);  s.tt = take(nj * 3);   s.N = take(nj * 12);
     s.dAt = take(nj * 3);  s.dJ = take(nj * 3);
     s.dR = take(nj * 9);   s.drel = take(nj * 3); s.dfeat = take(npf);   s.gth = take(nj * 3);
     s.g = take(np);
@@ -71,6 +72,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * nb); s.sel_pd = take(npf * ns * 3);
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
     s.proj = take(nviews * 12);
+    s.nzw = take(ns * BF_SEL_NNZ);  s.nzj = (int *)take(ns * BF_SEL_NNZ);
     (void)nl;
     return o * sizeof(float);
 }
@@ -173,6 +175,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     copy_f(S.sel_sd, T.sel_sd, ns3 * nb, tid, nt);
     copy_f(S.sel_pd, T.sel_pd, npf * ns3, tid, nt);
     copy_f(S.sel_w, T.sel_w, ns * nj, tid, nt);
+    for (int i = tid; i < ns * BF_SEL_NNZ; i += nt) { S.nzw[i] = T.sel_nzw[i]; S.nzj[i] = T.sel_nzj[i]; }
+    const int sel_nnz = T.sel_nnz;           // 0 = some selector vertex has more than BF_SEL_NNZ bones: dense loop
     for (int i = tid; i < BF_GMM_M * BF_GMM_LD; i += nt) {
         int m = i / BF_GMM_LD, j = i % BF_GMM_LD;
         S.means[i] = j < BF_GMM_D ? T.g_means[m * BF_GMM_D + j] : 0.f;
@@ -234,6 +238,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const float icoeff = 1.0f / hp.coeff;
     const float kscale = -1.0f / (hp.coeff * ndiv_f);
     const float s2 = hp.sigma2;
+    const float cscale = io.cscale ? io.cscale[frame] : hp.cscale;
+    const int EXT0 = npf, EXT_A = npf, EXT_B = npf + nj * 12, EXT_T = npf + nj * 12 + nb;
+    const float *ext = io.ext ? io.ext + (size_t)frame * (npf + nj * 12 + nb + 4) : nullptr;
+    (void)EXT0;
 
     // pose-blend role: (row slice sl, output column o of the selector vertices)
     const int NSL = ns3 <= nt ? nt / ns3 : 1;
@@ -263,7 +271,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     auto project = [&]() {
         {
         float tX = Pcur[0], tY = Pcur[1], tZ = Pcur[2];
-        float sc = Pcur[3] * hp.cscale;
+        float sc = Pcur[3] * cscale;
         float y0 = 0.f, y1 = 0.f, y2 = 0.f;
         if (j_on) { y0 = lsrc[0] + tX; y1 = lsrc[lstride] + tY; y2 = lsrc[2 * lstride] + tZ; }
         float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
@@ -370,7 +378,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 const float *row = S.sel_pd + p * ns3;
 #pragma unroll 11
                 for (int o = 0; o < ns3; ++o) acc += row[o] * S.dvp[o];
-                S.dfeat[p] = acc;
+                S.dfeat[p] = ext ? acc + ext[p] : acc;
             }
             BF_SYNC();                 // G
             BF_SYNC();                 // H
@@ -464,11 +472,16 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     vpb = S.vs[sv * 3 + b] + acc;
                     if (k == 0) S.vp[sv * 3 + b] = vpb;
                 }
-                const float *w = S.sel_w + sv * nj;
                 const float *A = b < 3 ? S.G + k * 4 + b : S.At + k;
                 const int stride = b < 3 ? 12 : 3;
+                if (sel_nnz > 0) {                 // the non-zero skinning weights only (exact: the rest add 0)
 #pragma unroll
-                for (int j = 0; j < nj; ++j) t += w[j] * A[j * stride];
+                    for (int q = 0; q < BF_SEL_NNZ; ++q) t += S.nzw[sv * BF_SEL_NNZ + q] * A[S.nzj[sv * BF_SEL_NNZ + q] * stride];
+                } else {
+                    const float *w = S.sel_w + sv * nj;
+#pragma unroll
+                    for (int j = 0; j < nj; ++j) t += w[j] * A[j * stride];
+                }
                 if (b < 3) S.TR[sv * 9 + k * 3 + b] = t;
             }
             float contrib = ok ? t * vpb : 0.f;
@@ -493,7 +506,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
             }
             a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
-            float sc = Pcur[3] * hp.cscale;
+            float sc = Pcur[3] * cscale;
             bool cnt = js < nl && h == 0;          // (jslot == js on both halves of waves 0 and 1)
             if (wave == 0) {
                 if (cnt) {
@@ -502,13 +515,16 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     atomicAdd(ldst + 2, a.z * sc);
                 }
                 float gt0 = wave_sum(cnt ? a.x : 0.f), gt1 = wave_sum(cnt ? a.y : 0.f), gt2 = wave_sum(cnt ? a.z : 0.f);
-                if (lane == 0) { S.g[0] = gt0 * sc; S.g[1] = gt1 * sc; S.g[2] = gt2 * sc; }   // d/d global_transl (smplify.py:189)
+                if (lane == 0) {                                                              // d/d global_transl (smplify.py:189)
+                    S.g[0] = gt0 * sc + (ext ? ext[EXT_T] : 0.f); S.g[1] = gt1 * sc + (ext ? ext[EXT_T + 1] : 0.f);
+                    S.g[2] = gt2 * sc + (ext ? ext[EXT_T + 2] : 0.f);
+                }
             } else {
                 float y0 = 0.f, y1 = 0.f, y2 = 0.f;
                 if (cnt) { y0 = lsrc[0] + Pcur[0]; y1 = lsrc[lstride] + Pcur[1]; y2 = lsrc[2 * lstride] + Pcur[2]; }
                 float gs = wave_sum(cnt ? a.x * y0 + a.y * y1 + a.z * y2 : 0.f);
                 float ls = wave_sum(cnt ? a.w : 0.f);
-                if (lane == 0) { S.g[3] = gs * hp.cscale; S.scal[0] = ls; }                   // d/d body_scale; sum conf^2 rho
+                if (lane == 0) { S.g[3] = gs * cscale + (ext ? ext[EXT_T + 3] : 0.f); S.scal[0] = ls; }                   // d/d body_scale; sum conf^2 rho
             }
         }
         BF_SYNC();
@@ -521,6 +537,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 float wd_ = S.sel_w[sv * nj + ci] * S.dvsel[sv * 3 + cr];
                 dat += wd_;
                 r0 += wd_ * S.vp[sv * 3]; r1 += wd_ * S.vp[sv * 3 + 1]; r2 += wd_ * S.vp[sv * 3 + 2];
+            }
+            if (ext) {                      // dense vertex losses: sum_v w_vj dv (x) [vp | 1] from bf_mesh_bwd_kernel
+                const float *ea = ext + EXT_A + ci * 12 + cr * 4;
+                r0 += ea[0]; r1 += ea[1]; r2 += ea[2]; dat += ea[3];
             }
             S.dAt[tid] = dat;
             S.dGt[tid] += dat;
@@ -540,8 +560,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         if (c_on) {
             float ttot = S.dGt[tid];
 #pragma unroll
-            for (int k = 0; k < nj; ++k)
-                if ((cmask >> k) & 1ull) ttot += S.dGt[k * 3 + cr];
+            for (int k = 0; k < nj; ++k) {             // unconditional loads, select on the subtree mask
+                float v = S.dGt[k * 3 + cr];
+                ttot += ((cmask >> k) & 1ull) ? v : 0.f;
+            }
             S.tt[tid] = ttot;
             float d0 = S.dGR[ci * 9 + cr * 3], d1 = S.dGR[ci * 9 + cr * 3 + 1], d2 = S.dGR[ci * 9 + cr * 3 + 2];
             dg0 = d0 * GR_(ci, 0, 0) + d1 * GR_(ci, 0, 1) + d2 * GR_(ci, 0, 2);     // row cr of D_i GR_i^T
@@ -549,9 +571,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             dg2 = d0 * GR_(ci, 2, 0) + d1 * GR_(ci, 2, 1) + d2 * GR_(ci, 2, 2);
             float u0 = 0.f, u1 = 0.f, u2 = 0.f;
             if (ci > 0) { u0 = GT_(ci, 0) - GT_(cp, 0); u1 = GT_(ci, 1) - GT_(cp, 1); u2 = GT_(ci, 2) - GT_(cp, 2); }
-            S.N[ci * 9 + cr * 3] = dg0 + ttot * u0;
-            S.N[ci * 9 + cr * 3 + 1] = dg1 + ttot * u1;
-            S.N[ci * 9 + cr * 3 + 2] = dg2 + ttot * u2;
+            float4 nrow = {dg0 + ttot * u0, dg1 + ttot * u1, dg2 + ttot * u2, 0.f};
+            *(float4 *)(S.N + (ci * 3 + cr) * 4) = nrow;
             S.dJ[tid] = -(GR_(ci, 0, cr) * S.dAt[ci * 3] + GR_(ci, 1, cr) * S.dAt[ci * 3 + 1] + GR_(ci, 2, cr) * S.dAt[ci * 3 + 2]);
         }
         BF_SYNC();
@@ -559,8 +580,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // ================= phase H: dL/dGR_p (total) = (D_p GR_p^T + sum over strict subtree of N_i) GR_p, row cr
         if (c_on) {
 #pragma unroll
-            for (int k = 0; k < nj; ++k)
-                if ((cmask >> k) & 1ull) { dg0 += S.N[k * 9 + cr * 3]; dg1 += S.N[k * 9 + cr * 3 + 1]; dg2 += S.N[k * 9 + cr * 3 + 2]; }
+            for (int k = 0; k < nj; ++k) {
+                float4 n = *(const float4 *)(S.N + (k * 3 + cr) * 4);
+                bool in = (cmask >> k) & 1ull;
+                dg0 += in ? n.x : 0.f; dg1 += in ? n.y : 0.f; dg2 += in ? n.z : 0.f;
+            }
             S.dGR[ci * 9 + cr * 3] = dg0 * GR_(ci, 0, 0) + dg1 * GR_(ci, 1, 0) + dg2 * GR_(ci, 2, 0);
             S.dGR[ci * 9 + cr * 3 + 1] = dg0 * GR_(ci, 0, 1) + dg1 * GR_(ci, 1, 1) + dg2 * GR_(ci, 2, 1);
             S.dGR[ci * 9 + cr * 3 + 2] = dg0 * GR_(ci, 0, 2) + dg1 * GR_(ci, 1, 2) + dg2 * GR_(ci, 2, 2);
@@ -598,7 +622,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 for (int o = sl; o < ns3; o += 16) acc += S.sel_sd[o * nb + l] * S.dvp[o];
             }
             acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
-            if (l < nb && sl == 0) S.g[T.off_beta + l] = acc;
+            if (l < nb && sl == 0) S.g[T.off_beta + l] = ext ? acc + ext[EXT_B + l] : acc;
         }
         BF_SYNC();
 
@@ -649,7 +673,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             for (int p = tid; p < npf; p += NG) st.feat[p] = S.feat[p];
             if (tid < nb) st.beta[tid] = Pcur[T.off_beta + tid];
             if (tid < 3) st.t[tid] = Pcur[tid];
-            if (tid == 3) { st.sc[0] = Pcur[3]; st.sc[1] = hp.cscale; }
+            if (tid == 3) { st.sc[0] = Pcur[3]; st.sc[1] = cscale; }
             if (io.grads && tid < np) io.grads[(size_t)frame * np + tid] = grad;
         }
         if (io.debug && it == 0 && frame == 0 && mode == 1) {

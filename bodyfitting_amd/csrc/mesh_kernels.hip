@@ -41,16 +41,21 @@ __device__ inline float m_wave_sum(float v) {
 
 // One 128-thread workgroup per parameter set.  betas[n][nb], orient[n][3], body_pose[n][3(nj-1)];
 // transl / scale are taken as (0,0,0) / 1 / 1 when `sim` is null, else sim[n][5] = t, s, c.
+// `packed` != null: read everything from the optimiser-order parameter block packed[n][np] instead
+// (transl, scale from it; constant scale from cscale[n] or cscale_all).
 extern "C" __global__ void __launch_bounds__(128)
 bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__restrict__ orient,
-                     const float *__restrict__ body_pose, const float *__restrict__ sim, float *state) {
+                     const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
+                     const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all) {
     __shared__ float R[64 * 9], J[64 * 3], GR[64 * 9], Gt[64 * 3];
     const int tid = threadIdx.x, nt = 128, f = blockIdx.x;
     const int nj = T.nj, nb = T.nb, npf = T.npf;
-    const float *beta = betas + (size_t)f * nb;
+    const float *pk = packed ? packed + (size_t)f * T.np : nullptr;
+    const float *beta = pk ? pk + T.off_beta : betas + (size_t)f * nb;
     StateView st = bf_state_view(state + (size_t)f * bf_state_stride(nj, npf, nb), nj, npf, nb);
     if (tid < nj) {
-        const float *th = tid == 0 ? orient + (size_t)f * 3 : body_pose + (size_t)f * 3 * (nj - 1) + 3 * (tid - 1);
+        const float *th = pk ? (tid == 0 ? pk + T.off_orient : pk + T.off_pose + 3 * (tid - 1))
+                             : (tid == 0 ? orient + (size_t)f * 3 : body_pose + (size_t)f * 3 * (nj - 1) + 3 * (tid - 1));
         m_rodrigues(th[0], th[1], th[2], R + tid * 9);
         st.theta[tid * 3] = th[0]; st.theta[tid * 3 + 1] = th[1]; st.theta[tid * 3 + 2] = th[2];
     }
@@ -89,13 +94,24 @@ bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__r
         st.feat[p] = R[j * 9 + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
     }
     if (tid < nb) st.beta[tid] = beta[tid];
-    if (tid < 3) st.t[tid] = sim ? sim[(size_t)f * 5 + tid] : 0.f;
-    if (tid == 3) { st.sc[0] = sim ? sim[(size_t)f * 5 + 3] : 1.f; st.sc[1] = sim ? sim[(size_t)f * 5 + 4] : 1.f; }
+    if (pk) {
+        if (tid < 3) st.t[tid] = pk[tid];
+        if (tid == 3) { st.sc[0] = pk[3]; st.sc[1] = cscale ? cscale[f] : cscale_all; }
+    } else {
+        if (tid < 3) st.t[tid] = sim ? sim[(size_t)f * 5 + tid] : 0.f;
+        if (tid == 3) { st.sc[0] = sim ? sim[(size_t)f * 5 + 3] : 1.f; st.sc[1] = sim ? sim[(size_t)f * 5 + 4] : 1.f; }
+    }
 }
 
 // grid (ceil(NV/32), F), block 96 x 8.  vraw = model-space vertices (lbs output), vout = (v + t) s c.
+// Every operand a thread will need is requested before the first barrier (posedirs slice by all
+// threads; lbs_weights row by row-group 0, shapedirs + template by row-group 1, the extra-regressor
+// slice by row-group 2), so the kernel pays one memory round trip instead of one per phase.
+#define BF_MESH_PF 26      // posedirs rows prefetched per thread (= ceil(207 / 8) for SMPL); more are streamed
+#define BF_MESH_WPF 24     // lbs weights prefetched per vertex thread
 extern "C" __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
-bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ vraw, float *__restrict__ vout) {
+bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ vraw, float *__restrict__ vout,
+               float *__restrict__ xpart, float *__restrict__ vposed) {
     constexpr int COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
@@ -111,12 +127,38 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
     const int ncols = 3 * nv;
     const int gcol = blockIdx.x * COLS + col;
     const bool ok = gcol < ncols;
+    const int vl = col / 3, k = col - vl * 3, v = blockIdx.x * BF_MESH_TILE + vl;
 
-    // issue this thread's slice of the posedirs stream first: every load is independent
+    // ---- request everything ------------------------------------------------------------------
     const int rows = (npf + BF_MESH_RG - 1) / BF_MESH_RG;
     const int p0 = rg * rows, p1 = min(npf, p0 + rows);
     const float *pd = M.posedirs + (size_t)p0 * ncols + (ok ? gcol : 0);
-    float acc = 0.f;
+    float pv[BF_MESH_PF];
+#pragma unroll
+    for (int i = 0; i < BF_MESH_PF; ++i) pv[i] = (p0 + i < p1) ? pd[(size_t)i * ncols] : 0.f;
+    float wreg[BF_MESH_WPF], sdreg[12], vt = 0.f, jx[BF_MESH_TILE];
+#pragma unroll
+    for (int j = 0; j < BF_MESH_WPF; ++j) wreg[j] = 0.f;
+#pragma unroll
+    for (int l = 0; l < 12; ++l) sdreg[l] = 0.f;
+#pragma unroll
+    for (int i = 0; i < BF_MESH_TILE; ++i) jx[i] = 0.f;
+    const int ne3 = M.n_extra * 3;
+    if (rg == 0 && ok) {
+        const float *w = M.lbs_weights + (size_t)v * nj;
+#pragma unroll
+        for (int j = 0; j < BF_MESH_WPF; ++j) if (j < nj) wreg[j] = w[j];
+    } else if (rg == 1 && ok) {
+        const float *sd = M.shapedirs + (size_t)gcol * nb;
+#pragma unroll
+        for (int l = 0; l < 12; ++l) if (l < nb) sdreg[l] = sd[l];
+        vt = M.v_template[gcol];
+    } else if (rg == 2 && col < ne3 && xpart) {
+        const int e = col / 3, v0 = blockIdx.x * BF_MESH_TILE;
+        const float *row = M.j_extra + (size_t)e * nv + v0;
+#pragma unroll
+        for (int i = 0; i < BF_MESH_TILE; ++i) if (v0 + i < nv) jx[i] = row[i];
+    }
     for (int i = tid; i < npf; i += nt) s_feat[i] = st.feat[i];
     for (int i = tid; i < nj * 12; i += nt) {
         int j = i / 12, e = i % 12, a = e / 4, b = e % 4;
@@ -124,40 +166,63 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
     }
     if (tid < nb + 5) s_beta[tid] = st.beta[tid];   // beta, t, sc are contiguous in the state record
     __syncthreads();
-#pragma unroll 13
-    for (int p = p0; p < p1; ++p) {
-        acc += s_feat[p] * pd[0];
-        pd += ncols;
-    }
+
+    // ---- pose blend: this row group's share, reduced through LDS -----------------------------------
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < BF_MESH_PF; ++i) acc += (p0 + i < p1 ? s_feat[p0 + i] : 0.f) * pv[i];
+    for (int p = p0 + BF_MESH_PF; p < p1; ++p) acc += s_feat[p] * pd[(size_t)(p - p0) * ncols];
     s_red[rg * COLS + col] = acc;
+    if (rg == 1) {
+        float a2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < 12; ++l) if (l < nb) a2 += sdreg[l] * s_beta[l];
+        for (int l = 12; l < nb; ++l) a2 += M.shapedirs[(size_t)gcol * nb + l] * s_beta[l];
+        s_vp[col] = ok ? vt + a2 : 0.f;          // shaped vertex; the pose offset is added below
+    }
     __syncthreads();
     if (rg == 0) {
         float off = 0.f;
 #pragma unroll
         for (int q = 0; q < BF_MESH_RG; ++q) off += s_red[q * COLS + col];
-        float vs = 0.f;
-        if (ok) {
-            const float *sd = M.shapedirs + (size_t)gcol * nb;
-            float a2 = 0.f;
-            for (int l = 0; l < nb; ++l) a2 += sd[l] * s_beta[l];
-            vs = M.v_template[gcol] + a2;
-        }
-        s_vp[col] = vs + off;
+        s_vp[col] += off;
     }
     __syncthreads();
-    if (rg == 0 && ok) {
-        int vl = col / 3, k = col % 3, v = blockIdx.x * BF_MESH_TILE + vl;
-        const float *w = M.lbs_weights + (size_t)v * nj;
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f, tt = 0.f;
-        for (int j = 0; j < nj; ++j) {
-            float wj = w[j];
-            const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
-            t0 += wj * a.x; t1 += wj * a.y; t2 += wj * a.z; tt += wj * a.w;
+    // ---- skinning ---------------------------------------------------------------------------------
+    if (rg == 0) {
+        float r = 0.f;
+        if (ok) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, tt = 0.f;
+#pragma unroll
+            for (int j = 0; j < BF_MESH_WPF; ++j) {
+                if (j < nj) {
+                    const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
+                    t0 += wreg[j] * a.x; t1 += wreg[j] * a.y; t2 += wreg[j] * a.z; tt += wreg[j] * a.w;
+                }
+            }
+            for (int j = BF_MESH_WPF; j < nj; ++j) {
+                float wj = M.lbs_weights[(size_t)v * nj + j];
+                const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
+                t0 += wj * a.x; t1 += wj * a.y; t2 += wj * a.z; tt += wj * a.w;
+            }
+            r = t0 * s_vp[vl * 3] + t1 * s_vp[vl * 3 + 1] + t2 * s_vp[vl * 3 + 2] + tt;
+            size_t o = (size_t)frame * ncols + gcol;
+            if (vraw) vraw[o] = r;
+            if (vout) vout[o] = (r + s_beta[nb + k]) * s_beta[nb + 3] * s_beta[nb + 4];
+            if (vposed) vposed[o] = s_vp[col];       // kept for the dense reverse pass
         }
-        float r = t0 * s_vp[vl * 3] + t1 * s_vp[vl * 3 + 1] + t2 * s_vp[vl * 3 + 2] + tt;
-        size_t o = (size_t)frame * ncols + gcol;
-        if (vraw) vraw[o] = r;
-        if (vout) vout[o] = (r + s_beta[nb + k]) * s_beta[nb + 3] * s_beta[nb + 4];
+        s_red[col] = r;                          // (own column of the reduce buffer: no hazard)
+    }
+    if (xpart) {
+        // this tile's share of J_regressor_extra . vertices (models/smpl.py:72); summed over tiles, in tile
+        // order, by bf_joints_kernel
+        __syncthreads();
+        if (rg == 2 && col < ne3) {
+            float a3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < BF_MESH_TILE; ++i) a3 += jx[i] * s_red[i * 3 + k];
+            xpart[((size_t)frame * gridDim.x + blockIdx.x) * ne3 + col] = a3;
+        }
     }
 }
 
@@ -168,27 +233,29 @@ extern "C" size_t bf_mesh_smem_bytes(int nj, int npf, int nb) {
 
 // One 256-thread workgroup per frame.  joints_ori = cat(chain joints, selector vertices) and
 // joints = cat(joints_ori, J_regressor_extra vraw)[joint_map] (models/smpl.py:72-75), both with the
-// similarity of smplify.py:189 applied.
+// similarity of smplify.py:189 applied.  The extra-regressor sums arrive as per-tile partials from
+// bf_mesh_kernel and are added here in tile order (8 lanes per output, fixed tree).
 extern "C" __global__ void __launch_bounds__(256)
 bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__restrict__ vraw,
-                 float *__restrict__ joints, float *__restrict__ joints_ori) {
-    __shared__ float s_part[4][32 * 3];
+                 const float *__restrict__ xpart, float *__restrict__ joints, float *__restrict__ joints_ori) {
+    __shared__ float s_extra[32 * 3];
     __shared__ float s_all[(64 + 32 + 32) * 3];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, frame = blockIdx.x;
+    const int tid = threadIdx.x, frame = blockIdx.x;
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv, ne = M.n_extra, nsel = M.n_selector;
     StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
     const float *vr = vraw + (size_t)frame * nv * 3;
     const float t0 = st.t[0], t1 = st.t[1], t2 = st.t[2], sc = st.sc[0] * st.sc[1];
-    // extra regressors: each thread strides over the vertices, then a fixed-order block reduction
-    for (int e = 0; e < ne; ++e) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        const float *row = M.j_extra + (size_t)e * nv;
-        for (int v = tid; v < nv; v += 256) {
-            float w = row[v];
-            a0 += w * vr[v * 3]; a1 += w * vr[v * 3 + 1]; a2 += w * vr[v * 3 + 2];
+    const int ne3 = ne * 3, nt8 = M.n_tiles;
+    for (int base = 0; base < ne3 * 8; base += 256) {
+        int idx = base + tid, o = idx >> 3, sl = idx & 7;
+        float acc = 0.f;
+        if (o < ne3) {
+            int per = (nt8 + 7) / 8, a = sl * per, b = min(nt8, a + per);
+            const float *p = xpart + ((size_t)frame * nt8 + a) * ne3 + o;
+            for (int t = a; t < b; ++t, p += ne3) acc += *p;
         }
-        a0 = m_wave_sum(a0); a1 = m_wave_sum(a1); a2 = m_wave_sum(a2);
-        if (lane == 0) { s_part[wave][e * 3] = a0; s_part[wave][e * 3 + 1] = a1; s_part[wave][e * 3 + 2] = a2; }
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+        if (o < ne3 && sl == 0) s_extra[o] = acc;
     }
     __syncthreads();
     const int n_ori = nj + nsel;
@@ -197,10 +264,7 @@ bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__rest
         float x;
         if (j < nj) x = st.Gt[j * 3 + k];
         else if (j < n_ori) x = vr[(size_t)M.selector_ids[j - nj] * 3 + k];
-        else {
-            int e = (j - n_ori) * 3 + k;
-            x = s_part[0][e] + s_part[1][e] + s_part[2][e] + s_part[3][e];
-        }
+        else x = s_extra[(j - n_ori) * 3 + k];
         float tk = k == 0 ? t0 : (k == 1 ? t1 : t2);
         s_all[i] = (x + tk) * sc;
     }

@@ -1,0 +1,210 @@
+// Host side of the scan (use_mesh) path: grid construction, closest-point queries, and the per-iteration
+// schedule of smplify.py:205-213 with the point-cloud loss switched on after num_iters // 3.
+#include "bf_host.h"
+
+extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
+extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int, int *, float *, float *);
+extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
+extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
+extern "C" __global__ void bf_mesh_bwd_kernel(MeshTab, const float *, const float *, const float *, const float *, const float *, float *);
+extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *);
+extern "C" size_t bf_mesh_bwd_smem_bytes(int);
+
+extern "C" {
+
+// MeshGridSearcher.set_mesh (utils/mesh_grid_searcher.py:56-79) + insert_grid_surface
+// (mesh_grid_kernel.cu:110-157): same cells, same triangle -> cell assignment, deterministic lists.
+int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, const int32_t *faces, bf_scan **out) {
+    if (!verts || !faces || !out || n_verts <= 0 || n_faces <= 0) return fail(BF_ERR_INVALID, "bf_scan_create: bad argument");
+    *out = nullptr;
+    for (int i = 0; i < n_faces * 3; ++i)
+        if (faces[i] < 0 || faces[i] >= n_verts) return fail(BF_ERR_INVALID, "bf_scan_create: face index out of range");
+    HIP_TRY(hipSetDevice(device));
+    float mn[3] = {verts[0], verts[1], verts[2]}, mx[3] = {verts[0], verts[1], verts[2]};
+    for (int v = 1; v < n_verts; ++v)
+        for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], verts[v * 3 + d]); mx[d] = std::max(mx[d], verts[v * 3 + d]); }
+    // float32 arithmetic in the order torch evaluates it
+    float ext[3] = {mx[0] - mn[0], mx[1] - mn[1], mx[2] - mn[2]};
+    float prod = ext[0] * ext[1]; prod = prod * ext[2];
+    float step = powf(prod / (float)n_verts, (float)(1.0 / 3.0));
+    if (!(step > 0.f)) return fail(BF_ERR_INVALID, "bf_scan_create: degenerate (flat) scan");
+    int num[3];
+    float org[3];
+    for (int d = 0; d < 3; ++d) {
+        float l = std::max(floorf(ext[d] / step), 0.f) + 1.f;
+        float c = (mx[d] + mn[d]) / 2.f;
+        org[d] = c - step * l / 2.f;
+        num[d] = (int)l;
+    }
+    const size_t ncell = (size_t)num[0] * num[1] * num[2];
+    if (ncell > (size_t)1 << 28) return fail(BF_ERR_UNSUPPORTED, "bf_scan_create: grid too large");
+    auto cell_range = [&](int f, int lo[3], int hi[3]) {
+        for (int d = 0; d < 3; ++d) {
+            float a = verts[faces[f * 3] * 3 + d], b = a;
+            for (int j = 1; j < 3; ++j) { float x = verts[faces[f * 3 + j] * 3 + d]; a = std::min(a, x); b = std::max(b, x); }
+            float x = (a - org[d]) / step;
+            lo[d] = x < 0 ? 0 : (x >= num[d] ? num[d] - 1 : (int)floorf(x));
+            x = (b - org[d]) / step;
+            hi[d] = (x < 0 ? 0 : (x >= num[d] ? num[d] - 1 : (int)floorf(x))) + 1;
+        }
+    };
+    std::vector<int> start(ncell + 1, 0);
+    for (int f = 0; f < n_faces; ++f) {
+        int lo[3], hi[3];
+        cell_range(f, lo, hi);
+        for (int x = lo[0]; x < hi[0]; ++x) for (int y = lo[1]; y < hi[1]; ++y) for (int z = lo[2]; z < hi[2]; ++z)
+            ++start[((size_t)x * num[1] + y) * num[2] + z + 1];
+    }
+    for (size_t c = 0; c < ncell; ++c) start[c + 1] += start[c];
+    std::vector<int> tris(start[ncell]), fill(start.begin(), start.end() - 1);
+    for (int f = 0; f < n_faces; ++f) {
+        int lo[3], hi[3];
+        cell_range(f, lo, hi);
+        for (int x = lo[0]; x < hi[0]; ++x) for (int y = lo[1]; y < hi[1]; ++y) for (int z = lo[2]; z < hi[2]; ++z)
+            tris[fill[((size_t)x * num[1] + y) * num[2] + z]++] = f;
+    }
+    // un-normalised face normals, float64 cross product rounded once (smplify.py:148-149)
+    std::vector<float> fn((size_t)n_faces * 3);
+    for (int f = 0; f < n_faces; ++f) {
+        const float *a = verts + faces[f * 3] * 3, *b = verts + faces[f * 3 + 1] * 3, *c = verts + faces[f * 3 + 2] * 3;
+        double u[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]};
+        double w[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
+        fn[f * 3] = (float)(u[1] * w[2] - u[2] * w[1]);
+        fn[f * 3 + 1] = (float)(u[2] * w[0] - u[0] * w[2]);
+        fn[f * 3 + 2] = (float)(u[0] * w[1] - u[1] * w[0]);
+    }
+    auto *s = new bf_scan();
+    s->device = device; s->nv = n_verts; s->nf = n_faces;
+    bool ok = s->verts.upload(std::vector<float>(verts, verts + (size_t)n_verts * 3)) == hipSuccess &&
+              s->faces.upload(std::vector<int>(faces, faces + (size_t)n_faces * 3)) == hipSuccess &&
+              s->cell_start.upload(start) == hipSuccess && s->cell_tris.upload(tris) == hipSuccess &&
+              s->face_norms.upload(fn) == hipSuccess;
+    if (!ok) { delete s; return fail(BF_ERR_HIP, "bf_scan_create: device allocation failed"); }
+    ScanDev &d = s->dev;
+    d.nv = n_verts; d.nf = n_faces; d.nx = num[0]; d.ny = num[1]; d.nz = num[2];
+    d.ox = org[0]; d.oy = org[1]; d.oz = org[2]; d.step = step; d.height = ext[1];
+    d.verts = s->verts.p; d.faces = s->faces.p; d.cell_start = s->cell_start.p; d.cell_tris = s->cell_tris.p;
+    *out = s;
+    return BF_OK;
+}
+
+void bf_scan_destroy(bf_scan *s) { delete s; }
+float bf_scan_height(const bf_scan *s) { return s ? s->dev.height : 0.f; }
+
+int bf_scan_grid_info(const bf_scan *s, int32_t dims[3], float origin_step[4]) {
+    if (!s || !dims || !origin_step) return fail(BF_ERR_INVALID, "bf_scan_grid_info: null argument");
+    dims[0] = s->dev.nx; dims[1] = s->dev.ny; dims[2] = s->dev.nz;
+    origin_step[0] = s->dev.ox; origin_step[1] = s->dev.oy; origin_step[2] = s->dev.oz; origin_step[3] = s->dev.step;
+    return BF_OK;
+}
+
+// MeshGridSearcher.nearest_points -> SurfaceNearest (utils/mesh_grid_searcher.py:6-15,81-84)
+int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, float *nearest, float *bary) {
+    if (!s || n <= 0 || !points) return fail(BF_ERR_INVALID, "bf_scan_nearest: bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf<float> d_p, d_c, d_b;
+    DevBuf<int> d_f;
+    DevBuf<ScanDev> d_s;
+    HIP_TRY(d_p.upload(std::vector<float>(points, points + (size_t)n * 3)));
+    HIP_TRY(d_c.alloc((size_t)n * 3)); HIP_TRY(d_b.alloc((size_t)n * 3)); HIP_TRY(d_f.alloc(n));
+    HIP_TRY(d_s.upload(std::vector<ScanDev>(1, s->dev)));
+    hipLaunchKernelGGL(bf_nearest_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, 0, (const ScanDev *)d_s.p, (const float *)d_p.p, n,
+                       d_f.p, d_c.p, d_b.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    if (face_ids) HIP_TRY(hipMemcpy(face_ids, d_f.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (nearest) HIP_TRY(hipMemcpy(nearest, d_c.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (bary) HIP_TRY(hipMemcpy(bary, d_b.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+static int ensure_dense_buffers(bf_batch *b) {
+    bf_model *m = b->m;
+    const size_t F = b->F, nv3 = (size_t)m->nv * 3;
+    const int EXT = m->npf + m->nj * 12 + m->nb + 4;
+    if (!b->dvout.p) {
+        bool ok = b->dvout.alloc(F * nv3) == hipSuccess && b->vposed.alloc(F * nv3) == hipSuccess &&
+                  b->cpts.alloc(F * nv3) == hipSuccess && b->cface.alloc(F * m->nv) == hipSuccess &&
+                  b->ext_part.alloc(F * m->mesh.n_tiles * EXT) == hipSuccess && b->ext.alloc(F * EXT) == hipSuccess &&
+                  b->pc_partial.alloc(F * ((m->nv + 255) / 256)) == hipSuccess && b->pc_loss.alloc(F) == hipSuccess;
+        if (!ok) return fail(BF_ERR_HIP, "dense-loss buffers: device allocation failed");
+    }
+    if (!m->posedirsT.p) {
+        // [3NV][npf] transpose for the reverse pass (thread = pose-feature row, contiguous reads)
+        const size_t ncols = nv3, npf = m->npf;
+        std::vector<float> t(ncols * npf);
+        for (size_t p = 0; p < npf; ++p)
+            for (size_t c = 0; c < ncols; ++c) t[c * npf + p] = m->posedirs_host[p * ncols + c];
+        HIP_TRY(m->posedirsT.upload(t));
+    }
+    return BF_OK;
+}
+
+// use_mesh=True, meshfile per frame (smplify.py:146-156): one scan per frame; constant_scale = scan_height / 1.7
+int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
+    if (!b) return fail(BF_ERR_INVALID, "bf_batch_set_scans: null batch");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (!scans) {                                  // detach
+        b->scans.clear();
+        if (b->cscale.p) { (void)hipFree(b->cscale.p); b->cscale.p = nullptr; }
+        return BF_OK;
+    }
+    std::vector<ScanDev> dev(b->F);
+    std::vector<float> cs(b->F);
+    for (int f = 0; f < b->F; ++f) {
+        if (!scans[f] || scans[f]->device != b->m->device) return fail(BF_ERR_INVALID, "bf_batch_set_scans: missing scan or wrong device");
+        dev[f] = scans[f]->dev;
+        cs[f] = scans[f]->dev.height / 1.7f;
+    }
+    b->scans.assign(scans, scans + b->F);
+    if (b->scan_dev.p) { (void)hipFree(b->scan_dev.p); b->scan_dev.p = nullptr; }
+    if (b->cscale.p) { (void)hipFree(b->cscale.p); b->cscale.p = nullptr; }
+    HIP_TRY(b->scan_dev.upload(dev));
+    HIP_TRY(b->cscale.upload(cs));
+    return ensure_dense_buffers(b);
+}
+
+// the loop of smplify.py:177-213 with use_mesh: iterations i <= n_iters // 3 are keypoint-only (one
+// persistent launch); every later iteration adds 5 * point_cloud_loss / scan_height * imsize.
+int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDev &hd, FrameIO io) {
+    bf_model *m = b->m;
+    const int F = b->F, nv = m->nv, thr = n_iters / 3;
+    const int n_plain = std::min(n_iters, thr + 1);
+    if (b->pc_weight.n != (size_t)F) {
+        std::vector<float> w(F);
+        for (int f = 0; f < F; ++f) w[f] = 5.0f * h.imsize / b->scans[f]->dev.height;      // smplify.py:206,210
+        if (b->pc_weight.p) { (void)hipFree(b->pc_weight.p); b->pc_weight.p = nullptr; }
+        HIP_TRY(b->pc_weight.upload(w));
+    }
+    HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, m->fit_smem, b->stream));
+    const int EXT = m->npf + m->nj * 12 + m->nb + 4, nblk = (nv + 255) / 256;
+    const size_t bwd_smem = bf_mesh_bwd_smem_bytes(m->nj);
+    for (int it = n_plain; it < n_iters; ++it) {
+        hipLaunchKernelGGL(bf_pose_state_kernel, dim3(F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
+                           (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
+        HIP_TRY(hipGetLastError());
+        int rc = bf_launch_mesh(m, F, b->state.p, b->vraw.p, b->vout.p, nullptr, nullptr, nullptr, b->stream, nullptr, b->vposed.p);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bf_nearest_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
+                           (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr);
+        hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
+                           (const float *)b->cpts.p, nv, b->pc_partial.p);
+        hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
+                           (const float *)b->cpts.p, nv, (const float *)b->pc_partial.p, (const float *)b->pc_weight.p,
+                           b->dvout.p, b->pc_loss.p, 0);
+        hipLaunchKernelGGL(bf_mesh_bwd_kernel, dim3(m->mesh.n_tiles, F), dim3(512), bwd_smem, b->stream, m->mesh,
+                           (const float *)m->posedirsT.p, (const float *)b->state.p, (const float *)b->dvout.p,
+                           (const float *)b->vposed.p, (const float *)b->vraw.p, b->ext_part.p);
+        hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 255) / 256, F), dim3(256), 0, b->stream,
+                           (const float *)b->ext_part.p, m->mesh.n_tiles, EXT, b->ext.p);
+        HIP_TRY(hipGetLastError());
+        FrameIO io2 = io;
+        io2.ext = b->ext.p;
+        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
+    }
+    return BF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// Scan closest-point search and the dense (all-vertex) reverse pass for gfx950.
+//
+//   bf_nearest_kernel     closest point on the scan surface per query vertex, uniform-grid pruned
+//                         (replaces thirdparty/mesh_grid/mesh_grid_kernel.cu:239-353, incl. its
+//                         per-triangle rule :12-109 with the argmin-coefficient edge fallback)
+//   bf_pc_partial_kernel / bf_pc_grad_kernel
+//                         point_cloud_loss_mesh_grid (smplify/loss.py:233-242): one Frobenius norm,
+//                         scaled 5 * imsize / scan_height (smplify.py:206,210), and its gradient
+//   bf_mesh_bwd_kernel / bf_ext_reduce_kernel
+//                         reverse of the full-mesh forward: dL/dvertices -> dL/d(pose feature, chain
+//                         matrices, betas, transl, scale), per 32-vertex tile then summed in tile order
+//
+// The grid itself (cell lists in CSR form, cells from MeshGridSearcher.set_mesh,
+// utils/mesh_grid_searcher.py:56-79) is built once per scan on the host - it is setup, not the loop -
+// with triangles in face order inside every cell, so the search is deterministic (the reference fills
+// its lists with atomicCAS in arbitrary order).
+#include "bf_internal.h"
+
+namespace {
+
+// closest point of triangle (p0,p1,p2), given relative to the query, by the reference's rule
+__device__ inline float closest_rule(const float *p0, const float *p1, const float *p2, float *coeff) {
+    float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
+    float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
+    float a11 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
+    float a12 = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
+    float a22 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
+    float b1 = -(p0[0] * e1[0] + p0[1] * e1[1] + p0[2] * e1[2]);
+    float b2 = -(p0[0] * e2[0] + p0[1] * e2[1] + p0[2] * e2[2]);
+    float det = a11 * a22 - a12 * a12;
+    bool ok = det > 1e-12f * a11 * a22 && det > 0.f;
+    float c[3] = {1.f / 3, 1.f / 3, 1.f / 3};
+    int i;
+    if (ok) {
+        float u = (b1 * a22 - b2 * a12) / det, v = (a11 * b2 - a12 * b1) / det;
+        c[0] = 1.f - u - v; c[1] = u; c[2] = v;
+        i = c[0] > c[1] ? 1 : 0;
+        i = c[i] > c[2] ? 2 : i;                       // most negative coefficient (mesh_grid_kernel.cu:82-83)
+        if (c[i] >= 0.f) {
+            coeff[0] = c[0]; coeff[1] = c[1]; coeff[2] = c[2];
+            float x0 = c[0] * p0[0] + c[1] * p1[0] + c[2] * p2[0];
+            float x1 = c[0] * p0[1] + c[1] * p1[1] + c[2] * p2[1];
+            float x2 = c[0] * p0[2] + c[1] * p1[2] + c[2] * p2[2];
+            return x0 * x0 + x1 * x1 + x2 * x2;
+        }
+    } else {
+        // degenerate triangle: the vertex opposite its longest edge (mesh_grid_kernel.cu:40-45)
+        float l0 = (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) + (p1[2] - p2[2]) * (p1[2] - p2[2]);
+        float l1 = a22, l2 = a11;
+        i = l0 < l1 ? 1 : 0;
+        i = (i == 0 ? l0 : l1) < l2 ? 2 : i;
+    }
+    const float *P[3] = {p0, p1, p2};
+    int j = (i + 1) % 3, k = 3 - i - j;
+    const float *pj = P[j], *pk = P[k];
+    float d[3] = {pk[0] - pj[0], pk[1] - pj[1], pk[2] - pj[2]};
+    float dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    float t = dd > 0.f ? -(pj[0] * d[0] + pj[1] * d[1] + pj[2] * d[2]) / dd : 0.5f;
+    float cj = 1.f - t, ck = t;
+    if (cj < 0.f) { cj = 0.f; ck = 1.f; }                 // same test order as the reference (:89-98)
+    else if (ck < 0.f) { cj = 1.f; ck = 0.f; }
+    coeff[i] = 0.f; coeff[j] = cj; coeff[k] = ck;
+    float x0 = cj * pj[0] + ck * pk[0], x1 = cj * pj[1] + ck * pk[1], x2 = cj * pj[2] + ck * pk[2];
+    return x0 * x0 + x1 * x1 + x2 * x2;
+}
+
+__device__ inline float blk_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+}  // namespace
+
+// grid (ceil(n/256), F).  points[F][n][3] -> face[F][n], pts[F][n][3], bary[F][n][3] (bary may be null)
+extern "C" __global__ void __launch_bounds__(256)
+bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
+                  int *__restrict__ face, float *__restrict__ pts, float *__restrict__ bary) {
+    const int id = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (id >= n) return;
+    const ScanDev S = scans[f];
+    const float *q = points + ((size_t)f * n + id) * 3;
+    const float qx = q[0], qy = q[1], qz = q[2];
+    int cx = (int)floorf((qx - S.ox) / S.step), cy = (int)floorf((qy - S.oy) / S.step), cz = (int)floorf((qz - S.oz) / S.step);
+    cx = min(max(cx, 0), S.nx - 1); cy = min(max(cy, 0), S.ny - 1); cz = min(max(cz, 0), S.nz - 1);
+    int maxL = max(max(max(cx, S.nx - 1 - cx), max(cy, S.ny - 1 - cy)), max(cz, S.nz - 1 - cz));
+    float best = -1.f, bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
+    int bface = -1;
+    for (int L = 0; L <= maxL; ++L) {
+        for (int dz = -L; dz <= L; ++dz) {
+            int z = cz + dz;
+            if (z < 0 || z >= S.nz) continue;
+            for (int dy = -L; dy <= L; ++dy) {
+                int y = cy + dy;
+                if (y < 0 || y >= S.ny) continue;
+                const bool face_zy = (dz == -L || dz == L || dy == -L || dy == L);
+                for (int dx = -L; dx <= L; dx += (face_zy ? 1 : max(2 * L, 1))) {      // shell cells only
+                    int x = cx + dx;
+                    if (x < 0 || x >= S.nx) continue;
+                    // lower bound: squared distance from the query to this cell's box
+                    float lo, e, d2 = 0.f;
+                    lo = S.ox + S.step * x; e = qx < lo ? lo - qx : (qx > lo + S.step ? qx - lo - S.step : 0.f); d2 += e * e;
+                    lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); d2 += e * e;
+                    lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); d2 += e * e;
+                    if (best >= 0.f && best < d2) continue;
+                    int cell = (x * S.ny + y) * S.nz + z;
+                    for (int i = S.cell_start[cell]; i < S.cell_start[cell + 1]; ++i) {
+                        int t = S.cell_tris[i];
+                        const int *tv = S.faces + (size_t)t * 3;
+                        float p[9];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float *v = S.verts + (size_t)tv[c] * 3;
+                            p[c * 3] = v[0] - qx; p[c * 3 + 1] = v[1] - qy; p[c * 3 + 2] = v[2] - qz;
+                        }
+                        float co[3];
+                        float dist = closest_rule(p, p + 3, p + 6, co);
+                        if (best < 0.f || dist < best || (dist == best && t < bface)) {
+                            best = dist; bface = t; bc0 = co[0]; bc1 = co[1]; bc2 = co[2];
+                        }
+                    }
+                }
+            }
+        }
+        if (best >= 0.f && best < (float)L * (float)L * S.step * S.step) break;     // mesh_grid_kernel.cu:349
+    }
+    const size_t o = (size_t)f * n + id;
+    face[o] = bface;
+    float r0 = qx, r1 = qy, r2 = qz;
+    if (bface >= 0) {
+        const int *tv = S.faces + (size_t)bface * 3;
+        const float *v0 = S.verts + (size_t)tv[0] * 3, *v1 = S.verts + (size_t)tv[1] * 3, *v2 = S.verts + (size_t)tv[2] * 3;
+        // proj = q + sum c_i (v_i - q), as the reference forms it (:318-329)
+        r0 = qx + bc0 * (v0[0] - qx) + bc1 * (v1[0] - qx) + bc2 * (v2[0] - qx);
+        r1 = qy + bc0 * (v0[1] - qy) + bc1 * (v1[1] - qy) + bc2 * (v2[1] - qy);
+        r2 = qz + bc0 * (v0[2] - qz) + bc1 * (v1[2] - qz) + bc2 * (v2[2] - qz);
+    }
+    pts[o * 3] = r0; pts[o * 3 + 1] = r1; pts[o * 3 + 2] = r2;
+    if (bary) { bary[o * 3] = bc0; bary[o * 3 + 1] = bc1; bary[o * 3 + 2] = bc2; }
+}
+
+// grid (nblk, F): partial[f][blk] = sum over this block's vertices of |P - C|^2
+extern "C" __global__ void __launch_bounds__(256)
+bf_pc_partial_kernel(const float *__restrict__ P, const float *__restrict__ C, int n, float *__restrict__ partial) {
+    __shared__ float s[4];
+    const int id = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    float a = 0.f;
+    if (id < n) {
+        const float *p = P + ((size_t)f * n + id) * 3, *c = C + ((size_t)f * n + id) * 3;
+        float d0 = p[0] - c[0], d1 = p[1] - c[1], d2 = p[2] - c[2];
+        a = d0 * d0 + d1 * d1 + d2 * d2;
+    }
+    a = blk_wave_sum(a);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(size_t)f * gridDim.x + blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// grid (nblk, F): dvout = weight[f] * (P - C) / ||P - C||_F ;  weight[f] = 5 * imsize / scan_height
+// `accumulate` != 0 adds to dvout instead of overwriting it.  loss[f] = weight[f] * norm (block 0 writes it).
+extern "C" __global__ void __launch_bounds__(256)
+bf_pc_grad_kernel(const float *__restrict__ P, const float *__restrict__ C, int n, const float *__restrict__ partial,
+                  const float *__restrict__ weight, float *__restrict__ dvout, float *__restrict__ loss, int accumulate) {
+    const int id = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    float tot = 0.f;
+    for (int b = 0; b < (int)gridDim.x; ++b) tot += partial[(size_t)f * gridDim.x + b];      // fixed order
+    const float norm = sqrtf(tot), w = weight[f];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && loss) loss[f] = w * norm;
+    if (id >= n) return;
+    const size_t o = ((size_t)f * n + id) * 3;
+    const float k = w / norm;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float g = k * (P[o + c] - C[o + c]);
+        dvout[o + c] = accumulate ? dvout[o + c] + g : g;
+    }
+}
+
+// Reverse of bf_mesh_kernel for one 32-vertex tile.  grid (n_tiles, F), 512 threads.
+//   in : dvout[F][NV][3] = dL/d((v + t) s c), vposed[F][NV][3] (pose-blended vertices saved by the forward),
+//        vraw[F][NV][3], state
+//   out: part[F][n_tiles][EXT] with EXT = npf + nj*12 + nb + 4:
+//        dfeat[npf] | per joint 3 rows of (sum w dv (x) vp | sum w dv) | dbeta[nb] | dt[3] ds[1]
+// posedirsT is the [3NV][npf] transpose, so that thread p streams row-contiguous memory.
+extern "C" __global__ void __launch_bounds__(512)
+bf_mesh_bwd_kernel(MeshTab M, const float *__restrict__ posedirsT, const float *__restrict__ state,
+                   const float *__restrict__ dvout, const float *__restrict__ vposed, const float *__restrict__ vraw,
+                   float *__restrict__ part) {
+    constexpr int TV = BF_MESH_TILE, COLS = BF_MESH_TILE * 3;
+    extern __shared__ __align__(16) float sm[];
+    const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
+    float *s_A = sm;                        // [nj][12]
+    float *s_w = s_A + nj * 12;             // [TV][nj]
+    float *s_dv = s_w + TV * nj;            // [COLS]  dL/dv (model space)
+    float *s_vp = s_dv + COLS;              // [COLS]
+    float *s_dvp = s_vp + COLS;             // [COLS]
+    float *s_sim = s_dvp + COLS;            // t[3], s, c
+    const int tid = threadIdx.x, frame = blockIdx.y, tile = blockIdx.x, v0 = tile * TV;
+    StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
+    const int nvt = min(TV, nv - v0);
+    for (int i = tid; i < nj * 12; i += 512) {
+        int j = i / 12, e = i % 12, a = e / 4, b = e % 4;
+        s_A[i] = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
+    }
+    for (int i = tid; i < TV * nj; i += 512) s_w[i] = i < nvt * nj ? M.lbs_weights[(size_t)v0 * nj + i] : 0.f;
+    if (tid < 5) s_sim[tid] = tid < 3 ? st.t[tid] : st.sc[tid - 3];
+    __syncthreads();
+    const float sc = s_sim[3] * s_sim[4];
+    float dt_part = 0.f, ds_part = 0.f;
+    if (tid < COLS) {
+        bool ok = tid < nvt * 3;
+        size_t o = ((size_t)frame * nv + v0) * 3 + tid;
+        float g = ok ? dvout[o] : 0.f;
+        s_dv[tid] = g * sc;
+        s_vp[tid] = ok ? vposed[o] : 0.f;
+        dt_part = g * sc;                                              // d/dt_k   = sum dvout * s c
+        ds_part = ok ? g * (vraw[o] + s_sim[tid % 3]) * s_sim[4] : 0.f;   // d/ds = sum dvout . (v + t) c
+    }
+    __syncthreads();
+    // dvp = T_v.R^T dv : thread (vl, b)
+    if (tid < COLS) {
+        int vl = tid / 3, b = tid - vl * 3;
+        float acc = 0.f;
+        for (int j = 0; j < nj; ++j) {
+            float w = s_w[vl * nj + j];
+            acc += w * (s_A[j * 12 + b] * s_dv[vl * 3] + s_A[j * 12 + 4 + b] * s_dv[vl * 3 + 1] + s_A[j * 12 + 8 + b] * s_dv[vl * 3 + 2]);
+        }
+        s_dvp[tid] = acc;
+    }
+    __syncthreads();
+    const int EXT = npf + nj * 12 + nb + 4;
+    float *out = part + ((size_t)frame * gridDim.x + tile) * EXT;
+    // (a) dfeat partial: thread p streams posedirsT[col][p]
+    for (int p = tid; p < npf; p += 512) {
+        const float *src = posedirsT + (size_t)v0 * 3 * npf + p;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int c = 0; c < COLS; ++c)
+            if (c < nvt * 3) acc += src[(size_t)c * npf] * s_dvp[c];
+        out[p] = acc;
+    }
+    // (b) chain-matrix partials: thread (j, row a, col b): sum_v w_vj dv_a [vp_b | 1]
+    for (int i = 511 - tid; i < nj * 12; i += 512) {
+        int j = i / 12, e = i - j * 12, a = e / 4, b = e - a * 4;
+        float acc = 0.f;
+        for (int vl = 0; vl < TV; ++vl) acc += s_w[vl * nj + j] * s_dv[vl * 3 + a] * (b < 3 ? s_vp[vl * 3 + b] : 1.f);
+        out[npf + i] = acc;
+    }
+    // (c) betas, transl, scale
+    if (tid >= 256 && tid < 256 + nb) {
+        int l = tid - 256;
+        float acc = 0.f;
+        for (int c = 0; c < nvt * 3; ++c) acc += M.shapedirs[((size_t)v0 * 3 + c) * nb + l] * s_dvp[c];
+        out[npf + nj * 12 + l] = acc;
+    }
+    __syncthreads();                       // s_dv / s_vp are free now: reuse for the t, s sums
+    if (tid < COLS) { s_dv[tid] = dt_part; s_vp[tid] = ds_part; }
+    __syncthreads();
+    if (tid < 4) {
+        float acc = 0.f;
+        if (tid < 3) { for (int vl = 0; vl < TV; ++vl) acc += s_dv[vl * 3 + tid]; }
+        else { for (int c = 0; c < COLS; ++c) acc += s_vp[c]; }
+        out[npf + nj * 12 + nb + tid] = acc;
+    }
+}
+
+extern "C" size_t bf_mesh_bwd_smem_bytes(int nj) {
+    return sizeof(float) * (nj * 12 + BF_MESH_TILE * nj + 3 * BF_MESH_TILE * 3 + 8);
+}
+
+// grid (ceil(EXT/256), F): ext[f][i] = sum over tiles (in tile order) of part[f][tile][i]
+extern "C" __global__ void __launch_bounds__(256)
+bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float *__restrict__ ext) {
+    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (i >= EXT) return;
+    const float *p = part + (size_t)f * n_tiles * EXT + i;
+    float acc = 0.f;
+    for (int t = 0; t < n_tiles; ++t) acc += p[(size_t)t * EXT];
+    ext[(size_t)f * EXT + i] = acc;
+}

@@ -49,3 +49,24 @@ def load_openpose(json_name, only_one=True):
         return parsed
     scores = [sum(p[:, -1].sum() for p in e.values()) for e in parsed]
     return parsed[int(np.argmax(scores))]
+
+
+def load_obj_mesh(mesh_file):
+    """vertices float64[NV,3], faces int[F,3] (0-based; quads split as the reference does,
+    utils/io_utils.py:430-475 with the default flags)."""
+    verts, faces = [], []
+    with open(mesh_file, "r") as f:
+        for line in f:
+            if line.startswith("#"):
+                continue
+            values = line.split()
+            if not values:
+                continue
+            if values[0] == "v":
+                verts.append([float(x) for x in values[1:4]])
+            elif values[0] == "f":
+                idx = [int(x.split("/")[0]) for x in values[1:]]
+                faces.append(idx[:3])
+                if len(idx) > 3:
+                    faces.append([idx[2], idx[3], idx[0]])
+    return np.array(verts), np.array(faces) - 1

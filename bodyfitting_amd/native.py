@@ -89,6 +89,47 @@ class DeviceModel:
         return verts, joints, jori
 
 
+class Scan:
+    """A scan mesh with its closest-point grid on the GPU (reference utils/mesh_grid_searcher.py:51-84)."""
+
+    def __init__(self, verts, faces, device=0):
+        self._lib = _lib.load()
+        v = _f32(verts, (-1, 3))
+        f = _i32(np.asarray(faces).reshape(-1, 3))
+        self.n_verts, self.n_faces = len(v), len(f)
+        self._h = C.c_void_p()
+        _lib.check(self._lib.bf_scan_create(int(device), len(v), _lib.fptr(v), len(f), _lib.iptr(f), C.byref(self._h)),
+                   "bf_scan_create")
+        self.height = float(self._lib.bf_scan_height(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bf_scan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def grid_info(self):
+        dims = np.zeros(3, np.int32)
+        os_ = np.zeros(4, np.float32)
+        _lib.check(self._lib.bf_scan_grid_info(self._h, _lib.iptr(dims), _lib.fptr(os_)), "bf_scan_grid_info")
+        return dims, os_[:3], float(os_[3])
+
+    def nearest_points(self, points):
+        """-> (nearest points [n,3], face ids [n], barycentrics [n,3]) like MeshGridSearcher.nearest_points"""
+        p = _f32(points, (-1, 3))
+        ids = np.empty(len(p), np.int32)
+        pts = np.empty((len(p), 3), np.float32)
+        bary = np.empty((len(p), 3), np.float32)
+        _lib.check(self._lib.bf_scan_nearest(self._h, len(p), _lib.fptr(p), _lib.iptr(ids), _lib.fptr(pts), _lib.fptr(bary)),
+                   "bf_scan_nearest")
+        return pts, ids, bary
+
+
 def make_hyper(**kw):
     h = _lib.Hyper()
     _lib.load().bf_hyper_default(C.byref(h))
@@ -135,6 +176,17 @@ class FrameBatch:
         b = _f32(init_betas, (self.F, self.model.n_betas))
         p = _f32(init_pose, (self.F, 3 * self.model.n_joints))
         _lib.check(self._lib.bf_batch_set_init(self._h, _lib.fptr(b), _lib.fptr(p)), "bf_batch_set_init")
+
+    def set_scans(self, scans):
+        """one Scan per frame (use_mesh=True); None detaches"""
+        if scans is None:
+            _lib.check(self._lib.bf_batch_set_scans(self._h, None), "bf_batch_set_scans")
+            self._scans = None
+            return
+        assert len(scans) == self.F
+        arr = (C.c_void_p * self.F)(*[s._h for s in scans])
+        _lib.check(self._lib.bf_batch_set_scans(self._h, arr), "bf_batch_set_scans")
+        self._scans = list(scans)          # keep them alive
 
     def reset(self):
         """re-arm for another fit of the same inputs (stream-ordered, no host traffic)"""

@@ -453,3 +453,39 @@ def make_problem(model, frame=0, n_views=48, imsize=512, constant_scale=0.3, pos
         "gt": {"betas": betas_gt, "pose": pose_gt, "transl": transl_gt, "scale": scale_gt},
         "constant_scale": constant_scale,
     }
+
+
+def make_scan_problem(model, frame=0, n_views=8, imsize=512, scan_scale=1.0, noise=0.003, pose_noise=0.1):
+    """A frame with a scan mesh (use_mesh=True, reference smplify.py:146-156): the scan is the ground-
+    truth posed body (the model's own topology) with smooth noise, in a world whose constant scale is
+    scan_height / 1.7 by construction.  Returns (problem dict, scan_verts float32[NV,3], scan_faces int32[F,3])."""
+    rng = np.random.default_rng(5000 + frame)
+    betas_gt = rng.normal(0.0, 0.5, size=10)
+    pose_gt = rng.normal(0.0, 0.15, size=72)
+    pose_gt[:3] = [0.0, rng.uniform(-np.pi, np.pi), 0.0]
+    transl_gt = rng.normal(0.0, 0.05, size=3)
+    verts, joints = smpl_joints64(model, betas_gt, pose_gt)
+    ext_y = verts[:, 1].max() - verts[:, 1].min()
+    scale_gt = 1.7 / ext_y                     # => scan_height / 1.7 == scan_scale exactly
+    scan = (verts + transl_gt) * scale_gt * scan_scale
+    bump = 0.5 * np.sin(scan * 9.0 + rng.uniform(0, 6.28, size=3)) + rng.normal(0.0, 0.3, size=scan.shape)
+    scan = scan + noise * scan_scale * bump
+    # the reference reads the scan from an OBJ written with 4 decimals (utils/io_utils.py:185-192)
+    scan = np.round(scan, 4).astype(np.float32)
+    cscale = float((scan[:, 1].max() - scan[:, 1].min()) / 1.7)
+    world = (joints[model["joint_map"][:25]] + transl_gt) * scale_gt * scan_scale
+    centre = world.mean(0)
+    c2ws, Ks = ring_cameras(n_views, radius=3.2 * scan_scale, imsize=imsize, focal=float(imsize), centre=centre.tolist())
+    keypoints = []
+    for v in range(n_views):
+        w2c = np.linalg.inv(c2ws[v].astype(np.float64))
+        cam = world @ w2c[:3, :3].T + w2c[:3, 3]
+        uvw = cam @ Ks[v].astype(np.float64).T
+        uv = uvw[:, :2] / uvw[:, 2:3] + rng.normal(0.0, 1.0, size=(25, 2))
+        conf = rng.uniform(0.5, 1.0, size=25)
+        keypoints.append({"pose": np.concatenate([uv, conf[:, None]], 1).astype(np.float32)})
+    init_pose = (pose_gt + rng.normal(0.0, pose_noise, size=72)).astype(np.float32)
+    prob = {"c2ws": c2ws, "Ks": Ks, "keypoints": keypoints, "imsize": imsize, "use_frames": list(range(n_views)),
+            "init_betas": np.zeros((1, 10), np.float32), "init_pose": init_pose[None], "constant_scale": cscale,
+            "gt": {"betas": betas_gt, "pose": pose_gt, "transl": transl_gt, "scale": scale_gt}}
+    return prob, scan, np.asarray(model["faces"], dtype=np.int32)

@@ -33,6 +33,7 @@ typedef enum bf_status {
 
 typedef struct bf_model bf_model;   /* body model + GMM prior resident on one device */
 typedef struct bf_batch bf_batch;   /* F independent frames being fitted against one model */
+typedef struct bf_scan bf_scan;     /* one scan mesh + its uniform closest-point grid on one device */
 
 /*
  * Body model tensors exactly as smplx==0.1.13 stores them and reference models/smpl.py:56-66 extends
@@ -144,6 +145,21 @@ int bf_batch_get_result(bf_batch *b, float *vertices, float *joints, float *full
 /* packed [F,n_params] stepped parameters copied into a DEVICE buffer (e.g. the send buffer of the
  * final RCCL all-gather when frames are sharded over GPUs) */
 int bf_batch_export_params_dev(bf_batch *b, void *dst_dev);
+
+/* ---- scan closest-point path (use_mesh, BASELINE config 5) ------------------------------------------
+ * MeshGridSearcher(verts, faces) (utils/mesh_grid_searcher.py:51-79 -> insert_grid_surface,
+ * thirdparty/mesh_grid/mesh_grid.cpp:31-52): verts[n_verts,3], faces[n_faces,3] int32. */
+int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, const int32_t *faces, bf_scan **out);
+void bf_scan_destroy(bf_scan *s);
+float bf_scan_height(const bf_scan *s);                 /* (max - min)[1], smplify.py:150-151 */
+int bf_scan_grid_info(const bf_scan *s, int32_t dims[3], float origin_step[4]);
+/* MeshGridSearcher.nearest_points / search_nearest_point (mesh_grid.cpp:54-72): points[n,3] ->
+ * face_ids[n] int32, nearest[n,3], bary[n,3] (any output may be NULL) */
+int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, float *nearest, float *bary);
+/* use_mesh=True: scans[F], one per frame (NULL detaches).  Sets each frame's constant scale to
+ * scan_height / 1.7 (smplify.py:156); bf_fit then adds 5 * point_cloud_loss / scan_height * imsize for
+ * iterations i > n_iters // 3 (smplify.py:205-210). */
+int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans);
 
 /* Device time of the kernels of the last bf_fit on this batch, from HIP events on the batch's
  * stream: ms[0] = fit loop kernel(s), ms[1] = final full-mesh forward kernel, ms[2] = joints kernel +

@@ -138,6 +138,81 @@ def reference_loss_terms(model, gmm, problem, params):
             {k: v.grad.numpy()[0].copy() for k, v in p.items()}, mj.detach().numpy()[0], bv.detach().numpy()[0])
 
 
+class StandInMeshGridSearcher:
+    """Replaces utils.mesh_grid_searcher.MeshGridSearcher (whose CUDA extension cannot be built here)
+    inside the imported reference: same interface, brute-force search with the reference's per-triangle
+    rule (oracle/mesh_oracle.py)."""
+
+    def __init__(self, verts=None, faces=None, device="cpu"):
+        self.verts, self.faces = np.asarray(verts), np.asarray(faces)
+
+    def nearest_points(self, points):
+        import torch
+        from oracle import mesh_oracle as MO
+        ids, pts, _ = MO.nearest_bruteforce(self.verts, self.faces, points.detach().cpu().numpy())
+        return torch.from_numpy(pts), torch.from_numpy(ids)
+
+
+def run_reference_scan_fit(problem, meshfile, num_iters, snapshots=(), displacement=False):
+    """reference SMPLify.__call__ with use_mesh=True (smplify.py:146-156,205-210,228-247)."""
+    import torch
+    import smplify.smplify as RS
+
+    RS.MeshGridSearcher = StandInMeshGridSearcher
+    snaps, disp_snaps = {}, {}
+    orig_step = torch.optim.Adam.step
+    counter = {"n": 0}
+
+    def step(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        g = self.param_groups
+        if len(g) > 1:
+            counter["n"] += 1
+            if counter["n"] in snapshots:
+                snaps[counter["n"]] = {n: g[i]["params"][0].detach().numpy()[0].copy() for i, n in
+                                       enumerate(("global_transl", "scale", "pose", "betas", "global_orient"))}
+        else:
+            counter["d"] = counter.get("d", 0) + 1
+            if counter["d"] in snapshots:
+                disp_snaps[counter["d"]] = g[0]["params"][0].detach().numpy()[0].copy()
+        return r
+
+    torch.optim.Adam.step = step
+    try:
+        fitter = RS.SMPLify(smpl_type="smpl", num_iters=num_iters, gender="neutral", device=torch.device("cpu"), debug=False)
+        net_output = (torch.from_numpy(problem["init_betas"].copy()), torch.from_numpy(problem["init_pose"].copy()))
+        res = fitter(net_output, problem["c2ws"], problem["Ks"], problem["keypoints"], None,
+                     use_frames=problem["use_frames"], imsize=problem["imsize"], use_mesh=True, meshfile=meshfile,
+                     displacement=displacement)
+    finally:
+        torch.optim.Adam.step = orig_step
+    return res, snaps, disp_snaps
+
+
+def scan_goldens():
+    """config 5 in miniature: reduced 690-vertex model so the brute-force stand-in search stays cheap."""
+    import smplx
+    from bodyfitting_amd import synthetic as S
+    from bodyfitting_amd.io import save_obj_mesh
+
+    model = S.make_model("smpl", seed=0, nv=690)
+    gmm = S.make_gmm(seed=0)
+    smplx.MODEL_REGISTRY["smpl"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_golden_scan_")
+    write_data_dir(tmp, model, gmm)
+    os.chdir(tmp)
+    prob, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
+    meshfile = os.path.join(tmp, "scan.obj")
+    save_obj_mesh(meshfile, sv, sf)
+    res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 30, snapshots=(1, 11, 12, 20, 30), displacement=True)
+    np.savez_compressed(os.path.join(GOLDEN, "scan_nv690_30it.npz"), frame=0, n_views=8, num_iters=30, nv=690,
+                        model_digest=S.model_digest(model), scan_verts=sv, scan_faces=sf,
+                        vertices=res["vertices"], joints=res["joints"], displacement=res["displacement"],
+                        final_global_transl=res["global_transl"], **flat_snaps(snaps),
+                        **{f"disp{k}": v for k, v in dsn.items()})
+    print("scan golden: max |disp|", np.abs(res["displacement"]).max())
+
+
 def flat_snaps(snaps):
     out = {}
     for k, d in snaps.items():
@@ -203,4 +278,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--scan-only" in sys.argv:
+        install_reference_imports()
+        scan_goldens()
+    else:
+        main()
+        scan_goldens()

@@ -1,0 +1,168 @@
+"""CPU oracle for the scan closest-point path (config 5).  TEST INFRASTRUCTURE ONLY.
+
+Restates, in numpy / torch:
+  * MeshGridSearcher.set_mesh grid parameters      reference utils/mesh_grid_searcher.py:56-79
+  * the per-triangle closest-point rule             thirdparty/mesh_grid/mesh_grid_kernel.cu:12-109
+    (KKT solve for the barycentric coefficients; if one is negative, fall back to the edge opposite
+    the MOST NEGATIVE coefficient and clamp to its end points - which is not the exact closest point
+    in some obtuse configurations; reproduced on purpose)
+  * nearest face / point / barycentrics per query   mesh_grid_kernel.cu:239-353 (here: brute force
+    over all faces - the grid only prunes, it does not change the argmin except on exact ties)
+  * point_cloud_loss_mesh_grid, normal_loss_mesh_grid, normal_laplacian_smoothness
+                                                    smplify/loss.py:233-242,260-288
+  * compute_normal_torch                            utils/io_utils.py:406-428
+
+PARITY PINNING: the reference's `mesh_grid` CUDA extension cannot be built here (needs the CUDA
+toolkit headers / ATen extension build; writing stand-in headers is not allowed), so the search
+itself is pinned by (i) an independent exact closest-point-on-triangle routine (Ericson) - equal
+wherever the rule's fallback is exact, and never closer - and (ii) goldens of the *imported* reference
+losses (loss.py / io_utils.py run unmodified on torch CPU) fed with this module's nearest points
+through a stand-in MeshGridSearcher (oracle/gen_golden.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def grid_params(verts):
+    """step, cell counts l[3], origin[3] exactly as set_mesh computes them (float32 torch ops)."""
+    v = torch.as_tensor(np.asarray(verts), dtype=torch.float32)
+    _min, _max = v.min(0)[0], v.max(0)[0]
+    step = (torch.cumprod(_max - _min, 0)[-1] / len(v)) ** (1.0 / 3.0)
+    l = _max - _min
+    c = (_max + _min) / 2
+    l = torch.max(torch.floor(l / step), torch.zeros_like(l)) + 1
+    origin = c - step * l / 2
+    return float(step), l.numpy().astype(np.int64), origin.numpy().astype(np.float32)
+
+
+def closest_rule(p0, p1, p2):
+    """Rule of search_nearest_proj for triangles given RELATIVE to the query (p_i = vertex_i - q).
+
+    p0,p1,p2: [N,3] float64.  Returns (coeff[N,3], dist2[N])."""
+    P = np.stack([p0, p1, p2], 1)                                   # [N,3,3]
+    N = len(P)
+    e1, e2 = p1 - p0, p2 - p0
+    a11, a12, a22 = (e1 * e1).sum(1), (e1 * e2).sum(1), (e2 * e2).sum(1)
+    b1, b2 = -(p0 * e1).sum(1), -(p0 * e2).sum(1)
+    det = a11 * a22 - a12 * a12
+    ok = det > 1e-30 * np.maximum(a11 * a22, 1e-300)
+    safe = np.where(ok, det, 1.0)
+    u = (b1 * a22 - b2 * a12) / safe
+    v = (a11 * b2 - a12 * b1) / safe
+    c = np.stack([1 - u - v, u, v], 1)
+    inside = ok & (c.min(1) >= 0)
+    # fallback edge: opposite the most negative coefficient; degenerate triangle: the longest edge
+    i_neg = np.argmin(c, 1)
+    elen = np.stack([((p1 - p2) ** 2).sum(1), ((p2 - p0) ** 2).sum(1), ((p0 - p1) ** 2).sum(1)], 1)
+    i_deg = np.argmax(elen, 1)
+    i = np.where(ok, i_neg, i_deg)
+    j = (i + 1) % 3
+    k = 3 - i - j
+    ar = np.arange(N)
+    pj, pk = P[ar, j], P[ar, k]
+    d = pk - pj
+    dd = (d * d).sum(1)
+    t = np.where(dd > 0, -(pj * d).sum(1) / np.where(dd > 0, dd, 1.0), 0.5)
+    cj, ck = 1 - t, t
+    # order of the reference's tests: coefficient of j negative -> vertex k; then k negative -> vertex j
+    at_k = cj < 0
+    at_j = (~at_k) & (ck < 0)
+    cj = np.where(at_k, 0.0, np.where(at_j, 1.0, cj))
+    ck = np.where(at_k, 1.0, np.where(at_j, 0.0, ck))
+    ce = np.zeros((N, 3))
+    ce[ar, j], ce[ar, k] = cj, ck
+    coeff = np.where(inside[:, None], c, ce)
+    x = np.einsum("ni,nik->nk", coeff, P)
+    return coeff, (x * x).sum(1)
+
+
+def closest_exact(p0, p1, p2):
+    """Independent exact closest point on a triangle to the origin (Ericson, Real-Time Collision
+    Detection 5.1.5), vectorised; returns dist2[N]."""
+    ab, ac, ap = p1 - p0, p2 - p0, -p0
+    d1, d2 = (ab * ap).sum(1), (ac * ap).sum(1)
+    bp = -p1
+    d3, d4 = (ab * bp).sum(1), (ac * bp).sum(1)
+    cp = -p2
+    d5, d6 = (ab * cp).sum(1), (ac * cp).sum(1)
+    vc = d1 * d4 - d3 * d2
+    vb = d5 * d2 - d1 * d6
+    va = d3 * d6 - d5 * d4
+    N = len(p0)
+    out = np.zeros((N, 3))
+    done = np.zeros(N, bool)
+
+    def put(mask, pts):
+        m = mask & ~done
+        out[m] = pts[m]
+        done[m] = True
+
+    put((d1 <= 0) & (d2 <= 0), p0)
+    put((d3 >= 0) & (d4 <= d3), p1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        put((vc <= 0) & (d1 >= 0) & (d3 <= 0), p0 + (d1 / (d1 - d3))[:, None] * ab)
+        put((d6 >= 0) & (d5 <= d6), p2)
+        put((vb <= 0) & (d2 >= 0) & (d6 <= 0), p0 + (d2 / (d2 - d6))[:, None] * ac)
+        w = (d4 - d3) / ((d4 - d3) + (d5 - d6))
+        put((va <= 0) & ((d4 - d3) >= 0) & ((d5 - d6) >= 0), p1 + w[:, None] * (p2 - p1))
+        den = 1.0 / (va + vb + vc)
+        put(np.ones(N, bool), p0 + ab * (vb * den)[:, None] + ac * (vc * den)[:, None])
+    return (out * out).sum(1)
+
+
+def nearest_bruteforce(verts, faces, queries, chunk=256):
+    """(face id int32[Q], nearest point f32[Q,3], barycentrics f32[Q,3]) by the reference rule over
+    ALL faces (float64 arithmetic on the float32 inputs)."""
+    V = np.asarray(verts, np.float32).astype(np.float64)
+    F = np.asarray(faces, np.int64)
+    Q = np.asarray(queries, np.float32).astype(np.float64)
+    tri = V[F]                                                     # [F,3,3]
+    ids = np.zeros(len(Q), np.int32)
+    pts = np.zeros((len(Q), 3), np.float32)
+    bary = np.zeros((len(Q), 3), np.float32)
+    for s in range(0, len(Q), chunk):
+        q = Q[s:s + chunk]
+        rel = tri[None] - q[:, None, None, :]                      # [q,F,3,3]
+        r = rel.reshape(-1, 3, 3)
+        coeff, d2 = closest_rule(r[:, 0], r[:, 1], r[:, 2])
+        d2 = d2.reshape(len(q), len(F))
+        best = np.argmin(d2, 1)
+        cb = coeff.reshape(len(q), len(F), 3)[np.arange(len(q)), best]
+        ids[s:s + chunk] = best
+        bary[s:s + chunk] = cb
+        pts[s:s + chunk] = np.einsum("qi,qik->qk", cb, tri[best])
+    return ids, pts, bary
+
+
+# ----------------------------------------------------------------------------------------------
+# the losses built on the search (torch, differentiable): restated from loss.py / io_utils.py
+# ----------------------------------------------------------------------------------------------
+
+def compute_normal_torch(vertices, faces):
+    """io_utils.py:406-428.  vertices[NV,3] float tensor, faces[F,3] long tensor."""
+    va, vb, vc = vertices[faces[:, 0]], vertices[faces[:, 1]], vertices[faces[:, 2]]
+    n = torch.cross(vb - va, vc - va, dim=1)
+    n = n / (torch.norm(n, dim=-1, keepdim=True) + 1e-8)
+    norm = torch.zeros_like(vertices)
+    for j in range(3):
+        norm = norm.index_add(0, faces[:, j], n)
+    return norm / (torch.norm(norm, dim=-1, keepdim=True) + 1e-8)
+
+
+def point_cloud_loss(points, closest):
+    """loss.py:233-242: ONE Frobenius norm over all vertices (the mean of a scalar is itself)."""
+    return torch.norm(points.reshape(-1, 3) - closest.detach(), p=2)
+
+
+def normal_loss(closest_face_norm, point_norm):
+    """loss.py:260-271 with the (un-normalised, smplify.py:149) scan face normals already gathered."""
+    return torch.mean(1 - torch.sum(closest_face_norm * point_norm, dim=-1))
+
+
+def normal_laplacian_smoothness(norms, faces):
+    """loss.py:273-288."""
+    na, nb, nc = norms[faces[:, 0]], norms[faces[:, 1]], norms[faces[:, 2]]
+    mse = lambda x, y: torch.sum((x - y) ** 2, dim=-1)   # noqa: E731
+    return torch.mean(mse(na, nb) + mse(nc, na) + mse(nb, nc))

@@ -207,7 +207,8 @@ def prepare_views(c2ws, Ks, keypoints, dtype=torch.float32):
     return w2cs, Kt, kps
 
 
-def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=(), trace=None):
+def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=(), trace=None, scan=None,
+        displacement=False, disp_snapshots=()):
     """Run the reference optimisation loop; returns the rtn_dict of smplify.py:216-226 as numpy.
 
     `snapshots`: iteration counts k at which the optimised parameters *after k steps* are
@@ -218,6 +219,12 @@ def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=
     w2cs, Kt, kps = prepare_views(problem["c2ws"], problem["Ks"], problem["keypoints"], dtype)
     n_use = len(problem["use_frames"])
     c = float(problem.get("constant_scale", 0.3))                                # smplify.py:160
+    scan_height = None
+    if scan is not None:                                                         # smplify.py:146-156
+        from oracle import mesh_oracle as MO
+        scan_v, scan_f = np.asarray(scan[0], np.float64), np.asarray(scan[1])
+        scan_height = float((scan_v.max(0) - scan_v.min(0))[1])
+        c = scan_height / 1.7
     init_pose = torch.as_tensor(problem["init_pose"], dtype=torch.float32).to(dtype)
     init_betas = torch.as_tensor(problem["init_betas"], dtype=torch.float32).to(dtype)
 
@@ -245,6 +252,10 @@ def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=
         body_vertices = (out["vertices"] + global_transl) * body_scale * c      # smplify.py:190
         loss, terms = multiview_keypoint_loss(w2cs, Kt, kps, model_joints, body_pose, betas, n_use, gmm,
                                               imsize=problem["imsize"])
+        if scan is not None and i > (num_iters // 3):                             # smplify.py:205-210
+            _, cpts, _ = MO.nearest_bruteforce(scan_v, scan_f, body_vertices.detach().numpy()[0])
+            pc = MO.point_cloud_loss(body_vertices, torch.as_tensor(cpts, dtype=dtype)) / scan_height * problem["imsize"]
+            loss = loss + 5 * pc
         if trace is not None:
             trace.append((float(loss), {k: float(v) for k, v in terms.items()}))
         opt.zero_grad()
@@ -268,6 +279,30 @@ def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=
         "raw_transl": global_transl.detach().numpy()[0].copy(),
         "snapshots": snaps,
     }
+    if displacement and scan is not None:
+        # SMPL+D stage, smplify.py:228-247: Adam(lr=5e-2) on a per-vertex displacement
+        bv = body_vertices.detach()
+        disp = torch.zeros_like(bv, requires_grad=True)
+        opt_d = torch.optim.Adam([disp], lr=5e-2, betas=(0.9, 0.999))
+        faces_t = torch.as_tensor(np.asarray(model["faces"]), dtype=torch.long)
+        tris = scan_v[scan_f]
+        face_norms = torch.as_tensor(np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]), dtype=torch.float32).to(dtype)
+        dsn = {}
+        for i in range(num_iters):
+            deformed = bv + disp
+            norms = MO.compute_normal_torch(deformed[0], faces_t)
+            ids, cpts, _ = MO.nearest_bruteforce(scan_v, scan_f, deformed.detach().numpy()[0])
+            icp = MO.point_cloud_loss(deformed, torch.as_tensor(cpts, dtype=dtype))
+            nl = MO.normal_loss(face_norms[torch.as_tensor(ids, dtype=torch.long)], norms)
+            sm = MO.normal_laplacian_smoothness(norms, faces_t)
+            loss_d = icp + (nl + sm) * c * 0.1
+            opt_d.zero_grad()
+            loss_d.backward()
+            opt_d.step()
+            if (i + 1) in disp_snapshots:
+                dsn[i + 1] = disp.detach().numpy()[0].copy()
+        res["displacement"] = disp.detach().numpy()[0].copy()
+        res["disp_snapshots"] = dsn
     return res
 
 

@@ -1,0 +1,101 @@
+"""HIP scan path (closest-point grid search, point-cloud loss, dense reverse pass) through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from bodyfitting_amd import native as N
+from bodyfitting_amd import synthetic as S
+from oracle import mesh_oracle as MO
+
+pytestmark = pytest.mark.gpu
+PARAMS = ("global_transl", "scale", "pose", "betas", "global_orient")
+
+
+@pytest.fixture(scope="module")
+def small():
+    model = S.make_model("smpl", seed=0, nv=690)
+    dev = N.DeviceModel(model, S.make_gmm(seed=0), device=0)
+    yield model, dev
+    dev.close()
+
+
+def test_grid_matches_set_mesh(small):
+    """cells / origin / step of MeshGridSearcher.set_mesh (utils/mesh_grid_searcher.py:63-71)"""
+    model, _ = small
+    _, sv, sf = S.make_scan_problem(model, 0)
+    scan = N.Scan(sv, sf)
+    dims, origin, step = scan.grid_info()
+    step_o, l_o, org_o = MO.grid_params(sv)
+    assert step == pytest.approx(step_o, rel=1e-6)
+    np.testing.assert_array_equal(dims, l_o)
+    np.testing.assert_allclose(origin, org_o, atol=1e-6)
+    assert scan.height == pytest.approx(float(sv[:, 1].max() - sv[:, 1].min()), rel=1e-6)
+    scan.close()
+
+
+@pytest.mark.parametrize("spread", [0.01, 0.2, 3.0])
+def test_nearest_points_match_bruteforce_rule(small, spread):
+    """near, far and way-outside-the-grid queries against the oracle's brute-force search"""
+    model, _ = small
+    _, sv, sf = S.make_scan_problem(model, 1)
+    rng = np.random.default_rng(7)
+    q = (sv[rng.integers(0, len(sv), 400)] + rng.normal(0, spread, (400, 3))).astype(np.float32)
+    scan = N.Scan(sv, sf)
+    pts, ids, bary = scan.nearest_points(q)
+    ids_o, pts_o, bary_o = MO.nearest_bruteforce(sv, sf, q)
+    d = np.linalg.norm(pts - q, axis=1)
+    d_o = np.linalg.norm(pts_o - q, axis=1)
+    np.testing.assert_allclose(d, d_o, rtol=2e-5, atol=2e-6)          # same distance (ties may pick another face)
+    same = ids == ids_o
+    assert same.mean() > 0.9
+    tol = 5e-6 * max(1.0, float(d_o.max()))                          # fp32 offsets relative to the query
+    np.testing.assert_allclose(pts[same], pts_o[same], atol=tol)
+    np.testing.assert_allclose(bary[same], bary_o[same], atol=2e-4 * max(1.0, float(d_o.max())))
+    np.testing.assert_allclose(bary.sum(1), 1.0, atol=1e-5)
+    # the returned point really is that barycentric combination of that face
+    np.testing.assert_allclose(np.einsum("qi,qik->qk", bary, sv[sf[ids]]), pts, atol=tol)
+    scan.close()
+
+
+def test_scan_fit_matches_reference_golden(small):
+    """smplify.py loop with use_mesh=True: 11 keypoint-only iterations, then 19 with the point-cloud
+    loss, against the imported reference (stand-in searcher)."""
+    model, dev = small
+    g = load_golden("scan_nv690_30it.npz")
+    prob, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
+    scan = N.Scan(sv, sf)
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
+    b = N.FrameBatch(dev, 1, 8)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+    b.set_scans([scan])
+    b.fit(30)            # the switch-on iteration is num_iters // 3 of THIS call, as in the reference
+    got = N.split_params(b.get_params()[0])
+    for n in PARAMS:
+        np.testing.assert_allclose(got[n], g[f"it30_{n}"], rtol=0, atol=1e-4, err_msg=n)
+    verts, joints, _, _ = b.get_result()
+    np.testing.assert_allclose(verts[0], g["vertices"], atol=1e-4)
+    np.testing.assert_allclose(joints[0], g["joints"], atol=1e-4)
+    b.close()
+    scan.close()
+
+
+def test_two_frames_two_scans(small):
+    """per-frame scans and per-frame constant scale inside one batch == each frame alone"""
+    model, dev = small
+    items = [S.make_scan_problem(model, frame=f, n_views=8, scan_scale=sc) for f, sc in ((0, 1.0), (1, 0.5))]
+    scans = [N.Scan(sv, sf) for _, sv, sf in items]
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([p for p, _, _ in items])
+    b = N.FrameBatch(dev, 2, 8)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose); b.set_scans(scans)
+    b.fit(15)
+    both = b.get_params()
+    b.close()
+    for i in range(2):
+        b1 = N.FrameBatch(dev, 1, 8)
+        b1.set_cameras(c2w[i:i + 1], K[i:i + 1]); b1.set_keypoints(kp[i:i + 1], ndiv[i:i + 1])
+        b1.set_init(betas[i:i + 1], pose[i:i + 1]); b1.set_scans([scans[i]])
+        b1.fit(15)
+        np.testing.assert_array_equal(b1.get_params()[0], both[i])
+        b1.close()
+    for s in scans:
+        s.close()

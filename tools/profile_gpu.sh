@@ -15,10 +15,16 @@ echo "trace rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_dense" -- $BENCH --dense > "$OUT/trace_dense.log" 2>&1
 echo "trace_dense rc=$?"
 # PMC passes on their own (no trace domains), one counter group per run
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- $BENCH --dense > "$OUT/pmc_fetch.log" 2>&1
-echo "pmc_fetch rc=$?"
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- $BENCH --dense > "$OUT/pmc_write.log" 2>&1
-echo "pmc_write rc=$?"
+# (counter collection serialises every dispatch: keep these runs tiny; the sparse leg gives the fit kernel's
+#  100-iteration launches, the dense leg many mesh-kernel launches)
+PMCB="python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
+for leg in sparse dense; do
+  flag=""; [ $leg = dense ] && flag="--dense --iters 10"
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$leg" -- $PMCB $flag > "$OUT/pmc_fetch_$leg.log" 2>&1
+  echo "pmc_fetch_$leg rc=$?"
+  timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_$leg" -- $PMCB $flag > "$OUT/pmc_write_$leg.log" 2>&1
+  echo "pmc_write_$leg rc=$?"
+done
 cd "$ROOT"
 python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2> "$OUT/summary.err"
 echo "summary rc=$?"
