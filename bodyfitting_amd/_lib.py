@@ -27,13 +27,14 @@ class ModelDesc(C.Structure):
         ("gmm_components", C.c_int32), ("gmm_dim", C.c_int32),
         ("gmm_means", C.POINTER(C.c_float)), ("gmm_precisions", C.POINTER(C.c_float)),
         ("gmm_nll_weights", C.POINTER(C.c_float)),
+        ("n_faces", C.c_int32), ("faces", C.POINTER(C.c_int32)),
     ]
 
 
 class Hyper(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "sigma", "pose_prior_weight", "angle_prior_weight", "shape_prior_weight", "constant_scale",
-        "imsize", "lr", "lr_transl_scale", "adam_beta1", "adam_beta2", "adam_eps")]
+        "imsize", "lr", "lr_transl_scale", "adam_beta1", "adam_beta2", "adam_eps", "lr_displacement")]
 
 
 FIT_DEFAULT, FIT_DENSE, FIT_NO_VERTICES, FIT_FETCH = 0, 1, 2, 4
@@ -70,6 +71,8 @@ SIGNATURES = {
     "bf_scan_grid_info": (C.c_int, [_VP, _IP, _FP]),
     "bf_scan_nearest": (C.c_int, [_VP, C.c_int, _FP, _IP, _FP, _FP]),
     "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "bf_fit_displacement": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper)]),
+    "bf_batch_get_displacement": (C.c_int, [_VP, _FP]),
     "bf_batch_last_timing": (C.c_int, [_VP, _FP]),
     "bf_batch_timing_reset": (C.c_int, [_VP]),
     "bf_batch_timing_sum": (C.c_int, [_VP, _FP, _IP]),

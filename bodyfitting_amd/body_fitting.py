@@ -52,4 +52,7 @@ class BodyFitting:
             os.makedirs(output_folder, exist_ok=True)
             np.save(os.path.join(output_folder, f"{self.smpl_type}_parameter.npy"), result)
             save_obj_mesh(os.path.join(output_folder, f"{self.smpl_type}.obj"), result["vertices"], result["faces"])
+            if disp and "displacement" in result:                                    # body_fitting.py:98-99
+                save_obj_mesh(os.path.join(output_folder, f"{self.smpl_type}+d.obj"),
+                              result["vertices"] + result["displacement"], result["faces"])
         return result

@@ -35,6 +35,7 @@ void bf_hyper_default(bf_hyper *h) {
     h->adam_beta1 = 0.9f;
     h->adam_beta2 = 0.999f;
     h->adam_eps = 1e-8f;
+    h->lr_displacement = 5e-2f;
 }
 
 int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
@@ -197,6 +198,11 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     up_f(m->shapedirs, d->shapedirs, (size_t)nv * 3 * nb);
     up_f(m->posedirs, d->posedirs, (size_t)npf * 3 * nv);
     m->posedirs_host.assign(d->posedirs, d->posedirs + (size_t)npf * 3 * nv);
+    if (d->n_faces > 0 && d->faces) {
+        for (int i = 0; i < d->n_faces * 3; ++i)
+            if (d->faces[i] < 0 || d->faces[i] >= nv) { delete m; return fail(BF_ERR_INVALID, "bf_model_create: face index out of range"); }
+        m->faces_host.assign(d->faces, d->faces + (size_t)d->n_faces * 3);
+    }
     up_f(m->lbs_weights, d->lbs_weights, (size_t)nv * nj);
     up_f(m->j_extra, d->j_regressor_extra, (size_t)d->n_extra * nv);
     up_vi(m->selector_ids, std::vector<int>(d->selector_ids, d->selector_ids + d->n_selector));

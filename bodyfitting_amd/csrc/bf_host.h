@@ -55,6 +55,7 @@ struct bf_model {
     DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass
     std::vector<float> posedirs_host;
     std::vector<int> faces_host;  // body-model topology (for the SMPL+D stage), optional
+    DevBuf<int> faces_d, adj_start, adj;   // faces and the vertex -> (face, corner) lists, built on first use
 };
 
 struct bf_batch {
@@ -81,7 +82,9 @@ struct bf_batch {
     DevBuf<float> cscale, pc_weight, pc_partial, pc_loss, dvout, vposed, cpts, ext_part, ext;
     DevBuf<int> cface;
     // SMPL+D stage (smplify.py:228-247)
-    DevBuf<float> disp, disp_m, disp_v, disp_base;
+    DevBuf<float> disp, disp_m, disp_v, disp_base, disp_P, disp_fn, disp_vn, disp_dv, disp_dPf;
+    DevBuf<const float *> scan_fn;
+    int disp_steps = 0;
     bool have_disp = false;
 };
 

@@ -9,6 +9,13 @@ extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, 
 extern "C" __global__ void bf_mesh_bwd_kernel(MeshTab, const float *, const float *, const float *, const float *, const float *, float *);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *);
 extern "C" size_t bf_mesh_bwd_smem_bytes(int);
+extern "C" __global__ void bf_disp_face_kernel(const int *, int, int, const float *, const float *, float *);
+extern "C" __global__ void bf_disp_vertex_kernel(const int *, const int *, int, int, const float *, const float *, const float *, float *, float *);
+extern "C" __global__ void bf_disp_vgrad_kernel(const int *, const int *, const int *, int, int, const float *, const float *const *,
+                                                const int *, const float *, float *);
+extern "C" __global__ void bf_disp_fgrad_kernel(const int *, int, int, const float *, const float *, const float *, float *);
+extern "C" __global__ void bf_disp_adam_kernel(const int *, const int *, int, int, const float *, const float *, const float *, int,
+                                               const float *, float *, float *, float *, float, float, float, float, float);
 
 extern "C" {
 
@@ -204,6 +211,94 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
         io2.ext = b->ext.p;
         HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
     }
+    return BF_OK;
+}
+
+int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
+    if (!b || n_iters <= 0) return fail(BF_ERR_INVALID, "bf_fit_displacement: bad argument");
+    bf_model *m = b->m;
+    if (b->scans.empty()) return fail(BF_ERR_INVALID, "bf_fit_displacement: no scans attached (bf_batch_set_scans)");
+    if (!b->have_result) return fail(BF_ERR_INVALID, "bf_fit_displacement: run bf_fit first (the stage starts from its vertices)");
+    if (m->faces_host.empty()) return fail(BF_ERR_INVALID, "bf_fit_displacement: the model was created without faces");
+    HIP_TRY(hipSetDevice(m->device));
+    bf_hyper h;
+    if (hyper) h = *hyper; else bf_hyper_default(&h);
+    const int F = b->F, nv = m->nv, nf = (int)m->faces_host.size() / 3;
+    if (!m->faces_d.p) {
+        // vertex -> (face, corner) lists in the order compute_normal_torch adds them: corner by corner, faces ascending
+        std::vector<int> start(nv + 1, 0), adj(m->faces_host.size());
+        for (int v : m->faces_host) ++start[v + 1];
+        for (int v = 0; v < nv; ++v) start[v + 1] += start[v];
+        std::vector<int> fill(start.begin(), start.end() - 1);
+        for (int c = 0; c < 3; ++c)
+            for (int f = 0; f < nf; ++f) adj[fill[m->faces_host[f * 3 + c]]++] = f * 4 + c;
+        HIP_TRY(m->faces_d.upload(m->faces_host));
+        HIP_TRY(m->adj_start.upload(start));
+        HIP_TRY(m->adj.upload(adj));
+    }
+    const size_t nv3 = (size_t)F * nv * 3;
+    if (!b->disp.p) {
+        bool ok = b->disp.alloc(nv3) == hipSuccess && b->disp_m.alloc(nv3) == hipSuccess && b->disp_v.alloc(nv3) == hipSuccess &&
+                  b->disp_base.alloc(nv3) == hipSuccess && b->disp_P.alloc(nv3) == hipSuccess && b->disp_dv.alloc(nv3) == hipSuccess &&
+                  b->disp_fn.alloc((size_t)F * nf * 4) == hipSuccess && b->disp_vn.alloc((size_t)F * nv * 4) == hipSuccess &&
+                  b->disp_dPf.alloc((size_t)F * nf * 9) == hipSuccess;
+        if (!ok) return fail(BF_ERR_HIP, "bf_fit_displacement: device allocation failed");
+    }
+    {
+        std::vector<const float *> fn(F);
+        for (int f = 0; f < F; ++f) fn[f] = b->scans[f]->face_norms.p;
+        if (b->scan_fn.p) { (void)hipFree((void *)b->scan_fn.p); b->scan_fn.p = nullptr; }
+        HIP_TRY(b->scan_fn.upload(fn));
+    }
+    // zeros for disp and its moments; the base is the mesh of the last forward, detached (smplify.py:229-231)
+    HIP_TRY(hipMemsetAsync(b->disp.p, 0, nv3 * sizeof(float), b->stream));
+    HIP_TRY(hipMemsetAsync(b->disp_m.p, 0, nv3 * sizeof(float), b->stream));
+    HIP_TRY(hipMemsetAsync(b->disp_v.p, 0, nv3 * sizeof(float), b->stream));
+    HIP_TRY(hipMemcpyAsync(b->disp_base.p, b->vout.p, nv3 * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    const dim3 gv((nv + 255) / 256, F), gf((nf + 255) / 256, F);
+    const int nblk = (nv + 255) / 256;
+    const double b1 = h.adam_beta1, b2 = h.adam_beta2;
+    for (int it = 1; it <= n_iters; ++it) {
+        hipLaunchKernelGGL(bf_disp_face_kernel, gf, dim3(256), 0, b->stream, (const int *)m->faces_d.p, nf, nv,
+                           (const float *)b->disp_base.p, (const float *)b->disp.p, b->disp_fn.p);
+        hipLaunchKernelGGL(bf_disp_vertex_kernel, gv, dim3(256), 0, b->stream, (const int *)m->adj_start.p, (const int *)m->adj.p, nf, nv,
+                           (const float *)b->disp_base.p, (const float *)b->disp.p, (const float *)b->disp_fn.p, b->disp_P.p, b->disp_vn.p);
+        hipLaunchKernelGGL(bf_nearest_kernel, gv, dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p, (const float *)b->disp_P.p, nv,
+                           b->cface.p, b->cpts.p, (float *)nullptr);
+        hipLaunchKernelGGL(bf_pc_partial_kernel, gv, dim3(256), 0, b->stream, (const float *)b->disp_P.p, (const float *)b->cpts.p, nv,
+                           b->pc_partial.p);
+        hipLaunchKernelGGL(bf_disp_vgrad_kernel, gv, dim3(256), 0, b->stream, (const int *)m->faces_d.p, (const int *)m->adj_start.p,
+                           (const int *)m->adj.p, nf, nv, (const float *)b->disp_vn.p, (const float *const *)b->scan_fn.p,
+                           (const int *)b->cface.p, (const float *)b->cscale.p, b->disp_dv.p);
+        hipLaunchKernelGGL(bf_disp_fgrad_kernel, gf, dim3(256), 0, b->stream, (const int *)m->faces_d.p, nf, nv, (const float *)b->disp_P.p,
+                           (const float *)b->disp_fn.p, (const float *)b->disp_dv.p, b->disp_dPf.p);
+        const float step_size = (float)((double)h.lr_displacement / (1.0 - std::pow(b1, it)));
+        const float bc2_sqrt = (float)std::sqrt(1.0 - std::pow(b2, it));
+        hipLaunchKernelGGL(bf_disp_adam_kernel, gv, dim3(256), 0, b->stream, (const int *)m->adj_start.p, (const int *)m->adj.p, nf, nv,
+                           (const float *)b->disp_P.p, (const float *)b->cpts.p, (const float *)b->pc_partial.p, nblk,
+                           (const float *)b->disp_dPf.p, b->disp.p, b->disp_m.p, b->disp_v.p, step_size, bc2_sqrt, h.adam_beta1,
+                           h.adam_beta2, h.adam_eps);
+        HIP_TRY(hipGetLastError());
+    }
+    b->have_disp = true;
+    return BF_OK;
+}
+
+int bf_batch_get_displacement(bf_batch *b, float *displacement) {
+    if (!b || !displacement) return fail(BF_ERR_INVALID, "bf_batch_get_displacement: null argument");
+    if (!b->have_disp) return fail(BF_ERR_INVALID, "bf_batch_get_displacement: no bf_fit_displacement yet");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(displacement, b->disp.p, b->disp.n * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+/* test hook: first Adam moment of the displacement (after one step it is 0.1 x the gradient) */
+int bf_batch_debug_disp_moment(bf_batch *b, float *m_out) {
+    if (!b || !m_out || !b->have_disp) return fail(BF_ERR_INVALID, "bf_batch_debug_disp_moment: bad argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemcpy(m_out, b->disp_m.p, b->disp_m.n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
 }
 

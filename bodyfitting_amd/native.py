@@ -59,6 +59,9 @@ class DeviceModel:
         d.n_selector, d.n_extra = self.n_selector, keep["j_regressor_extra"].shape[0]
         d.n_joint_map, d.n_loss_joints = self.n_joint_map, N_LOSS_JOINTS
         d.gmm_components, d.gmm_dim = keep["gmm_means"].shape
+        if self.faces is not None:
+            keep["faces"] = _i32(self.faces.reshape(-1, 3))
+            d.n_faces, d.faces = len(keep["faces"]), _lib.iptr(keep["faces"])
         self._h = C.c_void_p()
         _lib.check(lib.bf_model_create(C.byref(d), int(device), C.byref(self._h)), "bf_model_create")
         self.device = int(device)
@@ -187,6 +190,16 @@ class FrameBatch:
         arr = (C.c_void_p * self.F)(*[s._h for s in scans])
         _lib.check(self._lib.bf_batch_set_scans(self._h, arr), "bf_batch_set_scans")
         self._scans = list(scans)          # keep them alive
+
+    def fit_displacement(self, n_iters, hyper=None):
+        """SMPL+D stage (smplify.py:228-247) on the vertices of the last fit"""
+        hp = C.byref(hyper) if hyper is not None else None
+        _lib.check(self._lib.bf_fit_displacement(self._h, int(n_iters), hp), "bf_fit_displacement")
+
+    def get_displacement(self):
+        d = np.empty((self.F, self.model.n_verts, 3), np.float32)
+        _lib.check(self._lib.bf_batch_get_displacement(self._h, _lib.fptr(d)), "bf_batch_get_displacement")
+        return d
 
     def reset(self):
         """re-arm for another fit of the same inputs (stream-ordered, no host traffic)"""

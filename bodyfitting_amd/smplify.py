@@ -7,7 +7,7 @@ global_transl[3] (= t*s, without the constant scale), scale[1], full_pose[72].
 Differences, all at the edges: the model / GMM are resolved once per process through
 `bodyfitting_amd.assets` instead of being re-read per frame; `net_output` may hold numpy arrays or
 anything with `.detach().cpu().numpy()`; `device` is a HIP device index (or a torch.device whose
-index is used).  Options whose kernels are not built yet (use_mask, use_mesh, displacement, smplx)
+index is used).  Options whose kernels are not built yet (use_mask, smplx)
 raise NotImplementedError - there is no silent CPU path.
 """
 from __future__ import annotations
@@ -15,7 +15,8 @@ from __future__ import annotations
 import numpy as np
 
 from . import assets
-from .native import FrameBatch, make_hyper, split_params, N_LOSS_JOINTS
+from .io import load_obj_mesh
+from .native import FrameBatch, Scan, make_hyper, split_params, N_LOSS_JOINTS
 
 
 def _np(x):
@@ -55,26 +56,40 @@ class SMPLify:
 
     # ------------------------------------------------------------------------------------------
     def fit_frames(self, init_betas, init_poses, c2ws, Ks, keypoints, n_use_frames=None, imsize=512,
-                   constant_scale=0.3, num_iters=None, flags=0):
+                   constant_scale=0.3, num_iters=None, flags=0, scans=None, displacement=False):
         """Fit F independent frames in one launch.
 
         init_betas[F,10], init_poses[F,72], c2ws[F,V,4,4], Ks[F,V,3,3], keypoints[F,V,25,3]
-        (confidence 0 = no detection).  Returns a list of F result dicts."""
+        (confidence 0 = no detection); scans: optional list of F (verts, faces) scan meshes (use_mesh=True:
+        the point-cloud loss switches on after num_iters // 3 and the constant scale becomes
+        scan_height / 1.7, smplify.py:146-156,205-210); displacement: run the SMPL+D stage afterwards
+        (smplify.py:228-247).  Returns a list of F result dicts."""
         init_betas = np.asarray(init_betas, np.float32).reshape(-1, self._dev.n_betas)
         F = init_betas.shape[0]
         c2ws = np.asarray(c2ws, np.float32).reshape(F, -1, 4, 4)
         V = c2ws.shape[1]
         batch = FrameBatch(self._dev, F, V)
+        dev_scans = []
+        disp = None
         try:
             batch.set_cameras(c2ws, Ks)
             batch.set_keypoints(keypoints, n_use_frames)
             batch.set_init(init_betas, init_poses)
+            if scans is not None:
+                dev_scans = [Scan(v, f, device=self.device) for v, f in scans]
+                batch.set_scans(dev_scans)
             hyper = make_hyper(imsize=imsize, constant_scale=constant_scale)
-            batch.fit(self.num_iters if num_iters is None else num_iters, hyper, flags | 4)
+            n = self.num_iters if num_iters is None else num_iters
+            batch.fit(n, hyper, flags | 4)
             params = batch.get_params()
             verts, joints, full_pose, terms = batch.get_result()
+            if displacement and scans is not None:
+                batch.fit_displacement(n, hyper)
+                disp = batch.get_displacement()
         finally:
             batch.close()
+            for sc in dev_scans:
+                sc.close()
         out = []
         for f in range(F):
             p = split_params(params[f], self._dev.n_joints, self._dev.n_betas)
@@ -86,6 +101,8 @@ class SMPLify:
                 "loss_terms": dict(zip(("reprojection_loss", "pose_prior_loss", "angle_prior_loss", "shape_prior_loss"),
                                        (float(t) for t in terms[f]))),
             })
+            if disp is not None:
+                out[-1]["displacement"] = disp[f]
         return out
 
     def __call__(self, net_output, c2ws, Ks, keypoints, output_folder=None, use_mask=False, masks=None,
@@ -93,8 +110,10 @@ class SMPLify:
                  displacement=False):
         if use_mask:
             raise NotImplementedError("the silhouette loss (loss.py:85-130) is not built yet")
-        if use_mesh or displacement:
-            raise NotImplementedError("the scan closest-point loss / SMPL+D stage (smplify.py:146-156,228-247) is not built yet")
+        scans = None
+        if use_mesh:
+            scan_verts, scan_faces = load_obj_mesh(meshfile)                         # smplify.py:147
+            scans = [(scan_verts.astype(np.float32), scan_faces.astype(np.int32))]
         init_betas, init_poses = (_np(x) for x in net_output)
         V = len(use_frames)
         c2w = np.stack([_np(c) for c in c2ws[:V]]).astype(np.float32)
@@ -103,7 +122,7 @@ class SMPLify:
         for i in range(V):
             if keypoints[i] is not None:                                               # loss.py:157
                 kp[i] = np.asarray(keypoints[i]["pose"], np.float32)[:N_LOSS_JOINTS]
-        res = self.fit_frames(init_betas[:1], init_poses[:1], c2w[None], K[None], kp[None],
-                              n_use_frames=[V], imsize=imsize)[0]                      # divisor loss.py:197
+        res = self.fit_frames(init_betas[:1], init_poses[:1], c2w[None], K[None], kp[None], n_use_frames=[V],
+                              imsize=imsize, scans=scans, displacement=displacement)[0]   # divisor loss.py:197
         res.pop("loss_terms")
         return res

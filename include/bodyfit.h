@@ -61,6 +61,8 @@ typedef struct bf_model_desc {
     const float *gmm_means;        /* [M,D] */
     const float *gmm_precisions;   /* [M,D,D] = inv(covars) */
     const float *gmm_nll_weights;  /* [M] (prior.py:153-160) */
+    int32_t n_faces;               /* body-model topology, only needed by the SMPL+D stage; may be 0 */
+    const int32_t *faces;          /* [n_faces,3] */
 } bf_model_desc;
 
 /* Loss weights and optimiser constants; bf_hyper_default() fills the reference's literals. */
@@ -76,6 +78,7 @@ typedef struct bf_hyper {
     float adam_beta1;          /* 0.9 */
     float adam_beta2;          /* 0.999 */
     float adam_eps;            /* 1e-8 */
+    float lr_displacement;     /* 5e-2  smplify.py:233 */
 } bf_hyper;
 
 /* bf_fit flags */
@@ -160,6 +163,11 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
  * scan_height / 1.7 (smplify.py:156); bf_fit then adds 5 * point_cloud_loss / scan_height * imsize for
  * iterations i > n_iters // 3 (smplify.py:205-210). */
 int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans);
+/* SMPL+D stage (displacement=True, smplify.py:228-247): n_iters Adam steps (lr 5e-2) on a per-vertex
+ * displacement of the vertices returned by the last bf_fit, against each frame's scan:
+ * loss = icp + (normal_loss + laplacian) * constant_scale * 0.1.  Needs faces in the model and scans. */
+int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper);
+int bf_batch_get_displacement(bf_batch *b, float *displacement /*[F,NV,3]*/);
 
 /* Device time of the kernels of the last bf_fit on this batch, from HIP events on the batch's
  * stream: ms[0] = fit loop kernel(s), ms[1] = final full-mesh forward kernel, ms[2] = joints kernel +

@@ -173,3 +173,31 @@ def test_fit_is_resumable(dev_model, smpl_model):
     np.testing.assert_array_equal(a.get_params(), b.get_params())
     a.close()
     b.close()
+
+
+def test_python_mirror_end_to_end(smpl_model, gmm, tmp_path):
+    """bodyfitting_amd.body_fitting.BodyFitting called the way apps/genebody_fitting.py:165-170 calls the
+    reference: same arguments, same files written, same result dict as the reference golden."""
+    import types
+    from bodyfitting_amd import assets
+    from bodyfitting_amd.body_fitting import BodyFitting
+    assets.register_model(smpl_model, "smpl", "neutral")
+    assets.register_gmm(gmm)
+    g = load_golden("cfg2_48view_100it_f0.npz")
+    prob = S.make_problem(smpl_model, frame=0, n_views=48)
+    opts = types.SimpleNamespace(debug=False, load_size=512, use_mask=False, smpl_type="smpl", age="adult", num_iters=100)
+    fitter = BodyFitting(opts)
+    images = [np.zeros((512, 512, 3), np.uint8)] * 48
+    out = tmp_path / "smplify"
+    res = fitter(images, prob["c2ws"], prob["Ks"], prob["keypoints"], gender="neutral", keyframe=25,
+                 use_frames=prob["use_frames"], output_folder=str(out),
+                 net_output=(prob["init_betas"], prob["init_pose"]))
+    for key, want in (("pose", "it100_pose"), ("betas", "it100_betas"), ("global_orient", "it100_global_orient"),
+                      ("global_transl", "final_global_transl"), ("scale", "it100_scale"), ("joints", "joints"),
+                      ("full_pose", "full_pose")):
+        np.testing.assert_allclose(res[key], g[want], atol=FIT_TOL, err_msg=key)
+    assert res["vertices"].shape == (6890, 3) and res["faces"].dtype == np.int32
+    saved = np.load(out / "smpl_parameter.npy", allow_pickle=True).item()        # body_fitting.py:96
+    assert set(saved) == {"vertices", "joints", "pose", "betas", "global_orient", "faces", "global_transl", "scale", "full_pose"}
+    first = (out / "smpl.obj").read_text().splitlines()[0]
+    assert first == "v %.4f %.4f %.4f" % tuple(res["vertices"][0])

@@ -99,3 +99,50 @@ def test_two_frames_two_scans(small):
         b1.close()
     for s in scans:
         s.close()
+
+
+def test_displacement_stage_first_steps(small, gmm_bufs):
+    """SMPL+D (smplify.py:228-247).  The stage is chaotic under round-off (see tests/test_scan_oracle.py), so
+    parity is asserted where it is meaningful: the gradient of the first step (to fp32 round-off, against
+    torch.autograd of the oracle), the first steps of the trajectory, and the reference's own first step."""
+    import ctypes as C
+    import torch
+    from bodyfitting_amd import _lib
+    from oracle import smplify_oracle as O
+    model, dev = small
+    g = load_golden("scan_nv690_30it.npz")
+    prob, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
+    scan = N.Scan(sv, sf)
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
+    b = N.FrameBatch(dev, 1, 8)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose); b.set_scans([scan])
+    b.fit(30)
+    base = b.get_result()[0][0]
+    b.fit_displacement(1)
+    d1 = b.get_displacement()[0]
+    np.testing.assert_allclose(d1, g["disp1"], atol=2e-5)                   # reference, first step
+    m1 = np.empty((1, 690, 3), np.float32)
+    _lib.check(_lib.load().bf_batch_debug_disp_moment(b._h, _lib.fptr(m1)))
+    grad = m1[0] / 0.1
+    # autograd gradient of the same objective at disp = 0 on the same base mesh (fp64 oracle pieces)
+    bv = torch.tensor(base, dtype=torch.float64)
+    disp = torch.zeros_like(bv, requires_grad=True)
+    faces_t = torch.as_tensor(np.asarray(model["faces"]), dtype=torch.long)
+    ids, cpts, _ = MO.nearest_bruteforce(sv, sf, base)
+    tris = sv.astype(np.float64)[sf]
+    fnorm = torch.tensor(np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]).astype(np.float32), dtype=torch.float64)
+    P = bv + disp
+    norms = MO.compute_normal_torch(P, faces_t)
+    c = float((sv[:, 1].max() - sv[:, 1].min()) / 1.7)
+    loss = MO.point_cloud_loss(P, torch.tensor(cpts, dtype=torch.float64)) + (
+        MO.normal_loss(fnorm[torch.as_tensor(ids, dtype=torch.long)], norms) + MO.normal_laplacian_smoothness(norms, faces_t)) * c * 0.1
+    loss.backward()
+    want = disp.grad.numpy()
+    np.testing.assert_allclose(grad, want, atol=1e-4 * np.abs(want).max())   # (observed: 4e-6 abs on values up to 0.1)
+    # a few more steps against the fp32 oracle trajectory from the golden's first step on
+    b.fit_displacement(3)
+    d3 = b.get_displacement()[0]
+    res = O.fit(model, gmm_bufs, prob, 30, scan=(sv, sf), displacement=True, disp_snapshots=(3,))
+    assert np.mean(np.abs(d3 - res["disp_snapshots"][3]) < 2e-4) > 0.97
+    b.close()
+    scan.close()
