@@ -71,6 +71,8 @@ SIGNATURES = {
     "bf_scan_grid_info": (C.c_int, [_VP, _IP, _FP]),
     "bf_scan_nearest": (C.c_int, [_VP, C.c_int, _FP, _IP, _FP, _FP]),
     "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "bf_batch_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP]),
+    "bf_batch_mask_loss": (C.c_int, [_VP, C.POINTER(Hyper), _FP, _FP]),
     "bf_fit_displacement": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper)]),
     "bf_batch_get_displacement": (C.c_int, [_VP, _FP]),
     "bf_batch_last_timing": (C.c_int, [_VP, _FP]),

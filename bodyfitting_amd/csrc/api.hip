@@ -510,11 +510,12 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (rc) return rc;
     HyperDev hd = bf_to_dev(h);
     FrameIO io = bf_frame_io(b, false);
-    if (!b->scans.empty()) flags &= ~BF_FIT_DENSE;
+    const bool dense_losses = !b->scans.empty() || b->has_masks;
+    if (dense_losses) flags &= ~BF_FIT_DENSE;
     const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES);
     b->ev = b->ring.data() + (size_t)(b->ring_n % bf_batch::kRing) * 4;
     HIP_TRY(hipEventRecord(b->ev[0], b->stream));
-    if (!b->scans.empty()) {
+    if (dense_losses) {
         rc = bf_fit_with_scans(b, n_iters, h, hd, io);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(b->ev[1], b->stream));

@@ -81,6 +81,12 @@ struct bf_batch {
     DevBuf<ScanDev> scan_dev;
     DevBuf<float> cscale, pc_weight, pc_partial, pc_loss, dvout, vposed, cpts, ext_part, ext;
     DevBuf<int> cface;
+    // silhouette loss (use_mask, smplify.py:138-144,197-199)
+    bool has_masks = false;
+    MaskIO mask{};
+    DevBuf<int> mk_view, mk_cstart, mk_ccount, mk_choice;
+    DevBuf<unsigned char> mk_masks;
+    DevBuf<float> mk_cxy, mk_uvi, mk_duvb, mk_cgrad, mk_part, mk_loss;
     // SMPL+D stage (smplify.py:228-247)
     DevBuf<float> disp, disp_m, disp_v, disp_base, disp_P, disp_fn, disp_vn, disp_dv, disp_dPf;
     DevBuf<const float *> scan_fn;

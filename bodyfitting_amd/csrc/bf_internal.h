@@ -90,6 +90,17 @@ struct ScanDev {
     const int *cell_tris;     // triangles per cell, ascending face id
 };
 
+// Silhouette-loss inputs of one batch (device pointers).
+struct MaskIO {
+    int nv, ns, n_views, n_masks, H, W, cmax, part_stride, proj_blocks;
+    float imsize, eps, weight;            // weight = 5 (smplify.py:210)
+    const int *view_index;                // [M] index of each mask view among the V views
+    const unsigned char *masks;           // [F][M][H][W], 1 = foreground (already > 128, smplify.py:139)
+    const int *contour_start;             // [F*M] offsets into contour_xy
+    const int *contour_count;             // [F*M]
+    const float *contour_xy;              // [sum][2] (x, y) contour points (loss.py:73-83)
+};
+
 struct FrameIO {
     int n_frames, n_views;
     const float *proj;        // [F][V][12]   K [R|t], world -> pixel

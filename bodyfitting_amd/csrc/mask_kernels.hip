@@ -1,0 +1,167 @@
+// Silhouette loss for gfx950: reference smplify/loss.py:85-130 `multview_mask_loss`, with its gradient
+// w.r.t. the (every 4th, loss.py:99) body vertices.
+//
+//   per mask view:  uv = project(verts[::4]);  inside = 0 <= uv < imsize (both axes)
+//     contour term  sum over contour points c of  coeff_c * min_{inside s} |uv_s - c|,
+//                   coeff_c = 10 if the mask is empty at trunc(uv_argmin) else 1        (loss.py:110-119)
+//     binary term   10 * sum over ALL sampled verts of bilinear(1 - mask)(uv)               (loss.py:123-128,
+//                   grid_sample: bilinear, zeros padding, align_corners=False as torch 2.x evaluates it)
+//
+//   bf_mask_project_kernel   thread = sampled vertex x view: uv, inside flag, binary term + d/duv
+//   bf_mask_contour_kernel   thread = contour point: exact nearest inside vertex (first minimum, like
+//                            torch.min), its weight, the unit direction
+//   bf_mask_gather_kernel    thread = sampled vertex: gathers the contour points that chose it IN CONTOUR
+//                            ORDER (deterministic; no atomics), maps d/duv back through the projection and
+//                            writes dL/dvertex
+// Distances are exact (a - b)^2 sums; torch.cdist switches to the |a|^2+|b|^2-2ab form for these sizes,
+// which is noisier (about 1e-2 px at 512 px) - see DESIGN.md.
+#include "bf_internal.h"
+
+namespace {
+__device__ inline float mk_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+}  // namespace
+
+// grid (ceil(Ns/256), M, F).  uvi[F][M][Ns] = (u, v, inside, 1/pix_z);  duvb[F][M][Ns][2] = d(binary term)/duv * weight
+extern "C" __global__ void __launch_bounds__(256)
+bf_mask_project_kernel(MaskIO K, const float *__restrict__ vout, const float *__restrict__ proj_all, float *__restrict__ uvi,
+                       float *__restrict__ duvb, float *__restrict__ loss_part) {
+    __shared__ float sred[4];
+    const int s = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y, f = blockIdx.z;
+    float lval = 0.f;
+    if (s < K.ns) {
+        const float *X = vout + ((size_t)f * K.nv + (size_t)s * 4) * 3;
+        const float *P = proj_all + ((size_t)f * K.n_views + K.view_index[m]) * 12;
+        float p0 = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3];
+        float p1 = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7];
+        float p2 = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11];
+        float u = p0 / p2, v = p1 / p2;
+        bool inside = u < K.imsize && u >= 0.f && v < K.imsize && v >= 0.f;
+        // grid_sample(1 - mask, uv / imsize * 2 - 1): ix = ((x + 1) W - 1) / 2
+        const float sx = (float)K.W / K.imsize, sy = (float)K.H / K.imsize;
+        float ix = ((u / K.imsize * 2.f - 1.f + 1.f) * K.W - 1.f) * 0.5f, iy = ((v / K.imsize * 2.f - 1.f + 1.f) * K.H - 1.f) * 0.5f;
+        float fx = floorf(ix), fy = floorf(iy);
+        int x0 = (int)fx, y0 = (int)fy;
+        float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
+        const unsigned char *mk = K.masks + ((size_t)f * K.n_masks + m) * K.H * K.W;
+        auto at = [&](int y, int x) -> float {
+            return (x >= 0 && x < K.W && y >= 0 && y < K.H) ? 1.f - (float)mk[(size_t)y * K.W + x] : 0.f;   // zeros padding
+        };
+        float v00 = at(y0, x0), v01 = at(y0, x0 + 1), v10 = at(y0 + 1, x0), v11 = at(y0 + 1, x0 + 1);
+        lval = K.eps * (v00 * wx0 * wy0 + v01 * wx1 * wy0 + v10 * wx0 * wy1 + v11 * wx1 * wy1);
+        float gx = ((v01 - v00) * wy0 + (v11 - v10) * wy1) * sx, gy = ((v10 - v00) * wx0 + (v11 - v01) * wx1) * sy;
+        const size_t o = ((size_t)f * K.n_masks + m) * K.ns + s;
+        float4 rec = {u, v, inside ? 1.f : 0.f, 1.f / p2};
+        ((float4 *)uvi)[o] = rec;
+        duvb[o * 2] = K.weight * K.eps * gx;
+        duvb[o * 2 + 1] = K.weight * K.eps * gy;
+    }
+    lval = mk_wave_sum(lval);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lval;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        loss_part[((size_t)f * K.n_masks + m) * K.part_stride + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+// grid (ceil(Cmax/256), M, F).  For contour point c: choice[F][M][Cmax] = sampled vertex (or -1),
+// cgrad[F][M][Cmax][2] = weight * coeff * (uv - c) / |uv - c|
+extern "C" __global__ void __launch_bounds__(256)
+bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict__ choice, float *__restrict__ cgrad,
+                       float *__restrict__ loss_part) {
+    __shared__ float4 tile[256];
+    __shared__ float sred[4];
+    const int c = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y, f = blockIdx.z;
+    const int vm = f * K.n_masks + m;
+    const int cnt = K.contour_count[vm];
+    const float *cp = K.contour_xy + ((size_t)K.contour_start[vm] + (c < cnt ? c : 0)) * 2;
+    const float cx = cp[0], cy = cp[1];
+    const float4 *rec = (const float4 *)uvi + (size_t)vm * K.ns;
+    float best = 3.0e38f, bu = 0.f, bv = 0.f;
+    int bidx = -1;
+    for (int base = 0; base < K.ns; base += 256) {
+        int s = base + threadIdx.x;
+        tile[threadIdx.x] = s < K.ns ? rec[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();
+        int lim = min(256, K.ns - base);
+        for (int i = 0; i < lim; ++i) {
+            float4 r = tile[i];
+            float dx = r.x - cx, dy = r.y - cy, d2 = dx * dx + dy * dy;
+            if (r.z > 0.5f && d2 < best) { best = d2; bidx = base + i; bu = r.x; bv = r.y; }    // first minimum wins
+        }
+        __syncthreads();
+    }
+    float lval = 0.f;
+    if (c < cnt) {
+        const size_t o = (size_t)vm * K.cmax + c;
+        float gx = 0.f, gy = 0.f;
+        if (bidx >= 0) {
+            float d = sqrtf(best);
+            int px = (int)bu, py = (int)bv;                                    // .long() truncation (loss.py:114)
+            const unsigned char *mk = K.masks + (size_t)vm * K.H * K.W;
+            float mval = (px >= 0 && px < K.W && py >= 0 && py < K.H) ? (float)mk[(size_t)py * K.W + px] : 0.f;
+            float coeff = mval < 0.1f ? K.eps : 1.f;                            // (eps - 1) * outside + 1
+            lval = coeff * d;
+            if (d > 0.f) { gx = K.weight * coeff * (bu - cx) / d; gy = K.weight * coeff * (bv - cy) / d; }
+        }
+        choice[o] = bidx;
+        cgrad[o * 2] = gx; cgrad[o * 2 + 1] = gy;
+    }
+    lval = mk_wave_sum(lval);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lval;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_part[(size_t)vm * K.part_stride + K.proj_blocks + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+// grid (ceil(Ns/256), F).  dvout[f][4 s] (+)= dL/dvertex over all mask views; other vertices untouched
+extern "C" __global__ void __launch_bounds__(256)
+bf_mask_gather_kernel(MaskIO K, const float *__restrict__ proj_all, const float *__restrict__ uvi, const float *__restrict__ duvb,
+                      const int *__restrict__ choice, const float *__restrict__ cgrad, float *__restrict__ dvout) {
+    __shared__ int s_choice[256];
+    __shared__ float2 s_grad[256];
+    const int s = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int m = 0; m < K.n_masks; ++m) {
+        const int vm = f * K.n_masks + m;
+        const int cnt = K.contour_count[vm];
+        float du = 0.f, dv = 0.f;
+        if (s < K.ns) { du = duvb[((size_t)vm * K.ns + s) * 2]; dv = duvb[((size_t)vm * K.ns + s) * 2 + 1]; }
+        for (int base = 0; base < cnt; base += 256) {
+            int c = base + threadIdx.x;
+            s_choice[threadIdx.x] = c < cnt ? choice[(size_t)vm * K.cmax + c] : -1;
+            s_grad[threadIdx.x] = c < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + c] : make_float2(0.f, 0.f);
+            __syncthreads();
+            int lim = min(256, cnt - base);
+            for (int i = 0; i < lim; ++i)
+                if (s_choice[i] == s) { du += s_grad[i].x; dv += s_grad[i].y; }
+            __syncthreads();
+        }
+        if (s < K.ns) {
+            float4 r = ((const float4 *)uvi)[(size_t)vm * K.ns + s];
+            const float *P = proj_all + ((size_t)f * K.n_views + K.view_index[m]) * 12;
+            float q0 = du * r.w, q1 = dv * r.w, q2 = -(du * r.x + dv * r.y) * r.w;
+            g0 += P[0] * q0 + P[4] * q1 + P[8] * q2;
+            g1 += P[1] * q0 + P[5] * q1 + P[9] * q2;
+            g2 += P[2] * q0 + P[6] * q1 + P[10] * q2;
+        }
+    }
+    if (s < K.ns) {
+        float *o = dvout + ((size_t)f * K.nv + (size_t)s * 4) * 3;
+        o[0] += g0; o[1] += g1; o[2] += g2;
+    }
+}
+
+// grid (F): loss[f] = sum over views / blocks of the partials (fixed order)
+extern "C" __global__ void bf_mask_loss_kernel(MaskIO K, const float *__restrict__ loss_part, float *__restrict__ loss) {
+    const int f = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    float tot = 0.f;
+    for (int m = 0; m < K.n_masks; ++m) {
+        const int vm = f * K.n_masks + m;
+        const int nb = K.proj_blocks + (K.contour_count[vm] + 255) / 256;
+        for (int b = 0; b < nb; ++b) tot += loss_part[(size_t)vm * K.part_stride + b];
+    }
+    loss[f] = tot;
+}

@@ -9,6 +9,10 @@ extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, 
 extern "C" __global__ void bf_mesh_bwd_kernel(MeshTab, const float *, const float *, const float *, const float *, const float *, float *);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *);
 extern "C" size_t bf_mesh_bwd_smem_bytes(int);
+extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const float *, float *, float *, float *);
+extern "C" __global__ void bf_mask_contour_kernel(MaskIO, const float *, int *, float *, float *);
+extern "C" __global__ void bf_mask_gather_kernel(MaskIO, const float *, const float *, const float *, const int *, const float *, float *);
+extern "C" __global__ void bf_mask_loss_kernel(MaskIO, const float *, float *);
 extern "C" __global__ void bf_disp_face_kernel(const int *, int, int, const float *, const float *, float *);
 extern "C" __global__ void bf_disp_vertex_kernel(const int *, const int *, int, int, const float *, const float *, const float *, float *, float *);
 extern "C" __global__ void bf_disp_vgrad_kernel(const int *, const int *, const int *, int, int, const float *, const float *const *,
@@ -172,35 +176,66 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
     return ensure_dense_buffers(b);
 }
 
-// the loop of smplify.py:177-213 with use_mesh: iterations i <= n_iters // 3 are keypoint-only (one
-// persistent launch); every later iteration adds 5 * point_cloud_loss / scan_height * imsize.
+static int launch_mask_kernels(bf_batch *b, float weight) {
+    MaskIO K = b->mask;
+    K.weight = weight;
+    const int F = b->F;
+    hipLaunchKernelGGL(bf_mask_project_kernel, dim3(K.proj_blocks, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->vout.p,
+                       (const float *)b->proj.p, b->mk_uvi.p, b->mk_duvb.p, b->mk_part.p);
+    hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
+                       (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p);
+    hipLaunchKernelGGL(bf_mask_gather_kernel, dim3(K.proj_blocks, F), dim3(256), 0, b->stream, K, (const float *)b->proj.p,
+                       (const float *)b->mk_uvi.p, (const float *)b->mk_duvb.p, (const int *)b->mk_choice.p,
+                       (const float *)b->mk_cgrad.p, b->dvout.p);
+    hipLaunchKernelGGL(bf_mask_loss_kernel, dim3(F), dim3(64), 0, b->stream, K, (const float *)b->mk_part.p, b->mk_loss.p);
+    HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
+    bf_model *m = b->m;
+    hipLaunchKernelGGL(bf_pose_state_kernel, dim3(b->F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
+                       (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
+    HIP_TRY(hipGetLastError());
+    return bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, nullptr, nullptr, nullptr, b->stream, nullptr, b->vposed.p);
+}
+
+// the loop of smplify.py:177-213 with use_mask and / or use_mesh: iterations i <= n_iters // 3 are
+// keypoint-only (one persistent launch); every later iteration adds 5 * mask_loss and / or
+// 5 * point_cloud_loss / scan_height * imsize (smplify.py:197-210) through the dense reverse pass.
 int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDev &hd, FrameIO io) {
     bf_model *m = b->m;
     const int F = b->F, nv = m->nv, thr = n_iters / 3;
     const int n_plain = std::min(n_iters, thr + 1);
-    if (b->pc_weight.n != (size_t)F) {
+    const bool scans = !b->scans.empty(), masks = b->has_masks;
+    if (scans && b->pc_weight.n != (size_t)F) {
         std::vector<float> w(F);
         for (int f = 0; f < F; ++f) w[f] = 5.0f * h.imsize / b->scans[f]->dev.height;      // smplify.py:206,210
         if (b->pc_weight.p) { (void)hipFree(b->pc_weight.p); b->pc_weight.p = nullptr; }
         HIP_TRY(b->pc_weight.upload(w));
     }
+    if (masks) b->mask.imsize = h.imsize;
     HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, m->fit_smem, b->stream));
     const int EXT = m->npf + m->nj * 12 + m->nb + 4, nblk = (nv + 255) / 256;
     const size_t bwd_smem = bf_mesh_bwd_smem_bytes(m->nj);
     for (int it = n_plain; it < n_iters; ++it) {
-        hipLaunchKernelGGL(bf_pose_state_kernel, dim3(F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
-                           (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
-                           (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
-        HIP_TRY(hipGetLastError());
-        int rc = bf_launch_mesh(m, F, b->state.p, b->vraw.p, b->vout.p, nullptr, nullptr, nullptr, b->stream, nullptr, b->vposed.p);
+        int rc = launch_state_and_mesh(b, hd);
         if (rc) return rc;
-        hipLaunchKernelGGL(bf_nearest_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
-                           (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr);
-        hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
-                           (const float *)b->cpts.p, nv, b->pc_partial.p);
-        hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
-                           (const float *)b->cpts.p, nv, (const float *)b->pc_partial.p, (const float *)b->pc_weight.p,
-                           b->dvout.p, b->pc_loss.p, 0);
+        if (masks) {
+            HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
+            rc = launch_mask_kernels(b, 5.0f);                                           // smplify.py:210
+            if (rc) return rc;
+        }
+        if (scans) {
+            hipLaunchKernelGGL(bf_nearest_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
+                               (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr);
+            hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
+                               (const float *)b->cpts.p, nv, b->pc_partial.p);
+            hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
+                               (const float *)b->cpts.p, nv, (const float *)b->pc_partial.p, (const float *)b->pc_weight.p,
+                               b->dvout.p, b->pc_loss.p, masks ? 1 : 0);
+        }
         hipLaunchKernelGGL(bf_mesh_bwd_kernel, dim3(m->mesh.n_tiles, F), dim3(512), bwd_smem, b->stream, m->mesh,
                            (const float *)m->posedirsT.p, (const float *)b->state.p, (const float *)b->dvout.p,
                            (const float *)b->vposed.p, (const float *)b->vraw.p, b->ext_part.p);
@@ -211,6 +246,70 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
         io2.ext = b->ext.p;
         HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
     }
+    return BF_OK;
+}
+
+// use_mask=True (smplify.py:138-144): masks[F,M,H,W] uint8 as read from disk (thresholded > 128 here),
+// view_index[M] = position of each mask view among the V views (use_frames.index(frame), smplify.py:141-142),
+// contours: for every (frame, mask view) contour_count points (x, y), concatenated in contour_xy
+// (extract_countours, loss.py:73-83 - the caller extracts them; the loss only sums over the points).
+int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
+                       const int32_t *contour_count, const float *contour_xy) {
+    if (!b) return fail(BF_ERR_INVALID, "bf_batch_set_masks: null batch");
+    HIP_TRY(hipSetDevice(b->m->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (n_masks <= 0 || !masks) { b->has_masks = false; return BF_OK; }
+    if (!view_index || !contour_count || !contour_xy || H <= 0 || W <= 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: bad argument");
+    const int F = b->F, nv = b->m->nv;
+    for (int i = 0; i < n_masks; ++i)
+        if (view_index[i] < 0 || view_index[i] >= b->V) return fail(BF_ERR_INVALID, "bf_batch_set_masks: view index out of range");
+    std::vector<int> start((size_t)F * n_masks), count(contour_count, contour_count + (size_t)F * n_masks);
+    int total = 0, cmax = 1;
+    for (size_t i = 0; i < count.size(); ++i) {
+        if (count[i] < 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: negative contour count");
+        start[i] = total; total += count[i]; cmax = std::max(cmax, count[i]);
+    }
+    std::vector<unsigned char> bin((size_t)F * n_masks * H * W);
+    for (size_t i = 0; i < bin.size(); ++i) bin[i] = masks[i] > 128 ? 1 : 0;                 // smplify.py:139
+    auto refresh = [](auto &buf) { if (buf.p) { (void)hipFree((void *)buf.p); buf.p = nullptr; } };
+    refresh(b->mk_view); refresh(b->mk_cstart); refresh(b->mk_ccount); refresh(b->mk_masks); refresh(b->mk_cxy);
+    refresh(b->mk_uvi); refresh(b->mk_duvb); refresh(b->mk_cgrad); refresh(b->mk_part); refresh(b->mk_loss); refresh(b->mk_choice);
+    const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256, stride = pblocks + (cmax + 255) / 256;
+    HIP_TRY(b->mk_view.upload(std::vector<int>(view_index, view_index + n_masks)));
+    HIP_TRY(b->mk_cstart.upload(start));
+    HIP_TRY(b->mk_ccount.upload(count));
+    HIP_TRY(b->mk_masks.upload(bin));
+    HIP_TRY(b->mk_cxy.upload(std::vector<float>(contour_xy, contour_xy + (size_t)std::max(total, 1) * 2)));
+    const size_t fm = (size_t)F * n_masks;
+    HIP_TRY(b->mk_uvi.alloc(fm * ns * 4)); HIP_TRY(b->mk_duvb.alloc(fm * ns * 2));
+    HIP_TRY(b->mk_choice.alloc(fm * cmax)); HIP_TRY(b->mk_cgrad.alloc(fm * cmax * 2));
+    HIP_TRY(b->mk_part.alloc(fm * stride)); HIP_TRY(b->mk_loss.alloc(F));
+    MaskIO &K = b->mask;
+    K.nv = nv; K.ns = ns; K.n_views = b->V; K.n_masks = n_masks; K.H = H; K.W = W; K.cmax = cmax;
+    K.part_stride = stride; K.proj_blocks = pblocks; K.imsize = 512.f; K.eps = 10.f; K.weight = 5.f;
+    K.view_index = b->mk_view.p; K.masks = b->mk_masks.p; K.contour_start = b->mk_cstart.p;
+    K.contour_count = b->mk_ccount.p; K.contour_xy = b->mk_cxy.p;
+    b->has_masks = true;
+    return ensure_dense_buffers(b);
+}
+
+// multview_mask_loss (loss.py:85-130) at the current parameters: loss[F] (unweighted, as the function
+// returns it) and its gradient w.r.t. body_vertices dverts[F,NV,3] (non-zero on every 4th vertex only).
+int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *dverts) {
+    if (!b || !b->has_masks) return fail(BF_ERR_INVALID, "bf_batch_mask_loss: no masks attached");
+    HIP_TRY(hipSetDevice(b->m->device));
+    bf_hyper h;
+    if (hyper) h = *hyper; else bf_hyper_default(&h);
+    HyperDev hd = bf_to_dev(h);
+    b->mask.imsize = h.imsize;
+    int rc = launch_state_and_mesh(b, hd);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
+    rc = launch_mask_kernels(b, 1.0f);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (loss) HIP_TRY(hipMemcpy(loss, b->mk_loss.p, (size_t)b->F * sizeof(float), hipMemcpyDeviceToHost));
+    if (dverts) HIP_TRY(hipMemcpy(dverts, b->dvout.p, b->dvout.n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
 }
 

@@ -191,6 +191,25 @@ class FrameBatch:
         _lib.check(self._lib.bf_batch_set_scans(self._h, arr), "bf_batch_set_scans")
         self._scans = list(scans)          # keep them alive
 
+    def set_masks(self, masks, view_index, contours):
+        """masks uint8[F,M,H,W] as loaded; view_index[M]; contours: F lists of M arrays [C,2] (x, y) (use_mask=True)"""
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        F, M, H, W = masks.shape
+        assert F == self.F
+        vi = _i32(view_index)
+        counts = _i32([[len(c) for c in per_frame] for per_frame in contours]).reshape(-1)
+        flat = [np.asarray(c, np.float32).reshape(-1, 2) for per_frame in contours for c in per_frame]
+        xy = _f32(np.concatenate(flat, 0)) if sum(len(c) for c in flat) else np.zeros((1, 2), np.float32)
+        _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, masks.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                _lib.iptr(counts), _lib.fptr(xy)), "bf_batch_set_masks")
+
+    def mask_loss(self, hyper=None):
+        loss = np.empty(self.F, np.float32)
+        dv = np.empty((self.F, self.model.n_verts, 3), np.float32)
+        hp = C.byref(hyper) if hyper is not None else None
+        _lib.check(self._lib.bf_batch_mask_loss(self._h, hp, _lib.fptr(loss), _lib.fptr(dv)), "bf_batch_mask_loss")
+        return loss, dv
+
     def fit_displacement(self, n_iters, hyper=None):
         """SMPL+D stage (smplify.py:228-247) on the vertices of the last fit"""
         hp = C.byref(hyper) if hyper is not None else None

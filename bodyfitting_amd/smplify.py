@@ -7,14 +7,14 @@ global_transl[3] (= t*s, without the constant scale), scale[1], full_pose[72].
 Differences, all at the edges: the model / GMM are resolved once per process through
 `bodyfitting_amd.assets` instead of being re-read per frame; `net_output` may hold numpy arrays or
 anything with `.detach().cpu().numpy()`; `device` is a HIP device index (or a torch.device whose
-index is used).  Options whose kernels are not built yet (use_mask, smplx)
-raise NotImplementedError - there is no silent CPU path.
+index is used).  smpl_type='smplx' is not built yet and raises NotImplementedError - there is no silent CPU path.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from . import assets
+from .contours import extract_contours
 from .io import load_obj_mesh
 from .native import FrameBatch, Scan, make_hyper, split_params, N_LOSS_JOINTS
 
@@ -56,14 +56,16 @@ class SMPLify:
 
     # ------------------------------------------------------------------------------------------
     def fit_frames(self, init_betas, init_poses, c2ws, Ks, keypoints, n_use_frames=None, imsize=512,
-                   constant_scale=0.3, num_iters=None, flags=0, scans=None, displacement=False):
+                   constant_scale=0.3, num_iters=None, flags=0, scans=None, displacement=False, masks=None,
+                   mask_view_index=None):
         """Fit F independent frames in one launch.
 
         init_betas[F,10], init_poses[F,72], c2ws[F,V,4,4], Ks[F,V,3,3], keypoints[F,V,25,3]
         (confidence 0 = no detection); scans: optional list of F (verts, faces) scan meshes (use_mesh=True:
         the point-cloud loss switches on after num_iters // 3 and the constant scale becomes
         scan_height / 1.7, smplify.py:146-156,205-210); displacement: run the SMPL+D stage afterwards
-        (smplify.py:228-247).  Returns a list of F result dicts."""
+        (smplify.py:228-247); masks: uint8[F,M,H,W] silhouettes of the views mask_view_index[M] (use_mask=True:
+        5 * multview_mask_loss after num_iters // 3, smplify.py:138-144,197-199).  Returns a list of F result dicts."""
         init_betas = np.asarray(init_betas, np.float32).reshape(-1, self._dev.n_betas)
         F = init_betas.shape[0]
         c2ws = np.asarray(c2ws, np.float32).reshape(F, -1, 4, 4)
@@ -78,6 +80,9 @@ class SMPLify:
             if scans is not None:
                 dev_scans = [Scan(v, f, device=self.device) for v, f in scans]
                 batch.set_scans(dev_scans)
+            if masks is not None:
+                masks = np.asarray(masks, np.uint8).reshape(F, -1, *np.asarray(masks).shape[-2:])
+                batch.set_masks(masks, mask_view_index, [extract_contours(m > 128) for m in masks])      # loss.py:73-83
             hyper = make_hyper(imsize=imsize, constant_scale=constant_scale)
             n = self.num_iters if num_iters is None else num_iters
             batch.fit(n, hyper, flags | 4)
@@ -108,8 +113,10 @@ class SMPLify:
     def __call__(self, net_output, c2ws, Ks, keypoints, output_folder=None, use_mask=False, masks=None,
                  use_frames=[0], mask_frames=[0], keyframe=6, imsize=512, use_mesh=False, meshfile=None,
                  displacement=False):
-        if use_mask:
-            raise NotImplementedError("the silhouette loss (loss.py:85-130) is not built yet")
+        mk, mk_idx = None, None
+        if use_mask:                                                                 # smplify.py:138-144
+            mk = np.stack([np.asarray(m) for m in masks])[None]
+            mk_idx = [list(use_frames).index(f) for f in mask_frames]
         scans = None
         if use_mesh:
             scan_verts, scan_faces = load_obj_mesh(meshfile)                         # smplify.py:147
@@ -123,6 +130,7 @@ class SMPLify:
             if keypoints[i] is not None:                                               # loss.py:157
                 kp[i] = np.asarray(keypoints[i]["pose"], np.float32)[:N_LOSS_JOINTS]
         res = self.fit_frames(init_betas[:1], init_poses[:1], c2w[None], K[None], kp[None], n_use_frames=[V],
-                              imsize=imsize, scans=scans, displacement=displacement)[0]   # divisor loss.py:197
+                              imsize=imsize, scans=scans, displacement=displacement, masks=mk,
+                              mask_view_index=mk_idx)[0]                               # divisor loss.py:197
         res.pop("loss_terms")
         return res

@@ -410,8 +410,23 @@ def smpl_joints64(model, betas, full_pose):
     return verts, joints
 
 
+def render_mask(verts_world, c2w, K, imsize=512, radius=5):
+    """uint8 [imsize,imsize] silhouette (255 = body): union of discs splatted at the projected vertices."""
+    from scipy import ndimage
+    w2c = np.linalg.inv(np.asarray(c2w, np.float64))
+    cam = verts_world @ w2c[:3, :3].T + w2c[:3, 3]
+    uvw = cam @ np.asarray(K, np.float64).T
+    uv = np.round(uvw[:, :2] / uvw[:, 2:3]).astype(int)
+    img = np.zeros((imsize, imsize), bool)
+    ok = (uv[:, 0] >= 0) & (uv[:, 0] < imsize) & (uv[:, 1] >= 0) & (uv[:, 1] < imsize)
+    img[uv[ok, 1], uv[ok, 0]] = True
+    yy, xx = np.mgrid[-radius:radius + 1, -radius:radius + 1]
+    img = ndimage.binary_dilation(img, structure=(xx * xx + yy * yy) <= radius * radius)
+    return (img * 255).astype(np.uint8)
+
+
 def make_problem(model, frame=0, n_views=48, imsize=512, constant_scale=0.3, pose_noise=0.1,
-                 drop=0.05, missing_views=()):
+                 drop=0.05, missing_views=(), mask_frames=None):
     """One synthetic SMPL frame: cameras, OpenPose-25 keypoints, HMR-like init.
 
     keypoints[v] is ``{'pose': float32[25,3]}`` (x, y, confidence) like utils/io_utils.py:138-183
@@ -426,7 +441,7 @@ def make_problem(model, frame=0, n_views=48, imsize=512, constant_scale=0.3, pos
     transl_gt = rng.normal(0.0, 0.05, size=3)
     scale_gt = rng.uniform(0.9, 1.1) / constant_scale
 
-    _, joints = smpl_joints64(model, betas_gt, pose_gt)
+    verts_gt, joints = smpl_joints64(model, betas_gt, pose_gt)
     op25 = joints[model["joint_map"][:25]]
     world = (op25 + transl_gt) * scale_gt * constant_scale
 
@@ -446,7 +461,13 @@ def make_problem(model, frame=0, n_views=48, imsize=512, constant_scale=0.3, pos
 
     init_pose = (pose_gt + rng.normal(0.0, pose_noise, size=72)).astype(np.float32)
     init_betas = np.zeros(10, dtype=np.float32)
+    extra = {}
+    if mask_frames is not None:        # ground-truth silhouettes for use_mask=True (smplify.py:138-144)
+        vw = (verts_gt + transl_gt) * scale_gt * constant_scale
+        extra = {"mask_frames": list(mask_frames),
+                 "masks": [render_mask(vw, c2ws[v], Ks[v], imsize) for v in mask_frames]}
     return {
+        **extra,
         "c2ws": c2ws, "Ks": Ks, "keypoints": keypoints, "imsize": imsize,
         "use_frames": list(range(n_views)),
         "init_betas": init_betas[None], "init_pose": init_pose[None],

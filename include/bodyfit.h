@@ -163,6 +163,17 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
  * scan_height / 1.7 (smplify.py:156); bf_fit then adds 5 * point_cloud_loss / scan_height * imsize for
  * iterations i > n_iters // 3 (smplify.py:205-210). */
 int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans);
+/* ---- silhouette loss (use_mask, BASELINE config 3) ----------------------------------------------------
+ * masks[F,M,H,W] uint8 as loaded (> 128 = foreground, smplify.py:139); view_index[M] = position of each mask
+ * view among the V views (smplify.py:141-142); per (frame, mask view) contour_count[F*M] contour points,
+ * concatenated as (x, y) pairs in contour_xy (what extract_countours returns, loss.py:73-83).  bf_fit then
+ * adds 5 * multview_mask_loss for iterations i > n_iters // 3 (smplify.py:197-199,210).  n_masks = 0 detaches. */
+int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
+                       const int32_t *contour_count, const float *contour_xy);
+/* one evaluation of multview_mask_loss (loss.py:85-130) at the current parameters: loss[F] and its gradient
+ * w.r.t. body_vertices, dverts[F,NV,3] (either may be NULL) */
+int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *dverts);
+
 /* SMPL+D stage (displacement=True, smplify.py:228-247): n_iters Adam steps (lr 5e-2) on a per-vertex
  * displacement of the vertices returned by the last bf_fit, against each frame's scan:
  * loss = icp + (normal_loss + laplacian) * constant_scale * 0.1.  Needs faces in the model and scans. */

@@ -213,6 +213,84 @@ def scan_goldens():
     print("scan golden: max |disp|", np.abs(res["displacement"]).max())
 
 
+def install_cv2_contour_stub():
+    """cv2.findContours (OpenCV-3 three-value API, as loss.py:79 unpacks it) backed by bodyfitting_amd.contours."""
+    import cv2
+    from bodyfitting_amd.contours import extract_contour
+
+    def findContours(img, mode, method):
+        c = extract_contour(np.asarray(img) > 0).astype(np.int32)
+        return None, [c[:, None, :]], None
+
+    cv2.findContours = findContours
+    cv2.RETR_EXTERNAL, cv2.CHAIN_APPROX_NONE = 0, 1
+
+
+def mask_goldens():
+    """(a) reference multview_mask_loss (loss.py:85-130) + autograd at one parameter set; (b) the reference loop
+    with use_mask=True (smplify.py:138-144,197-199)."""
+    import torch
+    import smplx
+    from bodyfitting_amd import synthetic as S
+    from bodyfitting_amd.contours import extract_contours
+    from oracle import smplify_oracle as O
+
+    model = S.make_model("smpl", seed=0)
+    gmm = S.make_gmm(seed=0)
+    smplx.MODEL_REGISTRY["smpl"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_golden_mask_")
+    write_data_dir(tmp, model, gmm)
+    os.chdir(tmp)
+    install_cv2_contour_stub()
+    from smplify.loss import multview_mask_loss
+    mask_frames = [1, 3, 5, 7]
+    prob = S.make_problem(model, frame=0, n_views=8, mask_frames=mask_frames)
+    # (a) function level, at the initial estimate
+    m = O.to_torch_model(model, torch.float32)
+    out = O.smpl_forward(m, torch.tensor(prob["init_betas"]), torch.tensor(prob["init_pose"][:, :3]),
+                         torch.tensor(prob["init_pose"][:, 3:]))
+    verts = ((out["vertices"] + torch.tensor([[0.01, -0.02, 0.015]])) * 3.3 * 0.3).detach().requires_grad_(True)
+    masks = torch.from_numpy((np.array(prob["masks"]) > 128).astype(np.float32))
+    contours = [torch.tensor(c[:, None, :], dtype=torch.float32) for c in extract_contours(masks.numpy())]
+    w2cs = torch.inverse(torch.from_numpy(np.array(prob["c2ws"])).float())
+    idx = [prob["use_frames"].index(f) for f in mask_frames]
+    loss = multview_mask_loss(contours, masks, verts, np.zeros((1, 1, 3), np.int32), [w2cs[i] for i in idx],
+                              [prob["Ks"][i] for i in idx], mask_frames, imsize=prob["imsize"])
+    loss.backward()
+    np.savez_compressed(os.path.join(GOLDEN, "mask_loss_f0.npz"), frame=0, n_views=8, mask_frames=np.array(mask_frames),
+                        transl=np.array([0.01, -0.02, 0.015], np.float32), scale=np.float32(3.3), loss=float(loss),
+                        grad_sampled=verts.grad.numpy()[0, ::4], contour_counts=np.array([len(c) for c in contours]),
+                        model_digest=S.model_digest(model))
+    print("mask loss", float(loss))
+    # (b) the loop
+    snaps = {}
+    orig_step = torch.optim.Adam.step
+    counter = {"n": 0}
+
+    def step(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        counter["n"] += 1
+        if counter["n"] in (1, 11, 12, 20, 30):
+            g = self.param_groups
+            snaps[counter["n"]] = {n: g[i]["params"][0].detach().numpy()[0].copy() for i, n in
+                                   enumerate(("global_transl", "scale", "pose", "betas", "global_orient"))}
+        return r
+
+    torch.optim.Adam.step = step
+    try:
+        from smplify.smplify import SMPLify
+        fitter = SMPLify(smpl_type="smpl", num_iters=30, gender="neutral", device=torch.device("cpu"), debug=False)
+        res = fitter((torch.from_numpy(prob["init_betas"].copy()), torch.from_numpy(prob["init_pose"].copy())), prob["c2ws"],
+                     prob["Ks"], prob["keypoints"], None, use_mask=True, masks=prob["masks"], use_frames=prob["use_frames"],
+                     mask_frames=mask_frames, imsize=prob["imsize"])
+    finally:
+        torch.optim.Adam.step = orig_step
+    np.savez_compressed(os.path.join(GOLDEN, "mask_fit_8view_30it.npz"), frame=0, n_views=8, num_iters=30,
+                        mask_frames=np.array(mask_frames), joints=res["joints"], vertices_sample=res["vertices"][::53],
+                        model_digest=S.model_digest(model), **flat_snaps(snaps))
+    print("mask fit done")
+
+
 def flat_snaps(snaps):
     out = {}
     for k, d in snaps.items():
@@ -281,6 +359,10 @@ if __name__ == "__main__":
     if "--scan-only" in sys.argv:
         install_reference_imports()
         scan_goldens()
+    elif "--mask-only" in sys.argv:
+        install_reference_imports()
+        mask_goldens()
     else:
         main()
         scan_goldens()
+        mask_goldens()

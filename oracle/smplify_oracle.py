@@ -187,6 +187,39 @@ def multiview_keypoint_loss(w2cs, Ks, keypoints, model_joints, poses, betas, n_u
     return total.sum(), terms
 
 
+def multview_mask_loss(contours, masks, verts, w2cs, Ks, imsize=512, epsilon=10.0, pairwise="exact"):
+    """loss.py:85-130.  contours: list of [C,2] tensors, masks [M,H,W] (0/1), verts [NV,3], w2cs [M,4,4],
+    Ks [M,3,3].  pairwise="torch" evaluates the distances literally as the reference does (torch.cdist, which
+    for these sizes takes the |a|^2+|b|^2-2ab matmul form: ~1e-2 px of fp32 noise) - used to pin this
+    restatement to the reference goldens bit for bit; pairwise="exact" sums (a-b)^2 directly, which is what
+    the HIP kernel does."""
+    v4 = verts[::4]
+    total = 0.0
+    uvs = []
+    for i in range(len(contours)):
+        uv = perspective_projection(v4.unsqueeze(0), w2cs[i][None, :3, :3], w2cs[i][None, :3, 3], Ks[i]).squeeze(0)
+        inside = ((uv < imsize) & (uv >= 0)).all(dim=1)
+        uvs.append(uv)
+        pin = uv[inside]
+        if len(pin) == 0 or len(contours[i]) == 0:
+            continue
+        if pairwise == "torch":
+            dist = torch.cdist(pin.unsqueeze(0), contours[i][:, None, :].unsqueeze(0)).squeeze(0)   # [C,Ni,1]
+            mind, index = torch.min(dist, 1)
+            mind, idx = mind[:, 0], index[:, 0]
+        else:
+            diff = contours[i][:, None, :] - pin[None, :, :]                   # [C,Ni,2]
+            d2 = (diff * diff).sum(-1)
+            idx = torch.argmin(d2, dim=1)                                     # first minimum, like torch.min
+            mind = torch.sqrt(d2[torch.arange(len(idx)), idx])
+        cl = pin[idx].long()
+        outside = (masks[i][cl[:, 1], cl[:, 0]] < 0.1).to(verts.dtype)
+        total = total + torch.sum(mind * (outside * (epsilon - 1) + 1))
+    grid = torch.stack(uvs, 0).view(len(contours), -1, 1, 2) / imsize * 2 - 1
+    binary = torch.nn.functional.grid_sample((1 - masks[:, None]).to(verts.dtype), grid, align_corners=False)
+    return total + binary.sum() * epsilon
+
+
 def to_torch_gmm(gmm_bufs, dtype=torch.float32):
     means, precisions, nll_w = gmm_bufs
     return (torch.as_tensor(means, dtype=dtype), torch.as_tensor(precisions, dtype=dtype),
@@ -208,7 +241,7 @@ def prepare_views(c2ws, Ks, keypoints, dtype=torch.float32):
 
 
 def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=(), trace=None, scan=None,
-        displacement=False, disp_snapshots=()):
+        displacement=False, disp_snapshots=(), mask_pairwise="exact"):
     """Run the reference optimisation loop; returns the rtn_dict of smplify.py:216-226 as numpy.
 
     `snapshots`: iteration counts k at which the optimised parameters *after k steps* are
@@ -225,6 +258,13 @@ def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=
         scan_v, scan_f = np.asarray(scan[0], np.float64), np.asarray(scan[1])
         scan_height = float((scan_v.max(0) - scan_v.min(0))[1])
         c = scan_height / 1.7
+    mask_in = None
+    if problem.get("masks") is not None and problem.get("use_mask", True):     # smplify.py:138-144
+        from bodyfitting_amd.contours import extract_contours
+        mk = (np.array(problem["masks"]) > 128).astype(np.float32)
+        idx = [problem["use_frames"].index(f) for f in problem["mask_frames"]]
+        mask_in = ([torch.as_tensor(c, dtype=dtype) for c in extract_contours(mk)], torch.as_tensor(mk, dtype=dtype),
+                   w2cs[idx], Kt[idx])
     init_pose = torch.as_tensor(problem["init_pose"], dtype=torch.float32).to(dtype)
     init_betas = torch.as_tensor(problem["init_betas"], dtype=torch.float32).to(dtype)
 
@@ -252,6 +292,9 @@ def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=
         body_vertices = (out["vertices"] + global_transl) * body_scale * c      # smplify.py:190
         loss, terms = multiview_keypoint_loss(w2cs, Kt, kps, model_joints, body_pose, betas, n_use, gmm,
                                               imsize=problem["imsize"])
+        if mask_in is not None and i > (num_iters // 3):                          # smplify.py:197-199,210
+            loss = loss + 5 * multview_mask_loss(mask_in[0], mask_in[1], body_vertices[0], mask_in[2], mask_in[3],
+                                                 imsize=problem["imsize"], pairwise=mask_pairwise)
         if scan is not None and i > (num_iters // 3):                             # smplify.py:205-210
             _, cpts, _ = MO.nearest_bruteforce(scan_v, scan_f, body_vertices.detach().numpy()[0])
             pc = MO.point_cloud_loss(body_vertices, torch.as_tensor(cpts, dtype=dtype)) / scan_height * problem["imsize"]
