@@ -510,3 +510,94 @@ def make_scan_problem(model, frame=0, n_views=8, imsize=512, scan_scale=1.0, noi
             "init_betas": np.zeros((1, 10), np.float32), "init_pose": init_pose[None], "constant_scale": cscale,
             "gt": {"betas": betas_gt, "pose": pose_gt, "transl": transl_gt, "scale": scale_gt}}
     return prob, scan, np.asarray(model["faces"], dtype=np.int32)
+
+
+FACE_MAPPING = list(range(17, 17 + 51)) + list(range(0, 17))       # reference smplify/loss.py:20
+
+
+def smplx_full_pose(model, global_orient, body_pose, leye, reye, lhand_pca, rhand_pca, jaw=None):
+    """[165] axis-angle vector smplx feeds to lbs: PCA hands, plus pose_mean."""
+    jaw = np.zeros(3) if jaw is None else np.asarray(jaw, np.float64).reshape(3)
+    lh = np.asarray(lhand_pca, np.float64) @ model["left_hand_components"].astype(np.float64)
+    rh = np.asarray(rhand_pca, np.float64) @ model["right_hand_components"].astype(np.float64)
+    fp = np.concatenate([np.asarray(global_orient, np.float64).reshape(3), np.asarray(body_pose, np.float64).reshape(63), jaw,
+                         np.asarray(leye, np.float64).reshape(3), np.asarray(reye, np.float64).reshape(3), lh, rh])
+    return fp + model["pose_mean"].astype(np.float64)
+
+
+def smplx_joints64(model, betas, full_pose):
+    """float64 SMPL-X joints for data synthesis: (vertices, 135 mapped joints, dynamic-contour row)."""
+    verts, j76 = smpl_joints64(model, betas, full_pose)
+    R = [_rodrigues64(full_pose[3 * j:3 * j + 3]) for j in model["neck_kin_chain"]]
+    rel = np.eye(3)
+    for r in R:
+        rel = r @ rel
+    yaw = np.arctan2(-rel[2, 0], np.sqrt(rel[0, 0] ** 2 + rel[1, 0] ** 2))
+    y = int(np.round(min(-yaw * 180.0 / np.pi, 39)))
+    if y < 0:
+        y = 78 if y < -39 else 39 - y
+    fidx = np.concatenate([model["lmk_faces_idx"], model["dynamic_lmk_faces_idx"][y]])
+    bary = np.concatenate([model["lmk_bary_coords"], model["dynamic_lmk_bary_coords"][y]]).astype(np.float64)
+    lm = np.einsum("lfi,lf->li", verts[model["faces"][fidx]], bary)
+    joints = np.concatenate([j76, lm], 0)
+    return verts, joints[model["joint_map"]], y
+
+
+def pack_keypoints_smplx(k, part_sum_confidence=True):
+    """OpenPose dict {'pose'[25,3], 'hand_left'[21,3], 'hand_right'[21,3], 'face'[70,3]} -> [135,3] in the order the
+    model joints are compared (loss.py:163-181: body | left hand | right hand | face[FACE_MAPPING]); missing parts
+    get confidence 0.
+
+    part_sum_confidence reproduces a reference quirk: for the hands and the face the confidence column is NOT
+    squeezed (loss.py:168,173,179 vs :162), so `conf**2 * err.sum(-1)` broadcasts to an outer product and every
+    joint of a part ends up weighted by the SUM of the part's squared confidences.  The packed confidence of
+    those joints is therefore sqrt(sum conf^2) of their part, which makes the ordinary conf_j^2 * rho_j identical."""
+    out = np.zeros((135, 3), np.float32)
+    if k is None:
+        return out
+    out[:25] = np.asarray(k["pose"], np.float32)[:25]
+    if "hand_left" in k:
+        out[25:46] = np.asarray(k["hand_left"], np.float32)
+    if "hand_right" in k:
+        out[46:67] = np.asarray(k["hand_right"], np.float32)
+    if "face" in k:
+        out[67:135] = np.asarray(k["face"], np.float32)[FACE_MAPPING]
+    if part_sum_confidence:
+        for a, b in ((25, 46), (46, 67), (67, 135)):
+            out[a:b, 2] = np.sqrt(np.sum(out[a:b, 2].astype(np.float64) ** 2))
+    return out
+
+
+def make_problem_smplx(model, frame=0, n_views=48, imsize=512, constant_scale=0.3, pose_noise=0.08, mask_frames=None):
+    """One synthetic SMPL-X frame (BASELINE config 3): body + hands + face OpenPose keypoints per view."""
+    assert model["model_type"] == "smplx"
+    rng = np.random.default_rng(3000 + frame)
+    gt = {"betas": rng.normal(0.0, 0.5, size=10), "body_pose": rng.normal(0.0, 0.15, size=63),
+          "global_orient": np.array([0.0, rng.uniform(-0.6, 0.6), 0.0]) + rng.normal(0.0, 0.05, size=3),
+          "leye": rng.normal(0.0, 0.05, size=3), "reye": rng.normal(0.0, 0.05, size=3),
+          "lhand": rng.normal(0.0, 0.5, size=6), "rhand": rng.normal(0.0, 0.5, size=6),
+          "transl": rng.normal(0.0, 0.05, size=3), "scale": rng.uniform(0.9, 1.1) / constant_scale}
+    fp = smplx_full_pose(model, gt["global_orient"], gt["body_pose"], gt["leye"], gt["reye"], gt["lhand"], gt["rhand"])
+    verts, joints, _ = smplx_joints64(model, np.concatenate([gt["betas"], np.zeros(10)]), fp)
+    world = (joints + gt["transl"]) * gt["scale"] * constant_scale
+    c2ws, Ks = ring_cameras(n_views, imsize=imsize, focal=float(imsize), centre=world[:25].mean(0).tolist())
+    inv_face = np.argsort(FACE_MAPPING)
+    keypoints = []
+    for v in range(n_views):
+        w2c = np.linalg.inv(c2ws[v].astype(np.float64))
+        cam = world @ w2c[:3, :3].T + w2c[:3, 3]
+        uvw = cam @ Ks[v].astype(np.float64).T
+        uv = uvw[:, :2] / uvw[:, 2:3] + rng.normal(0.0, 0.7, size=(135, 2))
+        conf = rng.uniform(0.5, 1.0, size=135)
+        kp = np.concatenate([uv, conf[:, None]], 1).astype(np.float32)
+        face70 = np.zeros((70, 3), np.float32)
+        face70[:68] = kp[67:][inv_face]                 # back to OpenPose's own face order
+        keypoints.append({"pose": kp[:25], "hand_left": kp[25:46], "hand_right": kp[46:67], "face": face70})
+    init_pose = np.concatenate([gt["global_orient"], gt["body_pose"]]) + rng.normal(0.0, pose_noise, size=66)
+    extra = {}
+    if mask_frames is not None:
+        vw = (verts + gt["transl"]) * gt["scale"] * constant_scale
+        extra = {"mask_frames": list(mask_frames), "masks": [render_mask(vw, c2ws[v], Ks[v], imsize) for v in mask_frames]}
+    return {**extra, "c2ws": c2ws, "Ks": Ks, "keypoints": keypoints, "imsize": imsize, "use_frames": list(range(n_views)),
+            "init_betas": np.zeros((1, 10), np.float32), "init_pose": np.concatenate([init_pose, np.zeros(6)]).astype(np.float32)[None],
+            "gt": gt, "constant_scale": constant_scale}

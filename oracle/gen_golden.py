@@ -291,6 +291,54 @@ def mask_goldens():
     print("mask fit done")
 
 
+def smplx_goldens():
+    """BASELINE config 3 in miniature: the reference loop with smpl_type='smplx' (hands + face keypoints,
+    smplify.py:57-80,103-128; loss.py:166-181,199-207) on the stand-in smplx.create."""
+    import torch
+    import smplx
+    from bodyfitting_amd import synthetic as S
+
+    model = S.make_model("smplx", seed=0)
+    gmm = S.make_gmm(seed=0)
+    smplx.MODEL_REGISTRY["smplx"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_golden_smplx_")
+    os.makedirs(os.path.join(tmp, "data"), exist_ok=True)
+    with open(os.path.join(tmp, "data", "gmm_08.pkl"), "wb") as f:
+        pickle.dump(gmm, f)
+    os.chdir(tmp)
+    names = ("global_transl", "scale", "pose", "betas", "global_orient", "leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose")
+    for tag, n_views, iters, mask_frames in (("smplx_8view_40it", 8, 40, None), ("smplx_mask_8view_15it", 8, 15, [1, 3, 5, 7])):
+        if mask_frames is not None:
+            install_cv2_contour_stub()
+        prob = S.make_problem_smplx(model, frame=0, n_views=n_views, mask_frames=mask_frames)
+        snaps = {}
+        orig_step = torch.optim.Adam.step
+        counter = {"n": 0}
+        want = (1, 2, 6, 10, 20, iters)
+
+        def step(self, *a, **k):
+            r = orig_step(self, *a, **k)
+            counter["n"] += 1
+            if counter["n"] in want:
+                g = self.param_groups
+                snaps[counter["n"]] = {n: g[i]["params"][0].detach().numpy().reshape(-1).copy() for i, n in enumerate(names)}
+            return r
+
+        torch.optim.Adam.step = step
+        try:
+            from smplify.smplify import SMPLify
+            fitter = SMPLify(smpl_type="smplx", num_iters=iters, gender="neutral", device=torch.device("cpu"), debug=False)
+            res = fitter((torch.from_numpy(prob["init_betas"].copy()), torch.from_numpy(prob["init_pose"].copy())), prob["c2ws"],
+                         prob["Ks"], prob["keypoints"], None, use_frames=prob["use_frames"], imsize=prob["imsize"],
+                         use_mask=mask_frames is not None, masks=prob.get("masks"), mask_frames=mask_frames or [0])
+        finally:
+            torch.optim.Adam.step = orig_step
+        np.savez_compressed(os.path.join(GOLDEN, tag + ".npz"), frame=0, n_views=n_views, num_iters=iters,
+                            joints=res["joints"], full_pose=res["full_pose"], vertices_sample=res["vertices"][::53],
+                            pose=res["pose"], model_digest=S.model_digest(model), **flat_snaps(snaps))
+        print(tag, "done")
+
+
 def flat_snaps(snaps):
     out = {}
     for k, d in snaps.items():
@@ -359,6 +407,9 @@ if __name__ == "__main__":
     if "--scan-only" in sys.argv:
         install_reference_imports()
         scan_goldens()
+    elif "--smplx-only" in sys.argv:
+        install_reference_imports()
+        smplx_goldens()
     elif "--mask-only" in sys.argv:
         install_reference_imports()
         mask_goldens()
@@ -366,3 +417,4 @@ if __name__ == "__main__":
         main()
         scan_goldens()
         mask_goldens()
+        smplx_goldens()

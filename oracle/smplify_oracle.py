@@ -109,6 +109,41 @@ def smpl_forward(m, betas, global_orient, body_pose):
     return {"vertices": verts, "joints": joints, "joints_ori": joints45, "full_pose": full_pose}
 
 
+def smplx_forward(m, betas, global_orient, body_pose, leye_pose, reye_pose, left_hand_pose, right_hand_pose,
+                  jaw_pose=None, expression=None, mapped=True):
+    """smplx 0.1.13 `SMPLX.forward` (use_pca with 6 components, flat_hand_mean=False, use_face_contour=True) + the
+    JointMapper of reference models/utils.py:16-29,75-94.  Returns dict(vertices[B,NV,3],
+    joints[B,135,3], full_pose[B,165])."""
+    B = betas.shape[0]
+    dt = betas.dtype
+    z3 = torch.zeros(B, 3, dtype=dt)
+    jaw = z3 if jaw_pose is None else jaw_pose.reshape(B, 3)
+    lh = torch.einsum("bi,ij->bj", left_hand_pose, m["left_hand_components"])
+    rh = torch.einsum("bi,ij->bj", right_hand_pose, m["right_hand_components"])
+    full_pose = torch.cat([global_orient, body_pose, jaw, leye_pose.reshape(B, 3), reye_pose.reshape(B, 3), lh, rh], dim=1)
+    full_pose = full_pose + m["pose_mean"]
+    expr = torch.zeros(B, m["shapedirs"].shape[2] - betas.shape[1], dtype=dt) if expression is None else expression
+    verts, chain_j = lbs(torch.cat([betas, expr], dim=1), full_pose, m)
+    # dynamic face-contour landmarks: yaw of the neck's global rotation -> row of a 79-entry table
+    R = batch_rodrigues(full_pose.reshape(-1, 3)).view(B, -1, 3, 3)
+    rel = torch.eye(3, dtype=dt).unsqueeze(0).expand(B, -1, -1)
+    for j in m["neck_kin_chain"]:
+        rel = torch.bmm(R[:, int(j)], rel)
+    sy = torch.sqrt(rel[:, 0, 0] ** 2 + rel[:, 1, 0] ** 2)
+    yaw = torch.atan2(-rel[:, 2, 0], sy)
+    y = torch.round(torch.clamp(-yaw * 180.0 / np.pi, max=39)).to(torch.long)
+    neg = y.lt(0).to(torch.long)
+    far = y.lt(-39).to(torch.long)
+    y = neg * (far * 78 + (1 - far) * (39 - y)) + (1 - neg) * y
+    lmk_faces = torch.cat([m["lmk_faces_idx"].unsqueeze(0).expand(B, -1), m["dynamic_lmk_faces_idx"][y]], 1)        # [B,68]
+    lmk_bary = torch.cat([m["lmk_bary_coords"].unsqueeze(0).expand(B, -1, -1), m["dynamic_lmk_bary_coords"][y]], 1)
+    tri = m["faces"][lmk_faces]                                                                               # [B,68,3]
+    lv = torch.stack([verts[b][tri[b]] for b in range(B)])                                                    # [B,68,3,3]
+    landmarks = torch.einsum("blfi,blf->bli", lv, lmk_bary)
+    joints = torch.cat([chain_j, verts[:, m["selector_ids"]], landmarks], dim=1)                              # 55 + 21 + 68
+    return {"vertices": verts, "joints": joints[:, m["joint_map"]] if mapped else joints, "full_pose": full_pose, "dyn_row": y}
+
+
 def to_torch_model(model, dtype=torch.float32):
     """numpy model dict (bodyfitting_amd.synthetic.make_model) -> torch tensors."""
     out = {}
@@ -118,6 +153,14 @@ def to_torch_model(model, dtype=torch.float32):
     out["parents"] = [int(p) for p in model["parents"]]
     out["selector_ids"] = torch.as_tensor(np.asarray(model["selector_ids"]), dtype=torch.long)
     out["joint_map"] = torch.as_tensor(np.asarray(model["joint_map"]), dtype=torch.long)
+    for k in ("left_hand_components", "right_hand_components", "pose_mean", "lmk_bary_coords", "dynamic_lmk_bary_coords"):
+        if k in model:
+            out[k] = torch.as_tensor(np.asarray(model[k]), dtype=dtype)
+    for k in ("lmk_faces_idx", "dynamic_lmk_faces_idx", "faces"):
+        if k in model and model.get("model_type") == "smplx":
+            out[k] = torch.as_tensor(np.asarray(model[k]), dtype=torch.long)
+    if "neck_kin_chain" in model:
+        out["neck_kin_chain"] = [int(j) for j in model["neck_kin_chain"]]
     return out
 
 
@@ -162,22 +205,34 @@ def gmm_merged_nll(pose, means, precisions, nll_weights):
     return torch.min(ll, dim=1)[0]
 
 
+HANDS_LENGTH, FACE_LENGTH = 42, 68                                  # loss.py:18-19
+
+
 def multiview_keypoint_loss(w2cs, Ks, keypoints, model_joints, poses, betas, n_use_frames, gmm,
-                            imsize=512, sigma=SIGMA):
+                            imsize=512, sigma=SIGMA, use_hand_face=False):
     """loss.py:139-230 for smpl_type='smpl' (use_hand_face False).
 
     w2cs[V,4,4], Ks[V,3,3] tensors; keypoints: list of None | float tensor [25,3].
     Returns (total scalar, dict of the four terms) - the dict mirrors loss.py:219-224."""
     scale_coeff = imsize / 1024.0
-    per_view = []
+    per_view, hand, face = [], [], []
     for i in range(len(keypoints)):
         if keypoints[i] is None:
             continue                                                             # loss.py:157
         w2c = w2cs[i]
         uv = perspective_projection(model_joints, w2c[:3, :3].unsqueeze(0), w2c[:3, 3].unsqueeze(0), Ks[i])
         gt, conf = keypoints[i][:, :2], keypoints[i][:, 2]
-        per_view.append(reprojection_loss(uv[0, :SKELETON_LENGTH], gt, conf, scale_coeff, sigma))
+        per_view.append(reprojection_loss(uv[0, :SKELETON_LENGTH], gt[:SKELETON_LENGTH], conf[:SKELETON_LENGTH], scale_coeff, sigma))
+        if use_hand_face:       # keypoints[i] rows: body 25 | hand_left 21 | hand_right 21 | face 68 (already FACE_MAPPING-ordered)
+            a, b2, c2 = SKELETON_LENGTH, SKELETON_LENGTH + HANDS_LENGTH // 2, SKELETON_LENGTH + HANDS_LENGTH
+            hand.append(reprojection_loss(uv[0, a:b2], gt[a:b2], conf[a:b2], scale_coeff, sigma))
+            hand.append(reprojection_loss(uv[0, b2:c2], gt[b2:c2], conf[b2:c2], scale_coeff, sigma))
+            face.append(reprojection_loss(uv[0, c2:], gt[c2:], conf[c2:], scale_coeff, sigma))
     loss_2d = torch.sum(torch.stack(per_view, dim=0)) / n_use_frames             # loss.py:197
+    if use_hand_face:                                                            # loss.py:199-203
+        loss_2d = loss_2d + torch.sum(torch.stack(hand, dim=0)) / n_use_frames
+        loss_2d = loss_2d + torch.sum(torch.stack(face, dim=0)) / n_use_frames
+        poses = torch.cat([poses, torch.zeros_like(poses[:, :6])], dim=-1)       # loss.py:206-207
     pose_prior = (POSE_PRIOR_WEIGHT ** 2) * gmm_merged_nll(poses, *gmm)
     ang = (ANGLE_PRIOR_WEIGHT ** 2) * angle_prior(poses).sum(dim=-1)
     shape = (SHAPE_PRIOR_WEIGHT ** 2) * (betas ** 2).sum(dim=-1)
@@ -368,3 +423,76 @@ def loss_and_grad(model, gmm_bufs, problem, params, dtype=torch.float64):
     grads = {k: v.grad.numpy()[0].copy() for k, v in p.items()}
     return (float(loss), {k: float(v) for k, v in terms.items()}, grads,
             mj.detach().numpy()[0], bv.detach().numpy()[0])
+
+
+SMPLX_PARAMS = ("global_transl", "scale", "pose", "betas", "global_orient", "leye_pose", "reye_pose",
+                "left_hand_pose", "right_hand_pose")                                   # smplify.py:167-173
+
+
+def fit_smplx(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=(), mask_pairwise="exact"):
+    """The reference loop for smpl_type='smplx' (smplify.py:103-226): body_pose = init[:, 3:66], zero eyes / hand
+    PCA, jaw and expression never optimised, hands + face keypoints in the loss (use_hand_face)."""
+    from bodyfitting_amd.synthetic import pack_keypoints_smplx
+    m = to_torch_model(model, dtype)
+    gmm = to_torch_gmm(gmm_bufs, dtype)
+    c2w = torch.as_tensor(np.asarray(problem["c2ws"]), dtype=torch.float32).to(dtype)
+    w2cs = torch.inverse(c2w)
+    Kt = torch.as_tensor(np.asarray(problem["Ks"]), dtype=torch.float32).to(dtype)
+    kps = [None if k is None else torch.as_tensor(pack_keypoints_smplx(k)).to(dtype) for k in problem["keypoints"]]
+    n_use = len(problem["use_frames"])
+    c = float(problem.get("constant_scale", 0.3))
+    init_pose = torch.as_tensor(problem["init_pose"], dtype=torch.float32).to(dtype)
+    P = {"global_transl": torch.zeros(1, 3, dtype=dtype), "scale": torch.ones(1, 1, dtype=dtype),
+         "pose": init_pose[:, 3:66].clone(), "betas": torch.as_tensor(problem["init_betas"], dtype=torch.float32).to(dtype).clone(),
+         "global_orient": init_pose[:, :3].clone(), "leye_pose": torch.zeros(1, 3, dtype=dtype), "reye_pose": torch.zeros(1, 3, dtype=dtype),
+         "left_hand_pose": torch.zeros(1, 6, dtype=dtype), "right_hand_pose": torch.zeros(1, 6, dtype=dtype)}
+    for v in P.values():
+        v.requires_grad_(True)
+    groups = [{"params": P["global_transl"], "lr": 0.1}, {"params": P["scale"], "lr": 0.1}] + [{"params": P[k]} for k in SMPLX_PARAMS[2:]]
+    opt = torch.optim.Adam(groups, lr=1e-2, betas=(0.9, 0.999))
+    mask_in = None
+    if problem.get("masks") is not None:
+        from bodyfitting_amd.contours import extract_contours
+        mk = (np.array(problem["masks"]) > 128).astype(np.float32)
+        idx = [problem["use_frames"].index(f) for f in problem["mask_frames"]]
+        mask_in = ([torch.as_tensor(cc, dtype=dtype) for cc in extract_contours(mk)], torch.as_tensor(mk, dtype=dtype), w2cs[idx], Kt[idx])
+    snaps = {}
+    for i in range(num_iters):
+        out = smplx_forward(m, P["betas"], P["global_orient"], P["pose"], P["leye_pose"], P["reye_pose"],
+                            P["left_hand_pose"], P["right_hand_pose"])
+        mj = (out["joints"] + P["global_transl"]) * P["scale"] * c
+        bv = (out["vertices"] + P["global_transl"]) * P["scale"] * c
+        loss, terms = multiview_keypoint_loss(w2cs, Kt, kps, mj, P["pose"], P["betas"], n_use, gmm, imsize=problem["imsize"],
+                                              use_hand_face=True)
+        if mask_in is not None and i > (num_iters // 3):
+            loss = loss + 5 * multview_mask_loss(mask_in[0], mask_in[1], bv[0], mask_in[2], mask_in[3], imsize=problem["imsize"],
+                                                 pairwise=mask_pairwise)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if (i + 1) in snapshots:
+            snaps[i + 1] = {k: v.detach().numpy().copy()[0] for k, v in P.items()}
+    return {"vertices": bv.detach().numpy()[0], "joints": mj.detach().numpy()[0], "full_pose": out["full_pose"].detach().numpy()[0],
+            "params": {k: v.detach().numpy().copy()[0] for k, v in P.items()}, "snapshots": snaps,
+            "global_transl": (P["global_transl"] * P["scale"]).detach().numpy()[0], "loss": float(loss),
+            "terms": {k: float(v) for k, v in terms.items()}}
+
+
+def smplx_loss_and_grad(model, gmm_bufs, problem, params, dtype=torch.float64):
+    """objective + autograd gradient at `params` (dict over SMPLX_PARAMS) for smpl_type='smplx'"""
+    from bodyfitting_amd.synthetic import pack_keypoints_smplx
+    m = to_torch_model(model, dtype)
+    gmm = to_torch_gmm(gmm_bufs, dtype)
+    w2cs = torch.inverse(torch.as_tensor(np.asarray(problem["c2ws"]), dtype=torch.float32).to(dtype))
+    Kt = torch.as_tensor(np.asarray(problem["Ks"]), dtype=torch.float32).to(dtype)
+    kps = [None if k is None else torch.as_tensor(pack_keypoints_smplx(k)).to(dtype) for k in problem["keypoints"]]
+    P = {k: torch.tensor(np.asarray(params[k], np.float64).reshape(1, -1), dtype=dtype, requires_grad=True) for k in SMPLX_PARAMS}
+    c = float(problem.get("constant_scale", 0.3))
+    out = smplx_forward(m, P["betas"], P["global_orient"], P["pose"], P["leye_pose"], P["reye_pose"], P["left_hand_pose"], P["right_hand_pose"])
+    mj = (out["joints"] + P["global_transl"]) * P["scale"] * c
+    bv = (out["vertices"] + P["global_transl"]) * P["scale"] * c
+    loss, terms = multiview_keypoint_loss(w2cs, Kt, kps, mj, P["pose"], P["betas"], len(problem["use_frames"]), gmm,
+                                          imsize=problem["imsize"], use_hand_face=True)
+    loss.backward()
+    return (float(loss), {k: float(v) for k, v in terms.items()}, {k: v.grad.numpy()[0].copy() for k, v in P.items()},
+            mj.detach().numpy()[0], bv.detach().numpy()[0], int(out["dyn_row"][0]))

@@ -57,7 +57,34 @@ class SMPL(nn.Module):
                        body_pose=body_pose, full_pose=full_pose)
 
 
+class SMPLX(nn.Module):
+    """`smplx.create(model_type='smplx', use_face_contour=True, joint_mapper=...)` as the reference builds it
+    (smplify/smplify.py:59-80): 6 hand PCA components, non-flat hand mean, the caller's JointMapper applied to the
+    144 joints (55 chain + 21 selector vertices + 51 static + 17 dynamic-contour landmarks)."""
+
+    def __init__(self, joint_mapper=None, **kwargs):
+        super().__init__()
+        from oracle import smplify_oracle as O
+        model = MODEL_REGISTRY["smplx"]
+        self._O = O
+        self.faces = np.asarray(model["faces"])
+        self._m = O.to_torch_model(model, torch.float32)
+        self.joint_mapper = joint_mapper
+
+    def forward(self, betas=None, global_orient=None, body_pose=None, left_hand_pose=None, right_hand_pose=None,
+                jaw_pose=None, leye_pose=None, reye_pose=None, expression=None, return_full_pose=False, **kwargs):
+        out = self._O.smplx_forward(self._m, betas, global_orient, body_pose, leye_pose, reye_pose, left_hand_pose,
+                                    right_hand_pose, jaw_pose=jaw_pose, mapped=False)
+        joints = out["joints"]
+        if self.joint_mapper is not None:
+            joints = self.joint_mapper(joints)
+        return _Output(vertices=out["vertices"], joints=joints, betas=betas, global_orient=global_orient, body_pose=body_pose,
+                       full_pose=out["full_pose"])
+
+
 def create(model_path=None, model_type="smpl", **kwargs):
     if model_type == "smpl":
         return SMPL(model_path, **kwargs)
-    raise NotImplementedError("stand-in smplx.create: model_type %r not provided yet" % model_type)
+    if model_type == "smplx":
+        return SMPLX(**kwargs)
+    raise NotImplementedError("stand-in smplx.create: model_type %r not provided" % model_type)

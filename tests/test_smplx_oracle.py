@@ -1,0 +1,45 @@
+"""SMPL-X (smpl_type='smplx') on CPU: the oracle restatement against goldens of the imported reference loop."""
+import numpy as np
+import torch
+
+from conftest import load_golden
+from bodyfitting_amd import synthetic as S
+from oracle import smplify_oracle as O
+
+import pytest
+
+
+@pytest.fixture(scope="module")
+def smplx_model():
+    return S.make_model("smplx", seed=0)
+
+
+def test_joint_map_is_the_reference_table(smplx_model):
+    # reference models/utils.py:75-94 with use_hands, use_face, use_face_contour
+    jm = smplx_model["joint_map"]
+    assert len(jm) == 135 and list(jm[:3]) == [55, 12, 17] and list(jm[25:29]) == [20, 37, 38, 39]
+    assert list(jm[46:50]) == [21, 52, 53, 54] and list(jm[67:]) == list(range(76, 144))
+
+
+def test_smplx_fit_matches_reference_golden(smplx_model, gmm_bufs):
+    torch.set_num_threads(1)
+    g = load_golden("smplx_8view_40it.npz")
+    assert S.model_digest(smplx_model) == str(g["model_digest"])
+    prob = S.make_problem_smplx(smplx_model, frame=0, n_views=8)
+    res = O.fit_smplx(smplx_model, gmm_bufs, prob, 40, snapshots=(1, 2, 6, 10, 20, 40))
+    for k in (1, 2, 6, 10, 20, 40):
+        for n in O.SMPLX_PARAMS:
+            np.testing.assert_allclose(res["snapshots"][k][n], g[f"it{k}_{n}"], rtol=0, atol=5e-6, err_msg=f"{k} {n}")
+    np.testing.assert_allclose(res["joints"], g["joints"], atol=5e-6)
+    np.testing.assert_allclose(res["full_pose"], g["full_pose"], atol=5e-6)
+    np.testing.assert_allclose(res["vertices"][::53], g["vertices_sample"], atol=5e-6)
+
+
+def test_smplx_mask_fit_matches_reference_golden(smplx_model, gmm_bufs):
+    torch.set_num_threads(1)
+    g = load_golden("smplx_mask_8view_15it.npz")
+    prob = S.make_problem_smplx(smplx_model, frame=0, n_views=8, mask_frames=[1, 3, 5, 7])
+    res = O.fit_smplx(smplx_model, gmm_bufs, prob, 15, snapshots=(6, 10, 15), mask_pairwise="torch")
+    for k, tol in ((6, 5e-6), (10, 2e-4), (15, 1e-3)):       # silhouette iterations start at i = 6 and are ill-conditioned
+        for n in O.SMPLX_PARAMS:
+            np.testing.assert_allclose(res["snapshots"][k][n], g[f"it{k}_{n}"], rtol=0, atol=tol, err_msg=f"{k} {n}")
