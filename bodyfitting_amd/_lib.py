@@ -28,6 +28,11 @@ class ModelDesc(C.Structure):
         ("gmm_means", C.POINTER(C.c_float)), ("gmm_precisions", C.POINTER(C.c_float)),
         ("gmm_nll_weights", C.POINTER(C.c_float)),
         ("n_faces", C.c_int32), ("faces", C.POINTER(C.c_int32)),
+        ("model_kind", C.c_int32), ("pose_mean", C.POINTER(C.c_float)), ("n_hand_pca", C.c_int32),
+        ("left_hand_components", C.POINTER(C.c_float)), ("right_hand_components", C.POINTER(C.c_float)),
+        ("n_lmk_static", C.c_int32), ("lmk_faces_idx", C.POINTER(C.c_int32)), ("lmk_bary_coords", C.POINTER(C.c_float)),
+        ("n_lmk_dynamic", C.c_int32), ("n_dyn_rows", C.c_int32), ("dynamic_lmk_faces_idx", C.POINTER(C.c_int32)),
+        ("dynamic_lmk_bary_coords", C.POINTER(C.c_float)), ("neck_joint", C.c_int32),
     ]
 
 
@@ -52,6 +57,7 @@ SIGNATURES = {
     "bf_model_destroy": (None, [_VP]),
     "bf_model_n_params": (C.c_int, [_VP]),
     "bf_smpl_forward": (C.c_int, [_VP, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP]),
+    "bf_model_forward": (C.c_int, [_VP, C.c_int, _FP, _FP, _FP]),
     "bf_batch_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(_VP)]),
     "bf_batch_destroy": (None, [_VP]),
     "bf_batch_set_cameras": (C.c_int, [_VP, _FP, _FP]),

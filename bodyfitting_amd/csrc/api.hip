@@ -4,7 +4,7 @@
 extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
 extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *);
-extern "C" __global__ void bf_joints_kernel(MeshTab, const float *, const float *, const float *, float *, float *);
+extern "C" __global__ void bf_joints_kernel(MeshTab, const float *, const float *, const float *, float *, float *, float *, int *, float *);
 extern "C" size_t bf_fit_smem_bytes(int, int, int, int, int, int, int);
 extern "C" size_t bf_mesh_smem_bytes(int, int, int);
 
@@ -46,17 +46,26 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         return fail(BF_ERR_UNSUPPORTED, "bf_model_create: need 2..64 joints and 1..12 betas");
     if (d->gmm_components != BF_GMM_M || d->gmm_dim != BF_GMM_D)
         return fail(BF_ERR_UNSUPPORTED, "bf_model_create: the GMM prior must be 8 components x 69 dims");
-    if (d->n_loss_joints <= 0 || d->n_loss_joints > 32 || d->n_loss_joints > d->n_joint_map)
-        return fail(BF_ERR_UNSUPPORTED, "bf_model_create: 1..32 loss joints supported");
-    if (d->n_extra > 32 || d->n_joints + d->n_selector + d->n_extra > 128)
+    if (d->n_loss_joints <= 0 || d->n_loss_joints > 192 || d->n_loss_joints > d->n_joint_map)
+        return fail(BF_ERR_UNSUPPORTED, "bf_model_create: 1..192 loss joints supported");
+    const bool smplx = d->model_kind == 1;
+    const int n_lmk = smplx ? d->n_lmk_static + d->n_lmk_dynamic : 0;
+    if (d->n_extra > 32 || d->n_joints + d->n_selector + d->n_extra + n_lmk > 256)
         return fail(BF_ERR_UNSUPPORTED, "bf_model_create: too many auxiliary joints");
+    if (smplx) {
+        if (d->n_joints != 55 || d->n_hand_pca <= 0 || d->n_hand_pca > 6 || !d->pose_mean || !d->left_hand_components ||
+            !d->right_hand_components || !d->faces || d->n_faces <= 0 || !d->lmk_faces_idx || !d->lmk_bary_coords ||
+            (d->n_lmk_dynamic > 0 && (!d->dynamic_lmk_faces_idx || !d->dynamic_lmk_bary_coords || d->n_dyn_rows < 79)) ||
+            d->neck_joint < 0 || d->neck_joint >= 55)
+            return fail(BF_ERR_INVALID, "bf_model_create: incomplete SMPL-X description");
+    }
     const int nv = d->n_verts, nj = d->n_joints, nb = d->n_betas, npf = 9 * (nj - 1);
     if (d->parents[0] != -1) return fail(BF_ERR_INVALID, "bf_model_create: parents[0] must be -1");
     for (int j = 1; j < nj; ++j)
         if (d->parents[j] < 0 || d->parents[j] >= j) return fail(BF_ERR_INVALID, "bf_model_create: parents[i] must be in [0,i)");
     for (int i = 0; i < d->n_selector; ++i)
         if (d->selector_ids[i] < 0 || d->selector_ids[i] >= nv) return fail(BF_ERR_INVALID, "bf_model_create: selector id out of range");
-    const int n_all = nj + d->n_selector + d->n_extra;
+    const int n_all = nj + d->n_selector + d->n_extra + ((d->model_kind == 1) ? d->n_lmk_static + d->n_lmk_dynamic : 0);
     for (int i = 0; i < d->n_joint_map; ++i)
         if (d->joint_map[i] < 0 || d->joint_map[i] >= n_all) return fail(BF_ERR_INVALID, "bf_model_create: joint_map entry out of range");
     HIP_TRY(hipSetDevice(device));
@@ -66,7 +75,11 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     m->nv = nv; m->nj = nj; m->nb = nb; m->npf = npf;
     m->n_selector = d->n_selector; m->n_extra = d->n_extra; m->n_joint_map = d->n_joint_map;
     m->nl = d->n_loss_joints;
-    m->np = 3 + 1 + 3 * (nj - 1) + nb + 3;
+    m->nl_loss = d->n_loss_joints;
+    m->kind = d->model_kind; m->n_lmk = n_lmk; m->n_all = n_all;
+    m->kp_dense = d->n_loss_joints > 32;
+    const int n_body = smplx ? 21 : nj - 1, n_pca = smplx ? d->n_hand_pca : 0;
+    m->np = smplx ? 3 + 1 + 63 + nb + 3 + 3 + 3 + 2 * n_pca : 3 + 1 + 3 * (nj - 1) + nb + 3;
 
     // ---- kinematic tree: depth levels and children lists ----------------------------------
     std::vector<int> parents(d->parents, d->parents + nj), depth(nj, 0);
@@ -87,6 +100,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     m->n_levels = n_levels;
 
     // ---- loss joints -> chain joint or selector-vertex slot (loss.py:163, models/smpl.py:75) ----
+    if (m->kp_dense) m->nl = 0;                   // the keypoint loss goes through the dense path (bf_kp_loss_kernel)
     std::vector<int> lj_kind(m->nl), lj_index(m->nl), sel;
     for (int k = 0; k < m->nl; ++k) {
         int s = d->joint_map[k];
@@ -223,8 +237,45 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
 
     FitTab &T = m->fit;
     T.nj = nj; T.nb = nb; T.npf = npf; T.ns = ns; T.nl = m->nl; T.np = m->np; T.n_levels = n_levels;
-    T.nbp = 3 * (nj - 1);
-    T.off_pose = 4; T.off_beta = 4 + 3 * (nj - 1); T.off_orient = T.off_beta + nb;
+    T.nbp = 3 * n_body;
+    T.off_pose = 4; T.off_beta = 4 + 3 * n_body; T.off_orient = T.off_beta + nb;
+    T.n_pca = n_pca; T.off_lh = T.off_orient + 9; T.off_rh = T.off_lh + n_pca;
+    T.kp_dense = m->kp_dense;
+    {
+        const int off_leye = T.off_orient + 3, off_reye = T.off_orient + 6;
+        std::vector<int> thk(nj, 0), tho(nj, 0), pk(m->np, 0), pa(m->np, 0), pb(m->np, -1);
+        for (int j = 0; j < nj; ++j) {
+            if (j == 0) { thk[j] = 0; tho[j] = T.off_orient; }
+            else if (j <= n_body) { thk[j] = 0; tho[j] = T.off_pose + 3 * (j - 1); }
+            else if (j == 22) { thk[j] = 1; }
+            else if (j == 23) { thk[j] = 0; tho[j] = off_leye; }
+            else if (j == 24) { thk[j] = 0; tho[j] = off_reye; }
+            else if (j < 40) { thk[j] = 2; tho[j] = j - 25; }
+            else { thk[j] = 3; tho[j] = j - 40; }
+        }
+        for (int i = 0; i < m->np; ++i) {
+            if (i < 4) pk[i] = 0;
+            else if (i < T.off_beta) { int ip = i - T.off_pose; pk[i] = 1; pa[i] = 3 + ip; pb[i] = ip; }
+            else if (i < T.off_orient) pk[i] = 2;
+            else if (i < T.off_orient + 3) { pk[i] = 1; pa[i] = i - T.off_orient; }
+            else if (i < off_reye) { pk[i] = 1; pa[i] = 23 * 3 + (i - off_leye); }
+            else if (i < T.off_lh) { pk[i] = 1; pa[i] = 24 * 3 + (i - off_reye); }
+            else if (i < T.off_rh) { pk[i] = 3; pa[i] = 0; pb[i] = i - T.off_lh; }
+            else { pk[i] = 3; pa[i] = 1; pb[i] = i - T.off_rh; }
+        }
+        bool up = m->th_kind.upload(thk) == hipSuccess && m->th_off.upload(tho) == hipSuccess && m->p_kind.upload(pk) == hipSuccess &&
+                  m->p_a.upload(pa) == hipSuccess && m->p_b.upload(pb) == hipSuccess;
+        if (smplx) {
+            std::vector<float> hc((size_t)2 * n_pca * 45);
+            std::memcpy(hc.data(), d->left_hand_components, sizeof(float) * n_pca * 45);
+            std::memcpy(hc.data() + (size_t)n_pca * 45, d->right_hand_components, sizeof(float) * n_pca * 45);
+            up = up && m->hand_comp.upload(hc) == hipSuccess &&
+                 m->pose_mean.upload(std::vector<float>(d->pose_mean, d->pose_mean + (size_t)nj * 3)) == hipSuccess;
+        }
+        if (!up) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (pose tables)"); }
+        T.th_kind = m->th_kind.p; T.th_off = m->th_off.p; T.p_kind = m->p_kind.p; T.p_a = m->p_a.p; T.p_b = m->p_b.p;
+        T.pose_mean = smplx ? m->pose_mean.p : nullptr; T.hand_comp = smplx ? m->hand_comp.p : nullptr;
+    }
     T.sel_nnz = sel_nnz; T.sel_nzw = m->sel_nzw.p; T.sel_nzj = m->sel_nzj.p;
     T.depth = m->depth_d.p; T.desc = m->desc_d.p; T.g_plane = m->g_plane.p; T.g_ptail = m->g_ptail.p;
     T.parents = m->parents.p; T.level_start = m->level_start.p; T.level_joints = m->level_joints.p;
@@ -240,6 +291,35 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     Q.lbs_weights = m->lbs_weights.p; Q.j_extra = m->j_extra.p;
     Q.selector_ids = m->selector_ids.p; Q.joint_map = m->joint_map.p;
     Q.n_tiles = (nv + BF_MESH_TILE - 1) / BF_MESH_TILE;
+    Q.n_lmk_static = smplx ? d->n_lmk_static : 0; Q.n_lmk_dyn = smplx ? d->n_lmk_dynamic : 0;
+    Q.n_dyn_rows = smplx ? d->n_dyn_rows : 0; Q.neck_joint = smplx ? d->neck_joint : 0;
+    if (smplx) {
+        bool up = m->faces_lm.upload(std::vector<int>(d->faces, d->faces + (size_t)d->n_faces * 3)) == hipSuccess &&
+                  m->lmk_faces.upload(std::vector<int>(d->lmk_faces_idx, d->lmk_faces_idx + d->n_lmk_static)) == hipSuccess &&
+                  m->lmk_bary.upload(std::vector<float>(d->lmk_bary_coords, d->lmk_bary_coords + (size_t)d->n_lmk_static * 3)) == hipSuccess &&
+                  m->dyn_faces.upload(std::vector<int>(d->dynamic_lmk_faces_idx, d->dynamic_lmk_faces_idx + (size_t)d->n_dyn_rows * d->n_lmk_dynamic)) == hipSuccess &&
+                  m->dyn_bary.upload(std::vector<float>(d->dynamic_lmk_bary_coords, d->dynamic_lmk_bary_coords + (size_t)d->n_dyn_rows * d->n_lmk_dynamic * 3)) == hipSuccess;
+        if (!up) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (landmarks)"); }
+        for (int i = 0; i < d->n_lmk_static; ++i)
+            if (d->lmk_faces_idx[i] < 0 || d->lmk_faces_idx[i] >= d->n_faces) { delete m; return fail(BF_ERR_INVALID, "bf_model_create: landmark face out of range"); }
+        Q.faces = m->faces_lm.p; Q.lmk_faces = m->lmk_faces.p; Q.lmk_bary = m->lmk_bary.p; Q.dyn_faces = m->dyn_faces.p; Q.dyn_bary = m->dyn_bary.p;
+    }
+    if (m->kp_dense) {
+        // dense keypoint loss tables: loss joints -> all-joints index; per chain joint the loss joints that use it
+        std::vector<int> jm(d->joint_map, d->joint_map + m->nl_loss), cs(nj + 1, 0), cl;
+        for (int j = 0; j < nj; ++j) {
+            cs[j] = (int)cl.size();
+            for (int q = 0; q < m->nl_loss; ++q) if (jm[q] == j) cl.push_back(q);
+        }
+        cs[nj] = (int)cl.size();
+        if (cl.empty()) cl.push_back(0);
+        bool up = m->kp_jm.upload(jm) == hipSuccess && m->cj_start.upload(cs) == hipSuccess && m->cj_list.upload(cl) == hipSuccess;
+        if (!up) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (keypoint tables)"); }
+        KpIO &K = m->kp;
+        K.nl = m->nl_loss; K.nj = nj; K.npf = npf; K.nb = nb; K.nv = nv; K.n_all = n_all; K.n_selector = d->n_selector;
+        K.n_extra = d->n_extra; K.n_lmk = n_lmk;
+        K.joint_map = m->kp_jm.p; K.selector_ids = m->selector_ids.p; K.cj_start = m->cj_start.p; K.cj_list = m->cj_list.p;
+    }
     m->mesh_smem = bf_mesh_smem_bytes(nj, npf, nb);
     *out = m;
     return BF_OK;
@@ -249,15 +329,16 @@ void bf_model_destroy(bf_model *m) { delete m; }
 int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
 
 int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
-                   float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed) {
+                   float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw, int *lmk_vid,
+                   float *lmk_w) {
     dim3 grid(m->mesh.n_tiles, n);
     hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, m->mesh,
-                       state_dev, vraw, vout, (joints || joints_ori) ? xpart : (float *)nullptr, vposed);
+                       state_dev, vraw, vout, (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed);
     HIP_TRY(hipGetLastError());
     if (after_mesh) HIP_TRY(hipEventRecord(after_mesh, stream));
-    if (joints || joints_ori) {
+    if (joints || joints_ori || jraw) {
         hipLaunchKernelGGL(bf_joints_kernel, dim3(n), dim3(256), 0, stream, m->mesh, state_dev, (const float *)vraw,
-                           (const float *)xpart, joints, joints_ori);
+                           (const float *)xpart, joints, joints_ori, jraw, lmk_vid, lmk_w);
         HIP_TRY(hipGetLastError());
     }
     return BF_OK;
@@ -311,7 +392,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
     ok = ok && hipHostMalloc((void **)&b->h_terms, F * 4 * sizeof(float)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&b->h_state, F * bf_state_stride(m->nj, m->npf, m->nb) * sizeof(float)) == hipSuccess;
     ok = ok && b->proj.alloc(F * n_views * 12) == hipSuccess;
-    ok = ok && b->keypoints.alloc(F * n_views * m->nl * 3) == hipSuccess;
+    ok = ok && b->keypoints.alloc(F * n_views * m->nl_loss * 3) == hipSuccess;
     ok = ok && b->ndiv.upload(std::vector<int>(F, n_views)) == hipSuccess;
     ok = ok && b->params.alloc(F * np) == hipSuccess && b->adam_m.alloc(F * np) == hipSuccess;
     ok = ok && b->adam_v.alloc(F * np) == hipSuccess && b->grads.alloc(F * np) == hipSuccess;
@@ -422,14 +503,15 @@ int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_po
     if (!b || !init_betas || !init_pose) return fail(BF_ERR_INVALID, "bf_batch_set_init: null argument");
     HIP_TRY(hipSetDevice(b->m->device));
     const bf_model *m = b->m;
-    const int np = m->np, nj = m->nj, nb = m->nb;
+    const int np = m->np, nb = m->nb;
+    const int pose_stride = 72;                  // net_output poses are [F,72] for both model kinds (smplify.py:108-112)
     std::vector<float> p((size_t)b->F * np, 0.f);
     for (int f = 0; f < b->F; ++f) {
         float *q = p.data() + (size_t)f * np;
         q[3] = 1.0f;                                                             // body_scale = 1, transl = 0
-        std::memcpy(q + m->fit.off_pose, init_pose + (size_t)f * 3 * nj + 3, sizeof(float) * 3 * (nj - 1));
+        std::memcpy(q + m->fit.off_pose, init_pose + (size_t)f * pose_stride + 3, sizeof(float) * m->fit.nbp);
         std::memcpy(q + m->fit.off_beta, init_betas + (size_t)f * nb, sizeof(float) * nb);
-        std::memcpy(q + m->fit.off_orient, init_pose + (size_t)f * 3 * nj, sizeof(float) * 3);
+        std::memcpy(q + m->fit.off_orient, init_pose + (size_t)f * pose_stride, sizeof(float) * 3);
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
     HIP_TRY(hipMemcpy(b->params.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -510,7 +592,7 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (rc) return rc;
     HyperDev hd = bf_to_dev(h);
     FrameIO io = bf_frame_io(b, false);
-    const bool dense_losses = !b->scans.empty() || b->has_masks;
+    const bool dense_losses = !b->scans.empty() || b->has_masks || m->kp_dense;
     if (dense_losses) flags &= ~BF_FIT_DENSE;
     const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES);
     b->ev = b->ring.data() + (size_t)(b->ring_n % bf_batch::kRing) * 4;
@@ -570,7 +652,8 @@ int bf_loss_grad(bf_batch *b, const bf_hyper *hyper, float *terms, float *grads)
     if (rc) return rc;
     HyperDev hd = bf_to_dev(h);
     FrameIO io = bf_frame_io(b, true);
-    HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, m->fit_smem, b->stream));
+    if (m->kp_dense) { rc = bf_dense_loss_grad(b, h, hd, io); if (rc) return rc; }
+    else HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, m->fit_smem, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (terms) HIP_TRY(hipMemcpy(terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));
     if (grads) HIP_TRY(hipMemcpy(grads, b->grads.p, b->grads.n * sizeof(float), hipMemcpyDeviceToHost));

@@ -52,6 +52,11 @@ struct bf_model {
     DevBuf<float> g_plane, g_ptail;
     DevBuf<int> parents, level_start, level_joints, child_start, child_list, lj_kind, lj_index;
     DevBuf<float> Jt, Jd, Jdrel, sel_vt, sel_sd, sel_pd, sel_w, g_means, g_psym, g_logw;
+    // SMPL-X pose assembly / parameter routing / landmarks / dense keypoint loss
+    int kind = 0, kp_dense = 0, n_lmk = 0, n_all = 0, nl_loss = 0;
+    DevBuf<int> th_kind, th_off, p_kind, p_a, p_b, faces_lm, lmk_faces, dyn_faces, kp_jm, cj_start, cj_list;
+    DevBuf<float> pose_mean, hand_comp, lmk_bary, dyn_bary;
+    KpIO kp{};
     DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass
     std::vector<float> posedirs_host;
     std::vector<int> faces_host;  // body-model topology (for the SMPL+D stage), optional
@@ -80,7 +85,8 @@ struct bf_batch {
     std::vector<struct bf_scan *> scans;
     DevBuf<ScanDev> scan_dev;
     DevBuf<float> cscale, pc_weight, pc_partial, pc_loss, dvout, vposed, cpts, ext_part, ext;
-    DevBuf<int> cface;
+    DevBuf<int> cface, lmk_vid;
+    DevBuf<float> jraw, lmk_w;
     // silhouette loss (use_mask, smplify.py:138-144,197-199)
     bool has_masks = false;
     MaskIO mask{};
@@ -105,8 +111,11 @@ struct bf_scan {
 // shared between api.hip and scan_api.hip
 extern "C" {
 int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
-                   float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed);
+                   float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw = nullptr,
+                   int *lmk_vid = nullptr, float *lmk_w = nullptr);
 int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDev &hd, FrameIO io);
+int bf_dense_loss_grad(bf_batch *b, const bf_hyper &h, const HyperDev &hd, FrameIO io);
+int bf_ensure_dense_buffers(bf_batch *b);
 HyperDev bf_to_dev(const bf_hyper &h);
 FrameIO bf_frame_io(bf_batch *b, bool want_grads);
 }

@@ -19,6 +19,16 @@ struct FitTab {
     int n_levels;                    // depth of the kinematic tree
     int nbp;                         // optimised body-pose dofs (69 SMPL); the GMM sees them zero-padded to 69
     int off_pose, off_beta, off_orient;
+    // full-pose assembly theta_j = pose_mean_j + (params | hand PCA | 0), SURVEY.md 10B
+    int n_pca, off_lh, off_rh;       // hand PCA coefficient blocks inside the parameter vector (n_pca = 0 for SMPL)
+    const int *th_kind;              // [nj] 0 = 3 parameters at th_off, 1 = constant (jaw), 2 / 3 = left / right hand joint th_off
+    const int *th_off;               // [nj]
+    const float *pose_mean;          // [nj*3] or null
+    const float *hand_comp;          // [2][n_pca][45] or null
+    const int *p_kind;               // [np] 0 = g[i] (transl, scale), 1 = d/dtheta[p_a] (+ body priors if p_b >= 0 = body dof),
+    const int *p_a;                  //      2 = beta (+ shape prior), 3 = hand PCA coefficient p_b of hand p_a
+    const int *p_b;
+    int kp_dense;                    // 1 = the keypoint loss arrives through `ext` (more than 32 loss joints)
     const int *parents;              // [nj]
     const int *depth;                // [nj]
     const unsigned long long *desc;  // [nj] bit k set = joint k is a strict descendant
@@ -57,7 +67,28 @@ struct MeshTab {
     const int *selector_ids;         // [n_selector]
     const int *joint_map;            // [n_joint_map]
     int n_tiles;                     // ceil(nv / BF_MESH_TILE)
+    // face landmarks (SMPL-X): 51 static + 17 contour landmarks picked by the neck's yaw out of a 79-row table
+    int n_lmk_static, n_lmk_dyn, n_dyn_rows, neck_joint;
+    const int *faces;                // [nf][3]
+    const int *lmk_faces;            // [n_lmk_static]
+    const float *lmk_bary;           // [n_lmk_static][3]
+    const int *dyn_faces;            // [rows][n_lmk_dyn]
+    const float *dyn_bary;           // [rows][n_lmk_dyn][3]
 };
+
+// theta_j[k] of the full pose: shared by the fit kernel (LDS copies of the tables) and the pose-state kernel
+__device__ inline float bf_theta(const float *params, int j, int k, const int *th_kind, const int *th_off, const float *pose_mean,
+                                 const float *hand_comp, int n_pca, int off_lh, int off_rh) {
+    float th = pose_mean ? pose_mean[j * 3 + k] : 0.f;
+    const int kind = th_kind[j], off = th_off[j];
+    if (kind == 0) th += params[off + k];
+    else if (kind >= 2) {
+        const float *comp = hand_comp + (kind - 2) * n_pca * 45 + off * 3 + k;
+        const float *c = params + (kind == 2 ? off_lh : off_rh);
+        for (int q = 0; q < n_pca; ++q) th += c[q] * comp[q * 45];
+    }
+    return th;
+}
 
 // Per-frame pose state handed from the fit / pose-prep kernel to the mesh kernel.
 // layout per frame (floats): GR[nj*9] At[nj*3] Gt[nj*3] feat[npf] theta[nj*3] beta[nb] t[3] s c
@@ -101,6 +132,16 @@ struct MaskIO {
     const float *contour_xy;              // [sum][2] (x, y) contour points (loss.py:73-83)
 };
 
+// Dense keypoint loss inputs (device pointers / sizes).
+struct KpIO {
+    int nl, n_views, nj, npf, nb, nv, n_all, n_selector, n_extra, n_lmk;
+    float sigma2, coeff;
+    const int *joint_map;        // [nl] index into the all-joints array
+    const int *selector_ids;     // [n_selector]
+    const int *cj_start;         // [nj+1]  loss joints mapping to each chain joint (CSR)
+    const int *cj_list;
+};
+
 struct FrameIO {
     int n_frames, n_views;
     const float *proj;        // [F][V][12]   K [R|t], world -> pixel
@@ -114,7 +155,8 @@ struct FrameIO {
     float *state;             // [F][state_stride]
     float *debug;             // optional dump of the first iteration's intermediates
     const float *cscale;      // [F] per-frame constant scale (scan_height / 1.7, smplify.py:156) or null
-    const float *ext;         // [F][npf + nj*12 + nb + 4] gradients arriving from the dense vertex losses, or null
+    const float *ext;         // [F][npf + nj*12 + nb + 4 + nj*3] gradients arriving from the dense losses (dfeat | per joint
+                              //  rows of sum w dv (x) [vp|1] | dbeta | dt ds | dL/d(chain joint positions)), or null
 };
 
 struct HyperDev {

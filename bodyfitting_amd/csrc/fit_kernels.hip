@@ -44,8 +44,8 @@ namespace {
 struct FitSmem {
     float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
-    float *Jt, *Jd, *Jdrel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw;
-    int *nzj;
+    float *Jt, *Jd, *Jdrel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp;
+    int *nzj, *thk, *tho;
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
@@ -73,6 +73,8 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
     s.proj = take(nviews * 12);
     s.nzw = take(ns * BF_SEL_NNZ);  s.nzj = (int *)take(ns * BF_SEL_NNZ);
+    s.theta = take(nj * 3);  s.pmean = take(nj * 3);  s.hcomp = take(2 * 6 * 45);
+    s.thk = (int *)take(nj); s.tho = (int *)take(nj);
     (void)nl;
     return o * sizeof(float);
 }
@@ -132,9 +134,6 @@ __device__ inline void rodrigues_bwd(float tx, float ty, float tz, const float *
     gth[2] = dn2 / a + k * (tz + 1e-8f);
 }
 
-__device__ inline float theta_of(const float *params, const FitTab &T, int j, int k) {
-    return j == 0 ? params[T.off_orient + k] : params[T.off_pose + 3 * (j - 1) + k];
-}
 
 #define GR_(j, r, c) S.G[((j) * 3 + (r)) * 4 + (c)]
 #define GT_(j, r) S.G[((j) * 3 + (r)) * 4 + 3]
@@ -176,7 +175,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     copy_f(S.sel_pd, T.sel_pd, npf * ns3, tid, nt);
     copy_f(S.sel_w, T.sel_w, ns * nj, tid, nt);
     for (int i = tid; i < ns * BF_SEL_NNZ; i += nt) { S.nzw[i] = T.sel_nzw[i]; S.nzj[i] = T.sel_nzj[i]; }
-    const int sel_nnz = T.sel_nnz;           // 0 = some selector vertex has more than BF_SEL_NNZ bones: dense loop
+    const int sel_nnz = T.sel_nnz;
+    for (int i = tid; i < nj; i += nt) { S.thk[i] = T.th_kind[i]; S.tho[i] = T.th_off[i]; }
+    for (int i = tid; i < nj * 3; i += nt) S.pmean[i] = T.pose_mean ? T.pose_mean[i] : 0.f;
+    for (int i = tid; i < 2 * T.n_pca * 45 && i < 2 * 6 * 45; i += nt) S.hcomp[i] = T.hand_comp[i];
+    auto theta_of = [&](const float *P, int j, int k) {
+        return bf_theta(P, j, k, S.thk, S.tho, S.pmean, S.hcomp, T.n_pca, T.off_lh, T.off_rh);
+    };           // 0 = some selector vertex has more than BF_SEL_NNZ bones: dense loop
     for (int i = tid; i < BF_GMM_M * BF_GMM_LD; i += nt) {
         int m = i / BF_GMM_LD, j = i % BF_GMM_LD;
         S.means[i] = j < BF_GMM_D ? T.g_means[m * BF_GMM_D + j] : 0.f;
@@ -240,21 +245,23 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const float s2 = hp.sigma2;
     const float cscale = io.cscale ? io.cscale[frame] : hp.cscale;
     const int EXT0 = npf, EXT_A = npf, EXT_B = npf + nj * 12, EXT_T = npf + nj * 12 + nb;
-    const float *ext = io.ext ? io.ext + (size_t)frame * (npf + nj * 12 + nb + 4) : nullptr;
+    const int EXT_G = npf + nj * 12 + nb + 4;
+    const int EXT_K = EXT_G + nj * 3;          // dt, ds of the dense keypoint loss
+    const float *ext = io.ext ? io.ext + (size_t)frame * (npf + nj * 12 + nb + 4 + nj * 3 + 4) : nullptr;
     (void)EXT0;
 
     // pose-blend role: (row slice sl, output column o of the selector vertices)
-    const int NSL = ns3 <= nt ? nt / ns3 : 1;
+    const int NSL = (ns3 > 0 && ns3 <= nt) ? nt / ns3 : 1;
     const int rows_sl = (npf + NSL - 1) / NSL;
 
     // Adam role: parameter `tid`, its moments in registers
     float am = 0.f, av = 0.f;
     if (tid < np) { am = io.adam_m[(size_t)frame * np + tid]; av = io.adam_v[(size_t)frame * np + tid]; }
-    float ang_sg = 0.f;                        // angle prior sign (loss.py:54-61: dofs 52, 55, 9, 12)
-    {
-        int ip = tid - T.off_pose;
-        if (tid >= T.off_pose && tid < T.off_beta) ang_sg = ip == 52 ? 1.f : ((ip == 55 || ip == 9 || ip == 12) ? -1.f : 0.f);
-    }
+    const int pk = tid < np ? T.p_kind[tid] : 0, pa = tid < np ? T.p_a[tid] : 0, pb = tid < np ? T.p_b[tid] : -1;
+    int hand_j0_l = 0, hand_j0_r = 0;          // first joint of each hand
+    for (int j = nj - 1; j >= 0; --j) { if (T.th_kind[j] == 2) hand_j0_l = j; if (T.th_kind[j] == 3) hand_j0_r = j; }
+    float ang_sg = 0.f;                        // angle prior sign (loss.py:54-61: body dofs 52, 55, 9, 12)
+    if (pk == 1 && pb >= 0) ang_sg = pb == 52 ? 1.f : ((pb == 55 || pb == 9 || pb == 12) ? -1.f : 0.f);
     __syncthreads();
 
     // phases shared by both wave roles
@@ -399,7 +406,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             float Ri[9], rc[3], Jj0 = 0.f, Jj1 = 0.f, Jj2 = 0.f, rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
             float4 row = {0.f, 0.f, 0.f, 0.f};
             if (cw_on) {
-                rodrigues_fwd(theta_of(Pcur, T, wj, 0), theta_of(Pcur, T, wj, 1), theta_of(Pcur, T, wj, 2), Ri, rc);
+                float th0 = theta_of(Pcur, wj, 0), th1 = theta_of(Pcur, wj, 1), th2 = theta_of(Pcur, wj, 2);
+                rodrigues_fwd(th0, th1, th2, Ri, rc);
+                if (wave == 0) { S.theta[wj * 3] = th0; S.theta[wj * 3 + 1] = th1; S.theta[wj * 3 + 2] = th2; }
                 const float *beta = Pcur + T.off_beta;
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
 #pragma unroll
@@ -516,15 +525,15 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 }
                 float gt0 = wave_sum(cnt ? a.x : 0.f), gt1 = wave_sum(cnt ? a.y : 0.f), gt2 = wave_sum(cnt ? a.z : 0.f);
                 if (lane == 0) {                                                              // d/d global_transl (smplify.py:189)
-                    S.g[0] = gt0 * sc + (ext ? ext[EXT_T] : 0.f); S.g[1] = gt1 * sc + (ext ? ext[EXT_T + 1] : 0.f);
-                    S.g[2] = gt2 * sc + (ext ? ext[EXT_T + 2] : 0.f);
+                    S.g[0] = gt0 * sc + (ext ? ext[EXT_T] + ext[EXT_K] : 0.f); S.g[1] = gt1 * sc + (ext ? ext[EXT_T + 1] + ext[EXT_K + 1] : 0.f);
+                    S.g[2] = gt2 * sc + (ext ? ext[EXT_T + 2] + ext[EXT_K + 2] : 0.f);
                 }
             } else {
                 float y0 = 0.f, y1 = 0.f, y2 = 0.f;
                 if (cnt) { y0 = lsrc[0] + Pcur[0]; y1 = lsrc[lstride] + Pcur[1]; y2 = lsrc[2 * lstride] + Pcur[2]; }
                 float gs = wave_sum(cnt ? a.x * y0 + a.y * y1 + a.z * y2 : 0.f);
                 float ls = wave_sum(cnt ? a.w : 0.f);
-                if (lane == 0) { S.g[3] = gs * cscale + (ext ? ext[EXT_T + 3] : 0.f); S.scal[0] = ls; }                   // d/d body_scale; sum conf^2 rho
+                if (lane == 0) { S.g[3] = gs * cscale + (ext ? ext[EXT_T + 3] + ext[EXT_K + 3] : 0.f); S.scal[0] = ls; }                   // d/d body_scale; sum conf^2 rho
             }
         }
         BF_SYNC();
@@ -543,7 +552,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 r0 += ea[0]; r1 += ea[1]; r2 += ea[2]; dat += ea[3];
             }
             S.dAt[tid] = dat;
-            S.dGt[tid] += dat;
+            S.dGt[tid] += ext ? dat + ext[EXT_G + tid] : dat;     // + dL/d(chain joint) of the dense keypoint loss
             S.dGR[ci * 9 + cr * 3] = r0 - dat * S.J[ci * 3];
             S.dGR[ci * 9 + cr * 3 + 1] = r1 - dat * S.J[ci * 3 + 1];
             S.dGR[ci * 9 + cr * 3 + 2] = r2 - dat * S.J[ci * 3 + 2];
@@ -610,8 +619,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
         // ================= phase J: Rodrigues reverse (wave 0) | geometric part of dL/dbeta (waves 1-3)
         if (tid < nj) {
-            rodrigues_bwd(theta_of(Pcur, T, tid, 0), theta_of(Pcur, T, tid, 1), theta_of(Pcur, T, tid, 2),
-                          S.rc + tid * 4, S.dR + tid * 9, S.gth + tid * 3);
+            rodrigues_bwd(S.theta[tid * 3], S.theta[tid * 3 + 1], S.theta[tid * 3 + 2], S.rc + tid * 4, S.dR + tid * 9, S.gth + tid * 3);
         }
         if (wave >= 1 && wave < 4) {
             // 16 lanes per beta component: sum Jd.dJ + Jdrel.drel + sel_sd.dvp
@@ -634,21 +642,28 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         float grad = 0.f, pval = 0.f;
         if (tid < np) {
             pval = Pcur[tid];
-            if (tid < 4) grad = S.g[tid];
-            else if (tid < T.off_beta) {
-                int ip = tid - T.off_pose;
-                grad = S.gth[3 + ip] + hp.w_pose * S.gy[mstar * BF_GMM_LD + ip];
-                if (ang_sg != 0.f) { float e = expf(pval * ang_sg); grad += hp.w_angle * 2.f * e * e * ang_sg; }
-            } else if (tid < T.off_orient) {
-                grad = S.g[tid] + 2.f * hp.w_shape * pval;
-            } else grad = S.gth[tid - T.off_orient];
+            if (pk == 0) grad = S.g[tid];
+            else if (pk == 1) {
+                grad = S.gth[pa];
+                if (pb >= 0) {                                       // body-pose dof pb: GMM + angle priors
+                    grad += hp.w_pose * S.gy[mstar * BF_GMM_LD + pb];
+                    if (ang_sg != 0.f) { float e = expf(pval * ang_sg); grad += hp.w_angle * 2.f * e * e * ang_sg; }
+                }
+            } else if (pk == 2) grad = S.g[tid] + 2.f * hp.w_shape * pval;
+            else {                                                   // hand PCA coefficient pb of hand pa
+                const float *comp = S.hcomp + (pa * T.n_pca + pb) * 45;
+                const float *gh = S.gth + (pa == 0 ? hand_j0_l : hand_j0_r) * 3;
+                float acc = 0.f;
+                for (int e = 0; e < 45; ++e) acc += comp[e] * gh[e];
+                grad = acc;
+            }
         }
         bool last = it == n_iters - 1;
         if (last || mode == 1) {
             // loss terms of this evaluation (loss.py:219-224) and the pose state of this forward pass
             if (tid == 0) {
                 float *tm = io.terms + (size_t)frame * 4;
-                tm[0] = S.scal[0] / ndiv_f;
+                if (!T.kp_dense) tm[0] = S.scal[0] / ndiv_f;         // (the dense keypoint kernel owns it otherwise)
                 tm[1] = hp.w_pose * qmin;
             }
             if (tid == 64) {
@@ -669,7 +684,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
             StateView st = bf_state_view(io.state + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
             for (int i = tid; i < nj * 9; i += NG) { int j = i / 9, e = i - j * 9; st.GR[i] = GR_(j, e / 3, e % 3); }
-            for (int i = tid; i < nj3; i += NG) { st.At[i] = S.At[i]; st.Gt[i] = GT_(i / 3, i % 3); st.theta[i] = theta_of(Pcur, T, i / 3, i % 3); }
+            for (int i = tid; i < nj3; i += NG) { st.At[i] = S.At[i]; st.Gt[i] = GT_(i / 3, i % 3); st.theta[i] = S.theta[i]; }
             for (int p = tid; p < npf; p += NG) st.feat[p] = S.feat[p];
             if (tid < nb) st.beta[tid] = Pcur[T.off_beta + tid];
             if (tid < 3) st.t[tid] = Pcur[tid];

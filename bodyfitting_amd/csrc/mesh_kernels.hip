@@ -54,8 +54,14 @@ bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__r
     const float *beta = pk ? pk + T.off_beta : betas + (size_t)f * nb;
     StateView st = bf_state_view(state + (size_t)f * bf_state_stride(nj, npf, nb), nj, npf, nb);
     if (tid < nj) {
-        const float *th = pk ? (tid == 0 ? pk + T.off_orient : pk + T.off_pose + 3 * (tid - 1))
-                             : (tid == 0 ? orient + (size_t)f * 3 : body_pose + (size_t)f * 3 * (nj - 1) + 3 * (tid - 1));
+        float th[3];
+        if (pk) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) th[k] = bf_theta(pk, tid, k, T.th_kind, T.th_off, T.pose_mean, T.hand_comp, T.n_pca, T.off_lh, T.off_rh);
+        } else {
+            const float *src = tid == 0 ? orient + (size_t)f * 3 : body_pose + (size_t)f * 3 * (nj - 1) + 3 * (tid - 1);
+            th[0] = src[0]; th[1] = src[1]; th[2] = src[2];
+        }
         m_rodrigues(th[0], th[1], th[2], R + tid * 9);
         st.theta[tid * 3] = th[0]; st.theta[tid * 3 + 1] = th[1]; st.theta[tid * 3 + 2] = th[2];
     }
@@ -231,17 +237,21 @@ extern "C" size_t bf_mesh_smem_bytes(int nj, int npf, int nb) {
     return sizeof(float) * (((npf + 3) & ~3) + nj * 12 + BF_MESH_RG * COLS + COLS + nb + 8);
 }
 
-// One 256-thread workgroup per frame.  joints_ori = cat(chain joints, selector vertices) and
-// joints = cat(joints_ori, J_regressor_extra vraw)[joint_map] (models/smpl.py:72-75), both with the
-// similarity of smplify.py:189 applied.  The extra-regressor sums arrive as per-tile partials from
-// bf_mesh_kernel and are added here in tile order (8 lanes per output, fixed tree).
+// One 256-thread workgroup per frame.  All joints in smplx order: chain joints | selector vertices |
+// J_regressor_extra rows (SMPL wrapper, models/smpl.py:72-75) | face landmarks (SMPL-X: 51 static + 17 contour
+// landmarks chosen by the neck's yaw), then gathered by joint_map; similarity of smplify.py:189
+// applied to the outputs.  `jraw` (optional) receives ALL joints in model space and `lmk_vid` / `lmk_w` the
+// vertex ids / barycentric weights of the landmarks actually used, for the dense keypoint loss.
 extern "C" __global__ void __launch_bounds__(256)
 bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__restrict__ vraw,
-                 const float *__restrict__ xpart, float *__restrict__ joints, float *__restrict__ joints_ori) {
+                 const float *__restrict__ xpart, float *__restrict__ joints, float *__restrict__ joints_ori,
+                 float *__restrict__ jraw, int *__restrict__ lmk_vid, float *__restrict__ lmk_w) {
     __shared__ float s_extra[32 * 3];
-    __shared__ float s_all[(64 + 32 + 32) * 3];
+    __shared__ float s_all[256 * 3];
+    __shared__ int s_row;
     const int tid = threadIdx.x, frame = blockIdx.x;
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv, ne = M.n_extra, nsel = M.n_selector;
+    const int nlm = M.n_lmk_static + M.n_lmk_dyn;
     StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
     const float *vr = vraw + (size_t)frame * nv * 3;
     const float t0 = st.t[0], t1 = st.t[1], t2 = st.t[2], sc = st.sc[0] * st.sc[1];
@@ -257,14 +267,35 @@ bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__rest
         acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
         if (o < ne3 && sl == 0) s_extra[o] = acc;
     }
+    if (tid == 0 && M.n_lmk_dyn > 0) {
+        // find_dynamic_lmk_idx_and_bcoords: y = round(clamp(-yaw * 180 / pi, max = 39)), negatives folded to 39 - y / 78
+        const float *G = st.GR + M.neck_joint * 9;
+        float yaw = atan2f(-G[6], sqrtf(G[0] * G[0] + G[3] * G[3]));
+        int y = (int)rintf(fminf(-yaw * 180.0f / 3.14159265358979323846f, 39.f));
+        if (y < 0) y = y < -39 ? 78 : 39 - y;
+        s_row = y;
+    }
     __syncthreads();
-    const int n_ori = nj + nsel;
-    for (int i = tid; i < (n_ori + ne) * 3; i += 256) {
-        int j = i / 3, k = i % 3;
+    const int n_ori = nj + nsel, n_all = n_ori + ne + nlm;
+    for (int i = tid; i < n_all * 3; i += 256) {
+        int j = i / 3, k = i - j * 3;
         float x;
         if (j < nj) x = st.Gt[j * 3 + k];
         else if (j < n_ori) x = vr[(size_t)M.selector_ids[j - nj] * 3 + k];
-        else x = s_extra[(j - n_ori) * 3 + k];
+        else if (j < n_ori + ne) x = s_extra[(j - n_ori) * 3 + k];
+        else {
+            int l = j - n_ori - ne;
+            int face = l < M.n_lmk_static ? M.lmk_faces[l] : M.dyn_faces[s_row * M.n_lmk_dyn + (l - M.n_lmk_static)];
+            const float *bw = l < M.n_lmk_static ? M.lmk_bary + l * 3 : M.dyn_bary + ((size_t)s_row * M.n_lmk_dyn + (l - M.n_lmk_static)) * 3;
+            const int *fv = M.faces + (size_t)face * 3;
+            x = bw[0] * vr[(size_t)fv[0] * 3 + k] + bw[1] * vr[(size_t)fv[1] * 3 + k] + bw[2] * vr[(size_t)fv[2] * 3 + k];
+            if (k == 0 && lmk_vid) {
+                int *vo = lmk_vid + ((size_t)frame * nlm + l) * 3;
+                float *wo = lmk_w + ((size_t)frame * nlm + l) * 3;
+                vo[0] = fv[0]; vo[1] = fv[1]; vo[2] = fv[2]; wo[0] = bw[0]; wo[1] = bw[1]; wo[2] = bw[2];
+            }
+        }
+        if (jraw) jraw[(size_t)frame * n_all * 3 + i] = x;
         float tk = k == 0 ? t0 : (k == 1 ? t1 : t2);
         s_all[i] = (x + tk) * sc;
     }

@@ -7,7 +7,9 @@ extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int
 extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
 extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
 extern "C" __global__ void bf_mesh_bwd_kernel(MeshTab, const float *, const float *, const float *, const float *, const float *, float *);
-extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *);
+extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int);
+extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
+                                             const float *, float *, float *, float *);
 extern "C" size_t bf_mesh_bwd_smem_bytes(int);
 extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const float *, float *, float *, float *);
 extern "C" __global__ void bf_mask_contour_kernel(MaskIO, const float *, int *, float *, float *);
@@ -129,16 +131,19 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
     return BF_OK;
 }
 
-static int ensure_dense_buffers(bf_batch *b) {
+int bf_ensure_dense_buffers(bf_batch *b) {
     bf_model *m = b->m;
     const size_t F = b->F, nv3 = (size_t)m->nv * 3;
-    const int EXT = m->npf + m->nj * 12 + m->nb + 4;
+    const int EXT = m->npf + m->nj * 12 + m->nb + 4, EXT_FULL = EXT + m->nj * 3 + 4;
     if (!b->dvout.p) {
         bool ok = b->dvout.alloc(F * nv3) == hipSuccess && b->vposed.alloc(F * nv3) == hipSuccess &&
                   b->cpts.alloc(F * nv3) == hipSuccess && b->cface.alloc(F * m->nv) == hipSuccess &&
-                  b->ext_part.alloc(F * m->mesh.n_tiles * EXT) == hipSuccess && b->ext.alloc(F * EXT) == hipSuccess &&
+                  b->ext_part.alloc(F * m->mesh.n_tiles * EXT) == hipSuccess && b->ext.alloc(F * EXT_FULL) == hipSuccess &&
+                  b->jraw.alloc(F * std::max(m->n_all, 1) * 3) == hipSuccess && b->lmk_vid.alloc(F * std::max(m->n_lmk, 1) * 3) == hipSuccess &&
+                  b->lmk_w.alloc(F * std::max(m->n_lmk, 1) * 3) == hipSuccess &&
                   b->pc_partial.alloc(F * ((m->nv + 255) / 256)) == hipSuccess && b->pc_loss.alloc(F) == hipSuccess;
         if (!ok) return fail(BF_ERR_HIP, "dense-loss buffers: device allocation failed");
+        HIP_TRY(hipMemset(b->ext.p, 0, b->ext.n * sizeof(float)));
     }
     if (!m->posedirsT.p) {
         // [3NV][npf] transpose for the reverse pass (thread = pose-feature row, contiguous reads)
@@ -173,7 +178,7 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
     if (b->cscale.p) { (void)hipFree(b->cscale.p); b->cscale.p = nullptr; }
     HIP_TRY(b->scan_dev.upload(dev));
     HIP_TRY(b->cscale.upload(cs));
-    return ensure_dense_buffers(b);
+    return bf_ensure_dense_buffers(b);
 }
 
 static int launch_mask_kernels(bf_batch *b, float weight) {
@@ -201,51 +206,115 @@ static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
     return bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, nullptr, nullptr, nullptr, b->stream, nullptr, b->vposed.p);
 }
 
-// the loop of smplify.py:177-213 with use_mask and / or use_mesh: iterations i <= n_iters // 3 are
-// keypoint-only (one persistent launch); every later iteration adds 5 * mask_loss and / or
-// 5 * point_cloud_loss / scan_height * imsize (smplify.py:197-210) through the dense reverse pass.
+static int launch_kp(bf_batch *b, const bf_hyper &h) {
+    bf_model *m = b->m;
+    KpIO K = m->kp;
+    K.n_views = b->V; K.sigma2 = h.sigma * h.sigma; K.coeff = h.imsize / 1024.0f;
+    const int NLP = (K.nl + 31) & ~31, slots = std::max(1, 512 / NLP);
+    const size_t smem = sizeof(float) * ((size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8);
+    hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), smem, b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
+                       (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
+                       (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p);
+    HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+// one dense iteration's forward + loss + reverse passes up to `ext` (everything except the fit kernel itself)
+static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight) {
+    bf_model *m = b->m;
+    const int F = b->F, nv = m->nv, nblk = (nv + 255) / 256;
+    const bool scans = late && !b->scans.empty(), masks = late && b->has_masks, kp = m->kp_dense;
+    hipLaunchKernelGGL(bf_pose_state_kernel, dim3(F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
+                       (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
+    HIP_TRY(hipGetLastError());
+    int rc = bf_launch_mesh(m, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
+                            b->vposed.p, kp ? b->jraw.p : nullptr, kp ? b->lmk_vid.p : nullptr, kp ? b->lmk_w.p : nullptr);
+    if (rc) return rc;
+    if (kp || masks) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
+    if (kp) { rc = launch_kp(b, h); if (rc) return rc; }
+    if (masks) { rc = launch_mask_kernels(b, mask_weight); if (rc) return rc; }
+    if (scans) {
+        hipLaunchKernelGGL(bf_nearest_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
+                           (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr);
+        hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
+                           (const float *)b->cpts.p, nv, b->pc_partial.p);
+        hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
+                           (const float *)b->cpts.p, nv, (const float *)b->pc_partial.p, (const float *)b->pc_weight.p,
+                           b->dvout.p, b->pc_loss.p, (kp || masks) ? 1 : 0);
+    }
+    const int EXT = m->npf + m->nj * 12 + m->nb + 4;
+    hipLaunchKernelGGL(bf_mesh_bwd_kernel, dim3(m->mesh.n_tiles, F), dim3(512), bf_mesh_bwd_smem_bytes(m->nj), b->stream, m->mesh,
+                       (const float *)m->posedirsT.p, (const float *)b->state.p, (const float *)b->dvout.p,
+                       (const float *)b->vposed.p, (const float *)b->vraw.p, b->ext_part.p);
+    hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 255) / 256, F), dim3(256), 0, b->stream,
+                       (const float *)b->ext_part.p, m->mesh.n_tiles, EXT, b->ext.p, EXT + m->nj * 3 + 4);
+    HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+// the loop of smplify.py:177-213 when a dense loss is present (use_mask, use_mesh, or the SMPL-X keypoints
+// with hands + face): iterations that need no dense loss run as one persistent launch; every other iteration
+// is state -> mesh -> losses -> reverse mesh pass -> one fit-kernel iteration (smplify.py:197-210).
 int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDev &hd, FrameIO io) {
     bf_model *m = b->m;
-    const int F = b->F, nv = m->nv, thr = n_iters / 3;
-    const int n_plain = std::min(n_iters, thr + 1);
-    const bool scans = !b->scans.empty(), masks = b->has_masks;
-    if (scans && b->pc_weight.n != (size_t)F) {
+    const int F = b->F, thr = n_iters / 3;
+    const int n_plain = m->kp_dense ? 0 : std::min(n_iters, thr + 1);
+    if (!b->scans.empty() && b->pc_weight.n != (size_t)F) {
         std::vector<float> w(F);
         for (int f = 0; f < F; ++f) w[f] = 5.0f * h.imsize / b->scans[f]->dev.height;      // smplify.py:206,210
         if (b->pc_weight.p) { (void)hipFree(b->pc_weight.p); b->pc_weight.p = nullptr; }
         HIP_TRY(b->pc_weight.upload(w));
     }
-    if (masks) b->mask.imsize = h.imsize;
-    HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, m->fit_smem, b->stream));
-    const int EXT = m->npf + m->nj * 12 + m->nb + 4, nblk = (nv + 255) / 256;
-    const size_t bwd_smem = bf_mesh_bwd_smem_bytes(m->nj);
+    if (b->has_masks) b->mask.imsize = h.imsize;
+    int rc = bf_ensure_dense_buffers(b);
+    if (rc) return rc;
+    if (n_plain > 0)
+        HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, m->fit_smem, b->stream));
     for (int it = n_plain; it < n_iters; ++it) {
-        int rc = launch_state_and_mesh(b, hd);
+        rc = dense_pass(b, h, hd, it > thr, 5.0f);                                     // smplify.py:210
         if (rc) return rc;
-        if (masks) {
-            HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
-            rc = launch_mask_kernels(b, 5.0f);                                           // smplify.py:210
-            if (rc) return rc;
-        }
-        if (scans) {
-            hipLaunchKernelGGL(bf_nearest_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
-                               (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr);
-            hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
-                               (const float *)b->cpts.p, nv, b->pc_partial.p);
-            hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
-                               (const float *)b->cpts.p, nv, (const float *)b->pc_partial.p, (const float *)b->pc_weight.p,
-                               b->dvout.p, b->pc_loss.p, masks ? 1 : 0);
-        }
-        hipLaunchKernelGGL(bf_mesh_bwd_kernel, dim3(m->mesh.n_tiles, F), dim3(512), bwd_smem, b->stream, m->mesh,
-                           (const float *)m->posedirsT.p, (const float *)b->state.p, (const float *)b->dvout.p,
-                           (const float *)b->vposed.p, (const float *)b->vraw.p, b->ext_part.p);
-        hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 255) / 256, F), dim3(256), 0, b->stream,
-                           (const float *)b->ext_part.p, m->mesh.n_tiles, EXT, b->ext.p);
-        HIP_TRY(hipGetLastError());
         FrameIO io2 = io;
         io2.ext = b->ext.p;
         HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
     }
+    return BF_OK;
+}
+
+// bf_loss_grad for models whose keypoint loss is dense (SMPL-X): one evaluation, no update
+int bf_dense_loss_grad(bf_batch *b, const bf_hyper &h, const HyperDev &hd, FrameIO io) {
+    int rc = bf_ensure_dense_buffers(b);
+    if (rc) return rc;
+    rc = dense_pass(b, h, hd, false, 5.0f);
+    if (rc) return rc;
+    io.ext = b->ext.p;
+    HIP_TRY(bf_fit_launch(&b->m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, b->m->fit_smem, b->stream));
+    return BF_OK;
+}
+
+// generic forward from packed parameters (bf_model_forward)
+int bf_model_forward(bf_model *m, int n, const float *params, float *vertices, float *joints) {
+    if (!m || n <= 0 || !params) return fail(BF_ERR_INVALID, "bf_model_forward: bad argument");
+    HIP_TRY(hipSetDevice(m->device));
+    DevBuf<float> d_p, d_state, d_vraw, d_j, d_xp;
+    HIP_TRY(d_p.upload(std::vector<float>(params, params + (size_t)n * m->np)));
+    HIP_TRY(d_state.alloc((size_t)n * bf_state_stride(m->nj, m->npf, m->nb)));
+    HIP_TRY(d_vraw.alloc((size_t)n * m->nv * 3));
+    HIP_TRY(d_j.alloc((size_t)n * m->n_joint_map * 3));
+    HIP_TRY(d_xp.alloc((size_t)n * m->mesh.n_tiles * std::max(m->n_extra, 1) * 3));
+    std::vector<float> zero((size_t)n * m->np, 0.f);
+    // model space: similarity parameters are ignored (transl 0, scale 1, constant scale 1)
+    std::vector<float> pk(params, params + (size_t)n * m->np);
+    for (int i = 0; i < n; ++i) { float *q = pk.data() + (size_t)i * m->np; q[0] = q[1] = q[2] = 0.f; q[3] = 1.f; }
+    HIP_TRY(hipMemcpy(d_p.p, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(bf_pose_state_kernel, dim3(n), dim3(128), 0, 0, m->fit, (const float *)nullptr, (const float *)nullptr,
+                       (const float *)nullptr, (const float *)nullptr, d_state.p, (const float *)d_p.p, (const float *)nullptr, 1.0f);
+    HIP_TRY(hipGetLastError());
+    int rc = bf_launch_mesh(m, n, d_state.p, d_vraw.p, nullptr, d_xp.p, d_j.p, nullptr, 0, nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    if (vertices) HIP_TRY(hipMemcpy(vertices, d_vraw.p, d_vraw.n * sizeof(float), hipMemcpyDeviceToHost));
+    if (joints) HIP_TRY(hipMemcpy(joints, d_j.p, d_j.n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
 }
 
@@ -290,7 +359,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     K.view_index = b->mk_view.p; K.masks = b->mk_masks.p; K.contour_start = b->mk_cstart.p;
     K.contour_count = b->mk_ccount.p; K.contour_xy = b->mk_cxy.p;
     b->has_masks = true;
-    return ensure_dense_buffers(b);
+    return bf_ensure_dense_buffers(b);
 }
 
 // multview_mask_loss (loss.py:85-130) at the current parameters: loss[F] (unweighted, as the function

@@ -270,11 +270,107 @@ extern "C" size_t bf_mesh_bwd_smem_bytes(int nj) {
 
 // grid (ceil(EXT/256), F): ext[f][i] = sum over tiles (in tile order) of part[f][tile][i]
 extern "C" __global__ void __launch_bounds__(256)
-bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float *__restrict__ ext) {
+bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float *__restrict__ ext, int ext_stride) {
     const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
     if (i >= EXT) return;
     const float *p = part + (size_t)f * n_tiles * EXT + i;
     float acc = 0.f;
     for (int t = 0; t < n_tiles; ++t) acc += p[(size_t)t * EXT];
-    ext[(size_t)f * EXT + i] = acc;
+    ext[(size_t)f * ext_stride + i] = acc;
+}
+
+
+// Dense keypoint loss (more than 32 loss joints, i.e. SMPL-X with hands + face): multiview_keypoint_loss
+// (smplify/loss.py:139-203) over nl joints x V views from the all-joints array of bf_joints_kernel, and the
+// routing of its gradient: chain joints -> ext's dGt / dt / ds blocks, vertex-based joints (selector vertices,
+// barycentric face landmarks) -> dL/dvout, added in joint order by one workgroup per frame (deterministic).
+// grid (F), 512 threads.
+extern "C" __global__ void __launch_bounds__(512)
+bf_kp_loss_kernel(KpIO Q, const float *__restrict__ jraw, const float *__restrict__ state, const float *__restrict__ proj_all,
+                  const float *__restrict__ keypoints, const int *__restrict__ ndiv, const int *__restrict__ lmk_vid,
+                  const float *__restrict__ lmk_w, float *__restrict__ ext, float *__restrict__ dvout, float *__restrict__ terms) {
+    extern __shared__ __align__(16) float sm[];
+    const int tid = threadIdx.x, f = blockIdx.x, nl = Q.nl, V = Q.n_views;
+    const int NLP = (nl + 31) & ~31, slots = max(1, 512 / NLP);
+    float *s_part = sm;                       // [slots][NLP][4]
+    float *s_g = s_part + slots * NLP * 4;    // [nl][4]  dL/dXw and the loss share
+    float *s_x = s_g + nl * 4;                // [nl][3]  model-space joint
+    StateView st = bf_state_view(const_cast<float *>(state) + (size_t)f * bf_state_stride(Q.nj, Q.npf, Q.nb), Q.nj, Q.npf, Q.nb);
+    const float t0 = st.t[0], t1 = st.t[1], t2 = st.t[2], cs = st.sc[1], sc = st.sc[0] * cs;
+    const float ndiv_f = (float)ndiv[f], icoeff = 1.0f / Q.coeff, kscale = -1.0f / (Q.coeff * ndiv_f), s2 = Q.sigma2;
+    const int j = tid % NLP, vs = tid / NLP;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, ls = 0.f;
+    if (vs < slots && j < nl) {
+        const float *x = jraw + ((size_t)f * Q.n_all + Q.joint_map[j]) * 3;
+        const float y0 = x[0] + t0, y1 = x[1] + t1, y2 = x[2] + t2;
+        const float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
+        if (vs == 0) { s_x[j * 3] = x[0]; s_x[j * 3 + 1] = x[1]; s_x[j * 3 + 2] = x[2]; }
+        for (int v = vs; v < V; v += slots) {
+            const float *P = proj_all + ((size_t)f * V + v) * 12;
+            const float *kp = keypoints + (((size_t)f * V + v) * nl + j) * 3;
+            float c2 = kp[2] * kp[2];
+            float p0 = P[0] * x0 + P[1] * x1 + P[2] * x2 + P[3];
+            float p1 = P[4] * x0 + P[5] * x1 + P[6] * x2 + P[7];
+            float p2 = P[8] * x0 + P[9] * x1 + P[10] * x2 + P[11];
+            float ip2 = 1.0f / p2, u = p0 * ip2, w = p1 * ip2;
+            float rx = (kp[0] - u) * icoeff, ry = (kp[1] - w) * icoeff;
+            float ix = 1.0f / (s2 + rx * rx), iy = 1.0f / (s2 + ry * ry);
+            ls += c2 * (s2 * rx * rx * ix + s2 * ry * ry * iy);
+            float k = c2 * kscale;
+            float du = k * (2.f * s2 * s2 * rx * ix * ix), dw = k * (2.f * s2 * s2 * ry * iy * iy);
+            float q0 = du * ip2, q1 = dw * ip2, q2 = -(du * u + dw * w) * ip2;
+            g0 += P[0] * q0 + P[4] * q1 + P[8] * q2;
+            g1 += P[1] * q0 + P[5] * q1 + P[9] * q2;
+            g2 += P[2] * q0 + P[6] * q1 + P[10] * q2;
+        }
+    }
+    if (vs < slots && j < NLP) { float4 pr = {g0, g1, g2, ls}; ((float4 *)s_part)[vs * NLP + j] = pr; }
+    __syncthreads();
+    if (tid < nl) {
+        float4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < slots; ++q) { float4 p = ((float4 *)s_part)[q * NLP + tid]; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+        ((float4 *)s_g)[tid] = a;
+    }
+    __syncthreads();
+    const int EXT_T = Q.npf + Q.nj * 12 + Q.nb, EXT_G = EXT_T + 4, EXT_K = EXT_G + Q.nj * 3, EXT = EXT_K + 4;
+    float *e = ext + (size_t)f * EXT;
+    // chain joints: pull the loss joints that map to each (CSR), in loss-joint order
+    for (int i = tid; i < Q.nj * 3; i += 512) {
+        int cj = i / 3, k = i - cj * 3;
+        float acc = 0.f;
+        for (int q = Q.cj_start[cj]; q < Q.cj_start[cj + 1]; ++q) acc += s_g[Q.cj_list[q] * 4 + k];
+        e[EXT_G + i] = acc * sc;
+    }
+    if (tid < 4) {
+        // d/dt, d/ds through the chain-joint-based loss joints only (the vertex-based ones go through dvout)
+        float acc = 0.f;
+        for (int q = 0; q < nl; ++q) {
+            if (Q.joint_map[q] >= Q.nj) continue;
+            if (tid < 3) acc += s_g[q * 4 + tid];
+            else acc += s_g[q * 4] * (s_x[q * 3] + t0) + s_g[q * 4 + 1] * (s_x[q * 3 + 1] + t1) + s_g[q * 4 + 2] * (s_x[q * 3 + 2] + t2);
+        }
+        e[EXT_K + tid] = tid < 3 ? acc * sc : acc * cs;
+    }
+    if (tid == 4) {
+        float acc = 0.f;
+        for (int q = 0; q < nl; ++q) acc += s_g[q * 4 + 3];
+        terms[(size_t)f * 4] = acc / ndiv_f;
+    }
+    // vertex-based joints, one after the other (their vertices may coincide): 9 threads = (corner, xyz)
+    float *dv = dvout + (size_t)f * Q.nv * 3;
+    const int n_ori = Q.nj + Q.n_selector;
+    for (int q = 0; q < nl; ++q) {
+        const int src = Q.joint_map[q];
+        if (src < Q.nj) continue;
+        if (tid < 9) {
+            int c = tid / 3, k = tid - c * 3;
+            if (src < n_ori) { if (c == 0) dv[(size_t)Q.selector_ids[src - Q.nj] * 3 + k] += s_g[q * 4 + k]; }
+            else {
+                int l = src - n_ori - Q.n_extra;
+                int vid = lmk_vid[((size_t)f * Q.n_lmk + l) * 3 + c];
+                dv[(size_t)vid * 3 + k] += lmk_w[((size_t)f * Q.n_lmk + l) * 3 + c] * s_g[q * 4 + k];
+            }
+        }
+        __syncthreads();
+    }
 }

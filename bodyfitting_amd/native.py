@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .synthetic import gmm_buffers
+from .synthetic import gmm_buffers, pack_keypoints_smplx
 
 N_LOSS_JOINTS = 25   # SKELETON_LENGTH, reference smplify/loss.py:17
 
@@ -34,8 +34,12 @@ class DeviceModel:
         self._lib = lib
         self.model_type = model.get("model_type", "smpl")
         means, prec, nllw = gmm_buffers(gmm) if isinstance(gmm, dict) else gmm
+        smplx = self.model_type == "smplx"
+        n_betas = 10 if smplx else np.asarray(model["shapedirs"]).shape[2]     # expression dirs stay unused (never optimised)
+        if "J_regressor_extra" not in model:
+            model = dict(model, J_regressor_extra=np.zeros((0, np.asarray(model["v_template"]).shape[0]), np.float32))
         keep = {
-            "v_template": _f32(model["v_template"]), "shapedirs": _f32(model["shapedirs"]),
+            "v_template": _f32(model["v_template"]), "shapedirs": _f32(np.asarray(model["shapedirs"])[:, :, :n_betas]),
             "posedirs": _f32(model["posedirs"]), "j_regressor": _f32(model["J_regressor"]),
             "lbs_weights": _f32(model["lbs_weights"]), "parents": _i32(model["parents"]),
             "selector_ids": _i32(model["selector_ids"]),
@@ -57,7 +61,19 @@ class DeviceModel:
         for name in ("parents", "selector_ids", "joint_map"):
             setattr(d, name, _lib.iptr(keep[name]))
         d.n_selector, d.n_extra = self.n_selector, keep["j_regressor_extra"].shape[0]
-        d.n_joint_map, d.n_loss_joints = self.n_joint_map, N_LOSS_JOINTS
+        self.n_loss_joints = 135 if smplx else N_LOSS_JOINTS               # loss.py:17-19: 25 (+ 42 hands + 68 face)
+        d.n_joint_map, d.n_loss_joints = self.n_joint_map, self.n_loss_joints
+        if smplx:
+            keep.update(pose_mean=_f32(model["pose_mean"]), lhc=_f32(model["left_hand_components"]),
+                        rhc=_f32(model["right_hand_components"]), lmk_f=_i32(model["lmk_faces_idx"]),
+                        lmk_b=_f32(model["lmk_bary_coords"]), dyn_f=_i32(model["dynamic_lmk_faces_idx"]),
+                        dyn_b=_f32(model["dynamic_lmk_bary_coords"]))
+            d.model_kind, d.pose_mean, d.n_hand_pca = 1, _lib.fptr(keep["pose_mean"]), keep["lhc"].shape[0]
+            d.left_hand_components, d.right_hand_components = _lib.fptr(keep["lhc"]), _lib.fptr(keep["rhc"])
+            d.n_lmk_static, d.lmk_faces_idx, d.lmk_bary_coords = len(keep["lmk_f"]), _lib.iptr(keep["lmk_f"]), _lib.fptr(keep["lmk_b"])
+            d.n_dyn_rows, d.n_lmk_dynamic = keep["dyn_f"].shape
+            d.dynamic_lmk_faces_idx, d.dynamic_lmk_bary_coords = _lib.iptr(keep["dyn_f"]), _lib.fptr(keep["dyn_b"])
+            d.neck_joint = int(np.asarray(model["neck_kin_chain"])[0])
         d.gmm_components, d.gmm_dim = keep["gmm_means"].shape
         if self.faces is not None:
             keep["faces"] = _i32(self.faces.reshape(-1, 3))
@@ -90,6 +106,14 @@ class DeviceModel:
         _lib.check(self._lib.bf_smpl_forward(self._h, n, _lib.fptr(betas), _lib.fptr(orient), _lib.fptr(pose),
                                              _lib.fptr(verts), _lib.fptr(joints), _lib.fptr(jori)), "bf_smpl_forward")
         return verts, joints, jori
+
+    def forward_packed(self, params):
+        """vertices / joints (model space) of packed parameter vectors [n, n_params] - any model kind"""
+        p = _f32(params, (-1, self.n_params))
+        verts = np.empty((len(p), self.n_verts, 3), np.float32)
+        joints = np.empty((len(p), self.n_joint_map, 3), np.float32)
+        _lib.check(self._lib.bf_model_forward(self._h, len(p), _lib.fptr(p), _lib.fptr(verts), _lib.fptr(joints)), "bf_model_forward")
+        return verts, joints
 
 
 class Scan:
@@ -171,13 +195,13 @@ class FrameBatch:
         _lib.check(self._lib.bf_batch_set_cameras(self._h, _lib.fptr(c2w), _lib.fptr(K)), "bf_batch_set_cameras")
 
     def set_keypoints(self, keypoints, n_use_frames=None):
-        kp = _f32(keypoints, (self.F, self.V, N_LOSS_JOINTS, 3))
+        kp = _f32(keypoints, (self.F, self.V, self.model.n_loss_joints, 3))
         nd = None if n_use_frames is None else _i32(np.broadcast_to(np.asarray(n_use_frames), (self.F,)))
         _lib.check(self._lib.bf_batch_set_keypoints(self._h, _lib.fptr(kp), _lib.iptr(nd)), "bf_batch_set_keypoints")
 
     def set_init(self, init_betas, init_pose):
         b = _f32(init_betas, (self.F, self.model.n_betas))
-        p = _f32(init_pose, (self.F, 3 * self.model.n_joints))
+        p = _f32(np.asarray(init_pose).reshape(self.F, -1)[:, :72], (self.F, 72))
         _lib.check(self._lib.bf_batch_set_init(self._h, _lib.fptr(b), _lib.fptr(p)), "bf_batch_set_init")
 
     def set_scans(self, scans):
@@ -283,17 +307,28 @@ class FrameBatch:
         return out
 
 
+SMPLX_EXTRA = (("leye_pose", 3), ("reye_pose", 3), ("left_hand_pose", 6), ("right_hand_pose", 6))
+
+
 def split_params(packed, n_joints=24, n_betas=10):
-    """packed[...,86] in optimiser order (reference smplify.py:167-171) -> dict of named blocks."""
+    """packed[...,86] (SMPL) or [...,98] (SMPL-X) in optimiser order (reference smplify.py:167-173) -> named blocks."""
     p = np.asarray(packed)
-    nbp = 3 * (n_joints - 1)
-    return {"global_transl": p[..., 0:3], "scale": p[..., 3:4], "pose": p[..., 4:4 + nbp],
-            "betas": p[..., 4 + nbp:4 + nbp + n_betas], "global_orient": p[..., 4 + nbp + n_betas:4 + nbp + n_betas + 3]}
+    smplx = p.shape[-1] == 98
+    nbp = 63 if smplx else 3 * (n_joints - 1)
+    o = 4 + nbp + n_betas
+    out = {"global_transl": p[..., 0:3], "scale": p[..., 3:4], "pose": p[..., 4:4 + nbp],
+           "betas": p[..., 4 + nbp:o], "global_orient": p[..., o:o + 3]}
+    if smplx:
+        o += 3
+        for name, n in SMPLX_EXTRA:
+            out[name] = p[..., o:o + n]
+            o += n
+    return out
 
 
 def pack_params(d):
-    return np.concatenate([np.asarray(d[k], dtype=np.float32).reshape(-1) for k in
-                           ("global_transl", "scale", "pose", "betas", "global_orient")]).astype(np.float32)
+    names = ("global_transl", "scale", "pose", "betas", "global_orient") + tuple(n for n, _ in SMPLX_EXTRA if n in d)
+    return np.concatenate([np.asarray(d[k], dtype=np.float32).reshape(-1) for k in names]).astype(np.float32)
 
 
 def pack_problem(problems):
@@ -301,11 +336,12 @@ def pack_problem(problems):
     F, V = len(problems), len(problems[0]["c2ws"])
     c2w = np.stack([np.stack(p["c2ws"]) for p in problems]).astype(np.float32)
     K = np.stack([np.stack(p["Ks"]) for p in problems]).astype(np.float32)
-    kp = np.zeros((F, V, N_LOSS_JOINTS, 3), np.float32)
+    smplx = any(k is not None and "face" in k for k in problems[0]["keypoints"])
+    kp = np.zeros((F, V, 135 if smplx else N_LOSS_JOINTS, 3), np.float32)
     for f, p in enumerate(problems):
         for v, k in enumerate(p["keypoints"]):
             if k is not None:                      # None view: confidence 0 everywhere (loss.py:157)
-                kp[f, v] = k["pose"]
+                kp[f, v] = pack_keypoints_smplx(k) if smplx else k["pose"]
     ndiv = np.array([len(p["use_frames"]) for p in problems], np.int32)
     betas = np.concatenate([p["init_betas"] for p in problems]).astype(np.float32)
     pose = np.concatenate([p["init_pose"] for p in problems]).astype(np.float32)

@@ -7,7 +7,7 @@ global_transl[3] (= t*s, without the constant scale), scale[1], full_pose[72].
 Differences, all at the edges: the model / GMM are resolved once per process through
 `bodyfitting_amd.assets` instead of being re-read per frame; `net_output` may hold numpy arrays or
 anything with `.detach().cpu().numpy()`; `device` is a HIP device index (or a torch.device whose
-index is used).  smpl_type='smplx' is not built yet and raises NotImplementedError - there is no silent CPU path.
+index is used).  smpl_type='smplx' adds hands + face keypoints (135 joints) and the 98-scalar parameter vector - there is no silent CPU path.
 """
 from __future__ import annotations
 
@@ -16,7 +16,8 @@ import numpy as np
 from . import assets
 from .contours import extract_contours
 from .io import load_obj_mesh
-from .native import FrameBatch, Scan, make_hyper, split_params, N_LOSS_JOINTS
+from .native import FrameBatch, Scan, make_hyper, split_params
+from .synthetic import pack_keypoints_smplx
 
 
 def _np(x):
@@ -39,19 +40,19 @@ class SMPLify:
 
     def __init__(self, smpl_type="smpl", age="adult", step_size=1e-2, batch_size=1, num_iters=600, gender="male",
                  use_mask=False, device=0, debug=True):
-        if smpl_type != "smpl":
-            raise NotImplementedError("smpl_type='smplx' is not built yet (DESIGN.md section 7)")
+        if smpl_type not in ("smpl", "smplx"):
+            raise ValueError(f"unknown smpl_type {smpl_type!r}")
         if age != "adult":
             raise NotImplementedError("age='kid' is out of scope (SURVEY.md 8c)")
         self.smpl_type, self.age, self.gender = smpl_type, age, gender
-        self.use_hand_face = False
+        self.use_hand_face = smpl_type == "smplx"
         self.use_mask = use_mask
         self.batch_size = batch_size
         self.num_iters = num_iters          # step_size is ignored by the reference too (smplify.py:24,174)
         self.debug = debug
         self.device = _device_index(device)
-        self._dev = assets.get_device_model("smpl", gender, self.device)
-        model = assets.get_model("smpl", gender)
+        self._dev = assets.get_device_model(smpl_type, gender, self.device)
+        model = assets.get_model(smpl_type, gender)
         self.smpl_faces = np.asarray(model["faces"]).astype(np.int32).reshape(1, -1, 3)    # smplify.py:82
 
     # ------------------------------------------------------------------------------------------
@@ -103,6 +104,7 @@ class SMPLify:
                 "global_orient": p["global_orient"].copy(), "faces": self.smpl_faces[0],
                 "global_transl": p["global_transl"] * p["scale"],                      # smplify.py:223
                 "scale": p["scale"].copy(), "full_pose": full_pose[f],
+                **({k: p[k].copy() for k in ("leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose")} if "leye_pose" in p else {}),
                 "loss_terms": dict(zip(("reprojection_loss", "pose_prior_loss", "angle_prior_loss", "shape_prior_loss"),
                                        (float(t) for t in terms[f]))),
             })
@@ -125,10 +127,11 @@ class SMPLify:
         V = len(use_frames)
         c2w = np.stack([_np(c) for c in c2ws[:V]]).astype(np.float32)
         K = np.stack([_np(k) for k in Ks[:V]]).astype(np.float32)
-        kp = np.zeros((V, N_LOSS_JOINTS, 3), np.float32)
+        nl = self._dev.n_loss_joints
+        kp = np.zeros((V, nl, 3), np.float32)
         for i in range(V):
             if keypoints[i] is not None:                                               # loss.py:157
-                kp[i] = np.asarray(keypoints[i]["pose"], np.float32)[:N_LOSS_JOINTS]
+                kp[i] = pack_keypoints_smplx(keypoints[i]) if self.use_hand_face else np.asarray(keypoints[i]["pose"], np.float32)[:nl]
         res = self.fit_frames(init_betas[:1], init_poses[:1], c2w[None], K[None], kp[None], n_use_frames=[V],
                               imsize=imsize, scans=scans, displacement=displacement, masks=mk,
                               mask_view_index=mk_idx)[0]                               # divisor loss.py:197

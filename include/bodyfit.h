@@ -63,6 +63,23 @@ typedef struct bf_model_desc {
     const float *gmm_nll_weights;  /* [M] (prior.py:153-160) */
     int32_t n_faces;               /* body-model topology, only needed by the SMPL+D stage; may be 0 */
     const int32_t *faces;          /* [n_faces,3] */
+    /* ---- SMPL-X (smplx.create(model_type='smplx', use_face_contour=True, use_pca with 6 comps), smplify.py:59-80).
+     * model_kind 0 = SMPL (everything below ignored), 1 = SMPL-X: joints 0 root, 1..21 body, 22 jaw, 23/24 eyes,
+     * 25..39 / 40..54 left / right hand; n_betas = 10 (expression stays 0, smplify.py:167-173); the optimised
+     * vector is transl3 scale1 body_pose63 betas10 global_orient3 leye3 reye3 left_hand_pca6 right_hand_pca6 (98). */
+    int32_t model_kind;
+    const float *pose_mean;                 /* [3 NJ], added to the assembled full pose */
+    int32_t n_hand_pca;                     /* 6 */
+    const float *left_hand_components;      /* [n_hand_pca,45] */
+    const float *right_hand_components;     /* [n_hand_pca,45] */
+    int32_t n_lmk_static;                   /* 51 */
+    const int32_t *lmk_faces_idx;           /* [n_lmk_static] face ids */
+    const float *lmk_bary_coords;           /* [n_lmk_static,3] */
+    int32_t n_lmk_dynamic;                  /* 17 */
+    int32_t n_dyn_rows;                     /* 79 */
+    const int32_t *dynamic_lmk_faces_idx;   /* [n_dyn_rows,n_lmk_dynamic] */
+    const float *dynamic_lmk_bary_coords;   /* [n_dyn_rows,n_lmk_dynamic,3] */
+    int32_t neck_joint;                     /* 12: its global rotation's yaw picks the contour row */
 } bf_model_desc;
 
 /* Loss weights and optimiser constants; bf_hyper_default() fills the reference's literals. */
@@ -110,6 +127,10 @@ int bf_model_n_params(const bf_model *m);
 int bf_smpl_forward(bf_model *m, int n, const float *betas, const float *global_orient,
                     const float *body_pose, float *vertices, float *joints, float *joints_ori);
 
+/* The model's forward for `n` packed parameter vectors params[n,n_params] (any model kind): vertices[n,NV,3] in
+ * model space and joints[n,n_joint_map,3], both before the similarity (either may be NULL). */
+int bf_model_forward(bf_model *m, int n, const float *params, float *vertices, float *joints);
+
 /* One batch = F frames that SMPLify.__call__ (smplify.py:84-250) would process one after another
  * (apps/genebody_fitting.py:183-192), each with V calibrated views. */
 int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out);
@@ -122,7 +143,8 @@ int bf_batch_set_cameras(bf_batch *b, const float *c2w, const float *K);
  * without a detection (None, loss.py:157) is passed with all confidences 0.  n_use_frames[F] is the
  * divisor len(use_frames) of loss.py:197 (NULL -> V). */
 int bf_batch_set_keypoints(bf_batch *b, const float *keypoints, const int32_t *n_use_frames);
-/* init_betas[F,NB], init_pose[F,3NJ] = net_output of smplify.py:103; transl=0, scale=1 (:126-128) */
+/* init_betas[F,NB], init_pose[F,72] = net_output of smplify.py:103 (SMPL-X takes [:, 3:66] as body pose,
+ * :110-112; eyes / hand PCA start at 0, :118-122); transl=0, scale=1 (:126-128) */
 int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_pose);
 /* Re-arm the batch for another fit of the same inputs without touching the host: restores the
  * parameters of the last bf_batch_set_init / bf_batch_set_params and clears the Adam state, as

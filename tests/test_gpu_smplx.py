@@ -1,0 +1,101 @@
+"""HIP SMPL-X path (smpl_type='smplx': 55 joints, hand PCA, 135 joints with face landmarks) through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from bodyfitting_amd import native as N
+from bodyfitting_amd import synthetic as S
+from oracle import smplify_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sx():
+    model = S.make_model("smplx", seed=0)
+    dev = N.DeviceModel(model, S.make_gmm(seed=0), device=0)
+    yield model, dev
+    dev.close()
+
+
+def _params(prob, rng=None):
+    p = {"global_transl": np.array([0.01, -0.02, 0.015]), "scale": np.array([1.05]), "pose": prob["init_pose"][0, 3:66],
+         "betas": np.linspace(-0.4, 0.4, 10), "global_orient": prob["init_pose"][0, :3], "leye_pose": np.array([0.02, -0.01, 0.03]),
+         "reye_pose": np.array([-0.02, 0.01, 0.0]), "left_hand_pose": np.linspace(-0.3, 0.3, 6), "right_hand_pose": np.linspace(0.2, -0.2, 6)}
+    return {k: np.asarray(v, np.float64) for k, v in p.items()}
+
+
+def _batch(dev, prob):
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
+    assert kp.shape[2] == 135
+    b = N.FrameBatch(dev, 1, c2w.shape[1])
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+    return b
+
+
+def test_forward_vertices_and_135_joints(sx):
+    model, dev = sx
+    assert dev.n_params == 98 and dev.n_loss_joints == 135
+    prob = S.make_problem_smplx(model, 0, 4)
+    P = _params(prob)
+    verts, joints = dev.forward_packed(N.pack_params(P)[None])
+    m = O.to_torch_model(model, torch.float64)
+    t = lambda k: torch.tensor(P[k][None], dtype=torch.float64)          # noqa: E731
+    ref = O.smplx_forward(m, t("betas"), t("global_orient"), t("pose"), t("leye_pose"), t("reye_pose"), t("left_hand_pose"), t("right_hand_pose"))
+    np.testing.assert_allclose(verts[0], ref["vertices"][0].numpy(), atol=3e-6)
+    np.testing.assert_allclose(joints[0], ref["joints"][0].numpy(), atol=3e-6)      # incl. 51 static + 17 contour landmarks
+
+
+def test_loss_and_gradient_match_autograd(sx, gmm_bufs):
+    model, dev = sx
+    prob = S.make_problem_smplx(model, 0, 8)
+    P = _params(prob)
+    b = _batch(dev, prob)
+    b.set_params(N.pack_params(P)[None])
+    terms, grads = b.loss_grad()
+    loss, t64, g64, _, _, _ = O.smplx_loss_and_grad(model, gmm_bufs, prob, P)
+    for i, n in enumerate(("reprojection_loss", "pose_prior_loss", "angle_prior_loss", "shape_prior_loss")):
+        assert terms[0, i] == pytest.approx(t64[n], rel=3e-6), n
+    got = N.split_params(grads[0])
+    for k in O.SMPLX_PARAMS:
+        np.testing.assert_allclose(got[k], g64[k], atol=1e-5 * np.abs(g64[k]).max(), err_msg=k)
+    b.close()
+
+
+def test_fit_matches_reference_golden(sx):
+    """the reference loop for smplx (hands + face keypoints, the unsqueezed-confidence quirk included): 40 iterations"""
+    model, dev = sx
+    g = load_golden("smplx_8view_40it.npz")
+    prob = S.make_problem_smplx(model, frame=0, n_views=8)
+    b = _batch(dev, prob)
+    done = 0
+    for k in (1, 2, 10, 40):
+        b.fit(k - done)
+        done = k
+        got = N.split_params(b.get_params()[0])
+        for n in O.SMPLX_PARAMS:
+            np.testing.assert_allclose(got[n], g[f"it{k}_{n}"], rtol=0, atol=1e-4, err_msg=f"it{k} {n}")
+    verts, joints, full_pose, _ = b.get_result()
+    np.testing.assert_allclose(joints[0], g["joints"], atol=1e-4)
+    np.testing.assert_allclose(verts[0][::53], g["vertices_sample"], atol=1e-4)
+    np.testing.assert_allclose(full_pose[0], g["full_pose"], atol=1e-4)
+    b.close()
+
+
+def test_smplx_with_masks_runs_and_improves(sx):
+    """BASELINE config 3 shape: SMPL-X + silhouette loss (ill-conditioned loop: progress, not trajectory, is asserted)"""
+    from bodyfitting_amd.contours import extract_contours
+    model, dev = sx
+    prob = S.make_problem_smplx(model, frame=0, n_views=8, mask_frames=[1, 3, 5, 7])
+    b = _batch(dev, prob)
+    b.set_masks(np.array(prob["masks"])[None], [1, 3, 5, 7], [extract_contours(np.array(prob["masks"]) > 128)])
+    l0 = b.mask_loss()[0][0]
+    b.fit(15)
+    assert np.isfinite(b.get_params()).all()
+    assert b.mask_loss()[0][0] < l0
+    g = load_golden("smplx_mask_8view_15it.npz")
+    got = N.split_params(b.get_params()[0])
+    for n in O.SMPLX_PARAMS:
+        assert np.abs(got[n] - g[f"it15_{n}"]).max() < 0.1, n
+    b.close()
