@@ -119,10 +119,10 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     m->ns = ns;
 
     // ---- pre-contracted joint regressor (float64 accumulate, rounded once) --------------------
-    std::vector<float> Jt(nj * 3), Jd((size_t)nj * 3 * nb), Jdrel((size_t)nj * 3 * nb);
+    std::vector<float> Jt(nj * 3), Jd((size_t)nj * 3 * nb), Jdrel((size_t)nj * 3 * nb), Jtrel(nj * 3);
     {
         std::vector<double> acc((size_t)3 + 3 * nb);
-        std::vector<double> Jd64((size_t)nj * 3 * nb);
+        std::vector<double> Jd64((size_t)nj * 3 * nb), Jt64((size_t)nj * 3);
         for (int j = 0; j < nj; ++j) {
             std::fill(acc.begin(), acc.end(), 0.0);
             const float *row = d->j_regressor + (size_t)j * nv;
@@ -137,12 +137,15 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
             }
             for (int k = 0; k < 3; ++k) {
                 Jt[j * 3 + k] = (float)acc[k];
+                Jt64[j * 3 + k] = acc[k];
                 for (int l = 0; l < nb; ++l) {
                     Jd64[((size_t)j * 3 + k) * nb + l] = acc[3 + k * nb + l];
                     Jd[((size_t)j * 3 + k) * nb + l] = (float)acc[3 + k * nb + l];
                 }
             }
         }
+        for (int j = 0; j < nj; ++j)
+            for (int k = 0; k < 3; ++k) Jtrel[j * 3 + k] = (float)(Jt64[j * 3 + k] - (j > 0 ? Jt64[parents[j] * 3 + k] : 0.0));
         for (int j = 0; j < nj; ++j)
             for (int e = 0; e < 3 * nb; ++e) {
                 double v = Jd64[(size_t)j * 3 * nb + e];
@@ -230,7 +233,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     up_vi(m->parents, parents); up_vi(m->level_start, level_start); up_vi(m->level_joints, level_joints);
     up_vi(m->child_start, child_start); up_vi(m->child_list, child_list);
     up_vi(m->lj_kind, lj_kind); up_vi(m->lj_index, lj_index);
-    up_vf(m->Jt, Jt); up_vf(m->Jd, Jd); up_vf(m->Jdrel, Jdrel);
+    up_vf(m->Jt, Jt); up_vf(m->Jd, Jd); up_vf(m->Jdrel, Jdrel); up_vf(m->Jtrel, Jtrel);
     up_vf(m->sel_vt, sel_vt); up_vf(m->sel_sd, sel_sd); up_vf(m->sel_pd, sel_pd); up_vf(m->sel_w, sel_w);
     up_vf(m->g_means, means); up_vf(m->g_psym, psym); up_vf(m->g_logw, logw);
     if (!okay) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation / upload failed"); }
@@ -281,7 +284,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     T.parents = m->parents.p; T.level_start = m->level_start.p; T.level_joints = m->level_joints.p;
     T.child_start = m->child_start.p; T.child_list = m->child_list.p;
     T.lj_kind = m->lj_kind.p; T.lj_index = m->lj_index.p;
-    T.Jt = m->Jt.p; T.Jd = m->Jd.p; T.Jdrel = m->Jdrel.p;
+    T.Jt = m->Jt.p; T.Jd = m->Jd.p; T.Jdrel = m->Jdrel.p; T.Jtrel = m->Jtrel.p;
     T.sel_vt = m->sel_vt.p; T.sel_sd = m->sel_sd.p; T.sel_pd = m->sel_pd.p; T.sel_w = m->sel_w.p;
     T.g_means = m->g_means.p; T.g_psym = m->g_psym.p; T.g_logw = m->g_logw.p;
     MeshTab &Q = m->mesh;

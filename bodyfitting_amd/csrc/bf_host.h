@@ -51,6 +51,7 @@ struct bf_model {
     DevBuf<unsigned long long> desc_d;
     DevBuf<float> g_plane, g_ptail;
     DevBuf<int> parents, level_start, level_joints, child_start, child_list, lj_kind, lj_index;
+    DevBuf<float> Jtrel;
     DevBuf<float> Jt, Jd, Jdrel, sel_vt, sel_sd, sel_pd, sel_w, g_means, g_psym, g_logw;
     // SMPL-X pose assembly / parameter routing / landmarks / dense keypoint loss
     int kind = 0, kp_dense = 0, n_lmk = 0, n_all = 0, nl_loss = 0;

@@ -41,6 +41,7 @@ struct FitTab {
     const float *Jt;                 // [nj*3]        J_regressor v_template
     const float *Jd;                 // [nj*3][nb]    J_regressor shapedirs
     const float *Jdrel;              // [nj*3][nb]    Jd[j] - Jd[parent(j)]   (Jd[0] for the root)
+    const float *Jtrel;              // [nj*3]        Jt[j] - Jt[parent(j)]   (Jt[0] for the root)
     const float *sel_vt;             // [ns*3]
     const float *sel_sd;             // [ns*3][nb]
     const float *sel_pd;             // [npf][ns*3]   posedirs columns of the selector vertices

@@ -44,7 +44,7 @@ namespace {
 struct FitSmem {
     float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
-    float *Jt, *Jd, *Jdrel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp;
+    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp;
     int *nzj, *thk, *tho;
 };
 
@@ -68,6 +68,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.gd = take(BF_GMM_M * BF_GMM_LD); s.gy = take(BF_GMM_M * BF_GMM_LD);
     s.gq = take(BF_GMM_M);             s.gtail = take(256);   s.scal = take(8);
     s.feat = take(npf);                s.vpp = take(BF_FIT_THREADS + ns * 3);
+    s.Jtrel = take(nj * 3); s.Dg = take(nj * 12);
     s.Jt = take(nj * 3);   s.Jd = take(nj * 3 * nb);      s.Jdrel = take(nj * 3 * nb);
     s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * nb); s.sel_pd = take(npf * ns * 3);
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
@@ -79,10 +80,23 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     return o * sizeof(float);
 }
 
+// Cross-lane sums on the VALU's DPP path (a few cycles each) instead of ds_bpermute (an LDS round trip each):
+//   quad_perm [1,0,3,2] / [2,3,0,1]  = xor 1 / xor 2 inside a quad; row_ror 4 / 8 rotate inside a 16-lane row.
+template <int CTRL>
+__device__ inline float dpp_add(float v) {
+    int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
+    return v + __int_as_float(r);
+}
+__device__ inline float quad_sum(float v) { v = dpp_add<0xB1>(v); return dpp_add<0x4E>(v); }        // all 4 lanes of a quad
+__device__ inline float row16_sum(float v) { v = quad_sum(v); v = dpp_add<0x124>(v); return dpp_add<0x128>(v); }   // all 16 lanes of a row
+// every lane gets the wave's total, added as ((row0 + row1) + (row2 + row3)): fixed order
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v = row16_sum(v);
+    float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (a + b) + (c + d);
 }
 
 // smplx batch_rodrigues for one joint
@@ -168,6 +182,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
     // ---- one-off loads --------------------------------------------------------------------
     copy_f(S.Jt, T.Jt, nj3, tid, nt);
+    copy_f(S.Jtrel, T.Jtrel, nj3, tid, nt);
     copy_f(S.Jd, T.Jd, nj3 * nb, tid, nt);
     copy_f(S.Jdrel, T.Jdrel, nj3 * nb, tid, nt);
     copy_f(S.sel_vt, T.sel_vt, ns3, tid, nt);
@@ -197,6 +212,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int wj = cw_on ? lane : 0;
     const int wp = wj > 0 ? T.parents[wj] : 0;
     const int wd = cw_on ? T.depth[wj] : -1;
+    const int w_kind = T.th_kind[wj], w_off = T.th_off[wj];
+    const float w_pm0 = T.pose_mean ? T.pose_mean[wj * 3] : 0.f, w_pm1 = T.pose_mean ? T.pose_mean[wj * 3 + 1] : 0.f,
+                w_pm2 = T.pose_mean ? T.pose_mean[wj * 3 + 2] : 0.f;
     // (joint, row) role of the reverse sweep: tid < 3 nj
     const bool c_on = tid < nj3;
     const int ci = c_on ? tid / 3 : 0, cr = c_on ? tid - ci * 3 : 0;
@@ -403,27 +421,27 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #endif
         // ================= phase A: forward chain (waves 0-2) | shaped selector verts (wave 3) | GMM (waves 4-7)
         if (wave < 3) {
-            float Ri[9], rc[3], Jj0 = 0.f, Jj1 = 0.f, Jj2 = 0.f, rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
+            float Ri[9], rc[3], rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
             float4 row = {0.f, 0.f, 0.f, 0.f};
             if (cw_on) {
-                float th0 = theta_of(Pcur, wj, 0), th1 = theta_of(Pcur, wj, 1), th2 = theta_of(Pcur, wj, 2);
+                float th0 = w_pm0, th1 = w_pm1, th2 = w_pm2;
+                if (w_kind == 0) { th0 += Pcur[w_off]; th1 += Pcur[w_off + 1]; th2 += Pcur[w_off + 2]; }
+                else if (w_kind >= 2) { th0 = theta_of(Pcur, wj, 0); th1 = theta_of(Pcur, wj, 1); th2 = theta_of(Pcur, wj, 2); }
                 rodrigues_fwd(th0, th1, th2, Ri, rc);
                 if (wave == 0) { S.theta[wj * 3] = th0; S.theta[wj * 3 + 1] = th1; S.theta[wj * 3 + 2] = th2; }
+                // rel_j = J_j - J_parent straight from the pre-contracted difference tables (rel_0 = J_0)
                 const float *beta = Pcur + T.off_beta;
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
                 for (int l = 0; l < nb; ++l) {
                     float bl = beta[l];
-                    a0 += S.Jd[(wj * 3 + 0) * nb + l] * bl; a1 += S.Jd[(wj * 3 + 1) * nb + l] * bl; a2 += S.Jd[(wj * 3 + 2) * nb + l] * bl;
-                    b0 += S.Jd[(wp * 3 + 0) * nb + l] * bl; b1 += S.Jd[(wp * 3 + 1) * nb + l] * bl; b2 += S.Jd[(wp * 3 + 2) * nb + l] * bl;
+                    a0 += S.Jdrel[(wj * 3 + 0) * nb + l] * bl; a1 += S.Jdrel[(wj * 3 + 1) * nb + l] * bl; a2 += S.Jdrel[(wj * 3 + 2) * nb + l] * bl;
                 }
-                Jj0 = S.Jt[wj * 3] + a0; Jj1 = S.Jt[wj * 3 + 1] + a1; Jj2 = S.Jt[wj * 3 + 2] + a2;
-                rel0 = Jj0 - (S.Jt[wp * 3] + b0); rel1 = Jj1 - (S.Jt[wp * 3 + 1] + b1); rel2 = Jj2 - (S.Jt[wp * 3 + 2] + b2);
+                rel0 = S.Jtrel[wj * 3] + a0; rel1 = S.Jtrel[wj * 3 + 1] + a1; rel2 = S.Jtrel[wj * 3 + 2] + a2;
                 if (wave == 0) {
 #pragma unroll
                     for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
                     S.rc[wj * 4] = rc[0]; S.rc[wj * 4 + 1] = rc[1]; S.rc[wj * 4 + 2] = rc[2];
-                    S.J[wj * 3] = Jj0; S.J[wj * 3 + 1] = Jj1; S.J[wj * 3 + 2] = Jj2;
                     if (wj > 0) {
                         float *f = S.feat + (wj - 1) * 9;
                         f[0] = Ri[0] - 1.f; f[1] = Ri[1]; f[2] = Ri[2]; f[3] = Ri[3]; f[4] = Ri[4] - 1.f;
@@ -434,7 +452,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     row.x = wave == 0 ? Ri[0] : (wave == 1 ? Ri[3] : Ri[6]);
                     row.y = wave == 0 ? Ri[1] : (wave == 1 ? Ri[4] : Ri[7]);
                     row.z = wave == 0 ? Ri[2] : (wave == 1 ? Ri[5] : Ri[8]);
-                    row.w = wave == 0 ? Jj0 : (wave == 1 ? Jj1 : Jj2);
+                    row.w = wave == 0 ? rel0 : (wave == 1 ? rel1 : rel2);
                     *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
                 }
             }
@@ -449,7 +467,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
                 }
             }
-            if (cw_on) S.At[wj * 3 + wave] = row.w - (row.x * Jj0 + row.y * Jj1 + row.z * Jj2);
         } else {
             const float *beta = Pcur + T.off_beta;
             for (int o = lane; o < ns3; o += 64) {
@@ -458,13 +475,28 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 for (int l = 0; l < nb; ++l) acc += S.sel_sd[o * nb + l] * beta[l];
                 S.vs[o] = S.sel_vt[o] + acc;
             }
-            for (int i = lane; i < nj3; i += 64) S.dGt[i] = 0.f;       // targets of phase E's routing
+            for (int i = lane; i < nj3; i += 64) {                     // rest joints J(beta) for the later phases
+                float acc = 0.f;
+#pragma unroll
+                for (int l = 0; l < nb; ++l) acc += S.Jd[i * nb + l] * beta[l];
+                S.J[i] = S.Jt[i] + acc;
+                S.dGt[i] = 0.f;                                        // target of phase E's routing
+            }
             for (int i = lane; i < ns3; i += 64) S.dvsel[i] = 0.f;
         }
         BF_SYNC();
 
         // ================= phase B: pose blend of the selector vertices, partial sums over row slices
         pose_blend();
+        if (c_on)                                   // A_j translation: Gt_j - GR_j J_j
+            S.At[tid] = GT_(ci, cr) - (GR_(ci, cr, 0) * S.J[ci * 3] + GR_(ci, cr, 1) * S.J[ci * 3 + 1] + GR_(ci, cr, 2) * S.J[ci * 3 + 2]);
+        if (tid == NG - 1) {                        // arg-min GMM component (prior.py:195), ready long before the Adam phase
+            int ms = 0;
+            float qm = S.gq[0];
+#pragma unroll
+            for (int m = 1; m < BF_GMM_M; ++m) { float q = S.gq[m]; if (q < qm) { qm = q; ms = m; } }
+            S.scal[1] = (float)ms; S.scal[2] = qm;
+        }
         BF_SYNC();
 
         // ================= phase C: finish the pose blend; skin the selector vertices.  Lane b of a quad owns
@@ -494,8 +526,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 if (b < 3) S.TR[sv * 9 + k * 3 + b] = t;
             }
             float contrib = ok ? t * vpb : 0.f;
-            contrib += __shfl_xor(contrib, 1);
-            contrib += __shfl_xor(contrib, 2);
+            contrib = quad_sum(contrib);
             if (ok && b == 0) S.vsel[o] = contrib;
         }
         BF_SYNC();
@@ -582,21 +613,35 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (ci > 0) { u0 = GT_(ci, 0) - GT_(cp, 0); u1 = GT_(ci, 1) - GT_(cp, 1); u2 = GT_(ci, 2) - GT_(cp, 2); }
             float4 nrow = {dg0 + ttot * u0, dg1 + ttot * u1, dg2 + ttot * u2, 0.f};
             *(float4 *)(S.N + (ci * 3 + cr) * 4) = nrow;
+            float4 drow = {dg0, dg1, dg2, 0.f};
+            *(float4 *)(S.Dg + (ci * 3 + cr) * 4) = drow;
             S.dJ[tid] = -(GR_(ci, 0, cr) * S.dAt[ci * 3] + GR_(ci, 1, cr) * S.dAt[ci * 3 + 1] + GR_(ci, 2, cr) * S.dAt[ci * 3 + 2]);
         }
         BF_SYNC();
 
-        // ================= phase H: dL/dGR_p (total) = (D_p GR_p^T + sum over strict subtree of N_i) GR_p, row cr
-        if (c_on) {
-#pragma unroll
-            for (int k = 0; k < nj; ++k) {
-                float4 n = *(const float4 *)(S.N + (k * 3 + cr) * 4);
-                bool in = (cmask >> k) & 1ull;
-                dg0 += in ? n.x : 0.f; dg1 += in ? n.y : 0.f; dg2 += in ? n.z : 0.f;
+        // ================= phase H: dL/dGR_p (total) = (D_p GR_p^T + sum over strict subtree of N_i) GR_p, row r.
+        // Two lanes per (joint, row): each sums half of the joints, combined on the DPP path.
+        for (int base = 0; base < nj3 * 2; base += NG) {
+            int t2 = base + tid, q = t2 >> 1, hf = t2 & 1;
+            bool ok = q < nj3;
+            int p = ok ? q / 3 : 0, r = ok ? q - p * 3 : 0;
+            unsigned long long mk = ok ? T.desc[p] : 0ull;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+            const int k0 = hf ? (nj + 1) / 2 : 0, k1 = hf ? nj : (nj + 1) / 2;
+#pragma unroll 4
+            for (int k = k0; k < k1; ++k) {
+                float4 n = *(const float4 *)(S.N + (k * 3 + r) * 4);
+                bool in = (mk >> k) & 1ull;
+                s0 += in ? n.x : 0.f; s1 += in ? n.y : 0.f; s2 += in ? n.z : 0.f;
             }
-            S.dGR[ci * 9 + cr * 3] = dg0 * GR_(ci, 0, 0) + dg1 * GR_(ci, 1, 0) + dg2 * GR_(ci, 2, 0);
-            S.dGR[ci * 9 + cr * 3 + 1] = dg0 * GR_(ci, 0, 1) + dg1 * GR_(ci, 1, 1) + dg2 * GR_(ci, 2, 1);
-            S.dGR[ci * 9 + cr * 3 + 2] = dg0 * GR_(ci, 0, 2) + dg1 * GR_(ci, 1, 2) + dg2 * GR_(ci, 2, 2);
+            s0 = dpp_add<0xB1>(s0); s1 = dpp_add<0xB1>(s1); s2 = dpp_add<0xB1>(s2);       // + the other half
+            if (ok && hf == 0) {
+                float4 dgr = *(const float4 *)(S.Dg + q * 4);
+                s0 += dgr.x; s1 += dgr.y; s2 += dgr.z;
+                S.dGR[p * 9 + r * 3] = s0 * GR_(p, 0, 0) + s1 * GR_(p, 1, 0) + s2 * GR_(p, 2, 0);
+                S.dGR[p * 9 + r * 3 + 1] = s0 * GR_(p, 0, 1) + s1 * GR_(p, 1, 1) + s2 * GR_(p, 2, 1);
+                S.dGR[p * 9 + r * 3 + 2] = s0 * GR_(p, 0, 2) + s1 * GR_(p, 1, 2) + s2 * GR_(p, 2, 2);
+            }
         }
         BF_SYNC();
 
@@ -629,16 +674,14 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 for (int i = sl; i < nj3; i += 16) acc += S.Jd[i * nb + l] * S.dJ[i] + S.Jdrel[i * nb + l] * S.drel[i];
                 for (int o = sl; o < ns3; o += 16) acc += S.sel_sd[o * nb + l] * S.dvp[o];
             }
-            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
+            acc = row16_sum(acc);
             if (l < nb && sl == 0) S.g[T.off_beta + l] = ext ? acc + ext[EXT_B + l] : acc;
         }
         BF_SYNC();
 
         // ================= phase K: priors, gradient assembly, Adam (one parameter per thread)
-        int mstar = 0;
-        float qmin = S.gq[0];
-#pragma unroll
-        for (int m = 1; m < BF_GMM_M; ++m) { float q = S.gq[m]; if (q < qmin) { qmin = q; mstar = m; } }
+        const int mstar = (int)S.scal[1];
+        const float qmin = S.scal[2];
         float grad = 0.f, pval = 0.f;
         if (tid < np) {
             pval = Pcur[tid];
