@@ -48,9 +48,13 @@ def parse():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--views", type=int, default=48)
     ap.add_argument("--dense", action="store_true", help="full mesh every iteration (reference-literal schedule)")
+    ap.add_argument("--no-graph", action="store_true", help="issue every HIP command from the host instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (dense schedule, batched shards)")
     ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (validation on a box with fewer GPUs than ranks)")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (validation of the N>1 code path on a 1-GPU box)")
+    ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed spin before the W warmup steps (clock ramp, page-in)")
     return ap.parse_args()
 
 
@@ -66,8 +70,7 @@ def build_batch(dev, model, frames, n_views):
 
 def run_steps(batch, steps, iters, flags, after_step=None):
     for _ in range(steps):
-        batch.reset()
-        batch.fit(iters, flags=flags)
+        batch.fit(iters, flags=flags | _lib.FIT_RESET)       # re-arm + fit + mesh + joints + fetch, one call
         if after_step is not None:
             after_step()
     batch.sync()
@@ -120,11 +123,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     gather = None
+    if a.same_device:
+        local = 0
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.dist_backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.dist_backend)
     if a.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
@@ -133,11 +141,11 @@ def main():
     F = a.frames_per_gpu
     frames = list(range(rank * F, rank * F + F))          # distinct frames on every rank
     batch, _ = build_batch(dev, model, frames, a.views)
-    flags = _lib.FIT_FETCH | (_lib.FIT_DENSE if a.dense else 0)
+    flags = _lib.FIT_FETCH | (_lib.FIT_DENSE if a.dense else 0) | (0 if a.no_graph else _lib.FIT_GRAPH)
 
     barrier = (lambda: None)
     after = None
-    if world > 1:
+    if world > 1 and a.dist_backend == "nccl":
         import torch
         send = torch.empty(F * dev.n_params, dtype=torch.float32, device=f"cuda:{local}")
         recv = torch.empty(world * F * dev.n_params, dtype=torch.float32, device=f"cuda:{local}")
@@ -150,12 +158,26 @@ def main():
             batch.export_params_dev(send.data_ptr())
             dist.all_gather_into_tensor(recv, send)
         gather = recv
+    elif world > 1:
+        import torch
+        recv = torch.empty(world * F * dev.n_params, dtype=torch.float32)
+
+        def barrier():
+            batch.sync()
+            dist.barrier()
+
+        def after():          # same gather through host memory (gloo)
+            dist.all_gather_into_tensor(recv, torch.from_numpy(batch.get_params().reshape(-1)))
+        gather = recv
+
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < a.prewarm_s:      # not part of W: lets clocks and page-in settle
+        run_steps(batch, 5, a.iters, flags)
 
     wall, ev = timed_leg(batch, a.steps, a.warmup, a.iters, flags, barrier, after)
     if world > 1:
         import torch
-        torch.cuda.synchronize()
-        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{local}" if a.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
@@ -168,6 +190,10 @@ def main():
 
     total_frames = world * F * a.steps
     value = total_frames / wall
+    if not a.no_graph and not a.dense:
+        # inside a hipGraph the kernels cannot be bracketed by events: per-kernel device times come from the same
+        # steps issued command by command right after the timed region
+        _, ev = timed_leg(batch, max(10, a.steps // 4), 2, a.iters, flags & ~_lib.FIT_GRAPH)
     fit_ms = ev["fit_ms"] / max(ev["calls"], 1)
     mesh_ms = ev["mesh_ms"] / max(ev["calls"], 1)
     traffic = pmc_traffic()
@@ -182,6 +208,7 @@ def main():
                                 + (" = BASELINE config 4 shard" if F == 32 else "")),
                    "frames_per_gpu": F, "views": a.views, "iters": a.iters,
                    "schedule": "dense (full mesh every iteration)" if a.dense else "sparse (gradient-carrying vertices only) + one final full mesh",
+                   "submission": "host-issued commands" if (a.no_graph or a.dense) else "one hipGraph launch per step",
                    "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of parameters per step" if world > 1 else "1 GPU"},
         "roofline": {
             "bound": "hbm", "kernel": "bf_fit_kernel" if not a.dense else "bf_fit_kernel+bf_mesh_kernel (per iteration)",
@@ -218,6 +245,8 @@ def main():
             bb, _ = build_batch(dev, model, list(range(fb)), a.views)
             n = 10
             w, e = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH)
+            wg, _ = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_GRAPH)
+            w = min(w, wg)
             extra[f"batch_{fb}_frames"] = {"value": fb * n / w, "unit": "frames/s", "ms_per_step": w / n * 1e3,
                                            "device_fit_ms": e["fit_ms"] / e["calls"], "device_mesh_ms": e["mesh_ms"] / e["calls"]}
             bb.close()

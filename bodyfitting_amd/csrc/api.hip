@@ -3,7 +3,9 @@
 
 extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
-extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *);
+extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *, const float *);
+extern "C" __global__ void bf_mesh_epilogue_kernel(MeshTab, const float *, const float *, float *, float *, float *, float *);
+extern "C" hipError_t bf_poseblend_launch(const MeshTab *, const float *, int, float *, hipStream_t);
 extern "C" __global__ void bf_joints_kernel(MeshTab, const float *, const float *, const float *, float *, float *, float *, int *, float *);
 extern "C" size_t bf_fit_smem_bytes(int, int, int, int, int, int, int);
 extern "C" size_t bf_mesh_smem_bytes(int, int, int);
@@ -335,8 +337,23 @@ int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, floa
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw, int *lmk_vid,
                    float *lmk_w) {
     dim3 grid(m->mesh.n_tiles, n);
+    const float *pose_off = nullptr;
+    if (n >= BF_MFMA_MIN_FRAMES) {
+        // batched pose blend on the matrix cores (posedirs streamed once for up to 256 frames), then the per-frame
+        // shape / skinning part only
+        const size_t ncols = (size_t)m->nv * 3, stride = bf_state_stride(m->nj, m->npf, m->nb);
+        if (m->pose_off.n < (size_t)n * ncols) {
+            if (m->pose_off.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(m->pose_off.p); m->pose_off.p = nullptr; }
+            HIP_TRY(m->pose_off.alloc((size_t)n * ncols));
+        }
+        for (int f0 = 0; f0 < n; f0 += 256)
+            HIP_TRY(bf_poseblend_launch(&m->mesh, state_dev + (size_t)f0 * stride, std::min(256, n - f0), m->pose_off.p + (size_t)f0 * ncols, stream));
+        pose_off = m->pose_off.p;
+        hipLaunchKernelGGL(bf_mesh_epilogue_kernel, grid, dim3(128), 0, stream, m->mesh, state_dev, pose_off, vraw, vout,
+                           (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed);
+    } else
     hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, m->mesh,
-                       state_dev, vraw, vout, (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed);
+                       state_dev, vraw, vout, (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed, pose_off);
     HIP_TRY(hipGetLastError());
     if (after_mesh) HIP_TRY(hipEventRecord(after_mesh, stream));
     if (joints || joints_ori || jraw) {
@@ -421,6 +438,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
 void bf_batch_destroy(bf_batch *b) {
     if (!b) return;
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     for (auto &e : b->ring) if (e) (void)hipEventDestroy(e);
     for (float *h : {b->h_params, b->h_vout, b->h_joints, b->h_terms, b->h_state}) if (h) (void)hipHostFree(h);
     delete b;
@@ -585,58 +603,125 @@ FrameIO bf_frame_io(bf_batch *b, bool want_grads) {
     return io;
 }
 
+// stream work of one sparse-schedule call: [re-arm] -> persistent fit -> [mesh + joints] -> [fetch]; `ev` = event
+// records between the parts (null inside a graph capture)
+static int enqueue_plain(bf_batch *b, int n_iters, const HyperDev &hd, const FrameIO &io, bool reset, bool want_v, bool fetch,
+                         int adam_t0, hipEvent_t *ev) {
+    bf_model *m = b->m;
+    const size_t fb = sizeof(float);
+    if (reset) {
+        HIP_TRY(hipMemcpyAsync(b->params.p, b->params0.p, b->params.n * fb, hipMemcpyDeviceToDevice, b->stream));
+        HIP_TRY(hipMemsetAsync(b->adam_m.p, 0, b->adam_m.n * fb, b->stream));
+        HIP_TRY(hipMemsetAsync(b->adam_v.p, 0, b->adam_v.n * fb, b->stream));
+    }
+    HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_iters, 0, b->adam_tab.p, adam_t0, m->fit_smem, b->stream));
+    if (ev) HIP_TRY(hipEventRecord(ev[1], b->stream));
+    if (want_v) {
+        int rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream,
+                                ev ? ev[2] : nullptr, nullptr);
+        if (rc) return rc;
+    } else if (ev) HIP_TRY(hipEventRecord(ev[2], b->stream));
+    if (fetch) {
+        HIP_TRY(hipMemcpyAsync(b->h_params, b->params.p, b->params.n * fb, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->h_terms, b->terms.p, b->terms.n * fb, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->h_state, b->state.p, b->state.n * fb, hipMemcpyDeviceToHost, b->stream));
+        if (want_v) {
+            HIP_TRY(hipMemcpyAsync(b->h_vout, b->vout.p, b->vout.n * fb, hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->h_joints, b->joints.p, b->joints.n * fb, hipMemcpyDeviceToHost, b->stream));
+        }
+    }
+    return BF_OK;
+}
+
 int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (!b || n_iters <= 0) return fail(BF_ERR_INVALID, "bf_fit: bad argument");
     bf_model *m = b->m;
     HIP_TRY(hipSetDevice(m->device));
     bf_hyper h;
     if (hyper) h = *hyper; else bf_hyper_default(&h);
+    const bool reset = flags & BF_FIT_RESET;
+    if (reset) { b->steps_done = 0; b->have_result = false; }
     int rc = ensure_adam_tab(b, h, b->steps_done + n_iters);
     if (rc) return rc;
     HyperDev hd = bf_to_dev(h);
     FrameIO io = bf_frame_io(b, false);
     const bool dense_losses = !b->scans.empty() || b->has_masks || m->kp_dense;
     if (dense_losses) flags &= ~BF_FIT_DENSE;
-    const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES);
+    const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES), fetch = flags & BF_FIT_FETCH;
     b->ev = b->ring.data() + (size_t)(b->ring_n % bf_batch::kRing) * 4;
-    HIP_TRY(hipEventRecord(b->ev[0], b->stream));
-    if (dense_losses) {
-        rc = bf_fit_with_scans(b, n_iters, h, hd, io);
-        if (rc) return rc;
-        HIP_TRY(hipEventRecord(b->ev[1], b->stream));
-        if (want_v) {
-            rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, b->ev[2], nullptr);
-            if (rc) return rc;
-        } else HIP_TRY(hipEventRecord(b->ev[2], b->stream));
-    } else if (!dense) {
-        HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_iters, 0, b->adam_tab.p, b->steps_done, m->fit_smem, b->stream));
-        HIP_TRY(hipEventRecord(b->ev[1], b->stream));
-        if (want_v) {
-            rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, b->ev[2], nullptr);
-            if (rc) return rc;
-        } else HIP_TRY(hipEventRecord(b->ev[2], b->stream));
-    } else {
-        // reference-literal schedule: every iteration evaluates the whole mesh (smplify.py:179-190)
-        for (int it = 0; it < n_iters; ++it) {
-            HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
+    const size_t fb = sizeof(float);
+    if ((flags & BF_FIT_GRAPH) && reset && !dense_losses && !dense) {
+        // the whole call as one hipGraph launch: the host issues a single command per fit
+        // the MFMA batch path may grow its scratch buffer: make sure that happened before capturing
+        if (want_v && b->F >= BF_MFMA_MIN_FRAMES && m->pose_off.n < (size_t)b->F * m->nv * 3) {
             rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
             if (rc) return rc;
+            HIP_TRY(hipStreamSynchronize(b->stream));
         }
-        HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+        bf_graph_key key{n_iters, flags, h};
+        if (!b->graph_exec || std::memcmp(&key, &b->graph_key, sizeof key) != 0) {
+            if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+            rc = enqueue_plain(b, n_iters, hd, io, true, want_v, fetch, 0, nullptr);
+            hipError_t e = hipStreamEndCapture(b->stream, &graph);
+            if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            HIP_TRY(e);
+            HIP_TRY(hipGraphInstantiate(&b->graph_exec, graph, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(graph);
+            b->graph_key = key;
+        }
+        HIP_TRY(hipEventRecord(b->ev[0], b->stream));
+        HIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
+        HIP_TRY(hipEventRecord(b->ev[1], b->stream));       // (no events inside a graph: the whole call is charged to ms[0])
         HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+        HIP_TRY(hipEventRecord(b->ev[3], b->stream));
+        b->fetched = fetch;
+        b->ring_n += 1;
+        b->steps_done = n_iters;
+        b->timed = true;
+        b->have_result = want_v;
+        return BF_OK;
     }
-    b->fetched = false;
-    if (flags & BF_FIT_FETCH) {
-        const size_t fb = sizeof(float);
-        HIP_TRY(hipMemcpyAsync(b->h_params, b->params.p, b->params.n * fb, hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->h_terms, b->terms.p, b->terms.n * fb, hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->h_state, b->state.p, b->state.n * fb, hipMemcpyDeviceToHost, b->stream));
-        if (want_v || dense) {
-            HIP_TRY(hipMemcpyAsync(b->h_vout, b->vout.p, b->vout.n * fb, hipMemcpyDeviceToHost, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->h_joints, b->joints.p, b->joints.n * fb, hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipEventRecord(b->ev[0], b->stream));
+    if (!dense_losses && !dense) {
+        rc = enqueue_plain(b, n_iters, hd, io, reset, want_v, fetch, b->steps_done, b->ev);
+        if (rc) return rc;
+    } else {
+        if (reset) {
+            HIP_TRY(hipMemcpyAsync(b->params.p, b->params0.p, b->params.n * fb, hipMemcpyDeviceToDevice, b->stream));
+            HIP_TRY(hipMemsetAsync(b->adam_m.p, 0, b->adam_m.n * fb, b->stream));
+            HIP_TRY(hipMemsetAsync(b->adam_v.p, 0, b->adam_v.n * fb, b->stream));
         }
-        b->fetched = true;
+        if (dense_losses) {
+            rc = bf_fit_with_scans(b, n_iters, h, hd, io);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+            if (want_v) {
+                rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, b->ev[2], nullptr);
+                if (rc) return rc;
+            } else HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+        } else {
+            // reference-literal schedule: every iteration evaluates the whole mesh (smplify.py:179-190)
+            for (int it = 0; it < n_iters; ++it) {
+                HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
+                rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
+                if (rc) return rc;
+            }
+            HIP_TRY(hipEventRecord(b->ev[1], b->stream));
+            HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+        }
+        if (fetch) {
+            HIP_TRY(hipMemcpyAsync(b->h_params, b->params.p, b->params.n * fb, hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->h_terms, b->terms.p, b->terms.n * fb, hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->h_state, b->state.p, b->state.n * fb, hipMemcpyDeviceToHost, b->stream));
+            if (want_v || dense) {
+                HIP_TRY(hipMemcpyAsync(b->h_vout, b->vout.p, b->vout.n * fb, hipMemcpyDeviceToHost, b->stream));
+                HIP_TRY(hipMemcpyAsync(b->h_joints, b->joints.p, b->joints.n * fb, hipMemcpyDeviceToHost, b->stream));
+            }
+        }
     }
+    b->fetched = fetch;
     HIP_TRY(hipEventRecord(b->ev[3], b->stream));
     b->ring_n += 1;
     b->steps_done += n_iters;

@@ -58,11 +58,14 @@ struct bf_model {
     DevBuf<int> th_kind, th_off, p_kind, p_a, p_b, faces_lm, lmk_faces, dyn_faces, kp_jm, cj_start, cj_list;
     DevBuf<float> pose_mean, hand_comp, lmk_bary, dyn_bary;
     KpIO kp{};
+    DevBuf<float> pose_off;       // [F][3NV] batched pose-blend result (MFMA path), grown on demand
     DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass
     std::vector<float> posedirs_host;
     std::vector<int> faces_host;  // body-model topology (for the SMPL+D stage), optional
     DevBuf<int> faces_d, adj_start, adj;   // faces and the vertex -> (face, corner) lists, built on first use
 };
+
+struct bf_graph_key { int n_iters; uint32_t flags; bf_hyper h; };
 
 struct bf_batch {
     bf_model *m = nullptr;
@@ -82,6 +85,8 @@ struct bf_batch {
     DevBuf<float> proj, keypoints, params, adam_m, adam_v, grads, terms, state, vraw, vout, joints, adam_tab, debug, xpart;
     DevBuf<int> ndiv;
     bool have_result = false;
+    hipGraphExec_t graph_exec = nullptr;     // BF_FIT_GRAPH: the captured [re-arm, fit, mesh, joints, fetch] sequence
+    bf_graph_key graph_key{};
     // dense vertex losses (use_mesh, smplify.py:146-156,205-206)
     std::vector<struct bf_scan *> scans;
     DevBuf<ScanDev> scan_dev;

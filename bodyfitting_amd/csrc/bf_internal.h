@@ -10,6 +10,7 @@
 #define BF_VSUB 16          // view sub-slots in the projection phase (512 / 32)
 #define BF_KP_ROUNDS 3      // keypoints cached in registers for V <= 16*3 = 48 views
 #define BF_SEL_NNZ 8         // compacted skinning weights per selector vertex (real SMPL has <= 4)
+#define BF_MFMA_MIN_FRAMES 16  // from this batch size on the pose blend runs as one fp32-MFMA GEMM for all frames
 #define BF_MESH_TILE 32     // vertices per workgroup of the full-mesh forward
 #define BF_MESH_RG 8        // pose-feature row groups per workgroup (split-K inside the workgroup)
 

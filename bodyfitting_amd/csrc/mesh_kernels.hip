@@ -117,7 +117,7 @@ bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__r
 #define BF_MESH_WPF 24     // lbs weights prefetched per vertex thread
 extern "C" __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
 bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ vraw, float *__restrict__ vout,
-               float *__restrict__ xpart, float *__restrict__ vposed) {
+               float *__restrict__ xpart, float *__restrict__ vposed, const float *__restrict__ pose_off) {
     constexpr int COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
@@ -141,7 +141,9 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
     const float *pd = M.posedirs + (size_t)p0 * ncols + (ok ? gcol : 0);
     float pv[BF_MESH_PF];
 #pragma unroll
-    for (int i = 0; i < BF_MESH_PF; ++i) pv[i] = (p0 + i < p1) ? pd[(size_t)i * ncols] : 0.f;
+    for (int i = 0; i < BF_MESH_PF; ++i) pv[i] = (!pose_off && p0 + i < p1) ? pd[(size_t)i * ncols] : 0.f;
+    // (pose_off: the pose blend of this frame was already formed by bf_poseblend_mfma_kernel for the whole batch)
+    const float poff = (pose_off && rg == 0 && ok) ? pose_off[(size_t)frame * ncols + gcol] : 0.f;
     float wreg[BF_MESH_WPF], sdreg[12], vt = 0.f, jx[BF_MESH_TILE];
 #pragma unroll
     for (int j = 0; j < BF_MESH_WPF; ++j) wreg[j] = 0.f;
@@ -177,8 +179,8 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < BF_MESH_PF; ++i) acc += (p0 + i < p1 ? s_feat[p0 + i] : 0.f) * pv[i];
-    for (int p = p0 + BF_MESH_PF; p < p1; ++p) acc += s_feat[p] * pd[(size_t)(p - p0) * ncols];
-    s_red[rg * COLS + col] = acc;
+    if (!pose_off) for (int p = p0 + BF_MESH_PF; p < p1; ++p) acc += s_feat[p] * pd[(size_t)(p - p0) * ncols];
+    s_red[rg * COLS + col] = pose_off ? (rg == 0 ? poff : 0.f) : acc;
     if (rg == 1) {
         float a2 = 0.f;
 #pragma unroll
@@ -305,4 +307,154 @@ bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__rest
     if (joints)
         for (int i = tid; i < M.n_joint_map * 3; i += 256)
             joints[(size_t)frame * M.n_joint_map * 3 + i] = s_all[M.joint_map[i / 3] * 3 + i % 3];
+}
+
+
+// Batched pose blend on the matrix cores: OFF[f][col] = sum_p feat[f][p] * posedirs[p][col] for a whole batch of
+// frames at once, i.e. the GEMM [F x P] . [P x 3NV] that the reference evaluates frame by frame as
+// `torch.matmul(pose_feature, posedirs)` (smplx lbs).  fp32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact fp32 fma chain in k order), so parity is unchanged.
+//   workgroup = 4 waves = 128 columns; wave = one 32-column strip x ALL frames (FT tiles of 32 frames, 16
+//   accumulator VGPRs each), so every posedirs element is read from HBM exactly once per launch and reused
+//   FT*32 times from registers; the pose features of the batch are staged through LDS in 16-deep k chunks
+//   (row stride 17 floats: conflict-free for the A-fragment pattern lane -> (frame, k)).
+// A fragment: lane l holds A[i = l & 31][k = l >> 5]; B fragment: lane l holds B[k = l >> 5][j = l & 31];
+// accumulator: column = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define BF_PB_KC 16
+#define BF_PB_LD 17
+template <int FT>
+__global__ void __launch_bounds__(256)
+poseblend_mfma_kernel(MeshTab M, const float *__restrict__ state, int n_frames, float *__restrict__ pose_off) {
+    __shared__ float s_a[FT * 32 * BF_PB_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int npf = M.npf, ncols = 3 * M.nv;
+    const int col0 = (blockIdx.x * 4 + wave) * 32, col = col0 + (lane & 31), kh = lane >> 5;
+    const bool col_ok = col < ncols;
+    const int stride = bf_state_stride(M.nj, npf, M.nb), feat_off = M.nj * 15;      // GR 9 + At 3 + Gt 3 per joint, then feat
+    f32x16 acc[FT];
+#pragma unroll
+    for (int t = 0; t < FT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    for (int p0 = 0; p0 < npf; p0 += BF_PB_KC) {
+        __syncthreads();
+        for (int i = tid; i < FT * 32 * BF_PB_KC; i += 256) {
+            int f = i / BF_PB_KC, kk = i - f * BF_PB_KC;
+            s_a[f * BF_PB_LD + kk] = (f < n_frames && p0 + kk < npf) ? state[(size_t)f * stride + feat_off + p0 + kk] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BF_PB_KC; kk += 2) {
+            const int p = p0 + kk + kh;
+            const float b = (col_ok && p < npf) ? M.posedirs[(size_t)p * ncols + col] : 0.f;
+#pragma unroll
+            for (int t = 0; t < FT; ++t) {
+                const float a = s_a[(t * 32 + (lane & 31)) * BF_PB_LD + kk + kh];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    if (col_ok) {
+#pragma unroll
+        for (int t = 0; t < FT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int f = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (f < n_frames) pose_off[(size_t)f * ncols + col] = acc[t][r];
+            }
+    }
+}
+
+// frames [f0, f0 + n) of the batch; `state` and `pose_off` already point at frame f0
+extern "C" hipError_t bf_poseblend_launch(const MeshTab *M, const float *state, int n, float *pose_off, hipStream_t stream) {
+    const int ncols = 3 * M->nv;
+    dim3 grid((ncols + 127) / 128);
+    if (n <= 32) hipLaunchKernelGGL(poseblend_mfma_kernel<1>, grid, dim3(256), 0, stream, *M, state, n, pose_off);
+    else if (n <= 64) hipLaunchKernelGGL(poseblend_mfma_kernel<2>, grid, dim3(256), 0, stream, *M, state, n, pose_off);
+    else if (n <= 128) hipLaunchKernelGGL(poseblend_mfma_kernel<4>, grid, dim3(256), 0, stream, *M, state, n, pose_off);
+    else hipLaunchKernelGGL(poseblend_mfma_kernel<8>, grid, dim3(256), 0, stream, *M, state, n, pose_off);
+    return hipGetLastError();
+}
+
+
+// Per-frame part of the batched path: shaped vertex + pose offset (from the MFMA GEMM) -> skinning, for one
+// 32-vertex tile.  grid (n_tiles, F), 128 threads (96 = vertex x coordinate, the last 32 take the extra-joint
+// partials), nothing idle: the batched path launches F x 216 of these.
+extern "C" __global__ void __launch_bounds__(128)
+bf_mesh_epilogue_kernel(MeshTab M, const float *__restrict__ state, const float *__restrict__ pose_off,
+                        float *__restrict__ vraw, float *__restrict__ vout, float *__restrict__ xpart, float *__restrict__ vposed) {
+    constexpr int COLS = BF_MESH_TILE * 3;
+    __shared__ __align__(16) float s_A[64 * 12];
+    __shared__ float s_vp[COLS], s_raw[COLS], s_beta[24];
+    const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv, ncols = 3 * nv;
+    const int tid = threadIdx.x, frame = blockIdx.y, col = tid;
+    StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
+    const int gcol = blockIdx.x * COLS + col;
+    const bool ok = col < COLS && gcol < ncols;
+    const int vl = col / 3, k = col - vl * 3, v = blockIdx.x * BF_MESH_TILE + vl;
+    float wreg[BF_MESH_WPF], sdreg[12], vt = 0.f, off = 0.f;
+#pragma unroll
+    for (int j = 0; j < BF_MESH_WPF; ++j) wreg[j] = 0.f;
+#pragma unroll
+    for (int l = 0; l < 12; ++l) sdreg[l] = 0.f;
+    if (ok) {
+        const float *w = M.lbs_weights + (size_t)v * nj;
+#pragma unroll
+        for (int j = 0; j < BF_MESH_WPF; ++j) if (j < nj) wreg[j] = w[j];
+        const float *sd = M.shapedirs + (size_t)gcol * nb;
+#pragma unroll
+        for (int l = 0; l < 12; ++l) if (l < nb) sdreg[l] = sd[l];
+        vt = M.v_template[gcol];
+        off = pose_off[(size_t)frame * ncols + gcol];
+    }
+    for (int i = tid; i < nj * 12; i += 128) {
+        int j = i / 12, e = i % 12, a = e / 4, b = e % 4;
+        s_A[i] = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
+    }
+    if (tid < nb + 5) s_beta[tid] = st.beta[tid];
+    __syncthreads();
+    if (col < COLS) {
+        float a2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < 12; ++l) if (l < nb) a2 += sdreg[l] * s_beta[l];
+        for (int l = 12; l < nb; ++l) a2 += M.shapedirs[(size_t)gcol * nb + l] * s_beta[l];
+        s_vp[col] = ok ? vt + a2 + off : 0.f;
+    }
+    __syncthreads();
+    if (col < COLS) {
+        float r = 0.f;
+        if (ok) {
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f, tt = 0.f;
+#pragma unroll
+            for (int j = 0; j < BF_MESH_WPF; ++j) {
+                if (j < nj) {
+                    const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
+                    t0 += wreg[j] * a.x; t1 += wreg[j] * a.y; t2 += wreg[j] * a.z; tt += wreg[j] * a.w;
+                }
+            }
+            for (int j = BF_MESH_WPF; j < nj; ++j) {
+                float wj = M.lbs_weights[(size_t)v * nj + j];
+                const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
+                t0 += wj * a.x; t1 += wj * a.y; t2 += wj * a.z; tt += wj * a.w;
+            }
+            r = t0 * s_vp[vl * 3] + t1 * s_vp[vl * 3 + 1] + t2 * s_vp[vl * 3 + 2] + tt;
+            size_t o = (size_t)frame * ncols + gcol;
+            if (vraw) vraw[o] = r;
+            if (vout) vout[o] = (r + s_beta[nb + k]) * s_beta[nb + 3] * s_beta[nb + 4];
+            if (vposed) vposed[o] = s_vp[col];
+        }
+        s_raw[col] = r;
+    }
+    if (xpart) {
+        __syncthreads();
+        const int ne3 = M.n_extra * 3, q = tid - COLS;
+        if (q >= 0 && q < ne3) {
+            int e = q / 3, kk = q - e * 3, v0 = blockIdx.x * BF_MESH_TILE;
+            const float *row = M.j_extra + (size_t)e * nv + v0;
+            float a3 = 0.f;
+            for (int i = 0; i < BF_MESH_TILE; ++i) if (v0 + i < nv) a3 += row[i] * s_raw[i * 3 + kk];
+            xpart[((size_t)frame * gridDim.x + blockIdx.x) * ne3 + q] = a3;
+        }
+    }
 }

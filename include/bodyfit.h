@@ -104,6 +104,10 @@ typedef struct bf_hyper {
                                     (smplify.py:179-190), instead of only the vertices that carry
                                     gradient; same results, used for measurement */
 #define BF_FIT_NO_VERTICES  2u   /* skip the final full-mesh evaluation (parameters only) */
+#define BF_FIT_RESET        8u   /* bf_batch_reset() first, inside the same call */
+#define BF_FIT_GRAPH       16u   /* with BF_FIT_RESET on the keypoint-only path: capture the call's whole command sequence
+                                    into a hipGraph once and replay it - one host command per fit (per-kernel device times are
+                                    then not split: bf_batch_last_timing charges everything to ms[0]) */
 #define BF_FIT_FETCH        4u   /* queue the device->host copies of the result into the batch's pinned
                                     staging buffers behind the kernels (bf_batch_get_result then only
                                     waits for them) */

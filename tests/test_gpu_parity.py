@@ -201,3 +201,41 @@ def test_python_mirror_end_to_end(smpl_model, gmm, tmp_path):
     assert set(saved) == {"vertices", "joints", "pose", "betas", "global_orient", "faces", "global_transl", "scale", "full_pose"}
     first = (out / "smpl.obj").read_text().splitlines()[0]
     assert first == "v %.4f %.4f %.4f" % tuple(res["vertices"][0])
+
+
+def test_batched_mfma_pose_blend_matches_per_frame_path(dev_model, smpl_model):
+    """>= 16 frames: the pose blend runs as one fp32-MFMA GEMM over the batch; same vertices as frame by frame"""
+    rng = np.random.default_rng(11)
+    n = 37                                            # not a multiple of the 32-frame MFMA tile
+    betas = rng.normal(0, 0.7, (n, 10)).astype(np.float32)
+    orient = rng.normal(0, 0.8, (n, 3)).astype(np.float32)
+    pose = rng.normal(0, 0.3, (n, 69)).astype(np.float32)
+    verts, joints, _ = dev_model.forward(betas, orient, pose)
+    for i in (0, 5, 31, 32, 36):
+        v1, j1, _ = dev_model.forward(betas[i:i + 1], orient[i:i + 1], pose[i:i + 1])
+        np.testing.assert_allclose(verts[i], v1[0], atol=2e-6)
+        np.testing.assert_allclose(joints[i], j1[0], atol=2e-6)
+    m = O.to_torch_model(smpl_model, torch.float64)
+    ref = O.smpl_forward(m, torch.tensor(betas[:3], dtype=torch.float64), torch.tensor(orient[:3], dtype=torch.float64),
+                         torch.tensor(pose[:3], dtype=torch.float64))
+    np.testing.assert_allclose(verts[:3], ref["vertices"].numpy(), atol=3e-6)
+
+
+def test_graph_replay_equals_host_issued_commands(dev_model, smpl_model):
+    """BF_FIT_RESET | BF_FIT_GRAPH: the captured command sequence gives bit-identical results, call after call"""
+    from bodyfitting_amd import _lib
+    probs = [S.make_problem(smpl_model, frame=f, n_views=48) for f in (0, 1)]
+    a, b = _batch(dev_model, probs), _batch(dev_model, probs)
+    a.fit(25, flags=_lib.FIT_FETCH)
+    want_p, want_r = a.get_params(), a.get_result()
+    for _ in range(3):
+        b.fit(25, flags=_lib.FIT_FETCH | _lib.FIT_RESET | _lib.FIT_GRAPH)
+        np.testing.assert_array_equal(b.get_params(), want_p)
+        got = b.get_result()
+        for x, y in zip(got, want_r):
+            np.testing.assert_array_equal(x, y)
+    b.fit(10, flags=_lib.FIT_RESET | _lib.FIT_GRAPH)                       # a different call shape re-captures
+    a.reset(); a.fit(10)
+    np.testing.assert_array_equal(b.get_params(), a.get_params())
+    a.close()
+    b.close()
