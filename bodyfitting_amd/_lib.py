@@ -84,6 +84,8 @@ SIGNATURES = {
     "bf_batch_last_timing": (C.c_int, [_VP, _FP]),
     "bf_batch_timing_reset": (C.c_int, [_VP]),
     "bf_batch_timing_sum": (C.c_int, [_VP, _FP, _IP]),
+    "bf_batch_debug_dump": (C.c_int, [_VP, _FP, C.c_int]),
+    "bf_batch_debug_disp_moment": (C.c_int, [_VP, _FP]),
 }
 
 _lib = None
@@ -106,8 +108,6 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    lib.bf_batch_debug_dump.restype = C.c_int
-    lib.bf_batch_debug_dump.argtypes = [_VP, _FP, C.c_int]
     _lib = lib
     return lib
 

@@ -215,6 +215,12 @@ int bf_batch_last_timing(bf_batch *b, float ms[4]);
 int bf_batch_timing_reset(bf_batch *b);
 int bf_batch_timing_sum(bf_batch *b, float ms[4], int32_t *n_calls);
 
+/* ---- test hooks (bring-up / parity tests only; not part of the drop-in surface) ----------------------------------
+ * first-iteration intermediates of frame 0 written by the last bf_loss_grad launch (layout: tests/gpu_debug.py) */
+int bf_batch_debug_dump(bf_batch *b, float *dst, int n);
+/* first Adam moment of the SMPL+D displacement (after one step = 0.1 x the gradient) */
+int bf_batch_debug_disp_moment(bf_batch *b, float *m_out);
+
 #ifdef __cplusplus
 }
 #endif
