@@ -220,8 +220,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int ci = c_on ? tid / 3 : 0, cr = c_on ? tid - ci * 3 : 0;
     const int cp = ci > 0 ? T.parents[ci] : 0;
     const unsigned long long cmask = c_on ? T.desc[ci] : 0ull;       // strict descendants of ci
-    // loss-joint routing of this thread's joint slot
-    const int jslot = tid & 31, vsub = tid >> 5;
+    // projection role: wave w owns loss joints 4w..4w+3, lane = (joint jl = lane >> 4, view lane vi = lane & 15);
+    // the 16 view lanes of a joint are one DPP row, so the sum over views never leaves the wave
+    const int jslot = wave * 4 + (lane >> 4), vsub = lane & 15;
     const bool j_on = jslot < nl;
     const int lkind = j_on ? T.lj_kind[jslot] : 0, lidx = j_on ? T.lj_index[jslot] : 0;
     const float *lsrc = lkind == 0 ? S.G + lidx * 12 + 3 : S.vsel + lidx * 3;
@@ -294,26 +295,26 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     }
     };
     auto project = [&]() {
-        {
         float tX = Pcur[0], tY = Pcur[1], tZ = Pcur[2];
         float sc = Pcur[3] * cscale;
         float y0 = 0.f, y1 = 0.f, y2 = 0.f;
         if (j_on) { y0 = lsrc[0] + tX; y1 = lsrc[lstride] + tY; y2 = lsrc[2 * lstride] + tZ; }
         float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, lsum = 0.f;
+        const float two_s4 = 2.f * s2 * s2;
         auto one_view = [&](int v, float gx, float gy, float c2) {
             const float4 *P = (const float4 *)(S.proj + v * 12);
             float4 Pa4 = P[0], Pb4 = P[1], Pc4 = P[2];
             float p0 = Pa4.x * x0 + Pa4.y * x1 + Pa4.z * x2 + Pa4.w;
             float p1 = Pb4.x * x0 + Pb4.y * x1 + Pb4.z * x2 + Pb4.w;
             float p2 = Pc4.x * x0 + Pc4.y * x1 + Pc4.z * x2 + Pc4.w;
-            float ip2 = 1.0f / p2;
+            float ip2 = __builtin_amdgcn_rcpf(p2);                       // v_rcp_f32: 1 ulp, one instruction
             float u = p0 * ip2, w = p1 * ip2;
             float rx = (gx - u) * icoeff, ry = (gy - w) * icoeff;
-            float ix = 1.0f / (s2 + rx * rx), iy = 1.0f / (s2 + ry * ry);
-            lsum += c2 * (s2 * rx * rx * ix + s2 * ry * ry * iy);
-            float k = c2 * kscale;
-            float du = k * (2.f * s2 * s2 * rx * ix * ix), dw = k * (2.f * s2 * s2 * ry * iy * iy);
+            float ix = __builtin_amdgcn_rcpf(s2 + rx * rx), iy = __builtin_amdgcn_rcpf(s2 + ry * ry);
+            lsum += c2 * s2 * (rx * rx * ix + ry * ry * iy);
+            float k = c2 * kscale * two_s4;
+            float du = k * rx * ix * ix, dw = k * ry * iy * iy;
             float q0 = du * ip2, q1 = dw * ip2, q2 = -(du * u + dw * w) * ip2;
             g0 += Pa4.x * q0 + Pb4.x * q1 + Pc4.x * q2;
             g1 += Pa4.y * q0 + Pb4.y * q1 + Pc4.y * q2;
@@ -330,9 +331,29 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 one_view(v, k[0], k[1], k[2] * k[2]);
             }
         }
-        float4 pr = {g0, g1, g2, lsum};
-        ((float4 *)S.part)[vsub * 32 + jslot] = pr;
-    }
+        // sum over the 16 view lanes of this joint (fixed DPP tree), route dL/dX to its source, and leave this
+        // wave's share of d/dt, d/ds and of the loss value for the Adam phase
+        g0 = row16_sum(g0); g1 = row16_sum(g1); g2 = row16_sum(g2); lsum = row16_sum(lsum);
+        const bool head = j_on && vsub == 0;
+        if (head) {
+            atomicAdd(ldst + 0, g0 * sc);           // LDS; distinct targets for the reference joint maps
+            atomicAdd(ldst + 1, g1 * sc);
+            atomicAdd(ldst + 2, g2 * sc);
+        }
+        float gs = g0 * y0 + g1 * y1 + g2 * y2;
+        auto four = [&](float v) {                  // rows 0..3 of the wave, each row-uniform: (r0 + r1) + (r2 + r3)
+            float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+            float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+            float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+            float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+            return (a + b) + (c + d);
+        };
+        float w0 = four(j_on ? g0 : 0.f), w1 = four(j_on ? g1 : 0.f), w2 = four(j_on ? g2 : 0.f);
+        float w3 = four(j_on ? gs : 0.f), w4 = four(j_on ? lsum : 0.f);
+        if (lane == 0) {
+            float *wp = S.part + wave * 8;
+            wp[0] = w0; wp[1] = w1; wp[2] = w2; wp[3] = w3; wp[4] = w4;
+        }
     };
 
     if (gw) {
@@ -395,8 +416,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             BF_SYNC();                 // B
             BF_SYNC();                 // C
             project();
-            BF_SYNC();                 // D
-            BF_SYNC();                 // E
+            BF_SYNC();                 // D (+E: the view reduction and routing happen in-wave)
             BF_SYNC();                 // F
             for (int p = tid - 256; p < npf; p += 256) {      // d(pose feature) = sel_pd . dvp
                 float acc = 0.f;
@@ -535,40 +555,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         project();
         BF_SYNC();
 
-        // ================= phase E: fixed-order reduce over the view slots; route dL/dX; d/dt, d/ds, loss value
-        if (wave < 2) {
-            // lane = (joint slot js, half h): each half sums 8 of the 16 view slots, then the halves combine
-            int js = lane & 31, h = lane >> 5;
-            float4 a = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < BF_VSUB / 2; ++q) {
-                float4 p = ((const float4 *)S.part)[(h * (BF_VSUB / 2) + q) * 32 + js];
-                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
-            }
-            a.x += __shfl_xor(a.x, 32); a.y += __shfl_xor(a.y, 32); a.z += __shfl_xor(a.z, 32); a.w += __shfl_xor(a.w, 32);
-            float sc = Pcur[3] * cscale;
-            bool cnt = js < nl && h == 0;          // (jslot == js on both halves of waves 0 and 1)
-            if (wave == 0) {
-                if (cnt) {
-                    atomicAdd(ldst + 0, a.x * sc);   // LDS; distinct targets for the reference joint maps
-                    atomicAdd(ldst + 1, a.y * sc);
-                    atomicAdd(ldst + 2, a.z * sc);
-                }
-                float gt0 = wave_sum(cnt ? a.x : 0.f), gt1 = wave_sum(cnt ? a.y : 0.f), gt2 = wave_sum(cnt ? a.z : 0.f);
-                if (lane == 0) {                                                              // d/d global_transl (smplify.py:189)
-                    S.g[0] = gt0 * sc + (ext ? ext[EXT_T] + ext[EXT_K] : 0.f); S.g[1] = gt1 * sc + (ext ? ext[EXT_T + 1] + ext[EXT_K + 1] : 0.f);
-                    S.g[2] = gt2 * sc + (ext ? ext[EXT_T + 2] + ext[EXT_K + 2] : 0.f);
-                }
-            } else {
-                float y0 = 0.f, y1 = 0.f, y2 = 0.f;
-                if (cnt) { y0 = lsrc[0] + Pcur[0]; y1 = lsrc[lstride] + Pcur[1]; y2 = lsrc[2 * lstride] + Pcur[2]; }
-                float gs = wave_sum(cnt ? a.x * y0 + a.y * y1 + a.z * y2 : 0.f);
-                float ls = wave_sum(cnt ? a.w : 0.f);
-                if (lane == 0) { S.g[3] = gs * cscale + (ext ? ext[EXT_T + 3] + ext[EXT_K + 3] : 0.f); S.scal[0] = ls; }                   // d/d body_scale; sum conf^2 rho
-            }
-        }
-        BF_SYNC();
-
         // ================= phase F: reverse skinning of the selector vertices
         if (c_on) {
             float dat = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
@@ -685,7 +671,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         float grad = 0.f, pval = 0.f;
         if (tid < np) {
             pval = Pcur[tid];
-            if (pk == 0) grad = S.g[tid];
+            if (pk == 0) {                                           // transl / scale: sum the 8 waves' shares in wave order
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) acc += S.part[w * 8 + tid];
+                grad = acc * (tid < 3 ? Pcur[3] * cscale : cscale) + (ext ? ext[EXT_T + tid] + ext[EXT_K + tid] : 0.f);
+                S.g[tid] = grad;                                     // (kept for the debug dump)
+            }
             else if (pk == 1) {
                 grad = S.gth[pa];
                 if (pb >= 0) {                                       // body-pose dof pb: GMM + angle priors
@@ -706,7 +698,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             // loss terms of this evaluation (loss.py:219-224) and the pose state of this forward pass
             if (tid == 0) {
                 float *tm = io.terms + (size_t)frame * 4;
-                if (!T.kp_dense) tm[0] = S.scal[0] / ndiv_f;         // (the dense keypoint kernel owns it otherwise)
+                if (!T.kp_dense) {                                   // (the dense keypoint kernel owns it otherwise)
+                    float acc = 0.f;
+                    for (int w = 0; w < 8; ++w) acc += S.part[w * 8 + 4];
+                    tm[0] = acc / ndiv_f;
+                }
                 tm[1] = hp.w_pose * qmin;
             }
             if (tid == 64) {
