@@ -44,7 +44,7 @@ namespace {
 struct FitSmem {
     float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
-    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp;
+    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *Jdp, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp;
     int *nzj, *thk, *tho;
 };
 
@@ -70,6 +70,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.feat = take(npf);                s.vpp = take(BF_FIT_THREADS + ns * 3);
     s.Jtrel = take(nj * 3); s.Dg = take(nj * 12);
     s.Jt = take(nj * 3);   s.Jd = take(nj * 3 * nb);      s.Jdrel = take(nj * 3 * nb);
+    s.Jdp = take(nj * 3 * pad4(nb));
     s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * nb); s.sel_pd = take(npf * ns * 3);
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
     s.proj = take(nviews * 12);
@@ -88,6 +89,7 @@ __device__ inline float dpp_add(float v) {
     return v + __int_as_float(r);
 }
 __device__ inline float quad_sum(float v) { v = dpp_add<0xB1>(v); return dpp_add<0x4E>(v); }        // all 4 lanes of a quad
+__device__ inline float half8_sum(float v) { v = quad_sum(v); return dpp_add<0x141>(v); }             // 8 lanes: + row_half_mirror
 __device__ inline float row16_sum(float v) { v = quad_sum(v); v = dpp_add<0x124>(v); return dpp_add<0x128>(v); }   // all 16 lanes of a row
 // every lane gets the wave's total, added as ((row0 + row1) + (row2 + row3)): fixed order
 __device__ inline float wave_sum(float v) {
@@ -99,12 +101,34 @@ __device__ inline float wave_sum(float v) {
     return (a + b) + (c + d);
 }
 
+// sin and cos of a non-negative angle of moderate size (|a| < ~1e4): Cody-Waite reduction by pi/2 in three
+// parts, then the classic degree-7 / degree-8 minimax kernels on [-pi/4, pi/4]; about 1 ulp, ~30 instructions
+// (the OCML sinf + cosf pair costs several hundred cycles on the critical path of every iteration)
+__device__ inline void sincos_small(float a, float *sn, float *cs) {
+    const float n = rintf(a * 0.636619772367581343f);
+    float r = fmaf(n, -1.57079625129699707031e+00f, a);
+    r = fmaf(n, -7.54978941586159635335e-08f, r);
+    r = fmaf(n, -5.39030285815811905290e-15f, r);
+    const float z = r * r;
+    const float ps = fmaf(z, fmaf(z, fmaf(z, 2.7557314297e-06f, -1.9841270114e-04f), 8.3333337680e-03f), -1.6666667163e-01f);
+    const float sr = fmaf(r * z, ps, r);
+    const float pc = fmaf(z, fmaf(z, fmaf(z, -2.7557314297e-07f, 2.4801587642e-05f), -1.3888889225e-03f), 4.1666667908e-02f);
+    const float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
+    const int q = (int)n & 3;
+    const float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
+    *sn = (q & 2) ? -s1 : s1;
+    *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
 // smplx batch_rodrigues for one joint
 __device__ inline void rodrigues_fwd(float tx, float ty, float tz, float *R, float *rc) {
     float ux = tx + 1e-8f, uy = ty + 1e-8f, uz = tz + 1e-8f;
     float a = sqrtf(ux * ux + uy * uy + uz * uz);
-    float nx = tx / a, ny = ty / a, nz = tz / a;
-    float s = sinf(a), c = cosf(a), oc = 1.0f - c;
+    float ia = 1.0f / a;
+    float nx = tx * ia, ny = ty * ia, nz = tz * ia;
+    float s, c;
+    sincos_small(a, &s, &c);
+    float oc = 1.0f - c;
     R[0] = 1.0f + oc * (-nz * nz - ny * ny);
     R[1] = s * (-nz) + oc * (nx * ny);
     R[2] = s * ny + oc * (nx * nz);
@@ -120,7 +144,8 @@ __device__ inline void rodrigues_fwd(float tx, float ty, float tz, float *R, flo
 // reverse of rodrigues_fwd: G = dL/dR (row-major 3x3) -> dL/dtheta
 __device__ inline void rodrigues_bwd(float tx, float ty, float tz, const float *rc, const float *G, float *gth) {
     float a = rc[0], s = rc[1], c = rc[2], oc = 1.0f - c;
-    float n[3] = {tx / a, ty / a, tz / a};
+    const float ia = 1.0f / a;
+    float n[3] = {tx * ia, ty * ia, tz * ia};
     float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
     float KK[9] = {-n[2] * n[2] - n[1] * n[1], n[0] * n[1], n[0] * n[2],
                    n[0] * n[1], -n[2] * n[2] - n[0] * n[0], n[1] * n[2],
@@ -141,11 +166,11 @@ __device__ inline void rodrigues_bwd(float tx, float ty, float tz, const float *
             H[r * 3 + q] = s * G[r * 3 + q] + oc * m;
         }
     float dn0 = H[7] - H[5], dn1 = H[2] - H[6], dn2 = H[3] - H[1];
-    da -= (dn0 * tx + dn1 * ty + dn2 * tz) / (a * a);
-    float k = da / a;
-    gth[0] = dn0 / a + k * (tx + 1e-8f);
-    gth[1] = dn1 / a + k * (ty + 1e-8f);
-    gth[2] = dn2 / a + k * (tz + 1e-8f);
+    da -= (dn0 * tx + dn1 * ty + dn2 * tz) * (ia * ia);
+    float k = da * ia;
+    gth[0] = dn0 * ia + k * (tx + 1e-8f);
+    gth[1] = dn1 * ia + k * (ty + 1e-8f);
+    gth[2] = dn2 * ia + k * (tz + 1e-8f);
 }
 
 
@@ -185,6 +210,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     copy_f(S.Jtrel, T.Jtrel, nj3, tid, nt);
     copy_f(S.Jd, T.Jd, nj3 * nb, tid, nt);
     copy_f(S.Jdrel, T.Jdrel, nj3 * nb, tid, nt);
+    const int nb4 = pad4(nb);                  // Jdrel again with rows padded to float4s, for the chain lanes' b128 reads
+    for (int i = tid; i < nj3 * nb4; i += nt) { int r = i / nb4, l = i - r * nb4; S.Jdp[i] = l < nb ? T.Jdrel[r * nb + l] : 0.f; }
     copy_f(S.sel_vt, T.sel_vt, ns3, tid, nt);
     copy_f(S.sel_sd, T.sel_sd, ns3 * nb, tid, nt);
     copy_f(S.sel_pd, T.sel_pd, npf * ns3, tid, nt);
@@ -213,6 +240,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int wp = wj > 0 ? T.parents[wj] : 0;
     const int wd = cw_on ? T.depth[wj] : -1;
     const int w_kind = T.th_kind[wj], w_off = T.th_off[wj];
+    float w_jt[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w_jt[k] = cw_on ? T.Jtrel[wj * 3 + k] : 0.f;
     const float w_pm0 = T.pose_mean ? T.pose_mean[wj * 3] : 0.f, w_pm1 = T.pose_mean ? T.pose_mean[wj * 3 + 1] : 0.f,
                 w_pm2 = T.pose_mean ? T.pose_mean[wj * 3 + 2] : 0.f;
     // (joint, row) role of the reverse sweep: tid < 3 nj
@@ -220,10 +250,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int ci = c_on ? tid / 3 : 0, cr = c_on ? tid - ci * 3 : 0;
     const int cp = ci > 0 ? T.parents[ci] : 0;
     const unsigned long long cmask = c_on ? T.desc[ci] : 0ull;       // strict descendants of ci
-    // projection role: wave w owns loss joints 4w..4w+3, lane = (joint jl = lane >> 4, view lane vi = lane & 15);
-    // the 16 view lanes of a joint are one DPP row, so the sum over views never leaves the wave
-    const int jslot = wave * 4 + (lane >> 4), vsub = lane & 15;
-    const bool j_on = jslot < nl;
+    // projection role (geometry waves 0-3 only, so the GMM waves keep their registers for the precision rows):
+    // wave w owns loss joints 8w..8w+7, lane = (joint jl = lane >> 3, view lane vi = lane & 7); the 8 view lanes of a
+    // joint sit in one half of a DPP row, so the sum over views never leaves the wave
+    const int jslot = (wave & 3) * 8 + (lane >> 3), vsub = lane & 7;
+    const bool j_on = wave < 4 && jslot < nl;
     const int lkind = j_on ? T.lj_kind[jslot] : 0, lidx = j_on ? T.lj_index[jslot] : 0;
     const float *lsrc = lkind == 0 ? S.G + lidx * 12 + 3 : S.vsel + lidx * 3;
     const int lstride = lkind == 0 ? 4 : 1;
@@ -234,16 +265,22 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int gwi = gw ? wave - 4 : 0;
     const int ma = 2 * gwi, mb = 2 * gwi + 1;
     const int tpiece = lane < 60 ? lane : 59;
-    const float *tail_d = S.gd + (tpiece < 30 ? ma : mb) * BF_GMM_LD + 12 * (tpiece % 6);
+    // d = theta - mu of a wave's two components sits interleaved in LDS, (d_a[j], d_b[j]) pairs, so one b128 read
+    // feeds two packed FMAs (v_pk_fma_f32) with no register shuffling
+    float *gdw = S.gd + gwi * 2 * BF_GMM_LD;
+    const int tail_c = tpiece < 30 ? 0 : 1;
+    const float4 *tail_d = (const float4 *)(gdw + 2 * 12 * (tpiece % 6));
     const float logw_a = T.g_logw[ma], logw_b = T.g_logw[mb];
     int gd_off[3], gd_src[3];                 // this lane's (component, dof) items of d = theta - mu
+    float gd_mu[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         int i = lane + q * 64;
         bool ok = gw && i < 2 * BF_GMM_D;
-        int c = i < BF_GMM_D ? ma : mb, j = i < BF_GMM_D ? i : i - BF_GMM_D;
-        gd_off[q] = ok ? c * BF_GMM_LD + j : -1;
+        int c = i < BF_GMM_D ? 0 : 1, j = i < BF_GMM_D ? i : i - BF_GMM_D;
+        gd_off[q] = ok ? 2 * j + c : -1;
         gd_src[q] = j < T.nbp ? T.off_pose + j : -1;       // smplx pads 63 -> 69 with zeros (loss.py:207)
+        gd_mu[q] = ok ? T.g_means[(c ? mb : ma) * BF_GMM_D + j] : 0.f;
     }
 
     // keypoints of this thread's (joint slot, view sub-slot) pinned in registers
@@ -333,7 +370,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         // sum over the 16 view lanes of this joint (fixed DPP tree), route dL/dX to its source, and leave this
         // wave's share of d/dt, d/ds and of the loss value for the Adam phase
-        g0 = row16_sum(g0); g1 = row16_sum(g1); g2 = row16_sum(g2); lsum = row16_sum(lsum);
+        g0 = half8_sum(g0); g1 = half8_sum(g1); g2 = half8_sum(g2); lsum = half8_sum(lsum);
         const bool head = j_on && vsub == 0;
         if (head) {
             atomicAdd(ldst + 0, g0 * sc);           // LDS; distinct targets for the reference joint maps
@@ -341,16 +378,15 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             atomicAdd(ldst + 2, g2 * sc);
         }
         float gs = g0 * y0 + g1 * y1 + g2 * y2;
-        auto four = [&](float v) {                  // rows 0..3 of the wave, each row-uniform: (r0 + r1) + (r2 + r3)
-            float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-            float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-            float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-            float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-            return (a + b) + (c + d);
+        auto four = [&](float v) {                  // the wave's 8 joints (values uniform per 8-lane group), fixed order
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), q * 8));
+            return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
         };
         float w0 = four(j_on ? g0 : 0.f), w1 = four(j_on ? g1 : 0.f), w2 = four(j_on ? g2 : 0.f);
         float w3 = four(j_on ? gs : 0.f), w4 = four(j_on ? lsum : 0.f);
-        if (lane == 0) {
+        if (lane == 0 && wave < 4) {
             float *wp = S.part + wave * 8;
             wp[0] = w0; wp[1] = w1; wp[2] = w2; wp[3] = w3; wp[4] = w4;
         }
@@ -358,14 +394,18 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
     if (gw) {
         // ================= GMM specialists (waves 4-7): the precision rows never leave their registers
-        float Pa[BF_GMM_LD], Pb[BF_GMM_LD], Pt[12];
+        typedef float v2f __attribute__((ext_vector_type(2)));
+        v2f P2[BF_GMM_LD];                      // (row `lane` of component a, of component b), column j
+        float Pt[12];
 #pragma unroll
         for (int j = 0; j < BF_GMM_LD; ++j) {
-            Pa[j] = T.g_plane[((size_t)ma * BF_GMM_LD + j) * 64 + lane];
-            Pb[j] = T.g_plane[((size_t)mb * BF_GMM_LD + j) * 64 + lane];
+            P2[j].x = T.g_plane[((size_t)ma * BF_GMM_LD + j) * 64 + lane];
+            P2[j].y = T.g_plane[((size_t)mb * BF_GMM_LD + j) * 64 + lane];
         }
 #pragma unroll
         for (int e = 0; e < 12; ++e) Pt[e] = T.g_ptail[((size_t)gwi * 12 + e) * 64 + lane];
+        const float4 *d4 = (const float4 *)__builtin_assume_aligned(gdw, 16);
+        const v2f *d2 = (const v2f *)__builtin_assume_aligned(gdw, 8);
         for (int it = 0; it < n_iters; ++it) {
 #ifdef BF_STAMP
             int sidx = 0;
@@ -374,25 +414,30 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             // GMM, wave-local: d = theta - mu, y = Psym d (rows 0..63 per lane + 60 tail pieces), q = 0.5 d'y - log w~
 #pragma unroll
             for (int q = 0; q < 3; ++q)
-                if (gd_off[q] >= 0) S.gd[gd_off[q]] = (gd_src[q] >= 0 ? Pcur[gd_src[q]] : 0.f) - S.means[gd_off[q]];
+                if (gd_off[q] >= 0) gdw[gd_off[q]] = (gd_src[q] >= 0 ? Pcur[gd_src[q]] : 0.f) - gd_mu[q];
             BF_WAVE_FENCE();
-            const float4 *da4 = (const float4 *)(S.gd + ma * BF_GMM_LD);
-            const float4 *db4 = (const float4 *)(S.gd + mb * BF_GMM_LD);
-            float ya = 0.f, yb = 0.f;
+            v2f y = {0.f, 0.f};
 #pragma unroll
-            for (int j4 = 0; j4 < BF_GMM_LD / 4; ++j4) {
-                float4 a = da4[j4], b = db4[j4];
-                ya += Pa[4 * j4] * a.x; ya += Pa[4 * j4 + 1] * a.y; ya += Pa[4 * j4 + 2] * a.z; ya += Pa[4 * j4 + 3] * a.w;
-                yb += Pb[4 * j4] * b.x; yb += Pb[4 * j4 + 1] * b.y; yb += Pb[4 * j4 + 2] * b.z; yb += Pb[4 * j4 + 3] * b.w;
+            for (int j2 = 0; j2 < BF_GMM_LD / 2; ++j2) {
+                float4 t = d4[j2];
+                v2f t0 = {t.x, t.y}, t1 = {t.z, t.w};
+                y += P2[2 * j2] * t0;
+                y += P2[2 * j2 + 1] * t1;
             }
+            const float ya = y.x, yb = y.y;
             S.gy[ma * BF_GMM_LD + lane] = ya;
             S.gy[mb * BF_GMM_LD + lane] = yb;
             float yt = 0.f;
 #pragma unroll
-            for (int e = 0; e < 12; ++e) yt += Pt[e] * tail_d[e];
+            for (int e2 = 0; e2 < 6; ++e2) {
+                float4 t = tail_d[e2];
+                yt += Pt[2 * e2] * (tail_c ? t.y : t.x);
+                yt += Pt[2 * e2 + 1] * (tail_c ? t.w : t.z);
+            }
             S.gtail[gwi * 64 + lane] = yt;
             BF_WAVE_FENCE();
-            float ta = S.gd[ma * BF_GMM_LD + lane] * ya, tb = S.gd[mb * BF_GMM_LD + lane] * yb;
+            v2f dl = d2[lane];
+            float ta = dl.x * ya, tb = dl.y * yb;
             if (lane < 5) {
                 float ysa = 0.f, ysb = 0.f;
 #pragma unroll
@@ -402,8 +447,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 }
                 S.gy[ma * BF_GMM_LD + 64 + lane] = ysa;
                 S.gy[mb * BF_GMM_LD + 64 + lane] = ysb;
-                ta += S.gd[ma * BF_GMM_LD + 64 + lane] * ysa;
-                tb += S.gd[mb * BF_GMM_LD + 64 + lane] * ysb;
+                v2f dt = d2[64 + lane];
+                ta += dt.x * ysa;
+                tb += dt.y * ysb;
             }
             ta = wave_sum(ta);
             tb = wave_sum(tb);
@@ -411,12 +457,14 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 S.gq[ma] = 0.5f * ta + logw_a;       // prior.py:188-189
                 S.gq[mb] = 0.5f * tb + logw_b;
             }
+#ifdef BF_STAMP
+            if (tid == 256 && it == 2 && io.debug) io.debug[4096 + 42] = (float)(long long)(clock64() - t_iter);
+#endif
             BF_SYNC();                 // A
             pose_blend();
             BF_SYNC();                 // B
             BF_SYNC();                 // C
-            project();
-            BF_SYNC();                 // D (+E: the view reduction and routing happen in-wave)
+            BF_SYNC();                 // D (+E): projection, view reduction and routing run on the geometry waves
             BF_SYNC();                 // F
             for (int p = tid - 256; p < npf; p += 256) {      // d(pose feature) = sel_pd . dvp
                 float acc = 0.f;
@@ -441,23 +489,34 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #endif
         // ================= phase A: forward chain (waves 0-2) | shaped selector verts (wave 3) | GMM (waves 4-7)
         if (wave < 3) {
-            float Ri[9], rc[3], rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
+            float Ri[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rc[3], rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
             float4 row = {0.f, 0.f, 0.f, 0.f};
             if (cw_on) {
                 float th0 = w_pm0, th1 = w_pm1, th2 = w_pm2;
                 if (w_kind == 0) { th0 += Pcur[w_off]; th1 += Pcur[w_off + 1]; th2 += Pcur[w_off + 2]; }
-                else if (w_kind >= 2) { th0 = theta_of(Pcur, wj, 0); th1 = theta_of(Pcur, wj, 1); th2 = theta_of(Pcur, wj, 2); }
+                else if (NJ != 24 && w_kind >= 2) { th0 = theta_of(Pcur, wj, 0); th1 = theta_of(Pcur, wj, 1); th2 = theta_of(Pcur, wj, 2); }
                 rodrigues_fwd(th0, th1, th2, Ri, rc);
                 if (wave == 0) { S.theta[wj * 3] = th0; S.theta[wj * 3 + 1] = th1; S.theta[wj * 3 + 2] = th2; }
                 // rel_j = J_j - J_parent straight from the pre-contracted difference tables (rel_0 = J_0)
-                const float *beta = Pcur + T.off_beta;
+                const float *beta = Pcur + T.off_beta;          // (table entries past nb are zero padding)
+                const float4 *jq = (const float4 *)(S.Jdp + wj * 3 * nb4);
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-                for (int l = 0; l < nb; ++l) {
-                    float bl = beta[l];
-                    a0 += S.Jdrel[(wj * 3 + 0) * nb + l] * bl; a1 += S.Jdrel[(wj * 3 + 1) * nb + l] * bl; a2 += S.Jdrel[(wj * 3 + 2) * nb + l] * bl;
+                for (int q = 0; q < (NB ? (NB + 3) / 4 : 3); ++q) {
+                    if (q * 4 < nb4) {
+                        float4 b = {beta[4 * q], 4 * q + 1 < nb ? beta[4 * q + 1] : 0.f, 4 * q + 2 < nb ? beta[4 * q + 2] : 0.f, 4 * q + 3 < nb ? beta[4 * q + 3] : 0.f}, j0 = jq[q], j1 = jq[nb4 / 4 + q], j2 = jq[2 * (nb4 / 4) + q];
+                        a0 += j0.x * b.x + j0.y * b.y + j0.z * b.z + j0.w * b.w;
+                        a1 += j1.x * b.x + j1.y * b.y + j1.z * b.z + j1.w * b.w;
+                        a2 += j2.x * b.x + j2.y * b.y + j2.z * b.z + j2.w * b.w;
+                    }
                 }
-                rel0 = S.Jtrel[wj * 3] + a0; rel1 = S.Jtrel[wj * 3 + 1] + a1; rel2 = S.Jtrel[wj * 3 + 2] + a2;
+                for (int q = (NB ? (NB + 3) / 4 : 3); q * 4 < nb4; ++q) {
+                    float4 b = {beta[4 * q], 4 * q + 1 < nb ? beta[4 * q + 1] : 0.f, 4 * q + 2 < nb ? beta[4 * q + 2] : 0.f, 4 * q + 3 < nb ? beta[4 * q + 3] : 0.f}, j0 = jq[q], j1 = jq[nb4 / 4 + q], j2 = jq[2 * (nb4 / 4) + q];
+                    a0 += j0.x * b.x + j0.y * b.y + j0.z * b.z + j0.w * b.w;
+                    a1 += j1.x * b.x + j1.y * b.y + j1.z * b.z + j1.w * b.w;
+                    a2 += j2.x * b.x + j2.y * b.y + j2.z * b.z + j2.w * b.w;
+                }
+                rel0 = w_jt[0] + a0; rel1 = w_jt[1] + a1; rel2 = w_jt[2] + a2;
                 if (wave == 0) {
 #pragma unroll
                     for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
@@ -476,17 +535,28 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
                 }
             }
+#ifdef BF_STAMP
+            if (tid == 0 && it == 2 && io.debug) io.debug[4096 + 40] = (float)(long long)(clock64() - t_iter);
+#endif
+            // level sweep: the parent's row comes straight out of the parent lane's registers (ds_bpermute, no LDS
+            // write -> read round trip on the critical path); the finished rows go to LDS once, at the end
+            const int wp4 = wp * 4;
             for (int lev = 1; lev < T.n_levels; ++lev) {
-                BF_WAVE_FENCE();
-                if (wd == lev) {
-                    float4 g = *(const float4 *)(S.G + (wp * 3 + wave) * 4);
-                    row.x = g.x * Ri[0] + g.y * Ri[3] + g.z * Ri[6];
-                    row.y = g.x * Ri[1] + g.y * Ri[4] + g.z * Ri[7];
-                    row.z = g.x * Ri[2] + g.y * Ri[5] + g.z * Ri[8];
-                    row.w = g.x * rel0 + g.y * rel1 + g.z * rel2 + g.w;
-                    *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
-                }
+                float gx = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(row.x)));
+                float gy = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(row.y)));
+                float gz = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(row.z)));
+                float gw_ = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(row.w)));
+                const bool mine = wd == lev;
+                float nx = gx * Ri[0] + gy * Ri[3] + gz * Ri[6];
+                float ny = gx * Ri[1] + gy * Ri[4] + gz * Ri[7];
+                float nz = gx * Ri[2] + gy * Ri[5] + gz * Ri[8];
+                float nw = gx * rel0 + gy * rel1 + gz * rel2 + gw_;
+                row.x = mine ? nx : row.x; row.y = mine ? ny : row.y; row.z = mine ? nz : row.z; row.w = mine ? nw : row.w;
             }
+            if (cw_on && wj > 0) *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
+#ifdef BF_STAMP
+            if (tid == 0 && it == 2 && io.debug) io.debug[4096 + 41] = (float)(long long)(clock64() - t_iter);
+#endif
         } else {
             const float *beta = Pcur + T.off_beta;
             for (int o = lane; o < ns3; o += 64) {
@@ -674,7 +744,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (pk == 0) {                                           // transl / scale: sum the 8 waves' shares in wave order
                 float acc = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) acc += S.part[w * 8 + tid];
+                for (int w = 0; w < 4; ++w) acc += S.part[w * 8 + tid];
                 grad = acc * (tid < 3 ? Pcur[3] * cscale : cscale) + (ext ? ext[EXT_T + tid] + ext[EXT_K + tid] : 0.f);
                 S.g[tid] = grad;                                     // (kept for the debug dump)
             }
@@ -700,7 +770,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 float *tm = io.terms + (size_t)frame * 4;
                 if (!T.kp_dense) {                                   // (the dense keypoint kernel owns it otherwise)
                     float acc = 0.f;
-                    for (int w = 0; w < 8; ++w) acc += S.part[w * 8 + 4];
+                    for (int w = 0; w < 4; ++w) acc += S.part[w * 8 + 4];
                     tm[0] = acc / ndiv_f;
                 }
                 tm[1] = hp.w_pose * qmin;

@@ -16,8 +16,9 @@ b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
 for rep in range(3):
     b.reset(); b.fit(100); b.sync()
     d = b.debug_dump(4096 + 96)[4096:]
-    n = int(np.max(np.nonzero(d)[0])) + 1 if np.any(d) else 0
+    n = int(np.max(np.nonzero(d[:32])[0])) + 1 if np.any(d[:32]) else 0
     st = d[:n]
     print("rep", rep, "timing", b.last_timing())
     print("  cumulative cycles after each barrier:", [int(x) for x in st])
     print("  per-phase:", [int(x) for x in np.diff(np.concatenate([[0], st]))])
+    print("  phase A inner: after rodrigues+rel, after chain levels, GMM wave done:", [int(x) for x in d[40:43]])
