@@ -7,8 +7,8 @@
 #define BF_GMM_D 69         // and a 69-dof body pose (smplify/prior.py:154)
 #define BF_GMM_LD 72        // padded row length of the d / y vectors in LDS
 #define BF_FIT_THREADS 512  // one workgroup (8 wave64, two per SIMD) per frame
-#define BF_VSUB 8           // view lanes per loss joint in the projection phase (half a DPP row)
-#define BF_KP_ROUNDS 6      // keypoints cached in registers for V <= 8*6 = 48 views
+#define BF_VSUB 16          // view lanes per loss-joint pair in the projection phase (one DPP row)
+#define BF_KP_ROUNDS 3      // keypoint records staged in LDS for V <= 16*3 = 48 views
 #define BF_SEL_NNZ 8         // compacted skinning weights per selector vertex (real SMPL has <= 4)
 #define BF_MFMA_MIN_FRAMES 16  // from this batch size on the pose blend runs as one fp32-MFMA GEMM for all frames
 #define BF_MESH_TILE 32     // vertices per workgroup of the full-mesh forward

@@ -44,8 +44,8 @@ namespace {
 struct FitSmem {
     float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
-    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *Jdp, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp;
-    int *nzj, *thk, *tho;
+    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *Jdp, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp;
+    int *nzj, *thk, *tho, *par;
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
@@ -61,7 +61,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.vs = take(ns * 3);   s.vp = take(ns * 3);   s.TR = take(ns * 9);   s.vsel = take(ns * 3);
     s.part = take(BF_VSUB * 32 * 4);
     s.dvsel = take(ns * 3); s.dvp = take(ns * 3);
-    s.dGR = take(nj * 9);  s.dGt = take(nj * 3);  s.tt = take(nj * 3);   s.N = take(nj * 12);
+    s.dGR = take(nj * 12); s.dGt = take(nj * 3);  s.tt = take(nj * 3);   s.N = take(nj * 12);
     s.dAt = take(nj * 3);  s.dJ = take(nj * 3);
     s.dR = take(nj * 9);   s.drel = take(nj * 3); s.dfeat = take(npf);   s.gth = take(nj * 3);
     s.g = take(np);
@@ -75,8 +75,9 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
     s.proj = take(nviews * 12);
     s.nzw = take(ns * BF_SEL_NNZ);  s.nzj = (int *)take(ns * BF_SEL_NNZ);
+    s.kp = take(BF_VSUB * BF_KP_ROUNDS * 16 * 8);      // 8-float keypoint record per (view, loss-joint pair), zero padded
     s.theta = take(nj * 3);  s.pmean = take(nj * 3);  s.hcomp = take(2 * 6 * 45);
-    s.thk = (int *)take(nj); s.tho = (int *)take(nj);
+    s.thk = (int *)take(nj); s.tho = (int *)take(nj); s.par = (int *)take(nj);
     (void)nl;
     return o * sizeof(float);
 }
@@ -192,7 +193,7 @@ __device__ inline void copy_i(int *dst, const int *src, int n, int tid, int nt) 
 // adam_tab[it] = {lr_transl_scale / bc1, lr / bc1, sqrt(bc2)} evaluated in double on the host exactly
 // as torch's single-tensor Adam does.  NJ/NB/NS/NL > 0 fix the sizes at compile time
 // (SMPL: 24, 10, 11, 25) so every inner loop unrolls; 0 = take them from the tables.
-template <int NJ, int NB, int NS, int NL>
+template <int NJ, int NB, int NS, int NL, bool EXT>
 __global__ void __launch_bounds__(BF_FIT_THREADS)
 fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float *__restrict__ adam_tab, int adam_t0) {
     extern __shared__ __align__(16) float smem_raw[];
@@ -218,7 +219,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     copy_f(S.sel_w, T.sel_w, ns * nj, tid, nt);
     for (int i = tid; i < ns * BF_SEL_NNZ; i += nt) { S.nzw[i] = T.sel_nzw[i]; S.nzj[i] = T.sel_nzj[i]; }
     const int sel_nnz = T.sel_nnz;
-    for (int i = tid; i < nj; i += nt) { S.thk[i] = T.th_kind[i]; S.tho[i] = T.th_off[i]; }
+    for (int i = tid; i < nj; i += nt) { S.thk[i] = T.th_kind[i]; S.tho[i] = T.th_off[i]; S.par[i] = i > 0 ? T.parents[i] : 0; }
     for (int i = tid; i < nj * 3; i += nt) S.pmean[i] = T.pose_mean ? T.pose_mean[i] : 0.f;
     for (int i = tid; i < 2 * T.n_pca * 45 && i < 2 * 6 * 45; i += nt) S.hcomp[i] = T.hand_comp[i];
     auto theta_of = [&](const float *P, int j, int k) {
@@ -239,6 +240,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int wj = cw_on ? lane : 0;
     const int wp = wj > 0 ? T.parents[wj] : 0;
     const int wd = cw_on ? T.depth[wj] : -1;
+    const int w_feat = (wj > 0 ? wj - 1 : 0) * 9;          // (non-negative base: the nine stores share one address register)
     const int w_kind = T.th_kind[wj], w_off = T.th_off[wj];
     float w_jt[3];
 #pragma unroll
@@ -250,15 +252,20 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int ci = c_on ? tid / 3 : 0, cr = c_on ? tid - ci * 3 : 0;
     const int cp = ci > 0 ? T.parents[ci] : 0;
     const unsigned long long cmask = c_on ? T.desc[ci] : 0ull;       // strict descendants of ci
-    // projection role (geometry waves 0-3 only, so the GMM waves keep their registers for the precision rows):
-    // wave w owns loss joints 8w..8w+7, lane = (joint jl = lane >> 3, view lane vi = lane & 7); the 8 view lanes of a
-    // joint sit in one half of a DPP row, so the sum over views never leaves the wave
-    const int jslot = (wave & 3) * 8 + (lane >> 3), vsub = lane & 7;
-    const bool j_on = wave < 4 && jslot < nl;
-    const int lkind = j_on ? T.lj_kind[jslot] : 0, lidx = j_on ? T.lj_index[jslot] : 0;
-    const float *lsrc = lkind == 0 ? S.G + lidx * 12 + 3 : S.vsel + lidx * 3;
-    const int lstride = lkind == 0 ? 4 : 1;
-    float *ldst = (lkind == 0 ? S.dGt : S.dvsel) + lidx * 3;
+    // projection role (geometry waves 0-3 only, so the GMM waves keep their registers for the precision rows): a lane
+    // owns a PAIR of loss joints (2 ps, 2 ps + 1) on one view lane, ps = 4 * wave + lane / 16, view lane = lane % 16.
+    // Both joints see the same projection matrix, so every multiply-add of the projection, the GMoF and the
+    // reverse pass is one packed v_pk_*_f32 over the pair; the 16 view lanes of a pair are one DPP row.
+    const int pslot = (wave & 3) * 4 + (lane >> 4), vsub = lane & 15;
+    const int ja = 2 * pslot, jb = 2 * pslot + 1;
+    const bool ja_on = wave < 4 && ja < nl, jb_on = wave < 4 && jb < nl;
+    const int lkind_a = ja_on ? T.lj_kind[ja] : 0, lidx_a = ja_on ? T.lj_index[ja] : 0;
+    const int lkind_b = jb_on ? T.lj_kind[jb] : 0, lidx_b = jb_on ? T.lj_index[jb] : 0;
+    const float *lsrc_a = lkind_a == 0 ? S.G + lidx_a * 12 + 3 : S.vsel + lidx_a * 3;
+    const float *lsrc_b = lkind_b == 0 ? S.G + lidx_b * 12 + 3 : S.vsel + lidx_b * 3;
+    const int lstride_a = lkind_a == 0 ? 4 : 1, lstride_b = lkind_b == 0 ? 4 : 1;
+    float *ldst_a = (lkind_a == 0 ? S.dGt : S.dvsel) + lidx_a * 3;
+    float *ldst_b = (lkind_b == 0 ? S.dGt : S.dvsel) + lidx_b * 3;
 
     // GMM role (waves 4-7): precision rows pinned in registers (lane-major host copies: coalesced)
     const bool gw = wave >= 4;
@@ -283,27 +290,37 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         gd_mu[q] = ok ? T.g_means[(c ? mb : ma) * BF_GMM_D + j] : 0.f;
     }
 
-    // keypoints of this thread's (joint slot, view sub-slot) pinned in registers
-    float kx[BF_KP_ROUNDS], ky[BF_KP_ROUNDS], kc2[BF_KP_ROUNDS];
-    const float *kp_frame = io.keypoints + (size_t)frame * V * nl * 3;
-#pragma unroll
-    for (int r = 0; r < BF_KP_ROUNDS; ++r) {
-        int v = vsub + BF_VSUB * r;
-        bool ok = v < V && j_on;
-        const float *k = kp_frame + ((size_t)(ok ? v : 0) * nl + (ok ? jslot : 0)) * 3;
-        kx[r] = k[0]; ky[r] = k[1];
-        float cf = ok ? k[2] : 0.f;
-        kc2[r] = cf * cf;
-    }
     const float ndiv_f = (float)io.ndiv[frame];
     const float icoeff = 1.0f / hp.coeff;
     const float kscale = -1.0f / (hp.coeff * ndiv_f);
     const float s2 = hp.sigma2;
     const float cscale = io.cscale ? io.cscale[frame] : hp.cscale;
+    // keypoints of the first BF_VSUB * BF_KP_ROUNDS views staged in LDS, one 8-float record per (view, joint pair):
+    // (x_a, x_b, y_a, y_b | k_a, k_b, c_a, c_b) with k = conf^2 * kscale * 2 sigma^4 (gradient factor) and
+    // c = conf^2 * sigma^2 (loss factor); records past V or nl are zero, so they add nothing
+    const float *kp_frame = io.keypoints + (size_t)frame * V * nl * 3;
+    for (int i = tid; i < BF_VSUB * BF_KP_ROUNDS * 16; i += nt) {
+        const int v = i >> 4, ps = i & 15;
+        float4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+        if (v < V && 2 * ps < nl) {
+            const float *k = kp_frame + ((size_t)v * nl + 2 * ps) * 3;
+            const float c2 = k[2] * k[2];
+            e0.x = k[0]; e0.z = k[1]; e1.x = c2 * kscale * (2.f * s2 * s2); e1.z = c2 * s2;
+        }
+        if (v < V && 2 * ps + 1 < nl) {
+            const float *k = kp_frame + ((size_t)v * nl + 2 * ps + 1) * 3;
+            const float c2 = k[2] * k[2];
+            e0.y = k[0]; e0.w = k[1]; e1.y = c2 * kscale * (2.f * s2 * s2); e1.w = c2 * s2;
+        }
+        ((float4 *)S.kp)[2 * i] = e0;
+        ((float4 *)S.kp)[2 * i + 1] = e1;
+    }
+    const float4 *kp_lane = (const float4 *)__builtin_assume_aligned(S.kp, 16) + (vsub * 16 + pslot) * 2;
     const int EXT0 = npf, EXT_A = npf, EXT_B = npf + nj * 12, EXT_T = npf + nj * 12 + nb;
     const int EXT_G = npf + nj * 12 + nb + 4;
     const int EXT_K = EXT_G + nj * 3;          // dt, ds of the dense keypoint loss
-    const float *ext = io.ext ? io.ext + (size_t)frame * (npf + nj * 12 + nb + 4 + nj * 3 + 4) : nullptr;
+    // (EXT = the dense schedule's per-iteration launch with outside gradient blocks; compiled out of the persistent loop)
+    const float *ext = EXT ? io.ext + (size_t)frame * (npf + nj * 12 + nb + 4 + nj * 3 + 4) : nullptr;
     (void)EXT0;
 
     // pose-blend role: (row slice sl, output column o of the selector vertices)
@@ -320,6 +337,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     if (pk == 1 && pb >= 0) ang_sg = pb == 52 ? 1.f : ((pb == 55 || pb == 9 || pb == 12) ? -1.f : 0.f);
     __syncthreads();
 
+#ifdef BF_STAMP
+    int bf_it = -1;
+    long long bf_t0 = 0;
+#endif
+    float grad_last = 0.f;
     // phases shared by both wave roles
     auto pose_blend = [&]() {
         for (int idx = tid; idx < ns3 * NSL; idx += nt) {
@@ -331,61 +353,80 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         S.vpp[idx] = acc;
     }
     };
+    typedef float v2f __attribute__((ext_vector_type(2)));
     auto project = [&]() {
-        float tX = Pcur[0], tY = Pcur[1], tZ = Pcur[2];
-        float sc = Pcur[3] * cscale;
-        float y0 = 0.f, y1 = 0.f, y2 = 0.f;
-        if (j_on) { y0 = lsrc[0] + tX; y1 = lsrc[lstride] + tY; y2 = lsrc[2 * lstride] + tZ; }
-        float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f, lsum = 0.f;
-        const float two_s4 = 2.f * s2 * s2;
-        auto one_view = [&](int v, float gx, float gy, float c2) {
-            const float4 *P = (const float4 *)(S.proj + v * 12);
-            float4 Pa4 = P[0], Pb4 = P[1], Pc4 = P[2];
-            float p0 = Pa4.x * x0 + Pa4.y * x1 + Pa4.z * x2 + Pa4.w;
-            float p1 = Pb4.x * x0 + Pb4.y * x1 + Pb4.z * x2 + Pb4.w;
-            float p2 = Pc4.x * x0 + Pc4.y * x1 + Pc4.z * x2 + Pc4.w;
-            float ip2 = __builtin_amdgcn_rcpf(p2);                       // v_rcp_f32: 1 ulp, one instruction
-            float u = p0 * ip2, w = p1 * ip2;
-            float rx = (gx - u) * icoeff, ry = (gy - w) * icoeff;
-            float ix = __builtin_amdgcn_rcpf(s2 + rx * rx), iy = __builtin_amdgcn_rcpf(s2 + ry * ry);
-            lsum += c2 * s2 * (rx * rx * ix + ry * ry * iy);
-            float k = c2 * kscale * two_s4;
-            float du = k * rx * ix * ix, dw = k * ry * iy * iy;
-            float q0 = du * ip2, q1 = dw * ip2, q2 = -(du * u + dw * w) * ip2;
+#ifdef BF_STAMP
+        if (tid == 0 && bf_it == 2 && io.debug) io.debug[4096 + 45] = (float)(long long)(clock64() - bf_t0);
+#endif
+        const float tX = Pcur[0], tY = Pcur[1], tZ = Pcur[2];
+        const float sc = Pcur[3] * cscale;
+        const v2f y0 = {lsrc_a[0] + tX, lsrc_b[0] + tX};
+        const v2f y1 = {lsrc_a[lstride_a] + tY, lsrc_b[lstride_b] + tY};
+        const v2f y2 = {lsrc_a[2 * lstride_a] + tZ, lsrc_b[2 * lstride_b] + tZ};
+        const v2f x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
+        v2f g0 = {0.f, 0.f}, g1 = {0.f, 0.f}, g2 = {0.f, 0.f}, lsum = {0.f, 0.f};
+        // one view for the lane's joint pair: gxy = (x_a, x_b, y_a, y_b), kc = (k_a, k_b, c_a, c_b)
+        auto one_view = [&](int v, float4 gxy, float4 kc) {
+            const float4 *P = (const float4 *)__builtin_assume_aligned(S.proj + v * 12, 16);
+            const float4 Pa4 = P[0], Pb4 = P[1], Pc4 = P[2];
+            const v2f p0 = Pa4.x * x0 + Pa4.y * x1 + Pa4.z * x2 + Pa4.w;
+            const v2f p1 = Pb4.x * x0 + Pb4.y * x1 + Pb4.z * x2 + Pb4.w;
+            const v2f p2 = Pc4.x * x0 + Pc4.y * x1 + Pc4.z * x2 + Pc4.w;
+            const v2f ip2 = {__builtin_amdgcn_rcpf(p2.x), __builtin_amdgcn_rcpf(p2.y)};     // v_rcp_f32: 1 ulp
+            const v2f u = p0 * ip2, w = p1 * ip2;
+            const v2f gx = {gxy.x, gxy.y}, gy = {gxy.z, gxy.w}, kk = {kc.x, kc.y}, cc = {kc.z, kc.w};
+            const v2f rx = (gx - u) * icoeff, ry = (gy - w) * icoeff;
+            const v2f ax = rx * rx, ay = ry * ry;
+            const v2f dx = ax + s2, dy = ay + s2;
+            const v2f ix = {__builtin_amdgcn_rcpf(dx.x), __builtin_amdgcn_rcpf(dx.y)};
+            const v2f iy = {__builtin_amdgcn_rcpf(dy.x), __builtin_amdgcn_rcpf(dy.y)};
+            lsum += cc * (ax * ix + ay * iy);
+            const v2f du = kk * rx * ix * ix, dw = kk * ry * iy * iy;
+            const v2f q0 = du * ip2, q1 = dw * ip2, q2 = -(du * u + dw * w) * ip2;
             g0 += Pa4.x * q0 + Pb4.x * q1 + Pc4.x * q2;
             g1 += Pa4.y * q0 + Pb4.y * q1 + Pc4.y * q2;
             g2 += Pa4.z * q0 + Pb4.z * q1 + Pc4.z * q2;
         };
+        // no per-round branch: records past V carry zero factors and the view index is clamped, so the rounds are
+        // independent straight-line code the scheduler interleaves
 #pragma unroll
         for (int r = 0; r < BF_KP_ROUNDS; ++r) {
-            int v = vsub + BF_VSUB * r;
-            if (v < V && j_on) one_view(v, kx[r], ky[r], kc2[r]);
+            const float4 *kq = kp_lane + r * BF_VSUB * 32;
+            one_view(min(vsub + BF_VSUB * r, V - 1), kq[0], kq[1]);
         }
-        for (int v = vsub + BF_VSUB * BF_KP_ROUNDS; v < V; v += BF_VSUB) {   // V > 48: stream the rest
-            if (j_on) {
-                const float *k = kp_frame + ((size_t)v * nl + jslot) * 3;
-                one_view(v, k[0], k[1], k[2] * k[2]);
-            }
+        for (int v = vsub + BF_VSUB * BF_KP_ROUNDS; v < V; v += BF_VSUB) {   // V > 48: stream the rest from global memory
+            float4 gxy = {0.f, 0.f, 0.f, 0.f}, kc = {0.f, 0.f, 0.f, 0.f};
+            if (ja_on) { const float *k = kp_frame + ((size_t)v * nl + ja) * 3; float c2 = k[2] * k[2];
+                         gxy.x = k[0]; gxy.z = k[1]; kc.x = c2 * kscale * (2.f * s2 * s2); kc.z = c2 * s2; }
+            if (jb_on) { const float *k = kp_frame + ((size_t)v * nl + jb) * 3; float c2 = k[2] * k[2];
+                         gxy.y = k[0]; gxy.w = k[1]; kc.y = c2 * kscale * (2.f * s2 * s2); kc.w = c2 * s2; }
+            one_view(v, gxy, kc);
         }
-        // sum over the 16 view lanes of this joint (fixed DPP tree), route dL/dX to its source, and leave this
-        // wave's share of d/dt, d/ds and of the loss value for the Adam phase
-        g0 = half8_sum(g0); g1 = half8_sum(g1); g2 = half8_sum(g2); lsum = half8_sum(lsum);
-        const bool head = j_on && vsub == 0;
-        if (head) {
-            atomicAdd(ldst + 0, g0 * sc);           // LDS; distinct targets for the reference joint maps
-            atomicAdd(ldst + 1, g1 * sc);
-            atomicAdd(ldst + 2, g2 * sc);
+#ifdef BF_STAMP
+        if (tid == 0 && bf_it == 2 && io.debug) io.debug[4096 + 43] = (float)(long long)(clock64() - bf_t0);
+#endif
+        // sum over the 16 view lanes of the pair (fixed DPP tree), route dL/dX to its source, and leave this wave's
+        // share of d/dt, d/ds and of the loss value for the Adam phase
+        float ga0 = row16_sum(g0.x), ga1 = row16_sum(g1.x), ga2 = row16_sum(g2.x), la = row16_sum(lsum.x);
+        float gb0 = row16_sum(g0.y), gb1 = row16_sum(g1.y), gb2 = row16_sum(g2.y), lb = row16_sum(lsum.y);
+        if (vsub == 0) {
+            if (ja_on) { atomicAdd(ldst_a + 0, ga0 * sc); atomicAdd(ldst_a + 1, ga1 * sc); atomicAdd(ldst_a + 2, ga2 * sc); }
+            if (jb_on) { atomicAdd(ldst_b + 0, gb0 * sc); atomicAdd(ldst_b + 1, gb1 * sc); atomicAdd(ldst_b + 2, gb2 * sc); }
         }
-        float gs = g0 * y0 + g1 * y1 + g2 * y2;
-        auto four = [&](float v) {                  // the wave's 8 joints (values uniform per 8-lane group), fixed order
-            float t[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) t[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), q * 8));
-            return ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+#ifdef BF_STAMP
+        if (tid == 0 && bf_it == 2 && io.debug) io.debug[4096 + 44] = (float)(long long)(clock64() - bf_t0);
+#endif
+        // (joints off the end have zero records: their sums are exactly 0)
+        const float gsa = ga0 * y0.x + ga1 * y1.x + ga2 * y2.x, gsb = gb0 * y0.y + gb1 * y1.y + gb2 * y2.y;
+        auto four = [&](float v) {                  // rows 0..3 of the wave, each row-uniform: (r0 + r1) + (r2 + r3)
+            float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+            float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+            float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+            float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+            return (a + b) + (c + d);
         };
-        float w0 = four(j_on ? g0 : 0.f), w1 = four(j_on ? g1 : 0.f), w2 = four(j_on ? g2 : 0.f);
-        float w3 = four(j_on ? gs : 0.f), w4 = four(j_on ? lsum : 0.f);
+        float w0 = four(ga0 + gb0), w1 = four(ga1 + gb1), w2 = four(ga2 + gb2);
+        float w3 = four(jb_on ? gsa + gsb : (ja_on ? gsa : 0.f)), w4 = four(la + lb);
         if (lane == 0 && wave < 4) {
             float *wp = S.part + wave * 8;
             wp[0] = w0; wp[1] = w1; wp[2] = w2; wp[3] = w3; wp[4] = w4;
@@ -394,7 +435,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
     if (gw) {
         // ================= GMM specialists (waves 4-7): the precision rows never leave their registers
-        typedef float v2f __attribute__((ext_vector_type(2)));
         v2f P2[BF_GMM_LD];                      // (row `lane` of component a, of component b), column j
         float Pt[12];
 #pragma unroll
@@ -475,8 +515,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
             BF_SYNC();                 // G
             BF_SYNC();                 // H
-            BF_SYNC();                 // I
-            BF_SYNC();                 // J
+            BF_SYNC();                 // I (+J)
             BF_SYNC();                 // K
             if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
         }
@@ -486,6 +525,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #ifdef BF_STAMP
         int sidx = 0;
         long long t_iter = clock64();
+        bf_it = it; bf_t0 = t_iter;
 #endif
         // ================= phase A: forward chain (waves 0-2) | shaped selector verts (wave 3) | GMM (waves 4-7)
         if (wave < 3) {
@@ -522,7 +562,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
                     S.rc[wj * 4] = rc[0]; S.rc[wj * 4 + 1] = rc[1]; S.rc[wj * 4 + 2] = rc[2];
                     if (wj > 0) {
-                        float *f = S.feat + (wj - 1) * 9;
+                        float *f = S.feat + w_feat;
                         f[0] = Ri[0] - 1.f; f[1] = Ri[1]; f[2] = Ri[2]; f[3] = Ri[3]; f[4] = Ri[4] - 1.f;
                         f[5] = Ri[5]; f[6] = Ri[6]; f[7] = Ri[7]; f[8] = Ri[8] - 1.f;
                     }
@@ -640,9 +680,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
             S.dAt[tid] = dat;
             S.dGt[tid] += ext ? dat + ext[EXT_G + tid] : dat;     // + dL/d(chain joint) of the dense keypoint loss
-            S.dGR[ci * 9 + cr * 3] = r0 - dat * S.J[ci * 3];
-            S.dGR[ci * 9 + cr * 3 + 1] = r1 - dat * S.J[ci * 3 + 1];
-            S.dGR[ci * 9 + cr * 3 + 2] = r2 - dat * S.J[ci * 3 + 2];
+            float4 drow0 = {r0 - dat * S.J[ci * 3], r1 - dat * S.J[ci * 3 + 1], r2 - dat * S.J[ci * 3 + 2], 0.f};
+            *(float4 *)(S.dGR + tid * 4) = drow0;
         }
         for (int idx = NG - 1 - tid; idx < ns3; idx += NG) {   // taken from the far end of the geometry waves
             int sv = idx / 3, b = idx - sv * 3;
@@ -661,7 +700,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 ttot += ((cmask >> k) & 1ull) ? v : 0.f;
             }
             S.tt[tid] = ttot;
-            float d0 = S.dGR[ci * 9 + cr * 3], d1 = S.dGR[ci * 9 + cr * 3 + 1], d2 = S.dGR[ci * 9 + cr * 3 + 2];
+            const float4 dq = *(const float4 *)(S.dGR + tid * 4);
+            float d0 = dq.x, d1 = dq.y, d2 = dq.z;
             dg0 = d0 * GR_(ci, 0, 0) + d1 * GR_(ci, 0, 1) + d2 * GR_(ci, 0, 2);     // row cr of D_i GR_i^T
             dg1 = d0 * GR_(ci, 1, 0) + d1 * GR_(ci, 1, 1) + d2 * GR_(ci, 1, 2);
             dg2 = d0 * GR_(ci, 2, 0) + d1 * GR_(ci, 2, 1) + d2 * GR_(ci, 2, 2);
@@ -694,40 +734,71 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (ok && hf == 0) {
                 float4 dgr = *(const float4 *)(S.Dg + q * 4);
                 s0 += dgr.x; s1 += dgr.y; s2 += dgr.z;
-                S.dGR[p * 9 + r * 3] = s0 * GR_(p, 0, 0) + s1 * GR_(p, 1, 0) + s2 * GR_(p, 2, 0);
-                S.dGR[p * 9 + r * 3 + 1] = s0 * GR_(p, 0, 1) + s1 * GR_(p, 1, 1) + s2 * GR_(p, 2, 1);
-                S.dGR[p * 9 + r * 3 + 2] = s0 * GR_(p, 0, 2) + s1 * GR_(p, 1, 2) + s2 * GR_(p, 2, 2);
+                float4 tot = {s0 * GR_(p, 0, 0) + s1 * GR_(p, 1, 0) + s2 * GR_(p, 2, 0),
+                              s0 * GR_(p, 0, 1) + s1 * GR_(p, 1, 1) + s2 * GR_(p, 2, 1),
+                              s0 * GR_(p, 0, 2) + s1 * GR_(p, 1, 2) + s2 * GR_(p, 2, 2), 0.f};
+                *(float4 *)(S.dGR + q * 4) = tot;
             }
         }
         BF_SYNC();
 
-        // ================= phase I: dL/dR_i and dL/d(rel_i) per joint column (cr plays the column b)
-        if (c_on) {
-            const int b = cr;
-            if (ci == 0) {
-                S.dR[b] = S.dGR[b]; S.dR[3 + b] = S.dGR[3 + b]; S.dR[6 + b] = S.dGR[6 + b];
-                S.drel[b] = S.tt[b];
-            } else {
-                float c0 = S.dGR[ci * 9 + b], c1 = S.dGR[ci * 9 + 3 + b], c2 = S.dGR[ci * 9 + 6 + b];
-                int pf = (ci - 1) * 9;
-                S.dR[ci * 9 + b] = GR_(cp, 0, 0) * c0 + GR_(cp, 1, 0) * c1 + GR_(cp, 2, 0) * c2 + S.dfeat[pf + b];
-                S.dR[ci * 9 + 3 + b] = GR_(cp, 0, 1) * c0 + GR_(cp, 1, 1) * c1 + GR_(cp, 2, 1) * c2 + S.dfeat[pf + 3 + b];
-                S.dR[ci * 9 + 6 + b] = GR_(cp, 0, 2) * c0 + GR_(cp, 1, 2) * c1 + GR_(cp, 2, 2) * c2 + S.dfeat[pf + 6 + b];
-                S.drel[tid] = GR_(cp, 0, b) * S.tt[ci * 3] + GR_(cp, 1, b) * S.tt[ci * 3 + 1] + GR_(cp, 2, b) * S.tt[ci * 3 + 2];
-            }
-        }
-        BF_SYNC();
-
-        // ================= phase J: Rodrigues reverse (wave 0) | geometric part of dL/dbeta (waves 1-3)
+        // ================= phase I: per joint (wave 0, lane = joint) dL/dR_i = GR_p^T dGR_i + d(pose feature), then the
+        // Rodrigues reverse on the same lane | geometric part of dL/dbeta (waves 1-3), with dL/drel_i = GR_p^T t_i
+        // formed inline so that nothing here waits for another wave
         if (tid < nj) {
-            rodrigues_bwd(S.theta[tid * 3], S.theta[tid * 3 + 1], S.theta[tid * 3 + 2], S.rc + tid * 4, S.dR + tid * 9, S.gth + tid * 3);
+            const float4 g0 = *(const float4 *)(S.G + wp * 12), g1 = *(const float4 *)(S.G + wp * 12 + 4),
+                         g2 = *(const float4 *)(S.G + wp * 12 + 8);
+            const float4 c0 = *(const float4 *)(S.dGR + tid * 12), c1 = *(const float4 *)(S.dGR + tid * 12 + 4),
+                         c2 = *(const float4 *)(S.dGR + tid * 12 + 8);
+            const float t0 = S.tt[tid * 3], t1 = S.tt[tid * 3 + 1], t2 = S.tt[tid * 3 + 2];
+            float dRl[9], drl[3];
+            if (tid == 0) {
+                dRl[0] = c0.x; dRl[1] = c0.y; dRl[2] = c0.z; dRl[3] = c1.x; dRl[4] = c1.y; dRl[5] = c1.z;
+                dRl[6] = c2.x; dRl[7] = c2.y; dRl[8] = c2.z;
+                drl[0] = t0; drl[1] = t1; drl[2] = t2;
+            } else {
+                const float *df = S.dfeat + (tid - 1) * 9;
+                dRl[0] = g0.x * c0.x + g1.x * c1.x + g2.x * c2.x + df[0];
+                dRl[1] = g0.x * c0.y + g1.x * c1.y + g2.x * c2.y + df[1];
+                dRl[2] = g0.x * c0.z + g1.x * c1.z + g2.x * c2.z + df[2];
+                dRl[3] = g0.y * c0.x + g1.y * c1.x + g2.y * c2.x + df[3];
+                dRl[4] = g0.y * c0.y + g1.y * c1.y + g2.y * c2.y + df[4];
+                dRl[5] = g0.y * c0.z + g1.y * c1.z + g2.y * c2.z + df[5];
+                dRl[6] = g0.z * c0.x + g1.z * c1.x + g2.z * c2.x + df[6];
+                dRl[7] = g0.z * c0.y + g1.z * c1.y + g2.z * c2.y + df[7];
+                dRl[8] = g0.z * c0.z + g1.z * c1.z + g2.z * c2.z + df[8];
+                drl[0] = g0.x * t0 + g1.x * t1 + g2.x * t2;
+                drl[1] = g0.y * t0 + g1.y * t1 + g2.y * t2;
+                drl[2] = g0.z * t0 + g1.z * t1 + g2.z * t2;
+            }
+            if (mode == 1) {                         // (kept for the debug dump only)
+#pragma unroll
+                for (int e = 0; e < 9; ++e) S.dR[tid * 9 + e] = dRl[e];
+                S.drel[tid * 3] = drl[0]; S.drel[tid * 3 + 1] = drl[1]; S.drel[tid * 3 + 2] = drl[2];
+            }
+            rodrigues_bwd(S.theta[tid * 3], S.theta[tid * 3 + 1], S.theta[tid * 3 + 2], S.rc + tid * 4, dRl, S.gth + tid * 3);
         }
         if (wave >= 1 && wave < 4) {
             // 16 lanes per beta component: sum Jd.dJ + Jdrel.drel + sel_sd.dvp
             int q = tid - 64, l = q >> 4, sl = q & 15;
             float acc = 0.f;
             if (l < nb) {
-                for (int i = sl; i < nj3; i += 16) acc += S.Jd[i * nb + l] * S.dJ[i] + S.Jdrel[i * nb + l] * S.drel[i];
+                for (int i = sl; i < nj; i += 16) {
+                    const int p = i > 0 ? S.par[i] : 0;
+                    const float t0 = S.tt[i * 3], t1 = S.tt[i * 3 + 1], t2 = S.tt[i * 3 + 2];
+                    float e0 = t0, e1 = t1, e2 = t2;
+                    if (i > 0) {
+                        const float4 g0 = *(const float4 *)(S.G + p * 12), g1 = *(const float4 *)(S.G + p * 12 + 4),
+                                     g2 = *(const float4 *)(S.G + p * 12 + 8);
+                        e0 = g0.x * t0 + g1.x * t1 + g2.x * t2;
+                        e1 = g0.y * t0 + g1.y * t1 + g2.y * t2;
+                        e2 = g0.z * t0 + g1.z * t1 + g2.z * t2;
+                    }
+                    const float *jd = S.Jd + i * 3 * nb + l, *jr = S.Jdrel + i * 3 * nb + l;
+                    acc += jd[0] * S.dJ[i * 3] + jr[0] * e0;
+                    acc += jd[nb] * S.dJ[i * 3 + 1] + jr[nb] * e1;
+                    acc += jd[2 * nb] * S.dJ[i * 3 + 2] + jr[2 * nb] * e2;
+                }
                 for (int o = sl; o < ns3; o += 16) acc += S.sel_sd[o * nb + l] * S.dvp[o];
             }
             acc = row16_sum(acc);
@@ -737,7 +808,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
         // ================= phase K: priors, gradient assembly, Adam (one parameter per thread)
         const int mstar = (int)S.scal[1];
-        const float qmin = S.scal[2];
         float grad = 0.f, pval = 0.f;
         if (tid < np) {
             pval = Pcur[tid];
@@ -763,51 +833,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 grad = acc;
             }
         }
-        bool last = it == n_iters - 1;
-        if (last || mode == 1) {
-            // loss terms of this evaluation (loss.py:219-224) and the pose state of this forward pass
-            if (tid == 0) {
-                float *tm = io.terms + (size_t)frame * 4;
-                if (!T.kp_dense) {                                   // (the dense keypoint kernel owns it otherwise)
-                    float acc = 0.f;
-                    for (int w = 0; w < 4; ++w) acc += S.part[w * 8 + 4];
-                    tm[0] = acc / ndiv_f;
-                }
-                tm[1] = hp.w_pose * qmin;
-            }
-            if (tid == 64) {
-                float acc = 0.f;
-                const int ai[4] = {52, 55, 9, 12};
-                const float as[4] = {1.f, -1.f, -1.f, -1.f};
-                for (int k = 0; k < 4; ++k) {
-                    float th = ai[k] < T.nbp ? Pcur[T.off_pose + ai[k]] : 0.f;
-                    float e = expf(th * as[k]);
-                    acc += e * e;
-                }
-                io.terms[(size_t)frame * 4 + 2] = hp.w_angle * acc;
-            }
-            if (tid == 128) {
-                float acc = 0.f;
-                for (int l = 0; l < nb; ++l) acc += Pcur[T.off_beta + l] * Pcur[T.off_beta + l];
-                io.terms[(size_t)frame * 4 + 3] = hp.w_shape * acc;
-            }
-            StateView st = bf_state_view(io.state + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
-            for (int i = tid; i < nj * 9; i += NG) { int j = i / 9, e = i - j * 9; st.GR[i] = GR_(j, e / 3, e % 3); }
-            for (int i = tid; i < nj3; i += NG) { st.At[i] = S.At[i]; st.Gt[i] = GT_(i / 3, i % 3); st.theta[i] = S.theta[i]; }
-            for (int p = tid; p < npf; p += NG) st.feat[p] = S.feat[p];
-            if (tid < nb) st.beta[tid] = Pcur[T.off_beta + tid];
-            if (tid < 3) st.t[tid] = Pcur[tid];
-            if (tid == 3) { st.sc[0] = Pcur[3]; st.sc[1] = cscale; }
-            if (io.grads && tid < np) io.grads[(size_t)frame * np + tid] = grad;
-        }
-        if (io.debug && it == 0 && frame == 0 && mode == 1) {
-            float *d = io.debug;
-            int o = 0;
-            auto dump = [&](const float *src, int n) { for (int i = tid; i < n; i += NG) d[o + i] = src[i]; o += n; };
-            dump(S.R, nj * 9); dump(S.J, nj3); dump(S.G, nj * 12); dump(S.vp, ns3);
-            dump(S.vsel, ns3); dump(S.g, 4); dump(S.dGR, nj * 9); dump(S.tt, nj3); dump(S.dR, nj * 9);
-            dump(S.gth, nj3); dump(S.gq, BF_GMM_M); dump(S.dfeat, npf); dump(S.dJ, nj3); dump(S.drel, nj3);
-        }
+        grad_last = grad;
         if (mode == 0 && tid < np) {
             // torch.optim.Adam, single-tensor path
             const float *at = adam_tab + (size_t)(adam_t0 + it) * 3;
@@ -819,6 +845,57 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         BF_SYNC();
         if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
+    }
+    {   // ---- after the last iteration: loss terms (loss.py:219-224) and the pose state of the LAST forward pass, i.e. of
+        // the parameters before the final Adam step (they sit in Pnext after the swap)
+        const float *Pold = mode == 0 ? Pnext : Pcur;
+        const float grad = grad_last;
+        {
+            if (tid == 0) {
+                float *tm = io.terms + (size_t)frame * 4;
+                if (!T.kp_dense) {                                   // (the dense keypoint kernel owns it otherwise)
+                    float acc = 0.f;
+                    for (int w = 0; w < 4; ++w) acc += S.part[w * 8 + 4];
+                    tm[0] = acc / ndiv_f;
+                }
+                tm[1] = hp.w_pose * S.scal[2];
+            }
+            if (tid == 64) {
+                float acc = 0.f;
+                const int ai[4] = {52, 55, 9, 12};
+                const float as[4] = {1.f, -1.f, -1.f, -1.f};
+                for (int k = 0; k < 4; ++k) {
+                    float th = ai[k] < T.nbp ? Pold[T.off_pose + ai[k]] : 0.f;
+                    float e = expf(th * as[k]);
+                    acc += e * e;
+                }
+                io.terms[(size_t)frame * 4 + 2] = hp.w_angle * acc;
+            }
+            if (tid == 128) {
+                float acc = 0.f;
+                for (int l = 0; l < nb; ++l) acc += Pold[T.off_beta + l] * Pold[T.off_beta + l];
+                io.terms[(size_t)frame * 4 + 3] = hp.w_shape * acc;
+            }
+            StateView st = bf_state_view(io.state + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
+            for (int i = tid; i < nj * 9; i += NG) { int j = i / 9, e = i - j * 9; st.GR[i] = GR_(j, e / 3, e % 3); }
+            for (int i = tid; i < nj3; i += NG) { st.At[i] = S.At[i]; st.Gt[i] = GT_(i / 3, i % 3); st.theta[i] = S.theta[i]; }
+            for (int p = tid; p < npf; p += NG) st.feat[p] = S.feat[p];
+            if (tid < nb) st.beta[tid] = Pold[T.off_beta + tid];
+            if (tid < 3) st.t[tid] = Pold[tid];
+            if (tid == 3) { st.sc[0] = Pold[3]; st.sc[1] = cscale; }
+            if (io.grads && tid < np) io.grads[(size_t)frame * np + tid] = grad;
+        }
+        if (io.debug && frame == 0 && mode == 1) {
+            float *d = io.debug;
+            int o = 0;
+            auto dump = [&](const float *src, int n) { for (int i = tid; i < n; i += NG) d[o + i] = src[i]; o += n; };
+            dump(S.R, nj * 9); dump(S.J, nj3); dump(S.G, nj * 12); dump(S.vp, ns3);
+            dump(S.vsel, ns3); dump(S.g, 4);
+            for (int i = tid; i < nj * 9; i += NG) d[o + i] = S.dGR[(i / 3) * 4 + i % 3];
+            o += nj * 9;
+            dump(S.tt, nj3); dump(S.dR, nj * 9);
+            dump(S.gth, nj3); dump(S.gq, BF_GMM_M); dump(S.dfeat, npf); dump(S.dJ, nj3); dump(S.drel, nj3);
+        }
     }
 
     }
@@ -839,11 +916,11 @@ extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int
 extern "C" hipError_t bf_fit_launch(const FitTab *T, const FrameIO *io, const HyperDev *hp, int n_iters, int mode,
                                     const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
     const bool smpl = T->nj == 24 && T->nb == 10 && T->ns == 11 && T->nl == 25;
-    auto k_smpl = fit_kernel<24, 10, 11, 25>;
-    auto k_any = fit_kernel<0, 0, 0, 0>;
-    auto kern = smpl ? k_smpl : k_any;
-    static size_t attr_smpl = 0, attr_any = 0;
-    size_t &have = smpl ? attr_smpl : attr_any;
+    const bool ext = io->ext != nullptr;
+    auto kern = smpl ? (ext ? fit_kernel<24, 10, 11, 25, true> : fit_kernel<24, 10, 11, 25, false>)
+                     : (ext ? fit_kernel<0, 0, 0, 0, true> : fit_kernel<0, 0, 0, 0, false>);
+    static size_t attr[4] = {0, 0, 0, 0};
+    size_t &have = attr[(smpl ? 2 : 0) + (ext ? 1 : 0)];
     if (smem > 64 * 1024 && smem > have) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
