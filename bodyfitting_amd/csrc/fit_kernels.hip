@@ -45,7 +45,8 @@ struct FitSmem {
     float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
     float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *Jdp, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp;
-    int *nzj, *thk, *tho, *par;
+    int *nzj, *thk, *tho, *par, *pk, *pa_, *pb_;
+    float *am, *av;
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
@@ -70,7 +71,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.feat = take(npf);                s.vpp = take(BF_FIT_THREADS + ns * 3);
     s.Jtrel = take(nj * 3); s.Dg = take(nj * 12);
     s.Jt = take(nj * 3);   s.Jd = take(nj * 3 * nb);      s.Jdrel = take(nj * 3 * nb);
-    s.Jdp = take(nj * 3 * pad4(nb));
+    s.Jdp = take(nj * 3 * pad4(nb + 1));
     s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * nb); s.sel_pd = take(npf * ns * 3);
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
     s.proj = take(nviews * 12);
@@ -78,6 +79,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.kp = take(BF_VSUB * BF_KP_ROUNDS * 16 * 8);      // 8-float keypoint record per (view, loss-joint pair), zero padded
     s.theta = take(nj * 3);  s.pmean = take(nj * 3);  s.hcomp = take(2 * 6 * 45);
     s.thk = (int *)take(nj); s.tho = (int *)take(nj); s.par = (int *)take(nj);
+    s.pk = (int *)take(np); s.pa_ = (int *)take(np); s.pb_ = (int *)take(np); s.am = take(np); s.av = take(np);
     (void)nl;
     return o * sizeof(float);
 }
@@ -211,8 +213,12 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     copy_f(S.Jtrel, T.Jtrel, nj3, tid, nt);
     copy_f(S.Jd, T.Jd, nj3 * nb, tid, nt);
     copy_f(S.Jdrel, T.Jdrel, nj3 * nb, tid, nt);
-    const int nb4 = pad4(nb);                  // Jdrel again with rows padded to float4s, for the chain lanes' b128 reads
-    for (int i = tid; i < nj3 * nb4; i += nt) { int r = i / nb4, l = i - r * nb4; S.Jdp[i] = l < nb ? T.Jdrel[r * nb + l] : 0.f; }
+    // Jdrel again with rows padded to float4s for the chain lanes' b128 reads; column nb holds Jtrel (it meets a 1)
+    const int nb4 = pad4(nb + 1);
+    for (int i = tid; i < nj3 * nb4; i += nt) {
+        int r = i / nb4, l = i - r * nb4;
+        S.Jdp[i] = l < nb ? T.Jdrel[r * nb + l] : (l == nb ? T.Jtrel[r] : 0.f);
+    }
     copy_f(S.sel_vt, T.sel_vt, ns3, tid, nt);
     copy_f(S.sel_sd, T.sel_sd, ns3 * nb, tid, nt);
     copy_f(S.sel_pd, T.sel_pd, npf * ns3, tid, nt);
@@ -242,11 +248,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int wd = cw_on ? T.depth[wj] : -1;
     const int w_feat = (wj > 0 ? wj - 1 : 0) * 9;          // (non-negative base: the nine stores share one address register)
     const int w_kind = T.th_kind[wj], w_off = T.th_off[wj];
-    float w_jt[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) w_jt[k] = cw_on ? T.Jtrel[wj * 3 + k] : 0.f;
-    const float w_pm0 = T.pose_mean ? T.pose_mean[wj * 3] : 0.f, w_pm1 = T.pose_mean ? T.pose_mean[wj * 3 + 1] : 0.f,
-                w_pm2 = T.pose_mean ? T.pose_mean[wj * 3 + 2] : 0.f;
+    const float w_pm0 = (NJ != 24 && T.pose_mean) ? T.pose_mean[wj * 3] : 0.f, w_pm1 = (NJ != 24 && T.pose_mean) ? T.pose_mean[wj * 3 + 1] : 0.f,
+                w_pm2 = (NJ != 24 && T.pose_mean) ? T.pose_mean[wj * 3 + 2] : 0.f;      // (SMPL has no pose mean)
     // (joint, row) role of the reverse sweep: tid < 3 nj
     const bool c_on = tid < nj3;
     const int ci = c_on ? tid / 3 : 0, cr = c_on ? tid - ci * 3 : 0;
@@ -328,13 +331,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int rows_sl = (npf + NSL - 1) / NSL;
 
     // Adam role: parameter `tid`, its moments in registers
-    float am = 0.f, av = 0.f;
-    if (tid < np) { am = io.adam_m[(size_t)frame * np + tid]; av = io.adam_v[(size_t)frame * np + tid]; }
-    const int pk = tid < np ? T.p_kind[tid] : 0, pa = tid < np ? T.p_a[tid] : 0, pb = tid < np ? T.p_b[tid] : -1;
+    // Adam role: parameter `tid`; its moments and descriptor live in LDS (read once per iteration, in the Adam phase)
+    for (int i = tid; i < np; i += nt) {
+        S.am[i] = io.adam_m[(size_t)frame * np + i]; S.av[i] = io.adam_v[(size_t)frame * np + i];
+        S.pk[i] = T.p_kind[i]; S.pa_[i] = T.p_a[i]; S.pb_[i] = T.p_b[i];
+    }
     int hand_j0_l = 0, hand_j0_r = 0;          // first joint of each hand
     for (int j = nj - 1; j >= 0; --j) { if (T.th_kind[j] == 2) hand_j0_l = j; if (T.th_kind[j] == 3) hand_j0_r = j; }
-    float ang_sg = 0.f;                        // angle prior sign (loss.py:54-61: body dofs 52, 55, 9, 12)
-    if (pk == 1 && pb >= 0) ang_sg = pb == 52 ? 1.f : ((pb == 55 || pb == 9 || pb == 12) ? -1.f : 0.f);
     __syncthreads();
 
 #ifdef BF_STAMP
@@ -344,14 +347,30 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     float grad_last = 0.f;
     // phases shared by both wave roles
     auto pose_blend = [&]() {
+        constexpr int RS = (NJ && NS) ? (9 * (NJ - 1) + (BF_FIT_THREADS / (NS * 3)) - 1) / (BF_FIT_THREADS / (NS * 3)) : 0;
         for (int idx = tid; idx < ns3 * NSL; idx += nt) {
-        int sl = idx / ns3, o = idx - sl * ns3;
-        int p0 = sl * rows_sl, p1 = min(npf, p0 + rows_sl);
-        float acc = 0.f;
-        const float *pd = S.sel_pd + p0 * ns3 + o;
-        for (int p = p0; p < p1; ++p, pd += ns3) acc += S.feat[p] * pd[0];
-        S.vpp[idx] = acc;
-    }
+            int sl = idx / ns3, o = idx - sl * ns3;
+            int p0 = sl * rows_sl, p1 = min(npf, p0 + rows_sl);
+            float acc = 0.f;
+            const float *pd = S.sel_pd + p0 * ns3 + o;
+            if (RS > 0) {
+                // compile-time slice length: every LDS read is issued before the first multiply-add (one wait instead of
+                // one per pair), rows past the end are clamped and weighted 0
+                float f[RS > 0 ? RS : 1], w[RS > 0 ? RS : 1];
+#pragma unroll
+                for (int i = 0; i < RS; ++i) {
+                    const int p = min(p0 + i, npf - 1);
+                    f[i] = S.feat[p];
+                    w[i] = S.sel_pd[p * ns3 + o];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < RS; ++i) acc += (p0 + i < p1 ? f[i] : 0.f) * w[i];
+            } else {
+                for (int p = p0; p < p1; ++p, pd += ns3) acc += S.feat[p] * pd[0];
+            }
+            S.vpp[idx] = acc;
+        }
     };
     typedef float v2f __attribute__((ext_vector_type(2)));
     auto project = [&]() {
@@ -538,25 +557,26 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 rodrigues_fwd(th0, th1, th2, Ri, rc);
                 if (wave == 0) { S.theta[wj * 3] = th0; S.theta[wj * 3 + 1] = th1; S.theta[wj * 3 + 2] = th2; }
                 // rel_j = J_j - J_parent straight from the pre-contracted difference tables (rel_0 = J_0)
-                const float *beta = Pcur + T.off_beta;          // (table entries past nb are zero padding)
+                const float *beta = Pcur + T.off_beta;          // (column nb is Jtrel x 1; the rest is zero padding)
+                auto bcol = [&](int c) { return c < nb ? beta[c] : (c == nb ? 1.0f : 0.f); };
                 const float4 *jq = (const float4 *)(S.Jdp + wj * 3 * nb4);
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-                for (int q = 0; q < (NB ? (NB + 3) / 4 : 3); ++q) {
+                for (int q = 0; q < (NB ? (NB + 4) / 4 : 3); ++q) {
                     if (q * 4 < nb4) {
-                        float4 b = {beta[4 * q], 4 * q + 1 < nb ? beta[4 * q + 1] : 0.f, 4 * q + 2 < nb ? beta[4 * q + 2] : 0.f, 4 * q + 3 < nb ? beta[4 * q + 3] : 0.f}, j0 = jq[q], j1 = jq[nb4 / 4 + q], j2 = jq[2 * (nb4 / 4) + q];
+                        float4 b = {bcol(4 * q), bcol(4 * q + 1), bcol(4 * q + 2), bcol(4 * q + 3)}, j0 = jq[q], j1 = jq[nb4 / 4 + q], j2 = jq[2 * (nb4 / 4) + q];
                         a0 += j0.x * b.x + j0.y * b.y + j0.z * b.z + j0.w * b.w;
                         a1 += j1.x * b.x + j1.y * b.y + j1.z * b.z + j1.w * b.w;
                         a2 += j2.x * b.x + j2.y * b.y + j2.z * b.z + j2.w * b.w;
                     }
                 }
-                for (int q = (NB ? (NB + 3) / 4 : 3); q * 4 < nb4; ++q) {
-                    float4 b = {beta[4 * q], 4 * q + 1 < nb ? beta[4 * q + 1] : 0.f, 4 * q + 2 < nb ? beta[4 * q + 2] : 0.f, 4 * q + 3 < nb ? beta[4 * q + 3] : 0.f}, j0 = jq[q], j1 = jq[nb4 / 4 + q], j2 = jq[2 * (nb4 / 4) + q];
+                for (int q = (NB ? (NB + 4) / 4 : 3); q * 4 < nb4; ++q) {
+                    float4 b = {bcol(4 * q), bcol(4 * q + 1), bcol(4 * q + 2), bcol(4 * q + 3)}, j0 = jq[q], j1 = jq[nb4 / 4 + q], j2 = jq[2 * (nb4 / 4) + q];
                     a0 += j0.x * b.x + j0.y * b.y + j0.z * b.z + j0.w * b.w;
                     a1 += j1.x * b.x + j1.y * b.y + j1.z * b.z + j1.w * b.w;
                     a2 += j2.x * b.x + j2.y * b.y + j2.z * b.z + j2.w * b.w;
                 }
-                rel0 = w_jt[0] + a0; rel1 = w_jt[1] + a1; rel2 = w_jt[2] + a2;
+                rel0 = a0; rel1 = a1; rel2 = a2;
                 if (wave == 0) {
 #pragma unroll
                     for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
@@ -636,22 +656,45 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             bool ok = o < ns3;
             int sv = ok ? o / 3 : 0, k = ok ? o - sv * 3 : 0;
             float t = 0.f, vpb = 1.f;
+            constexpr int CSL = (NJ && NS) ? BF_FIT_THREADS / (NS * 3) : 0;      // compile-time slice count (SMPL instance)
             if (ok) {
-                if (b < 3) {
-                    float acc = 0.f;
-                    for (int sl = 0; sl < NSL; ++sl) acc += S.vpp[sl * ns3 + sv * 3 + b];
-                    vpb = S.vs[sv * 3 + b] + acc;
-                    if (k == 0) S.vp[sv * 3 + b] = vpb;
-                }
                 const float *A = b < 3 ? S.G + k * 4 + b : S.At + k;
                 const int stride = b < 3 ? 12 : 3;
-                if (sel_nnz > 0) {                 // the non-zero skinning weights only (exact: the rest add 0)
+                const int bb = b < 3 ? b : 0;
+                if (CSL > 0 && sel_nnz > 0) {
+                    // all LDS reads of the lane in two batches: (pose-blend slices, weights, bone indices), then the bones
+                    float pv[CSL > 0 ? CSL : 1], wq[BF_SEL_NNZ], aq[BF_SEL_NNZ];
+                    int jq[BF_SEL_NNZ];
 #pragma unroll
-                    for (int q = 0; q < BF_SEL_NNZ; ++q) t += S.nzw[sv * BF_SEL_NNZ + q] * A[S.nzj[sv * BF_SEL_NNZ + q] * stride];
+                    for (int sl = 0; sl < CSL; ++sl) pv[sl] = S.vpp[sl * ns3 + sv * 3 + bb];
+                    const float vs0 = S.vs[sv * 3 + bb];
+#pragma unroll
+                    for (int q = 0; q < BF_SEL_NNZ; ++q) { wq[q] = S.nzw[sv * BF_SEL_NNZ + q]; jq[q] = S.nzj[sv * BF_SEL_NNZ + q]; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < BF_SEL_NNZ; ++q) aq[q] = A[jq[q] * stride];
+                    float acc = 0.f;
+#pragma unroll
+                    for (int sl = 0; sl < CSL; ++sl) acc += pv[sl];
+                    if (b < 3) { vpb = vs0 + acc; if (k == 0) S.vp[sv * 3 + b] = vpb; }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < BF_SEL_NNZ; ++q) t += wq[q] * aq[q];
                 } else {
-                    const float *w = S.sel_w + sv * nj;
+                    if (b < 3) {
+                        float acc = 0.f;
+                        for (int sl = 0; sl < NSL; ++sl) acc += S.vpp[sl * ns3 + sv * 3 + b];
+                        vpb = S.vs[sv * 3 + b] + acc;
+                        if (k == 0) S.vp[sv * 3 + b] = vpb;
+                    }
+                    if (sel_nnz > 0) {                 // the non-zero skinning weights only (exact: the rest add 0)
 #pragma unroll
-                    for (int j = 0; j < nj; ++j) t += w[j] * A[j * stride];
+                        for (int q = 0; q < BF_SEL_NNZ; ++q) t += S.nzw[sv * BF_SEL_NNZ + q] * A[S.nzj[sv * BF_SEL_NNZ + q] * stride];
+                    } else {
+                        const float *w = S.sel_w + sv * nj;
+#pragma unroll
+                        for (int j = 0; j < nj; ++j) t += w[j] * A[j * stride];
+                    }
                 }
                 if (b < 3) S.TR[sv * 9 + k * 3 + b] = t;
             }
@@ -742,6 +785,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         BF_SYNC();
 
+        // (this step's Adam constants: a global read, issued a phase ahead of its use)
+        const float *at = adam_tab + (size_t)(adam_t0 + it) * 3;
+        const float at0 = at[0], at1 = at[1], at2 = at[2];
         // ================= phase I: per joint (wave 0, lane = joint) dL/dR_i = GR_p^T dGR_i + d(pose feature), then the
         // Rodrigues reverse on the same lane | geometric part of dL/dbeta (waves 1-3), with dL/drel_i = GR_p^T t_i
         // formed inline so that nothing here waits for another wave
@@ -806,25 +852,37 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         BF_SYNC();
 
-        // ================= phase K: priors, gradient assembly, Adam (one parameter per thread)
-        const int mstar = (int)S.scal[1];
-        float grad = 0.f, pval = 0.f;
+        // ================= phase K: priors, gradient assembly, Adam (one parameter per thread).  Two batches of LDS
+        // reads: (value, moments, descriptor), then every candidate gradient source at a clamped index; the parameter
+        // kind selects afterwards.
+        float grad = 0.f, pval = 0.f, am = 0.f, av = 0.f;
         if (tid < np) {
             pval = Pcur[tid];
-            if (pk == 0) {                                           // transl / scale: sum the 8 waves' shares in wave order
-                float acc = 0.f;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) acc += S.part[w * 8 + tid];
-                grad = acc * (tid < 3 ? Pcur[3] * cscale : cscale) + (ext ? ext[EXT_T + tid] + ext[EXT_K + tid] : 0.f);
+            am = S.am[tid]; av = S.av[tid];
+            const int pk = S.pk[tid], pa = S.pa_[tid], pb = S.pb_[tid];
+            const int mstar = (int)S.scal[1];
+            const float sc3 = Pcur[3];
+            __builtin_amdgcn_sched_barrier(0);
+            const int t8 = tid < 8 ? tid : 0;
+            const float p0 = S.part[t8], p1 = S.part[8 + t8], p2 = S.part[16 + t8], p3 = S.part[24 + t8];
+            const float gth_v = S.gth[pk == 1 ? pa : 0];
+            const float gy_v = S.gy[mstar * BF_GMM_LD + (pb >= 0 && pb < BF_GMM_LD ? pb : 0)];
+            const float g_v = S.g[tid];
+            __builtin_amdgcn_sched_barrier(0);
+            // angle prior sign (loss.py:54-61: body dofs 52, 55, 9, 12)
+            const float ang_sg = (pk == 1 && pb >= 0) ? (pb == 52 ? 1.f : ((pb == 55 || pb == 9 || pb == 12) ? -1.f : 0.f)) : 0.f;
+            if (pk == 0) {                                           // transl / scale: the geometry waves' shares in wave order
+                const float acc = ((p0 + p1) + p2) + p3;
+                grad = acc * (tid < 3 ? sc3 * cscale : cscale) + (ext ? ext[EXT_T + tid] + ext[EXT_K + tid] : 0.f);
                 S.g[tid] = grad;                                     // (kept for the debug dump)
             }
             else if (pk == 1) {
-                grad = S.gth[pa];
+                grad = gth_v;
                 if (pb >= 0) {                                       // body-pose dof pb: GMM + angle priors
-                    grad += hp.w_pose * S.gy[mstar * BF_GMM_LD + pb];
-                    if (ang_sg != 0.f) { float e = expf(pval * ang_sg); grad += hp.w_angle * 2.f * e * e * ang_sg; }
+                    grad += hp.w_pose * gy_v;
+                    if (ang_sg != 0.f) { float e = __expf(pval * ang_sg); grad += hp.w_angle * 2.f * e * e * ang_sg; }
                 }
-            } else if (pk == 2) grad = S.g[tid] + 2.f * hp.w_shape * pval;
+            } else if (pk == 2) grad = g_v + 2.f * hp.w_shape * pval;
             else {                                                   // hand PCA coefficient pb of hand pa
                 const float *comp = S.hcomp + (pa * T.n_pca + pb) * 45;
                 const float *gh = S.gth + (pa == 0 ? hand_j0_l : hand_j0_r) * 3;
@@ -836,12 +894,12 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         grad_last = grad;
         if (mode == 0 && tid < np) {
             // torch.optim.Adam, single-tensor path
-            const float *at = adam_tab + (size_t)(adam_t0 + it) * 3;
             am = am + (grad - am) * (1.0f - hp.beta1);
             av = av * hp.beta2 + (1.0f - hp.beta2) * grad * grad;
-            float denom = sqrtf(av) / at[2] + hp.eps;
-            float step = tid < 4 ? at[0] : at[1];
+            float denom = sqrtf(av) / at2 + hp.eps;
+            float step = tid < 4 ? at0 : at1;
             Pnext[tid] = pval - step * (am / denom);
+            S.am[tid] = am; S.av[tid] = av;
         }
         BF_SYNC();
         if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
@@ -902,8 +960,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
     if (mode == 0 && tid < np) {
         io.params[(size_t)frame * np + tid] = Pcur[tid];
-        io.adam_m[(size_t)frame * np + tid] = am;
-        io.adam_v[(size_t)frame * np + tid] = av;
+        io.adam_m[(size_t)frame * np + tid] = S.am[tid];
+        io.adam_v[(size_t)frame * np + tid] = S.av[tid];
     }
 }
 
