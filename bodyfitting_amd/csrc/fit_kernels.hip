@@ -91,6 +91,7 @@ __device__ inline float dpp_add(float v) {
     int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true);
     return v + __int_as_float(r);
 }
+__device__ inline int bf_launder(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ inline float quad_sum(float v) { v = dpp_add<0xB1>(v); return dpp_add<0x4E>(v); }        // all 4 lanes of a quad
 __device__ inline float half8_sum(float v) { v = quad_sum(v); return dpp_add<0x141>(v); }             // 8 lanes: + row_half_mirror
 __device__ inline float row16_sum(float v) { v = quad_sum(v); v = dpp_add<0x124>(v); return dpp_add<0x128>(v); }   // all 16 lanes of a row
@@ -452,6 +453,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
     };
 
+#ifndef BF_NO_GMM
     if (gw) {
         // ================= GMM specialists (waves 4-7): the precision rows never leave their registers
         v2f P2[BF_GMM_LD];                      // (row `lane` of component a, of component b), column j
@@ -538,7 +540,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             BF_SYNC();                 // K
             if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
         }
-    } else {
+    } else
+#endif
+    {
     // ================= geometry waves (0-3)
     for (int it = 0; it < n_iters; ++it) {
 #ifdef BF_STAMP
@@ -636,23 +640,28 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         BF_SYNC();
 
+        {
         // ================= phase B: pose blend of the selector vertices, partial sums over row slices
+        const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
         pose_blend();
         if (c_on)                                   // A_j translation: Gt_j - GR_j J_j
-            S.At[tid] = GT_(ci, cr) - (GR_(ci, cr, 0) * S.J[ci * 3] + GR_(ci, cr, 1) * S.J[ci * 3 + 1] + GR_(ci, cr, 2) * S.J[ci * 3 + 2]);
-        if (tid == NG - 1) {                        // arg-min GMM component (prior.py:195), ready long before the Adam phase
+            S.At[tq] = GT_(ci, cr) - (GR_(ci, cr, 0) * S.J[ci * 3] + GR_(ci, cr, 1) * S.J[ci * 3 + 1] + GR_(ci, cr, 2) * S.J[ci * 3 + 2]);
+        if (tq == NG - 1) {                        // arg-min GMM component (prior.py:195), ready long before the Adam phase
             int ms = 0;
             float qm = S.gq[0];
 #pragma unroll
             for (int m = 1; m < BF_GMM_M; ++m) { float q = S.gq[m]; if (q < qm) { qm = q; ms = m; } }
             S.scal[1] = (float)ms; S.scal[2] = qm;
         }
+        }
         BF_SYNC();
 
+        {
         // ================= phase C: finish the pose blend; skin the selector vertices.  Lane b of a quad owns
         // column b of row k of T_s = sum_j w_sj A_j
+        const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
         for (int base = 0; base < ns3 * 4; base += nt) {
-            int o = (base + tid) >> 2, b = tid & 3;
+            int o = (base + tq) >> 2, b = tq & 3;
             bool ok = o < ns3;
             int sv = ok ? o / 3 : 0, k = ok ? o - sv * 3 : 0;
             float t = 0.f, vpb = 1.f;
@@ -702,76 +711,141 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             contrib = quad_sum(contrib);
             if (ok && b == 0) S.vsel[o] = contrib;
         }
+        }
         BF_SYNC();
 
         // ================= phase D: similarity, multi-view projection, GMoF and its gradient
         project();
         BF_SYNC();
 
+        {
         // ================= phase F: reverse skinning of the selector vertices
+        const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
+        const int ci = tq / 3, cr = tq - ci * 3;
         if (c_on) {
             float dat = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+            if (NS > 0) {
+                // every LDS read first (weights, dL/dvsel, the posed vertices as b128), then the arithmetic
+                constexpr int NSC = NS > 0 ? NS : 1;
+                float wv[NSC], dv[NSC];
+                float4 vq[(NSC * 3 + 3) / 4];
 #pragma unroll
-            for (int sv = 0; sv < ns; ++sv) {
-                float wd_ = S.sel_w[sv * nj + ci] * S.dvsel[sv * 3 + cr];
-                dat += wd_;
-                r0 += wd_ * S.vp[sv * 3]; r1 += wd_ * S.vp[sv * 3 + 1]; r2 += wd_ * S.vp[sv * 3 + 2];
+                for (int sv = 0; sv < NSC; ++sv) { wv[sv] = S.sel_w[sv * nj + ci]; dv[sv] = S.dvsel[sv * 3 + cr]; }
+#pragma unroll
+                for (int q = 0; q < (NSC * 3 + 3) / 4; ++q) vq[q] = ((const float4 *)__builtin_assume_aligned(S.vp, 16))[q];
+                __builtin_amdgcn_sched_barrier(0);
+                const float *vpr = (const float *)vq;
+#pragma unroll
+                for (int sv = 0; sv < NSC; ++sv) {
+                    float wd_ = wv[sv] * dv[sv];
+                    dat += wd_;
+                    r0 += wd_ * vpr[sv * 3]; r1 += wd_ * vpr[sv * 3 + 1]; r2 += wd_ * vpr[sv * 3 + 2];
+                }
+            } else {
+                for (int sv = 0; sv < ns; ++sv) {
+                    float wd_ = S.sel_w[sv * nj + ci] * S.dvsel[sv * 3 + cr];
+                    dat += wd_;
+                    r0 += wd_ * S.vp[sv * 3]; r1 += wd_ * S.vp[sv * 3 + 1]; r2 += wd_ * S.vp[sv * 3 + 2];
+                }
             }
             if (ext) {                      // dense vertex losses: sum_v w_vj dv (x) [vp | 1] from bf_mesh_bwd_kernel
                 const float *ea = ext + EXT_A + ci * 12 + cr * 4;
                 r0 += ea[0]; r1 += ea[1]; r2 += ea[2]; dat += ea[3];
             }
-            S.dAt[tid] = dat;
-            S.dGt[tid] += ext ? dat + ext[EXT_G + tid] : dat;     // + dL/d(chain joint) of the dense keypoint loss
+            S.dAt[tq] = dat;
+            S.dGt[tq] += ext ? dat + ext[EXT_G + tq] : dat;     // + dL/d(chain joint) of the dense keypoint loss
             float4 drow0 = {r0 - dat * S.J[ci * 3], r1 - dat * S.J[ci * 3 + 1], r2 - dat * S.J[ci * 3 + 2], 0.f};
-            *(float4 *)(S.dGR + tid * 4) = drow0;
+            *(float4 *)(S.dGR + tq * 4) = drow0;
         }
-        for (int idx = NG - 1 - tid; idx < ns3; idx += NG) {   // taken from the far end of the geometry waves
+        for (int idx = NG - 1 - tq; idx < ns3; idx += NG) {   // taken from the far end of the geometry waves
             int sv = idx / 3, b = idx - sv * 3;
             S.dvp[idx] = S.TR[sv * 9 + b] * S.dvsel[sv * 3] + S.TR[sv * 9 + 3 + b] * S.dvsel[sv * 3 + 1] +
                          S.TR[sv * 9 + 6 + b] * S.dvsel[sv * 3 + 2];
         }
+        }
         BF_SYNC();
 
+        {
         // ================= phase G: subtree sums t_i of dL/dGt, N_i rows, direct dJ (tid < 3 nj) | d(pose feature)
+        const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
+        const int ci = tq / 3, cr = tq - ci * 3;
         float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f;
         if (c_on) {
-            float ttot = S.dGt[tid];
+            // LDS reads up front: own row of dL/dGR, the three rows of G_i, the parent's translation, dL/dAt_i, and the
+            // dL/dGt column of every joint for the subtree sum (unconditional loads, select on the subtree mask)
+            const float4 dq = *(const float4 *)(S.dGR + tq * 4);
+            const float4 gi0 = *(const float4 *)(S.G + ci * 12), gi1 = *(const float4 *)(S.G + ci * 12 + 4),
+                         gi2 = *(const float4 *)(S.G + ci * 12 + 8);
+            const float gp0 = GT_(cp, 0), gp1 = GT_(cp, 1), gp2 = GT_(cp, 2);
+            const float da0 = S.dAt[ci * 3], da1 = S.dAt[ci * 3 + 1], da2 = S.dAt[ci * 3 + 2];
+            float ttot = S.dGt[tq];
+            constexpr int NJC = NJ > 0 ? NJ : 1;
+            if (NJ > 0) {
+                float tv[NJC];
 #pragma unroll
-            for (int k = 0; k < nj; ++k) {             // unconditional loads, select on the subtree mask
-                float v = S.dGt[k * 3 + cr];
-                ttot += ((cmask >> k) & 1ull) ? v : 0.f;
+                for (int k = 0; k < NJC; ++k) tv[k] = S.dGt[k * 3 + cr];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < NJC; ++k) ttot += ((cmask >> k) & 1ull) ? tv[k] : 0.f;
+            } else {
+                for (int k = 0; k < nj; ++k) {
+                    float v = S.dGt[k * 3 + cr];
+                    ttot += ((cmask >> k) & 1ull) ? v : 0.f;
+                }
             }
-            S.tt[tid] = ttot;
-            const float4 dq = *(const float4 *)(S.dGR + tid * 4);
+            S.tt[tq] = ttot;
             float d0 = dq.x, d1 = dq.y, d2 = dq.z;
-            dg0 = d0 * GR_(ci, 0, 0) + d1 * GR_(ci, 0, 1) + d2 * GR_(ci, 0, 2);     // row cr of D_i GR_i^T
-            dg1 = d0 * GR_(ci, 1, 0) + d1 * GR_(ci, 1, 1) + d2 * GR_(ci, 1, 2);
-            dg2 = d0 * GR_(ci, 2, 0) + d1 * GR_(ci, 2, 1) + d2 * GR_(ci, 2, 2);
+            dg0 = d0 * gi0.x + d1 * gi0.y + d2 * gi0.z;     // row cr of D_i GR_i^T
+            dg1 = d0 * gi1.x + d1 * gi1.y + d2 * gi1.z;
+            dg2 = d0 * gi2.x + d1 * gi2.y + d2 * gi2.z;
             float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-            if (ci > 0) { u0 = GT_(ci, 0) - GT_(cp, 0); u1 = GT_(ci, 1) - GT_(cp, 1); u2 = GT_(ci, 2) - GT_(cp, 2); }
+            if (ci > 0) { u0 = gi0.w - gp0; u1 = gi1.w - gp1; u2 = gi2.w - gp2; }
             float4 nrow = {dg0 + ttot * u0, dg1 + ttot * u1, dg2 + ttot * u2, 0.f};
             *(float4 *)(S.N + (ci * 3 + cr) * 4) = nrow;
             float4 drow = {dg0, dg1, dg2, 0.f};
             *(float4 *)(S.Dg + (ci * 3 + cr) * 4) = drow;
-            S.dJ[tid] = -(GR_(ci, 0, cr) * S.dAt[ci * 3] + GR_(ci, 1, cr) * S.dAt[ci * 3 + 1] + GR_(ci, 2, cr) * S.dAt[ci * 3 + 2]);
+            const float c0 = cr == 0 ? gi0.x : (cr == 1 ? gi0.y : gi0.z), c1 = cr == 0 ? gi1.x : (cr == 1 ? gi1.y : gi1.z),
+                        c2 = cr == 0 ? gi2.x : (cr == 1 ? gi2.y : gi2.z);
+            S.dJ[tq] = -(c0 * da0 + c1 * da1 + c2 * da2);
+        }
         }
         BF_SYNC();
 
+        {
         // ================= phase H: dL/dGR_p (total) = (D_p GR_p^T + sum over strict subtree of N_i) GR_p, row r.
         // Two lanes per (joint, row): each sums half of the joints, combined on the DPP path.
+        const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
         for (int base = 0; base < nj3 * 2; base += NG) {
-            int t2 = base + tid, q = t2 >> 1, hf = t2 & 1;
+            int t2 = base + tq, q = t2 >> 1, hf = t2 & 1;
             bool ok = q < nj3;
             int p = ok ? q / 3 : 0, r = ok ? q - p * 3 : 0;
             unsigned long long mk = ok ? T.desc[p] : 0ull;
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
             const int k0 = hf ? (nj + 1) / 2 : 0, k1 = hf ? nj : (nj + 1) / 2;
+            if (NJ > 0) {
+                constexpr int HK = NJ > 0 ? (NJ + 1) / 2 : 1;
+                constexpr int HB = (HK + 1) / 2;              // two batches of b128 reads (registers)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float4 nq[HB];
+#pragma unroll
+                    for (int i = 0; i < HB; ++i) nq[i] = *(const float4 *)(S.N + (min(k0 + h * HB + i, nj - 1) * 3 + r) * 4);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < HB; ++i) {
+                        const int k = k0 + h * HB + i;
+                        const bool in = (k < k1) && ((mk >> k) & 1ull);
+                        s0 += in ? nq[i].x : 0.f; s1 += in ? nq[i].y : 0.f; s2 += in ? nq[i].z : 0.f;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
 #pragma unroll 4
-            for (int k = k0; k < k1; ++k) {
-                float4 n = *(const float4 *)(S.N + (k * 3 + r) * 4);
-                bool in = (mk >> k) & 1ull;
-                s0 += in ? n.x : 0.f; s1 += in ? n.y : 0.f; s2 += in ? n.z : 0.f;
+                for (int k = k0; k < k1; ++k) {
+                    float4 n = *(const float4 *)(S.N + (k * 3 + r) * 4);
+                    bool in = (mk >> k) & 1ull;
+                    s0 += in ? n.x : 0.f; s1 += in ? n.y : 0.f; s2 += in ? n.z : 0.f;
+                }
             }
             s0 = dpp_add<0xB1>(s0); s1 = dpp_add<0xB1>(s1); s2 = dpp_add<0xB1>(s2);       // + the other half
             if (ok && hf == 0) {
@@ -783,27 +857,30 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 *(float4 *)(S.dGR + q * 4) = tot;
             }
         }
+        }
         BF_SYNC();
 
         // (this step's Adam constants: a global read, issued a phase ahead of its use)
         const float *at = adam_tab + (size_t)(adam_t0 + it) * 3;
         const float at0 = at[0], at1 = at[1], at2 = at[2];
+        {
         // ================= phase I: per joint (wave 0, lane = joint) dL/dR_i = GR_p^T dGR_i + d(pose feature), then the
         // Rodrigues reverse on the same lane | geometric part of dL/dbeta (waves 1-3), with dL/drel_i = GR_p^T t_i
         // formed inline so that nothing here waits for another wave
-        if (tid < nj) {
+        const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
+        if (tq < nj) {
             const float4 g0 = *(const float4 *)(S.G + wp * 12), g1 = *(const float4 *)(S.G + wp * 12 + 4),
                          g2 = *(const float4 *)(S.G + wp * 12 + 8);
-            const float4 c0 = *(const float4 *)(S.dGR + tid * 12), c1 = *(const float4 *)(S.dGR + tid * 12 + 4),
-                         c2 = *(const float4 *)(S.dGR + tid * 12 + 8);
-            const float t0 = S.tt[tid * 3], t1 = S.tt[tid * 3 + 1], t2 = S.tt[tid * 3 + 2];
+            const float4 c0 = *(const float4 *)(S.dGR + tq * 12), c1 = *(const float4 *)(S.dGR + tq * 12 + 4),
+                         c2 = *(const float4 *)(S.dGR + tq * 12 + 8);
+            const float t0 = S.tt[tq * 3], t1 = S.tt[tq * 3 + 1], t2 = S.tt[tq * 3 + 2];
             float dRl[9], drl[3];
-            if (tid == 0) {
+            if (tq == 0) {
                 dRl[0] = c0.x; dRl[1] = c0.y; dRl[2] = c0.z; dRl[3] = c1.x; dRl[4] = c1.y; dRl[5] = c1.z;
                 dRl[6] = c2.x; dRl[7] = c2.y; dRl[8] = c2.z;
                 drl[0] = t0; drl[1] = t1; drl[2] = t2;
             } else {
-                const float *df = S.dfeat + (tid - 1) * 9;
+                const float *df = S.dfeat + (tq - 1) * 9;
                 dRl[0] = g0.x * c0.x + g1.x * c1.x + g2.x * c2.x + df[0];
                 dRl[1] = g0.x * c0.y + g1.x * c1.y + g2.x * c2.y + df[1];
                 dRl[2] = g0.x * c0.z + g1.x * c1.z + g2.x * c2.z + df[2];
@@ -819,14 +896,14 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
             if (mode == 1) {                         // (kept for the debug dump only)
 #pragma unroll
-                for (int e = 0; e < 9; ++e) S.dR[tid * 9 + e] = dRl[e];
-                S.drel[tid * 3] = drl[0]; S.drel[tid * 3 + 1] = drl[1]; S.drel[tid * 3 + 2] = drl[2];
+                for (int e = 0; e < 9; ++e) S.dR[tq * 9 + e] = dRl[e];
+                S.drel[tq * 3] = drl[0]; S.drel[tq * 3 + 1] = drl[1]; S.drel[tq * 3 + 2] = drl[2];
             }
-            rodrigues_bwd(S.theta[tid * 3], S.theta[tid * 3 + 1], S.theta[tid * 3 + 2], S.rc + tid * 4, dRl, S.gth + tid * 3);
+            rodrigues_bwd(S.theta[tq * 3], S.theta[tq * 3 + 1], S.theta[tq * 3 + 2], S.rc + tq * 4, dRl, S.gth + tq * 3);
         }
         if (wave >= 1 && wave < 4) {
             // 16 lanes per beta component: sum Jd.dJ + Jdrel.drel + sel_sd.dvp
-            int q = tid - 64, l = q >> 4, sl = q & 15;
+            int q = tq - 64, l = q >> 4, sl = q & 15;
             float acc = 0.f;
             if (l < nb) {
                 for (int i = sl; i < nj; i += 16) {
@@ -850,31 +927,34 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             acc = row16_sum(acc);
             if (l < nb && sl == 0) S.g[T.off_beta + l] = ext ? acc + ext[EXT_B + l] : acc;
         }
+        }
         BF_SYNC();
 
+        {
         // ================= phase K: priors, gradient assembly, Adam (one parameter per thread).  Two batches of LDS
         // reads: (value, moments, descriptor), then every candidate gradient source at a clamped index; the parameter
         // kind selects afterwards.
+        const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
         float grad = 0.f, pval = 0.f, am = 0.f, av = 0.f;
-        if (tid < np) {
-            pval = Pcur[tid];
-            am = S.am[tid]; av = S.av[tid];
-            const int pk = S.pk[tid], pa = S.pa_[tid], pb = S.pb_[tid];
+        if (tq < np) {
+            pval = Pcur[tq];
+            am = S.am[tq]; av = S.av[tq];
+            const int pk = S.pk[tq], pa = S.pa_[tq], pb = S.pb_[tq];
             const int mstar = (int)S.scal[1];
             const float sc3 = Pcur[3];
             __builtin_amdgcn_sched_barrier(0);
-            const int t8 = tid < 8 ? tid : 0;
+            const int t8 = tq < 8 ? tq : 0;
             const float p0 = S.part[t8], p1 = S.part[8 + t8], p2 = S.part[16 + t8], p3 = S.part[24 + t8];
             const float gth_v = S.gth[pk == 1 ? pa : 0];
             const float gy_v = S.gy[mstar * BF_GMM_LD + (pb >= 0 && pb < BF_GMM_LD ? pb : 0)];
-            const float g_v = S.g[tid];
+            const float g_v = S.g[tq];
             __builtin_amdgcn_sched_barrier(0);
             // angle prior sign (loss.py:54-61: body dofs 52, 55, 9, 12)
             const float ang_sg = (pk == 1 && pb >= 0) ? (pb == 52 ? 1.f : ((pb == 55 || pb == 9 || pb == 12) ? -1.f : 0.f)) : 0.f;
             if (pk == 0) {                                           // transl / scale: the geometry waves' shares in wave order
                 const float acc = ((p0 + p1) + p2) + p3;
-                grad = acc * (tid < 3 ? sc3 * cscale : cscale) + (ext ? ext[EXT_T + tid] + ext[EXT_K + tid] : 0.f);
-                S.g[tid] = grad;                                     // (kept for the debug dump)
+                grad = acc * (tq < 3 ? sc3 * cscale : cscale) + (ext ? ext[EXT_T + tq] + ext[EXT_K + tq] : 0.f);
+                S.g[tq] = grad;                                     // (kept for the debug dump)
             }
             else if (pk == 1) {
                 grad = gth_v;
@@ -892,14 +972,15 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
         }
         grad_last = grad;
-        if (mode == 0 && tid < np) {
+        if (mode == 0 && tq < np) {
             // torch.optim.Adam, single-tensor path
             am = am + (grad - am) * (1.0f - hp.beta1);
             av = av * hp.beta2 + (1.0f - hp.beta2) * grad * grad;
             float denom = sqrtf(av) / at2 + hp.eps;
-            float step = tid < 4 ? at0 : at1;
-            Pnext[tid] = pval - step * (am / denom);
-            S.am[tid] = am; S.av[tid] = av;
+            float step = tq < 4 ? at0 : at1;
+            Pnext[tq] = pval - step * (am / denom);
+            S.am[tq] = am; S.av[tq] = av;
+        }
         }
         BF_SYNC();
         if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
