@@ -558,23 +558,34 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 float th0 = w_pm0, th1 = w_pm1, th2 = w_pm2;
                 if (w_kind == 0) { th0 += Pcur[w_off]; th1 += Pcur[w_off + 1]; th2 += Pcur[w_off + 2]; }
                 else if (NJ != 24 && w_kind >= 2) { th0 = theta_of(Pcur, wj, 0); th1 = theta_of(Pcur, wj, 1); th2 = theta_of(Pcur, wj, 2); }
+                // rel_j = J_j - J_parent straight from the pre-contracted difference tables (rel_0 = J_0); the table
+                // rows and the betas are read before the Rodrigues arithmetic so their latency hides under it
+                const float *beta = Pcur + T.off_beta;          // (column nb is Jtrel x 1; the rest is zero padding)
+                const float4 *jq = (const float4 *)(S.Jdp + wj * 3 * nb4);
+                constexpr int NQ = NB ? (NB + 4) / 4 : 3;
+                float4 jr0[NQ], jr1[NQ], jr2[NQ];
+                float bq[NQ * 4];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const int qq = q * 4 < nb4 ? q : 0;
+                    jr0[q] = jq[qq]; jr1[q] = jq[nb4 / 4 + qq]; jr2[q] = jq[2 * (nb4 / 4) + qq];
+                }
+#pragma unroll
+                for (int c = 0; c < NQ * 4; ++c) bq[c] = c < nb ? beta[c] : (c == nb ? 1.0f : 0.f);
+                __builtin_amdgcn_sched_barrier(0);
                 rodrigues_fwd(th0, th1, th2, Ri, rc);
                 if (wave == 0) { S.theta[wj * 3] = th0; S.theta[wj * 3 + 1] = th1; S.theta[wj * 3 + 2] = th2; }
-                // rel_j = J_j - J_parent straight from the pre-contracted difference tables (rel_0 = J_0)
-                const float *beta = Pcur + T.off_beta;          // (column nb is Jtrel x 1; the rest is zero padding)
-                auto bcol = [&](int c) { return c < nb ? beta[c] : (c == nb ? 1.0f : 0.f); };
-                const float4 *jq = (const float4 *)(S.Jdp + wj * 3 * nb4);
                 float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-                for (int q = 0; q < (NB ? (NB + 4) / 4 : 3); ++q) {
+                for (int q = 0; q < NQ; ++q) {
                     if (q * 4 < nb4) {
-                        float4 b = {bcol(4 * q), bcol(4 * q + 1), bcol(4 * q + 2), bcol(4 * q + 3)}, j0 = jq[q], j1 = jq[nb4 / 4 + q], j2 = jq[2 * (nb4 / 4) + q];
-                        a0 += j0.x * b.x + j0.y * b.y + j0.z * b.z + j0.w * b.w;
-                        a1 += j1.x * b.x + j1.y * b.y + j1.z * b.z + j1.w * b.w;
-                        a2 += j2.x * b.x + j2.y * b.y + j2.z * b.z + j2.w * b.w;
+                        a0 += jr0[q].x * bq[4 * q] + jr0[q].y * bq[4 * q + 1] + jr0[q].z * bq[4 * q + 2] + jr0[q].w * bq[4 * q + 3];
+                        a1 += jr1[q].x * bq[4 * q] + jr1[q].y * bq[4 * q + 1] + jr1[q].z * bq[4 * q + 2] + jr1[q].w * bq[4 * q + 3];
+                        a2 += jr2[q].x * bq[4 * q] + jr2[q].y * bq[4 * q + 1] + jr2[q].z * bq[4 * q + 2] + jr2[q].w * bq[4 * q + 3];
                     }
                 }
-                for (int q = (NB ? (NB + 4) / 4 : 3); q * 4 < nb4; ++q) {
+                auto bcol = [&](int c) { return c < nb ? beta[c] : (c == nb ? 1.0f : 0.f); };
+                for (int q = NQ; q * 4 < nb4; ++q) {
                     float4 b = {bcol(4 * q), bcol(4 * q + 1), bcol(4 * q + 2), bcol(4 * q + 3)}, j0 = jq[q], j1 = jq[nb4 / 4 + q], j2 = jq[2 * (nb4 / 4) + q];
                     a0 += j0.x * b.x + j0.y * b.y + j0.z * b.z + j0.w * b.w;
                     a1 += j1.x * b.x + j1.y * b.y + j1.z * b.z + j1.w * b.w;
@@ -582,8 +593,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 }
                 rel0 = a0; rel1 = a1; rel2 = a2;
                 if (wave == 0) {
+                    if (mode == 1) {                      // (debug dump only)
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
+                        for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
+                    }
                     S.rc[wj * 4] = rc[0]; S.rc[wj * 4 + 1] = rc[1]; S.rc[wj * 4 + 2] = rc[2];
                     if (wj > 0) {
                         float *f = S.feat + w_feat;
@@ -869,18 +882,25 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // formed inline so that nothing here waits for another wave
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
         if (tq < nj) {
+            // all LDS reads of the lane first
             const float4 g0 = *(const float4 *)(S.G + wp * 12), g1 = *(const float4 *)(S.G + wp * 12 + 4),
                          g2 = *(const float4 *)(S.G + wp * 12 + 8);
             const float4 c0 = *(const float4 *)(S.dGR + tq * 12), c1 = *(const float4 *)(S.dGR + tq * 12 + 4),
                          c2 = *(const float4 *)(S.dGR + tq * 12 + 8);
             const float t0 = S.tt[tq * 3], t1 = S.tt[tq * 3 + 1], t2 = S.tt[tq * 3 + 2];
+            const float *dfp = S.dfeat + (tq > 0 ? tq - 1 : 0) * 9;
+            float df[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) df[e] = dfp[e];
+            const float th0 = S.theta[tq * 3], th1 = S.theta[tq * 3 + 1], th2 = S.theta[tq * 3 + 2];
+            float rcl[3] = {S.rc[tq * 4], S.rc[tq * 4 + 1], S.rc[tq * 4 + 2]};
+            __builtin_amdgcn_sched_barrier(0);
             float dRl[9], drl[3];
             if (tq == 0) {
                 dRl[0] = c0.x; dRl[1] = c0.y; dRl[2] = c0.z; dRl[3] = c1.x; dRl[4] = c1.y; dRl[5] = c1.z;
                 dRl[6] = c2.x; dRl[7] = c2.y; dRl[8] = c2.z;
                 drl[0] = t0; drl[1] = t1; drl[2] = t2;
             } else {
-                const float *df = S.dfeat + (tq - 1) * 9;
                 dRl[0] = g0.x * c0.x + g1.x * c1.x + g2.x * c2.x + df[0];
                 dRl[1] = g0.x * c0.y + g1.x * c1.y + g2.x * c2.y + df[1];
                 dRl[2] = g0.x * c0.z + g1.x * c1.z + g2.x * c2.z + df[2];
@@ -899,30 +919,74 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 for (int e = 0; e < 9; ++e) S.dR[tq * 9 + e] = dRl[e];
                 S.drel[tq * 3] = drl[0]; S.drel[tq * 3 + 1] = drl[1]; S.drel[tq * 3 + 2] = drl[2];
             }
-            rodrigues_bwd(S.theta[tq * 3], S.theta[tq * 3 + 1], S.theta[tq * 3 + 2], S.rc + tq * 4, dRl, S.gth + tq * 3);
+            float gl[3];
+            rodrigues_bwd(th0, th1, th2, rcl, dRl, gl);
+            S.gth[tq * 3] = gl[0]; S.gth[tq * 3 + 1] = gl[1]; S.gth[tq * 3 + 2] = gl[2];
         }
         if (wave >= 1 && wave < 4) {
             // 16 lanes per beta component: sum Jd.dJ + Jdrel.drel + sel_sd.dvp
             int q = tq - 64, l = q >> 4, sl = q & 15;
             float acc = 0.f;
             if (l < nb) {
-                for (int i = sl; i < nj; i += 16) {
-                    const int p = i > 0 ? S.par[i] : 0;
-                    const float t0 = S.tt[i * 3], t1 = S.tt[i * 3 + 1], t2 = S.tt[i * 3 + 2];
-                    float e0 = t0, e1 = t1, e2 = t2;
-                    if (i > 0) {
-                        const float4 g0 = *(const float4 *)(S.G + p * 12), g1 = *(const float4 *)(S.G + p * 12 + 4),
-                                     g2 = *(const float4 *)(S.G + p * 12 + 8);
-                        e0 = g0.x * t0 + g1.x * t1 + g2.x * t2;
-                        e1 = g0.y * t0 + g1.y * t1 + g2.y * t2;
-                        e2 = g0.z * t0 + g1.z * t1 + g2.z * t2;
+                if (NJ > 0 && NJ <= 32 && NS > 0 && NS * 3 <= 48) {
+                    // this lane's (at most) two joints and three selector outputs, reads in two batches
+                    const int i0 = sl, i1 = sl + 16 < nj ? sl + 16 : 0;
+                    const bool h1 = sl + 16 < nj;
+                    const int p0 = S.par[i0], p1 = S.par[i1];
+                    float tA[3], tB[3], jA[3], jB[3], rA[3], rB[3], dA[3], dB[3], sw[3], sd[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        tA[k] = S.tt[i0 * 3 + k]; tB[k] = S.tt[i1 * 3 + k];
+                        dA[k] = S.dJ[i0 * 3 + k]; dB[k] = S.dJ[i1 * 3 + k];
+                        jA[k] = S.Jd[(i0 * 3 + k) * nb + l]; jB[k] = S.Jd[(i1 * 3 + k) * nb + l];
+                        rA[k] = S.Jdrel[(i0 * 3 + k) * nb + l]; rB[k] = S.Jdrel[(i1 * 3 + k) * nb + l];
+                        const int o = min(sl + 16 * k, ns3 - 1);
+                        sw[k] = S.sel_sd[o * nb + l]; sd[k] = S.dvp[o];
                     }
-                    const float *jd = S.Jd + i * 3 * nb + l, *jr = S.Jdrel + i * 3 * nb + l;
-                    acc += jd[0] * S.dJ[i * 3] + jr[0] * e0;
-                    acc += jd[nb] * S.dJ[i * 3 + 1] + jr[nb] * e1;
-                    acc += jd[2 * nb] * S.dJ[i * 3 + 2] + jr[2 * nb] * e2;
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float4 a0 = *(const float4 *)(S.G + p0 * 12), a1 = *(const float4 *)(S.G + p0 * 12 + 4),
+                                 a2 = *(const float4 *)(S.G + p0 * 12 + 8);
+                    const float4 b0 = *(const float4 *)(S.G + p1 * 12), b1 = *(const float4 *)(S.G + p1 * 12 + 4),
+                                 b2 = *(const float4 *)(S.G + p1 * 12 + 8);
+                    __builtin_amdgcn_sched_barrier(0);
+                    float eA0 = tA[0], eA1 = tA[1], eA2 = tA[2];
+                    if (i0 > 0) {
+                        eA0 = a0.x * tA[0] + a1.x * tA[1] + a2.x * tA[2];
+                        eA1 = a0.y * tA[0] + a1.y * tA[1] + a2.y * tA[2];
+                        eA2 = a0.z * tA[0] + a1.z * tA[1] + a2.z * tA[2];
+                    }
+                    const float eB0 = b0.x * tB[0] + b1.x * tB[1] + b2.x * tB[2];
+                    const float eB1 = b0.y * tB[0] + b1.y * tB[1] + b2.y * tB[2];
+                    const float eB2 = b0.z * tB[0] + b1.z * tB[1] + b2.z * tB[2];
+                    acc += jA[0] * dA[0] + rA[0] * eA0;
+                    acc += jA[1] * dA[1] + rA[1] * eA1;
+                    acc += jA[2] * dA[2] + rA[2] * eA2;
+                    if (h1) {
+                        acc += jB[0] * dB[0] + rB[0] * eB0;
+                        acc += jB[1] * dB[1] + rB[1] * eB1;
+                        acc += jB[2] * dB[2] + rB[2] * eB2;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) acc += (sl + 16 * k < ns3) ? sw[k] * sd[k] : 0.f;
+                } else {
+                    for (int i = sl; i < nj; i += 16) {
+                        const int p = i > 0 ? S.par[i] : 0;
+                        const float t0 = S.tt[i * 3], t1 = S.tt[i * 3 + 1], t2 = S.tt[i * 3 + 2];
+                        float e0 = t0, e1 = t1, e2 = t2;
+                        if (i > 0) {
+                            const float4 g0 = *(const float4 *)(S.G + p * 12), g1 = *(const float4 *)(S.G + p * 12 + 4),
+                                         g2 = *(const float4 *)(S.G + p * 12 + 8);
+                            e0 = g0.x * t0 + g1.x * t1 + g2.x * t2;
+                            e1 = g0.y * t0 + g1.y * t1 + g2.y * t2;
+                            e2 = g0.z * t0 + g1.z * t1 + g2.z * t2;
+                        }
+                        const float *jd = S.Jd + i * 3 * nb + l, *jr = S.Jdrel + i * 3 * nb + l;
+                        acc += jd[0] * S.dJ[i * 3] + jr[0] * e0;
+                        acc += jd[nb] * S.dJ[i * 3 + 1] + jr[nb] * e1;
+                        acc += jd[2 * nb] * S.dJ[i * 3 + 2] + jr[2 * nb] * e2;
+                    }
+                    for (int o = sl; o < ns3; o += 16) acc += S.sel_sd[o * nb + l] * S.dvp[o];
                 }
-                for (int o = sl; o < ns3; o += 16) acc += S.sel_sd[o * nb + l] * S.dvp[o];
             }
             acc = row16_sum(acc);
             if (l < nb && sl == 0) S.g[T.off_beta + l] = ext ? acc + ext[EXT_B + l] : acc;
