@@ -44,7 +44,7 @@ namespace {
 struct FitSmem {
     float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
-    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *Jdp, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp;
+    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *rel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp;
     int *nzj, *thk, *tho, *par, *pk, *pa_, *pb_;
     float *am, *av;
 };
@@ -70,9 +70,9 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.gq = take(BF_GMM_M);             s.gtail = take(256);   s.scal = take(8);
     s.feat = take(npf);                s.vpp = take(BF_FIT_THREADS + ns * 3);
     s.Jtrel = take(nj * 3); s.Dg = take(nj * 12);
-    s.Jt = take(nj * 3);   s.Jd = take(nj * 3 * nb);      s.Jdrel = take(nj * 3 * nb);
-    s.Jdp = take(nj * 3 * pad4(nb + 1));
-    s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * nb); s.sel_pd = take(npf * ns * 3);
+    s.Jt = take(nj * 3);   s.Jd = take(nj * 3 * pad4(nb + 1));      s.Jdrel = take(nj * 3 * pad4(nb + 1));
+    s.rel = take(nj * 3);
+    s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * pad4(nb + 1)); s.sel_pd = take(npf * ns * 3);
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
     s.proj = take(nviews * 12);
     s.nzw = take(ns * BF_SEL_NNZ);  s.nzj = (int *)take(ns * BF_SEL_NNZ);
@@ -127,8 +127,9 @@ __device__ inline void sincos_small(float a, float *sn, float *cs) {
 // smplx batch_rodrigues for one joint
 __device__ inline void rodrigues_fwd(float tx, float ty, float tz, float *R, float *rc) {
     float ux = tx + 1e-8f, uy = ty + 1e-8f, uz = tz + 1e-8f;
-    float a = sqrtf(ux * ux + uy * uy + uz * uz);
-    float ia = 1.0f / a;
+    // (v_sqrt_f32 / v_rcp_f32, 1 ulp each: the correctly rounded forms cost ~25 more instructions on the critical path)
+    float a = __builtin_amdgcn_sqrtf(ux * ux + uy * uy + uz * uz);
+    float ia = __builtin_amdgcn_rcpf(a);
     float nx = tx * ia, ny = ty * ia, nz = tz * ia;
     float s, c;
     sincos_small(a, &s, &c);
@@ -148,7 +149,7 @@ __device__ inline void rodrigues_fwd(float tx, float ty, float tz, float *R, flo
 // reverse of rodrigues_fwd: G = dL/dR (row-major 3x3) -> dL/dtheta
 __device__ inline void rodrigues_bwd(float tx, float ty, float tz, const float *rc, const float *G, float *gth) {
     float a = rc[0], s = rc[1], c = rc[2], oc = 1.0f - c;
-    const float ia = 1.0f / a;
+    const float ia = __builtin_amdgcn_rcpf(a);
     float n[3] = {tx * ia, ty * ia, tz * ia};
     float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
     float KK[9] = {-n[2] * n[2] - n[1] * n[1], n[0] * n[1], n[0] * n[2],
@@ -212,16 +213,18 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     // ---- one-off loads --------------------------------------------------------------------
     copy_f(S.Jt, T.Jt, nj3, tid, nt);
     copy_f(S.Jtrel, T.Jtrel, nj3, tid, nt);
-    copy_f(S.Jd, T.Jd, nj3 * nb, tid, nt);
-    copy_f(S.Jdrel, T.Jdrel, nj3 * nb, tid, nt);
-    // Jdrel again with rows padded to float4s for the chain lanes' b128 reads; column nb holds Jtrel (it meets a 1)
-    const int nb4 = pad4(nb + 1);
-    for (int i = tid; i < nj3 * nb4; i += nt) {
-        int r = i / nb4, l = i - r * nb4;
-        S.Jdp[i] = l < nb ? T.Jdrel[r * nb + l] : (l == nb ? T.Jtrel[r] : 0.f);
+    // beta tables with rows padded to float4s (stride nbp); column nb carries the constant term (it meets a 1)
+    const int nbp = pad4(nb + 1);
+    for (int i = tid; i < nj3 * nbp; i += nt) {
+        const int r = i / nbp, l = i - r * nbp;
+        S.Jd[i] = l < nb ? T.Jd[r * nb + l] : (l == nb ? T.Jt[r] : 0.f);
+        S.Jdrel[i] = l < nb ? T.Jdrel[r * nb + l] : (l == nb ? T.Jtrel[r] : 0.f);
+    }
+    for (int i = tid; i < ns3 * nbp; i += nt) {
+        const int r = i / nbp, l = i - r * nbp;
+        S.sel_sd[i] = l < nb ? T.sel_sd[r * nb + l] : (l == nb ? T.sel_vt[r] : 0.f);
     }
     copy_f(S.sel_vt, T.sel_vt, ns3, tid, nt);
-    copy_f(S.sel_sd, T.sel_sd, ns3 * nb, tid, nt);
     copy_f(S.sel_pd, T.sel_pd, npf * ns3, tid, nt);
     copy_f(S.sel_w, T.sel_w, ns * nj, tid, nt);
     for (int i = tid; i < ns * BF_SEL_NNZ; i += nt) { S.nzw[i] = T.sel_nzw[i]; S.nzj[i] = T.sel_nzj[i]; }
@@ -331,7 +334,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int NSL = (ns3 > 0 && ns3 <= nt) ? nt / ns3 : 1;
     const int rows_sl = (npf + NSL - 1) / NSL;
 
-    // Adam role: parameter `tid`, its moments in registers
     // Adam role: parameter `tid`; its moments and descriptor live in LDS (read once per iteration, in the Adam phase)
     for (int i = tid; i < np; i += nt) {
         S.am[i] = io.adam_m[(size_t)frame * np + i]; S.av[i] = io.adam_v[(size_t)frame * np + i];
@@ -346,6 +348,54 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     long long bf_t0 = 0;
 #endif
     float grad_last = 0.f;
+    int pidx_last = -1;
+    // Everything that depends on the betas alone, for the NEXT forward pass (wave 3; its lanes cover the outputs):
+    // shaped selector vertices, rest joints J, joint offsets rel_j = J_j - J_parent from the pre-contracted difference
+    // tables, and the zeroed targets of the projection phase's routing
+    auto beta_dependent = [&](const float *P) {
+        const float *beta = P + T.off_beta;
+        constexpr int NQ = NB ? (NB + 4) / 4 : 0;          // float4s per table row (compile-time for the SMPL instance)
+        if (NQ > 0 && NS > 0 && NS * 3 <= 64 && NJ > 0 && NJ * 3 <= 128) {
+            // one selector output and two joint coordinates per lane; every LDS read issued before the arithmetic
+            const int o = lane < ns3 ? lane : 0, i0 = lane, i1 = lane + 64 < nj3 ? lane + 64 : 0;
+            float bq[NQ > 0 ? NQ * 4 : 4];
+#pragma unroll
+            for (int c = 0; c < NQ * 4; ++c) bq[c] = c < nb ? beta[c] : (c == nb ? 1.0f : 0.f);
+            float4 sq[NQ > 0 ? NQ : 1], ja[NQ > 0 ? NQ : 1], ra[NQ > 0 ? NQ : 1], jb[NQ > 0 ? NQ : 1], rb[NQ > 0 ? NQ : 1];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                sq[q] = ((const float4 *)(S.sel_sd + o * nbp))[q];
+                ja[q] = ((const float4 *)(S.Jd + i0 * nbp))[q]; ra[q] = ((const float4 *)(S.Jdrel + i0 * nbp))[q];
+                jb[q] = ((const float4 *)(S.Jd + i1 * nbp))[q]; rb[q] = ((const float4 *)(S.Jdrel + i1 * nbp))[q];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            auto dot = [&](const float4 *t) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) acc += t[q].x * bq[4 * q] + t[q].y * bq[4 * q + 1] + t[q].z * bq[4 * q + 2] + t[q].w * bq[4 * q + 3];
+                return acc;
+            };
+            if (lane < ns3) { S.vs[lane] = dot(sq); S.dvsel[lane] = 0.f; }
+            S.J[i0] = dot(ja); S.rel[i0] = dot(ra); S.dGt[i0] = 0.f;
+            if (lane + 64 < nj3) { S.J[i1] = dot(jb); S.rel[i1] = dot(rb); S.dGt[i1] = 0.f; }
+        } else {
+            for (int o = lane; o < ns3; o += 64) {
+                float acc = S.sel_sd[o * nbp + nb];
+                for (int l = 0; l < nb; ++l) acc += S.sel_sd[o * nbp + l] * beta[l];
+                S.vs[o] = acc;
+                S.dvsel[o] = 0.f;
+            }
+            for (int i = lane; i < nj3; i += 64) {
+                float acc = S.Jd[i * nbp + nb], acr = S.Jdrel[i * nbp + nb];
+                for (int l = 0; l < nb; ++l) { const float bl = beta[l]; acc += S.Jd[i * nbp + l] * bl; acr += S.Jdrel[i * nbp + l] * bl; }
+                S.J[i] = acc;
+                S.rel[i] = acr;
+                S.dGt[i] = 0.f;
+            }
+        }
+    };
+    if (wave == 3) beta_dependent(S.pa);
+    __syncthreads();
     // phases shared by both wave roles
     auto pose_blend = [&]() {
         constexpr int RS = (NJ && NS) ? (9 * (NJ - 1) + (BF_FIT_THREADS / (NS * 3)) - 1) / (BF_FIT_THREADS / (NS * 3)) : 0;
@@ -558,51 +608,23 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 float th0 = w_pm0, th1 = w_pm1, th2 = w_pm2;
                 if (w_kind == 0) { th0 += Pcur[w_off]; th1 += Pcur[w_off + 1]; th2 += Pcur[w_off + 2]; }
                 else if (NJ != 24 && w_kind >= 2) { th0 = theta_of(Pcur, wj, 0); th1 = theta_of(Pcur, wj, 1); th2 = theta_of(Pcur, wj, 2); }
-                // rel_j = J_j - J_parent straight from the pre-contracted difference tables (rel_0 = J_0); the table
-                // rows and the betas are read before the Rodrigues arithmetic so their latency hides under it
-                const float *beta = Pcur + T.off_beta;          // (column nb is Jtrel x 1; the rest is zero padding)
-                const float4 *jq = (const float4 *)(S.Jdp + wj * 3 * nb4);
-                constexpr int NQ = NB ? (NB + 4) / 4 : 3;
-                float4 jr0[NQ], jr1[NQ], jr2[NQ];
-                float bq[NQ * 4];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const int qq = q * 4 < nb4 ? q : 0;
-                    jr0[q] = jq[qq]; jr1[q] = jq[nb4 / 4 + qq]; jr2[q] = jq[2 * (nb4 / 4) + qq];
-                }
-#pragma unroll
-                for (int c = 0; c < NQ * 4; ++c) bq[c] = c < nb ? beta[c] : (c == nb ? 1.0f : 0.f);
+                // rel_j = J_j - J_parent (rel_0 = J_0) was formed from the betas by wave 3 at the end of the previous
+                // iteration (or in the prologue); read it before the Rodrigues arithmetic so the latency hides under it
+                const float a0 = S.rel[wj * 3], a1 = S.rel[wj * 3 + 1], a2 = S.rel[wj * 3 + 2];
                 __builtin_amdgcn_sched_barrier(0);
                 rodrigues_fwd(th0, th1, th2, Ri, rc);
-                if (wave == 0) { S.theta[wj * 3] = th0; S.theta[wj * 3 + 1] = th1; S.theta[wj * 3 + 2] = th2; }
-                float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    if (q * 4 < nb4) {
-                        a0 += jr0[q].x * bq[4 * q] + jr0[q].y * bq[4 * q + 1] + jr0[q].z * bq[4 * q + 2] + jr0[q].w * bq[4 * q + 3];
-                        a1 += jr1[q].x * bq[4 * q] + jr1[q].y * bq[4 * q + 1] + jr1[q].z * bq[4 * q + 2] + jr1[q].w * bq[4 * q + 3];
-                        a2 += jr2[q].x * bq[4 * q] + jr2[q].y * bq[4 * q + 1] + jr2[q].z * bq[4 * q + 2] + jr2[q].w * bq[4 * q + 3];
-                    }
-                }
-                auto bcol = [&](int c) { return c < nb ? beta[c] : (c == nb ? 1.0f : 0.f); };
-                for (int q = NQ; q * 4 < nb4; ++q) {
-                    float4 b = {bcol(4 * q), bcol(4 * q + 1), bcol(4 * q + 2), bcol(4 * q + 3)}, j0 = jq[q], j1 = jq[nb4 / 4 + q], j2 = jq[2 * (nb4 / 4) + q];
-                    a0 += j0.x * b.x + j0.y * b.y + j0.z * b.z + j0.w * b.w;
-                    a1 += j1.x * b.x + j1.y * b.y + j1.z * b.z + j1.w * b.w;
-                    a2 += j2.x * b.x + j2.y * b.y + j2.z * b.z + j2.w * b.w;
-                }
+                if (wave == 2) { S.theta[wj * 3] = th0; S.theta[wj * 3 + 1] = th1; S.theta[wj * 3 + 2] = th2; }
                 rel0 = a0; rel1 = a1; rel2 = a2;
-                if (wave == 0) {
-                    if (mode == 1) {                      // (debug dump only)
+                // bookkeeping stores spread over the three (otherwise identical) chain waves
+                if (wave == 0 && mode == 1) {                 // (debug dump only)
 #pragma unroll
-                        for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
-                    }
-                    S.rc[wj * 4] = rc[0]; S.rc[wj * 4 + 1] = rc[1]; S.rc[wj * 4 + 2] = rc[2];
-                    if (wj > 0) {
-                        float *f = S.feat + w_feat;
-                        f[0] = Ri[0] - 1.f; f[1] = Ri[1]; f[2] = Ri[2]; f[3] = Ri[3]; f[4] = Ri[4] - 1.f;
-                        f[5] = Ri[5]; f[6] = Ri[6]; f[7] = Ri[7]; f[8] = Ri[8] - 1.f;
-                    }
+                    for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
+                }
+                if (wave == 2) { S.rc[wj * 4] = rc[0]; S.rc[wj * 4 + 1] = rc[1]; S.rc[wj * 4 + 2] = rc[2]; }
+                if (wave == 1 && wj > 0) {
+                    float *f = S.feat + w_feat;
+                    f[0] = Ri[0] - 1.f; f[1] = Ri[1]; f[2] = Ri[2]; f[3] = Ri[3]; f[4] = Ri[4] - 1.f;
+                    f[5] = Ri[5]; f[6] = Ri[6]; f[7] = Ri[7]; f[8] = Ri[8] - 1.f;
                 }
                 if (wj == 0) {
                     row.x = wave == 0 ? Ri[0] : (wave == 1 ? Ri[3] : Ri[6]);
@@ -634,22 +656,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #ifdef BF_STAMP
             if (tid == 0 && it == 2 && io.debug) io.debug[4096 + 41] = (float)(long long)(clock64() - t_iter);
 #endif
-        } else {
-            const float *beta = Pcur + T.off_beta;
-            for (int o = lane; o < ns3; o += 64) {
-                float acc = 0.f;
-#pragma unroll
-                for (int l = 0; l < nb; ++l) acc += S.sel_sd[o * nb + l] * beta[l];
-                S.vs[o] = S.sel_vt[o] + acc;
-            }
-            for (int i = lane; i < nj3; i += 64) {                     // rest joints J(beta) for the later phases
-                float acc = 0.f;
-#pragma unroll
-                for (int l = 0; l < nb; ++l) acc += S.Jd[i * nb + l] * beta[l];
-                S.J[i] = S.Jt[i] + acc;
-                S.dGt[i] = 0.f;                                        // target of phase E's routing
-            }
-            for (int i = lane; i < ns3; i += 64) S.dvsel[i] = 0.f;
         }
         BF_SYNC();
 
@@ -938,10 +944,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     for (int k = 0; k < 3; ++k) {
                         tA[k] = S.tt[i0 * 3 + k]; tB[k] = S.tt[i1 * 3 + k];
                         dA[k] = S.dJ[i0 * 3 + k]; dB[k] = S.dJ[i1 * 3 + k];
-                        jA[k] = S.Jd[(i0 * 3 + k) * nb + l]; jB[k] = S.Jd[(i1 * 3 + k) * nb + l];
-                        rA[k] = S.Jdrel[(i0 * 3 + k) * nb + l]; rB[k] = S.Jdrel[(i1 * 3 + k) * nb + l];
+                        jA[k] = S.Jd[(i0 * 3 + k) * nbp + l]; jB[k] = S.Jd[(i1 * 3 + k) * nbp + l];
+                        rA[k] = S.Jdrel[(i0 * 3 + k) * nbp + l]; rB[k] = S.Jdrel[(i1 * 3 + k) * nbp + l];
                         const int o = min(sl + 16 * k, ns3 - 1);
-                        sw[k] = S.sel_sd[o * nb + l]; sd[k] = S.dvp[o];
+                        sw[k] = S.sel_sd[o * nbp + l]; sd[k] = S.dvp[o];
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const float4 a0 = *(const float4 *)(S.G + p0 * 12), a1 = *(const float4 *)(S.G + p0 * 12 + 4),
@@ -980,12 +986,12 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                             e1 = g0.y * t0 + g1.y * t1 + g2.y * t2;
                             e2 = g0.z * t0 + g1.z * t1 + g2.z * t2;
                         }
-                        const float *jd = S.Jd + i * 3 * nb + l, *jr = S.Jdrel + i * 3 * nb + l;
+                        const float *jd = S.Jd + i * 3 * nbp + l, *jr = S.Jdrel + i * 3 * nbp + l;
                         acc += jd[0] * S.dJ[i * 3] + jr[0] * e0;
-                        acc += jd[nb] * S.dJ[i * 3 + 1] + jr[nb] * e1;
-                        acc += jd[2 * nb] * S.dJ[i * 3 + 2] + jr[2 * nb] * e2;
+                        acc += jd[nbp] * S.dJ[i * 3 + 1] + jr[nbp] * e1;
+                        acc += jd[2 * nbp] * S.dJ[i * 3 + 2] + jr[2 * nbp] * e2;
                     }
-                    for (int o = sl; o < ns3; o += 16) acc += S.sel_sd[o * nb + l] * S.dvp[o];
+                    for (int o = sl; o < ns3; o += 16) acc += S.sel_sd[o * nbp + l] * S.dvp[o];
                 }
             }
             acc = row16_sum(acc);
@@ -999,26 +1005,30 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // reads: (value, moments, descriptor), then every candidate gradient source at a clamped index; the parameter
         // kind selects afterwards.
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
+        // The betas belong to wave 3 (lanes 0..nb-1) instead of the threads numbered like them: once they are stepped the
+        // same wave rebuilds everything the next forward pass derives from them, in the shadow of the other updates.
+        const bool isbeta = tq >= T.off_beta && tq < T.off_beta + nb;
+        const int pidx = (tq < np && !isbeta) ? tq : ((wave == 3 && lane < nb) ? T.off_beta + lane : -1);
         float grad = 0.f, pval = 0.f, am = 0.f, av = 0.f;
-        if (tq < np) {
-            pval = Pcur[tq];
-            am = S.am[tq]; av = S.av[tq];
-            const int pk = S.pk[tq], pa = S.pa_[tq], pb = S.pb_[tq];
+        if (pidx >= 0) {
+            pval = Pcur[pidx];
+            am = S.am[pidx]; av = S.av[pidx];
+            const int pk = S.pk[pidx], pa = S.pa_[pidx], pb = S.pb_[pidx];
             const int mstar = (int)S.scal[1];
             const float sc3 = Pcur[3];
             __builtin_amdgcn_sched_barrier(0);
-            const int t8 = tq < 8 ? tq : 0;
+            const int t8 = pidx < 8 ? pidx : 0;
             const float p0 = S.part[t8], p1 = S.part[8 + t8], p2 = S.part[16 + t8], p3 = S.part[24 + t8];
             const float gth_v = S.gth[pk == 1 ? pa : 0];
             const float gy_v = S.gy[mstar * BF_GMM_LD + (pb >= 0 && pb < BF_GMM_LD ? pb : 0)];
-            const float g_v = S.g[tq];
+            const float g_v = S.g[pidx];
             __builtin_amdgcn_sched_barrier(0);
             // angle prior sign (loss.py:54-61: body dofs 52, 55, 9, 12)
             const float ang_sg = (pk == 1 && pb >= 0) ? (pb == 52 ? 1.f : ((pb == 55 || pb == 9 || pb == 12) ? -1.f : 0.f)) : 0.f;
             if (pk == 0) {                                           // transl / scale: the geometry waves' shares in wave order
                 const float acc = ((p0 + p1) + p2) + p3;
-                grad = acc * (tq < 3 ? sc3 * cscale : cscale) + (ext ? ext[EXT_T + tq] + ext[EXT_K + tq] : 0.f);
-                S.g[tq] = grad;                                     // (kept for the debug dump)
+                grad = acc * (pidx < 3 ? sc3 * cscale : cscale) + (ext ? ext[EXT_T + pidx] + ext[EXT_K + pidx] : 0.f);
+                S.g[pidx] = grad;                                    // (kept for the debug dump)
             }
             else if (pk == 1) {
                 grad = gth_v;
@@ -1036,14 +1046,20 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
         }
         grad_last = grad;
-        if (mode == 0 && tq < np) {
+        pidx_last = pidx;
+        if (mode == 0 && pidx >= 0) {
             // torch.optim.Adam, single-tensor path
             am = am + (grad - am) * (1.0f - hp.beta1);
             av = av * hp.beta2 + (1.0f - hp.beta2) * grad * grad;
-            float denom = sqrtf(av) / at2 + hp.eps;
-            float step = tq < 4 ? at0 : at1;
-            Pnext[tq] = pval - step * (am / denom);
-            S.am[tq] = am; S.av[tq] = av;
+            // (v_sqrt_f32 / v_rcp_f32, 1 ulp each, on the critical path of every iteration)
+            float denom = __builtin_amdgcn_sqrtf(av) * __builtin_amdgcn_rcpf(at2) + hp.eps;
+            float step = pidx < 4 ? at0 : at1;
+            Pnext[pidx] = pval - step * (am * __builtin_amdgcn_rcpf(denom));
+            S.am[pidx] = am; S.av[pidx] = av;
+        }
+        if (wave == 3) {
+            BF_WAVE_FENCE();
+            beta_dependent(mode == 0 ? Pnext : Pcur);
         }
         }
         BF_SYNC();
@@ -1086,7 +1102,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (tid < nb) st.beta[tid] = Pold[T.off_beta + tid];
             if (tid < 3) st.t[tid] = Pold[tid];
             if (tid == 3) { st.sc[0] = Pold[3]; st.sc[1] = cscale; }
-            if (io.grads && tid < np) io.grads[(size_t)frame * np + tid] = grad;
+            if (io.grads && pidx_last >= 0) io.grads[(size_t)frame * np + pidx_last] = grad;
         }
         if (io.debug && frame == 0 && mode == 1) {
             float *d = io.debug;
