@@ -28,13 +28,16 @@
 // N_i = D_i GR_i^T + t_i (Gt_i - Gt_parent)^T, dL/dGR_p = (D_p GR_p^T + sum_{i in strict subtree} N_i) GR_p,
 // i.e. two subtree sums instead of one barrier per tree level.  All reductions have a fixed order.
 #include "bf_internal.h"
+#include <type_traits>
 
 // Diagnostic build only (-DBF_STAMP, libbodyfit_stamp.so): thread 0 stamps the shader clock after every
 // barrier of iteration 2 into io.debug[4096..]; the product library has no stamps.
 #ifdef BF_STAMP
-#define BF_SYNC() do { __syncthreads(); if (tid == 0 && it == 2 && io.debug && sidx < 96) { io.debug[4096 + sidx] = (float)(long long)(clock64() - t_iter); } ++sidx; } while (0)
+#define BF_SYNC() do { __syncthreads(); if (tid == 0 && it == 2 && sidx < 32) { S.stamp[sidx] = (float)(long long)(clock64() - t_iter); } ++sidx; } while (0)
+#define BF_MARK(k, who, itv, t0v) do { if (tid == (who) && (itv) == 2) S.stamp[k] = (float)(long long)(clock64() - (t0v)); } while (0)
 #else
 #define BF_SYNC() __syncthreads()
+#define BF_MARK(k, who, itv, t0v) do { (void)(itv); (void)(t0v); } while (0)
 #endif
 // orders this wave's LDS traffic for the compiler; the hardware executes a wave's LDS ops in order
 #define BF_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
@@ -44,7 +47,7 @@ namespace {
 struct FitSmem {
     float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
-    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *rel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp;
+    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *rel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp, *stamp;
     int *nzj, *thk, *tho, *par, *pk, *pa_, *pb_;
     float *am, *av;
 };
@@ -77,6 +80,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.proj = take(nviews * 12);
     s.nzw = take(ns * BF_SEL_NNZ);  s.nzj = (int *)take(ns * BF_SEL_NNZ);
     s.kp = take(BF_VSUB * BF_KP_ROUNDS * 16 * 8);      // 8-float keypoint record per (view, loss-joint pair), zero padded
+    s.stamp = take(64);
     s.theta = take(nj * 3);  s.pmean = take(nj * 3);  s.hcomp = take(2 * 6 * 45);
     s.thk = (int *)take(nj); s.tho = (int *)take(nj); s.par = (int *)take(nj);
     s.pk = (int *)take(np); s.pa_ = (int *)take(np); s.pb_ = (int *)take(np); s.am = take(np); s.av = take(np);
@@ -250,6 +254,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int wj = cw_on ? lane : 0;
     const int wp = wj > 0 ? T.parents[wj] : 0;
     const int wd = cw_on ? T.depth[wj] : -1;
+    const int w_gp = wp > 0 ? T.parents[wp] : 0;          // grandparent (root for the first two levels)
     const int w_feat = (wj > 0 ? wj - 1 : 0) * 9;          // (non-negative base: the nine stores share one address register)
     const int w_kind = T.th_kind[wj], w_off = T.th_off[wj];
     const float w_pm0 = (NJ != 24 && T.pose_mean) ? T.pose_mean[wj * 3] : 0.f, w_pm1 = (NJ != 24 && T.pose_mean) ? T.pose_mean[wj * 3 + 1] : 0.f,
@@ -285,16 +290,15 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int tail_c = tpiece < 30 ? 0 : 1;
     const float4 *tail_d = (const float4 *)(gdw + 2 * 12 * (tpiece % 6));
     const float logw_a = T.g_logw[ma], logw_b = T.g_logw[mb];
-    int gd_off[3], gd_src[3];                 // this lane's (component, dof) items of d = theta - mu
-    float gd_mu[3];
+    int gd_src[2];                            // parameter index of theta_j for j = lane and j = 64 + lane (-1: zero pad)
+    float gd_mu[4];                           // mu_a[lane], mu_b[lane], mu_a[64 + lane], mu_b[64 + lane]
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        int i = lane + q * 64;
-        bool ok = gw && i < 2 * BF_GMM_D;
-        int c = i < BF_GMM_D ? 0 : 1, j = i < BF_GMM_D ? i : i - BF_GMM_D;
-        gd_off[q] = ok ? 2 * j + c : -1;
-        gd_src[q] = j < T.nbp ? T.off_pose + j : -1;       // smplx pads 63 -> 69 with zeros (loss.py:207)
-        gd_mu[q] = ok ? T.g_means[(c ? mb : ma) * BF_GMM_D + j] : 0.f;
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        const bool ok = gw && j < BF_GMM_D;
+        gd_src[q] = (ok && j < T.nbp) ? T.off_pose + j : -1;       // smplx pads 63 -> 69 with zeros (loss.py:207)
+        gd_mu[2 * q] = ok ? T.g_means[ma * BF_GMM_D + j] : 0.f;
+        gd_mu[2 * q + 1] = ok ? T.g_means[mb * BF_GMM_D + j] : 0.f;
     }
 
     const float ndiv_f = (float)io.ndiv[frame];
@@ -343,10 +347,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     for (int j = nj - 1; j >= 0; --j) { if (T.th_kind[j] == 2) hand_j0_l = j; if (T.th_kind[j] == 3) hand_j0_r = j; }
     __syncthreads();
 
-#ifdef BF_STAMP
-    int bf_it = -1;
+    int bf_it = -1;                            // (stamp build only; dead otherwise)
     long long bf_t0 = 0;
-#endif
     float grad_last = 0.f;
     int pidx_last = -1;
     // Everything that depends on the betas alone, for the NEXT forward pass (wave 3; its lanes cover the outputs):
@@ -397,37 +399,70 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     if (wave == 3) beta_dependent(S.pa);
     __syncthreads();
     // phases shared by both wave roles
-    auto pose_blend = [&]() {
+    auto pose_blend = [&](auto nbatch) {
+        constexpr int NBATCH = decltype(nbatch)::value;     // 1: all reads up front; 2: two half batches (fewer registers)
         constexpr int RS = (NJ && NS) ? (9 * (NJ - 1) + (BF_FIT_THREADS / (NS * 3)) - 1) / (BF_FIT_THREADS / (NS * 3)) : 0;
+        constexpr int RB = RS > 0 ? (RS + NBATCH - 1) / NBATCH : 1;
         for (int idx = tid; idx < ns3 * NSL; idx += nt) {
             int sl = idx / ns3, o = idx - sl * ns3;
             int p0 = sl * rows_sl, p1 = min(npf, p0 + rows_sl);
             float acc = 0.f;
             const float *pd = S.sel_pd + p0 * ns3 + o;
             if (RS > 0) {
-                // compile-time slice length: every LDS read is issued before the first multiply-add (one wait instead of
-                // one per pair), rows past the end are clamped and weighted 0
-                float f[RS > 0 ? RS : 1], w[RS > 0 ? RS : 1];
+                // compile-time slice length: the LDS reads of a batch are issued before its multiply-adds (one wait instead
+                // of one per pair), rows past the end are clamped and weighted 0
 #pragma unroll
-                for (int i = 0; i < RS; ++i) {
-                    const int p = min(p0 + i, npf - 1);
-                    f[i] = S.feat[p];
-                    w[i] = S.sel_pd[p * ns3 + o];
+                for (int h = 0; h < NBATCH; ++h) {
+                    float f[RB], w[RB];
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) {
+                        const int p = min(p0 + h * RB + i, npf - 1);
+                        f[i] = S.feat[p];
+                        w[i] = S.sel_pd[p * ns3 + o];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) acc += (h * RB + i < RS && p0 + h * RB + i < p1 ? f[i] : 0.f) * w[i];
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < RS; ++i) acc += (p0 + i < p1 ? f[i] : 0.f) * w[i];
             } else {
                 for (int p = p0; p < p1; ++p, pd += ns3) acc += S.feat[p] * pd[0];
             }
             S.vpp[idx] = acc;
         }
     };
+    // d(pose feature) = sel_pd . dvp for rows first, first + step, ... < last (the GMM waves' registers are full of
+    // precision rows, so the geometry waves the reverse sweep leaves idle take it: waves 2-3 in phase G)
+    auto dfeat_rows = [&](int first, int last, int step) {
+        constexpr int NO = NS > 0 ? NS * 3 : 1;
+        if (NS > 0) {
+            float4 dq4[(NO + 3) / 4];
+#pragma unroll
+            for (int q = 0; q < (NO + 3) / 4; ++q) dq4[q] = ((const float4 *)__builtin_assume_aligned(S.dvp, 16))[q];
+            const float *dv = (const float *)dq4;
+            for (int p = first; p < last; p += step) {
+                const float *row = S.sel_pd + p * ns3;
+                float rv[NO];
+#pragma unroll
+                for (int o = 0; o < NO; ++o) rv[o] = row[o];
+                __builtin_amdgcn_sched_barrier(0);
+                float acc = 0.f;
+#pragma unroll
+                for (int o = 0; o < NO; ++o) acc += rv[o] * dv[o];
+                S.dfeat[p] = ext ? acc + ext[p] : acc;
+            }
+        } else {
+            for (int p = first; p < last; p += step) {
+                float acc = 0.f;
+                const float *row = S.sel_pd + p * ns3;
+                for (int o = 0; o < ns3; ++o) acc += row[o] * S.dvp[o];
+                S.dfeat[p] = ext ? acc + ext[p] : acc;
+            }
+        }
+    };
     typedef float v2f __attribute__((ext_vector_type(2)));
     auto project = [&]() {
-#ifdef BF_STAMP
-        if (tid == 0 && bf_it == 2 && io.debug) io.debug[4096 + 45] = (float)(long long)(clock64() - bf_t0);
-#endif
+        BF_MARK(45, 0, bf_it, bf_t0);
         const float tX = Pcur[0], tY = Pcur[1], tZ = Pcur[2];
         const float sc = Pcur[3] * cscale;
         const v2f y0 = {lsrc_a[0] + tX, lsrc_b[0] + tX};
@@ -472,9 +507,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                          gxy.y = k[0]; gxy.w = k[1]; kc.y = c2 * kscale * (2.f * s2 * s2); kc.w = c2 * s2; }
             one_view(v, gxy, kc);
         }
-#ifdef BF_STAMP
-        if (tid == 0 && bf_it == 2 && io.debug) io.debug[4096 + 43] = (float)(long long)(clock64() - bf_t0);
-#endif
+        BF_MARK(43, 0, bf_it, bf_t0);
         // sum over the 16 view lanes of the pair (fixed DPP tree), route dL/dX to its source, and leave this wave's
         // share of d/dt, d/ds and of the loss value for the Adam phase
         float ga0 = row16_sum(g0.x), ga1 = row16_sum(g1.x), ga2 = row16_sum(g2.x), la = row16_sum(lsum.x);
@@ -483,9 +516,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (ja_on) { atomicAdd(ldst_a + 0, ga0 * sc); atomicAdd(ldst_a + 1, ga1 * sc); atomicAdd(ldst_a + 2, ga2 * sc); }
             if (jb_on) { atomicAdd(ldst_b + 0, gb0 * sc); atomicAdd(ldst_b + 1, gb1 * sc); atomicAdd(ldst_b + 2, gb2 * sc); }
         }
-#ifdef BF_STAMP
-        if (tid == 0 && bf_it == 2 && io.debug) io.debug[4096 + 44] = (float)(long long)(clock64() - bf_t0);
-#endif
+        BF_MARK(44, 0, bf_it, bf_t0);
         // (joints off the end have zero records: their sums are exactly 0)
         const float gsa = ga0 * y0.x + ga1 * y1.x + ga2 * y2.x, gsb = gb0 * y0.y + gb1 * y1.y + gb2 * y2.y;
         auto four = [&](float v) {                  // rows 0..3 of the wave, each row-uniform: (r0 + r1) + (r2 + r3)
@@ -516,25 +547,49 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #pragma unroll
         for (int e = 0; e < 12; ++e) Pt[e] = T.g_ptail[((size_t)gwi * 12 + e) * 64 + lane];
         const float4 *d4 = (const float4 *)__builtin_assume_aligned(gdw, 16);
-        const v2f *d2 = (const v2f *)__builtin_assume_aligned(gdw, 8);
         for (int it = 0; it < n_iters; ++it) {
 #ifdef BF_STAMP
             int sidx = 0;
-            long long t_iter = clock64();
+            const long long t_iter = clock64();
 #endif
-            // GMM, wave-local: d = theta - mu, y = Psym d (rows 0..63 per lane + 60 tail pieces), q = 0.5 d'y - log w~
-#pragma unroll
-            for (int q = 0; q < 3; ++q)
-                if (gd_off[q] >= 0) gdw[gd_off[q]] = (gd_src[q] >= 0 ? Pcur[gd_src[q]] : 0.f) - gd_mu[q];
-            BF_WAVE_FENCE();
-            v2f y = {0.f, 0.f};
-#pragma unroll
-            for (int j2 = 0; j2 < BF_GMM_LD / 2; ++j2) {
-                float4 t = d4[j2];
-                v2f t0 = {t.x, t.y}, t1 = {t.z, t.w};
-                y += P2[2 * j2] * t0;
-                y += P2[2 * j2 + 1] * t1;
+            // The GMM prior (d = theta - mu, y = Psym d, q = 0.5 d'y - log w~ for this wave's two components) feeds only
+            // the Adam phase and costs one wave ~3000 cycles, so it is cut into eight-column chunks, one or two per phase:
+            // it never holds a barrier up and runs in the issue slots the geometry waves leave free.
+            v2f dA = {0.f, 0.f}, dB = {0.f, 0.f};       // (d_a[lane], d_b[lane]) and (d_a[64 + lane], d_b[64 + lane])
+            if (gd_src[0] >= 0) { const float th = Pcur[gd_src[0]]; dA.x = th - gd_mu[0]; dA.y = th - gd_mu[1]; }
+            else { dA.x = -gd_mu[0]; dA.y = -gd_mu[1]; }
+            if (lane < BF_GMM_D - 64) {
+                const float th = gd_src[1] >= 0 ? Pcur[gd_src[1]] : 0.f;
+                dB.x = th - gd_mu[2]; dB.y = th - gd_mu[3];
             }
+            ((v2f *)gdw)[lane] = dA;                   // LDS copy, interleaved (d_a[j], d_b[j]) pairs: one b128 = two columns
+            if (lane < BF_GMM_LD - 64) ((v2f *)gdw)[64 + lane] = dB;
+            BF_WAVE_FENCE();
+            v2f y0 = {0.f, 0.f}, y1 = {0.f, 0.f};
+#define BF_GMM_CHUNK(c)                                                                         \
+            _Pragma("unroll") for (int j2 = 4 * (c); j2 < 4 * (c) + 4; ++j2) {                  \
+                const float4 t = d4[j2];                                                        \
+                const v2f t0 = {t.x, t.y}, t1 = {t.z, t.w};                                     \
+                y0 += P2[2 * j2] * t0;                                                          \
+                y1 += P2[2 * j2 + 1] * t1;                                                      \
+            }
+            BF_GMM_CHUNK(0)
+            BF_GMM_CHUNK(1)
+            BF_SYNC();                 // A
+            pose_blend(std::integral_constant<int, 2>());
+            BF_SYNC();                 // B
+            BF_GMM_CHUNK(2)
+            BF_SYNC();                 // C
+            BF_GMM_CHUNK(3)
+            BF_GMM_CHUNK(4)
+            BF_GMM_CHUNK(5)
+            BF_GMM_CHUNK(6)
+            BF_SYNC();                 // D (+E): projection, view reduction and routing run on the geometry waves
+            BF_GMM_CHUNK(7)
+            BF_SYNC();                 // F
+            BF_GMM_CHUNK(8)
+#undef BF_GMM_CHUNK
+            const v2f y = y0 + y1;
             const float ya = y.x, yb = y.y;
             S.gy[ma * BF_GMM_LD + lane] = ya;
             S.gy[mb * BF_GMM_LD + lane] = yb;
@@ -546,9 +601,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 yt += Pt[2 * e2 + 1] * (tail_c ? t.w : t.z);
             }
             S.gtail[gwi * 64 + lane] = yt;
-            BF_WAVE_FENCE();
-            v2f dl = d2[lane];
-            float ta = dl.x * ya, tb = dl.y * yb;
+            BF_SYNC();                 // G
+            float ta = dA.x * ya, tb = dA.y * yb;
             if (lane < 5) {
                 float ysa = 0.f, ysb = 0.f;
 #pragma unroll
@@ -558,9 +612,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 }
                 S.gy[ma * BF_GMM_LD + 64 + lane] = ysa;
                 S.gy[mb * BF_GMM_LD + 64 + lane] = ysb;
-                v2f dt = d2[64 + lane];
-                ta += dt.x * ysa;
-                tb += dt.y * ysb;
+                ta += dB.x * ysa;
+                tb += dB.y * ysb;
             }
             ta = wave_sum(ta);
             tb = wave_sum(tb);
@@ -568,24 +621,14 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 S.gq[ma] = 0.5f * ta + logw_a;       // prior.py:188-189
                 S.gq[mb] = 0.5f * tb + logw_b;
             }
-#ifdef BF_STAMP
-            if (tid == 256 && it == 2 && io.debug) io.debug[4096 + 42] = (float)(long long)(clock64() - t_iter);
-#endif
-            BF_SYNC();                 // A
-            pose_blend();
-            BF_SYNC();                 // B
-            BF_SYNC();                 // C
-            BF_SYNC();                 // D (+E): projection, view reduction and routing run on the geometry waves
-            BF_SYNC();                 // F
-            for (int p = tid - 256; p < npf; p += 256) {      // d(pose feature) = sel_pd . dvp
-                float acc = 0.f;
-                const float *row = S.sel_pd + p * ns3;
-#pragma unroll 11
-                for (int o = 0; o < ns3; ++o) acc += row[o] * S.dvp[o];
-                S.dfeat[p] = ext ? acc + ext[p] : acc;
-            }
-            BF_SYNC();                 // G
             BF_SYNC();                 // H
+            if (tid == 256) {                        // arg-min GMM component (prior.py:195) for the Adam phase
+                int ms = 0;
+                float qm = S.gq[0];
+#pragma unroll
+                for (int m = 1; m < BF_GMM_M; ++m) { float q = S.gq[m]; if (q < qm) { qm = q; ms = m; } }
+                S.scal[1] = (float)ms; S.scal[2] = qm;
+            }
             BF_SYNC();                 // I (+J)
             BF_SYNC();                 // K
             if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
@@ -597,8 +640,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     for (int it = 0; it < n_iters; ++it) {
 #ifdef BF_STAMP
         int sidx = 0;
-        long long t_iter = clock64();
+        const long long t_iter = clock64();
         bf_it = it; bf_t0 = t_iter;
+#else
+        const long long t_iter = 0;
 #endif
         // ================= phase A: forward chain (waves 0-2) | shaped selector verts (wave 3) | GMM (waves 4-7)
         if (wave < 3) {
@@ -634,44 +679,57 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
                 }
             }
-#ifdef BF_STAMP
-            if (tid == 0 && it == 2 && io.debug) io.debug[4096 + 40] = (float)(long long)(clock64() - t_iter);
-#endif
-            // level sweep: the parent's row comes straight out of the parent lane's registers (ds_bpermute, no LDS
-            // write -> read round trip on the critical path); the finished rows go to LDS once, at the end
+            BF_MARK(40, 0, it, t_iter);
+            // level sweep, two tree levels per round.  Every lane first composes its local transform with its parent's,
+            // M_j = L_parent L_j (the parent's 3x4 comes out of the parent lane's registers with ds_bpermute: every chain
+            // wave holds the full local transforms); a joint of depth d then needs the finished row of its ancestor at
+            // depth d - 2 (d - 1 for the first level): ceil(depth / 2) dependent rounds instead of depth.
             const int wp4 = wp * 4;
-            for (int lev = 1; lev < T.n_levels; ++lev) {
-                float gx = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(row.x)));
-                float gy = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(row.y)));
-                float gz = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(row.z)));
-                float gw_ = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(row.w)));
-                const bool mine = wd == lev;
-                float nx = gx * Ri[0] + gy * Ri[3] + gz * Ri[6];
-                float ny = gx * Ri[1] + gy * Ri[4] + gz * Ri[7];
-                float nz = gx * Ri[2] + gy * Ri[5] + gz * Ri[8];
-                float nw = gx * rel0 + gy * rel1 + gz * rel2 + gw_;
+            float Mr[9], Mt[3];
+            {
+                float pr[9], pt[3];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) pr[e] = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(Ri[e])));
+                pt[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(rel0)));
+                pt[1] = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(rel1)));
+                pt[2] = __int_as_float(__builtin_amdgcn_ds_bpermute(wp4, __float_as_int(rel2)));
+                const bool two = wd >= 2;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = pr[r * 3] * Ri[c] + pr[r * 3 + 1] * Ri[3 + c] + pr[r * 3 + 2] * Ri[6 + c];
+                        Mr[r * 3 + c] = two ? v : Ri[r * 3 + c];
+                    }
+                    const float v = pr[r * 3] * rel0 + pr[r * 3 + 1] * rel1 + pr[r * 3 + 2] * rel2 + pt[r];
+                    Mt[r] = two ? v : (r == 0 ? rel0 : (r == 1 ? rel1 : rel2));
+                }
+            }
+            const int wa4 = (wd >= 2 ? w_gp : wp) * 4;            // ancestor lane: grandparent (parent on the first level)
+            const int wround = (wd + 1) >> 1;                      // the round this joint is finished in
+            for (int rd = 1; 2 * rd - 1 < T.n_levels; ++rd) {
+                float gx = __int_as_float(__builtin_amdgcn_ds_bpermute(wa4, __float_as_int(row.x)));
+                float gy = __int_as_float(__builtin_amdgcn_ds_bpermute(wa4, __float_as_int(row.y)));
+                float gz = __int_as_float(__builtin_amdgcn_ds_bpermute(wa4, __float_as_int(row.z)));
+                float gw_ = __int_as_float(__builtin_amdgcn_ds_bpermute(wa4, __float_as_int(row.w)));
+                const bool mine = wround == rd;
+                float nx = gx * Mr[0] + gy * Mr[3] + gz * Mr[6];
+                float ny = gx * Mr[1] + gy * Mr[4] + gz * Mr[7];
+                float nz = gx * Mr[2] + gy * Mr[5] + gz * Mr[8];
+                float nw = gx * Mt[0] + gy * Mt[1] + gz * Mt[2] + gw_;
                 row.x = mine ? nx : row.x; row.y = mine ? ny : row.y; row.z = mine ? nz : row.z; row.w = mine ? nw : row.w;
             }
             if (cw_on && wj > 0) *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
-#ifdef BF_STAMP
-            if (tid == 0 && it == 2 && io.debug) io.debug[4096 + 41] = (float)(long long)(clock64() - t_iter);
-#endif
+            BF_MARK(41, 0, it, t_iter);
         }
         BF_SYNC();
 
         {
         // ================= phase B: pose blend of the selector vertices, partial sums over row slices
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
-        pose_blend();
+        pose_blend(std::integral_constant<int, 1>());
         if (c_on)                                   // A_j translation: Gt_j - GR_j J_j
             S.At[tq] = GT_(ci, cr) - (GR_(ci, cr, 0) * S.J[ci * 3] + GR_(ci, cr, 1) * S.J[ci * 3 + 1] + GR_(ci, cr, 2) * S.J[ci * 3 + 2]);
-        if (tq == NG - 1) {                        // arg-min GMM component (prior.py:195), ready long before the Adam phase
-            int ms = 0;
-            float qm = S.gq[0];
-#pragma unroll
-            for (int m = 1; m < BF_GMM_M; ++m) { float q = S.gq[m]; if (q < qm) { qm = q; ms = m; } }
-            S.scal[1] = (float)ms; S.scal[2] = qm;
-        }
         }
         BF_SYNC();
 
@@ -789,6 +847,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
         const int ci = tq / 3, cr = tq - ci * 3;
         float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f;
+        if (wave >= 2) dfeat_rows(tq - 128, npf, 128);
         if (c_on) {
             // LDS reads up front: own row of dL/dGR, the three rows of G_i, the parent's translation, dL/dAt_i, and the
             // dL/dGt column of every joint for the subtree sum (unconditional loads, select on the subtree mask)
@@ -1119,6 +1178,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
     }
 
+#ifdef BF_STAMP
+    __syncthreads();
+    if (tid < 64 && io.debug && frame == 0) io.debug[4096 + tid] = S.stamp[tid];
+#endif
     if (mode == 0 && tid < np) {
         io.params[(size_t)frame * np + tid] = Pcur[tid];
         io.adam_m[(size_t)frame * np + tid] = S.am[tid];

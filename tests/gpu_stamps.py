@@ -23,3 +23,4 @@ for rep in range(3):
     print("  per-phase:", [int(x) for x in np.diff(np.concatenate([[0], st]))])
     print("  phase A inner: after rodrigues+rel, after chain levels, GMM wave done:", [int(x) for x in d[40:43]])
     print("  phase D inner: start, after view loop, after reduce+route:", [int(d[45]), int(d[43]), int(d[44])])
+    print("  GMM inner (from the G barrier): start-of-GMM.., after d, after matvec, after tails, done:", [int(d[46]), int(d[47]), int(d[48]), int(d[42])])
