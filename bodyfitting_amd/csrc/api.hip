@@ -406,20 +406,30 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
     for (auto &e : b->ring) ok = ok && hipEventCreate(&e) == hipSuccess;
     b->ev = b->ring.data();
     ok = ok && b->params0.alloc(F * np) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&b->h_params, F * np * sizeof(float)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&b->h_vout, F * m->nv * 3 * sizeof(float)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&b->h_joints, F * m->n_joint_map * 3 * sizeof(float)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&b->h_terms, F * 4 * sizeof(float)) == hipSuccess;
-    ok = ok && hipHostMalloc((void **)&b->h_state, F * bf_state_stride(m->nj, m->npf, m->nb) * sizeof(float)) == hipSuccess;
+    {
+        auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };          // 256-byte slices
+        const size_t n_par = F * np, n_terms = F * 4, n_state = F * bf_state_stride(m->nj, m->npf, m->nb),
+                     n_joints = F * m->n_joint_map * 3, n_v = F * m->nv * 3;
+        const size_t o_terms = up(n_par), o_state = o_terms + up(n_terms), o_joints = o_state + up(n_state),
+                     o_v = o_joints + up(n_joints), total = o_v + up(n_v);
+        ok = ok && b->res.alloc(total) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&b->h_res, total * sizeof(float)) == hipSuccess;
+        if (ok) {
+            ok = hipMemset(b->res.p, 0, total * sizeof(float)) == hipSuccess;
+            b->params.slice(b->res.p, n_par); b->terms.slice(b->res.p + o_terms, n_terms);
+            b->state.slice(b->res.p + o_state, n_state); b->joints.slice(b->res.p + o_joints, n_joints);
+            b->vout.slice(b->res.p + o_v, n_v);
+            b->h_params = b->h_res; b->h_terms = b->h_res + o_terms; b->h_state = b->h_res + o_state;
+            b->h_joints = b->h_res + o_joints; b->h_vout = b->h_res + o_v;
+            b->res_small = o_v;
+        }
+    }
     ok = ok && b->proj.alloc(F * n_views * 12) == hipSuccess;
     ok = ok && b->keypoints.alloc(F * n_views * m->nl_loss * 3) == hipSuccess;
     ok = ok && b->ndiv.upload(std::vector<int>(F, n_views)) == hipSuccess;
-    ok = ok && b->params.alloc(F * np) == hipSuccess && b->adam_m.alloc(F * np) == hipSuccess;
+    ok = ok && b->adam_m.alloc(F * np) == hipSuccess;
     ok = ok && b->adam_v.alloc(F * np) == hipSuccess && b->grads.alloc(F * np) == hipSuccess;
-    ok = ok && b->terms.alloc(F * 4) == hipSuccess;
-    ok = ok && b->state.alloc(F * bf_state_stride(m->nj, m->npf, m->nb)) == hipSuccess;
-    ok = ok && b->vraw.alloc(F * m->nv * 3) == hipSuccess && b->vout.alloc(F * m->nv * 3) == hipSuccess;
-    ok = ok && b->joints.alloc(F * m->n_joint_map * 3) == hipSuccess;
+    ok = ok && b->vraw.alloc(F * m->nv * 3) == hipSuccess;
     ok = ok && b->xpart.alloc(F * m->mesh.n_tiles * std::max(m->n_extra, 1) * 3) == hipSuccess;
     ok = ok && b->debug.alloc(8192) == hipSuccess;
     if (ok) {
@@ -440,7 +450,7 @@ void bf_batch_destroy(bf_batch *b) {
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     for (auto &e : b->ring) if (e) (void)hipEventDestroy(e);
-    for (float *h : {b->h_params, b->h_vout, b->h_joints, b->h_terms, b->h_state}) if (h) (void)hipHostFree(h);
+    if (b->h_res) (void)hipHostFree(b->h_res);
     delete b;
 }
 
@@ -594,7 +604,7 @@ FrameIO bf_frame_io(bf_batch *b, bool want_grads) {
     FrameIO io;
     io.n_frames = b->F; io.n_views = b->V;
     io.proj = b->proj.p; io.keypoints = b->keypoints.p; io.ndiv = b->ndiv.p;
-    io.params = b->params.p; io.adam_m = b->adam_m.p; io.adam_v = b->adam_v.p;
+    io.params = b->params.p; io.params0 = nullptr; io.adam_m = b->adam_m.p; io.adam_v = b->adam_v.p;
     io.grads = want_grads ? b->grads.p : nullptr;
     io.terms = b->terms.p; io.state = b->state.p;
     io.debug = b->debug.p;
@@ -609,12 +619,9 @@ static int enqueue_plain(bf_batch *b, int n_iters, const HyperDev &hd, const Fra
                          int adam_t0, hipEvent_t *ev) {
     bf_model *m = b->m;
     const size_t fb = sizeof(float);
-    if (reset) {
-        HIP_TRY(hipMemcpyAsync(b->params.p, b->params0.p, b->params.n * fb, hipMemcpyDeviceToDevice, b->stream));
-        HIP_TRY(hipMemsetAsync(b->adam_m.p, 0, b->adam_m.n * fb, b->stream));
-        HIP_TRY(hipMemsetAsync(b->adam_v.p, 0, b->adam_v.n * fb, b->stream));
-    }
-    HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_iters, 0, b->adam_tab.p, adam_t0, m->fit_smem, b->stream));
+    FrameIO io2 = io;
+    if (reset) io2.params0 = b->params0.p;      // re-arm inside the fit kernel: no copy / memset commands
+    HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, adam_t0, m->fit_smem, b->stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], b->stream));
     if (want_v) {
         int rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream,
@@ -622,13 +629,8 @@ static int enqueue_plain(bf_batch *b, int n_iters, const HyperDev &hd, const Fra
         if (rc) return rc;
     } else if (ev) HIP_TRY(hipEventRecord(ev[2], b->stream));
     if (fetch) {
-        HIP_TRY(hipMemcpyAsync(b->h_params, b->params.p, b->params.n * fb, hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->h_terms, b->terms.p, b->terms.n * fb, hipMemcpyDeviceToHost, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->h_state, b->state.p, b->state.n * fb, hipMemcpyDeviceToHost, b->stream));
-        if (want_v) {
-            HIP_TRY(hipMemcpyAsync(b->h_vout, b->vout.p, b->vout.n * fb, hipMemcpyDeviceToHost, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->h_joints, b->joints.p, b->joints.n * fb, hipMemcpyDeviceToHost, b->stream));
-        }
+        // one copy of the result arena: [params | terms | state | joints] and, when they were built, the vertices
+        HIP_TRY(hipMemcpyAsync(b->h_res, b->res.p, (want_v ? b->res.n : b->res_small) * fb, hipMemcpyDeviceToHost, b->stream));
     }
     return BF_OK;
 }
@@ -712,13 +714,7 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
             HIP_TRY(hipEventRecord(b->ev[2], b->stream));
         }
         if (fetch) {
-            HIP_TRY(hipMemcpyAsync(b->h_params, b->params.p, b->params.n * fb, hipMemcpyDeviceToHost, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->h_terms, b->terms.p, b->terms.n * fb, hipMemcpyDeviceToHost, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->h_state, b->state.p, b->state.n * fb, hipMemcpyDeviceToHost, b->stream));
-            if (want_v || dense) {
-                HIP_TRY(hipMemcpyAsync(b->h_vout, b->vout.p, b->vout.n * fb, hipMemcpyDeviceToHost, b->stream));
-                HIP_TRY(hipMemcpyAsync(b->h_joints, b->joints.p, b->joints.n * fb, hipMemcpyDeviceToHost, b->stream));
-            }
+            HIP_TRY(hipMemcpyAsync(b->h_res, b->res.p, ((want_v || dense) ? b->res.n : b->res_small) * fb, hipMemcpyDeviceToHost, b->stream));
         }
     }
     b->fetched = fetch;

@@ -25,6 +25,8 @@ template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool view = false;          // a slice of another allocation: not freed here
+    void slice(T *base, size_t count) { p = base; n = count; view = true; }
     hipError_t alloc(size_t count) {
         n = count;
         return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
@@ -34,7 +36,7 @@ struct DevBuf {
         if (e != hipSuccess) return e;
         return h.empty() ? hipSuccess : hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     }
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    ~DevBuf() { if (p && !view) (void)hipFree(p); }
 };
 
 struct bf_model {
@@ -77,6 +79,11 @@ struct bf_batch {
     hipEvent_t *ev = nullptr;       // the triple of the last call
     bool timed = false;
     DevBuf<float> params0;          // parameters of the last set_init / set_params
+    // results live in ONE device arena [params | terms | state | joints | vout] mirrored by ONE pinned host arena, so a
+    // fetch is a single device-to-host copy of the prefix that is wanted
+    DevBuf<float> res;
+    float *h_res = nullptr;
+    size_t res_small = 0;           // floats up to the end of `joints` (everything but the vertices)
     float *h_params = nullptr, *h_vout = nullptr, *h_joints = nullptr, *h_terms = nullptr, *h_state = nullptr;
     bool fetched = false;
     int steps_done = 0;

@@ -150,6 +150,7 @@ struct FrameIO {
     const float *keypoints;   // [F][V][nl][3]
     const int *ndiv;          // [F]
     float *params;            // [F][np]
+    const float *params0;     // [F][np] or null: start from these parameters with zero Adam moments (in-kernel re-arm)
     float *adam_m;            // [F][np]
     float *adam_v;            // [F][np]
     float *grads;             // [F][np]       (grad-only mode)

@@ -246,7 +246,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         S.gy[i] = 0.f;
     }
     copy_f(S.proj, io.proj + (size_t)frame * V * 12, V * 12, tid, nt);
-    copy_f(S.pa, io.params + (size_t)frame * np, np, tid, nt);
+    copy_f(S.pa, (io.params0 ? io.params0 : io.params) + (size_t)frame * np, np, tid, nt);
     float *Pcur = S.pa, *Pnext = S.pb;
 
     // chain-row role (waves 0-2): lane = joint
@@ -340,7 +340,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
     // Adam role: parameter `tid`; its moments and descriptor live in LDS (read once per iteration, in the Adam phase)
     for (int i = tid; i < np; i += nt) {
-        S.am[i] = io.adam_m[(size_t)frame * np + i]; S.av[i] = io.adam_v[(size_t)frame * np + i];
+        S.am[i] = io.params0 ? 0.f : io.adam_m[(size_t)frame * np + i];
+        S.av[i] = io.params0 ? 0.f : io.adam_v[(size_t)frame * np + i];
         S.pk[i] = T.p_kind[i]; S.pa_[i] = T.p_a[i]; S.pb_[i] = T.p_b[i];
     }
     int hand_j0_l = 0, hand_j0_r = 0;          // first joint of each hand
