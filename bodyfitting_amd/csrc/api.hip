@@ -5,7 +5,8 @@ extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const Hyper
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
 extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *, const float *);
 extern "C" __global__ void bf_mesh_epilogue_kernel(MeshTab, const float *, const float *, float *, float *, float *, float *);
-extern "C" hipError_t bf_poseblend_launch(const MeshTab *, const float *, int, float *, hipStream_t);
+extern "C" hipError_t bf_poseblend_launch(const MeshTab *M, const float *state, int n, float *featT, int kpad, int fpad, float *pose_off, hipStream_t stream);
+extern "C" __global__ void bf_mesh_epilogue_batch_kernel(MeshTab M, const float *state, const float *pose_off, int n_frames, float *vraw, float *vout, float *xpart);
 extern "C" __global__ void bf_joints_kernel(MeshTab, const float *, const float *, const float *, float *, float *, float *, int *, float *);
 extern "C" size_t bf_fit_smem_bytes(int, int, int, int, int, int, int);
 extern "C" size_t bf_mesh_smem_bytes(int, int, int);
@@ -223,6 +224,22 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         m->faces_host.assign(d->faces, d->faces + (size_t)d->n_faces * 3);
     }
     up_f(m->lbs_weights, d->lbs_weights, (size_t)nv * nj);
+    int v_nnz = 0;
+    {   // sparse skinning rows: exact (the dropped entries are zeros)
+        int mx = 0;
+        for (int v = 0; v < nv; ++v) { int c = 0; for (int j = 0; j < nj; ++j) c += d->lbs_weights[(size_t)v * nj + j] != 0.f; mx = std::max(mx, c); }
+        v_nnz = mx <= 4 ? 4 : (mx <= 8 ? 8 : 0);
+        std::vector<int> zj((size_t)nv * std::max(v_nnz, 1), 0);
+        std::vector<float> zw((size_t)nv * std::max(v_nnz, 1), 0.f);
+        for (int v = 0; v < nv && v_nnz; ++v) {
+            int c = 0;
+            for (int j = 0; j < nj; ++j) {
+                float w = d->lbs_weights[(size_t)v * nj + j];
+                if (w != 0.f) { zj[(size_t)v * v_nnz + c] = j; zw[(size_t)v * v_nnz + c] = w; ++c; }
+            }
+        }
+        up_vi(m->v_nzj, zj); up_vf(m->v_nzw, zw);
+    }
     up_f(m->j_extra, d->j_regressor_extra, (size_t)d->n_extra * nv);
     up_vi(m->selector_ids, std::vector<int>(d->selector_ids, d->selector_ids + d->n_selector));
     up_vi(m->joint_map, std::vector<int>(d->joint_map, d->joint_map + d->n_joint_map));
@@ -296,6 +313,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     Q.lbs_weights = m->lbs_weights.p; Q.j_extra = m->j_extra.p;
     Q.selector_ids = m->selector_ids.p; Q.joint_map = m->joint_map.p;
     Q.n_tiles = (nv + BF_MESH_TILE - 1) / BF_MESH_TILE;
+    Q.v_nnz = v_nnz; Q.v_nzj = m->v_nzj.p; Q.v_nzw = m->v_nzw.p;
     Q.n_lmk_static = smplx ? d->n_lmk_static : 0; Q.n_lmk_dyn = smplx ? d->n_lmk_dynamic : 0;
     Q.n_dyn_rows = smplx ? d->n_dyn_rows : 0; Q.neck_joint = smplx ? d->neck_joint : 0;
     if (smplx) {
@@ -341,14 +359,24 @@ int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, floa
     if (n >= BF_MFMA_MIN_FRAMES) {
         // batched pose blend on the matrix cores (posedirs streamed once for up to 256 frames), then the per-frame
         // shape / skinning part only
-        const size_t ncols = (size_t)m->nv * 3, stride = bf_state_stride(m->nj, m->npf, m->nb);
+        const size_t ncols = (size_t)m->nv * 3;
         if (m->pose_off.n < (size_t)n * ncols) {
             if (m->pose_off.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(m->pose_off.p); m->pose_off.p = nullptr; }
             HIP_TRY(m->pose_off.alloc((size_t)n * ncols));
         }
-        for (int f0 = 0; f0 < n; f0 += 256)
-            HIP_TRY(bf_poseblend_launch(&m->mesh, state_dev + (size_t)f0 * stride, std::min(256, n - f0), m->pose_off.p + (size_t)f0 * ncols, stream));
+        // A operand of the GEMM: the pose features of the batch, frame-minor and zero padded
+        const int kpad = ((m->npf + 2 * BF_GEMM_KB - 1) / (2 * BF_GEMM_KB)) * 2 * BF_GEMM_KB, fpad = ((n + 127) / 128) * 128;
+        if (m->featT.n < (size_t)kpad * fpad) {
+            if (m->featT.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(m->featT.p); m->featT.p = nullptr; }
+            HIP_TRY(m->featT.alloc((size_t)kpad * fpad));
+        }
+        HIP_TRY(bf_poseblend_launch(&m->mesh, state_dev, n, m->featT.p, kpad, fpad, m->pose_off.p, stream));
         pose_off = m->pose_off.p;
+        if (m->mesh.v_nnz == 4 && m->nb <= 10 && !vposed) {
+            hipLaunchKernelGGL(bf_mesh_epilogue_batch_kernel, dim3((m->nv + 127) / 128, (n + BF_EPI_FRAMES - 1) / BF_EPI_FRAMES), dim3(128),
+                               (size_t)BF_EPI_FRAMES * (m->nj * 12 + 128 * 3) * sizeof(float), stream, m->mesh, state_dev, pose_off, n, vraw, vout,
+                               (joints || joints_ori || jraw) ? xpart : (float *)nullptr);
+        } else
         hipLaunchKernelGGL(bf_mesh_epilogue_kernel, grid, dim3(128), 0, stream, m->mesh, state_dev, pose_off, vraw, vout,
                            (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed);
     } else

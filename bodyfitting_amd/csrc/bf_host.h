@@ -61,6 +61,9 @@ struct bf_model {
     DevBuf<float> pose_mean, hand_comp, lmk_bary, dyn_bary;
     KpIO kp{};
     DevBuf<float> pose_off;       // [F][3NV] batched pose-blend result (MFMA path), grown on demand
+    DevBuf<float> featT;          // [K padded][F padded] pose features of a batch, frame-minor (the GEMM's A operand)
+    DevBuf<int> v_nzj;            // sparse skinning rows (MeshTab::v_nnz)
+    DevBuf<float> v_nzw;
     DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass
     std::vector<float> posedirs_host;
     std::vector<int> faces_host;  // body-model topology (for the SMPL+D stage), optional

@@ -10,7 +10,9 @@
 #define BF_VSUB 16          // view lanes per loss-joint pair in the projection phase (one DPP row)
 #define BF_KP_ROUNDS 3      // keypoint records staged in LDS for V <= 16*3 = 48 views
 #define BF_SEL_NNZ 8         // compacted skinning weights per selector vertex (real SMPL has <= 4)
-#define BF_MFMA_MIN_FRAMES 16  // from this batch size on the pose blend runs as one fp32-MFMA GEMM for all frames
+#define BF_MFMA_MIN_FRAMES 16
+#define BF_EPI_FRAMES 8      // frames one workgroup of the batched mesh epilogue walks over (its tile's tables stay in registers)
+#define BF_GEMM_KB 52        // K pairs per register block of the pose-blend GEMM (A operand resident in VGPRs)  // from this batch size on the pose blend runs as one fp32-MFMA GEMM for all frames
 #define BF_MESH_TILE 32     // vertices per workgroup of the full-mesh forward
 #define BF_MESH_RG 8        // pose-feature row groups per workgroup (split-K inside the workgroup)
 
@@ -69,6 +71,11 @@ struct MeshTab {
     const int *selector_ids;         // [n_selector]
     const int *joint_map;            // [n_joint_map]
     int n_tiles;                     // ceil(nv / BF_MESH_TILE)
+    // the non-zero skinning weights of every vertex, padded to v_nnz (4 or 8) entries; v_nnz = 0: some vertex has
+    // more than 8 bones, use the dense rows
+    int v_nnz;
+    const int *v_nzj;                // [nv][v_nnz]
+    const float *v_nzw;              // [nv][v_nnz]
     // face landmarks (SMPL-X): 51 static + 17 contour landmarks picked by the neck's yaw out of a 79-row table
     int n_lmk_static, n_lmk_dyn, n_dyn_rows, neck_joint;
     const int *faces;                // [nf][3]

@@ -321,62 +321,239 @@ bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__rest
 // A fragment: lane l holds A[i = l & 31][k = l >> 5]; B fragment: lane l holds B[k = l >> 5][j = l & 31];
 // accumulator: column = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-#define BF_PB_KC 16
-#define BF_PB_LD 17
-template <int FT>
-__global__ void __launch_bounds__(256)
-poseblend_mfma_kernel(MeshTab M, const float *__restrict__ state, int n_frames, float *__restrict__ pose_off) {
-    __shared__ float s_a[FT * 32 * BF_PB_LD];
+
+// A operand of the pose-blend GEMM: featT[p][f] = pose feature p of frame f, frame-minor so that the GEMM's lanes read
+// it coalesced; rows past npf and frames past n are zero.
+extern "C" __global__ void __launch_bounds__(256)
+bf_pack_feat_kernel(MeshTab M, const float *__restrict__ state, int n_frames, int kpad, int fpad, float *__restrict__ featT) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= kpad * fpad) return;
+    const int p = idx / fpad, f = idx - p * fpad;
+    const int stride = bf_state_stride(M.nj, M.npf, M.nb), feat_off = M.nj * 15;      // GR 9 + At 3 + Gt 3 per joint, then feat
+    featT[idx] = (p < M.npf && f < n_frames) ? state[(size_t)f * stride + feat_off + p] : 0.f;
+}
+
+// Pose blend of a whole batch on the matrix cores: pose_off[f][c] = sum_p feat[f][p] posedirs[p][c] (SURVEY.md 8a,
+// lbs.py pose_offsets), fp32 MFMA 32x32x2.  A workgroup owns 64 columns x 128 frames: each of its four waves takes 32
+// frames (two 32x32 accumulator tiles).  posedirs streams through LDS in blocks of 2 * BF_GEMM_KB rows, double
+// buffered: the global loads of block k + 1 (float2, coalesced 256-byte rows, 13 per thread) are in flight while the
+// MFMAs of block k run, and every posedirs element is fetched once per 128 frames.  The A operand (the frames' pose
+// features, frame-minor featT) sits in VGPRs, one block at a time with the next prefetched.
+extern "C" __global__ void __launch_bounds__(256, 2)
+bf_poseblend_gemm_kernel(MeshTab M, const float *__restrict__ featT, int kpad, int fpad, int n_frames, float *__restrict__ pose_off) {
+    constexpr int KB = BF_GEMM_KB, ROWS = 2 * KB, NLD = (ROWS * 32 + 255) / 256;      // float2 loads per thread and block
+    __shared__ __align__(16) float s_b[2][ROWS][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int npf = M.npf, ncols = 3 * M.nv;
-    const int col0 = (blockIdx.x * 4 + wave) * 32, col = col0 + (lane & 31), kh = lane >> 5;
-    const bool col_ok = col < ncols;
-    const int stride = bf_state_stride(M.nj, npf, M.nb), feat_off = M.nj * 15;      // GR 9 + At 3 + Gt 3 per joint, then feat
-    f32x16 acc[FT];
+    const int mi = lane & 31, kh = lane >> 5;
+    const int f0 = (blockIdx.y * 4 + wave) * 32;
+    const bool live = f0 < n_frames;                      // (idle waves still help with the staging)
+    const int cbase = blockIdx.x * 64;
+    const float *ap = featT + min(f0, fpad - 32) + mi;
+    // staging role: thread -> (row r0 + 8 q, column pair c2)
+    const int c2 = (tid & 31) * 2, r0 = tid >> 5;
+    const bool cpair = cbase + c2 + 1 < ncols, csingle = cbase + c2 < ncols;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int t = 0; t < FT; ++t)
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    float a_cur[KB];
+    float2 st[NLD];
+    auto fetch = [&](int kb) {                           // rows 2 kb .. 2 kb + ROWS of posedirs -> registers
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    for (int p0 = 0; p0 < npf; p0 += BF_PB_KC) {
-        __syncthreads();
-        for (int i = tid; i < FT * 32 * BF_PB_KC; i += 256) {
-            int f = i / BF_PB_KC, kk = i - f * BF_PB_KC;
-            s_a[f * BF_PB_LD + kk] = (f < n_frames && p0 + kk < npf) ? state[(size_t)f * stride + feat_off + p0 + kk] : 0.f;
+        for (int q = 0; q < NLD; ++q) {
+            const int r = r0 + 8 * q, p = 2 * kb + r;
+            float2 v = {0.f, 0.f};
+            if (r < ROWS && p < npf) {
+                const float *src = M.posedirs + (size_t)p * ncols + cbase + c2;
+                if (cpair) v = *(const float2 *)src; else if (csingle) v.x = src[0];
+            }
+            st[q] = v;
         }
-        __syncthreads();
+    };
+    auto stash = [&](int buf) {
 #pragma unroll
-        for (int kk = 0; kk < BF_PB_KC; kk += 2) {
-            const int p = p0 + kk + kh;
-            const float b = (col_ok && p < npf) ? M.posedirs[(size_t)p * ncols + col] : 0.f;
+        for (int q = 0; q < NLD; ++q) { const int r = r0 + 8 * q; if (r < ROWS) *(float2 *)&s_b[buf][r][c2] = st[q]; }
+    };
+    fetch(0);
 #pragma unroll
-            for (int t = 0; t < FT; ++t) {
-                const float a = s_a[(t * 32 + (lane & 31)) * BF_PB_LD + kk + kh];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+    for (int i = 0; i < KB; ++i) a_cur[i] = ap[(size_t)(2 * i + kh) * fpad];
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kb = 0; kb < kpad / 2; kb += KB) {
+        const bool more = kb + KB < kpad / 2;
+        if (more) fetch(kb + KB);
+        if (live) {
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+                const float b0 = s_b[buf][2 * i + kh][mi], b1 = s_b[buf][2 * i + kh][32 + mi];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b1, acc1, 0, 0, 0);
             }
         }
+        if (more) {
+            stash(buf ^ 1);
+#pragma unroll
+            for (int i = 0; i < KB; ++i) a_cur[i] = ap[(size_t)(2 * (kb + KB + i) + kh) * fpad];
+        }
+        __syncthreads();
+        buf ^= 1;
     }
-    if (col_ok) {
+    if (!live) return;
+    const int c0 = cbase + mi, c1 = c0 + 32;
 #pragma unroll
-        for (int t = 0; t < FT; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int f = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (f < n_frames) pose_off[(size_t)f * ncols + col] = acc[t][r];
-            }
+    for (int r = 0; r < 16; ++r) {
+        const int f = f0 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (f < n_frames) {
+            if (c0 < ncols) pose_off[(size_t)f * ncols + c0] = acc0[r];
+            if (c1 < ncols) pose_off[(size_t)f * ncols + c1] = acc1[r];
+        }
     }
 }
 
-// frames [f0, f0 + n) of the batch; `state` and `pose_off` already point at frame f0
-extern "C" hipError_t bf_poseblend_launch(const MeshTab *M, const float *state, int n, float *pose_off, hipStream_t stream) {
+// frames [0, n) of the batch
+extern "C" hipError_t bf_poseblend_launch(const MeshTab *M, const float *state, int n, float *featT, int kpad, int fpad,
+                                          float *pose_off, hipStream_t stream) {
     const int ncols = 3 * M->nv;
-    dim3 grid((ncols + 127) / 128);
-    if (n <= 32) hipLaunchKernelGGL(poseblend_mfma_kernel<1>, grid, dim3(256), 0, stream, *M, state, n, pose_off);
-    else if (n <= 64) hipLaunchKernelGGL(poseblend_mfma_kernel<2>, grid, dim3(256), 0, stream, *M, state, n, pose_off);
-    else if (n <= 128) hipLaunchKernelGGL(poseblend_mfma_kernel<4>, grid, dim3(256), 0, stream, *M, state, n, pose_off);
-    else hipLaunchKernelGGL(poseblend_mfma_kernel<8>, grid, dim3(256), 0, stream, *M, state, n, pose_off);
+    hipLaunchKernelGGL(bf_pack_feat_kernel, dim3((kpad * fpad + 255) / 256), dim3(256), 0, stream, *M, state, n, kpad, fpad, featT);
+    hipLaunchKernelGGL(bf_poseblend_gemm_kernel, dim3((ncols + 63) / 64, fpad / 128), dim3(256), 0, stream, *M, (const float *)featT,
+                       kpad, fpad, n, pose_off);
     return hipGetLastError();
 }
 
+// Batched epilogue (4-sparse skinning rows, nb <= 10): one THREAD per vertex, 128 vertices per workgroup, walking
+// BF_EPI_FRAMES frames.  The vertex's tables stay in registers (three shapedirs rows, template, four bones + weights);
+// the frames' bone transforms and (beta | t | s) records are staged in LDS once.  Per vertex and frame: shaped vertex +
+// pose offset (from the GEMM) -> T = sum_4 w A_j -> skinning -> similarity: ~100 VALU instructions, 16 b128 LDS reads,
+// nothing of the model re-read.  The extra-joint partial sums keep the 32-vertex tiling the joints kernel expects.
+extern "C" __global__ void __launch_bounds__(128)
+bf_mesh_epilogue_batch_kernel(MeshTab M, const float *__restrict__ state, const float *__restrict__ pose_off, int n_frames,
+                              float *__restrict__ vraw, float *__restrict__ vout, float *__restrict__ xpart) {
+    constexpr int FE = BF_EPI_FRAMES, VT = 128;
+    extern __shared__ __align__(16) float s_dyn[];          // [FE][nj * 12] bone transforms | [FE][VT * 3] raw vertices
+    __shared__ __align__(16) float s_beta[FE][16];            // beta (12, zero padded) | t (3) | s * cscale
+    const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv, ncols = 3 * nv;
+    const int tid = threadIdx.x, nj12 = nj * 12;
+    float *s_raw = s_dyn + FE * nj12;
+    const int fbase = blockIdx.y * FE, nf = min(FE, n_frames - fbase);
+    const size_t stride = bf_state_stride(nj, npf, nb);
+    for (int e0 = tid; e0 < nj12; e0 += 128) {
+        const int j = e0 / 12, e = e0 - j * 12, a = e >> 2, b = e & 3;
+        const size_t src = b < 3 ? (size_t)(j * 9 + a * 3 + b) : (size_t)(nj * 9 + j * 3 + a);
+        float tmp[FE];
+#pragma unroll
+        for (int f = 0; f < FE; ++f) tmp[f] = f < nf ? state[(size_t)(fbase + f) * stride + src] : 0.f;
+#pragma unroll
+        for (int f = 0; f < FE; ++f) s_dyn[f * nj12 + e0] = tmp[f];
+    }
+    {
+        const size_t boff = (size_t)nj * 15 + npf + (size_t)nj * 3;           // beta, t, sc are contiguous in the state record
+        for (int i = tid; i < FE * 16; i += 128) {
+            const int f = i >> 4, e = i & 15;
+            float v = 0.f;
+            if (f < nf) {
+                const float *rec = state + (size_t)(fbase + f) * stride + boff;
+                if (e < 12) v = e < nb ? rec[e] : 0.f;
+                else if (e < 15) v = rec[nb + (e - 12)];
+                else v = rec[nb + 3] * rec[nb + 4];
+            }
+            s_beta[f][e] = v;
+        }
+    }
+    const int v = blockIdx.x * VT + tid;
+    const bool ok = v < nv;
+    const int vc = ok ? v : nv - 1;
+    float sd[3][10], vt[3], w4[4];
+    int j4[4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float *sp = M.shapedirs + (size_t)(vc * 3 + c) * nb;
+#pragma unroll
+        for (int l = 0; l < 10; ++l) sd[c][l] = l < nb ? sp[l] : 0.f;
+        vt[c] = M.v_template[vc * 3 + c];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { j4[q] = M.v_nzj[(size_t)vc * 4 + q] * 12; w4[q] = M.v_nzw[(size_t)vc * 4 + q]; }
+    // the pose offsets of all the frames are requested up front (one memory latency, not one per frame)
+    float ofs[FE][3];
+#pragma unroll
+    for (int f = 0; f < FE; ++f) {
+        const float *po = pose_off + (size_t)(fbase + (f < nf ? f : 0)) * ncols + (size_t)vc * 3;
+        ofs[f][0] = po[0]; ofs[f][1] = po[1]; ofs[f][2] = po[2];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < FE; ++f) {
+        if (f < nf) {
+            const float4 bq0 = *(const float4 *)&s_beta[f][0], bq1 = *(const float4 *)&s_beta[f][4], bq2 = *(const float4 *)&s_beta[f][8];
+            const float be[10] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w, bq2.x, bq2.y};
+            float vp[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float a2 = 0.f;
+#pragma unroll
+                for (int l = 0; l < 10; ++l) a2 += sd[c][l] * be[l];
+                vp[c] = vt[c] + a2 + ofs[f][c];
+            }
+            float T[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 *A = (const float4 *)(s_dyn + f * nj12 + j4[q]);
+                const float4 r0 = A[0], r1 = A[1], r2 = A[2];
+                T[0] += w4[q] * r0.x; T[1] += w4[q] * r0.y; T[2] += w4[q] * r0.z; T[3] += w4[q] * r0.w;
+                T[4] += w4[q] * r1.x; T[5] += w4[q] * r1.y; T[6] += w4[q] * r1.z; T[7] += w4[q] * r1.w;
+                T[8] += w4[q] * r2.x; T[9] += w4[q] * r2.y; T[10] += w4[q] * r2.z; T[11] += w4[q] * r2.w;
+            }
+            const float x0 = T[0] * vp[0] + T[1] * vp[1] + T[2] * vp[2] + T[3];
+            const float x1 = T[4] * vp[0] + T[5] * vp[1] + T[6] * vp[2] + T[7];
+            const float x2 = T[8] * vp[0] + T[9] * vp[1] + T[10] * vp[2] + T[11];
+            s_raw[(f * VT + tid) * 3] = ok ? x0 : 0.f; s_raw[(f * VT + tid) * 3 + 1] = ok ? x1 : 0.f; s_raw[(f * VT + tid) * 3 + 2] = ok ? x2 : 0.f;
+        }
+    }
+    __syncthreads();
+    // coalesced stores out of the LDS copy: 384 consecutive floats per frame
+    {
+        const int c0 = blockIdx.x * VT * 3;
+#pragma unroll
+        for (int f = 0; f < FE; ++f) {
+            if (f < nf) {
+                const float4 bq3 = *(const float4 *)&s_beta[f][12];
+                const size_t o = (size_t)(fbase + f) * ncols + c0;
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int c = tid + 128 * r, kk = c % 3;
+                    if (c0 + c < ncols) {
+                        const float x = s_raw[f * VT * 3 + c];
+                        if (vraw) vraw[o + c] = x;
+                        if (vout) vout[o + c] = (x + (kk == 0 ? bq3.x : (kk == 1 ? bq3.y : bq3.z))) * bq3.w;
+                    }
+                }
+            }
+        }
+    }
+    if (xpart) {
+        // extra-joint partial sums: a thread keeps one (32-vertex sub-tile, extra joint, coordinate) regressor row in
+        // registers and walks the frames
+        const int ne3 = M.n_extra * 3, nsub = VT / BF_MESH_TILE;
+        for (int i = tid; i < nsub * ne3; i += 128) {
+            const int sub = i / ne3, q = i - sub * ne3, e = q / 3, kk = q - e * 3;
+            const int tile = blockIdx.x * nsub + sub, v0 = tile * BF_MESH_TILE;
+            if (tile >= M.n_tiles) continue;
+            const float *row = M.j_extra + (size_t)e * nv + v0;
+            float rv[BF_MESH_TILE];
+#pragma unroll
+            for (int t = 0; t < BF_MESH_TILE; ++t) rv[t] = v0 + t < nv ? row[t] : 0.f;
+            for (int f = 0; f < nf; ++f) {
+                float a3 = 0.f;
+#pragma unroll
+                for (int t = 0; t < BF_MESH_TILE; ++t) a3 += rv[t] * s_raw[(f * VT + sub * BF_MESH_TILE + t) * 3 + kk];
+                xpart[((size_t)(fbase + f) * M.n_tiles + tile) * ne3 + q] = a3;
+            }
+        }
+    }
+}
 
 // Per-frame part of the batched path: shaped vertex + pose offset (from the MFMA GEMM) -> skinning, for one
 // 32-vertex tile.  grid (n_tiles, F), 128 threads (96 = vertex x coordinate, the last 32 take the extra-joint
