@@ -420,6 +420,32 @@ int bf_smpl_forward(bf_model *m, int n, const float *betas, const float *global_
     return BF_OK;
 }
 
+// result arena k becomes the one the DevBuf views and the pinned mirrors point at
+void bf_use_arena(bf_batch *b, int k) {
+    float *d = k ? b->res_b.p : b->res.p, *h = k ? b->h_res_b : b->h_res;
+    b->params.slice(d + b->res_off[0], b->res_cnt[0]); b->terms.slice(d + b->res_off[1], b->res_cnt[1]);
+    b->state.slice(d + b->res_off[2], b->res_cnt[2]); b->joints.slice(d + b->res_off[3], b->res_cnt[3]);
+    b->vout.slice(d + b->res_off[4], b->res_cnt[4]);
+    b->h_params = h + b->res_off[0]; b->h_terms = h + b->res_off[1]; b->h_state = h + b->res_off[2];
+    b->h_joints = h + b->res_off[3]; b->h_vout = h + b->res_off[4];
+    b->cur = k;
+}
+
+int bf_sync_all(bf_batch *b) {
+    if (b->copy_stream) HIP_TRY(hipStreamSynchronize(b->copy_stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->copy_pending[0] = b->copy_pending[1] = false;
+    return BF_OK;
+}
+
+int bf_guard_arena(bf_batch *b) {
+    if (b->copy_pending[b->cur]) {
+        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_copied[b->cur], 0));
+        b->copy_pending[b->cur] = false;
+    }
+    return BF_OK;
+}
+
 int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
     if (!m || !out || n_frames <= 0 || n_views <= 0) return fail(BF_ERR_INVALID, "bf_batch_create: bad argument");
     *out = nullptr;
@@ -440,16 +466,19 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
                      n_joints = F * m->n_joint_map * 3, n_v = F * m->nv * 3;
         const size_t o_terms = up(n_par), o_state = o_terms + up(n_terms), o_joints = o_state + up(n_state),
                      o_v = o_joints + up(n_joints), total = o_v + up(n_v);
-        ok = ok && b->res.alloc(total) == hipSuccess;
+        ok = ok && b->res.alloc(total) == hipSuccess && b->res_b.alloc(total) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&b->h_res, total * sizeof(float)) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&b->h_res_b, total * sizeof(float)) == hipSuccess;
+        ok = ok && hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking) == hipSuccess;
+        for (int k = 0; k < 2; ++k)
+            ok = ok && hipEventCreateWithFlags(&b->ev_done[k], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&b->ev_copied[k], hipEventDisableTiming) == hipSuccess;
         if (ok) {
-            ok = hipMemset(b->res.p, 0, total * sizeof(float)) == hipSuccess;
-            b->params.slice(b->res.p, n_par); b->terms.slice(b->res.p + o_terms, n_terms);
-            b->state.slice(b->res.p + o_state, n_state); b->joints.slice(b->res.p + o_joints, n_joints);
-            b->vout.slice(b->res.p + o_v, n_v);
-            b->h_params = b->h_res; b->h_terms = b->h_res + o_terms; b->h_state = b->h_res + o_state;
-            b->h_joints = b->h_res + o_joints; b->h_vout = b->h_res + o_v;
+            ok = hipMemset(b->res.p, 0, total * sizeof(float)) == hipSuccess && hipMemset(b->res_b.p, 0, total * sizeof(float)) == hipSuccess;
+            const size_t offs[5] = {0, o_terms, o_state, o_joints, o_v}, cnts[5] = {n_par, n_terms, n_state, n_joints, n_v};
+            for (int i = 0; i < 5; ++i) { b->res_off[i] = offs[i]; b->res_cnt[i] = cnts[i]; }
             b->res_small = o_v;
+            bf_use_arena(b, 0);
         }
     }
     ok = ok && b->proj.alloc(F * n_views * 12) == hipSuccess;
@@ -475,10 +504,18 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
 
 void bf_batch_destroy(bf_batch *b) {
     if (!b) return;
+    if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     for (auto &e : b->ring) if (e) (void)hipEventDestroy(e);
     if (b->h_res) (void)hipHostFree(b->h_res);
+    if (b->h_res_b) (void)hipHostFree(b->h_res_b);
+    for (int k = 0; k < 2; ++k) {
+        if (b->graph_pipe[k]) (void)hipGraphExecDestroy(b->graph_pipe[k]);
+        if (b->ev_done[k]) (void)hipEventDestroy(b->ev_done[k]);
+        if (b->ev_copied[k]) (void)hipEventDestroy(b->ev_copied[k]);
+    }
+    if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
     delete b;
 }
 
@@ -549,6 +586,7 @@ static int reset_adam(bf_batch *b) {
 int bf_batch_reset(bf_batch *b) {
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_reset: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
+    { int rg_ = bf_guard_arena(b); if (rg_) return rg_; }
     HIP_TRY(hipMemcpyAsync(b->params.p, b->params0.p, b->params.n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
     HIP_TRY(hipMemsetAsync(b->adam_m.p, 0, b->adam_m.n * sizeof(float), b->stream));
     HIP_TRY(hipMemsetAsync(b->adam_v.p, 0, b->adam_v.n * sizeof(float), b->stream));
@@ -572,7 +610,7 @@ int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_po
         std::memcpy(q + m->fit.off_beta, init_betas + (size_t)f * nb, sizeof(float) * nb);
         std::memcpy(q + m->fit.off_orient, init_pose + (size_t)f * pose_stride, sizeof(float) * 3);
     }
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     HIP_TRY(hipMemcpy(b->params.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
     return reset_adam(b);
 }
@@ -580,7 +618,7 @@ int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_po
 int bf_batch_set_params(bf_batch *b, const float *params) {
     if (!b || !params) return fail(BF_ERR_INVALID, "bf_batch_set_params: null argument");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     HIP_TRY(hipMemcpy(b->params.p, params, b->params.n * sizeof(float), hipMemcpyHostToDevice));
     return reset_adam(b);
 }
@@ -588,7 +626,7 @@ int bf_batch_set_params(bf_batch *b, const float *params) {
 int bf_batch_get_params(bf_batch *b, float *params) {
     if (!b || !params) return fail(BF_ERR_INVALID, "bf_batch_get_params: null argument");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (b->fetched) std::memcpy(params, b->h_params, b->params.n * sizeof(float));
     else HIP_TRY(hipMemcpy(params, b->params.p, b->params.n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
@@ -620,7 +658,7 @@ static int ensure_adam_tab(bf_batch *b, const bf_hyper &h, int upto) {
         tab[(size_t)(t - 1) * 3 + 1] = (float)((double)h.lr / bc1);
         tab[(size_t)(t - 1) * 3 + 2] = (float)std::sqrt(bc2);
     }
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (b->adam_tab.p) { (void)hipFree(b->adam_tab.p); b->adam_tab.p = nullptr; }
     HIP_TRY(b->adam_tab.upload(tab));
     b->adam_cap = cap;
@@ -658,7 +696,8 @@ static int enqueue_plain(bf_batch *b, int n_iters, const HyperDev &hd, const Fra
     } else if (ev) HIP_TRY(hipEventRecord(ev[2], b->stream));
     if (fetch) {
         // one copy of the result arena: [params | terms | state | joints] and, when they were built, the vertices
-        HIP_TRY(hipMemcpyAsync(b->h_res, b->res.p, (want_v ? b->res.n : b->res_small) * fb, hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->cur ? b->h_res_b : b->h_res, b->cur ? b->res_b.p : b->res.p, (want_v ? b->res.n : b->res_small) * fb,
+                                hipMemcpyDeviceToHost, b->stream));
     }
     return BF_OK;
 }
@@ -680,15 +719,54 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES), fetch = flags & BF_FIT_FETCH;
     b->ev = b->ring.data() + (size_t)(b->ring_n % bf_batch::kRing) * 4;
     const size_t fb = sizeof(float);
+    // (a small fetch is cheaper as a copy node inside the graph than as a second stream with two event hand-offs)
+    const bool big_fetch = (want_v ? b->res.n : b->res_small) * sizeof(float) >= (size_t)512 * 1024;
+    const bool pipelined = (flags & BF_FIT_GRAPH) && reset && !dense_losses && !dense && fetch && big_fetch;
+    if (!pipelined) {                // (a pipelined fetch may still be reading the arena this call writes)
+        rc = bf_guard_arena(b);
+        if (rc) return rc;
+    }
     if ((flags & BF_FIT_GRAPH) && reset && !dense_losses && !dense) {
         // the whole call as one hipGraph launch: the host issues a single command per fit
         // the MFMA batch path may grow its scratch buffer: make sure that happened before capturing
         if (want_v && b->F >= BF_MFMA_MIN_FRAMES && m->pose_off.n < (size_t)b->F * m->nv * 3) {
+            { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
             rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
             if (rc) return rc;
-            HIP_TRY(hipStreamSynchronize(b->stream));
+            { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
         }
-        bf_graph_key key{n_iters, flags, h};
+        bf_graph_key key{n_iters, flags, pipelined ? (b->cur ^ 1) : b->cur, h};
+        if (pipelined) {
+            // pipelined fetch: this fit writes the result arena the previous one did not use; its device-to-host copy
+            // runs on the copy stream, under the kernels of whatever is enqueued next
+            const int k = b->cur ^ 1;
+            if (b->copy_pending[k]) { HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_copied[k], 0)); b->copy_pending[k] = false; }
+            bf_use_arena(b, k);
+            io = bf_frame_io(b, false);
+            if (!b->graph_pipe[k] || std::memcmp(&key, &b->graph_pipe_key[k], sizeof key) != 0) {
+                if (b->graph_pipe[k]) { (void)hipGraphExecDestroy(b->graph_pipe[k]); b->graph_pipe[k] = nullptr; }
+                hipGraph_t graph = nullptr;
+                HIP_TRY(hipStreamBeginCapture(b->stream, hipStreamCaptureModeThreadLocal));
+                rc = enqueue_plain(b, n_iters, hd, io, true, want_v, false, 0, nullptr);
+                hipError_t e = hipStreamEndCapture(b->stream, &graph);
+                if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                HIP_TRY(e);
+                HIP_TRY(hipGraphInstantiate(&b->graph_pipe[k], graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                b->graph_pipe_key[k] = key;
+            }
+            HIP_TRY(hipEventRecord(b->ev[0], b->stream));
+            HIP_TRY(hipGraphLaunch(b->graph_pipe[k], b->stream));
+            HIP_TRY(hipEventRecord(b->ev[1], b->stream));       // (no events inside a graph: the whole call is charged to ms[0])
+            HIP_TRY(hipEventRecord(b->ev[2], b->stream));
+            HIP_TRY(hipEventRecord(b->ev[3], b->stream));
+            HIP_TRY(hipEventRecord(b->ev_done[k], b->stream));
+            HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_done[k], 0));
+            HIP_TRY(hipMemcpyAsync(k ? b->h_res_b : b->h_res, k ? b->res_b.p : b->res.p, (want_v ? b->res.n : b->res_small) * fb,
+                                   hipMemcpyDeviceToHost, b->copy_stream));
+            HIP_TRY(hipEventRecord(b->ev_copied[k], b->copy_stream));
+            b->copy_pending[k] = true;
+        } else {
         if (!b->graph_exec || std::memcmp(&key, &b->graph_key, sizeof key) != 0) {
             if (b->graph_exec) { (void)hipGraphExecDestroy(b->graph_exec); b->graph_exec = nullptr; }
             hipGraph_t graph = nullptr;
@@ -706,6 +784,7 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
         HIP_TRY(hipEventRecord(b->ev[1], b->stream));       // (no events inside a graph: the whole call is charged to ms[0])
         HIP_TRY(hipEventRecord(b->ev[2], b->stream));
         HIP_TRY(hipEventRecord(b->ev[3], b->stream));
+        }
         b->fetched = fetch;
         b->ring_n += 1;
         b->steps_done = n_iters;
@@ -742,7 +821,8 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
             HIP_TRY(hipEventRecord(b->ev[2], b->stream));
         }
         if (fetch) {
-            HIP_TRY(hipMemcpyAsync(b->h_res, b->res.p, ((want_v || dense) ? b->res.n : b->res_small) * fb, hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->cur ? b->h_res_b : b->h_res, b->cur ? b->res_b.p : b->res.p,
+                                   ((want_v || dense) ? b->res.n : b->res_small) * fb, hipMemcpyDeviceToHost, b->stream));
         }
     }
     b->fetched = fetch;
@@ -763,10 +843,12 @@ int bf_loss_grad(bf_batch *b, const bf_hyper *hyper, float *terms, float *grads)
     int rc = ensure_adam_tab(b, h, 1);
     if (rc) return rc;
     HyperDev hd = bf_to_dev(h);
+    rc = bf_guard_arena(b);
+    if (rc) return rc;
     FrameIO io = bf_frame_io(b, true);
     if (m->kp_dense) { rc = bf_dense_loss_grad(b, h, hd, io); if (rc) return rc; }
     else HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, m->fit_smem, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (terms) HIP_TRY(hipMemcpy(terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));
     if (grads) HIP_TRY(hipMemcpy(grads, b->grads.p, b->grads.n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
@@ -775,7 +857,7 @@ int bf_loss_grad(bf_batch *b, const bf_hyper *hyper, float *terms, float *grads)
 int bf_batch_sync(bf_batch *b) {
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_sync: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     return BF_OK;
 }
 
@@ -783,7 +865,7 @@ int bf_batch_get_result(bf_batch *b, float *vertices, float *joints, float *full
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_get_result: null batch");
     const bf_model *m = b->m;
     HIP_TRY(hipSetDevice(m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if ((vertices || joints) && !b->have_result)
         return fail(BF_ERR_INVALID, "bf_batch_get_result: no mesh was evaluated (BF_FIT_NO_VERTICES or no bf_fit yet)");
     if (b->fetched) {
@@ -812,7 +894,7 @@ int bf_batch_export_params_dev(bf_batch *b, void *dst_dev) {
     if (!b || !dst_dev) return fail(BF_ERR_INVALID, "bf_batch_export_params_dev: null argument");
     HIP_TRY(hipSetDevice(b->m->device));
     HIP_TRY(hipMemcpyAsync(dst_dev, b->params.p, b->params.n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     return BF_OK;
 }
 
@@ -837,7 +919,7 @@ int bf_batch_timing_reset(bf_batch *b) {
 int bf_batch_timing_sum(bf_batch *b, float ms[4], int32_t *n_calls) {
     if (!b || !ms || !n_calls) return fail(BF_ERR_INVALID, "bf_batch_timing_sum: null argument");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     int n = std::min(b->ring_n, (int)bf_batch::kRing);
     double acc[4] = {0, 0, 0, 0};
     for (int i = 0; i < n; ++i) {
@@ -858,7 +940,7 @@ int bf_batch_timing_sum(bf_batch *b, float ms[4], int32_t *n_calls) {
 int bf_batch_debug_dump(bf_batch *b, float *dst, int n) {
     if (!b || !dst || n <= 0 || n > 8192) return fail(BF_ERR_INVALID, "bf_batch_debug_dump: bad argument");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     HIP_TRY(hipMemcpy(dst, b->debug.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
 }

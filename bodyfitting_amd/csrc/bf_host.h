@@ -70,7 +70,7 @@ struct bf_model {
     DevBuf<int> faces_d, adj_start, adj;   // faces and the vertex -> (face, corner) lists, built on first use
 };
 
-struct bf_graph_key { int n_iters; uint32_t flags; bf_hyper h; };
+struct bf_graph_key { int n_iters; uint32_t flags; int arena; bf_hyper h; };     // (arena: the result arena its nodes point at)
 
 struct bf_batch {
     bf_model *m = nullptr;
@@ -84,9 +84,19 @@ struct bf_batch {
     DevBuf<float> params0;          // parameters of the last set_init / set_params
     // results live in ONE device arena [params | terms | state | joints | vout] mirrored by ONE pinned host arena, so a
     // fetch is a single device-to-host copy of the prefix that is wanted
-    DevBuf<float> res;
-    float *h_res = nullptr;
+    // Two such pairs: a fresh fit (BF_FIT_RESET + GRAPH + FETCH) writes the arena the previous fit did not use and its
+    // fetch runs on a second stream, under the next fit's kernels.
+    DevBuf<float> res;              // (device arena 0; arena 1 is res_b)
+    DevBuf<float> res_b;
+    float *h_res = nullptr, *h_res_b = nullptr;
     size_t res_small = 0;           // floats up to the end of `joints` (everything but the vertices)
+    size_t res_off[5] = {0, 0, 0, 0, 0}, res_cnt[5] = {0, 0, 0, 0, 0};   // params, terms, state, joints, vout
+    int cur = 0;                    // arena the DevBuf views / h_* pointers are on
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    bool copy_pending[2] = {false, false};
+    hipGraphExec_t graph_pipe[2] = {nullptr, nullptr};   // kernels-only graphs of the pipelined path, one per arena
+    bf_graph_key graph_pipe_key[2]{};
     float *h_params = nullptr, *h_vout = nullptr, *h_joints = nullptr, *h_terms = nullptr, *h_state = nullptr;
     bool fetched = false;
     int steps_done = 0;
@@ -133,6 +143,9 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
 int bf_dense_loss_grad(bf_batch *b, const bf_hyper &h, const HyperDev &hd, FrameIO io);
 int bf_ensure_dense_buffers(bf_batch *b);
 HyperDev bf_to_dev(const bf_hyper &h);
+int bf_sync_all(bf_batch *b);            // copy stream, then compute stream
+int bf_guard_arena(bf_batch *b);         // the compute stream waits for a fetch still reading the current arena
+void bf_use_arena(bf_batch *b, int k);
 FrameIO bf_frame_io(bf_batch *b, bool want_grads);
 }
 extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);

@@ -160,7 +160,7 @@ int bf_ensure_dense_buffers(bf_batch *b) {
 int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_set_scans: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (!scans) {                                  // detach
         b->scans.clear();
         if (b->cscale.p) { (void)hipFree(b->cscale.p); b->cscale.p = nullptr; }
@@ -326,7 +326,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
                        const int32_t *contour_count, const float *contour_xy) {
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_set_masks: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (n_masks <= 0 || !masks) { b->has_masks = false; return BF_OK; }
     if (!view_index || !contour_count || !contour_xy || H <= 0 || W <= 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: bad argument");
     const int F = b->F, nv = b->m->nv;
@@ -371,12 +371,14 @@ int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *d
     if (hyper) h = *hyper; else bf_hyper_default(&h);
     HyperDev hd = bf_to_dev(h);
     b->mask.imsize = h.imsize;
-    int rc = launch_state_and_mesh(b, hd);
+    int rc = bf_guard_arena(b);
+    if (rc) return rc;
+    rc = launch_state_and_mesh(b, hd);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
     rc = launch_mask_kernels(b, 1.0f);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (loss) HIP_TRY(hipMemcpy(loss, b->mk_loss.p, (size_t)b->F * sizeof(float), hipMemcpyDeviceToHost));
     if (dverts) HIP_TRY(hipMemcpy(dverts, b->dvout.p, b->dvout.n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
@@ -392,6 +394,7 @@ int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
     bf_hyper h;
     if (hyper) h = *hyper; else bf_hyper_default(&h);
     const int F = b->F, nv = m->nv, nf = (int)m->faces_host.size() / 3;
+    { int rg_ = bf_guard_arena(b); if (rg_) return rg_; }
     if (!m->faces_d.p) {
         // vertex -> (face, corner) lists in the order compute_normal_torch adds them: corner by corner, faces ascending
         std::vector<int> start(nv + 1, 0), adj(m->faces_host.size());
@@ -456,7 +459,7 @@ int bf_batch_get_displacement(bf_batch *b, float *displacement) {
     if (!b || !displacement) return fail(BF_ERR_INVALID, "bf_batch_get_displacement: null argument");
     if (!b->have_disp) return fail(BF_ERR_INVALID, "bf_batch_get_displacement: no bf_fit_displacement yet");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     HIP_TRY(hipMemcpy(displacement, b->disp.p, b->disp.n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
 }
@@ -465,7 +468,7 @@ int bf_batch_get_displacement(bf_batch *b, float *displacement) {
 int bf_batch_debug_disp_moment(bf_batch *b, float *m_out) {
     if (!b || !m_out || !b->have_disp) return fail(BF_ERR_INVALID, "bf_batch_debug_disp_moment: bad argument");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     HIP_TRY(hipMemcpy(m_out, b->disp_m.p, b->disp_m.n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
 }

@@ -239,3 +239,28 @@ def test_graph_replay_equals_host_issued_commands(dev_model, smpl_model):
     np.testing.assert_array_equal(b.get_params(), a.get_params())
     a.close()
     b.close()
+
+
+def test_pipelined_fetch_alternates_result_arenas(dev_model, smpl_model):
+    """A fetch of >= 512 KB leaves the graph: fresh fits alternate between two result arenas and the device-to-host
+    copy of one runs under the kernels of the next.  Results must not depend on it, including when a host-issued
+    (non-graph) call follows immediately and writes the arena a copy may still be reading."""
+    from bodyfitting_amd import _lib
+    probs = [S.make_problem(smpl_model, frame=f % 4, n_views=12) for f in range(8)]     # 8 x 82 KB of vertices
+    a, b = _batch(dev_model, probs), _batch(dev_model, probs)
+    a.fit(12, flags=_lib.FIT_FETCH)
+    want_p, want_r = a.get_params(), a.get_result()
+    for _ in range(4):                                                      # back to back, no sync in between
+        b.fit(12, flags=_lib.FIT_FETCH | _lib.FIT_RESET | _lib.FIT_GRAPH)
+    np.testing.assert_array_equal(b.get_params(), want_p)
+    for x, y in zip(b.get_result(), want_r):
+        np.testing.assert_array_equal(x, y)
+    # pipelined call, then straight away a continuing host-issued call on the same arena
+    b.fit(12, flags=_lib.FIT_FETCH | _lib.FIT_RESET | _lib.FIT_GRAPH)
+    b.fit(5, flags=_lib.FIT_FETCH)
+    a.fit(5, flags=_lib.FIT_FETCH)
+    np.testing.assert_array_equal(b.get_params(), a.get_params())
+    for x, y in zip(b.get_result(), a.get_result()):
+        np.testing.assert_array_equal(x, y)
+    a.close()
+    b.close()
