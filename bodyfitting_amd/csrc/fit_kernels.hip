@@ -462,7 +462,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
     };
     typedef float v2f __attribute__((ext_vector_type(2)));
-    auto project = [&]() {
+    auto project = [&](bool want_loss) {
         BF_MARK(45, 0, bf_it, bf_t0);
         const float tX = Pcur[0], tY = Pcur[1], tZ = Pcur[2];
         const float sc = Pcur[3] * cscale;
@@ -511,28 +511,21 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_MARK(43, 0, bf_it, bf_t0);
         // sum over the 16 view lanes of the pair (fixed DPP tree), route dL/dX to its source, and leave this wave's
         // share of d/dt, d/ds and of the loss value for the Adam phase
-        float ga0 = row16_sum(g0.x), ga1 = row16_sum(g1.x), ga2 = row16_sum(g2.x), la = row16_sum(lsum.x);
-        float gb0 = row16_sum(g0.y), gb1 = row16_sum(g1.y), gb2 = row16_sum(g2.y), lb = row16_sum(lsum.y);
-        if (vsub == 0) {
+        const float ga0 = row16_sum(g0.x), ga1 = row16_sum(g1.x), ga2 = row16_sum(g2.x);
+        const float gb0 = row16_sum(g0.y), gb1 = row16_sum(g1.y), gb2 = row16_sum(g2.y);
+        float la = 0.f, lb = 0.f;
+        if (want_loss) { la = row16_sum(lsum.x); lb = row16_sum(lsum.y); }     // (the value only leaves with the last forward pass)
+        if (vsub == 0 && wave < 4) {
             if (ja_on) { atomicAdd(ldst_a + 0, ga0 * sc); atomicAdd(ldst_a + 1, ga1 * sc); atomicAdd(ldst_a + 2, ga2 * sc); }
             if (jb_on) { atomicAdd(ldst_b + 0, gb0 * sc); atomicAdd(ldst_b + 1, gb1 * sc); atomicAdd(ldst_b + 2, gb2 * sc); }
+            // this pair's share of d/dt, d/ds and of the loss value, for the Adam phase (which adds the 16 pair slots in
+            // slot order); joints off the end have zero records, their sums are exactly 0
+            const float gsa = ga0 * y0.x + ga1 * y1.x + ga2 * y2.x, gsb = gb0 * y0.y + gb1 * y1.y + gb2 * y2.y;
+            float4 q0 = {ga0 + gb0, ga1 + gb1, ga2 + gb2, jb_on ? gsa + gsb : (ja_on ? gsa : 0.f)};
+            *(float4 *)(S.part + pslot * 8) = q0;
+            S.part[pslot * 8 + 4] = la + lb;
         }
         BF_MARK(44, 0, bf_it, bf_t0);
-        // (joints off the end have zero records: their sums are exactly 0)
-        const float gsa = ga0 * y0.x + ga1 * y1.x + ga2 * y2.x, gsb = gb0 * y0.y + gb1 * y1.y + gb2 * y2.y;
-        auto four = [&](float v) {                  // rows 0..3 of the wave, each row-uniform: (r0 + r1) + (r2 + r3)
-            float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
-            float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
-            float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
-            float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
-            return (a + b) + (c + d);
-        };
-        float w0 = four(ga0 + gb0), w1 = four(ga1 + gb1), w2 = four(ga2 + gb2);
-        float w3 = four(jb_on ? gsa + gsb : (ja_on ? gsa : 0.f)), w4 = four(la + lb);
-        if (lane == 0 && wave < 4) {
-            float *wp = S.part + wave * 8;
-            wp[0] = w0; wp[1] = w1; wp[2] = w2; wp[3] = w3; wp[4] = w4;
-        }
     };
 
 #ifndef BF_NO_GMM
@@ -580,14 +573,15 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             pose_blend(std::integral_constant<int, 2>());
             BF_SYNC();                 // B
             BF_GMM_CHUNK(2)
-            BF_SYNC();                 // C
             BF_GMM_CHUNK(3)
+            BF_SYNC();                 // C
+            BF_SYNC();                 // D (+E): projection, view reduction and routing: VALU-bound on the geometry waves, no GMM here
             BF_GMM_CHUNK(4)
             BF_GMM_CHUNK(5)
-            BF_GMM_CHUNK(6)
-            BF_SYNC();                 // D (+E): projection, view reduction and routing run on the geometry waves
-            BF_GMM_CHUNK(7)
             BF_SYNC();                 // F
+            BF_GMM_CHUNK(6)
+            BF_GMM_CHUNK(7)
+            BF_SYNC();                 // G
             BF_GMM_CHUNK(8)
 #undef BF_GMM_CHUNK
             const v2f y = y0 + y1;
@@ -602,7 +596,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 yt += Pt[2 * e2 + 1] * (tail_c ? t.w : t.z);
             }
             S.gtail[gwi * 64 + lane] = yt;
-            BF_SYNC();                 // G
+            BF_WAVE_FENCE();
             float ta = dA.x * ya, tb = dA.y * yb;
             if (lane < 5) {
                 float ysa = 0.f, ysb = 0.f;
@@ -793,7 +787,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_SYNC();
 
         // ================= phase D: similarity, multi-view projection, GMoF and its gradient
-        project();
+        project(it == n_iters - 1 || mode == 1);
         BF_SYNC();
 
         {
@@ -834,6 +828,16 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             S.dGt[tq] += ext ? dat + ext[EXT_G + tq] : dat;     // + dL/d(chain joint) of the dense keypoint loss
             float4 drow0 = {r0 - dat * S.J[ci * 3], r1 - dat * S.J[ci * 3 + 1], r2 - dat * S.J[ci * 3 + 2], 0.f};
             *(float4 *)(S.dGR + tq * 4) = drow0;
+        }
+        if (tq >= 128 && tq < 133) {            // the projection phase's 16 pair slots -> d/dt, d/ds, loss value (slot order)
+            const int q = tq - 128;
+            float pq[16];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) pq[w] = S.part[w * 8 + q];
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) acc += pq[w];
+            S.scal[3 + q] = acc;
         }
         for (int idx = NG - 1 - tq; idx < ns3; idx += NG) {   // taken from the far end of the geometry waves
             int sv = idx / 3, b = idx - sv * 3;
@@ -1078,7 +1082,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             const float sc3 = Pcur[3];
             __builtin_amdgcn_sched_barrier(0);
             const int t8 = pidx < 8 ? pidx : 0;
-            const float p0 = S.part[t8], p1 = S.part[8 + t8], p2 = S.part[16 + t8], p3 = S.part[24 + t8];
+            const float psum = S.scal[3 + (t8 < 5 ? t8 : 0)];
             const float gth_v = S.gth[pk == 1 ? pa : 0];
             const float gy_v = S.gy[mstar * BF_GMM_LD + (pb >= 0 && pb < BF_GMM_LD ? pb : 0)];
             const float g_v = S.g[pidx];
@@ -1086,7 +1090,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             // angle prior sign (loss.py:54-61: body dofs 52, 55, 9, 12)
             const float ang_sg = (pk == 1 && pb >= 0) ? (pb == 52 ? 1.f : ((pb == 55 || pb == 9 || pb == 12) ? -1.f : 0.f)) : 0.f;
             if (pk == 0) {                                           // transl / scale: the geometry waves' shares in wave order
-                const float acc = ((p0 + p1) + p2) + p3;
+                const float acc = psum;
                 grad = acc * (pidx < 3 ? sc3 * cscale : cscale) + (ext ? ext[EXT_T + pidx] + ext[EXT_K + pidx] : 0.f);
                 S.g[pidx] = grad;                                    // (kept for the debug dump)
             }
@@ -1134,7 +1138,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 float *tm = io.terms + (size_t)frame * 4;
                 if (!T.kp_dense) {                                   // (the dense keypoint kernel owns it otherwise)
                     float acc = 0.f;
-                    for (int w = 0; w < 4; ++w) acc += S.part[w * 8 + 4];
+                    acc = S.scal[3 + 4];
                     tm[0] = acc / ndiv_f;
                 }
                 tm[1] = hp.w_pose * S.scal[2];
