@@ -152,10 +152,17 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
 #pragma unroll
     for (int i = 0; i < BF_MESH_TILE; ++i) jx[i] = 0.f;
     const int ne3 = M.n_extra * 3;
+    const bool sparse4 = M.v_nnz == 4;             // four bones per vertex (SMPL): exact, the dropped weights are zeros
+    int zj[4] = {0, 0, 0, 0};
     if (rg == 0 && ok) {
-        const float *w = M.lbs_weights + (size_t)v * nj;
+        if (sparse4) {
 #pragma unroll
-        for (int j = 0; j < BF_MESH_WPF; ++j) if (j < nj) wreg[j] = w[j];
+            for (int q = 0; q < 4; ++q) { zj[q] = M.v_nzj[(size_t)v * 4 + q] * 12; wreg[q] = M.v_nzw[(size_t)v * 4 + q]; }
+        } else {
+            const float *w = M.lbs_weights + (size_t)v * nj;
+#pragma unroll
+            for (int j = 0; j < BF_MESH_WPF; ++j) if (j < nj) wreg[j] = w[j];
+        }
     } else if (rg == 1 && ok) {
         const float *sd = M.shapedirs + (size_t)gcol * nb;
 #pragma unroll
@@ -201,17 +208,25 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
         float r = 0.f;
         if (ok) {
             float t0 = 0.f, t1 = 0.f, t2 = 0.f, tt = 0.f;
+            if (sparse4) {
 #pragma unroll
-            for (int j = 0; j < BF_MESH_WPF; ++j) {
-                if (j < nj) {
-                    const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
-                    t0 += wreg[j] * a.x; t1 += wreg[j] * a.y; t2 += wreg[j] * a.z; tt += wreg[j] * a.w;
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = *(const float4 *)(s_A + zj[q] + k * 4);
+                    t0 += wreg[q] * a.x; t1 += wreg[q] * a.y; t2 += wreg[q] * a.z; tt += wreg[q] * a.w;
                 }
-            }
-            for (int j = BF_MESH_WPF; j < nj; ++j) {
-                float wj = M.lbs_weights[(size_t)v * nj + j];
-                const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
-                t0 += wj * a.x; t1 += wj * a.y; t2 += wj * a.z; tt += wj * a.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < BF_MESH_WPF; ++j) {
+                    if (j < nj) {
+                        const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
+                        t0 += wreg[j] * a.x; t1 += wreg[j] * a.y; t2 += wreg[j] * a.z; tt += wreg[j] * a.w;
+                    }
+                }
+                for (int j = BF_MESH_WPF; j < nj; ++j) {
+                    float wj = M.lbs_weights[(size_t)v * nj + j];
+                    const float4 a = *(const float4 *)(s_A + j * 12 + k * 4);
+                    t0 += wj * a.x; t1 += wj * a.y; t2 += wj * a.z; tt += wj * a.w;
+                }
             }
             r = t0 * s_vp[vl * 3] + t1 * s_vp[vl * 3 + 1] + t2 * s_vp[vl * 3 + 2] + tt;
             size_t o = (size_t)frame * ncols + gcol;
@@ -258,15 +273,22 @@ bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__rest
     const float *vr = vraw + (size_t)frame * nv * 3;
     const float t0 = st.t[0], t1 = st.t[1], t2 = st.t[2], sc = st.sc[0] * st.sc[1];
     const int ne3 = ne * 3, nt8 = M.n_tiles;
-    for (int base = 0; base < ne3 * 8; base += 256) {
-        int idx = base + tid, o = idx >> 3, sl = idx & 7;
+    // extra-regressor joints: sum the mesh kernel's per-tile partials; 32 lanes per output, each lane's loads issued
+    // together (a serial loop over the tiles costs one memory latency per tile), fixed xor tree
+    for (int base = 0; base < ne3 * 32; base += 256) {
+        const int idx = base + tid, o = idx >> 5, sl = idx & 31;
         float acc = 0.f;
         if (o < ne3) {
-            int per = (nt8 + 7) / 8, a = sl * per, b = min(nt8, a + per);
-            const float *p = xpart + ((size_t)frame * nt8 + a) * ne3 + o;
-            for (int t = a; t < b; ++t, p += ne3) acc += *p;
+            const float *p = xpart + (size_t)frame * nt8 * ne3 + o;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int t = sl + 32 * q; v[q] = t < nt8 ? p[(size_t)t * ne3] : 0.f; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+            for (int t = sl + 256; t < nt8; t += 32) acc += p[(size_t)t * ne3];
         }
-        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
+        acc += __shfl_xor(acc, 16);
         if (o < ne3 && sl == 0) s_extra[o] = acc;
     }
     if (tid == 0 && M.n_lmk_dyn > 0) {
@@ -310,16 +332,8 @@ bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__rest
 }
 
 
-// Batched pose blend on the matrix cores: OFF[f][col] = sum_p feat[f][p] * posedirs[p][col] for a whole batch of
-// frames at once, i.e. the GEMM [F x P] . [P x 3NV] that the reference evaluates frame by frame as
-// `torch.matmul(pose_feature, posedirs)` (smplx lbs).  fp32-input MFMA
-// (v_mfma_f32_32x32x2_f32: exact fp32 fma chain in k order), so parity is unchanged.
-//   workgroup = 4 waves = 128 columns; wave = one 32-column strip x ALL frames (FT tiles of 32 frames, 16
-//   accumulator VGPRs each), so every posedirs element is read from HBM exactly once per launch and reused
-//   FT*32 times from registers; the pose features of the batch are staged through LDS in 16-deep k chunks
-//   (row stride 17 floats: conflict-free for the A-fragment pattern lane -> (frame, k)).
-// A fragment: lane l holds A[i = l & 31][k = l >> 5]; B fragment: lane l holds B[k = l >> 5][j = l & 31];
-// accumulator: column = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+// MFMA fragments (v_mfma_f32_32x32x2_f32): A: lane l holds A[i = l & 31][k = l >> 5]; B: lane l holds
+// B[k = l >> 5][j = l & 31]; accumulator: column = l & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // A operand of the pose-blend GEMM: featT[p][f] = pose feature p of frame f, frame-minor so that the GEMM's lanes read
