@@ -48,7 +48,9 @@ def parse():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--views", type=int, default=48)
     ap.add_argument("--dense", action="store_true", help="full mesh every iteration (reference-literal schedule)")
-    ap.add_argument("--no-graph", action="store_true", help="issue every HIP command from the host instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay one hipGraph per step instead of issuing the step's four kernels from the host")
+    ap.add_argument("--no-graph", action="store_true", help="(default since the step is four kernels and nothing else; kept for old command lines)")
+    ap.add_argument("--events", action="store_true", help="keep the HIP event records inside the timed steps (4 per step, ~13 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (dense schedule, batched shards)")
     ap.add_argument("--cpu-frames", type=int, default=3)
@@ -141,7 +143,9 @@ def main():
     F = a.frames_per_gpu
     frames = list(range(rank * F, rank * F + F))          # distinct frames on every rank
     batch, _ = build_batch(dev, model, frames, a.views)
-    flags = _lib.FIT_FETCH | (_lib.FIT_DENSE if a.dense else 0) | (0 if a.no_graph else _lib.FIT_GRAPH)
+    a.no_graph = not a.graph
+    a.no_events = not a.events and a.no_graph and not a.dense
+    flags = _lib.FIT_FETCH | (_lib.FIT_DENSE if a.dense else 0) | (0 if a.no_graph else _lib.FIT_GRAPH) | (_lib.FIT_NOTIME if a.no_events else 0)
 
     barrier = (lambda: None)
     after = None
@@ -190,10 +194,10 @@ def main():
 
     total_frames = world * F * a.steps
     value = total_frames / wall
-    if not a.no_graph and not a.dense:
-        # inside a hipGraph the kernels cannot be bracketed by events: per-kernel device times come from the same
-        # steps issued command by command right after the timed region
-        _, ev = timed_leg(batch, max(10, a.steps // 4), 2, a.iters, flags & ~_lib.FIT_GRAPH)
+    if (not a.no_graph or a.no_events) and not a.dense:
+        # inside a hipGraph (or with the event records switched off) the kernels are not bracketed by events: per-kernel
+        # device times come from the same steps issued command by command, with events, right after the timed region
+        _, ev = timed_leg(batch, max(10, a.steps // 4), 2, a.iters, flags & ~(_lib.FIT_GRAPH | _lib.FIT_NOTIME))
     fit_ms = ev["fit_ms"] / max(ev["calls"], 1)
     mesh_ms = ev["mesh_ms"] / max(ev["calls"], 1)
     traffic = pmc_traffic()
@@ -208,7 +212,8 @@ def main():
                                 + (" = BASELINE config 4 shard" if F == 32 else "")),
                    "frames_per_gpu": F, "views": a.views, "iters": a.iters,
                    "schedule": "dense (full mesh every iteration)" if a.dense else "sparse (gradient-carrying vertices only) + one final full mesh",
-                   "submission": "host-issued commands" if (a.no_graph or a.dense) else "one hipGraph launch per step",
+                   "submission": ("host-issued: 4 kernels per step (fit, mesh, joints, publish)" + (", no event records in the timed steps" if a.no_events else ""))
+                                 if (a.no_graph or a.dense) else "one hipGraph launch per step",
                    "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of parameters per step" if world > 1 else "1 GPU"},
         "roofline": {
             "bound": "hbm", "kernel": "bf_fit_kernel" if not a.dense else "bf_fit_kernel+bf_mesh_kernel (per iteration)",
@@ -244,8 +249,9 @@ def main():
                 continue
             bb, _ = build_batch(dev, model, list(range(fb)), a.views)
             n = 10
-            w, e = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH)
-            wg, _ = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_GRAPH)
+            _, e = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH)                                  # (with events: device times)
+            w, _ = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_RESET | _lib.FIT_NOTIME)
+            wg, _ = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_GRAPH)        # (pipelined fetch from 8 frames on)
             w = min(w, wg)
             extra[f"batch_{fb}_frames"] = {"value": fb * n / w, "unit": "frames/s", "ms_per_step": w / n * 1e3,
                                            "device_fit_ms": e["fit_ms"] / e["calls"], "device_mesh_ms": e["mesh_ms"] / e["calls"]}

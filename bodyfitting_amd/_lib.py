@@ -42,7 +42,7 @@ class Hyper(C.Structure):
         "imsize", "lr", "lr_transl_scale", "adam_beta1", "adam_beta2", "adam_eps", "lr_displacement")]
 
 
-FIT_DEFAULT, FIT_DENSE, FIT_NO_VERTICES, FIT_FETCH, FIT_RESET, FIT_GRAPH = 0, 1, 2, 4, 8, 16
+FIT_DEFAULT, FIT_DENSE, FIT_NO_VERTICES, FIT_FETCH, FIT_RESET, FIT_GRAPH, FIT_NOTIME = 0, 1, 2, 4, 8, 16, 32
 
 # every entry point include/bodyfit.h declares: name -> (restype, argtypes)
 _FP = C.POINTER(C.c_float)

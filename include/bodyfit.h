@@ -108,6 +108,8 @@ typedef struct bf_hyper {
 #define BF_FIT_GRAPH       16u   /* with BF_FIT_RESET on the keypoint-only path: capture the call's whole command sequence
                                     into a hipGraph once and replay it - one host command per fit (per-kernel device times are
                                     then not split: bf_batch_last_timing charges everything to ms[0]) */
+#define BF_FIT_NOTIME      32u   /* do not bracket the parts of this call with HIP events (bf_batch_last_timing / timing_sum skip it):
+                                     four event records per call are a measurable share of a 0.65 ms step */
 #define BF_FIT_FETCH        4u   /* queue the device->host copies of the result into the batch's pinned
                                     staging buffers behind the kernels (bf_batch_get_result then only
                                     waits for them) */
