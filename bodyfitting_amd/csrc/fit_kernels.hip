@@ -47,7 +47,7 @@ namespace {
 struct FitSmem {
     float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
-    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *rel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp, *stamp;
+    float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *rel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp, *stamp, *sel_pd2;
     int *nzj, *thk, *tho, *par, *pk, *pa_, *pb_;
     float *am, *av;
 };
@@ -81,6 +81,8 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.nzw = take(ns * BF_SEL_NNZ);  s.nzj = (int *)take(ns * BF_SEL_NNZ);
     s.kp = take(BF_VSUB * BF_KP_ROUNDS * 16 * 8);      // 8-float keypoint record per (view, loss-joint pair), zero padded
     s.stamp = take(64);
+    s.sel_pd2 = take(npf * (ns * 3 + 1));     // sel_pd again with row stride 3 ns + 1: 2-way instead of 3-way bank conflicts for
+                                              // the merged pose blend's (slice, output) lane pattern
     s.theta = take(nj * 3);  s.pmean = take(nj * 3);  s.hcomp = take(2 * 6 * 45);
     s.thk = (int *)take(nj); s.tho = (int *)take(nj); s.par = (int *)take(nj);
     s.pk = (int *)take(np); s.pa_ = (int *)take(np); s.pb_ = (int *)take(np); s.am = take(np); s.av = take(np);
@@ -230,6 +232,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     }
     copy_f(S.sel_vt, T.sel_vt, ns3, tid, nt);
     copy_f(S.sel_pd, T.sel_pd, npf * ns3, tid, nt);
+    for (int i = tid; i < npf * (ns3 + 1); i += nt) { const int p = i / (ns3 + 1), o = i - p * (ns3 + 1); S.sel_pd2[i] = o < ns3 ? T.sel_pd[p * ns3 + o] : 0.f; }
     copy_f(S.sel_w, T.sel_w, ns * nj, tid, nt);
     for (int i = tid; i < ns * BF_SEL_NNZ; i += nt) { S.nzw[i] = T.sel_nzw[i]; S.nzj[i] = T.sel_nzj[i]; }
     const int sel_nnz = T.sel_nnz;
@@ -461,6 +464,74 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
         }
     };
+    // Merged pose blend + skinning of the selector vertices on the four geometry waves, three vertices per wave:
+    // lane = (output ol = lane / 7 of the wave's nine coordinates, row slice sl = lane % 7 of 30 rows).  The slice
+    // partials cross lanes through a wave-private LDS strip (write, wave fence, 7 reads in slot order), so the finished
+    // pose-blended coordinates are in the wave that skins them: no barrier between the two steps.  Lanes 0..35 then own
+    // T[k][b] of T_s = sum_j w_sj A_j for the wave's three vertices (the <= 4 non-zero weights only; quad = one row k).
+    const bool merge_bc = NS > 0 && NS <= 12 && NJ > 0 && sel_nnz > 0 && sel_nnz <= 4;
+    const int bl_ol = lane / 7, bl_sl = lane - bl_ol * 7;            // (63 = 9 x 7: lane 63 idles)
+    auto blend_and_skin = [&]() {
+        constexpr int NPF = NJ > 0 ? 9 * (NJ - 1) : 8, RS = (NPF + 6) / 7, RB = (RS + 1) / 2, NZ = 4;
+        const int lq = bf_launder(lane);
+        const int ol = min(bl_ol, 8), sl = bl_sl;
+        const int sv = wave * 3 + ol / 3, c = ol - (ol / 3) * 3;
+        const bool on = bl_ol < 9 && sv < ns;
+        const int o = (on ? sv : 0) * 3 + c;
+        const int p0 = sl * RS;
+        // skinning role: lane = (vertex vloc, row k, column b)
+        const int vloc = lq / 12, e12 = lq - vloc * 12, k = e12 >> 2, b = e12 & 3;
+        const int sv2 = wave * 3 + vloc;
+        const bool trl = lq < 36 && sv2 < ns;
+        const int sv2c = trl ? sv2 : 0;
+        float wq[NZ], aq[NZ];
+        int jq[NZ];
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) { wq[q] = S.nzw[sv2c * BF_SEL_NNZ + q]; jq[q] = S.nzj[sv2c * BF_SEL_NNZ + q]; }
+        const float vs0 = S.vs[sv2c * 3 + (b < 3 ? b : 0)];
+        const float *A = b < 3 ? S.G + k * 4 + b : S.At + k;
+        const int stride = b < 3 ? 12 : 3;
+        float acc = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float f[RB], w[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int p = min(p0 + h * RB + i, NPF - 1);
+                f[i] = S.feat[p];
+                w[i] = S.sel_pd2[p * (ns3 + 1) + o];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (h == 0) {
+#pragma unroll
+                for (int q = 0; q < NZ; ++q) aq[q] = A[jq[q] * stride];
+            }
+#pragma unroll
+            for (int i = 0; i < RB; ++i) acc += (h * RB + i < RS && p0 + h * RB + i < NPF ? f[i] : 0.f) * w[i];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float *strip = S.vpp + wave * 64;              // this wave's 63 partials
+        strip[lq] = on ? acc : 0.f;
+        BF_WAVE_FENCE();
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) t += wq[q] * aq[q];
+        // pose-blended coordinate b of the lane's vertex: the seven slice partials in slot order
+        const float *pp = strip + (vloc * 3 + (b < 3 ? b : 0)) * 7;
+        float pr[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pr[i] = pp[i];
+        float vpb = vs0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) vpb += pr[i];
+        if (trl && b < 3) {
+            S.TR[sv2c * 9 + k * 3 + b] = t;
+            if (k == 0) S.vp[sv2c * 3 + b] = vpb;
+        }
+        float contrib = trl ? (b < 3 ? t * vpb : t) : 0.f;
+        contrib = quad_sum(contrib);
+        if (trl && b == 0) S.vsel[sv2c * 3 + k] = contrib;
+    };
     typedef float v2f __attribute__((ext_vector_type(2)));
     auto project = [&](bool want_loss) {
         BF_MARK(45, 0, bf_it, bf_t0);
@@ -570,10 +641,16 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             BF_GMM_CHUNK(0)
             BF_GMM_CHUNK(1)
             BF_SYNC();                 // A
-            pose_blend(std::integral_constant<int, 2>());
-            BF_SYNC();                 // B
-            BF_GMM_CHUNK(2)
-            BF_GMM_CHUNK(3)
+            if (merge_bc) {
+                // (the geometry waves do the merged pose blend + skinning alone)
+                BF_GMM_CHUNK(2)
+                BF_GMM_CHUNK(3)
+            } else {
+                pose_blend(std::integral_constant<int, 2>());
+                BF_SYNC();             // B
+                BF_GMM_CHUNK(2)
+                BF_GMM_CHUNK(3)
+            }
             BF_SYNC();                 // C
             BF_SYNC();                 // D (+E): projection, view reduction and routing: VALU-bound on the geometry waves, no GMM here
             BF_GMM_CHUNK(4)
@@ -644,6 +721,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         if (wave < 3) {
             float Ri[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rc[3], rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
             float4 row = {0.f, 0.f, 0.f, 0.f};
+            float jj0 = 0.f, jj1 = 0.f, jj2 = 0.f;
             if (cw_on) {
                 float th0 = w_pm0, th1 = w_pm1, th2 = w_pm2;
                 if (w_kind == 0) { th0 += Pcur[w_off]; th1 += Pcur[w_off + 1]; th2 += Pcur[w_off + 2]; }
@@ -651,6 +729,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 // rel_j = J_j - J_parent (rel_0 = J_0) was formed from the betas by wave 3 at the end of the previous
                 // iteration (or in the prologue); read it before the Rodrigues arithmetic so the latency hides under it
                 const float a0 = S.rel[wj * 3], a1 = S.rel[wj * 3 + 1], a2 = S.rel[wj * 3 + 2];
+                jj0 = S.J[wj * 3]; jj1 = S.J[wj * 3 + 1]; jj2 = S.J[wj * 3 + 2];
                 __builtin_amdgcn_sched_barrier(0);
                 rodrigues_fwd(th0, th1, th2, Ri, rc);
                 if (wave == 2) { S.theta[wj * 3] = th0; S.theta[wj * 3 + 1] = th1; S.theta[wj * 3 + 2] = th2; }
@@ -715,19 +794,22 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 row.x = mine ? nx : row.x; row.y = mine ? ny : row.y; row.z = mine ? nz : row.z; row.w = mine ? nw : row.w;
             }
             if (cw_on && wj > 0) *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
+            // A_j translation row: Gt_j - GR_j J_j (J of this pass was formed with the betas, in the Adam phase)
+            if (cw_on) S.At[wj * 3 + wave] = row.w - (row.x * jj0 + row.y * jj1 + row.z * jj2);
             BF_MARK(41, 0, it, t_iter);
         }
         BF_SYNC();
 
+        if (merge_bc) {
+            // ================= phase B (+C): pose blend and skinning of the selector vertices in one phase
+            blend_and_skin();
+        } else {
         {
         // ================= phase B: pose blend of the selector vertices, partial sums over row slices
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
         pose_blend(std::integral_constant<int, 1>());
-        if (c_on)                                   // A_j translation: Gt_j - GR_j J_j
-            S.At[tq] = GT_(ci, cr) - (GR_(ci, cr, 0) * S.J[ci * 3] + GR_(ci, cr, 1) * S.J[ci * 3 + 1] + GR_(ci, cr, 2) * S.J[ci * 3 + 2]);
         }
-        BF_SYNC();
-
+                BF_SYNC();
         {
         // ================= phase C: finish the pose blend; skin the selector vertices.  Lane b of a quad owns
         // column b of row k of T_s = sum_j w_sj A_j
@@ -784,6 +866,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (ok && b == 0) S.vsel[o] = contrib;
         }
         }
+                }
         BF_SYNC();
 
         // ================= phase D: similarity, multi-view projection, GMoF and its gradient
