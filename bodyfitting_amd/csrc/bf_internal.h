@@ -128,6 +128,8 @@ struct ScanDev {
     const int *faces;         // [nf][3]
     const int *cell_start;    // [nx*ny*nz + 1], cell = (x*ny + y)*nz + z
     const int *cell_tris;     // triangles per cell, ascending face id
+    const float4 *cell_pack;  // per cell-list entry: the triangle's corners and id, 3 x float4 = (p0.xyz p1.x)(p1.yz p2.xy)(p2.z id 0 0):
+                              // one contiguous 48-byte record instead of the list -> faces -> vertices pointer chase
 };
 
 // Silhouette-loss inputs of one batch (device pointers).

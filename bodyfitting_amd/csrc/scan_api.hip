@@ -86,9 +86,17 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
         fn[f * 3 + 1] = (float)(u[2] * w[0] - u[0] * w[2]);
         fn[f * 3 + 2] = (float)(u[0] * w[1] - u[1] * w[0]);
     }
+    std::vector<float> pack((size_t)tris.size() * 12, 0.f);
+    for (size_t i = 0; i < tris.size(); ++i) {
+        const int t = tris[i];
+        float *r = pack.data() + i * 12;
+        for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) r[c * 3 + k] = verts[(size_t)faces[t * 3 + c] * 3 + k];
+        std::memcpy(r + 9, &t, sizeof(int));
+    }
+    if (pack.empty()) pack.assign(12, 0.f);
     auto *s = new bf_scan();
     s->device = device; s->nv = n_verts; s->nf = n_faces;
-    bool ok = s->verts.upload(std::vector<float>(verts, verts + (size_t)n_verts * 3)) == hipSuccess &&
+    bool ok = s->cell_pack.upload(pack) == hipSuccess && s->verts.upload(std::vector<float>(verts, verts + (size_t)n_verts * 3)) == hipSuccess &&
               s->faces.upload(std::vector<int>(faces, faces + (size_t)n_faces * 3)) == hipSuccess &&
               s->cell_start.upload(start) == hipSuccess && s->cell_tris.upload(tris) == hipSuccess &&
               s->face_norms.upload(fn) == hipSuccess;
@@ -97,6 +105,7 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
     d.nv = n_verts; d.nf = n_faces; d.nx = num[0]; d.ny = num[1]; d.nz = num[2];
     d.ox = org[0]; d.oy = org[1]; d.oz = org[2]; d.step = step; d.height = ext[1];
     d.verts = s->verts.p; d.faces = s->faces.p; d.cell_start = s->cell_start.p; d.cell_tris = s->cell_tris.p;
+    d.cell_pack = (const float4 *)s->cell_pack.p;
     *out = s;
     return BF_OK;
 }
@@ -121,7 +130,7 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
     HIP_TRY(d_p.upload(std::vector<float>(points, points + (size_t)n * 3)));
     HIP_TRY(d_c.alloc((size_t)n * 3)); HIP_TRY(d_b.alloc((size_t)n * 3)); HIP_TRY(d_f.alloc(n));
     HIP_TRY(d_s.upload(std::vector<ScanDev>(1, s->dev)));
-    hipLaunchKernelGGL(bf_nearest_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, 0, (const ScanDev *)d_s.p, (const float *)d_p.p, n,
+    hipLaunchKernelGGL(bf_nearest_kernel, dim3((n * 8 + 255) / 256, 1), dim3(256), 0, 0, (const ScanDev *)d_s.p, (const float *)d_p.p, n,
                        d_f.p, d_c.p, d_b.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
@@ -235,8 +244,8 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     if (kp) { rc = launch_kp(b, h); if (rc) return rc; }
     if (masks) { rc = launch_mask_kernels(b, mask_weight); if (rc) return rc; }
     if (scans) {
-        hipLaunchKernelGGL(bf_nearest_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
-                           (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr);
+        hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv * 8 + 255) / 256, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
+                           (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr);   // (8 lanes per query)
         hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, b->pc_partial.p);
         hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
@@ -434,7 +443,7 @@ int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
                            (const float *)b->disp_base.p, (const float *)b->disp.p, b->disp_fn.p);
         hipLaunchKernelGGL(bf_disp_vertex_kernel, gv, dim3(256), 0, b->stream, (const int *)m->adj_start.p, (const int *)m->adj.p, nf, nv,
                            (const float *)b->disp_base.p, (const float *)b->disp.p, (const float *)b->disp_fn.p, b->disp_P.p, b->disp_vn.p);
-        hipLaunchKernelGGL(bf_nearest_kernel, gv, dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p, (const float *)b->disp_P.p, nv,
+        hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv * 8 + 255) / 256, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p, (const float *)b->disp_P.p, nv,
                            b->cface.p, b->cpts.p, (float *)nullptr);
         hipLaunchKernelGGL(bf_pc_partial_kernel, gv, dim3(256), 0, b->stream, (const float *)b->disp_P.p, (const float *)b->cpts.p, nv,
                            b->pc_partial.p);

@@ -72,18 +72,24 @@ __device__ inline float blk_wave_sum(float v) {
 
 }  // namespace
 
-// grid (ceil(n/256), F).  points[F][n][3] -> face[F][n], pts[F][n][3], bary[F][n][3] (bary may be null)
+// grid (ceil(8 n / 256), F).  points[F][n][3] -> face[F][n], pts[F][n][3], bary[F][n][3] (bary may be null).
+// EIGHT lanes per query: they walk the same cells of the expanding L-infinity shells and split every cell's triangle
+// list (entry i goes to lane i % 8; one 48-byte packed record per entry, so the eight lanes of a query read 384
+// contiguous bytes); after each shell the eight partial results are merged with the lexicographic (distance, face id)
+// minimum, which is what the reference's "first strictly closer triangle in face order" amounts to, so the result does
+// not depend on how the work was split.  The box lower bound prunes with the lane's own best so far (a weaker bound than
+// the query's, never a wrong one); the reference's stop test `best < (L step)^2` uses the merged value.
 extern "C" __global__ void __launch_bounds__(256)
 bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                   int *__restrict__ face, float *__restrict__ pts, float *__restrict__ bary) {
-    const int id = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    if (id >= n) return;
+    const int gid = blockIdx.x * 256 + threadIdx.x, id = gid >> 3, sub = gid & 7, f = blockIdx.y;
+    const bool live = id < n;
     const ScanDev S = scans[f];
-    const float *q = points + ((size_t)f * n + id) * 3;
+    const float *q = points + ((size_t)f * n + (live ? id : 0)) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     int cx = (int)floorf((qx - S.ox) / S.step), cy = (int)floorf((qy - S.oy) / S.step), cz = (int)floorf((qz - S.oz) / S.step);
     cx = min(max(cx, 0), S.nx - 1); cy = min(max(cy, 0), S.ny - 1); cz = min(max(cz, 0), S.nz - 1);
-    int maxL = max(max(max(cx, S.nx - 1 - cx), max(cy, S.ny - 1 - cy)), max(cz, S.nz - 1 - cz));
+    const int maxL = live ? max(max(max(cx, S.nx - 1 - cx), max(cy, S.ny - 1 - cy)), max(cz, S.nz - 1 - cz)) : -1;
     float best = -1.f, bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
     int bface = -1;
     for (int L = 0; L <= maxL; ++L) {
@@ -103,16 +109,12 @@ bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ p
                     lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); d2 += e * e;
                     lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); d2 += e * e;
                     if (best >= 0.f && best < d2) continue;
-                    int cell = (x * S.ny + y) * S.nz + z;
-                    for (int i = S.cell_start[cell]; i < S.cell_start[cell + 1]; ++i) {
-                        int t = S.cell_tris[i];
-                        const int *tv = S.faces + (size_t)t * 3;
-                        float p[9];
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const float *v = S.verts + (size_t)tv[c] * 3;
-                            p[c * 3] = v[0] - qx; p[c * 3 + 1] = v[1] - qy; p[c * 3 + 2] = v[2] - qz;
-                        }
+                    const int cell = (x * S.ny + y) * S.nz + z;
+                    const int i1 = S.cell_start[cell + 1];
+                    for (int i = S.cell_start[cell] + sub; i < i1; i += 8) {
+                        const float4 r0 = S.cell_pack[(size_t)i * 3], r1 = S.cell_pack[(size_t)i * 3 + 1], r2 = S.cell_pack[(size_t)i * 3 + 2];
+                        const int t = __float_as_int(r2.y);
+                        float p[9] = {r0.x - qx, r0.y - qy, r0.z - qz, r0.w - qx, r1.x - qy, r1.y - qz, r1.z - qx, r1.w - qy, r2.x - qz};
                         float co[3];
                         float dist = closest_rule(p, p + 3, p + 6, co);
                         if (best < 0.f || dist < best || (dist == best && t < bface)) {
@@ -122,8 +124,17 @@ bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ p
                 }
             }
         }
+        // merge the eight lanes of the query: lexicographic minimum of (distance, face id); "none yet" loses
+#pragma unroll
+        for (int m = 1; m < 8; m <<= 1) {
+            const float ob = __shfl_xor(best, m), o0 = __shfl_xor(bc0, m), o1 = __shfl_xor(bc1, m), o2 = __shfl_xor(bc2, m);
+            const int of = __shfl_xor(bface, m);
+            const bool take = of >= 0 && (bface < 0 || ob < best || (ob == best && of < bface));
+            if (take) { best = ob; bface = of; bc0 = o0; bc1 = o1; bc2 = o2; }
+        }
         if (best >= 0.f && best < (float)L * (float)L * S.step * S.step) break;     // mesh_grid_kernel.cu:349
     }
+    if (!live || sub != 0) return;
     const size_t o = (size_t)f * n + id;
     face[o] = bface;
     float r0 = qx, r1 = qy, r2 = qz;

@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Timings of the dense-loss paths on one GPU (not part of the bench.py contract): BASELINE config 3
+(SMPL-X, 48 views, keypoint + silhouette loss, 200 iterations) and a config-5-shaped shard (frames with a scan:
+closest-point loss for 300 iterations, then the SMPL+D stage).  Synthetic data (bodyfitting_amd/synthetic.py),
+one JSON object per line.   usage: python tools/bench_configs.py [--cfg3] [--cfg5] [--frames N] [--reps R]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+from bodyfitting_amd import native as N, synthetic as S   # noqa: E402
+from bodyfitting_amd.contours import extract_contours      # noqa: E402
+
+
+def timed(fn, reps):
+    fn()                                   # warm (allocations, first-use tables)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def cfg3(reps, n_views=48, iters=200, mask_views=8):
+    model, gmm = S.make_model("smplx", seed=0), S.make_gmm(seed=0)
+    dev = N.DeviceModel(model, gmm, device=0)
+    mask_frames = list(range(0, n_views, max(1, n_views // mask_views)))[:mask_views]
+    prob = S.make_problem_smplx(model, frame=0, n_views=n_views, mask_frames=mask_frames)
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
+    b = N.FrameBatch(dev, 1, n_views)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+    masks = np.array(prob["masks"])
+    b.set_masks(masks[None], mask_frames, [extract_contours(masks > 128)])
+
+    def run():
+        b.reset(); b.fit(iters); b.sync()
+    dt = timed(run, reps)
+    out = {"config": "cfg3: 1 frame x %d views, SMPL-X (10475 v, 55 joints, 135 loss joints), keypoint + silhouette loss "
+                     "(%d mask views), %d iterations" % (n_views, len(mask_frames), iters),
+           "frames_per_s": 1.0 / dt, "ms_per_fit": dt * 1e3, "ms_per_iteration": dt * 1e3 / iters}
+    b.close(); dev.close()
+    return out
+
+
+def cfg5(reps, frames=8, n_views=8, iters=300, disp_iters=100):
+    model, gmm = S.make_model("smpl", seed=0), S.make_gmm(seed=0)
+    dev = N.DeviceModel(model, gmm, device=0)
+    items = [S.make_scan_problem(model, frame=f, n_views=n_views) for f in range(frames)]
+    scans = [N.Scan(sv, sf) for _, sv, sf in items]
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([p for p, _, _ in items])
+    b = N.FrameBatch(dev, frames, n_views)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose); b.set_scans(scans)
+
+    def run_fit():
+        b.reset(); b.fit(iters); b.sync()
+    dt = timed(run_fit, reps)
+
+    def run_disp():
+        b.fit_displacement(disp_iters); b.sync()
+    dd = timed(run_disp, reps)
+    out = {"config": "cfg5-shaped shard: %d frames x %d views, SMPL (6890 v) with a 6890-vertex scan each, closest-point loss, "
+                     "%d iterations, then %d SMPL+D iterations" % (frames, n_views, iters, disp_iters),
+           "frames_per_s_fit": frames / dt, "ms_per_fit": dt * 1e3, "ms_per_iteration": dt * 1e3 / iters,
+           "ms_per_displacement_iteration": dd * 1e3 / disp_iters}
+    b.close()
+    for s in scans:
+        s.close()
+    dev.close()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cfg3", action="store_true"); ap.add_argument("--cfg5", action="store_true")
+    ap.add_argument("--frames", type=int, default=8); ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    if not (a.cfg3 or a.cfg5):
+        a.cfg3 = a.cfg5 = True
+    if a.cfg3:
+        print(json.dumps(cfg3(a.reps)), flush=True)
+    if a.cfg5:
+        print(json.dumps(cfg5(a.reps, frames=a.frames)), flush=True)
