@@ -118,7 +118,7 @@ struct bf_batch {
     MaskIO mask{};
     DevBuf<int> mk_view, mk_cstart, mk_ccount, mk_choice;
     DevBuf<unsigned char> mk_masks;
-    DevBuf<float> mk_cxy, mk_uvi, mk_duvb, mk_cgrad, mk_part, mk_loss;
+    DevBuf<float> mk_cxy, mk_uvi, mk_duvb, mk_cgrad, mk_part, mk_loss, mk_gpart;
     // SMPL+D stage (smplify.py:228-247)
     DevBuf<float> disp, disp_m, disp_v, disp_base, disp_P, disp_fn, disp_vn, disp_dv, disp_dPf;
     DevBuf<const float *> scan_fn;

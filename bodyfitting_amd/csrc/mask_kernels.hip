@@ -10,9 +10,9 @@
 //   bf_mask_project_kernel   thread = sampled vertex x view: uv, inside flag, binary term + d/duv
 //   bf_mask_contour_kernel   thread = contour point: exact nearest inside vertex (first minimum, like
 //                            torch.min), its weight, the unit direction
-//   bf_mask_gather_kernel    thread = sampled vertex: gathers the contour points that chose it IN CONTOUR
-//                            ORDER (deterministic; no atomics), maps d/duv back through the projection and
-//                            writes dL/dvertex
+//   bf_mask_gather_kernel    thread = (sampled vertex, view): gathers the contour points that chose it IN CONTOUR
+//                            ORDER (deterministic; no atomics), maps d/duv back through the projection
+//   bf_mask_gsum_kernel      adds the views in view order into dL/dvertex
 // Distances are exact (a - b)^2 sums; torch.cdist switches to the |a|^2+|b|^2-2ab form for these sizes,
 // which is noisier (about 1e-2 px at 512 px) - see DESIGN.md.
 #include "bf_internal.h"
@@ -66,14 +66,15 @@ bf_mask_project_kernel(MaskIO K, const float *__restrict__ vout, const float *__
         loss_part[((size_t)f * K.n_masks + m) * K.part_stride + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-// grid (ceil(Cmax/256), M, F).  For contour point c: choice[F][M][Cmax] = sampled vertex (or -1),
-// cgrad[F][M][Cmax][2] = weight * coeff * (uv - c) / |uv - c|
+// grid (ceil(4 Cmax/256), M, F).  For contour point c: choice[F][M][Cmax] = sampled vertex (or -1),
+// cgrad[F][M][Cmax][2] = weight * coeff * (uv - c) / |uv - c|.  FOUR lanes per contour point, each scanning every fourth
+// sampled vertex; the quad is merged with the lexicographic (distance, index) minimum = torch.min's first minimum.
 extern "C" __global__ void __launch_bounds__(256)
 bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict__ choice, float *__restrict__ cgrad,
                        float *__restrict__ loss_part) {
     __shared__ float4 tile[256];
     __shared__ float sred[4];
-    const int c = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y, f = blockIdx.z;
+    const int gid = blockIdx.x * 256 + threadIdx.x, c = gid >> 2, sub = gid & 3, m = blockIdx.y, f = blockIdx.z;
     const int vm = f * K.n_masks + m;
     const int cnt = K.contour_count[vm];
     const float *cp = K.contour_xy + ((size_t)K.contour_start[vm] + (c < cnt ? c : 0)) * 2;
@@ -86,15 +87,21 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
         tile[threadIdx.x] = s < K.ns ? rec[s] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         int lim = min(256, K.ns - base);
-        for (int i = 0; i < lim; ++i) {
+        for (int i = sub; i < lim; i += 4) {
             float4 r = tile[i];
             float dx = r.x - cx, dy = r.y - cy, d2 = dx * dx + dy * dy;
-            if (r.z > 0.5f && d2 < best) { best = d2; bidx = base + i; bu = r.x; bv = r.y; }    // first minimum wins
+            if (r.z > 0.5f && d2 < best) { best = d2; bidx = base + i; bu = r.x; bv = r.y; }    // first minimum of this lane's subset
         }
         __syncthreads();
     }
+#pragma unroll
+    for (int x = 1; x < 4; x <<= 1) {
+        const float ob = __shfl_xor(best, x), ou = __shfl_xor(bu, x), ov = __shfl_xor(bv, x);
+        const int oi = __shfl_xor(bidx, x);
+        if (oi >= 0 && (bidx < 0 || ob < best || (ob == best && oi < bidx))) { best = ob; bidx = oi; bu = ou; bv = ov; }
+    }
     float lval = 0.f;
-    if (c < cnt) {
+    if (c < cnt && sub == 0) {
         const size_t o = (size_t)vm * K.cmax + c;
         float gx = 0.f, gy = 0.f;
         if (bidx >= 0) {
@@ -115,42 +122,51 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
     if (threadIdx.x == 0) loss_part[(size_t)vm * K.part_stride + K.proj_blocks + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-// grid (ceil(Ns/256), F).  dvout[f][4 s] (+)= dL/dvertex over all mask views; other vertices untouched
+// grid (ceil(Ns/256), M, F).  gpart[f][m][s][3] = dL/dvertex 4 s from mask view m (one workgroup per view and vertex
+// block: the views run in parallel; bf_mask_gsum_kernel adds them in view order)
 extern "C" __global__ void __launch_bounds__(256)
 bf_mask_gather_kernel(MaskIO K, const float *__restrict__ proj_all, const float *__restrict__ uvi, const float *__restrict__ duvb,
-                      const int *__restrict__ choice, const float *__restrict__ cgrad, float *__restrict__ dvout) {
+                      const int *__restrict__ choice, const float *__restrict__ cgrad, float *__restrict__ gpart) {
     __shared__ int s_choice[256];
     __shared__ float2 s_grad[256];
-    const int s = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    for (int m = 0; m < K.n_masks; ++m) {
-        const int vm = f * K.n_masks + m;
-        const int cnt = K.contour_count[vm];
-        float du = 0.f, dv = 0.f;
-        if (s < K.ns) { du = duvb[((size_t)vm * K.ns + s) * 2]; dv = duvb[((size_t)vm * K.ns + s) * 2 + 1]; }
-        for (int base = 0; base < cnt; base += 256) {
-            int c = base + threadIdx.x;
-            s_choice[threadIdx.x] = c < cnt ? choice[(size_t)vm * K.cmax + c] : -1;
-            s_grad[threadIdx.x] = c < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + c] : make_float2(0.f, 0.f);
-            __syncthreads();
-            int lim = min(256, cnt - base);
-            for (int i = 0; i < lim; ++i)
-                if (s_choice[i] == s) { du += s_grad[i].x; dv += s_grad[i].y; }
-            __syncthreads();
-        }
-        if (s < K.ns) {
-            float4 r = ((const float4 *)uvi)[(size_t)vm * K.ns + s];
-            const float *P = proj_all + ((size_t)f * K.n_views + K.view_index[m]) * 12;
-            float q0 = du * r.w, q1 = dv * r.w, q2 = -(du * r.x + dv * r.y) * r.w;
-            g0 += P[0] * q0 + P[4] * q1 + P[8] * q2;
-            g1 += P[1] * q0 + P[5] * q1 + P[9] * q2;
-            g2 += P[2] * q0 + P[6] * q1 + P[10] * q2;
-        }
+    const int s = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y, f = blockIdx.z;
+    const int vm = f * K.n_masks + m;
+    const int cnt = K.contour_count[vm];
+    float du = 0.f, dv = 0.f;
+    if (s < K.ns) { du = duvb[((size_t)vm * K.ns + s) * 2]; dv = duvb[((size_t)vm * K.ns + s) * 2 + 1]; }
+    for (int base = 0; base < cnt; base += 256) {
+        int c = base + threadIdx.x;
+        s_choice[threadIdx.x] = c < cnt ? choice[(size_t)vm * K.cmax + c] : -1;
+        s_grad[threadIdx.x] = c < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + c] : make_float2(0.f, 0.f);
+        __syncthreads();
+        int lim = min(256, cnt - base);
+        for (int i = 0; i < lim; ++i)
+            if (s_choice[i] == s) { du += s_grad[i].x; dv += s_grad[i].y; }          // in contour order
+        __syncthreads();
     }
     if (s < K.ns) {
-        float *o = dvout + ((size_t)f * K.nv + (size_t)s * 4) * 3;
-        o[0] += g0; o[1] += g1; o[2] += g2;
+        float4 r = ((const float4 *)uvi)[(size_t)vm * K.ns + s];
+        const float *P = proj_all + ((size_t)f * K.n_views + K.view_index[m]) * 12;
+        float q0 = du * r.w, q1 = dv * r.w, q2 = -(du * r.x + dv * r.y) * r.w;
+        float *o = gpart + ((size_t)vm * K.ns + s) * 3;
+        o[0] = P[0] * q0 + P[4] * q1 + P[8] * q2;
+        o[1] = P[1] * q0 + P[5] * q1 + P[9] * q2;
+        o[2] = P[2] * q0 + P[6] * q1 + P[10] * q2;
     }
+}
+
+// grid (ceil(Ns/256), F).  dvout[f][4 s] += sum over the mask views, in view order; other vertices untouched
+extern "C" __global__ void __launch_bounds__(256)
+bf_mask_gsum_kernel(MaskIO K, const float *__restrict__ gpart, float *__restrict__ dvout) {
+    const int s = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+    if (s >= K.ns) return;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    for (int m = 0; m < K.n_masks; ++m) {
+        const float *p = gpart + (((size_t)f * K.n_masks + m) * K.ns + s) * 3;
+        g0 += p[0]; g1 += p[1]; g2 += p[2];
+    }
+    float *o = dvout + ((size_t)f * K.nv + (size_t)s * 4) * 3;
+    o[0] += g0; o[1] += g1; o[2] += g2;
 }
 
 // grid (F): loss[f] = sum over views / blocks of the partials (fixed order)
@@ -160,7 +176,7 @@ extern "C" __global__ void bf_mask_loss_kernel(MaskIO K, const float *__restrict
     float tot = 0.f;
     for (int m = 0; m < K.n_masks; ++m) {
         const int vm = f * K.n_masks + m;
-        const int nb = K.proj_blocks + (K.contour_count[vm] + 255) / 256;
+        const int nb = K.proj_blocks + (K.contour_count[vm] * 4 + 255) / 256;          // (4 lanes per contour point)
         for (int b = 0; b < nb; ++b) tot += loss_part[(size_t)vm * K.part_stride + b];
     }
     loss[f] = tot;

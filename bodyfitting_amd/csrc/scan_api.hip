@@ -15,6 +15,7 @@ extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const f
 extern "C" __global__ void bf_mask_contour_kernel(MaskIO, const float *, int *, float *, float *);
 extern "C" __global__ void bf_mask_gather_kernel(MaskIO, const float *, const float *, const float *, const int *, const float *, float *);
 extern "C" __global__ void bf_mask_loss_kernel(MaskIO, const float *, float *);
+extern "C" __global__ void bf_mask_gsum_kernel(MaskIO, const float *, float *);
 extern "C" __global__ void bf_disp_face_kernel(const int *, int, int, const float *, const float *, float *);
 extern "C" __global__ void bf_disp_vertex_kernel(const int *, const int *, int, int, const float *, const float *, const float *, float *, float *);
 extern "C" __global__ void bf_disp_vgrad_kernel(const int *, const int *, const int *, int, int, const float *, const float *const *,
@@ -196,11 +197,12 @@ static int launch_mask_kernels(bf_batch *b, float weight) {
     const int F = b->F;
     hipLaunchKernelGGL(bf_mask_project_kernel, dim3(K.proj_blocks, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->vout.p,
                        (const float *)b->proj.p, b->mk_uvi.p, b->mk_duvb.p, b->mk_part.p);
-    hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
+    hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax * 4 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
                        (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p);
-    hipLaunchKernelGGL(bf_mask_gather_kernel, dim3(K.proj_blocks, F), dim3(256), 0, b->stream, K, (const float *)b->proj.p,
+    hipLaunchKernelGGL(bf_mask_gather_kernel, dim3(K.proj_blocks, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->proj.p,
                        (const float *)b->mk_uvi.p, (const float *)b->mk_duvb.p, (const int *)b->mk_choice.p,
-                       (const float *)b->mk_cgrad.p, b->dvout.p);
+                       (const float *)b->mk_cgrad.p, b->mk_gpart.p);
+    hipLaunchKernelGGL(bf_mask_gsum_kernel, dim3(K.proj_blocks, F), dim3(256), 0, b->stream, K, (const float *)b->mk_gpart.p, b->dvout.p);
     hipLaunchKernelGGL(bf_mask_loss_kernel, dim3(F), dim3(64), 0, b->stream, K, (const float *)b->mk_part.p, b->mk_loss.p);
     HIP_TRY(hipGetLastError());
     return BF_OK;
@@ -351,15 +353,15 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     for (size_t i = 0; i < bin.size(); ++i) bin[i] = masks[i] > 128 ? 1 : 0;                 // smplify.py:139
     auto refresh = [](auto &buf) { if (buf.p) { (void)hipFree((void *)buf.p); buf.p = nullptr; } };
     refresh(b->mk_view); refresh(b->mk_cstart); refresh(b->mk_ccount); refresh(b->mk_masks); refresh(b->mk_cxy);
-    refresh(b->mk_uvi); refresh(b->mk_duvb); refresh(b->mk_cgrad); refresh(b->mk_part); refresh(b->mk_loss); refresh(b->mk_choice);
-    const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256, stride = pblocks + (cmax + 255) / 256;
+    refresh(b->mk_uvi); refresh(b->mk_duvb); refresh(b->mk_gpart); refresh(b->mk_cgrad); refresh(b->mk_part); refresh(b->mk_loss); refresh(b->mk_choice);
+    const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256, stride = pblocks + (cmax * 4 + 255) / 256;      // (4 lanes per contour point)
     HIP_TRY(b->mk_view.upload(std::vector<int>(view_index, view_index + n_masks)));
     HIP_TRY(b->mk_cstart.upload(start));
     HIP_TRY(b->mk_ccount.upload(count));
     HIP_TRY(b->mk_masks.upload(bin));
     HIP_TRY(b->mk_cxy.upload(std::vector<float>(contour_xy, contour_xy + (size_t)std::max(total, 1) * 2)));
     const size_t fm = (size_t)F * n_masks;
-    HIP_TRY(b->mk_uvi.alloc(fm * ns * 4)); HIP_TRY(b->mk_duvb.alloc(fm * ns * 2));
+    HIP_TRY(b->mk_uvi.alloc(fm * ns * 4)); HIP_TRY(b->mk_duvb.alloc(fm * ns * 2)); HIP_TRY(b->mk_gpart.alloc(fm * ns * 3));
     HIP_TRY(b->mk_choice.alloc(fm * cmax)); HIP_TRY(b->mk_cgrad.alloc(fm * cmax * 2));
     HIP_TRY(b->mk_part.alloc(fm * stride)); HIP_TRY(b->mk_loss.alloc(F));
     MaskIO &K = b->mask;
