@@ -222,7 +222,7 @@ static int launch_kp(bf_batch *b, const bf_hyper &h) {
     KpIO K = m->kp;
     K.n_views = b->V; K.sigma2 = h.sigma * h.sigma; K.coeff = h.imsize / 1024.0f;
     const int NLP = (K.nl + 31) & ~31, slots = std::max(1, 512 / NLP);
-    const size_t smem = sizeof(float) * ((size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8);
+    const size_t smem = sizeof(float) * ((size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + (size_t)K.nl * 18);    // (+ item list)
     hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), smem, b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
                        (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
                        (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p);
@@ -258,7 +258,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     hipLaunchKernelGGL(bf_mesh_bwd_kernel, dim3(m->mesh.n_tiles, F), dim3(512), bf_mesh_bwd_smem_bytes(m->nj), b->stream, m->mesh,
                        (const float *)m->posedirsT.p, (const float *)b->state.p, (const float *)b->dvout.p,
                        (const float *)b->vposed.p, (const float *)b->vraw.p, b->ext_part.p);
-    hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 255) / 256, F), dim3(256), 0, b->stream,
+    hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 31) / 32, F), dim3(256), 0, b->stream,
                        (const float *)b->ext_part.p, m->mesh.n_tiles, EXT, b->ext.p, EXT + m->nj * 3 + 4);
     HIP_TRY(hipGetLastError());
     return BF_OK;

@@ -279,15 +279,35 @@ extern "C" size_t bf_mesh_bwd_smem_bytes(int nj) {
     return sizeof(float) * (nj * 12 + BF_MESH_TILE * nj + 3 * BF_MESH_TILE * 3 + 8);
 }
 
-// grid (ceil(EXT/256), F): ext[f][i] = sum over tiles (in tile order) of part[f][tile][i]
+// grid (ceil(EXT/32), F), 256 threads = 32 outputs x 8 tile chunks: ext[f][i] = sum over the tiles of part[f][tile][i].
+// A chunk lane adds its contiguous run of tiles in tile order (loads issued eight at a time: a plain serial loop costs
+// one memory latency per tile), then the eight chunk sums are added in chunk order: a fixed order, run to run.
 extern "C" __global__ void __launch_bounds__(256)
 bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float *__restrict__ ext, int ext_stride) {
-    const int i = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
-    if (i >= EXT) return;
-    const float *p = part + (size_t)f * n_tiles * EXT + i;
+    __shared__ float s_c[8][32];
+    const int li = threadIdx.x & 31, ch = threadIdx.x >> 5, i = blockIdx.x * 32 + li, f = blockIdx.y;
+    const int per = (n_tiles + 7) / 8, t0 = ch * per, t1 = min(n_tiles, t0 + per);
     float acc = 0.f;
-    for (int t = 0; t < n_tiles; ++t) acc += p[(size_t)t * EXT];
-    ext[(size_t)f * ext_stride + i] = acc;
+    if (i < EXT) {
+        const float *p = part + (size_t)f * n_tiles * EXT + i;
+        int t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(t + q) * EXT];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += v[q];
+        }
+        for (; t < t1; ++t) acc += p[(size_t)t * EXT];
+    }
+    s_c[ch][li] = acc;
+    __syncthreads();
+    if (ch == 0 && i < EXT) {
+        float tot = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) tot += s_c[c][li];
+        ext[(size_t)f * ext_stride + i] = tot;
+    }
 }
 
 
@@ -367,21 +387,62 @@ bf_kp_loss_kernel(KpIO Q, const float *__restrict__ jraw, const float *__restric
         for (int q = 0; q < nl; ++q) acc += s_g[q * 4 + 3];
         terms[(size_t)f * 4] = acc / ndiv_f;
     }
-    // vertex-based joints, one after the other (their vertices may coincide): 9 threads = (corner, xyz)
+    // vertex-based joints: their vertices may coincide, so the order of the additions matters.  Every (joint, corner)
+    // item gets its rank among the earlier items on the same vertex (one batched scan of the item list in LDS); round r
+    // applies the items of rank r, so each vertex receives its additions in joint order - typically in one or two rounds
+    // instead of one barrier + global round trip per joint.
     float *dv = dvout + (size_t)f * Q.nv * 3;
     const int n_ori = Q.nj + Q.n_selector;
-    for (int q = 0; q < nl; ++q) {
-        const int src = Q.joint_map[q];
-        if (src < Q.nj) continue;
-        if (tid < 9) {
-            int c = tid / 3, k = tid - c * 3;
-            if (src < n_ori) { if (c == 0) dv[(size_t)Q.selector_ids[src - Q.nj] * 3 + k] += s_g[q * 4 + k]; }
-            else {
-                int l = src - n_ori - Q.n_extra;
-                int vid = lmk_vid[((size_t)f * Q.n_lmk + l) * 3 + c];
-                dv[(size_t)vid * 3 + k] += lmk_w[((size_t)f * Q.n_lmk + l) * 3 + c] * s_g[q * 4 + k];
+    int *s_vid = (int *)(s_x + nl * 3 + 8);               // [nl * 3]
+    int *s_max = s_vid + nl * 3;
+    const int n_items = nl * 3;
+    __syncthreads();
+    if (tid == 0) *s_max = 0;
+    for (int i = tid; i < n_items; i += 512) {
+        const int q = i / 3, c = i - q * 3, src = Q.joint_map[q];
+        int vid = -1;
+        if (src >= Q.nj) {
+            if (src < n_ori) { if (c == 0) vid = Q.selector_ids[src - Q.nj]; }
+            else vid = lmk_vid[((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c];
+        }
+        s_vid[i] = vid;
+    }
+    __syncthreads();
+    int my_rank[2] = {-1, -1}, my_vid[2] = {-1, -1};
+    float my_w[2] = {0.f, 0.f};
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int i = tid + 512 * rr;
+        if (i < n_items) {
+            const int vid = s_vid[i];
+            if (vid >= 0) {
+                int rank = 0;
+                for (int j0 = 0; j0 < i; j0 += 16) {
+                    int t[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t[u] = s_vid[min(j0 + u, n_items - 1)];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) rank += (j0 + u < i && t[u] == vid) ? 1 : 0;
+                }
+                const int q = i / 3, c = i - q * 3, src = Q.joint_map[q];
+                my_rank[rr] = rank; my_vid[rr] = vid;
+                my_w[rr] = src < n_ori ? 1.f : lmk_w[((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c];
+                atomicMax(s_max, rank);
             }
         }
+    }
+    __syncthreads();
+    const int n_rounds = *s_max + 1;
+    for (int r = 0; r < n_rounds; ++r) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            if (my_rank[rr] == r) {
+                const int q = (tid + 512 * rr) / 3;
+                float *o = dv + (size_t)my_vid[rr] * 3;
+                o[0] += my_w[rr] * s_g[q * 4]; o[1] += my_w[rr] * s_g[q * 4 + 1]; o[2] += my_w[rr] * s_g[q * 4 + 2];
+            }
+        }
+        __threadfence_block();
         __syncthreads();
     }
 }
