@@ -122,32 +122,39 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
     if (threadIdx.x == 0) loss_part[(size_t)vm * K.part_stride + K.proj_blocks + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-// grid (ceil(Ns/256), M, F).  gpart[f][m][s][3] = dL/dvertex 4 s from mask view m (one workgroup per view and vertex
-// block: the views run in parallel; bf_mask_gsum_kernel adds them in view order)
+// grid (ceil(4 Ns/256), M, F).  gpart[f][m][s][3] = dL/dvertex 4 s from mask view m (one workgroup per view and block
+// of 64 vertices: the views run in parallel; bf_mask_gsum_kernel adds them in view order).  FOUR lanes per vertex: lane
+// q takes the q-th quarter of every 256-point tile of the contour, in contour order; the four partial sums are added
+// in quarter order (a fixed association: deterministic).
 extern "C" __global__ void __launch_bounds__(256)
 bf_mask_gather_kernel(MaskIO K, const float *__restrict__ proj_all, const float *__restrict__ uvi, const float *__restrict__ duvb,
                       const int *__restrict__ choice, const float *__restrict__ cgrad, float *__restrict__ gpart) {
     __shared__ int s_choice[256];
     __shared__ float2 s_grad[256];
-    const int s = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y, f = blockIdx.z;
+    const int gid = blockIdx.x * 256 + threadIdx.x, s = gid >> 2, sub = gid & 3, m = blockIdx.y, f = blockIdx.z;
     const int vm = f * K.n_masks + m;
     const int cnt = K.contour_count[vm];
     float du = 0.f, dv = 0.f;
-    if (s < K.ns) { du = duvb[((size_t)vm * K.ns + s) * 2]; dv = duvb[((size_t)vm * K.ns + s) * 2 + 1]; }
     for (int base = 0; base < cnt; base += 256) {
         int c = base + threadIdx.x;
         s_choice[threadIdx.x] = c < cnt ? choice[(size_t)vm * K.cmax + c] : -1;
         s_grad[threadIdx.x] = c < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + c] : make_float2(0.f, 0.f);
         __syncthreads();
-        int lim = min(256, cnt - base);
-        for (int i = 0; i < lim; ++i)
+        const int i0 = sub * 64;
+#pragma unroll 8
+        for (int i = i0; i < i0 + 64; ++i)
             if (s_choice[i] == s) { du += s_grad[i].x; dv += s_grad[i].y; }          // in contour order
         __syncthreads();
     }
-    if (s < K.ns) {
+    // quarter sums -> lane 0 of the quad, in quarter order
+    const float du1 = __shfl_down(du, 1), dv1 = __shfl_down(dv, 1), du2 = __shfl_down(du, 2), dv2 = __shfl_down(dv, 2),
+                du3 = __shfl_down(du, 3), dv3 = __shfl_down(dv, 3);
+    if (s < K.ns && sub == 0) {
+        float tu = duvb[((size_t)vm * K.ns + s) * 2], tv = duvb[((size_t)vm * K.ns + s) * 2 + 1];
+        tu += du; tv += dv; tu += du1; tv += dv1; tu += du2; tv += dv2; tu += du3; tv += dv3;
         float4 r = ((const float4 *)uvi)[(size_t)vm * K.ns + s];
         const float *P = proj_all + ((size_t)f * K.n_views + K.view_index[m]) * 12;
-        float q0 = du * r.w, q1 = dv * r.w, q2 = -(du * r.x + dv * r.y) * r.w;
+        float q0 = tu * r.w, q1 = tv * r.w, q2 = -(tu * r.x + tv * r.y) * r.w;
         float *o = gpart + ((size_t)vm * K.ns + s) * 3;
         o[0] = P[0] * q0 + P[4] * q1 + P[8] * q2;
         o[1] = P[1] * q0 + P[5] * q1 + P[9] * q2;
