@@ -655,10 +655,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             BF_SYNC();                 // D (+E): projection, view reduction and routing: VALU-bound on the geometry waves, no GMM here
             BF_GMM_CHUNK(4)
             BF_GMM_CHUNK(5)
-            BF_SYNC();                 // F
             BF_GMM_CHUNK(6)
+            BF_SYNC();                 // F
             BF_GMM_CHUNK(7)
-            BF_SYNC();                 // G
             BF_GMM_CHUNK(8)
 #undef BF_GMM_CHUNK
             const v2f y = y0 + y1;
@@ -693,7 +692,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 S.gq[ma] = 0.5f * ta + logw_a;       // prior.py:188-189
                 S.gq[mb] = 0.5f * tb + logw_b;
             }
-            BF_SYNC();                 // H
+            BF_SYNC();                 // G (+H)
             if (tid == 256) {                        // arg-min GMM component (prior.py:195) for the Adam phase
                 int ms = 0;
                 float qm = S.gq[0];
@@ -908,9 +907,22 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 r0 += ea[0]; r1 += ea[1]; r2 += ea[2]; dat += ea[3];
             }
             S.dAt[tq] = dat;
-            S.dGt[tq] += ext ? dat + ext[EXT_G + tq] : dat;     // + dL/d(chain joint) of the dense keypoint loss
-            float4 drow0 = {r0 - dat * S.J[ci * 3], r1 - dat * S.J[ci * 3 + 1], r2 - dat * S.J[ci * 3 + 2], 0.f};
-            *(float4 *)(S.dGR + tq * 4) = drow0;
+            const float gt_fin = S.dGt[tq] + (ext ? dat + ext[EXT_G + tq] : dat);     // + dL/d(chain joint) of the dense keypoint loss
+            const float d0 = r0 - dat * S.J[ci * 3], d1 = r1 - dat * S.J[ci * 3 + 1], d2 = r2 - dat * S.J[ci * 3 + 2];   // row cr of D_i
+            // Row cr of Dg_i = D_i GR_i^T and of M_i = Dg_i + dGt_i (Gt_i - Gt_0)^T.  With these, the sum over the strict
+            // subtree of p of N_i = Dg_i + t_i (Gt_i - Gt_parent(i))^T (t_i itself a subtree sum) telescopes to
+            //   sum_k M_k - (sum_k dGt_k) (Gt_p - Gt_0)^T,
+            // two INDEPENDENT masked sums, so the next phase does both at once (one phase less than summing t_i first).
+            const float4 gi0 = *(const float4 *)(S.G + ci * 12), gi1 = *(const float4 *)(S.G + ci * 12 + 4),
+                         gi2 = *(const float4 *)(S.G + ci * 12 + 8);
+            const float c0 = GT_(0, 0), c1 = GT_(0, 1), c2 = GT_(0, 2);
+            const float dg0 = d0 * gi0.x + d1 * gi0.y + d2 * gi0.z;
+            const float dg1 = d0 * gi1.x + d1 * gi1.y + d2 * gi1.z;
+            const float dg2 = d0 * gi2.x + d1 * gi2.y + d2 * gi2.z;
+            float4 drow = {dg0, dg1, dg2, 0.f};
+            *(float4 *)(S.Dg + tq * 4) = drow;
+            float4 mrow = {dg0 + gt_fin * (gi0.w - c0), dg1 + gt_fin * (gi1.w - c1), dg2 + gt_fin * (gi2.w - c2), gt_fin};
+            *(float4 *)(S.N + tq * 4) = mrow;
         }
         if (tq >= 128 && tq < 133) {            // the projection phase's 16 pair slots -> d/dt, d/ds, loss value (slot order)
             const int q = tq - 128;
@@ -931,97 +943,51 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_SYNC();
 
         {
-        // ================= phase G: subtree sums t_i of dL/dGt, N_i rows, direct dJ (tid < 3 nj) | d(pose feature)
+        // ================= phase G (+H): per (joint p, row r) the two masked subtree sums (M rows and dL/dGt, one b128
+        // read each), t_p, dL/dGR_p (total) = (Dg_p + sum_k M_k - st (Gt_p - Gt_0)^T) GR_p, direct dJ | d(pose feature)
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
-        const int ci = tq / 3, cr = tq - ci * 3;
-        float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f;
         if (wave >= 2) dfeat_rows(tq - 128, npf, 128);
-        if (c_on) {
-            // LDS reads up front: own row of dL/dGR, the three rows of G_i, the parent's translation, dL/dAt_i, and the
-            // dL/dGt column of every joint for the subtree sum (unconditional loads, select on the subtree mask)
-            const float4 dq = *(const float4 *)(S.dGR + tq * 4);
-            const float4 gi0 = *(const float4 *)(S.G + ci * 12), gi1 = *(const float4 *)(S.G + ci * 12 + 4),
-                         gi2 = *(const float4 *)(S.G + ci * 12 + 8);
-            const float gp0 = GT_(cp, 0), gp1 = GT_(cp, 1), gp2 = GT_(cp, 2);
-            const float da0 = S.dAt[ci * 3], da1 = S.dAt[ci * 3 + 1], da2 = S.dAt[ci * 3 + 2];
-            float ttot = S.dGt[tq];
-            constexpr int NJC = NJ > 0 ? NJ : 1;
+        for (int q = tq; q < nj3 && wave < 2; q += 128) {
+            const int p = q / 3, r = q - p * 3;
+            const unsigned long long mk = T.desc[p];
+            const float4 own = *(const float4 *)(S.N + q * 4), dgr = *(const float4 *)(S.Dg + q * 4);
+            const float4 gp0 = *(const float4 *)(S.G + p * 12), gp1 = *(const float4 *)(S.G + p * 12 + 4),
+                         gp2 = *(const float4 *)(S.G + p * 12 + 8);
+            const float c0 = GT_(0, 0), c1 = GT_(0, 1), c2 = GT_(0, 2);
+            const float da0 = S.dAt[p * 3], da1 = S.dAt[p * 3 + 1], da2 = S.dAt[p * 3 + 2];
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, st = 0.f;
             if (NJ > 0) {
-                float tv[NJC];
+                constexpr int NJC = NJ > 0 ? NJ : 1, HB = (NJC + 2) / 3;       // three batches of b128 reads (registers)
 #pragma unroll
-                for (int k = 0; k < NJC; ++k) tv[k] = S.dGt[k * 3 + cr];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int k = 0; k < NJC; ++k) ttot += ((cmask >> k) & 1ull) ? tv[k] : 0.f;
-            } else {
-                for (int k = 0; k < nj; ++k) {
-                    float v = S.dGt[k * 3 + cr];
-                    ttot += ((cmask >> k) & 1ull) ? v : 0.f;
-                }
-            }
-            S.tt[tq] = ttot;
-            float d0 = dq.x, d1 = dq.y, d2 = dq.z;
-            dg0 = d0 * gi0.x + d1 * gi0.y + d2 * gi0.z;     // row cr of D_i GR_i^T
-            dg1 = d0 * gi1.x + d1 * gi1.y + d2 * gi1.z;
-            dg2 = d0 * gi2.x + d1 * gi2.y + d2 * gi2.z;
-            float u0 = 0.f, u1 = 0.f, u2 = 0.f;
-            if (ci > 0) { u0 = gi0.w - gp0; u1 = gi1.w - gp1; u2 = gi2.w - gp2; }
-            float4 nrow = {dg0 + ttot * u0, dg1 + ttot * u1, dg2 + ttot * u2, 0.f};
-            *(float4 *)(S.N + (ci * 3 + cr) * 4) = nrow;
-            float4 drow = {dg0, dg1, dg2, 0.f};
-            *(float4 *)(S.Dg + (ci * 3 + cr) * 4) = drow;
-            const float c0 = cr == 0 ? gi0.x : (cr == 1 ? gi0.y : gi0.z), c1 = cr == 0 ? gi1.x : (cr == 1 ? gi1.y : gi1.z),
-                        c2 = cr == 0 ? gi2.x : (cr == 1 ? gi2.y : gi2.z);
-            S.dJ[tq] = -(c0 * da0 + c1 * da1 + c2 * da2);
-        }
-        }
-        BF_SYNC();
-
-        {
-        // ================= phase H: dL/dGR_p (total) = (D_p GR_p^T + sum over strict subtree of N_i) GR_p, row r.
-        // Two lanes per (joint, row): each sums half of the joints, combined on the DPP path.
-        const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
-        for (int base = 0; base < nj3 * 2; base += NG) {
-            int t2 = base + tq, q = t2 >> 1, hf = t2 & 1;
-            bool ok = q < nj3;
-            int p = ok ? q / 3 : 0, r = ok ? q - p * 3 : 0;
-            unsigned long long mk = ok ? T.desc[p] : 0ull;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-            const int k0 = hf ? (nj + 1) / 2 : 0, k1 = hf ? nj : (nj + 1) / 2;
-            if (NJ > 0) {
-                constexpr int HK = NJ > 0 ? (NJ + 1) / 2 : 1;
-                constexpr int HB = (HK + 1) / 2;              // two batches of b128 reads (registers)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < 3; ++h) {
                     float4 nq[HB];
 #pragma unroll
-                    for (int i = 0; i < HB; ++i) nq[i] = *(const float4 *)(S.N + (min(k0 + h * HB + i, nj - 1) * 3 + r) * 4);
+                    for (int i = 0; i < HB; ++i) nq[i] = *(const float4 *)(S.N + (min(h * HB + i, nj - 1) * 3 + r) * 4);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < HB; ++i) {
-                        const int k = k0 + h * HB + i;
-                        const bool in = (k < k1) && ((mk >> k) & 1ull);
-                        s0 += in ? nq[i].x : 0.f; s1 += in ? nq[i].y : 0.f; s2 += in ? nq[i].z : 0.f;
+                        const int k = h * HB + i;
+                        const bool in = (k < nj) && ((mk >> k) & 1ull);
+                        s0 += in ? nq[i].x : 0.f; s1 += in ? nq[i].y : 0.f; s2 += in ? nq[i].z : 0.f; st += in ? nq[i].w : 0.f;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
 #pragma unroll 4
-                for (int k = k0; k < k1; ++k) {
-                    float4 n = *(const float4 *)(S.N + (k * 3 + r) * 4);
-                    bool in = (mk >> k) & 1ull;
-                    s0 += in ? n.x : 0.f; s1 += in ? n.y : 0.f; s2 += in ? n.z : 0.f;
+                for (int k = 0; k < nj; ++k) {
+                    const float4 n = *(const float4 *)(S.N + (k * 3 + r) * 4);
+                    const bool in = (mk >> k) & 1ull;
+                    s0 += in ? n.x : 0.f; s1 += in ? n.y : 0.f; s2 += in ? n.z : 0.f; st += in ? n.w : 0.f;
                 }
             }
-            s0 = dpp_add<0xB1>(s0); s1 = dpp_add<0xB1>(s1); s2 = dpp_add<0xB1>(s2);       // + the other half
-            if (ok && hf == 0) {
-                float4 dgr = *(const float4 *)(S.Dg + q * 4);
-                s0 += dgr.x; s1 += dgr.y; s2 += dgr.z;
-                float4 tot = {s0 * GR_(p, 0, 0) + s1 * GR_(p, 1, 0) + s2 * GR_(p, 2, 0),
-                              s0 * GR_(p, 0, 1) + s1 * GR_(p, 1, 1) + s2 * GR_(p, 2, 1),
-                              s0 * GR_(p, 0, 2) + s1 * GR_(p, 1, 2) + s2 * GR_(p, 2, 2), 0.f};
-                *(float4 *)(S.dGR + q * 4) = tot;
-            }
+            S.tt[q] = own.w + st;                                   // t_p: dL/dGt summed over the whole subtree of p
+            s0 += dgr.x - st * (gp0.w - c0); s1 += dgr.y - st * (gp1.w - c1); s2 += dgr.z - st * (gp2.w - c2);
+            float4 tot = {s0 * gp0.x + s1 * gp1.x + s2 * gp2.x, s0 * gp0.y + s1 * gp1.y + s2 * gp2.y,
+                          s0 * gp0.z + s1 * gp1.z + s2 * gp2.z, 0.f};
+            *(float4 *)(S.dGR + q * 4) = tot;
+            const float k0 = r == 0 ? gp0.x : (r == 1 ? gp0.y : gp0.z), k1 = r == 0 ? gp1.x : (r == 1 ? gp1.y : gp1.z),
+                        k2 = r == 0 ? gp2.x : (r == 1 ? gp2.y : gp2.z);
+            S.dJ[q] = -(k0 * da0 + k1 * da1 + k2 * da2);
         }
         }
         BF_SYNC();
