@@ -114,15 +114,19 @@ __device__ inline float wave_sum(float v) {
 // sin and cos of a non-negative angle of moderate size (|a| < ~1e4): Cody-Waite reduction by pi/2 in three
 // parts, then the classic degree-7 / degree-8 minimax kernels on [-pi/4, pi/4]; about 1 ulp, ~30 instructions
 // (the OCML sinf + cosf pair costs several hundred cycles on the critical path of every iteration)
+__device__ inline float bf_launder_f(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ inline void sincos_small(float a, float *sn, float *cs) {
     const float n = rintf(a * 0.636619772367581343f);
     float r = fmaf(n, -1.57079625129699707031e+00f, a);
     r = fmaf(n, -7.54978941586159635335e-08f, r);
     r = fmaf(n, -5.39030285815811905290e-15f, r);
     const float z = r * r;
-    const float ps = fmaf(z, fmaf(z, fmaf(z, 2.7557314297e-06f, -1.9841270114e-04f), 8.3333337680e-03f), -1.6666667163e-01f);
+    // (the leading coefficients are materialised here each time: hoisted out of the persistent loop as a VGPR pair for
+    //  the packed fma they end up spilled, and the reload sits on the critical path of every iteration)
+    const float s4 = bf_launder_f(2.7557314297e-06f), c4 = bf_launder_f(-2.7557314297e-07f);
+    const float ps = fmaf(z, fmaf(z, fmaf(z, s4, -1.9841270114e-04f), 8.3333337680e-03f), -1.6666667163e-01f);
     const float sr = fmaf(r * z, ps, r);
-    const float pc = fmaf(z, fmaf(z, fmaf(z, -2.7557314297e-07f, 2.4801587642e-05f), -1.3888889225e-03f), 4.1666667908e-02f);
+    const float pc = fmaf(z, fmaf(z, fmaf(z, c4, 2.4801587642e-05f), -1.3888889225e-03f), 4.1666667908e-02f);
     const float cr = fmaf(z * z, pc, fmaf(z, -0.5f, 1.0f));
     const int q = (int)n & 3;
     const float s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
@@ -693,6 +697,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 S.gq[mb] = 0.5f * tb + logw_b;
             }
             BF_SYNC();                 // G (+H)
+            if (!(NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36)) {     // (two-phase I, K path only)
             if (tid == 256) {                        // arg-min GMM component (prior.py:195) for the Adam phase
                 int ms = 0;
                 float qm = S.gq[0];
@@ -701,6 +706,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 S.scal[1] = (float)ms; S.scal[2] = qm;
             }
             BF_SYNC();                 // I (+J)
+            }
             BF_SYNC();                 // K
             if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
         }
@@ -721,26 +727,30 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             float Ri[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rc[3], rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
             float4 row = {0.f, 0.f, 0.f, 0.f};
             float jj0 = 0.f, jj1 = 0.f, jj2 = 0.f;
+            const int wjq = bf_launder(wj);               // (this phase's LDS addresses are formed here, not kept across the loop)
             if (cw_on) {
                 float th0 = w_pm0, th1 = w_pm1, th2 = w_pm2;
-                if (w_kind == 0) { th0 += Pcur[w_off]; th1 += Pcur[w_off + 1]; th2 += Pcur[w_off + 2]; }
+                // (SMPL: the joint's parameter offset is arithmetic; kept in a register across the loop it gets spilled and the
+                //  reload delays the first read of the chain)
+                const int woff = NJ == 24 ? (wjq > 0 ? T.off_pose + 3 * (wjq - 1) : T.off_orient) : w_off;
+                if (NJ == 24 || w_kind == 0) { th0 += Pcur[woff]; th1 += Pcur[woff + 1]; th2 += Pcur[woff + 2]; }
                 else if (NJ != 24 && w_kind >= 2) { th0 = theta_of(Pcur, wj, 0); th1 = theta_of(Pcur, wj, 1); th2 = theta_of(Pcur, wj, 2); }
                 // rel_j = J_j - J_parent (rel_0 = J_0) was formed from the betas by wave 3 at the end of the previous
                 // iteration (or in the prologue); read it before the Rodrigues arithmetic so the latency hides under it
-                const float a0 = S.rel[wj * 3], a1 = S.rel[wj * 3 + 1], a2 = S.rel[wj * 3 + 2];
-                jj0 = S.J[wj * 3]; jj1 = S.J[wj * 3 + 1]; jj2 = S.J[wj * 3 + 2];
+                const float a0 = S.rel[wjq * 3], a1 = S.rel[wjq * 3 + 1], a2 = S.rel[wjq * 3 + 2];
+                jj0 = S.J[wjq * 3]; jj1 = S.J[wjq * 3 + 1]; jj2 = S.J[wjq * 3 + 2];
                 __builtin_amdgcn_sched_barrier(0);
                 rodrigues_fwd(th0, th1, th2, Ri, rc);
-                if (wave == 2) { S.theta[wj * 3] = th0; S.theta[wj * 3 + 1] = th1; S.theta[wj * 3 + 2] = th2; }
+                if (wave == 2) { S.theta[wjq * 3] = th0; S.theta[wjq * 3 + 1] = th1; S.theta[wjq * 3 + 2] = th2; }
                 rel0 = a0; rel1 = a1; rel2 = a2;
                 // bookkeeping stores spread over the three (otherwise identical) chain waves
                 if (wave == 0 && mode == 1) {                 // (debug dump only)
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) S.R[wj * 9 + e] = Ri[e];
+                    for (int e = 0; e < 9; ++e) S.R[wjq * 9 + e] = Ri[e];
                 }
-                if (wave == 2) { S.rc[wj * 4] = rc[0]; S.rc[wj * 4 + 1] = rc[1]; S.rc[wj * 4 + 2] = rc[2]; }
+                if (wave == 2) { S.rc[wjq * 4] = rc[0]; S.rc[wjq * 4 + 1] = rc[1]; S.rc[wjq * 4 + 2] = rc[2]; }
                 if (wave == 1 && wj > 0) {
-                    float *f = S.feat + w_feat;
+                    float *f = S.feat + (wjq > 0 ? wjq - 1 : 0) * 9;
                     f[0] = Ri[0] - 1.f; f[1] = Ri[1]; f[2] = Ri[2]; f[3] = Ri[3]; f[4] = Ri[4] - 1.f;
                     f[5] = Ri[5]; f[6] = Ri[6]; f[7] = Ri[7]; f[8] = Ri[8] - 1.f;
                 }
@@ -749,7 +759,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     row.y = wave == 0 ? Ri[1] : (wave == 1 ? Ri[4] : Ri[7]);
                     row.z = wave == 0 ? Ri[2] : (wave == 1 ? Ri[5] : Ri[8]);
                     row.w = wave == 0 ? rel0 : (wave == 1 ? rel1 : rel2);
-                    *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
+                    *(float4 *)(S.G + (wjq * 3 + wave) * 4) = row;
                 }
             }
             BF_MARK(40, 0, it, t_iter);
@@ -792,9 +802,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 float nw = gx * Mt[0] + gy * Mt[1] + gz * Mt[2] + gw_;
                 row.x = mine ? nx : row.x; row.y = mine ? ny : row.y; row.z = mine ? nz : row.z; row.w = mine ? nw : row.w;
             }
-            if (cw_on && wj > 0) *(float4 *)(S.G + (wj * 3 + wave) * 4) = row;
+            if (cw_on && wj > 0) *(float4 *)(S.G + (wjq * 3 + wave) * 4) = row;
             // A_j translation row: Gt_j - GR_j J_j (J of this pass was formed with the betas, in the Adam phase)
-            if (cw_on) S.At[wj * 3 + wave] = row.w - (row.x * jj0 + row.y * jj1 + row.z * jj2);
+            if (cw_on) S.At[wjq * 3 + wave] = row.w - (row.x * jj0 + row.y * jj1 + row.z * jj2);
             BF_MARK(41, 0, it, t_iter);
         }
         BF_SYNC();
@@ -872,6 +882,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         project(it == n_iters - 1 || mode == 1);
         BF_SYNC();
 
+        // (this step's Adam constants: a global read, issued two phases ahead of its use)
+        const float *at = adam_tab + (size_t)(adam_t0 + it) * 3;
+        const float at0 = at[0], at1 = at[1], at2 = at[2];
         {
         // ================= phase F: reverse skinning of the selector vertices
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
@@ -992,9 +1005,197 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         BF_SYNC();
 
-        // (this step's Adam constants: a global read, issued a phase ahead of its use)
-        const float *at = adam_tab + (size_t)(adam_t0 + it) * 3;
-        const float at0 = at[0], at1 = at[1], at2 = at[2];
+        constexpr bool MERGE_IK = NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36;     // plain axis-angle body (SMPL)
+        if (MERGE_IK) {
+        // ================= phase I (+K): the reverse sweep's last step and the Adam step in ONE phase, each parameter
+        // stepped by the lane that finishes its gradient:
+        //   wave 0, lane = joint: dL/dR_i, Rodrigues reverse, + GMM / angle prior, Adam for the joint's three pose dofs
+        //   wave 1, lanes 0-3:    transl / scale from the pair-slot sums of the projection phase
+        //   wave 3:               geometric dL/dbeta (6 lanes per beta, summed through a wave-private LDS strip), + shape
+        //                         prior, Adam, then everything the next forward pass derives from the betas
+        // Every consumer takes the arg-min GMM component from the eight q values itself (no hand-off between waves).
+        const int tq = bf_launder(tid);
+        auto adam = [&](int pidx, float pval, float am, float av, float grad) {
+            // torch.optim.Adam, single-tensor path; v_sqrt_f32 / v_rcp_f32 (1 ulp) on the critical path
+            if (mode == 1) { if (io.grads) io.grads[(size_t)frame * np + pidx] = grad; return; }
+            am = am + (grad - am) * (1.0f - hp.beta1);
+            av = av * hp.beta2 + (1.0f - hp.beta2) * grad * grad;
+            const float denom = __builtin_amdgcn_sqrtf(av) * __builtin_amdgcn_rcpf(at2) + hp.eps;
+            const float step = pidx < 4 ? at0 : at1;
+            Pnext[pidx] = pval - step * (am * __builtin_amdgcn_rcpf(denom));
+            S.am[pidx] = am; S.av[pidx] = av;
+        };
+        if (tq < nj) {
+            // all LDS reads of the lane first
+            const float4 g0 = *(const float4 *)(S.G + wp * 12), g1 = *(const float4 *)(S.G + wp * 12 + 4),
+                         g2 = *(const float4 *)(S.G + wp * 12 + 8);
+            const float4 c0 = *(const float4 *)(S.dGR + tq * 12), c1 = *(const float4 *)(S.dGR + tq * 12 + 4),
+                         c2 = *(const float4 *)(S.dGR + tq * 12 + 8);
+            const float t0 = S.tt[tq * 3], t1 = S.tt[tq * 3 + 1], t2 = S.tt[tq * 3 + 2];
+            const float *dfp = S.dfeat + (tq > 0 ? tq - 1 : 0) * 9;
+            float df[9];
+#pragma unroll
+            for (int e = 0; e < 9; ++e) df[e] = dfp[e];
+            const float th0 = S.theta[tq * 3], th1 = S.theta[tq * 3 + 1], th2 = S.theta[tq * 3 + 2];
+            float rcl[3] = {S.rc[tq * 4], S.rc[tq * 4 + 1], S.rc[tq * 4 + 2]};
+            const int pb0 = tq > 0 ? 3 * (tq - 1) : 0;                       // body-pose dof of the joint's first component
+            const int pi0 = tq > 0 ? T.off_pose + pb0 : T.off_orient;        // its parameter index
+            float pv[3], pm[3], pw[3], gq[BF_GMM_M];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { pv[c] = Pcur[pi0 + c]; pm[c] = S.am[pi0 + c]; pw[c] = S.av[pi0 + c]; }
+#pragma unroll
+            for (int m = 0; m < BF_GMM_M; ++m) gq[m] = S.gq[m];
+            __builtin_amdgcn_sched_barrier(0);
+            int ms = 0;
+            float qm = gq[0];
+#pragma unroll
+            for (int m = 1; m < BF_GMM_M; ++m) if (gq[m] < qm) { qm = gq[m]; ms = m; }     // arg-min component (prior.py:195)
+            if (tq == 0) { S.scal[1] = (float)ms; S.scal[2] = qm; }
+            float gy[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gy[c] = S.gy[ms * BF_GMM_LD + pb0 + c];
+            float dRl[9], drl[3];
+            if (tq == 0) {
+                dRl[0] = c0.x; dRl[1] = c0.y; dRl[2] = c0.z; dRl[3] = c1.x; dRl[4] = c1.y; dRl[5] = c1.z;
+                dRl[6] = c2.x; dRl[7] = c2.y; dRl[8] = c2.z;
+                drl[0] = t0; drl[1] = t1; drl[2] = t2;
+            } else {
+                dRl[0] = g0.x * c0.x + g1.x * c1.x + g2.x * c2.x + df[0];
+                dRl[1] = g0.x * c0.y + g1.x * c1.y + g2.x * c2.y + df[1];
+                dRl[2] = g0.x * c0.z + g1.x * c1.z + g2.x * c2.z + df[2];
+                dRl[3] = g0.y * c0.x + g1.y * c1.x + g2.y * c2.x + df[3];
+                dRl[4] = g0.y * c0.y + g1.y * c1.y + g2.y * c2.y + df[4];
+                dRl[5] = g0.y * c0.z + g1.y * c1.z + g2.y * c2.z + df[5];
+                dRl[6] = g0.z * c0.x + g1.z * c1.x + g2.z * c2.x + df[6];
+                dRl[7] = g0.z * c0.y + g1.z * c1.y + g2.z * c2.y + df[7];
+                dRl[8] = g0.z * c0.z + g1.z * c1.z + g2.z * c2.z + df[8];
+                drl[0] = g0.x * t0 + g1.x * t1 + g2.x * t2;
+                drl[1] = g0.y * t0 + g1.y * t1 + g2.y * t2;
+                drl[2] = g0.z * t0 + g1.z * t1 + g2.z * t2;
+            }
+            float gl[3];
+            rodrigues_bwd(th0, th1, th2, rcl, dRl, gl);
+            BF_MARK(50, 0, it, t_iter);
+            if (mode == 1) {                         // (kept for the debug dump only)
+#pragma unroll
+                for (int e = 0; e < 9; ++e) S.dR[tq * 9 + e] = dRl[e];
+                S.drel[tq * 3] = drl[0]; S.drel[tq * 3 + 1] = drl[1]; S.drel[tq * 3 + 2] = drl[2];
+                S.gth[tq * 3] = gl[0]; S.gth[tq * 3 + 1] = gl[1]; S.gth[tq * 3 + 2] = gl[2];
+            }
+            // body-pose dofs: + GMM and angle priors (loss.py:54-61: dofs 52, 55, 9, 12), branch-free: the sign is 0 for every
+            // other dof (and for the root joint), which zeroes the exponential term exactly.  The joint's three Adam steps
+            // are written stage by stage so that their dependent chains (sqrt, two rcp) interleave.
+            {
+                const float body = tq > 0 ? 1.f : 0.f;
+                float grad[3], sg[3], ex[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int pb = pb0 + c;
+                    sg[c] = body * ((pb == 52 ? 1.f : 0.f) - (pb == 55 ? 1.f : 0.f) - (pb == 9 ? 1.f : 0.f) - (pb == 12 ? 1.f : 0.f));
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) ex[c] = __expf(pv[c] * sg[c]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) grad[c] = gl[c] + body * (hp.w_pose * gy[c]) + hp.w_angle * 2.f * ex[c] * ex[c] * sg[c];
+                if (mode == 1) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) if (io.grads) io.grads[(size_t)frame * np + pi0 + c] = grad[c];
+                } else {
+                    float sq[3], rd[3];
+                    const float ir2 = __builtin_amdgcn_rcpf(at2);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { pm[c] = pm[c] + (grad[c] - pm[c]) * (1.0f - hp.beta1); pw[c] = pw[c] * hp.beta2 + (1.0f - hp.beta2) * grad[c] * grad[c]; }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) sq[c] = __builtin_amdgcn_sqrtf(pw[c]);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) rd[c] = __builtin_amdgcn_rcpf(sq[c] * ir2 + hp.eps);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) { Pnext[pi0 + c] = pv[c] - at1 * (pm[c] * rd[c]); S.am[pi0 + c] = pm[c]; S.av[pi0 + c] = pw[c]; }
+                }
+            }
+            BF_MARK(51, 0, it, t_iter);
+        }
+        if (tq >= 64 && tq < 68) {                                   // transl / scale
+            const int pidx = tq - 64;
+            const float pval = Pcur[pidx], am = S.am[pidx], av = S.av[pidx], psum = S.scal[3 + pidx], sc3 = Pcur[3];
+            const float grad = psum * (pidx < 3 ? sc3 * cscale : cscale) + (ext ? ext[EXT_T + pidx] + ext[EXT_K + pidx] : 0.f);
+            S.g[pidx] = grad;                                        // (kept for the debug dump)
+            adam(pidx, pval, am, av, grad);
+        }
+        if (wave == 3) {
+            // geometric part of dL/dbeta: sum Jd.dJ + Jdrel.drel + sel_sd.dvp with dL/drel_i = GR_p^T t_i formed inline;
+            // lane = (beta l = lane / 6, slice sl = lane % 6): joints sl, sl + 6, sl + 12, sl + 18 and outputs sl + 6 m
+            const int l = min(lane / 6, nb - 1), sl = lane - (lane / 6) * 6;
+            const bool on = lane < 6 * nb;
+            float acc = 0.f;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                  // two joints at a time (registers)
+                int pj[2];
+                float tv[2][3], dj[2][3], jd[2][3], jr[2][3];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int i = sl + 6 * (2 * h + m);
+                    pj[m] = S.par[i];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        tv[m][k] = S.tt[i * 3 + k]; dj[m][k] = S.dJ[i * 3 + k];
+                        jd[m][k] = S.Jd[(i * 3 + k) * nbp + l]; jr[m][k] = S.Jdrel[(i * 3 + k) * nbp + l];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                float4 ga[2][3];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ga[m][0] = *(const float4 *)(S.G + pj[m] * 12); ga[m][1] = *(const float4 *)(S.G + pj[m] * 12 + 4);
+                    ga[m][2] = *(const float4 *)(S.G + pj[m] * 12 + 8);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int i = sl + 6 * (2 * h + m);
+                    float e0 = tv[m][0], e1 = tv[m][1], e2 = tv[m][2];
+                    if (i > 0) {
+                        e0 = ga[m][0].x * tv[m][0] + ga[m][1].x * tv[m][1] + ga[m][2].x * tv[m][2];
+                        e1 = ga[m][0].y * tv[m][0] + ga[m][1].y * tv[m][1] + ga[m][2].y * tv[m][2];
+                        e2 = ga[m][0].z * tv[m][0] + ga[m][1].z * tv[m][1] + ga[m][2].z * tv[m][2];
+                    }
+                    acc += jd[m][0] * dj[m][0] + jr[m][0] * e0;
+                    acc += jd[m][1] * dj[m][1] + jr[m][1] * e1;
+                    acc += jd[m][2] * dj[m][2] + jr[m][2] * e2;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            {
+                float sw[6], sd[6];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) { const int o = min(sl + 6 * m, ns3 - 1); sw[m] = S.sel_sd[o * nbp + l]; sd[m] = S.dvp[o]; }
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc += (sl + 6 * m < ns3) ? sw[m] * sd[m] : 0.f;
+            }
+            BF_MARK(52, 192, it, t_iter);
+            float *strip = S.vpp + 4 * 64;                 // (the pose-blend strips of waves 0-3 are dead by now; this is a fifth)
+            strip[lane] = on ? acc : 0.f;
+            // this lane's beta (lanes 0..nb-1): value, moments
+            const int pidx = T.off_beta + min(lane, nb - 1);
+            const float pval = Pcur[pidx], am = S.am[pidx], av = S.av[pidx];
+            BF_WAVE_FENCE();
+            if (lane < nb) {
+                float pr[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) pr[i] = strip[lane * 6 + i];
+                float g = 0.f;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) g += pr[i];
+                if (ext) g += ext[EXT_B + lane];
+                S.g[pidx] = g;                                       // (kept for the debug dump)
+                adam(pidx, pval, am, av, g + 2.f * hp.w_shape * pval);
+            }
+            BF_MARK(53, 192, it, t_iter);
+            BF_WAVE_FENCE();
+            beta_dependent(mode == 0 ? Pnext : Pcur);
+            BF_MARK(54, 192, it, t_iter);
+        }
+        } else {
         {
         // ================= phase I: per joint (wave 0, lane = joint) dL/dR_i = GR_p^T dGR_i + d(pose feature), then the
         // Rodrigues reverse on the same lane | geometric part of dL/dbeta (waves 1-3), with dL/drel_i = GR_p^T t_i
@@ -1175,6 +1376,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             beta_dependent(mode == 0 ? Pnext : Pcur);
         }
         }
+        }
         BF_SYNC();
         if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
     }
@@ -1215,7 +1417,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (tid < nb) st.beta[tid] = Pold[T.off_beta + tid];
             if (tid < 3) st.t[tid] = Pold[tid];
             if (tid == 3) { st.sc[0] = Pold[3]; st.sc[1] = cscale; }
-            if (io.grads && pidx_last >= 0) io.grads[(size_t)frame * np + pidx_last] = grad;
+            if (io.grads && pidx_last >= 0 && !(NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36)) io.grads[(size_t)frame * np + pidx_last] = grad;
         }
         if (io.debug && frame == 0 && mode == 1) {
             float *d = io.debug;

@@ -15,7 +15,8 @@ b = N.FrameBatch(dev, 1, 48)
 b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
 for rep in range(3):
     b.reset(); b.fit(100); b.sync()
-    d = b.debug_dump(4096 + 96)[4096:]
+    d = np.nan_to_num(b.debug_dump(4096 + 96)[4096:], nan=0.0, posinf=0.0, neginf=0.0)
+    d = np.where(np.abs(d) > 1e7, 0.0, d)          # (uninitialised stamp slots)
     n = int(np.max(np.nonzero(d[:32])[0])) + 1 if np.any(d[:32]) else 0
     st = d[:n]
     print("rep", rep, "timing", b.last_timing())
@@ -24,3 +25,4 @@ for rep in range(3):
     print("  phase A inner: after rodrigues+rel, after chain levels, GMM wave done:", [int(x) for x in d[40:43]])
     print("  phase D inner: start, after view loop, after reduce+route:", [int(d[45]), int(d[43]), int(d[44])])
     print("  GMM inner (from the G barrier): start-of-GMM.., after d, after matvec, after tails, done:", [int(d[46]), int(d[47]), int(d[48]), int(d[42])])
+    print("  IK inner: wave0 after rodrigues_bwd, wave0 end | wave3 after g_beta partials, after beta Adam, end:", [int(d[50]), int(d[51]), int(d[52]), int(d[53]), int(d[54])])
