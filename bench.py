@@ -10,7 +10,7 @@ parameters / vertices / joints into pinned host memory (the rtn_dict of smplify.
 Inputs (cameras, keypoints, initial estimate, model) are already resident in HBM when the timed
 region starts.  N=1 default workload = BASELINE config 2 (1 frame per GPU per step); frames are
 independent, so for N>1 every rank fits its own frames (weak scaling, no data-path collective) and
-the packed parameters are all-gathered over RCCL once per step.
+the packed parameters are all-gathered over RCCL once per job (after the K timed steps, inside the timed region).
 
 PyTorch appears here only for torch.distributed (barrier, RCCL all-gather) and - in the clearly
 separated `cpu_baseline` leg - to execute the oracle; the measured path is numpy + ctypes + HIP.
@@ -70,21 +70,21 @@ def build_batch(dev, model, frames, n_views):
     return b, probs
 
 
-def run_steps(batch, steps, iters, flags, after_step=None):
+def run_steps(batch, steps, iters, flags, finish=None):
     for _ in range(steps):
         batch.fit(iters, flags=flags | _lib.FIT_RESET)       # re-arm + fit + mesh + joints + fetch, one call
-        if after_step is not None:
-            after_step()
     batch.sync()
+    if finish is not None:
+        finish()                                             # the job's one collective: gather of the fitted parameters
 
 
-def timed_leg(batch, steps, warmup, iters, flags, barrier=lambda: None, after_step=None):
-    run_steps(batch, warmup, iters, flags, after_step)
+def timed_leg(batch, steps, warmup, iters, flags, barrier=lambda: None, finish=None):
+    run_steps(batch, warmup, iters, flags, finish)
     batch.timing_reset()
     barrier()
     batch.sync()
     t0 = time.perf_counter()
-    run_steps(batch, steps, iters, flags, after_step)
+    run_steps(batch, steps, iters, flags, finish)
     barrier()
     t1 = time.perf_counter()
     return t1 - t0, batch.timing_sum()
@@ -158,9 +158,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-        def after():          # the one collective of the path: final gather of the fitted parameters
+        def after():          # the one collective of the path: final gather of the fitted parameters, once per job
             batch.export_params_dev(send.data_ptr())
+            batch.sync()      # (the export runs on the batch's stream, the collective on torch's)
             dist.all_gather_into_tensor(recv, send)
+            torch.cuda.synchronize()
         gather = recv
     elif world > 1:
         import torch
@@ -214,7 +216,7 @@ def main():
                    "schedule": "dense (full mesh every iteration)" if a.dense else "sparse (gradient-carrying vertices only) + one final full mesh",
                    "submission": ("host-issued: 4 kernels per step (fit, mesh, joints, publish)" + (", no event records in the timed steps" if a.no_events else ""))
                                  if (a.no_graph or a.dense) else "one hipGraph launch per step",
-                   "parallelism": f"frames sharded over {world} GPU(s), RCCL all-gather of parameters per step" if world > 1 else "1 GPU"},
+                   "parallelism": f"frames sharded over {world} GPU(s), one RCCL all-gather of the fitted parameters per job" if world > 1 else "1 GPU"},
         "roofline": {
             "bound": "hbm", "kernel": "bf_fit_kernel" if not a.dense else "bf_fit_kernel+bf_mesh_kernel (per iteration)",
             "achieved": BYTES_PER_FRAME_ITER * a.iters * F / (fit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
