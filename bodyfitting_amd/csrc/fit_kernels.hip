@@ -586,8 +586,21 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_MARK(43, 0, bf_it, bf_t0);
         // sum over the 16 view lanes of the pair (fixed DPP tree), route dL/dX to its source, and leave this wave's
         // share of d/dt, d/ds and of the loss value for the Adam phase
-        const float ga0 = row16_sum(g0.x), ga1 = row16_sum(g1.x), ga2 = row16_sum(g2.x);
-        const float gb0 = row16_sum(g0.y), gb1 = row16_sum(g1.y), gb2 = row16_sum(g2.y);
+        // the six 16-lane sums stage by stage (a dependent DPP costs ~20 cycles on gfx950: six chains of four in a row are
+        // 24 of them back to back, four stages of six independent ones are four)
+        float rv[6] = {g0.x, g1.x, g2.x, g0.y, g1.y, g2.y};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rv[q] = dpp_add<0xB1>(rv[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rv[q] = dpp_add<0x4E>(rv[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rv[q] = dpp_add<0x124>(rv[q]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rv[q] = dpp_add<0x128>(rv[q]);
+        const float ga0 = rv[0], ga1 = rv[1], ga2 = rv[2], gb0 = rv[3], gb1 = rv[4], gb2 = rv[5];
         float la = 0.f, lb = 0.f;
         if (want_loss) { la = row16_sum(lsum.x); lb = row16_sum(lsum.y); }     // (the value only leaves with the last forward pass)
         if (vsub == 0 && wave < 4) {
