@@ -247,6 +247,21 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         std::vector<unsigned long long> desc(nj, 0ull);
         for (int j = nj - 1; j >= 1; --j) desc[parents[j]] |= desc[j] | (1ull << j);
         okay = okay && m->desc_d.upload(desc) == hipSuccess;
+        // depth-first order (children in index order): a subtree is a contiguous run of positions, so subtree sums are
+        // differences of a prefix sum
+        std::vector<int> order, last(nj, 0), pos(nj, 0);
+        std::vector<int> stack{0};
+        while (!stack.empty()) {
+            int j = stack.back(); stack.pop_back();
+            pos[j] = (int)order.size(); order.push_back(j);
+            for (int c = nj - 1; c >= 1; --c) if (parents[c] == j) stack.push_back(c);
+        }
+        for (int i = 0; i < nj; ++i) {
+            int j = order[i], cnt = 1;
+            for (int k = 0; k < nj; ++k) if ((desc[j] >> k) & 1ull) ++cnt;
+            last[i] = i + cnt - 1;
+        }
+        okay = okay && m->dfs_order.upload(order) == hipSuccess && m->dfs_last.upload(last) == hipSuccess;
     }
     up_vi(m->depth_d, depth); up_vf(m->sel_nzw, nzw); up_vi(m->sel_nzj, nzj); up_vf(m->g_plane, plane); up_vf(m->g_ptail, ptail);
     up_vi(m->parents, parents); up_vi(m->level_start, level_start); up_vi(m->level_joints, level_joints);
@@ -299,7 +314,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         T.pose_mean = smplx ? m->pose_mean.p : nullptr; T.hand_comp = smplx ? m->hand_comp.p : nullptr;
     }
     T.sel_nnz = sel_nnz; T.sel_nzw = m->sel_nzw.p; T.sel_nzj = m->sel_nzj.p;
-    T.depth = m->depth_d.p; T.desc = m->desc_d.p; T.g_plane = m->g_plane.p; T.g_ptail = m->g_ptail.p;
+    T.depth = m->depth_d.p; T.desc = m->desc_d.p; T.dfs_order = m->dfs_order.p; T.dfs_last = m->dfs_last.p; T.g_plane = m->g_plane.p; T.g_ptail = m->g_ptail.p;
     T.parents = m->parents.p; T.level_start = m->level_start.p; T.level_joints = m->level_joints.p;
     T.child_start = m->child_start.p; T.child_list = m->child_list.p;
     T.lj_kind = m->lj_kind.p; T.lj_index = m->lj_index.p;

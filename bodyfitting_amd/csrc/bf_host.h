@@ -51,6 +51,7 @@ struct bf_model {
     DevBuf<int> depth_d, sel_nzj;
     DevBuf<float> sel_nzw;
     DevBuf<unsigned long long> desc_d;
+    DevBuf<int> dfs_order, dfs_last;
     DevBuf<float> g_plane, g_ptail;
     DevBuf<int> parents, level_start, level_joints, child_start, child_list, lj_kind, lj_index;
     DevBuf<float> Jtrel;

@@ -35,6 +35,8 @@ struct FitTab {
     const int *parents;              // [nj]
     const int *depth;                // [nj]
     const unsigned long long *desc;  // [nj] bit k set = joint k is a strict descendant
+    const int *dfs_order;            // [nj] joint at depth-first position i (children in index order)
+    const int *dfs_last;             // [nj] last depth-first position of the subtree rooted at position i (inclusive)
     const int *level_start;          // [n_levels+1]  joints sorted by depth
     const int *level_joints;         // [nj]
     const int *child_start;          // [nj+1]        CSR children lists

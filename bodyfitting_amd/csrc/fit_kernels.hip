@@ -266,6 +266,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int w_kind = T.th_kind[wj], w_off = T.th_off[wj];
     const float w_pm0 = (NJ != 24 && T.pose_mean) ? T.pose_mean[wj * 3] : 0.f, w_pm1 = (NJ != 24 && T.pose_mean) ? T.pose_mean[wj * 3 + 1] : 0.f,
                 w_pm2 = (NJ != 24 && T.pose_mean) ? T.pose_mean[wj * 3 + 2] : 0.f;      // (SMPL has no pose mean)
+    // depth-first role of the merged reverse-skinning + subtree-sum phase (waves 0-2 = rows, lane = DFS position)
+    const int fg_k = (wave < 3 && lane < nj) ? T.dfs_order[lane] : 0;
+    const int fg_last4 = ((wave < 3 && lane < nj) ? T.dfs_last[lane] : 0) * 4;
     // (joint, row) role of the reverse sweep: tid < 3 nj
     const bool c_on = tid < nj3;
     const int ci = c_on ? tid / 3 : 0, cr = c_on ? tid - ci * 3 : 0;
@@ -441,12 +444,12 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     };
     // d(pose feature) = sel_pd . dvp for rows first, first + step, ... < last (the GMM waves' registers are full of
     // precision rows, so the geometry waves the reverse sweep leaves idle take it: waves 2-3 in phase G)
-    auto dfeat_rows = [&](int first, int last, int step) {
+    auto dfeat_rows = [&](const float *dvp_src, int first, int last, int step) {
         constexpr int NO = NS > 0 ? NS * 3 : 1;
         if (NS > 0) {
             float4 dq4[(NO + 3) / 4];
 #pragma unroll
-            for (int q = 0; q < (NO + 3) / 4; ++q) dq4[q] = ((const float4 *)__builtin_assume_aligned(S.dvp, 16))[q];
+            for (int q = 0; q < (NO + 3) / 4; ++q) dq4[q] = ((const float4 *)__builtin_assume_aligned(dvp_src, 16))[q];
             const float *dv = (const float *)dq4;
             for (int p = first; p < last; p += step) {
                 const float *row = S.sel_pd + p * ns3;
@@ -463,7 +466,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             for (int p = first; p < last; p += step) {
                 float acc = 0.f;
                 const float *row = S.sel_pd + p * ns3;
-                for (int o = 0; o < ns3; ++o) acc += row[o] * S.dvp[o];
+                for (int o = 0; o < ns3; ++o) acc += row[o] * dvp_src[o];
                 S.dfeat[p] = ext ? acc + ext[p] : acc;
             }
         }
@@ -655,25 +658,27 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 y0 += P2[2 * j2] * t0;                                                          \
                 y1 += P2[2 * j2 + 1] * t1;                                                      \
             }
+            constexpr bool GMM_FG = NJ > 0 && NJ <= 32 && NS > 0 && NS * 3 <= 36;     // (= MERGE_FG of the geometry loop)
             BF_GMM_CHUNK(0)
             BF_GMM_CHUNK(1)
+            BF_GMM_CHUNK(2)
             BF_SYNC();                 // A
             if (merge_bc) {
                 // (the geometry waves do the merged pose blend + skinning alone)
-                BF_GMM_CHUNK(2)
                 BF_GMM_CHUNK(3)
+                BF_GMM_CHUNK(4)
+                BF_GMM_CHUNK(5)
             } else {
                 pose_blend(std::integral_constant<int, 2>());
                 BF_SYNC();             // B
-                BF_GMM_CHUNK(2)
                 BF_GMM_CHUNK(3)
+                BF_GMM_CHUNK(4)
+                BF_GMM_CHUNK(5)
             }
             BF_SYNC();                 // C
             BF_SYNC();                 // D (+E): projection, view reduction and routing: VALU-bound on the geometry waves, no GMM here
-            BF_GMM_CHUNK(4)
-            BF_GMM_CHUNK(5)
             BF_GMM_CHUNK(6)
-            BF_SYNC();                 // F
+            if (!GMM_FG) BF_SYNC();    // F (two-phase path only)
             BF_GMM_CHUNK(7)
             BF_GMM_CHUNK(8)
 #undef BF_GMM_CHUNK
@@ -895,9 +900,130 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         project(it == n_iters - 1 || mode == 1);
         BF_SYNC();
 
-        // (this step's Adam constants: a global read, issued two phases ahead of its use)
+        // (this step's Adam constants: a global read, issued ahead of its use)
         const float *at = adam_tab + (size_t)(adam_t0 + it) * 3;
         const float at0 = at[0], at1 = at[1], at2 = at[2];
+        constexpr bool MERGE_FG = NJ > 0 && NJ <= 32 && NS > 0 && NS * 3 <= 36;
+        if (MERGE_FG) {
+        // ================= phase F (+G, H): reverse skinning AND the subtree sums in one phase.  Wave r (0-2) owns row r of
+        // every joint, lane = depth-first position: a subtree is a contiguous run of positions, so with X_k = (row r of
+        // M_k, dL/dGt_k[r]) the two subtree sums are P[last(k)] - P[k] of ONE inclusive prefix sum over the lanes (four DPP
+        // row_shr stages + a cross-row fix-up) - no LDS round trip, no barrier between the reverse skinning that produces
+        // X_k and the sums that consume it.  Every wave then takes its share of d(pose feature) = sel_pd . dvp (wave 3 first).
+        const int lq = bf_launder(lane);
+        float *strip = S.vpp + wave * 64;
+        if (lq < ns3) {                             // dvp = T_s^T dvsel, by every geometry wave into its own strip
+            const int sv = lq / 3, b = lq - sv * 3;
+            const float dvp = S.TR[sv * 9 + b] * S.dvsel[sv * 3] + S.TR[sv * 9 + 3 + b] * S.dvsel[sv * 3 + 1] +
+                              S.TR[sv * 9 + 6 + b] * S.dvsel[sv * 3 + 2];
+            strip[lq] = dvp;
+            if (wave == 3) S.dvp[lq] = dvp;          // (for the betas' gradient in the next phase)
+        }
+        if (wave == 3 && lq >= 40 && lq < 45) {      // the projection phase's 16 pair slots -> d/dt, d/ds, loss value (slot order)
+            const int q = lq - 40;
+            float pq[16];
+#pragma unroll
+            for (int w = 0; w < 16; ++w) pq[w] = S.part[w * 8 + q];
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) acc += pq[w];
+            S.scal[3 + q] = acc;
+        }
+        if (wave < 3) {
+            constexpr int NSC = NS > 0 ? NS : 1, NV4 = (NSC * 3 + 3) / 4;
+            const int r = wave, k = fg_k;
+            const bool on = lq < nj;
+            // LDS reads first, the selector vertices in two halves (registers: 2 x 9 b128 + 2 x 11 would not fit)
+            const float4 gi0 = *(const float4 *)(S.G + k * 12), gi1 = *(const float4 *)(S.G + k * 12 + 4),
+                         gi2 = *(const float4 *)(S.G + k * 12 + 8);
+            const float j0 = S.J[k * 3], j1 = S.J[k * 3 + 1], j2 = S.J[k * 3 + 2];
+            const float c0 = GT_(0, 0), c1 = GT_(0, 1), c2 = GT_(0, 2);
+            const float routed = S.dGt[k * 3 + r];
+            float da0 = 0.f, da1 = 0.f, da2 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
+            constexpr int HV = (NSC + 1) / 2 + ((((NSC + 1) / 2) * 3) % 4 ? (4 - (((NSC + 1) / 2) * 3) % 4) % 4 : 0) * 0;     // vertices per half
+            constexpr int H4 = (HV * 3 + 3) / 4 + 1;                                  // b128 reads covering a half (start may be unaligned by up to 3)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int sv0 = h * HV, f0 = (sv0 * 3) & ~3;                          // first float of the half, rounded down to a b128
+                float wv[HV], dvr[HV];
+                float4 dq[H4], vq[H4];
+#pragma unroll
+                for (int i = 0; i < HV; ++i) { const int sv = min(sv0 + i, NSC - 1); wv[i] = S.sel_w[sv * nj + k]; dvr[i] = S.dvsel[sv * 3 + r]; }
+#pragma unroll
+                for (int q = 0; q < H4; ++q) {
+                    const int q4 = min(f0 / 4 + q, NV4 - 1);
+                    dq[q] = ((const float4 *)__builtin_assume_aligned(S.dvsel, 16))[q4];
+                    vq[q] = ((const float4 *)__builtin_assume_aligned(S.vp, 16))[q4];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float *dva = (const float *)dq, *vpr = (const float *)vq;
+#pragma unroll
+                for (int i = 0; i < HV; ++i) {
+                    const int sv = sv0 + i;
+                    if (sv < NSC) {
+                        const int o = sv * 3 - f0;                                   // (compile-time after unrolling)
+                        da0 += wv[i] * dva[o]; da1 += wv[i] * dva[o + 1]; da2 += wv[i] * dva[o + 2];
+                        const float wd_ = wv[i] * dvr[i];
+                        r0 += wd_ * vpr[o]; r1 += wd_ * vpr[o + 1]; r2 += wd_ * vpr[o + 2];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float dat = r == 0 ? da0 : (r == 1 ? da1 : da2);
+            if (ext) {                      // dense vertex losses: sum_v w_vj dv (x) [vp | 1] from bf_mesh_bwd_kernel (all rows of dAt)
+                const float *ea = ext + EXT_A + k * 12;
+                r0 += ea[r * 4]; r1 += ea[r * 4 + 1]; r2 += ea[r * 4 + 2];
+                da0 += ea[3]; da1 += ea[7]; da2 += ea[11];
+                dat = r == 0 ? da0 : (r == 1 ? da1 : da2);
+            }
+            const float gt_fin = routed + (ext ? dat + ext[EXT_G + k * 3 + r] : dat);
+            const float d0 = r0 - dat * j0, d1 = r1 - dat * j1, d2 = r2 - dat * j2;       // row r of D_k
+            const float dg0 = d0 * gi0.x + d1 * gi0.y + d2 * gi0.z;                      // row r of Dg_k = D_k GR_k^T
+            const float dg1 = d0 * gi1.x + d1 * gi1.y + d2 * gi1.z;
+            const float dg2 = d0 * gi2.x + d1 * gi2.y + d2 * gi2.z;
+            const float u0 = gi0.w - c0, u1 = gi1.w - c1, u2 = gi2.w - c2;              // Gt_k - Gt_0
+            // X_k = (row r of M_k = Dg_k + dGt_k (Gt_k - Gt_0)^T, dGt_k[r]); inclusive prefix sum over the DFS positions
+            float x[4] = {on ? dg0 + gt_fin * u0 : 0.f, on ? dg1 + gt_fin * u1 : 0.f, on ? dg2 + gt_fin * u2 : 0.f, on ? gt_fin : 0.f};
+            float p[4] = {x[0], x[1], x[2], x[3]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = dpp_add<0x111>(p[c]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = dpp_add<0x112>(p[c]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = dpp_add<0x114>(p[c]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = dpp_add<0x118>(p[c]);
+            float sres[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float t15 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p[c]), 15));
+                p[c] += lq >= 16 ? t15 : 0.f;                       // (positions 16..31 sit in the second DPP row)
+                const float pl = __int_as_float(__builtin_amdgcn_ds_bpermute(fg_last4, __float_as_int(p[c])));
+                sres[c] = pl - p[c];                                // sum over the strict subtree
+            }
+            if (on) {
+                S.tt[k * 3 + r] = sres[3] + x[3];                   // t_k: dL/dGt over the whole subtree
+                const float s0 = sres[0] - sres[3] * u0 + dg0, s1 = sres[1] - sres[3] * u1 + dg1, s2 = sres[2] - sres[3] * u2 + dg2;
+                float4 tot = {s0 * gi0.x + s1 * gi1.x + s2 * gi2.x, s0 * gi0.y + s1 * gi1.y + s2 * gi2.y,
+                              s0 * gi0.z + s1 * gi1.z + s2 * gi2.z, 0.f};
+                *(float4 *)(S.dGR + (k * 3 + r) * 4) = tot;
+                const float k0 = r == 0 ? gi0.x : (r == 1 ? gi0.y : gi0.z), k1 = r == 0 ? gi1.x : (r == 1 ? gi1.y : gi1.z),
+                            k2 = r == 0 ? gi2.x : (r == 1 ? gi2.y : gi2.z);
+                S.dJ[k * 3 + r] = -(k0 * da0 + k1 * da1 + k2 * da2);
+            }
+        }
+        BF_WAVE_FENCE();
+        // d(pose feature): wave 3 rows 0..63 right away, waves 0-2 rows 64 + 64 w + lane after their subtree work
+        if (wave == 3) dfeat_rows(strip, lq, min(npf, 64), 64);
+        else {
+            dfeat_rows(strip, 64 + wave * 64 + lq, min(npf, 128 + wave * 64), 64);
+            for (int p0 = 256; p0 < npf; p0 += 192) dfeat_rows(strip, p0 + wave * 64 + lq, min(npf, p0 + wave * 64 + 64), 64);
+        }
+        BF_SYNC();
+        } else {
         {
         // ================= phase F: reverse skinning of the selector vertices
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
@@ -972,7 +1098,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // ================= phase G (+H): per (joint p, row r) the two masked subtree sums (M rows and dL/dGt, one b128
         // read each), t_p, dL/dGR_p (total) = (Dg_p + sum_k M_k - st (Gt_p - Gt_0)^T) GR_p, direct dJ | d(pose feature)
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
-        if (wave >= 2) dfeat_rows(tq - 128, npf, 128);
+        if (wave >= 2) dfeat_rows(S.dvp, tq - 128, npf, 128);
         for (int q = tq; q < nj3 && wave < 2; q += 128) {
             const int p = q / 3, r = q - p * 3;
             const unsigned long long mk = T.desc[p];
@@ -1018,6 +1144,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         BF_SYNC();
 
+        }
         constexpr bool MERGE_IK = NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36;     // plain axis-angle body (SMPL)
         if (MERGE_IK) {
         // ================= phase I (+K): the reverse sweep's last step and the Adam step in ONE phase, each parameter
