@@ -909,15 +909,15 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // every joint, lane = depth-first position: a subtree is a contiguous run of positions, so with X_k = (row r of
         // M_k, dL/dGt_k[r]) the two subtree sums are P[last(k)] - P[k] of ONE inclusive prefix sum over the lanes (four DPP
         // row_shr stages + a cross-row fix-up) - no LDS round trip, no barrier between the reverse skinning that produces
-        // X_k and the sums that consume it.  Every wave then takes its share of d(pose feature) = sel_pd . dvp (wave 3 first).
+        // X_k and the sums that consume it.  Wave 3 meanwhile forms d(pose feature) = sel_pd . dvp.
         const int lq = bf_launder(lane);
         float *strip = S.vpp + wave * 64;
-        if (lq < ns3) {                             // dvp = T_s^T dvsel, by every geometry wave into its own strip
+        if (wave == 3 && lq < ns3) {                 // dvp = T_s^T dvsel
             const int sv = lq / 3, b = lq - sv * 3;
             const float dvp = S.TR[sv * 9 + b] * S.dvsel[sv * 3] + S.TR[sv * 9 + 3 + b] * S.dvsel[sv * 3 + 1] +
                               S.TR[sv * 9 + 6 + b] * S.dvsel[sv * 3 + 2];
             strip[lq] = dvp;
-            if (wave == 3) S.dvp[lq] = dvp;          // (for the betas' gradient in the next phase)
+            S.dvp[lq] = dvp;                         // (for the betas' gradient in the next phase)
         }
         if (wave == 3 && lq >= 40 && lq < 45) {      // the projection phase's 16 pair slots -> d/dt, d/ds, loss value (slot order)
             const int q = lq - 40;
@@ -933,41 +933,32 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             constexpr int NSC = NS > 0 ? NS : 1, NV4 = (NSC * 3 + 3) / 4;
             const int r = wave, k = fg_k;
             const bool on = lq < nj;
-            // LDS reads first, the selector vertices in two halves (registers: 2 x 9 b128 + 2 x 11 would not fit)
+            // LDS reads first.  dL/dvsel and the posed vertices (33 floats each, the same for every lane) are read ONCE per
+            // wave, one float per lane, and reach the arithmetic as scalars (v_readlane): 66 broadcast b128 reads per wave
+            // cost ~700 cycles, 66 readlanes ~300.
             const float4 gi0 = *(const float4 *)(S.G + k * 12), gi1 = *(const float4 *)(S.G + k * 12 + 4),
                          gi2 = *(const float4 *)(S.G + k * 12 + 8);
             const float j0 = S.J[k * 3], j1 = S.J[k * 3 + 1], j2 = S.J[k * 3 + 2];
             const float c0 = GT_(0, 0), c1 = GT_(0, 1), c2 = GT_(0, 2);
             const float routed = S.dGt[k * 3 + r];
+            const int lcl = min(lq, NSC * 3 - 1);
+            const float my_dv = S.dvsel[lcl], my_vp = S.vp[lcl];
+            float wv[NSC];
+#pragma unroll
+            for (int sv = 0; sv < NSC; ++sv) wv[sv] = S.sel_w[sv * nj + k];
+            __builtin_amdgcn_sched_barrier(0);
             float da0 = 0.f, da1 = 0.f, da2 = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f;
-            constexpr int HV = (NSC + 1) / 2 + ((((NSC + 1) / 2) * 3) % 4 ? (4 - (((NSC + 1) / 2) * 3) % 4) % 4 : 0) * 0;     // vertices per half
-            constexpr int H4 = (HV * 3 + 3) / 4 + 1;                                  // b128 reads covering a half (start may be unaligned by up to 3)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int sv0 = h * HV, f0 = (sv0 * 3) & ~3;                          // first float of the half, rounded down to a b128
-                float wv[HV], dvr[HV];
-                float4 dq[H4], vq[H4];
-#pragma unroll
-                for (int i = 0; i < HV; ++i) { const int sv = min(sv0 + i, NSC - 1); wv[i] = S.sel_w[sv * nj + k]; dvr[i] = S.dvsel[sv * 3 + r]; }
-#pragma unroll
-                for (int q = 0; q < H4; ++q) {
-                    const int q4 = min(f0 / 4 + q, NV4 - 1);
-                    dq[q] = ((const float4 *)__builtin_assume_aligned(S.dvsel, 16))[q4];
-                    vq[q] = ((const float4 *)__builtin_assume_aligned(S.vp, 16))[q4];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                const float *dva = (const float *)dq, *vpr = (const float *)vq;
-#pragma unroll
-                for (int i = 0; i < HV; ++i) {
-                    const int sv = sv0 + i;
-                    if (sv < NSC) {
-                        const int o = sv * 3 - f0;                                   // (compile-time after unrolling)
-                        da0 += wv[i] * dva[o]; da1 += wv[i] * dva[o + 1]; da2 += wv[i] * dva[o + 2];
-                        const float wd_ = wv[i] * dvr[i];
-                        r0 += wd_ * vpr[o]; r1 += wd_ * vpr[o + 1]; r2 += wd_ * vpr[o + 2];
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int sv = 0; sv < NSC; ++sv) {
+                const float g0s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_dv), sv * 3));
+                const float g1s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_dv), sv * 3 + 1));
+                const float g2s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_dv), sv * 3 + 2));
+                const float v0s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_vp), sv * 3));
+                const float v1s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_vp), sv * 3 + 1));
+                const float v2s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_vp), sv * 3 + 2));
+                da0 += wv[sv] * g0s; da1 += wv[sv] * g1s; da2 += wv[sv] * g2s;
+                const float wd_ = wv[sv] * (r == 0 ? g0s : (r == 1 ? g1s : g2s));
+                r0 += wd_ * v0s; r1 += wd_ * v1s; r2 += wd_ * v2s;
             }
             float dat = r == 0 ? da0 : (r == 1 ? da1 : da2);
             if (ext) {                      // dense vertex losses: sum_v w_vj dv (x) [vp | 1] from bf_mesh_bwd_kernel (all rows of dAt)
@@ -1016,12 +1007,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
         }
         BF_WAVE_FENCE();
-        // d(pose feature): wave 3 rows 0..63 right away, waves 0-2 rows 64 + 64 w + lane after their subtree work
-        if (wave == 3) dfeat_rows(strip, lq, min(npf, 64), 64);
-        else {
-            dfeat_rows(strip, 64 + wave * 64 + lq, min(npf, 128 + wave * 64), 64);
-            for (int p0 = 256; p0 < npf; p0 += 192) dfeat_rows(strip, p0 + wave * 64 + lq, min(npf, p0 + wave * 64 + 64), 64);
-        }
+        // d(pose feature) = sel_pd . dvp: all of it on wave 3 (dvp stays in its registers across the passes), in the shadow of
+        // the row waves
+        if (wave == 3) dfeat_rows(strip, lq, npf, 64);
         BF_SYNC();
         } else {
         {
