@@ -564,7 +564,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             const v2f dx = ax + s2, dy = ay + s2;
             const v2f ix = {__builtin_amdgcn_rcpf(dx.x), __builtin_amdgcn_rcpf(dx.y)};
             const v2f iy = {__builtin_amdgcn_rcpf(dy.x), __builtin_amdgcn_rcpf(dy.y)};
-            lsum += cc * (ax * ix + ay * iy);
+            if (want_loss) lsum += cc * (ax * ix + ay * iy);          // (the value only leaves with the last forward pass)
             const v2f du = kk * rx * ix * ix, dw = kk * ry * iy * iy;
             const v2f q0 = du * ip2, q1 = dw * ip2, q2 = -(du * u + dw * w) * ip2;
             g0 += Pa4.x * q0 + Pb4.x * q1 + Pc4.x * q2;
