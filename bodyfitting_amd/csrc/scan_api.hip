@@ -191,7 +191,7 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
     return bf_ensure_dense_buffers(b);
 }
 
-static int launch_mask_kernels(bf_batch *b, float weight) {
+static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss) {
     MaskIO K = b->mask;
     K.weight = weight;
     const int F = b->F;
@@ -203,7 +203,8 @@ static int launch_mask_kernels(bf_batch *b, float weight) {
                        (const float *)b->mk_uvi.p, (const float *)b->mk_duvb.p, (const int *)b->mk_choice.p,
                        (const float *)b->mk_cgrad.p, b->mk_gpart.p);
     hipLaunchKernelGGL(bf_mask_gsum_kernel, dim3(K.proj_blocks, F), dim3(256), 0, b->stream, K, (const float *)b->mk_gpart.p, b->dvout.p);
-    hipLaunchKernelGGL(bf_mask_loss_kernel, dim3(F), dim3(64), 0, b->stream, K, (const float *)b->mk_part.p, b->mk_loss.p);
+    // (the loss VALUE is a serial sum over the partial blocks: only when somebody reads it - the fit loop needs the gradient)
+    if (want_loss) hipLaunchKernelGGL(bf_mask_loss_kernel, dim3(F), dim3(64), 0, b->stream, K, (const float *)b->mk_part.p, b->mk_loss.p);
     HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -244,7 +245,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     if (rc) return rc;
     if (kp || masks) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
     if (kp) { rc = launch_kp(b, h); if (rc) return rc; }
-    if (masks) { rc = launch_mask_kernels(b, mask_weight); if (rc) return rc; }
+    if (masks) { rc = launch_mask_kernels(b, mask_weight, false); if (rc) return rc; }
     if (scans) {
         hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv * 8 + 255) / 256, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
                            (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr);   // (8 lanes per query)
@@ -387,7 +388,7 @@ int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *d
     rc = launch_state_and_mesh(b, hd);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
-    rc = launch_mask_kernels(b, 1.0f);
+    rc = launch_mask_kernels(b, 1.0f, true);
     if (rc) return rc;
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (loss) HIP_TRY(hipMemcpy(loss, b->mk_loss.p, (size_t)b->F * sizeof(float), hipMemcpyDeviceToHost));
