@@ -66,15 +66,15 @@ bf_mask_project_kernel(MaskIO K, const float *__restrict__ vout, const float *__
         loss_part[((size_t)f * K.n_masks + m) * K.part_stride + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-// grid (ceil(4 Cmax/256), M, F).  For contour point c: choice[F][M][Cmax] = sampled vertex (or -1),
-// cgrad[F][M][Cmax][2] = weight * coeff * (uv - c) / |uv - c|.  FOUR lanes per contour point, each scanning every fourth
-// sampled vertex; the quad is merged with the lexicographic (distance, index) minimum = torch.min's first minimum.
+// grid (ceil(16 Cmax/256), M, F).  For contour point c: choice[F][M][Cmax] = sampled vertex (or -1),
+// cgrad[F][M][Cmax][2] = weight * coeff * (uv - c) / |uv - c|.  SIXTEEN lanes per contour point, each scanning every 16th
+// sampled vertex; the group is merged with the lexicographic (distance, index) minimum = torch.min's first minimum.
 extern "C" __global__ void __launch_bounds__(256)
 bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict__ choice, float *__restrict__ cgrad,
                        float *__restrict__ loss_part) {
     __shared__ float4 tile[256];
     __shared__ float sred[4];
-    const int gid = blockIdx.x * 256 + threadIdx.x, c = gid >> 2, sub = gid & 3, m = blockIdx.y, f = blockIdx.z;
+    const int gid = blockIdx.x * 256 + threadIdx.x, c = gid >> 4, sub = gid & 15, m = blockIdx.y, f = blockIdx.z;
     const int vm = f * K.n_masks + m;
     const int cnt = K.contour_count[vm];
     const float *cp = K.contour_xy + ((size_t)K.contour_start[vm] + (c < cnt ? c : 0)) * 2;
@@ -87,7 +87,7 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
         tile[threadIdx.x] = s < K.ns ? rec[s] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         int lim = min(256, K.ns - base);
-        for (int i = sub; i < lim; i += 4) {
+        for (int i = sub; i < lim; i += 16) {
             float4 r = tile[i];
             float dx = r.x - cx, dy = r.y - cy, d2 = dx * dx + dy * dy;
             if (r.z > 0.5f && d2 < best) { best = d2; bidx = base + i; bu = r.x; bv = r.y; }    // first minimum of this lane's subset
@@ -95,7 +95,7 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
         __syncthreads();
     }
 #pragma unroll
-    for (int x = 1; x < 4; x <<= 1) {
+    for (int x = 1; x < 16; x <<= 1) {
         const float ob = __shfl_xor(best, x), ou = __shfl_xor(bu, x), ov = __shfl_xor(bv, x);
         const int oi = __shfl_xor(bidx, x);
         if (oi >= 0 && (bidx < 0 || ob < best || (ob == best && oi < bidx))) { best = ob; bidx = oi; bu = ou; bv = ov; }
@@ -183,7 +183,7 @@ extern "C" __global__ void bf_mask_loss_kernel(MaskIO K, const float *__restrict
     float tot = 0.f;
     for (int m = 0; m < K.n_masks; ++m) {
         const int vm = f * K.n_masks + m;
-        const int nb = K.proj_blocks + (K.contour_count[vm] * 4 + 255) / 256;          // (4 lanes per contour point)
+        const int nb = K.proj_blocks + (K.contour_count[vm] * 16 + 255) / 256;         // (16 lanes per contour point)
         for (int b = 0; b < nb; ++b) tot += loss_part[(size_t)vm * K.part_stride + b];
     }
     loss[f] = tot;

@@ -197,7 +197,7 @@ static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss) {
     const int F = b->F;
     hipLaunchKernelGGL(bf_mask_project_kernel, dim3(K.proj_blocks, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->vout.p,
                        (const float *)b->proj.p, b->mk_uvi.p, b->mk_duvb.p, b->mk_part.p);
-    hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax * 4 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
+    hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax * 16 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
                        (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p);
     hipLaunchKernelGGL(bf_mask_gather_kernel, dim3((K.ns * 4 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->proj.p,
                        (const float *)b->mk_uvi.p, (const float *)b->mk_duvb.p, (const int *)b->mk_choice.p,
@@ -355,7 +355,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     auto refresh = [](auto &buf) { if (buf.p) { (void)hipFree((void *)buf.p); buf.p = nullptr; } };
     refresh(b->mk_view); refresh(b->mk_cstart); refresh(b->mk_ccount); refresh(b->mk_masks); refresh(b->mk_cxy);
     refresh(b->mk_uvi); refresh(b->mk_duvb); refresh(b->mk_gpart); refresh(b->mk_cgrad); refresh(b->mk_part); refresh(b->mk_loss); refresh(b->mk_choice);
-    const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256, stride = pblocks + (cmax * 4 + 255) / 256;      // (4 lanes per contour point)
+    const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256, stride = pblocks + (cmax * 16 + 255) / 256;     // (16 lanes per contour point)
     HIP_TRY(b->mk_view.upload(std::vector<int>(view_index, view_index + n_masks)));
     HIP_TRY(b->mk_cstart.upload(start));
     HIP_TRY(b->mk_ccount.upload(count));
