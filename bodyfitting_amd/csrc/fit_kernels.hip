@@ -274,6 +274,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int ci = c_on ? tid / 3 : 0, cr = c_on ? tid - ci * 3 : 0;
     const int cp = ci > 0 ? T.parents[ci] : 0;
     const unsigned long long cmask = c_on ? T.desc[ci] : 0ull;       // strict descendants of ci
+    (void)cr; (void)cp; (void)cmask; (void)w_feat;                    // (only the two-phase variants read them)
     // projection role (geometry waves 0-3 only, so the GMM waves keep their registers for the precision rows): a lane
     // owns a PAIR of loss joints (2 ps, 2 ps + 1) on one view lane, ps = 4 * wave + lane / 16, view lane = lane % 16.
     // Both joints see the same projection matrix, so every multiply-add of the projection, the GMoF and the
@@ -833,7 +834,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         } else {
         {
         // ================= phase B: pose blend of the selector vertices, partial sums over row slices
-        const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
         pose_blend(std::integral_constant<int, 1>());
         }
                 BF_SYNC();
@@ -930,7 +930,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             S.scal[3 + q] = acc;
         }
         if (wave < 3) {
-            constexpr int NSC = NS > 0 ? NS : 1, NV4 = (NSC * 3 + 3) / 4;
+            constexpr int NSC = NS > 0 ? NS : 1;
             const int r = wave, k = fg_k;
             const bool on = lq < nj;
             // LDS reads first.  dL/dvsel and the posed vertices (33 floats each, the same for every lane) are read ONCE per

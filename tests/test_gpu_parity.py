@@ -264,3 +264,38 @@ def test_pipelined_fetch_alternates_result_arenas(dev_model, smpl_model):
         np.testing.assert_array_equal(x, y)
     a.close()
     b.close()
+
+
+def test_more_than_48_views_streams_the_rest(dev_model, smpl_model, gmm_bufs):
+    """Views past the 48 staged in LDS are streamed from global memory by the projection phase: 60 views against the
+    fp64 oracle (gradient) and the fp64 analytic loop (a short fit)."""
+    from oracle import analytic as A
+    prob = S.make_problem(smpl_model, frame=2, n_views=60)
+    b = _batch(dev_model, [prob])
+    terms, grads = b.loss_grad()
+    P0 = {k: np.asarray(v, np.float64) for k, v in N.split_params(b.get_params()[0]).items()}
+    _, _, g64, _, _ = O.loss_and_grad(smpl_model, gmm_bufs, prob, P0)
+    got = N.split_params(grads[0])
+    for k in PARAMS:
+        np.testing.assert_allclose(got[k], g64[k], atol=2e-5 * np.abs(g64[k]).max(), err_msg=k)
+    b.fit(10)
+    want, _, _ = A.fit(smpl_model, gmm_bufs, prob, 10, dtype=np.float64)
+    got = N.split_params(b.get_params()[0])
+    for k, v in want.items():
+        np.testing.assert_allclose(got[k], v, atol=1e-4, err_msg=k)
+    b.close()
+
+
+def test_untimed_submission_gives_the_same_fit(dev_model, smpl_model):
+    """BF_FIT_NOTIME (what bench.py steps with): no event records, same commands, same bits"""
+    from bodyfitting_amd import _lib
+    prob = S.make_problem(smpl_model, frame=1, n_views=48)
+    a, b = _batch(dev_model, [prob]), _batch(dev_model, [prob])
+    a.fit(20, flags=_lib.FIT_FETCH | _lib.FIT_RESET)
+    for _ in range(2):
+        b.fit(20, flags=_lib.FIT_FETCH | _lib.FIT_RESET | _lib.FIT_NOTIME)
+    np.testing.assert_array_equal(b.get_params(), a.get_params())
+    for x, y in zip(b.get_result(), a.get_result()):
+        np.testing.assert_array_equal(x, y)
+    a.close()
+    b.close()
