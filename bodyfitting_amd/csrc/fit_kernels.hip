@@ -59,7 +59,8 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
                                                   int nl, int np, int nviews) {
     size_t o = 0;
     auto take = [&](int n) { float *p = base ? base + o : nullptr; o += pad4(n); return p; };
-    s.pa = take(np);       s.pb = take(np);
+    // arrays whose size follows from (nj, nb, npf, ns) first: in the compile-time-sized instance their offsets are
+    // immediates of the ds instructions; the ones sized by np (a launch value) and by the number of views come last
     s.R = take(nj * 9);    s.rc = take(nj * 4);   s.J = take(nj * 3);
     s.G = take(nj * 12);   s.At = take(nj * 3);
     s.vs = take(ns * 3);   s.vp = take(ns * 3);   s.TR = take(ns * 9);   s.vsel = take(ns * 3);
@@ -68,7 +69,6 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.dGR = take(nj * 12); s.dGt = take(nj * 3);  s.tt = take(nj * 3);   s.N = take(nj * 12);
     s.dAt = take(nj * 3);  s.dJ = take(nj * 3);
     s.dR = take(nj * 9);   s.drel = take(nj * 3); s.dfeat = take(npf);   s.gth = take(nj * 3);
-    s.g = take(np);
     s.gd = take(BF_GMM_M * BF_GMM_LD); s.gy = take(BF_GMM_M * BF_GMM_LD);
     s.gq = take(BF_GMM_M);             s.gtail = take(256);   s.scal = take(8);
     s.feat = take(npf);                s.vpp = take(BF_FIT_THREADS + ns * 3);
@@ -77,7 +77,6 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.rel = take(nj * 3);
     s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * pad4(nb + 1)); s.sel_pd = take(npf * ns * 3);
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
-    s.proj = take(nviews * 12);
     s.nzw = take(ns * BF_SEL_NNZ);  s.nzj = (int *)take(ns * BF_SEL_NNZ);
     s.kp = take(BF_VSUB * BF_KP_ROUNDS * 16 * 8);      // 8-float keypoint record per (view, loss-joint pair), zero padded
     s.stamp = take(64);
@@ -85,7 +84,9 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
                                               // the merged pose blend's (slice, output) lane pattern
     s.theta = take(nj * 3);  s.pmean = take(nj * 3);  s.hcomp = take(2 * 6 * 45);
     s.thk = (int *)take(nj); s.tho = (int *)take(nj); s.par = (int *)take(nj);
+    s.pa = take(np);       s.pb = take(np);   s.g = take(np);
     s.pk = (int *)take(np); s.pa_ = (int *)take(np); s.pb_ = (int *)take(np); s.am = take(np); s.av = take(np);
+    s.proj = take(nviews * 12);
     (void)nl;
     return o * sizeof(float);
 }
