@@ -113,6 +113,7 @@ struct bf_batch {
     DevBuf<ScanDev> scan_dev;
     DevBuf<float> cscale, pc_weight, pc_partial, pc_loss, dvout, vposed, cpts, ext_part, ext;
     DevBuf<int> cface, lmk_vid;
+    bool cface_valid = false;       // cface holds the faces of an earlier closest-point call for these scans (warm start)
     DevBuf<float> jraw, lmk_w;
     // silhouette loss (use_mask, smplify.py:138-144,197-199)
     bool has_masks = false;

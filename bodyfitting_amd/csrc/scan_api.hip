@@ -3,7 +3,7 @@
 #include "bf_host.h"
 
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
-extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int, int *, float *, float *);
+extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int, int *, float *, float *, int);
 extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
 extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
 extern "C" __global__ void bf_mesh_bwd_kernel(MeshTab, const float *, const float *, const float *, const float *, const float *, float *);
@@ -131,8 +131,8 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
     HIP_TRY(d_p.upload(std::vector<float>(points, points + (size_t)n * 3)));
     HIP_TRY(d_c.alloc((size_t)n * 3)); HIP_TRY(d_b.alloc((size_t)n * 3)); HIP_TRY(d_f.alloc(n));
     HIP_TRY(d_s.upload(std::vector<ScanDev>(1, s->dev)));
-    hipLaunchKernelGGL(bf_nearest_kernel, dim3((n * 8 + 255) / 256, 1), dim3(256), 0, 0, (const ScanDev *)d_s.p, (const float *)d_p.p, n,
-                       d_f.p, d_c.p, d_b.p);
+    hipLaunchKernelGGL(bf_nearest_kernel, dim3((n + 3) / 4, 1), dim3(256), 0, 0, (const ScanDev *)d_s.p, (const float *)d_p.p, n,
+                       d_f.p, d_c.p, d_b.p, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (face_ids) HIP_TRY(hipMemcpy(face_ids, d_f.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
@@ -147,7 +147,7 @@ int bf_ensure_dense_buffers(bf_batch *b) {
     const int EXT = m->npf + m->nj * 12 + m->nb + 4, EXT_FULL = EXT + m->nj * 3 + 4;
     if (!b->dvout.p) {
         bool ok = b->dvout.alloc(F * nv3) == hipSuccess && b->vposed.alloc(F * nv3) == hipSuccess &&
-                  b->cpts.alloc(F * nv3) == hipSuccess && b->cface.alloc(F * m->nv) == hipSuccess &&
+                  b->cpts.alloc(F * nv3) == hipSuccess && b->cface.alloc(F * m->nv) == hipSuccess && !(b->cface_valid = false) &&
                   b->ext_part.alloc(F * m->mesh.n_tiles * EXT) == hipSuccess && b->ext.alloc(F * EXT_FULL) == hipSuccess &&
                   b->jraw.alloc(F * std::max(m->n_all, 1) * 3) == hipSuccess && b->lmk_vid.alloc(F * std::max(m->n_lmk, 1) * 3) == hipSuccess &&
                   b->lmk_w.alloc(F * std::max(m->n_lmk, 1) * 3) == hipSuccess &&
@@ -184,6 +184,7 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
         cs[f] = scans[f]->dev.height / 1.7f;
     }
     b->scans.assign(scans, scans + b->F);
+    b->cface_valid = false;
     if (b->scan_dev.p) { (void)hipFree(b->scan_dev.p); b->scan_dev.p = nullptr; }
     if (b->cscale.p) { (void)hipFree(b->cscale.p); b->cscale.p = nullptr; }
     HIP_TRY(b->scan_dev.upload(dev));
@@ -247,8 +248,9 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     if (kp) { rc = launch_kp(b, h); if (rc) return rc; }
     if (masks) { rc = launch_mask_kernels(b, mask_weight, false); if (rc) return rc; }
     if (scans) {
-        hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv * 8 + 255) / 256, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
-                           (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr);   // (8 lanes per query)
+        hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv + 3) / 4, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
+                           (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);   // (one wave per query; warm start from the previous call's faces)
+        b->cface_valid = true;
         hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, b->pc_partial.p);
         hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
@@ -446,8 +448,9 @@ int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
                            (const float *)b->disp_base.p, (const float *)b->disp.p, b->disp_fn.p);
         hipLaunchKernelGGL(bf_disp_vertex_kernel, gv, dim3(256), 0, b->stream, (const int *)m->adj_start.p, (const int *)m->adj.p, nf, nv,
                            (const float *)b->disp_base.p, (const float *)b->disp.p, (const float *)b->disp_fn.p, b->disp_P.p, b->disp_vn.p);
-        hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv * 8 + 255) / 256, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p, (const float *)b->disp_P.p, nv,
-                           b->cface.p, b->cpts.p, (float *)nullptr);
+        hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv + 3) / 4, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p, (const float *)b->disp_P.p, nv,
+                           b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);
+        b->cface_valid = true;
         hipLaunchKernelGGL(bf_pc_partial_kernel, gv, dim3(256), 0, b->stream, (const float *)b->disp_P.p, (const float *)b->cpts.p, nv,
                            b->pc_partial.p);
         hipLaunchKernelGGL(bf_disp_vgrad_kernel, gv, dim3(256), 0, b->stream, (const int *)m->faces_d.p, (const int *)m->adj_start.p,

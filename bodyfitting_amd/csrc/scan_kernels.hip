@@ -72,82 +72,127 @@ __device__ inline float blk_wave_sum(float v) {
 
 }  // namespace
 
-// grid (ceil(8 n / 256), F).  points[F][n][3] -> face[F][n], pts[F][n][3], bary[F][n][3] (bary may be null).
-// EIGHT lanes per query: they walk the same cells of the expanding L-infinity shells and split every cell's triangle
-// list (entry i goes to lane i % 8; one 48-byte packed record per entry, so the eight lanes of a query read 384
-// contiguous bytes); after each shell the eight partial results are merged with the lexicographic (distance, face id)
-// minimum, which is what the reference's "first strictly closer triangle in face order" amounts to, so the result does
-// not depend on how the work was split.  The box lower bound prunes with the lane's own best so far (a weaker bound than
-// the query's, never a wrong one); the reference's stop test `best < (L step)^2` uses the merged value.
+// wave-wide minimum of a float / an int on the DPP path (all lanes get it)
+__device__ inline float nn_wave_min_f(float v) {
+    auto step = [&](int t) { v = fminf(v, __int_as_float(t)); };
+    step(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xf, 0xf, false));
+    step(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xf, 0xf, false));
+    step(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x124, 0xf, 0xf, false));
+    step(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x128, 0xf, 0xf, false));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fminf(fminf(a, b), fminf(c, d));
+}
+__device__ inline int nn_wave_min_i(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+// grid (ceil(n / 4), F), 256 threads: ONE WAVE PER QUERY.  points[F][n][3] -> face[F][n], pts[F][n][3], bary[F][n][3]
+// (bary may be null).  The wave walks the expanding L-infinity shells of the uniform grid together: the cells of a shell
+// are spread over the lanes (box lower bound, list bounds: one memory latency for the whole shell instead of one per
+// cell), then the lanes walk every surviving cell's triangle list side by side (entry i to lane i: one packed 48-byte
+// record each, consecutive lanes read consecutive records).  The result is the lexicographic (distance, face id) minimum,
+// which is what the reference's "first strictly closer triangle in face order" amounts to, so it does not depend on how
+// the work is split; a cell is only skipped when its box lies strictly beyond the best distance so far, the reference's
+// stop test `best < (L step)^2` is applied to the merged value after every shell.  `warm`: face[] still holds this
+// query's answer of the previous call - a real candidate, hence a valid upper bound that prunes almost everything.
 extern "C" __global__ void __launch_bounds__(256)
 bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
-                  int *__restrict__ face, float *__restrict__ pts, float *__restrict__ bary) {
-    const int gid = blockIdx.x * 256 + threadIdx.x, id = gid >> 3, sub = gid & 7, f = blockIdx.y;
-    const bool live = id < n;
+                  int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
+    const int lane = threadIdx.x & 63, id = blockIdx.x * 4 + (threadIdx.x >> 6), f = blockIdx.y;
+    if (id >= n) return;                                   // (wave-uniform)
     const ScanDev S = scans[f];
-    const float *q = points + ((size_t)f * n + (live ? id : 0)) * 3;
+    const float *q = points + ((size_t)f * n + id) * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     int cx = (int)floorf((qx - S.ox) / S.step), cy = (int)floorf((qy - S.oy) / S.step), cz = (int)floorf((qz - S.oz) / S.step);
     cx = min(max(cx, 0), S.nx - 1); cy = min(max(cy, 0), S.ny - 1); cz = min(max(cz, 0), S.nz - 1);
-    const int maxL = live ? max(max(max(cx, S.nx - 1 - cx), max(cy, S.ny - 1 - cy)), max(cz, S.nz - 1 - cz)) : -1;
-    float best = -1.f, bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
-    int bface = -1;
+    const int maxL = max(max(max(cx, S.nx - 1 - cx), max(cy, S.ny - 1 - cy)), max(cz, S.nz - 1 - cz));
+    // this lane's best so far (distance, face, coefficients); merged after every shell
+    float best = 3.0e38f, bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
+    int bface = 0x7fffffff;
+    auto test = [&](const float *p, int t) {
+        float co[3];
+        const float dist = closest_rule(p, p + 3, p + 6, co);
+        if (dist < best || (dist == best && t < bface)) { best = dist; bface = t; bc0 = co[0]; bc1 = co[1]; bc2 = co[2]; }
+    };
+    if (warm) {
+        const int t = face[(size_t)f * n + id];
+        if (t >= 0 && t < S.nf && lane == 0) {
+            const int *tv = S.faces + (size_t)t * 3;
+            float p[9];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *v = S.verts + (size_t)tv[c] * 3;
+                p[c * 3] = v[0] - qx; p[c * 3 + 1] = v[1] - qy; p[c * 3 + 2] = v[2] - qz;
+            }
+            test(p, t);
+        }
+    }
+    float gbest = nn_wave_min_f(best);                      // (wave-uniform running best distance, for the pruning)
     for (int L = 0; L <= maxL; ++L) {
-        for (int dz = -L; dz <= L; ++dz) {
-            int z = cz + dz;
-            if (z < 0 || z >= S.nz) continue;
-            for (int dy = -L; dy <= L; ++dy) {
-                int y = cy + dy;
-                if (y < 0 || y >= S.ny) continue;
-                const bool face_zy = (dz == -L || dz == L || dy == -L || dy == L);
-                for (int dx = -L; dx <= L; dx += (face_zy ? 1 : max(2 * L, 1))) {      // shell cells only
-                    int x = cx + dx;
-                    if (x < 0 || x >= S.nx) continue;
-                    // lower bound: squared distance from the query to this cell's box
-                    float lo, e, d2 = 0.f;
-                    lo = S.ox + S.step * x; e = qx < lo ? lo - qx : (qx > lo + S.step ? qx - lo - S.step : 0.f); d2 += e * e;
-                    lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); d2 += e * e;
-                    lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); d2 += e * e;
-                    if (best >= 0.f && best < d2) continue;
+        const int side = 2 * L + 1, ncube = side * side * side;
+        for (int base = 0; base < ncube; base += 64) {
+            // one cube cell per lane; only the shell (max |d| == L), in bounds, not beyond the best so far
+            const int c = base + lane;
+            const int dz = c / (side * side) - L, rem = c % (side * side), dy = rem / side - L, dx = rem % side - L;
+            const int x = cx + dx, y = cy + dy, z = cz + dz;
+            bool use = c < ncube && max(max(abs(dx), abs(dy)), abs(dz)) == L && x >= 0 && x < S.nx && y >= 0 && y < S.ny && z >= 0 && z < S.nz;
+            int st = 0, cnt = 0;
+            if (use) {
+                float lo, e, d2 = 0.f;
+                lo = S.ox + S.step * x; e = qx < lo ? lo - qx : (qx > lo + S.step ? qx - lo - S.step : 0.f); d2 += e * e;
+                lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); d2 += e * e;
+                lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); d2 += e * e;
+                use = !(gbest < d2);
+                if (use) {
                     const int cell = (x * S.ny + y) * S.nz + z;
-                    const int i1 = S.cell_start[cell + 1];
-                    for (int i = S.cell_start[cell] + sub; i < i1; i += 8) {
-                        const float4 r0 = S.cell_pack[(size_t)i * 3], r1 = S.cell_pack[(size_t)i * 3 + 1], r2 = S.cell_pack[(size_t)i * 3 + 2];
-                        const int t = __float_as_int(r2.y);
-                        float p[9] = {r0.x - qx, r0.y - qy, r0.z - qz, r0.w - qx, r1.x - qy, r1.y - qz, r1.z - qx, r1.w - qy, r2.x - qz};
-                        float co[3];
-                        float dist = closest_rule(p, p + 3, p + 6, co);
-                        if (best < 0.f || dist < best || (dist == best && t < bface)) {
-                            best = dist; bface = t; bc0 = co[0]; bc1 = co[1]; bc2 = co[2];
-                        }
-                    }
+                    st = S.cell_start[cell];
+                    cnt = S.cell_start[cell + 1] - st;
                 }
             }
+            unsigned long long todo = __ballot(use && cnt > 0);
+            while (todo) {                                  // (wave-uniform) the surviving cells, their lists lane-parallel
+                const int src = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const int s0 = __builtin_amdgcn_readlane(st, src), n0 = __builtin_amdgcn_readlane(cnt, src);
+                for (int i = lane; i < n0; i += 64) {
+                    const size_t r = (size_t)(s0 + i) * 3;
+                    const float4 r0 = S.cell_pack[r], r1 = S.cell_pack[r + 1], r2 = S.cell_pack[r + 2];
+                    float p[9] = {r0.x - qx, r0.y - qy, r0.z - qz, r0.w - qx, r1.x - qy, r1.y - qz, r1.z - qx, r1.w - qy, r2.x - qz};
+                    test(p, __float_as_int(r2.y));
+                }
+            }
+            gbest = fminf(gbest, nn_wave_min_f(best));
         }
-        // merge the eight lanes of the query: lexicographic minimum of (distance, face id); "none yet" loses
-#pragma unroll
-        for (int m = 1; m < 8; m <<= 1) {
-            const float ob = __shfl_xor(best, m), o0 = __shfl_xor(bc0, m), o1 = __shfl_xor(bc1, m), o2 = __shfl_xor(bc2, m);
-            const int of = __shfl_xor(bface, m);
-            const bool take = of >= 0 && (bface < 0 || ob < best || (ob == best && of < bface));
-            if (take) { best = ob; bface = of; bc0 = o0; bc1 = o1; bc2 = o2; }
-        }
-        if (best >= 0.f && best < (float)L * (float)L * S.step * S.step) break;     // mesh_grid_kernel.cu:349
+        if (gbest < (float)L * (float)L * S.step * S.step) break;     // mesh_grid_kernel.cu:349 (gbest = 3e38 while nothing was found)
     }
-    if (!live || sub != 0) return;
+    // merge: the lexicographic (distance, face id) minimum over the lanes, then its owner's coefficients
+    const float dmin = nn_wave_min_f(best);
+    const int fmin_ = nn_wave_min_i(best == dmin ? bface : 0x7fffffff);
+    const unsigned long long own = __ballot(best == dmin && bface == fmin_);
+    const int wl = __ffsll((long long)own) - 1;
+    const bool found = fmin_ != 0x7fffffff && wl >= 0;
+    const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc0), wl < 0 ? 0 : wl));
+    const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc1), wl < 0 ? 0 : wl));
+    const float w2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc2), wl < 0 ? 0 : wl));
+    if (lane != 0) return;
     const size_t o = (size_t)f * n + id;
-    face[o] = bface;
+    face[o] = found ? fmin_ : -1;
     float r0 = qx, r1 = qy, r2 = qz;
-    if (bface >= 0) {
-        const int *tv = S.faces + (size_t)bface * 3;
+    if (found) {
+        const int *tv = S.faces + (size_t)fmin_ * 3;
         const float *v0 = S.verts + (size_t)tv[0] * 3, *v1 = S.verts + (size_t)tv[1] * 3, *v2 = S.verts + (size_t)tv[2] * 3;
         // proj = q + sum c_i (v_i - q), as the reference forms it (:318-329)
-        r0 = qx + bc0 * (v0[0] - qx) + bc1 * (v1[0] - qx) + bc2 * (v2[0] - qx);
-        r1 = qy + bc0 * (v0[1] - qy) + bc1 * (v1[1] - qy) + bc2 * (v2[1] - qy);
-        r2 = qz + bc0 * (v0[2] - qz) + bc1 * (v1[2] - qz) + bc2 * (v2[2] - qz);
+        r0 = qx + w0 * (v0[0] - qx) + w1 * (v1[0] - qx) + w2 * (v2[0] - qx);
+        r1 = qy + w0 * (v0[1] - qy) + w1 * (v1[1] - qy) + w2 * (v2[1] - qy);
+        r2 = qz + w0 * (v0[2] - qz) + w1 * (v1[2] - qz) + w2 * (v2[2] - qz);
     }
     pts[o * 3] = r0; pts[o * 3 + 1] = r1; pts[o * 3 + 2] = r2;
-    if (bary) { bary[o * 3] = bc0; bary[o * 3 + 1] = bc1; bary[o * 3 + 2] = bc2; }
+    if (bary) { bary[o * 3] = found ? w0 : 0.f; bary[o * 3 + 1] = found ? w1 : 0.f; bary[o * 3 + 2] = found ? w2 : 0.f; }
 }
 
 // grid (nblk, F): partial[f][blk] = sum over this block's vertices of |P - C|^2
