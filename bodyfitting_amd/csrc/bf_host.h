@@ -129,7 +129,7 @@ struct bf_batch {
 };
 
 struct bf_scan {
-    int device = 0, nv = 0, nf = 0;
+    int device = 0, nv = 0, nf = 0, n_entries = 0;
     ScanDev dev{};
     DevBuf<float> verts, face_norms;
     DevBuf<int> faces, cell_start, cell_tris;

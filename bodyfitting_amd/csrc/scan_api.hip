@@ -10,6 +10,11 @@ extern "C" __global__ void bf_mesh_bwd_kernel(MeshTab, const float *, const floa
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int);
 extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
                                              const float *, float *, float *, float *);
+extern "C" __global__ void bf_grid_count_kernel(ScanDev, int *);
+extern "C" __global__ void bf_grid_scan_kernel(int *, int *, int);
+extern "C" __global__ void bf_grid_fill_kernel(ScanDev, int *, int *);
+extern "C" __global__ void bf_grid_pack_kernel(ScanDev, const int *, int *, float4 *, int);
+extern "C" __global__ void bf_face_normal_kernel(const float *, const int *, int, float *);
 extern "C" size_t bf_mesh_bwd_smem_bytes(int);
 extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const float *, float *, float *, float *);
 extern "C" __global__ void bf_mask_contour_kernel(MaskIO, const float *, int *, float *, float *);
@@ -52,61 +57,45 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
     }
     const size_t ncell = (size_t)num[0] * num[1] * num[2];
     if (ncell > (size_t)1 << 28) return fail(BF_ERR_UNSUPPORTED, "bf_scan_create: grid too large");
-    auto cell_range = [&](int f, int lo[3], int hi[3]) {
-        for (int d = 0; d < 3; ++d) {
-            float a = verts[faces[f * 3] * 3 + d], b = a;
-            for (int j = 1; j < 3; ++j) { float x = verts[faces[f * 3 + j] * 3 + d]; a = std::min(a, x); b = std::max(b, x); }
-            float x = (a - org[d]) / step;
-            lo[d] = x < 0 ? 0 : (x >= num[d] ? num[d] - 1 : (int)floorf(x));
-            x = (b - org[d]) / step;
-            hi[d] = (x < 0 ? 0 : (x >= num[d] ? num[d] - 1 : (int)floorf(x))) + 1;
-        }
-    };
-    std::vector<int> start(ncell + 1, 0);
-    for (int f = 0; f < n_faces; ++f) {
-        int lo[3], hi[3];
-        cell_range(f, lo, hi);
-        for (int x = lo[0]; x < hi[0]; ++x) for (int y = lo[1]; y < hi[1]; ++y) for (int z = lo[2]; z < hi[2]; ++z)
-            ++start[((size_t)x * num[1] + y) * num[2] + z + 1];
-    }
-    for (size_t c = 0; c < ncell; ++c) start[c + 1] += start[c];
-    std::vector<int> tris(start[ncell]), fill(start.begin(), start.end() - 1);
-    for (int f = 0; f < n_faces; ++f) {
-        int lo[3], hi[3];
-        cell_range(f, lo, hi);
-        for (int x = lo[0]; x < hi[0]; ++x) for (int y = lo[1]; y < hi[1]; ++y) for (int z = lo[2]; z < hi[2]; ++z)
-            tris[fill[((size_t)x * num[1] + y) * num[2] + z]++] = f;
-    }
-    // un-normalised face normals, float64 cross product rounded once (smplify.py:148-149)
-    std::vector<float> fn((size_t)n_faces * 3);
-    for (int f = 0; f < n_faces; ++f) {
-        const float *a = verts + faces[f * 3] * 3, *b = verts + faces[f * 3 + 1] * 3, *c = verts + faces[f * 3 + 2] * 3;
-        double u[3] = {(double)b[0] - a[0], (double)b[1] - a[1], (double)b[2] - a[2]};
-        double w[3] = {(double)c[0] - a[0], (double)c[1] - a[1], (double)c[2] - a[2]};
-        fn[f * 3] = (float)(u[1] * w[2] - u[2] * w[1]);
-        fn[f * 3 + 1] = (float)(u[2] * w[0] - u[0] * w[2]);
-        fn[f * 3 + 2] = (float)(u[0] * w[1] - u[1] * w[0]);
-    }
-    std::vector<float> pack((size_t)tris.size() * 12, 0.f);
-    for (size_t i = 0; i < tris.size(); ++i) {
-        const int t = tris[i];
-        float *r = pack.data() + i * 12;
-        for (int c = 0; c < 3; ++c) for (int k = 0; k < 3; ++k) r[c * 3 + k] = verts[(size_t)faces[t * 3 + c] * 3 + k];
-        std::memcpy(r + 9, &t, sizeof(int));
-    }
-    if (pack.empty()) pack.assign(12, 0.f);
+    // everything below runs on the device: only the vertices and faces cross PCIe (the packed cell records would be ~50x that)
     auto *s = new bf_scan();
     s->device = device; s->nv = n_verts; s->nf = n_faces;
-    bool ok = s->cell_pack.upload(pack) == hipSuccess && s->verts.upload(std::vector<float>(verts, verts + (size_t)n_verts * 3)) == hipSuccess &&
+    DevBuf<int> cursor, tris_raw;
+    bool ok = s->verts.upload(std::vector<float>(verts, verts + (size_t)n_verts * 3)) == hipSuccess &&
               s->faces.upload(std::vector<int>(faces, faces + (size_t)n_faces * 3)) == hipSuccess &&
-              s->cell_start.upload(start) == hipSuccess && s->cell_tris.upload(tris) == hipSuccess &&
-              s->face_norms.upload(fn) == hipSuccess;
+              s->cell_start.alloc(ncell + 1) == hipSuccess && cursor.alloc(ncell + 1) == hipSuccess &&
+              s->face_norms.alloc((size_t)n_faces * 3) == hipSuccess;
     if (!ok) { delete s; return fail(BF_ERR_HIP, "bf_scan_create: device allocation failed"); }
     ScanDev &d = s->dev;
     d.nv = n_verts; d.nf = n_faces; d.nx = num[0]; d.ny = num[1]; d.nz = num[2];
     d.ox = org[0]; d.oy = org[1]; d.oz = org[2]; d.step = step; d.height = ext[1];
-    d.verts = s->verts.p; d.faces = s->faces.p; d.cell_start = s->cell_start.p; d.cell_tris = s->cell_tris.p;
-    d.cell_pack = (const float4 *)s->cell_pack.p;
+    d.verts = s->verts.p; d.faces = s->faces.p; d.cell_start = s->cell_start.p;
+    d.cell_tris = nullptr; d.cell_pack = nullptr;
+    const dim3 fgrid((n_faces + 255) / 256);
+    int total = 0;
+    hipError_t e = hipMemsetAsync(s->cell_start.p, 0, (ncell + 1) * sizeof(int), 0);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(bf_grid_count_kernel, fgrid, dim3(256), 0, 0, d, s->cell_start.p);
+        hipLaunchKernelGGL(bf_grid_scan_kernel, dim3(1), dim3(1024), 0, 0, s->cell_start.p, cursor.p, (int)(ncell + 1));
+        hipLaunchKernelGGL(bf_face_normal_kernel, fgrid, dim3(256), 0, 0, (const float *)s->verts.p, (const int *)s->faces.p, n_faces,
+                           s->face_norms.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&total, s->cell_start.p + ncell, sizeof(int), hipMemcpyDeviceToHost);   // (syncs)
+    if (e == hipSuccess && total > 0) {
+        ok = tris_raw.alloc(total) == hipSuccess && s->cell_tris.alloc(total) == hipSuccess &&
+             s->cell_pack.alloc((size_t)total * 12) == hipSuccess;
+        if (!ok) { delete s; return fail(BF_ERR_HIP, "bf_scan_create: device allocation failed (cell lists)"); }
+        d.cell_tris = s->cell_tris.p;
+        d.cell_pack = (const float4 *)s->cell_pack.p;
+        hipLaunchKernelGGL(bf_grid_fill_kernel, fgrid, dim3(256), 0, 0, d, cursor.p, tris_raw.p);
+        hipLaunchKernelGGL(bf_grid_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, 0, d, (const int *)tris_raw.p, s->cell_tris.p,
+                           (float4 *)s->cell_pack.p, total);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();       // tris_raw / cursor are released on return
+    }
+    if (e != hipSuccess) { delete s; return fail(BF_ERR_HIP, std::string("bf_scan_create: grid build: ") + hipGetErrorString(e)); }
+    s->n_entries = total;
     *out = s;
     return BF_OK;
 }
@@ -118,6 +107,21 @@ int bf_scan_grid_info(const bf_scan *s, int32_t dims[3], float origin_step[4]) {
     if (!s || !dims || !origin_step) return fail(BF_ERR_INVALID, "bf_scan_grid_info: null argument");
     dims[0] = s->dev.nx; dims[1] = s->dev.ny; dims[2] = s->dev.nz;
     origin_step[0] = s->dev.ox; origin_step[1] = s->dev.oy; origin_step[2] = s->dev.oz; origin_step[3] = s->dev.step;
+    return BF_OK;
+}
+
+// The two tensors insert_grid_surface hands back to its caller (mesh_grid.cpp:129-136, mesh_grid_kernel.cu:209-215):
+// tri_num = inclusive cumulative triangle count per cell, tri_idx = face id + 1 per list entry (here: ascending per cell).
+int bf_scan_grid_lists(const bf_scan *s, int32_t *tri_num, int32_t *tri_idx, int32_t *n_entries) {
+    if (!s) return fail(BF_ERR_INVALID, "bf_scan_grid_lists: null scan");
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t ncell = (size_t)s->dev.nx * s->dev.ny * s->dev.nz;
+    if (n_entries) *n_entries = s->n_entries;
+    if (tri_num) HIP_TRY(hipMemcpy(tri_num, s->cell_start.p + 1, ncell * sizeof(int), hipMemcpyDeviceToHost));
+    if (tri_idx && s->n_entries > 0) {
+        HIP_TRY(hipMemcpy(tri_idx, s->cell_tris.p, (size_t)s->n_entries * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < s->n_entries; ++i) tri_idx[i] += 1;
+    }
     return BF_OK;
 }
 

@@ -146,6 +146,16 @@ class Scan:
         _lib.check(self._lib.bf_scan_grid_info(self._h, _lib.iptr(dims), _lib.fptr(os_)), "bf_scan_grid_info")
         return dims, os_[:3], float(os_[3])
 
+    def grid_lists(self):
+        """-> (tri_num int32[cells] inclusive cumsum, tri_idx int32[entries] face id + 1): insert_grid_surface's outputs"""
+        dims, _, _ = self.grid_info()
+        n = np.zeros(1, np.int32)
+        _lib.check(self._lib.bf_scan_grid_lists(self._h, None, None, _lib.iptr(n)), "bf_scan_grid_lists")
+        tri_num = np.empty(int(np.prod(dims)), np.int32)
+        tri_idx = np.empty(max(int(n[0]), 1), np.int32)
+        _lib.check(self._lib.bf_scan_grid_lists(self._h, _lib.iptr(tri_num), _lib.iptr(tri_idx), None), "bf_scan_grid_lists")
+        return tri_num, tri_idx[:int(n[0])]
+
     def nearest_points(self, points):
         """-> (nearest points [n,3], face ids [n], barycentrics [n,3]) like MeshGridSearcher.nearest_points"""
         p = _f32(points, (-1, 3))

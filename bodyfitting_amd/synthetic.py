@@ -512,6 +512,24 @@ def make_scan_problem(model, frame=0, n_views=8, imsize=512, scan_scale=1.0, noi
     return prob, scan, np.asarray(model["faces"], dtype=np.int32)
 
 
+def subdivide_mesh(verts, faces, times=1):
+    """Midpoint (1 -> 4) subdivision: the scan meshes of BASELINE config 5 have ~100k triangles,
+    SMPL-X's 20,908 faces once subdivided give 83,632.  Deterministic: new vertices in sorted-edge order."""
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    for _ in range(times):
+        e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+        e.sort(1)
+        key = e[:, 0] * len(v) + e[:, 1]
+        uniq, inv = np.unique(key, return_inverse=True)
+        mid = 0.5 * (v[uniq // len(v)] + v[uniq % len(v)])
+        m = inv.reshape(3, -1).T + len(v)                     # midpoints of edges (01, 12, 20) per face
+        f = np.concatenate([np.stack([f[:, 0], m[:, 0], m[:, 2]], 1), np.stack([f[:, 1], m[:, 1], m[:, 0]], 1),
+                            np.stack([f[:, 2], m[:, 2], m[:, 1]], 1), np.stack([m[:, 0], m[:, 1], m[:, 2]], 1)], 0)
+        v = np.concatenate([v, mid], 0)
+    return v, f.astype(np.int32)
+
+
 FACE_MAPPING = list(range(17, 17 + 51)) + list(range(0, 17))       # reference smplify/loss.py:20
 
 
@@ -601,3 +619,42 @@ def make_problem_smplx(model, frame=0, n_views=48, imsize=512, constant_scale=0.
     return {**extra, "c2ws": c2ws, "Ks": Ks, "keypoints": keypoints, "imsize": imsize, "use_frames": list(range(n_views)),
             "init_betas": np.zeros((1, 10), np.float32), "init_pose": np.concatenate([init_pose, np.zeros(6)]).astype(np.float32)[None],
             "gt": gt, "constant_scale": constant_scale}
+
+
+def make_scan_problem_smplx(model, frame=0, n_views=8, imsize=512, noise=0.003, pose_noise=0.08, subdivide=1):
+    """A SMPL-X frame with a scan mesh (BASELINE config 5: use_mesh + SMPL+D): make_problem_smplx's ground truth in
+    a world whose constant scale is scan_height / 1.7 (smplify.py:150-156), the scan = the posed ground-truth
+    body, `subdivide` times midpoint-subdivided (once: 83,632 triangles), with smooth + white noise, rounded to
+    the 4 decimals of the OBJ it would be read from.  Returns (problem dict, scan_verts, scan_faces)."""
+    assert model["model_type"] == "smplx"
+    rng = np.random.default_rng(7000 + frame)
+    gt = {"betas": rng.normal(0.0, 0.5, size=10), "body_pose": rng.normal(0.0, 0.15, size=63),
+          "global_orient": np.array([0.0, rng.uniform(-np.pi, np.pi), 0.0]),
+          "leye": rng.normal(0.0, 0.05, size=3), "reye": rng.normal(0.0, 0.05, size=3),
+          "lhand": rng.normal(0.0, 0.5, size=6), "rhand": rng.normal(0.0, 0.5, size=6),
+          "transl": rng.normal(0.0, 0.05, size=3)}
+    fp = smplx_full_pose(model, gt["global_orient"], gt["body_pose"], gt["leye"], gt["reye"], gt["lhand"], gt["rhand"])
+    verts, joints, _ = smplx_joints64(model, np.concatenate([gt["betas"], np.zeros(10)]), fp)
+    gt["scale"] = 1.7 / (verts[:, 1].max() - verts[:, 1].min())
+    sv, sf = subdivide_mesh((verts + gt["transl"]) * gt["scale"], model["faces"], subdivide)
+    bump = 0.5 * np.sin(sv * 9.0 + rng.uniform(0, 6.28, size=3)) + rng.normal(0.0, 0.3, size=sv.shape)
+    sv = np.round(sv + noise * bump, 4).astype(np.float32)
+    cscale = float((sv[:, 1].max() - sv[:, 1].min()) / 1.7)
+    world = (joints + gt["transl"]) * gt["scale"]
+    c2ws, Ks = ring_cameras(n_views, radius=3.2, imsize=imsize, focal=float(imsize), centre=world[:25].mean(0).tolist())
+    inv_face = np.argsort(FACE_MAPPING)
+    keypoints = []
+    for v in range(n_views):
+        w2c = np.linalg.inv(c2ws[v].astype(np.float64))
+        cam = world @ w2c[:3, :3].T + w2c[:3, 3]
+        uvw = cam @ Ks[v].astype(np.float64).T
+        uv = uvw[:, :2] / uvw[:, 2:3] + rng.normal(0.0, 0.7, size=(135, 2))
+        kp = np.concatenate([uv, rng.uniform(0.5, 1.0, size=(135, 1))], 1).astype(np.float32)
+        face70 = np.zeros((70, 3), np.float32)
+        face70[:68] = kp[67:][inv_face]
+        keypoints.append({"pose": kp[:25], "hand_left": kp[25:46], "hand_right": kp[46:67], "face": face70})
+    init_pose = np.concatenate([gt["global_orient"], gt["body_pose"]]) + rng.normal(0.0, pose_noise, size=66)
+    prob = {"c2ws": c2ws, "Ks": Ks, "keypoints": keypoints, "imsize": imsize, "use_frames": list(range(n_views)),
+            "init_betas": np.zeros((1, 10), np.float32),
+            "init_pose": np.concatenate([init_pose, np.zeros(6)]).astype(np.float32)[None], "gt": gt, "constant_scale": cscale}
+    return prob, sv, sf

@@ -184,6 +184,11 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
 void bf_scan_destroy(bf_scan *s);
 float bf_scan_height(const bf_scan *s);                 /* (max - min)[1], smplify.py:150-151 */
 int bf_scan_grid_info(const bf_scan *s, int32_t dims[3], float origin_step[4]);
+/* The tensors insert_grid_surface leaves with its caller (mesh_grid.cpp:129-136, mesh_grid_kernel.cu:178-236; built on
+ * the device by bf_scan_create): tri_num[nx*ny*nz] = inclusive cumulative triangle count per cell (cell = (x*ny+y)*nz+z),
+ * tri_idx[*n_entries] = face id + 1 per list entry, ascending inside a cell (the reference's order inside a cell is
+ * whatever its atomicCAS race produced).  Any pointer may be NULL; call once with tri_idx NULL to learn n_entries. */
+int bf_scan_grid_lists(const bf_scan *s, int32_t *tri_num, int32_t *tri_idx, int32_t *n_entries);
 /* MeshGridSearcher.nearest_points / search_nearest_point (mesh_grid.cpp:54-72): points[n,3] ->
  * face_ids[n] int32, nearest[n,3], bary[n,3] (any output may be NULL) */
 int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, float *nearest, float *bary);

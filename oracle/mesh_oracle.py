@@ -2,6 +2,7 @@
 
 Restates, in numpy / torch:
   * MeshGridSearcher.set_mesh grid parameters      reference utils/mesh_grid_searcher.py:56-79
+  * insert_grid_surface (cell lists of the grid)    thirdparty/mesh_grid/mesh_grid_kernel.cu:110-157,178-236
   * the per-triangle closest-point rule             thirdparty/mesh_grid/mesh_grid_kernel.cu:12-109
     (KKT solve for the barycentric coefficients; if one is negative, fall back to the edge opposite
     the MOST NEGATIVE coefficient and clamp to its end points - which is not the exact closest point
@@ -35,6 +36,37 @@ def grid_params(verts):
     l = torch.max(torch.floor(l / step), torch.zeros_like(l)) + 1
     origin = c - step * l / 2
     return float(step), l.numpy().astype(np.int64), origin.numpy().astype(np.float32)
+
+
+def insert_grid_surface(verts, faces, step, origin, num):
+    """insert_grid_surface_kernel + the cumulative sum between its two passes (mesh_grid_kernel.cu:110-157,209):
+    every triangle enters each cell its axis-aligned bounding box touches (float32 `(x - min) / step`, clamped to
+    the grid, kernel.cu:127-141).  -> (tri_num int32[cells] inclusive cumsum, tri_idx int32[entries] = face id + 1,
+    ascending inside a cell - the reference's own order inside a cell is decided by an atomicCAS race)."""
+    v = np.asarray(verts, np.float32)
+    f = np.asarray(faces, np.int64).reshape(-1, 3)
+    num = np.asarray(num, np.int64)
+    org = np.asarray(origin, np.float32)
+    step = np.float32(step)
+    tri = v[f]                                                        # [F,3 corners,3]
+    lo_f = (tri.min(1) - org) / step
+    hi_f = (tri.max(1) - org) / step
+
+    def cell(x):
+        c = np.floor(x).astype(np.int64)
+        c = np.where(x < 0, 0, c)
+        return np.where(x >= num[None].astype(np.float32), num[None] - 1, c)
+    lo, hi = cell(lo_f), cell(hi_f) + 1
+    cells, ids = [], []
+    for t in range(len(f)):
+        xs, ys, zs = (np.arange(lo[t, d], hi[t, d]) for d in range(3))
+        c = ((xs[:, None, None] * num[1] + ys[None, :, None]) * num[2] + zs[None, None, :]).reshape(-1)
+        cells.append(c)
+        ids.append(np.full(len(c), t + 1, np.int64))
+    cells, ids = np.concatenate(cells), np.concatenate(ids)
+    order = np.lexsort((ids, cells))
+    tri_num = np.cumsum(np.bincount(cells, minlength=int(num.prod()))).astype(np.int32)
+    return tri_num, ids[order].astype(np.int32)
 
 
 def closest_rule(p0, p1, p2):

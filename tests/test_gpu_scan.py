@@ -33,6 +33,28 @@ def test_grid_matches_set_mesh(small):
     scan.close()
 
 
+@pytest.mark.parametrize("big", [False, True])
+def test_device_grid_lists_match_insert_grid_surface(small, big):
+    """the grid is built by HIP kernels (count, prefix sum, fill, sort + pack): its cell lists are exactly those of
+    insert_grid_surface (mesh_grid_kernel.cu:110-157), and the same bytes on every build"""
+    model, _ = small
+    _, sv, sf = S.make_scan_problem(model, 2)
+    if big:                                                   # ~21k triangles, boundary cells on every side
+        sv, sf = S.subdivide_mesh(sv, sf, 2)
+        sv = sv.astype(np.float32)
+    scan = N.Scan(sv, sf)
+    dims, origin, step = scan.grid_info()
+    tri_num, tri_idx = scan.grid_lists()
+    tn_o, ti_o = MO.insert_grid_surface(sv, sf, step, origin, dims)
+    np.testing.assert_array_equal(tri_num, tn_o)
+    np.testing.assert_array_equal(tri_idx, ti_o)
+    again = N.Scan(sv, sf)
+    tn2, ti2 = again.grid_lists()
+    np.testing.assert_array_equal(tri_idx, ti2)
+    np.testing.assert_array_equal(tri_num, tn2)
+    again.close(); scan.close()
+
+
 @pytest.mark.parametrize("spread", [0.01, 0.2, 3.0])
 def test_nearest_points_match_bruteforce_rule(small, spread):
     """near, far and way-outside-the-grid queries against the oracle's brute-force search"""

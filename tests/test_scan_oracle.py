@@ -44,6 +44,35 @@ def test_known_answers_for_the_rule():
     assert d2[0] == pytest.approx(1.0)
 
 
+def test_insert_grid_surface_known_answer_and_bbox_property(small_model):
+    """mesh_grid_kernel.cu:110-157: one triangle in a 4x4x4 unit grid, then every cell list of a body scan"""
+    v = np.array([[0.5, 0.5, 0.5], [2.5, 0.5, 0.5], [0.5, 1.5, 0.5], [9, 9, 9]], np.float32)
+    tri_num, tri_idx = MO.insert_grid_surface(v, [[0, 1, 2], [3, 3, 3]], 1.0, [0, 0, 0], [4, 4, 4])
+    count = np.diff(np.concatenate([[0], tri_num])).reshape(4, 4, 4)
+    want = np.zeros((4, 4, 4), int)
+    want[0:3, 0:2, 0] = 1                       # bounding box of triangle 0: x cells 0..2, y cells 0..1, z cell 0
+    want[3, 3, 3] += 1                          # the far triangle is clamped into the last cell (kernel.cu:138-140)
+    np.testing.assert_array_equal(count, want)
+    assert tri_num[-1] == len(tri_idx) == 7 and set(tri_idx.tolist()) == {1, 2}
+    _, sv, sf = S.make_scan_problem(small_model, 0)
+    step, num, org = MO.grid_params(sv)
+    tri_num, tri_idx = MO.insert_grid_surface(sv, sf, step, org, num)
+    assert tri_num[-1] == len(tri_idx) and tri_idx.min() >= 1 and tri_idx.max() <= len(sf)
+    start = np.concatenate([[0], tri_num])
+    rng = np.random.default_rng(0)
+    for c in rng.integers(0, len(tri_num), 40):
+        xyz = np.array(np.unravel_index(c, num))
+        lo, hi = org + step * xyz, org + step * (xyz + 1)
+        tri = sv[sf]
+        inside = np.all((tri.max(1) >= lo - 1e-6) & (tri.min(1) < hi + 1e-6), axis=1)    # bbox touches the cell
+        got = np.zeros(len(sf), bool)
+        got[tri_idx[start[c]:start[c + 1]] - 1] = True
+        assert not np.any(got & ~inside)                 # nothing listed that cannot touch the cell
+        strict = np.all((tri.max(1) > lo + 1e-5) & (tri.min(1) < hi - 1e-5), axis=1)
+        assert np.all(got[strict])                       # everything that clearly overlaps is listed
+        assert np.all(np.diff(tri_idx[start[c]:start[c + 1]]) > 0)
+
+
 def test_oracle_scan_fit_matches_reference_golden(small_model, gmm_bufs):
     torch.set_num_threads(1)
     g = load_golden("scan_nv690_30it.npz")
