@@ -128,12 +128,14 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
     float *s_beta = s_vp + COLS;                // [nb] + t[3] + sc[2]
     const int tid = threadIdx.x, nt = COLS * BF_MESH_RG;
     const int col = tid % COLS, rg = tid / COLS;
-    const int frame = blockIdx.y;
+    int tile_, frame_;
+    bf_xcd_tile_frame(tile_, frame_);
+    const int frame = frame_, tile = tile_;
     StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
     const int ncols = 3 * nv;
-    const int gcol = blockIdx.x * COLS + col;
+    const int gcol = tile * COLS + col;
     const bool ok = gcol < ncols;
-    const int vl = col / 3, k = col - vl * 3, v = blockIdx.x * BF_MESH_TILE + vl;
+    const int vl = col / 3, k = col - vl * 3, v = tile * BF_MESH_TILE + vl;
 
     // ---- request everything ------------------------------------------------------------------
     const int rows = (npf + BF_MESH_RG - 1) / BF_MESH_RG;
@@ -169,7 +171,7 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
         for (int l = 0; l < 12; ++l) if (l < nb) sdreg[l] = sd[l];
         vt = M.v_template[gcol];
     } else if (rg == 2 && col < ne3 && xpart) {
-        const int e = col / 3, v0 = blockIdx.x * BF_MESH_TILE;
+        const int e = col / 3, v0 = tile * BF_MESH_TILE;
         const float *row = M.j_extra + (size_t)e * nv + v0;
 #pragma unroll
         for (int i = 0; i < BF_MESH_TILE; ++i) if (v0 + i < nv) jx[i] = row[i];
@@ -244,7 +246,7 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
             float a3 = 0.f;
 #pragma unroll
             for (int i = 0; i < BF_MESH_TILE; ++i) a3 += jx[i] * s_red[i * 3 + k];
-            xpart[((size_t)frame * gridDim.x + blockIdx.x) * ne3 + col] = a3;
+            xpart[((size_t)frame * gridDim.x + tile) * ne3 + col] = a3;
         }
     }
 }

@@ -11,56 +11,59 @@
 //                         matrices, betas, transl, scale), per 32-vertex tile then summed in tile order
 //
 // The grid itself (cell lists in CSR form, cells from MeshGridSearcher.set_mesh,
-// utils/mesh_grid_searcher.py:56-79) is built once per scan on the host - it is setup, not the loop -
-// with triangles in face order inside every cell, so the search is deterministic (the reference fills
-// its lists with atomicCAS in arbitrary order).
+// utils/mesh_grid_searcher.py:56-79) is built once per scan by grid_kernels.hip, with triangles in face
+// order inside every cell (the reference fills its lists with atomicCAS in arbitrary order).
 #include "bf_internal.h"
 
 namespace {
 
-// closest point of triangle (p0,p1,p2), given relative to the query, by the reference's rule
-__device__ inline float closest_rule(const float *p0, const float *p1, const float *p2, float *coeff) {
-    float e1[3] = {p1[0] - p0[0], p1[1] - p0[1], p1[2] - p0[2]};
-    float e2[3] = {p2[0] - p0[0], p2[1] - p0[1], p2[2] - p0[2]};
-    float a11 = e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2];
-    float a12 = e1[0] * e2[0] + e1[1] * e2[1] + e1[2] * e2[2];
-    float a22 = e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2];
-    float b1 = -(p0[0] * e1[0] + p0[1] * e1[1] + p0[2] * e1[2]);
-    float b2 = -(p0[0] * e2[0] + p0[1] * e2[1] + p0[2] * e2[2]);
-    float det = a11 * a22 - a12 * a12;
-    bool ok = det > 1e-12f * a11 * a22 && det > 0.f;
-    float c[3] = {1.f / 3, 1.f / 3, 1.f / 3};
+// closest point of triangle (p0,p1,p2), given relative to the query, by the reference's rule (mesh_grid_kernel.cu:12-109).
+// Everything stays in registers: the edge the fallback picks is chosen with selects, not by indexing a local array.
+__device__ __forceinline__ float closest_rule(const float *p0, const float *p1, const float *p2, float *coeff) {
+    const float e1x = p1[0] - p0[0], e1y = p1[1] - p0[1], e1z = p1[2] - p0[2];
+    const float e2x = p2[0] - p0[0], e2y = p2[1] - p0[1], e2z = p2[2] - p0[2];
+    const float a11 = e1x * e1x + e1y * e1y + e1z * e1z;
+    const float a12 = e1x * e2x + e1y * e2y + e1z * e2z;
+    const float a22 = e2x * e2x + e2y * e2y + e2z * e2z;
+    const float b1 = -(p0[0] * e1x + p0[1] * e1y + p0[2] * e1z);
+    const float b2 = -(p0[0] * e2x + p0[1] * e2y + p0[2] * e2z);
+    const float det = a11 * a22 - a12 * a12;
+    const bool ok = det > 1e-12f * a11 * a22 && det > 0.f;
     int i;
     if (ok) {
-        float u = (b1 * a22 - b2 * a12) / det, v = (a11 * b2 - a12 * b1) / det;
-        c[0] = 1.f - u - v; c[1] = u; c[2] = v;
-        i = c[0] > c[1] ? 1 : 0;
-        i = c[i] > c[2] ? 2 : i;                       // most negative coefficient (mesh_grid_kernel.cu:82-83)
-        if (c[i] >= 0.f) {
-            coeff[0] = c[0]; coeff[1] = c[1]; coeff[2] = c[2];
-            float x0 = c[0] * p0[0] + c[1] * p1[0] + c[2] * p2[0];
-            float x1 = c[0] * p0[1] + c[1] * p1[1] + c[2] * p2[1];
-            float x2 = c[0] * p0[2] + c[1] * p1[2] + c[2] * p2[2];
+        const float u = (b1 * a22 - b2 * a12) / det, v = (a11 * b2 - a12 * b1) / det;
+        const float c0 = 1.f - u - v;
+        i = c0 > u ? 1 : 0;
+        const float ci = i ? u : c0;
+        i = ci > v ? 2 : i;                            // most negative coefficient (mesh_grid_kernel.cu:82-83)
+        if ((i == 2 ? v : ci) >= 0.f) {
+            coeff[0] = c0; coeff[1] = u; coeff[2] = v;
+            const float x0 = c0 * p0[0] + u * p1[0] + v * p2[0];
+            const float x1 = c0 * p0[1] + u * p1[1] + v * p2[1];
+            const float x2 = c0 * p0[2] + u * p1[2] + v * p2[2];
             return x0 * x0 + x1 * x1 + x2 * x2;
         }
     } else {
         // degenerate triangle: the vertex opposite its longest edge (mesh_grid_kernel.cu:40-45)
-        float l0 = (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) + (p1[2] - p2[2]) * (p1[2] - p2[2]);
-        float l1 = a22, l2 = a11;
+        const float l0 = (p1[0] - p2[0]) * (p1[0] - p2[0]) + (p1[1] - p2[1]) * (p1[1] - p2[1]) + (p1[2] - p2[2]) * (p1[2] - p2[2]);
+        const float l1 = a22, l2 = a11;
         i = l0 < l1 ? 1 : 0;
         i = (i == 0 ? l0 : l1) < l2 ? 2 : i;
     }
-    const float *P[3] = {p0, p1, p2};
-    int j = (i + 1) % 3, k = 3 - i - j;
-    const float *pj = P[j], *pk = P[k];
-    float d[3] = {pk[0] - pj[0], pk[1] - pj[1], pk[2] - pj[2]};
-    float dd = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-    float t = dd > 0.f ? -(pj[0] * d[0] + pj[1] * d[1] + pj[2] * d[2]) / dd : 0.5f;
+    // edge (j, k) opposite corner i: i=0 -> (1,2), i=1 -> (2,0), i=2 -> (0,1)
+    const bool i0 = i == 0, i1 = i == 1;
+    const float pjx = i0 ? p1[0] : (i1 ? p2[0] : p0[0]), pjy = i0 ? p1[1] : (i1 ? p2[1] : p0[1]), pjz = i0 ? p1[2] : (i1 ? p2[2] : p0[2]);
+    const float pkx = i0 ? p2[0] : (i1 ? p0[0] : p1[0]), pky = i0 ? p2[1] : (i1 ? p0[1] : p1[1]), pkz = i0 ? p2[2] : (i1 ? p0[2] : p1[2]);
+    const float dx = pkx - pjx, dy = pky - pjy, dz = pkz - pjz;
+    const float dd = dx * dx + dy * dy + dz * dz;
+    const float t = dd > 0.f ? -(pjx * dx + pjy * dy + pjz * dz) / dd : 0.5f;
     float cj = 1.f - t, ck = t;
     if (cj < 0.f) { cj = 0.f; ck = 1.f; }                 // same test order as the reference (:89-98)
     else if (ck < 0.f) { cj = 1.f; ck = 0.f; }
-    coeff[i] = 0.f; coeff[j] = cj; coeff[k] = ck;
-    float x0 = cj * pj[0] + ck * pk[0], x1 = cj * pj[1] + ck * pk[1], x2 = cj * pj[2] + ck * pk[2];
+    coeff[0] = i0 ? 0.f : (i1 ? ck : cj);
+    coeff[1] = i0 ? cj : (i1 ? 0.f : ck);
+    coeff[2] = i0 ? ck : (i1 ? cj : 0.f);
+    const float x0 = cj * pjx + ck * pkx, x1 = cj * pjy + ck * pky, x2 = cj * pjz + ck * pkz;
     return x0 * x0 + x1 * x1 + x2 * x2;
 }
 
@@ -94,19 +97,24 @@ __device__ inline int nn_wave_min_i(int v) {
 // grid (ceil(n / 4), F), 256 threads: ONE WAVE PER QUERY.  points[F][n][3] -> face[F][n], pts[F][n][3], bary[F][n][3]
 // (bary may be null).  The wave walks the expanding L-infinity shells of the uniform grid together: the cells of a shell
 // are spread over the lanes (box lower bound, list bounds: one memory latency for the whole shell instead of one per
-// cell), then the lanes walk every surviving cell's triangle list side by side (entry i to lane i: one packed 48-byte
-// record each, consecutive lanes read consecutive records).  The result is the lexicographic (distance, face id) minimum,
-// which is what the reference's "first strictly closer triangle in face order" amounts to, so it does not depend on how
-// the work is split; a cell is only skipped when its box lies strictly beyond the best distance so far, the reference's
-// stop test `best < (L step)^2` is applied to the merged value after every shell.  `warm`: face[] still holds this
-// query's answer of the previous call - a real candidate, hence a valid upper bound that prunes almost everything.
+// cell), then the triangle lists of the surviving cells are laid end to end over the lanes (one packed 48-byte record per
+// lane).  The result is the lexicographic (distance, face id) minimum, which is what the reference's "first strictly
+// closer triangle in face order" amounts to, so it does not depend on how the work is split; a cell is only skipped
+// when its box lies strictly beyond the best distance so far, and the reference's stop test `best < (L step)^2` is
+// applied to the merged value after every shell.
+// Shells 0 and 1 are one step over the 27-cell cube (the reference can never stop after shell 0: `best < 0`): the list
+// bounds of all 27 cells are requested at once, the HOME cell's list is walked first, and only then are the 26
+// neighbours pruned - with the distance the home cell gave.  `warm`: face[] still holds this query's answer of the
+// previous call - a real candidate; it rides on the last lane of the home-cell pass (its vertices arrive while the
+// cell bounds do), so the warm start costs no pass of its own.
 extern "C" __global__ void __launch_bounds__(256)
 bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                   int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
     const int lane = threadIdx.x & 63, id = blockIdx.x * 4 + (threadIdx.x >> 6), f = blockIdx.y;
     if (id >= n) return;                                   // (wave-uniform)
     const ScanDev S = scans[f];
-    const float *q = points + ((size_t)f * n + id) * 3;
+    const size_t o = (size_t)f * n + id;
+    const float *q = points + o * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     int cx = (int)floorf((qx - S.ox) / S.step), cy = (int)floorf((qy - S.oy) / S.step), cz = (int)floorf((qz - S.oz) / S.step);
     cx = min(max(cx, 0), S.nx - 1); cy = min(max(cy, 0), S.ny - 1); cz = min(max(cz, 0), S.nz - 1);
@@ -114,26 +122,99 @@ bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ p
     // this lane's best so far (distance, face, coefficients); merged after every shell
     float best = 3.0e38f, bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
     int bface = 0x7fffffff;
+    float gbest = 3.0e38f;                                  // (wave-uniform) best distance so far, for the pruning
     auto test = [&](const float *p, int t) {
         float co[3];
         const float dist = closest_rule(p, p + 3, p + 6, co);
         if (dist < best || (dist == best && t < bface)) { best = dist; bface = t; bc0 = co[0]; bc1 = co[1]; bc2 = co[2]; }
     };
-    if (warm) {
-        const int t = face[(size_t)f * n + id];
-        if (t >= 0 && t < S.nf && lane == 0) {
-            const int *tv = S.faces + (size_t)t * 3;
-            float p[9];
+    auto test_record = [&](int rec) {
+        const size_t r = (size_t)rec * 3;
+        const float4 r0 = S.cell_pack[r], r1 = S.cell_pack[r + 1], r2 = S.cell_pack[r + 2];
+        const float p[9] = {r0.x - qx, r0.y - qy, r0.z - qz, r0.w - qx, r1.x - qy, r1.y - qz, r1.z - qx, r1.w - qy, r2.x - qz};
+        test(p, __float_as_int(r2.y));
+    };
+    // the lists of the cells in `cells` (lane masks; st / cnt in those lanes), end to end over the lanes
+    auto walk = [&](unsigned long long cells, int st, int cnt) {
+        if (!cells) return;
+        if (__popcll(cells) > 6) {                          // many cells (cold start): one cell at a time
+            for (unsigned long long m = cells; m; m &= m - 1) {
+                const int src = __ffsll((long long)m) - 1;
+                const int s0 = __builtin_amdgcn_readlane(st, src), n0 = __builtin_amdgcn_readlane(cnt, src);
+                for (int i = lane; i < n0; i += 64) test_record(s0 + i);
+            }
+        } else {
+            int total = 0;
+            for (unsigned long long m = cells; m; m &= m - 1) total += __builtin_amdgcn_readlane(cnt, __ffsll((long long)m) - 1);
+            for (int e0 = 0; e0 < total; e0 += 64) {
+                const int e = e0 + lane;
+                int rec = -1, off = 0;
+                for (unsigned long long m = cells; m; m &= m - 1) {      // which cell's list entry e falls into
+                    const int src = __ffsll((long long)m) - 1;
+                    const int s0 = __builtin_amdgcn_readlane(st, src), n0 = __builtin_amdgcn_readlane(cnt, src);
+                    rec = (e >= off && e < off + n0) ? s0 + (e - off) : rec;
+                    off += n0;
+                }
+                if (rec >= 0) test_record(rec);
+            }
+        }
+        gbest = fminf(gbest, nn_wave_min_f(best));
+    };
+    {   // ---- shells 0 and 1: the 27-cell cube, lane c = (dz+1)*9 + (dy+1)*3 + (dx+1); the home cell is lane 13
+        const int dz = lane / 9 - 1, rem = lane % 9, dy = rem / 3 - 1, dx = rem % 3 - 1;
+        const int x = cx + dx, y = cy + dy, z = cz + dz;
+        const bool cell_ok = lane < 27 && x >= 0 && x < S.nx && y >= 0 && y < S.ny && z >= 0 && z < S.nz;
+        int st = 0, cnt = 0;
+        float d2 = 0.f;
+        if (cell_ok) {
+            const int cell = (x * S.ny + y) * S.nz + z;
+            st = S.cell_start[cell];
+            cnt = S.cell_start[cell + 1] - st;
+            float lo, e;
+            lo = S.ox + S.step * x; e = qx < lo ? lo - qx : (qx > lo + S.step ? qx - lo - S.step : 0.f); d2 += e * e;
+            lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); d2 += e * e;
+            lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); d2 += e * e;
+        }
+        // the previous answer, on lane 63 (never a cell lane)
+        const int wt = warm ? face[o] : -1;
+        const bool wok = wt >= 0 && wt < S.nf;
+        float wp[9];
+        if (wok && lane == 63) {
+            const int *tv = S.faces + (size_t)wt * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float *v = S.verts + (size_t)tv[c] * 3;
-                p[c * 3] = v[0] - qx; p[c * 3 + 1] = v[1] - qy; p[c * 3 + 2] = v[2] - qz;
+                wp[c * 3] = v[0] - qx; wp[c * 3 + 1] = v[1] - qy; wp[c * 3 + 2] = v[2] - qz;
             }
-            test(p, t);
         }
+        const int s0 = __builtin_amdgcn_readlane(st, 13), n0 = __builtin_amdgcn_readlane(cnt, 13);
+        {   // home cell: entries on lanes 0..62 (63 while no warm triangle), the warm triangle on lane 63
+            const int width = wok ? 63 : 64;
+            for (int e0 = 0; e0 < n0 || e0 == 0; e0 += width) {
+                const int e = e0 + lane;
+                float p[9];
+                int t = -1;
+                if (wok && lane == 63) {
+                    if (e0 == 0) {
+                        t = wt;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) p[k] = wp[k];
+                    }
+                } else if (e < n0) {
+                    const size_t r = (size_t)(s0 + e) * 3;
+                    const float4 r0 = S.cell_pack[r], r1 = S.cell_pack[r + 1], r2 = S.cell_pack[r + 2];
+                    p[0] = r0.x - qx; p[1] = r0.y - qy; p[2] = r0.z - qz; p[3] = r0.w - qx; p[4] = r1.x - qy; p[5] = r1.y - qz;
+                    p[6] = r1.z - qx; p[7] = r1.w - qy; p[8] = r2.x - qz;
+                    t = __float_as_int(r2.y);
+                }
+                if (t >= 0) test(p, t);
+            }
+            gbest = fminf(gbest, nn_wave_min_f(best));
+        }
+        walk(__ballot(cell_ok && lane != 13 && cnt > 0 && !(gbest < d2)), st, cnt);
     }
-    float gbest = nn_wave_min_f(best);                      // (wave-uniform running best distance, for the pruning)
-    for (int L = 0; L <= maxL; ++L) {
+    if (!(gbest < S.step * S.step))                          // mesh_grid_kernel.cu:349 after shell 1 (gbest = 3e38 while nothing was found)
+    for (int L = 2; L <= maxL; ++L) {
         const int side = 2 * L + 1, ncube = side * side * side;
         for (int base = 0; base < ncube; base += 64) {
             // one cube cell per lane; only the shell (max |d| == L), in bounds, not beyond the best so far
@@ -154,24 +235,12 @@ bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ p
                     cnt = S.cell_start[cell + 1] - st;
                 }
             }
-            unsigned long long todo = __ballot(use && cnt > 0);
-            while (todo) {                                  // (wave-uniform) the surviving cells, their lists lane-parallel
-                const int src = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const int s0 = __builtin_amdgcn_readlane(st, src), n0 = __builtin_amdgcn_readlane(cnt, src);
-                for (int i = lane; i < n0; i += 64) {
-                    const size_t r = (size_t)(s0 + i) * 3;
-                    const float4 r0 = S.cell_pack[r], r1 = S.cell_pack[r + 1], r2 = S.cell_pack[r + 2];
-                    float p[9] = {r0.x - qx, r0.y - qy, r0.z - qz, r0.w - qx, r1.x - qy, r1.y - qz, r1.z - qx, r1.w - qy, r2.x - qz};
-                    test(p, __float_as_int(r2.y));
-                }
-            }
-            gbest = fminf(gbest, nn_wave_min_f(best));
+            walk(__ballot(use && cnt > 0), st, cnt);
         }
-        if (gbest < (float)L * (float)L * S.step * S.step) break;     // mesh_grid_kernel.cu:349 (gbest = 3e38 while nothing was found)
+        if (gbest < (float)L * (float)L * S.step * S.step) break;     // mesh_grid_kernel.cu:349
     }
     // merge: the lexicographic (distance, face id) minimum over the lanes, then its owner's coefficients
-    const float dmin = nn_wave_min_f(best);
+    const float dmin = gbest;
     const int fmin_ = nn_wave_min_i(best == dmin ? bface : 0x7fffffff);
     const unsigned long long own = __ballot(best == dmin && bface == fmin_);
     const int wl = __ffsll((long long)own) - 1;
@@ -180,7 +249,6 @@ bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ p
     const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc1), wl < 0 ? 0 : wl));
     const float w2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc2), wl < 0 ? 0 : wl));
     if (lane != 0) return;
-    const size_t o = (size_t)f * n + id;
     face[o] = found ? fmin_ : -1;
     float r0 = qx, r1 = qy, r2 = qz;
     if (found) {
@@ -251,7 +319,9 @@ bf_mesh_bwd_kernel(MeshTab M, const float *__restrict__ posedirsT, const float *
     float *s_vp = s_dv + COLS;              // [COLS]
     float *s_dvp = s_vp + COLS;             // [COLS]
     float *s_sim = s_dvp + COLS;            // t[3], s, c
-    const int tid = threadIdx.x, frame = blockIdx.y, tile = blockIdx.x, v0 = tile * TV;
+    int tile, frame;
+    bf_xcd_tile_frame(tile, frame);
+    const int tid = threadIdx.x, v0 = tile * TV;
     StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
     const int nvt = min(TV, nv - v0);
     for (int i = tid; i < nj * 12; i += 512) {
