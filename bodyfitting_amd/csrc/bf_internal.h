@@ -122,21 +122,6 @@ __host__ __device__ inline StateView bf_state_view(float *base, int nj, int npf,
     return s;
 }
 
-// (tile, frame) of a workgroup in a grid (n_tiles, F) whose tiles stream model tensors that every frame re-reads.
-// Workgroups are handed to the 8 XCDs round-robin in linear order (x fastest), each XCD with its own L2: the plain
-// (blockIdx.x, blockIdx.y) order puts the F readers of one tile a whole row of tiles apart, so every frame pulls the
-// tile through its XCD's L2 again.  Here the F frames of a tile are consecutive workgroups of ONE XCD: the first one
-// brings the tile in, the others hit it.  (Needs n_tiles % 8 == 0 - true for SMPL's 216 and SMPL-X's 328 tiles -
-// otherwise the plain order is kept.)
-__device__ __forceinline__ void bf_xcd_tile_frame(int &tile, int &frame) {
-    const int nt = (int)gridDim.x, nf = (int)gridDim.y;
-    tile = (int)blockIdx.x; frame = (int)blockIdx.y;
-    if (nf > 1 && (nt & 7) == 0) {
-        const int lin = tile + nt * frame, xcd = lin & 7, slot = lin >> 3;
-        tile = (slot / nf) * 8 + xcd;
-        frame = slot - (slot / nf) * nf;
-    }
-}
 
 
 // One scan mesh with its uniform search grid (device pointers).

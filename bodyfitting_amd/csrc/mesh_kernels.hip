@@ -128,9 +128,7 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
     float *s_beta = s_vp + COLS;                // [nb] + t[3] + sc[2]
     const int tid = threadIdx.x, nt = COLS * BF_MESH_RG;
     const int col = tid % COLS, rg = tid / COLS;
-    int tile_, frame_;
-    bf_xcd_tile_frame(tile_, frame_);
-    const int frame = frame_, tile = tile_;
+    const int frame = blockIdx.y, tile = blockIdx.x;
     StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
     const int ncols = 3 * nv;
     const int gcol = tile * COLS + col;
@@ -250,6 +248,190 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
         }
     }
 }
+
+// Small batches (2..15 frames) and models whose pose feature is longer than the 8 x BF_MESH_PF rows the kernel above
+// keeps in flight (SMPL-X: 486): ONE workgroup streams a tile's posedirs slice once for up to FPW frames.
+// grid (n_tiles, ceil(F / FPW)), block 96 x 8 as above.  The rows of a row group are requested in chunks of BF_MM_CH,
+// every chunk's loads in flight together, and each loaded value feeds one fma per frame (pose features of the frames sit
+// frame-minor in LDS: one b128 read serves four frames).  After the split-K reduce the eight row groups become eight
+// FRAMES: row group f shape-blends, skins and stores frame f, so the epilogue keeps all 768 threads busy.
+// Arithmetic and its order per frame are those of bf_mesh_kernel (rows ascending inside a row group, row groups
+// ascending, template + shape offset first, pose offset added to it), so a frame's result does not depend on the
+// batch it was in.
+#define BF_MM_CH 16
+template <int FPW>
+__global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
+bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, float *__restrict__ vraw, float *__restrict__ vout,
+                     float *__restrict__ xpart, float *__restrict__ vposed) {
+    static_assert(FPW == 1 || FPW == 2 || FPW == 4 || FPW == 8, "frames per workgroup");
+    constexpr int COLS = BF_MESH_TILE * 3;
+    extern __shared__ __align__(16) float sm[];
+    const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
+    const int rows = (npf + BF_MESH_RG - 1) / BF_MESH_RG, npad = rows * BF_MESH_RG;
+    float *s_feat = sm;                                  // [npad][FPW]  (frame-minor; rows beyond npf are zero)
+    float *s_A = s_feat + npad * FPW;                    // [FPW][nj][12]
+    float *s_red = s_A + FPW * nj * 12;                  // [FPW][RG][COLS]
+    float *s_vp = s_red + FPW * BF_MESH_RG * COLS;       // [FPW][COLS]
+    float *s_beta = s_vp + FPW * COLS;                   // [FPW][32]: beta[nb], t[3], sc[2]
+    const int tid = threadIdx.x, nt = COLS * BF_MESH_RG;
+    const int col = tid % COLS, rg = tid / COLS;
+    const int tile = blockIdx.x, fbase = blockIdx.y * FPW, nf = min(FPW, n_frames - fbase);
+    const int ncols = 3 * nv, gcol = tile * COLS + col;
+    const bool ok = gcol < ncols;
+    const int vl = col / 3, k = col - vl * 3, v = tile * BF_MESH_TILE + vl;
+    const size_t sstride = bf_state_stride(nj, npf, nb);
+
+    // ---- first chunk of the stream, then the per-frame state into LDS ----------------------------------------------
+    const int p0 = rg * rows, p1 = min(npf, p0 + rows);
+    const float *pd = M.posedirs + (size_t)p0 * ncols + (ok ? gcol : 0);
+    float pv[BF_MM_CH];
+#pragma unroll
+    for (int i = 0; i < BF_MM_CH; ++i) pv[i] = p0 + i < p1 ? pd[(size_t)i * ncols] : 0.f;
+    for (int i = tid; i < npad * FPW; i += nt) {
+        const int p = i / FPW, f = i - p * FPW;
+        s_feat[i] = (p < npf && f < nf) ? bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).feat[p] : 0.f;
+    }
+    for (int i = tid; i < FPW * nj * 12; i += nt) {
+        const int f = i / (nj * 12), r = i - f * nj * 12, j = r / 12, e = r % 12, a = e / 4, b = e % 4;
+        float x = 0.f;
+        if (f < nf) {
+            StateView st = bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb);
+            x = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
+        }
+        s_A[i] = x;
+    }
+    for (int i = tid; i < FPW * 32; i += nt) {
+        const int f = i >> 5, l = i & 31;
+        s_beta[i] = (f < nf && l < nb + 5) ? bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).beta[l] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- pose blend: the row group's rows, chunk by chunk, one fma per frame and loaded value ------------------------
+    float acc[FPW];
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) acc[f] = 0.f;
+    for (int c0 = 0; c0 < rows; c0 += BF_MM_CH) {
+        float nx[BF_MM_CH];
+        const bool more = c0 + BF_MM_CH < rows;
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < BF_MM_CH; ++i) nx[i] = p0 + c0 + BF_MM_CH + i < p1 ? pd[(size_t)(c0 + BF_MM_CH + i) * ncols] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < BF_MM_CH; ++i) {
+            if (c0 + i < rows) {                             // (s_feat rows up to npad exist and are zero beyond npf)
+                const float *fr = s_feat + (size_t)(p0 + c0 + i) * FPW;
+                if constexpr (FPW >= 4) {
+#pragma unroll
+                    for (int f4 = 0; f4 < FPW; f4 += 4) {
+                        const float4 x = *(const float4 *)(fr + f4);
+                        acc[f4] += x.x * pv[i]; acc[f4 + 1] += x.y * pv[i]; acc[f4 + 2] += x.z * pv[i]; acc[f4 + 3] += x.w * pv[i];
+                    }
+                } else {
+#pragma unroll
+                    for (int f = 0; f < FPW; ++f) acc[f] += fr[f] * pv[i];
+                }
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < BF_MM_CH; ++i) pv[i] = nx[i];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < FPW; ++f) s_red[(f * BF_MESH_RG + rg) * COLS + col] = acc[f];
+    // ---- from here on row group rg works for FRAME rg -----------------------------------------------------------------
+    const int f = rg;
+    const bool mine = f < nf;
+    float a2 = 0.f, vt = 0.f;
+    if (mine && ok) {
+        const float *sd = M.shapedirs + (size_t)gcol * nb;
+        vt = M.v_template[gcol];
+        for (int l = 0; l < nb; ++l) a2 += sd[l] * s_beta[f * 32 + l];
+    }
+    __syncthreads();
+    if (mine) {
+        float off = 0.f;
+#pragma unroll
+        for (int q = 0; q < BF_MESH_RG; ++q) off += s_red[(f * BF_MESH_RG + q) * COLS + col];
+        float vp = ok ? vt + a2 : 0.f;
+        vp += off;
+        s_vp[f * COLS + col] = vp;
+    }
+    __syncthreads();
+    // ---- skinning ---------------------------------------------------------------------------------------------------
+    float r = 0.f;
+    if (mine && ok) {
+        const float *A = s_A + f * nj * 12;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, tt = 0.f;
+        if (M.v_nnz) {
+            const int nnz = M.v_nnz;
+            for (int q = 0; q < nnz; ++q) {
+                const float w = M.v_nzw[(size_t)v * nnz + q];
+                const float4 a = *(const float4 *)(A + M.v_nzj[(size_t)v * nnz + q] * 12 + k * 4);
+                t0 += w * a.x; t1 += w * a.y; t2 += w * a.z; tt += w * a.w;
+            }
+        } else {
+            for (int j = 0; j < nj; ++j) {
+                const float w = M.lbs_weights[(size_t)v * nj + j];
+                const float4 a = *(const float4 *)(A + j * 12 + k * 4);
+                t0 += w * a.x; t1 += w * a.y; t2 += w * a.z; tt += w * a.w;
+            }
+        }
+        const float *vp = s_vp + f * COLS + vl * 3;
+        r = t0 * vp[0] + t1 * vp[1] + t2 * vp[2] + tt;
+        const size_t o = (size_t)(fbase + f) * ncols + gcol;
+        const float *sb = s_beta + f * 32 + nb;
+        if (vraw) vraw[o] = r;
+        if (vout) vout[o] = (r + sb[k]) * sb[3] * sb[4];
+        if (vposed) vposed[o] = vp[k];
+    }
+    if (xpart) {
+        // this tile's share of J_regressor_extra . vertices (models/smpl.py:72), per frame
+        const int ne3 = M.n_extra * 3;
+        __syncthreads();                                     // (s_red is free: every sum above has been taken)
+        if (mine) s_red[f * COLS + col] = r;
+        __syncthreads();
+        if (mine && col < ne3) {
+            const int e = col / 3, v0 = tile * BF_MESH_TILE;
+            const float *row = M.j_extra + (size_t)e * nv + v0;
+            float jx[BF_MESH_TILE];
+#pragma unroll
+            for (int i = 0; i < BF_MESH_TILE; ++i) jx[i] = v0 + i < nv ? row[i] : 0.f;
+            float a3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < BF_MESH_TILE; ++i) a3 += jx[i] * s_red[f * COLS + i * 3 + k];
+            xpart[((size_t)(fbase + f) * gridDim.x + tile) * ne3 + col] = a3;
+        }
+    }
+}
+
+extern "C" int bf_mesh_multi_launch(const MeshTab *M, const float *state, int n, float *vraw, float *vout, float *xpart, float *vposed,
+                                    hipStream_t stream) {
+    constexpr int COLS = BF_MESH_TILE * 3;
+    const int fpw = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
+    const int rows = (M->npf + BF_MESH_RG - 1) / BF_MESH_RG;
+    const size_t smem = sizeof(float) * ((size_t)rows * BF_MESH_RG * fpw + (size_t)fpw * M->nj * 12 + (size_t)fpw * BF_MESH_RG * COLS +
+                                         (size_t)fpw * COLS + (size_t)fpw * 32);
+    const dim3 grid(M->n_tiles, (n + fpw - 1) / fpw), block(COLS * BF_MESH_RG);
+    if (smem > 64 * 1024) {
+        hipError_t e = hipSuccess;
+        if (fpw == 8) e = hipFuncSetAttribute((const void *)bf_mesh_multi_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        else if (fpw == 4) e = hipFuncSetAttribute((const void *)bf_mesh_multi_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    switch (fpw) {
+    case 1: hipLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed); break;
+    case 2: hipLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed); break;
+    case 4: hipLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed); break;
+    default: hipLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed); break;
+    }
+    return (int)hipGetLastError();
+}
+
+// which forward the single-launch path takes: the multi-frame kernel for 2..15 frames, and for one frame when the pose
+// feature has more rows than bf_mesh_kernel keeps in flight
+extern "C" int bf_mesh_use_multi(int npf, int n) { return n >= 2 || npf > BF_MESH_PF * BF_MESH_RG; }
 
 extern "C" size_t bf_mesh_smem_bytes(int nj, int npf, int nb) {
     constexpr int COLS = BF_MESH_TILE * 3;

@@ -6,7 +6,7 @@ extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const flo
 extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int, int *, float *, float *, int);
 extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
 extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
-extern "C" __global__ void bf_mesh_bwd_kernel(MeshTab, const float *, const float *, const float *, const float *, const float *, float *);
+extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const float *, int, const float *, const float *, const float *, float *, hipStream_t);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int);
 extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
                                              const float *, float *, float *, float *);
@@ -15,7 +15,6 @@ extern "C" __global__ void bf_grid_scan_kernel(int *, int *, int);
 extern "C" __global__ void bf_grid_fill_kernel(ScanDev, int *, int *);
 extern "C" __global__ void bf_grid_pack_kernel(ScanDev, const int *, int *, float4 *, int);
 extern "C" __global__ void bf_face_normal_kernel(const float *, const int *, int, float *);
-extern "C" size_t bf_mesh_bwd_smem_bytes(int);
 extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const float *, float *, float *, float *);
 extern "C" __global__ void bf_mask_contour_kernel(MaskIO, const float *, int *, float *, float *);
 extern "C" __global__ void bf_mask_gather_kernel(MaskIO, const float *, const float *, const float *, const int *, const float *, float *);
@@ -262,9 +261,10 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
                            b->dvout.p, b->pc_loss.p, (kp || masks) ? 1 : 0);
     }
     const int EXT = m->npf + m->nj * 12 + m->nb + 4;
-    hipLaunchKernelGGL(bf_mesh_bwd_kernel, dim3(m->mesh.n_tiles, F), dim3(512), bf_mesh_bwd_smem_bytes(m->nj), b->stream, m->mesh,
-                       (const float *)m->posedirsT.p, (const float *)b->state.p, (const float *)b->dvout.p,
-                       (const float *)b->vposed.p, (const float *)b->vraw.p, b->ext_part.p);
+    {
+        const int e = bf_mesh_bwd_multi_launch(&m->mesh, m->posedirsT.p, b->state.p, F, b->dvout.p, b->vposed.p, b->vraw.p, b->ext_part.p, b->stream);
+        if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_bwd_multi_kernel: ") + hipGetErrorString((hipError_t)e));
+    }
     hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 31) / 32, F), dim3(256), 0, b->stream,
                        (const float *)b->ext_part.p, m->mesh.n_tiles, EXT, b->ext.p, EXT + m->nj * 3 + 4);
     HIP_TRY(hipGetLastError());

@@ -300,99 +300,155 @@ bf_pc_grad_kernel(const float *__restrict__ P, const float *__restrict__ C, int 
     }
 }
 
-// Reverse of bf_mesh_kernel for one 32-vertex tile.  grid (n_tiles, F), 512 threads.
+// Reverse of the full-mesh forward for one 32-vertex tile and up to FPW frames.  grid (n_tiles, ceil(F / FPW)), 512 threads.
 //   in : dvout[F][NV][3] = dL/d((v + t) s c), vposed[F][NV][3] (pose-blended vertices saved by the forward),
 //        vraw[F][NV][3], state
 //   out: part[F][n_tiles][EXT] with EXT = npf + nj*12 + nb + 4:
 //        dfeat[npf] | per joint 3 rows of (sum w dv (x) vp | sum w dv) | dbeta[nb] | dt[3] ds[1]
 // posedirsT is the [3NV][npf] transpose, so that thread p streams row-contiguous memory.
-extern "C" __global__ void __launch_bounds__(512)
-bf_mesh_bwd_kernel(MeshTab M, const float *__restrict__ posedirsT, const float *__restrict__ state,
-                   const float *__restrict__ dvout, const float *__restrict__ vposed, const float *__restrict__ vraw,
-                   float *__restrict__ part) {
+// The tile's posedirsT slice (96 x npf floats - the 61 MB of SMPL-X spread over 328 tiles) is streamed ONCE and every loaded value
+// feeds one fma per frame; the per-frame vectors it is dotted with sit frame-minor in LDS (one b128 read for four
+// frames).  shapedirs of the tile are staged in LDS, so the beta sums do not chase 96 dependent loads.  Every sum has a
+// fixed order that does not depend on FPW or on the frame's position in the batch.
+template <int FPW>
+__global__ void __launch_bounds__(512)
+bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const float *__restrict__ state, int n_frames,
+                         const float *__restrict__ dvout, const float *__restrict__ vposed, const float *__restrict__ vraw,
+                         float *__restrict__ part) {
     constexpr int TV = BF_MESH_TILE, COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
-    float *s_A = sm;                        // [nj][12]
-    float *s_w = s_A + nj * 12;             // [TV][nj]
-    float *s_dv = s_w + TV * nj;            // [COLS]  dL/dv (model space)
-    float *s_vp = s_dv + COLS;              // [COLS]
-    float *s_dvp = s_vp + COLS;             // [COLS]
-    float *s_sim = s_dvp + COLS;            // t[3], s, c
-    int tile, frame;
-    bf_xcd_tile_frame(tile, frame);
+    float *s_dvpT = sm;                      // [COLS][FPW]  T_v.R^T dv, frame-minor
+    float *s_A = s_dvpT + COLS * FPW;        // [FPW][nj][12]
+    float *s_w = s_A + FPW * nj * 12;        // [TV][nj]
+    float *s_dv = s_w + TV * nj;             // [FPW][COLS]  dL/dv (model space)
+    float *s_vp = s_dv + FPW * COLS;         // [FPW][COLS]
+    float *s_sim = s_vp + FPW * COLS;        // [FPW][8]: t[3], s, c
+    float *s_sd = s_sim + FPW * 8;           // [COLS][nb]
+    float *s_ts = s_sd + COLS * nb;          // [FPW][2][COLS]  dt, ds terms
+    const int tile = blockIdx.x, fbase = blockIdx.y * FPW, nf = min(FPW, n_frames - fbase);
     const int tid = threadIdx.x, v0 = tile * TV;
-    StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
+    const size_t sstride = bf_state_stride(nj, npf, nb);
     const int nvt = min(TV, nv - v0);
-    for (int i = tid; i < nj * 12; i += 512) {
-        int j = i / 12, e = i % 12, a = e / 4, b = e % 4;
-        s_A[i] = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
+    for (int i = tid; i < FPW * nj * 12; i += 512) {
+        const int f = i / (nj * 12), r = i - f * nj * 12, j = r / 12, e = r % 12, a = e / 4, b = e % 4;
+        float x = 0.f;
+        if (f < nf) {
+            StateView st = bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb);
+            x = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
+        }
+        s_A[i] = x;
     }
     for (int i = tid; i < TV * nj; i += 512) s_w[i] = i < nvt * nj ? M.lbs_weights[(size_t)v0 * nj + i] : 0.f;
-    if (tid < 5) s_sim[tid] = tid < 3 ? st.t[tid] : st.sc[tid - 3];
-    __syncthreads();
-    const float sc = s_sim[3] * s_sim[4];
-    float dt_part = 0.f, ds_part = 0.f;
-    if (tid < COLS) {
-        bool ok = tid < nvt * 3;
-        size_t o = ((size_t)frame * nv + v0) * 3 + tid;
-        float g = ok ? dvout[o] : 0.f;
-        s_dv[tid] = g * sc;
-        s_vp[tid] = ok ? vposed[o] : 0.f;
-        dt_part = g * sc;                                              // d/dt_k   = sum dvout * s c
-        ds_part = ok ? g * (vraw[o] + s_sim[tid % 3]) * s_sim[4] : 0.f;   // d/ds = sum dvout . (v + t) c
+    for (int i = tid; i < COLS * nb; i += 512) s_sd[i] = i < nvt * 3 * nb ? M.shapedirs[(size_t)v0 * 3 * nb + i] : 0.f;
+    if (tid < FPW * 8) {
+        const int f = tid >> 3, l = tid & 7;
+        float x = 0.f;
+        if (f < nf && l < 5) {
+            StateView st = bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb);
+            x = l < 3 ? st.t[l] : st.sc[l - 3];
+        }
+        s_sim[tid] = x;
     }
     __syncthreads();
-    // dvp = T_v.R^T dv : thread (vl, b)
-    if (tid < COLS) {
-        int vl = tid / 3, b = tid - vl * 3;
+    for (int i = tid; i < FPW * COLS; i += 512) {
+        const int f = i / COLS, c = i - f * COLS;
+        const bool ok = f < nf && c < nvt * 3;
+        const size_t o = ((size_t)(fbase + f) * nv + v0) * 3 + c;
+        const float sc = s_sim[f * 8 + 3] * s_sim[f * 8 + 4];
+        const float g = ok ? dvout[o] : 0.f;
+        s_dv[i] = g * sc;
+        s_vp[i] = ok ? vposed[o] : 0.f;
+        s_ts[(f * 2) * COLS + c] = g * sc;                                                          // d/dt_k = sum dvout * s c
+        s_ts[(f * 2 + 1) * COLS + c] = ok ? g * (vraw[o] + s_sim[f * 8 + c % 3]) * s_sim[f * 8 + 4] : 0.f;   // d/ds = sum dvout . (v + t) c
+    }
+    __syncthreads();
+    // dvp = T_v.R^T dv : item (f, vl, b)
+    for (int i = tid; i < FPW * COLS; i += 512) {
+        const int f = i / COLS, c = i - f * COLS, vl = c / 3, b = c - vl * 3;
+        const float *A = s_A + f * nj * 12, *dv = s_dv + f * COLS + vl * 3;
         float acc = 0.f;
         for (int j = 0; j < nj; ++j) {
-            float w = s_w[vl * nj + j];
-            acc += w * (s_A[j * 12 + b] * s_dv[vl * 3] + s_A[j * 12 + 4 + b] * s_dv[vl * 3 + 1] + s_A[j * 12 + 8 + b] * s_dv[vl * 3 + 2]);
+            const float w = s_w[vl * nj + j];
+            acc += w * (A[j * 12 + b] * dv[0] + A[j * 12 + 4 + b] * dv[1] + A[j * 12 + 8 + b] * dv[2]);
         }
-        s_dvp[tid] = acc;
+        s_dvpT[c * FPW + f] = acc;
     }
     __syncthreads();
     const int EXT = npf + nj * 12 + nb + 4;
-    float *out = part + ((size_t)frame * gridDim.x + tile) * EXT;
-    // (a) dfeat partial: thread p streams posedirsT[col][p]
+    float *out0 = part + ((size_t)fbase * gridDim.x + tile) * EXT;
+    const size_t fstride = (size_t)gridDim.x * EXT;
+    // (a) dfeat partials: thread p streams posedirsT[col][p] once for all frames
     for (int p = tid; p < npf; p += 512) {
         const float *src = posedirsT + (size_t)v0 * 3 * npf + p;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < COLS; ++c)
-            if (c < nvt * 3) acc += src[(size_t)c * npf] * s_dvp[c];
-        out[p] = acc;
+        float acc[FPW];
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) acc[f] = 0.f;
+        for (int c0 = 0; c0 < COLS; c0 += 16) {
+            float x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = c0 + i < nvt * 3 ? src[(size_t)(c0 + i) * npf] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (c0 + i < nvt * 3) {
+                    const float *d = s_dvpT + (c0 + i) * FPW;
+                    if constexpr (FPW >= 4) {
+#pragma unroll
+                        for (int f4 = 0; f4 < FPW; f4 += 4) {
+                            const float4 y = *(const float4 *)(d + f4);
+                            acc[f4] += x[i] * y.x; acc[f4 + 1] += x[i] * y.y; acc[f4 + 2] += x[i] * y.z; acc[f4 + 3] += x[i] * y.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < FPW; ++f) acc[f] += x[i] * d[f];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < FPW; ++f) if (f < nf) out0[f * fstride + p] = acc[f];
     }
-    // (b) chain-matrix partials: thread (j, row a, col b): sum_v w_vj dv_a [vp_b | 1]
-    for (int i = 511 - tid; i < nj * 12; i += 512) {
-        int j = i / 12, e = i - j * 12, a = e / 4, b = e - a * 4;
+    // (b) chain-matrix partials: item (f, j, row a, col b): sum_v w_vj dv_a [vp_b | 1]
+    for (int i = 511 - tid; i < nf * nj * 12; i += 512) {
+        const int f = i / (nj * 12), r = i - f * nj * 12, j = r / 12, e = r - j * 12, a = e / 4, b = e - a * 4;
+        const float *dv = s_dv + f * COLS, *vp = s_vp + f * COLS;
         float acc = 0.f;
-        for (int vl = 0; vl < TV; ++vl) acc += s_w[vl * nj + j] * s_dv[vl * 3 + a] * (b < 3 ? s_vp[vl * 3 + b] : 1.f);
-        out[npf + i] = acc;
+        for (int vl = 0; vl < TV; ++vl) acc += s_w[vl * nj + j] * dv[vl * 3 + a] * (b < 3 ? vp[vl * 3 + b] : 1.f);
+        out0[f * fstride + npf + r] = acc;
     }
-    // (c) betas, transl, scale
-    if (tid >= 256 && tid < 256 + nb) {
-        int l = tid - 256;
+    // (c) betas (item (f, l)), transl, scale (item (f, 0..3))
+    for (int i = tid; i < nf * nb; i += 512) {
+        const int f = i / nb, l = i - f * nb;
         float acc = 0.f;
-        for (int c = 0; c < nvt * 3; ++c) acc += M.shapedirs[((size_t)v0 * 3 + c) * nb + l] * s_dvp[c];
-        out[npf + nj * 12 + l] = acc;
+        for (int c = 0; c < nvt * 3; ++c) acc += s_sd[c * nb + l] * s_dvpT[c * FPW + f];
+        out0[f * fstride + npf + nj * 12 + l] = acc;
     }
-    __syncthreads();                       // s_dv / s_vp are free now: reuse for the t, s sums
-    if (tid < COLS) { s_dv[tid] = dt_part; s_vp[tid] = ds_part; }
-    __syncthreads();
-    if (tid < 4) {
+    for (int i = tid; i < nf * 4; i += 512) {
+        const int f = i >> 2, k = i & 3;
         float acc = 0.f;
-        if (tid < 3) { for (int vl = 0; vl < TV; ++vl) acc += s_dv[vl * 3 + tid]; }
-        else { for (int c = 0; c < COLS; ++c) acc += s_vp[c]; }
-        out[npf + nj * 12 + nb + tid] = acc;
+        if (k < 3) { for (int vl = 0; vl < TV; ++vl) acc += s_ts[(f * 2) * COLS + vl * 3 + k]; }
+        else { for (int c = 0; c < COLS; ++c) acc += s_ts[(f * 2 + 1) * COLS + c]; }
+        out0[f * fstride + npf + nj * 12 + nb + k] = acc;
     }
 }
 
-extern "C" size_t bf_mesh_bwd_smem_bytes(int nj) {
-    return sizeof(float) * (nj * 12 + BF_MESH_TILE * nj + 3 * BF_MESH_TILE * 3 + 8);
+extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT, const float *state, int n, const float *dvout,
+                                        const float *vposed, const float *vraw, float *part, hipStream_t stream) {
+    constexpr int COLS = BF_MESH_TILE * 3;
+    const int fpw = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
+    const size_t smem = sizeof(float) * ((size_t)COLS * fpw + (size_t)fpw * M->nj * 12 + (size_t)BF_MESH_TILE * M->nj + 2 * (size_t)fpw * COLS +
+                                         (size_t)fpw * 8 + (size_t)COLS * M->nb + 2 * (size_t)fpw * COLS);
+    const dim3 grid(M->n_tiles, (n + fpw - 1) / fpw), block(512);
+    if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
+    switch (fpw) {
+    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part); break;
+    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part); break;
+    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part); break;
+    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part); break;
+    }
+    return (int)hipGetLastError();
 }
+
 
 // grid (ceil(EXT/32), F), 256 threads = 32 outputs x 8 tile chunks: ext[f][i] = sum over the tiles of part[f][tile][i].
 // A chunk lane adds its contiguous run of tiles in tile order (loads issued eight at a time: a plain serial loop costs

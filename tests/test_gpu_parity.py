@@ -221,6 +221,22 @@ def test_batched_mfma_pose_blend_matches_per_frame_path(dev_model, smpl_model):
     np.testing.assert_allclose(verts[:3], ref["vertices"].numpy(), atol=3e-6)
 
 
+@pytest.mark.parametrize("n", [2, 3, 8, 13])
+def test_small_batch_forward_is_bitwise_the_single_frame_forward(dev_model, n):
+    """2..15 frames: one workgroup streams a tile's posedirs slice once for up to 8 frames (bf_mesh_multi_kernel);
+    per frame the same arithmetic in the same order as the single-frame kernel"""
+    rng = np.random.default_rng(100 + n)
+    betas = rng.normal(0, 0.7, (n, 10)).astype(np.float32)
+    orient = rng.normal(0, 0.8, (n, 3)).astype(np.float32)
+    pose = rng.normal(0, 0.3, (n, 69)).astype(np.float32)
+    verts, joints, jori = dev_model.forward(betas, orient, pose)
+    for i in range(n):
+        v1, j1, o1 = dev_model.forward(betas[i:i + 1], orient[i:i + 1], pose[i:i + 1])
+        np.testing.assert_array_equal(verts[i], v1[0])
+        np.testing.assert_array_equal(joints[i], j1[0])
+        np.testing.assert_array_equal(jori[i], o1[0])
+
+
 def test_graph_replay_equals_host_issued_commands(dev_model, smpl_model):
     """BF_FIT_RESET | BF_FIT_GRAPH: the captured command sequence gives bit-identical results, call after call"""
     from bodyfitting_amd import _lib

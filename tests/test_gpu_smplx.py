@@ -47,6 +47,20 @@ def test_forward_vertices_and_135_joints(sx):
     np.testing.assert_allclose(joints[0], ref["joints"][0].numpy(), atol=3e-6)      # incl. 51 static + 17 contour landmarks
 
 
+def test_small_batch_forward_is_bitwise_the_single_frame_forward(sx):
+    """SMPL-X, 5 frames in one launch (486 pose-feature rows streamed once for all of them) vs frame by frame"""
+    model, dev = sx
+    rng = np.random.default_rng(5)
+    prob = S.make_problem_smplx(model, 0, n_views=2)
+    base = N.pack_params(_params(prob))
+    p = (base[None] + rng.normal(0, 0.05, (5, len(base)))).astype(np.float32)
+    verts, joints = dev.forward_packed(p)
+    for i in range(5):
+        v1, j1 = dev.forward_packed(p[i:i + 1])
+        np.testing.assert_array_equal(verts[i], v1[0])
+        np.testing.assert_array_equal(joints[i], j1[0])
+
+
 def test_loss_and_gradient_match_autograd(sx, gmm_bufs):
     model, dev = sx
     prob = S.make_problem_smplx(model, 0, 8)

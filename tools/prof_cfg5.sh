@@ -3,10 +3,10 @@
 TAG=${1:-x}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
-timeout 600 python -m pytest tests/test_gpu_scan.py -x -q > gpurun_out/pytest_scan_$TAG.log 2>&1; tail -3 gpurun_out/pytest_scan_$TAG.log
+timeout 900 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_scan_$TAG.log 2>&1; tail -3 gpurun_out/pytest_scan_$TAG.log
 export TMPDIR=/tmp
 cd /tmp
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg5_$TAG -- python3 $R/tools/bench_configs.py --cfg5x --cfg5 --reps 1 > $R/gpurun_out/prof_cfg5_$TAG.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_cfg5_$TAG -- python3 $R/tools/bench_configs.py --cfg5x --cfg5 --cfg3 --reps 1 > $R/gpurun_out/prof_cfg5_$TAG.log 2>&1
 cd $R
 find gpurun_out/prof_cfg5_$TAG -name "*.db" -delete
 grep config gpurun_out/prof_cfg5_$TAG.log
