@@ -76,9 +76,11 @@ SIGNATURES = {
     "bf_scan_height": (C.c_float, [_VP]),
     "bf_scan_grid_info": (C.c_int, [_VP, _IP, _FP]),
     "bf_scan_grid_lists": (C.c_int, [_VP, _IP, _IP, _IP]),
+    "bf_scan_inside": (C.c_int, [_VP, C.c_int, _FP, _FP]),
     "bf_scan_nearest": (C.c_int, [_VP, C.c_int, _FP, _IP, _FP, _FP]),
     "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
     "bf_batch_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP]),
+    "bf_extract_contours": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP]),
     "bf_batch_mask_loss": (C.c_int, [_VP, C.POINTER(Hyper), _FP, _FP]),
     "bf_fit_displacement": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper)]),
     "bf_batch_get_displacement": (C.c_int, [_VP, _FP]),

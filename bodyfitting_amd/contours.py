@@ -1,35 +1,38 @@
-"""Silhouette contours without OpenCV.
+"""Silhouette contours on the GPU (reference smplify/loss.py:73-83, `extract_countours`).
 
-The reference extracts them with `cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_NONE)` and keeps one
-contour (smplify/loss.py:73-83).  cv2 is not available here, so this is a restatement of what that call
-returns for a mask: the border points of the outer boundary in Suzuki-Abe's sense - foreground pixels with a
-background pixel (or the image edge) in their 4-neighbourhood, holes ignored - of the largest 8-connected
-component.  The silhouette loss only sums over the points, so their order does not matter.
-Parity note: unpinned against cv2 itself (absent); pixel sets can differ from OpenCV's trace where it visits
-a pixel twice (one-pixel-wide spurs).
+The reference extracts them with `cv2.findContours(mask * 255, RETR_EXTERNAL, CHAIN_APPROX_NONE)` and keeps one contour.
+Here `libbodyfit.so` follows the borders itself (bf_contour_kernel: Suzuki-Abe border following, one wave per mask, the
+image as bit planes in LDS) and keeps the longest external border - see include/bodyfit.h `bf_extract_contours` and
+oracle/contour_oracle.py for the restatement it is tested against.  There is no CPU fallback: without the library or
+a GPU these functions raise.  `FrameBatch.set_masks(masks, view_index, None)` runs the same kernel without the points
+ever visiting the host.
 """
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
-from scipy import ndimage
+
+from . import _lib
 
 
-def extract_contour(mask):
-    """mask[H,W] (truthy = foreground) -> float32[C,2] contour points (x, y), row-major order."""
-    fg = np.asarray(mask) > 0
-    if not fg.any():
-        return np.zeros((0, 2), np.float32)
-    lab, n = ndimage.label(fg, structure=np.ones((3, 3), int))
-    if n > 1:
-        sizes = ndimage.sum(fg, lab, index=np.arange(1, n + 1))
-        fg = lab == (1 + int(np.argmax(sizes)))
-    fg = ndimage.binary_fill_holes(fg)                     # RETR_EXTERNAL: outer border only
-    pad = np.pad(fg, 1, constant_values=False)
-    all4 = pad[:-2, 1:-1] & pad[2:, 1:-1] & pad[1:-1, :-2] & pad[1:-1, 2:]
-    ys, xs = np.nonzero(fg & ~all4)
-    return np.stack([xs, ys], 1).astype(np.float32)
+def extract_contours(masks, device=0):
+    """masks [M,H,W] (truthy = foreground) -> list of float32[C_m,2] arrays of (x, y) contour points in border-following
+    order (every pixel the walk stands on: pixels of one-pixel-wide parts appear more than once), like loss.py:73-83."""
+    m = np.ascontiguousarray(np.asarray(masks) > 0, dtype=np.uint8)
+    if m.ndim == 2:
+        m = m[None]
+    n, H, W = m.shape
+    lib = _lib.load()
+    counts = np.zeros(n, np.int32)
+    mp = m.ctypes.data_as(C.POINTER(C.c_uint8))
+    _lib.check(lib.bf_extract_contours(int(device), n, H, W, mp, _lib.iptr(counts), None), "bf_extract_contours")
+    xy = np.zeros((max(int(counts.sum()), 1), 2), np.float32)
+    _lib.check(lib.bf_extract_contours(int(device), n, H, W, mp, _lib.iptr(counts), _lib.fptr(xy)), "bf_extract_contours")
+    ends = np.cumsum(counts)
+    return [xy[e - c:e].copy() for c, e in zip(counts, ends)]
 
 
-def extract_contours(masks):
-    """list / array of masks -> list of float32[C,2] arrays (one per mask view), like loss.py:73-83."""
-    return [extract_contour(m) for m in masks]
+def extract_contour(mask, device=0):
+    """mask[H,W] -> float32[C,2]"""
+    return extract_contours(np.asarray(mask)[None], device)[0]

@@ -10,6 +10,7 @@
 //   bf_grid_fill_kernel    thread per triangle: face id into a free slot of every covered cell   (kernel.cu:149-155)
 //   bf_grid_pack_kernel    thread per list entry: rank inside its cell -> sorted list + (corners | face id) record
 //   bf_face_normal_kernel  un-normalised scan face normals, float64 cross product rounded once (smplify.py:148-149)
+//   bf_inside_mesh_kernel  MeshGridSearcher.inside_mesh: parity of the triangles an axis ray crosses (kernel.cu:461-641)
 #include <hip/hip_runtime.h>
 #include "bf_internal.h"
 
@@ -125,4 +126,91 @@ extern "C" __global__ void __launch_bounds__(256) bf_face_normal_kernel(const fl
     fn[f * 3] = (float)__dsub_rn(__dmul_rn(u1, w2), __dmul_rn(u2, w1));
     fn[f * 3 + 1] = (float)__dsub_rn(__dmul_rn(u2, w0), __dmul_rn(u0, w2));
     fn[f * 3 + 2] = (float)__dsub_rn(__dmul_rn(u0, w1), __dmul_rn(u1, w0));
+}
+
+// ---- MeshGridSearcher.inside_mesh (utils/mesh_grid_searcher.py:86-91 -> search_inside_mesh_kernel, kernel.cu:569-641) ----------
+// Does the axis ray from q (axis a, towards + if `plus`) cross the triangle?  The reference's test (kernel.cu:461-567), for
+// three dimensions: (1) some corner lies strictly ahead of q along the axis; (2) q's projection on the other two axes is
+// inside the projected triangle by crossing parity - a 2-D ray towards -u crosses edge (A, B) iff the edge has a corner
+// with u < 0, its cross product det = A.u B.w - A.w B.u is non-zero and (det > 0 ? A.w > 0 > B.w : A.w <= 0 <= B.w);
+// (3) the cofactors c_i of the corners' axis coordinate (det = sum c_i V_i[a]) all carry the sign that puts the hit ahead.
+__device__ inline bool axis_ray_hits(const float q[3], int a, bool plus, const float v[3][3]) {
+    bool ahead = false;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ahead = ahead || (plus ? v[i][a] > q[a] : v[i][a] < q[a]);
+    if (!ahead) return false;
+    const int u = (a + 1) % 3, w = (a + 2) % 3;
+    int crossings = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const int ia = (d + 1) % 3, ib = (d + 2) % 3;
+        if (!(v[ia][u] < q[u] || v[ib][u] < q[u])) continue;
+        const float au = v[ia][u] - q[u], aw = v[ia][w] - q[w], bu = v[ib][u] - q[u], bw = v[ib][w] - q[w];
+        const float det = __fsub_rn(__fmul_rn(au, bw), __fmul_rn(aw, bu));
+        if (det == 0.f) continue;
+        crossings += det > 0.f ? (!(bw >= 0.f) && !(-aw >= 0.f)) : (bw >= 0.f && -aw >= 0.f);
+    }
+    if ((crossings & 1) == 0) return false;
+    float r[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) r[i][k] = v[i][k] - q[k];
+    // cofactor of corner i's coordinate a: (V_j x V_k)[a] over the cyclic (i, j, k)
+    float c[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        c[i] = __fsub_rn(__fmul_rn(r[j][u], r[k][w]), __fmul_rn(r[j][w], r[k][u]));
+    }
+    const float det = __fadd_rn(__fadd_rn(__fmul_rn(c[0], r[0][a]), __fmul_rn(c[1], r[1][a])), __fmul_rn(c[2], r[2][a]));
+    if (det == 0.f) return false;
+    const bool want_negative = (det > 0.f) != plus;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (want_negative != (c[i] < 0.f)) return false;
+    return true;
+}
+
+// One thread per query.  sign = +1 when the ray towards the nearest grid wall (ties: -x, +x, -y, +y, -z, +z order) crosses an odd
+// number of distinct triangles, -1 otherwise and for queries outside the grid.  A triangle listed in several cells of the walk is
+// counted once as long as it is among the last 15 hits (the reference's fixed `visited[16]`).
+extern "C" __global__ void __launch_bounds__(256) bf_inside_mesh_kernel(ScanDev S, const float *__restrict__ points, int n,
+                                                                       float *__restrict__ sign) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const float q[3] = {points[id * 3], points[id * 3 + 1], points[id * 3 + 2]};
+    const float org[3] = {S.ox, S.oy, S.oz};
+    const int num[3] = {S.nx, S.ny, S.nz};
+    int x[3], to_end[6];
+    for (int d = 0; d < 3; ++d) {
+        const float xf = __fdiv_rn(__fsub_rn(q[d], org[d]), S.step);
+        if (xf < 0.f || xf >= (float)num[d]) { sign[id] = -1.f; return; }
+        x[d] = (int)xf;
+        to_end[2 * d] = x[d];
+        to_end[2 * d + 1] = num[d] - 1 - x[d];
+    }
+    int dir = 0;
+    for (int d = 1; d < 6; ++d) if (to_end[d] < to_end[dir]) dir = d;
+    const int a = dir >> 1;
+    const bool plus = dir & 1;
+    int seen[15], n_seen = 0, hits = 0;
+    for (int i = 0; i <= to_end[dir]; ++i) {
+        const int cell = (x[0] * S.ny + x[1]) * S.nz + x[2];
+        for (int e = S.cell_start[cell]; e < S.cell_start[cell + 1]; ++e) {
+            const int t = S.cell_tris[e];
+            float v[3][3];
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < 3; ++k) v[c][k] = S.verts[(size_t)S.faces[t * 3 + c] * 3 + k];
+            if (!axis_ray_hits(q, a, plus, v)) continue;
+            bool known = false;
+            for (int s = 0; s < n_seen; ++s) known = known || seen[s] == t;
+            if (known) continue;
+            if (n_seen < 15) seen[n_seen++] = t;
+            else { for (int s = 0; s + 1 < 15; ++s) seen[s] = seen[s + 1]; seen[14] = t; }
+            ++hits;
+        }
+        x[a] += plus ? 1 : -1;
+    }
+    sign[id] = (hits & 1) ? 1.f : -1.f;
 }

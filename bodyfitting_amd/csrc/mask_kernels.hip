@@ -188,3 +188,151 @@ extern "C" __global__ void bf_mask_loss_kernel(MaskIO K, const float *__restrict
     }
     loss[f] = tot;
 }
+
+// ---- extract_countours (smplify/loss.py:73-83) on the device ----------------------------------------------------------------
+// cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_NONE) is Suzuki-Abe border following (CVGIP 30, 1985, Algorithm 1); this
+// kernel runs it per mask: ONE WAVE PER MASK, the image as three bit planes in LDS (foreground | marked | negative mark:
+// 96 KB for 512 x 512; images too large for LDS use the same planes in global memory).  The lanes build the planes by ballot, then the wave
+// scans the rows a 32-pixel word at a time (outer-border starts = foreground & ~(left neighbour) & ~marked, by bit tricks) and
+// follows every external border once, marking it and writing its points; the longest one (first on ties) is kept.  A walk step reads the 3 x 3 neighbourhood as three word pairs and finishes in registers.
+// External = not inside a hole of another component: a start is skipped while the last marked pixel met on its row carries a
+// positive mark (between the left and the right edge of a traced border).  See oracle/contour_oracle.py for the restatement
+// this is tested against, and for which contour the reference keeps.
+namespace {
+struct ContourPlanes {
+    unsigned *fg, *mk, *ng;
+    int H, W, wpr;                         // wpr = 32-bit words per row
+    __device__ bool get(const unsigned *pl, int x, int y) const {
+        return x >= 0 && y >= 0 && x < W && y < H && ((pl[y * wpr + (x >> 5)] >> (x & 31)) & 1u);
+    }
+    // the eight neighbours of (x, y) as a bit mask: bit c = direction code c (0 east, then counter-clockwise on the screen).
+    // Called by the whole wave with the same (x, y): lane c < 8 fetches neighbour c, the ballot is the mask.
+    __device__ unsigned around(int x, int y) const {
+        const int c = threadIdx.x & 7;
+        const int dx = (c == 0 || c == 1 || c == 7) ? 1 : ((c == 3 || c == 4 || c == 5) ? -1 : 0);
+        const int dy = (c >= 1 && c <= 3) ? -1 : ((c >= 5) ? 1 : 0);
+        return (unsigned)__ballot(threadIdx.x < 8 && get(fg, x + dx, y + dy)) & 0xffu;
+    }
+    __device__ void mark(int x, int y, bool negative) {
+        const int w = y * wpr + (x >> 5);
+        const unsigned b = 1u << (x & 31);
+        if (negative) { mk[w] |= b; ng[w] |= b; }
+        else if (!(mk[w] & b)) mk[w] |= b;                 // (a positive mark never replaces an earlier mark)
+    }
+};
+
+// Follow the outer border that starts at (x0, y0) - the whole wave in step, every lane with the same state (the lanes share
+// the neighbourhood fetch; lane 0 alone marks and writes).  out != null: write the points (at most cap).  Returns the length.
+__device__ int contour_follow(ContourPlanes &P, int x0, int y0, float *out, int cap, bool set_marks) {
+    const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1}, DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+    unsigned nb = P.around(x0, y0);
+    // first neighbour clockwise, starting after the left one: codes 3, 2, 1, 0, 7, 6, 5
+    int first = -1;
+    for (int k = 0, s = 3; k < 7; ++k, s = (s - 1) & 7)
+        if (nb & (1u << s)) { first = s; break; }
+    if (first < 0) {
+        if (threadIdx.x == 0) {
+            if (set_marks) P.mark(x0, y0, true);
+            if (out && cap > 0) { out[0] = (float)x0; out[1] = (float)y0; }
+        }
+        return 1;
+    }
+    const int x1 = x0 + DX[first], y1 = y0 + DY[first];
+    int x3 = x0, y3 = y0, s = first, n = 0;
+    for (;;) {
+        // first neighbour counter-clockwise, starting after the direction we came from; `passed_east`: code 8 was examined
+        int t = s + 1;
+        while (!(nb & (1u << (t & 7)))) ++t;
+        const bool passed_east = t >= 9;
+        if (threadIdx.x == 0) {
+            if (set_marks) P.mark(x3, y3, passed_east);
+            if (out && n < cap) { out[n * 2] = (float)x3; out[n * 2 + 1] = (float)y3; }
+        }
+        ++n;
+        const int x4 = x3 + DX[t & 7], y4 = y3 + DY[t & 7];
+        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
+        x3 = x4; y3 = y4;
+        s = ((t & 7) + 4) & 7;
+        nb = P.around(x3, y3);
+    }
+}
+}  // namespace
+
+// grid (n_masks), 64 threads.  masks[n][H][W] (non-zero = foreground) -> count[n] = length of the kept contour (also when it
+// exceeds cap: the caller retries with more room), count[n + m] = which half of xy[m][2][cap][2] holds its points (x, y).  planes_global: 3 * H * wpr words per mask,
+// or null when the planes fit the dynamic LDS given to the launch.
+extern "C" __global__ void __launch_bounds__(64)
+bf_contour_kernel(const unsigned char *__restrict__ masks, int H, int W, int cap, float *__restrict__ xy, int *__restrict__ count,
+                  unsigned *planes_global) {
+    extern __shared__ unsigned s_planes[];
+    const int m = blockIdx.x, lane = threadIdx.x;
+    ContourPlanes P;
+    P.H = H; P.W = W; P.wpr = (W + 31) >> 5;
+    const int plane = H * P.wpr;
+    P.fg = planes_global ? planes_global + (size_t)m * 3 * plane : s_planes;
+    P.mk = P.fg + plane; P.ng = P.mk + plane;
+    const unsigned char *img = masks + (size_t)m * H * W;
+    // bit planes: 64 consecutive pixels per step, one coalesced byte load per lane, the ballot is two finished words
+    const int chunks = (W + 63) >> 6;
+    for (int it = 0; it < H * chunks; it += 4) {
+        unsigned long long bits[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = it + k, y = i / chunks, x = (i - y * chunks) * 64 + lane;
+            const bool on = i < H * chunks && x < W && img[(size_t)y * W + x] != 0;
+            bits[k] = __ballot(on);
+        }
+        if (lane < 8) {
+            const int k = lane >> 1, half = lane & 1, i = it + k, y = i / chunks, wi = (i - y * chunks) * 2 + half;
+            if (i < H * chunks && wi < P.wpr) {
+                const int w = y * P.wpr + wi;
+                P.fg[w] = (unsigned)(bits[k] >> (32 * half)); P.mk[w] = 0; P.ng[w] = 0;
+            }
+        }
+    }
+    __syncthreads();
+    // from here on every lane runs the same scalar program (one wave: lock-step, LDS accesses in program order)
+    // Outer-border starts are rare (one per component, plus the skipped ones next to holes), so the words are screened 64
+    // at a time - lane l looks at word base + l - and only a word with a start is handled, serially.  A walk changes marks,
+    // so the screen is repeated from the handled word on.  Points are written while walking, into the half of the slab that
+    // does not hold the longest border so far.
+    int best_len = 0, best_half = 0;
+    float *slab = xy + (size_t)m * 2 * cap * 2;
+    for (int base = 0; base < plane; base += 64) {
+        int cursor = 0;
+        for (;;) {
+            const int wl = base + lane;
+            bool any = false;
+            if (wl < plane && lane >= cursor) {
+                const unsigned fgw = P.fg[wl];
+                const unsigned left = (wl % P.wpr) ? P.fg[wl - 1] >> 31 : 0u;
+                any = (fgw & ~((fgw << 1) | left) & ~P.mk[wl]) != 0u;
+            }
+            const unsigned long long has = __ballot(any);
+            if (!has) break;
+            const int L = __ffsll((long long)has) - 1, w = base + L, y = w / P.wpr, wi = w - y * P.wpr;
+            cursor = L + 1;
+            const unsigned fg = P.fg[w], carry = wi ? P.fg[w - 1] >> 31 : 0u;
+            bool inside = false;                           // sign of the last marked pixel met on this row before the word
+            for (int k = w - 1; k >= y * P.wpr; --k) {
+                const unsigned mk = P.mk[k];
+                if (mk) { inside = !((P.ng[k] >> (31 - __clz(mk))) & 1u); break; }
+            }
+            int pos = 0;                                   // bits below pos have been passed (their marks are in `inside`)
+            for (;;) {
+                const unsigned mk = P.mk[w], ng = P.ng[w], from = pos < 32 ? ~0u << pos : 0u;
+                const unsigned starts = fg & ~((fg << 1) | carry) & ~mk & from;
+                const int b = starts ? __ffs(starts) - 1 : 32;
+                const unsigned passed = mk & from & (b < 32 ? (1u << b) - 1u : ~0u);      // marked pixels in [pos, b)
+                if (passed) inside = !((ng >> (31 - __clz(passed))) & 1u);
+                if (b == 32) break;
+                pos = b + 1;
+                if (inside) continue;                      // inside a hole of a traced component: not external
+                const int len = contour_follow(P, wi * 32 + b, y, slab + (size_t)(1 - best_half) * cap * 2, cap, true);
+                if (len > best_len) { best_len = len; best_half = 1 - best_half; }
+                inside = !((P.ng[w] >> b) & 1u);           // the start pixel carries a mark now
+            }
+        }
+    }
+    if (lane == 0) { count[m] = best_len; count[gridDim.x + m] = best_half; }
+}

@@ -15,6 +15,8 @@ extern "C" __global__ void bf_grid_scan_kernel(int *, int *, int);
 extern "C" __global__ void bf_grid_fill_kernel(ScanDev, int *, int *);
 extern "C" __global__ void bf_grid_pack_kernel(ScanDev, const int *, int *, float4 *, int);
 extern "C" __global__ void bf_face_normal_kernel(const float *, const int *, int, float *);
+extern "C" __global__ void bf_inside_mesh_kernel(ScanDev, const float *, int, float *);
+extern "C" __global__ void bf_contour_kernel(const unsigned char *, int, int, int, float *, int *, unsigned *);
 extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const float *, float *, float *, float *);
 extern "C" __global__ void bf_mask_contour_kernel(MaskIO, const float *, int *, float *, float *);
 extern "C" __global__ void bf_mask_gather_kernel(MaskIO, const float *, const float *, const float *, const int *, const float *, float *);
@@ -121,6 +123,19 @@ int bf_scan_grid_lists(const bf_scan *s, int32_t *tri_num, int32_t *tri_idx, int
         HIP_TRY(hipMemcpy(tri_idx, s->cell_tris.p, (size_t)s->n_entries * sizeof(int), hipMemcpyDeviceToHost));
         for (int i = 0; i < s->n_entries; ++i) tri_idx[i] += 1;
     }
+    return BF_OK;
+}
+
+// MeshGridSearcher.inside_mesh (utils/mesh_grid_searcher.py:86-91 -> search_inside_mesh, mesh_grid.cpp:74-90)
+int bf_scan_inside(bf_scan *s, int n, const float *points, float *signs) {
+    if (!s || n <= 0 || !points || !signs) return fail(BF_ERR_INVALID, "bf_scan_inside: bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf<float> d_p, d_s;
+    HIP_TRY(d_p.upload(std::vector<float>(points, points + (size_t)n * 3)));
+    HIP_TRY(d_s.alloc(n));
+    hipLaunchKernelGGL(bf_inside_mesh_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, s->dev, (const float *)d_p.p, n, d_s.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(signs, d_s.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
 }
 
@@ -340,33 +355,101 @@ int bf_model_forward(bf_model *m, int n, const float *params, float *vertices, f
 // view_index[M] = position of each mask view among the V views (use_frames.index(frame), smplify.py:141-142),
 // contours: for every (frame, mask view) contour_count points (x, y), concatenated in contour_xy
 // (extract_countours, loss.py:73-83 - the caller extracts them; the loss only sums over the points).
+// Contours of n binary masks on the device (bf_contour_kernel).  d_bin[n][H][W] -> counts (host), d_xy[n][2][cap][2] (device slab;
+// half[i] says which half holds mask i's contour).
+// The slab is grown and the kernel re-run when a contour is longer than the first guess.
+static int contours_on_device(const unsigned char *d_bin, int n, int H, int W, std::vector<int> &counts, std::vector<int> &half,
+                              DevBuf<float> &d_xy, int &cap) {
+    const int wpr = (W + 31) / 32;
+    const size_t plane_bytes = (size_t)3 * H * wpr * sizeof(unsigned);
+    const bool in_lds = plane_bytes <= 150 * 1024;
+    DevBuf<unsigned> planes;
+    DevBuf<int> d_cnt;
+    if (!in_lds) HIP_TRY(planes.alloc((size_t)n * 3 * H * wpr));
+    HIP_TRY(d_cnt.alloc(2 * (size_t)n));
+    if (in_lds && plane_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)bf_contour_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plane_bytes));
+    counts.assign(n, 0);
+    cap = std::max(64, 4 * (H + W));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (d_xy.p) { (void)hipFree(d_xy.p); d_xy.p = nullptr; }
+        HIP_TRY(d_xy.alloc((size_t)n * 2 * cap * 2));
+        hipLaunchKernelGGL(bf_contour_kernel, dim3(n), dim3(64), in_lds ? plane_bytes : 0, 0, d_bin, H, W, cap, d_xy.p, d_cnt.p,
+                           in_lds ? (unsigned *)nullptr : planes.p);
+        HIP_TRY(hipGetLastError());
+        std::vector<int> both(2 * (size_t)n);
+        HIP_TRY(hipMemcpy(both.data(), d_cnt.p, both.size() * sizeof(int), hipMemcpyDeviceToHost));
+        counts.assign(both.begin(), both.begin() + n);
+        half.assign(both.begin() + n, both.end());
+        const int longest = *std::max_element(counts.begin(), counts.end());
+        if (longest <= cap) return BF_OK;
+        cap = longest;
+    }
+    return fail(BF_ERR_HIP, "contour extraction: inconsistent contour length");
+}
+
+// extract_countours (smplify/loss.py:73-83): masks[n][H][W] uint8, non-zero = foreground (the reference passes
+// (mask > 128) * 255) -> counts[n] and, when xy != NULL, the contours' (x, y) points concatenated (sum(counts) pairs,
+// which the caller learns from a first call with xy == NULL).
+int bf_extract_contours(int device, int n, int H, int W, const uint8_t *masks, int32_t *counts, float *xy) {
+    if (n <= 0 || H <= 0 || W <= 0 || !masks || !counts) return fail(BF_ERR_INVALID, "bf_extract_contours: bad argument");
+    if (bf_device_count() <= device || device < 0) return fail(BF_ERR_NO_DEVICE, "bf_extract_contours: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<unsigned char> d_bin;
+    HIP_TRY(d_bin.upload(std::vector<unsigned char>(masks, masks + (size_t)n * H * W)));
+    std::vector<int> cnt, half;
+    DevBuf<float> d_xy;
+    int cap = 0;
+    int rc = contours_on_device(d_bin.p, n, H, W, cnt, half, d_xy, cap);
+    if (rc) return rc;
+    size_t o = 0;
+    for (int i = 0; i < n; ++i) {
+        counts[i] = cnt[i];
+        if (xy && cnt[i] > 0) HIP_TRY(hipMemcpy(xy + o * 2, d_xy.p + ((size_t)i * 2 + half[i]) * cap * 2, (size_t)cnt[i] * 2 * sizeof(float), hipMemcpyDeviceToHost));
+        o += cnt[i];
+    }
+    return BF_OK;
+}
+
 int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
                        const int32_t *contour_count, const float *contour_xy) {
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_set_masks: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (n_masks <= 0 || !masks) { b->has_masks = false; return BF_OK; }
-    if (!view_index || !contour_count || !contour_xy || H <= 0 || W <= 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: bad argument");
+    if (!view_index || (contour_count && !contour_xy) || H <= 0 || W <= 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: bad argument");
     const int F = b->F, nv = b->m->nv;
     for (int i = 0; i < n_masks; ++i)
         if (view_index[i] < 0 || view_index[i] >= b->V) return fail(BF_ERR_INVALID, "bf_batch_set_masks: view index out of range");
-    std::vector<int> start((size_t)F * n_masks), count(contour_count, contour_count + (size_t)F * n_masks);
+    std::vector<unsigned char> bin((size_t)F * n_masks * H * W);
+    for (size_t i = 0; i < bin.size(); ++i) bin[i] = masks[i] > 128 ? 1 : 0;                 // smplify.py:139
+    auto refresh = [](auto &buf) { if (buf.p) { (void)hipFree((void *)buf.p); buf.p = nullptr; } };
+    refresh(b->mk_masks);
+    HIP_TRY(b->mk_masks.upload(bin));
+    std::vector<int> start((size_t)F * n_masks), count((size_t)F * n_masks, 0), half;
+    DevBuf<float> slab;                       // contours found on the device (contour_count == NULL): [F*M][cap][2]
+    int cap = 0;
+    if (contour_count) count.assign(contour_count, contour_count + (size_t)F * n_masks);
+    else { int rc = contours_on_device(b->mk_masks.p, F * n_masks, H, W, count, half, slab, cap); if (rc) return rc; }
     int total = 0, cmax = 1;
     for (size_t i = 0; i < count.size(); ++i) {
         if (count[i] < 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: negative contour count");
         start[i] = total; total += count[i]; cmax = std::max(cmax, count[i]);
     }
-    std::vector<unsigned char> bin((size_t)F * n_masks * H * W);
-    for (size_t i = 0; i < bin.size(); ++i) bin[i] = masks[i] > 128 ? 1 : 0;                 // smplify.py:139
-    auto refresh = [](auto &buf) { if (buf.p) { (void)hipFree((void *)buf.p); buf.p = nullptr; } };
-    refresh(b->mk_view); refresh(b->mk_cstart); refresh(b->mk_ccount); refresh(b->mk_masks); refresh(b->mk_cxy);
+    refresh(b->mk_view); refresh(b->mk_cstart); refresh(b->mk_ccount); refresh(b->mk_cxy);
     refresh(b->mk_uvi); refresh(b->mk_duvb); refresh(b->mk_gpart); refresh(b->mk_cgrad); refresh(b->mk_part); refresh(b->mk_loss); refresh(b->mk_choice);
     const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256, stride = pblocks + (cmax * 16 + 255) / 256;     // (16 lanes per contour point)
     HIP_TRY(b->mk_view.upload(std::vector<int>(view_index, view_index + n_masks)));
     HIP_TRY(b->mk_cstart.upload(start));
     HIP_TRY(b->mk_ccount.upload(count));
-    HIP_TRY(b->mk_masks.upload(bin));
-    HIP_TRY(b->mk_cxy.upload(std::vector<float>(contour_xy, contour_xy + (size_t)std::max(total, 1) * 2)));
+    if (contour_count) HIP_TRY(b->mk_cxy.upload(std::vector<float>(contour_xy, contour_xy + (size_t)std::max(total, 1) * 2)));
+    else {
+        HIP_TRY(b->mk_cxy.alloc((size_t)std::max(total, 1) * 2));
+        for (size_t i = 0; i < count.size(); ++i)
+            if (count[i] > 0)
+                HIP_TRY(hipMemcpy(b->mk_cxy.p + (size_t)start[i] * 2, slab.p + (i * 2 + half[i]) * (size_t)cap * 2, (size_t)count[i] * 2 * sizeof(float),
+                                  hipMemcpyDeviceToDevice));
+    }
     const size_t fm = (size_t)F * n_masks;
     HIP_TRY(b->mk_uvi.alloc(fm * ns * 4)); HIP_TRY(b->mk_duvb.alloc(fm * ns * 2)); HIP_TRY(b->mk_gpart.alloc(fm * ns * 3));
     HIP_TRY(b->mk_choice.alloc(fm * cmax)); HIP_TRY(b->mk_cgrad.alloc(fm * cmax * 2));

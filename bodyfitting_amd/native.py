@@ -156,6 +156,13 @@ class Scan:
         _lib.check(self._lib.bf_scan_grid_lists(self._h, _lib.iptr(tri_num), _lib.iptr(tri_idx), None), "bf_scan_grid_lists")
         return tri_num, tri_idx[:int(n[0])]
 
+    def inside_mesh(self, points):
+        """-> float32[n]: +1 inside the scan surface, -1 outside (MeshGridSearcher.inside_mesh)"""
+        p = _f32(points, (-1, 3))
+        sign = np.empty(len(p), np.float32)
+        _lib.check(self._lib.bf_scan_inside(self._h, len(p), _lib.fptr(p), _lib.fptr(sign)), "bf_scan_inside")
+        return sign
+
     def nearest_points(self, points):
         """-> (nearest points [n,3], face ids [n], barycentrics [n,3]) like MeshGridSearcher.nearest_points"""
         p = _f32(points, (-1, 3))
@@ -225,17 +232,21 @@ class FrameBatch:
         _lib.check(self._lib.bf_batch_set_scans(self._h, arr), "bf_batch_set_scans")
         self._scans = list(scans)          # keep them alive
 
-    def set_masks(self, masks, view_index, contours):
-        """masks uint8[F,M,H,W] as loaded; view_index[M]; contours: F lists of M arrays [C,2] (x, y) (use_mask=True)"""
+    def set_masks(self, masks, view_index, contours=None):
+        """masks uint8[F,M,H,W] as loaded; view_index[M]; contours: F lists of M arrays [C,2] (x, y), or None to have them
+        extracted from the masks on the device (use_mask=True, smplify.py:138-144)"""
         masks = np.ascontiguousarray(masks, dtype=np.uint8)
         F, M, H, W = masks.shape
         assert F == self.F
         vi = _i32(view_index)
+        mp = masks.ctypes.data_as(C.POINTER(C.c_uint8))
+        if contours is None:
+            _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, mp, None, None), "bf_batch_set_masks")
+            return
         counts = _i32([[len(c) for c in per_frame] for per_frame in contours]).reshape(-1)
         flat = [np.asarray(c, np.float32).reshape(-1, 2) for per_frame in contours for c in per_frame]
         xy = _f32(np.concatenate(flat, 0)) if sum(len(c) for c in flat) else np.zeros((1, 2), np.float32)
-        _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, masks.ctypes.data_as(C.POINTER(C.c_uint8)),
-                                                _lib.iptr(counts), _lib.fptr(xy)), "bf_batch_set_masks")
+        _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, mp, _lib.iptr(counts), _lib.fptr(xy)), "bf_batch_set_masks")
 
     def mask_loss(self, hyper=None):
         loss = np.empty(self.F, np.float32)

@@ -14,7 +14,6 @@ from __future__ import annotations
 import numpy as np
 
 from . import assets
-from .contours import extract_contours
 from .io import load_obj_mesh
 from .native import FrameBatch, Scan, make_hyper, split_params
 from .synthetic import pack_keypoints_smplx
@@ -83,7 +82,7 @@ class SMPLify:
                 batch.set_scans(dev_scans)
             if masks is not None:
                 masks = np.asarray(masks, np.uint8).reshape(F, -1, *np.asarray(masks).shape[-2:])
-                batch.set_masks(masks, mask_view_index, [extract_contours(m > 128) for m in masks])      # loss.py:73-83
+                batch.set_masks(masks, mask_view_index, None)      # contours on the device (loss.py:73-83)
             hyper = make_hyper(imsize=imsize, constant_scale=constant_scale)
             n = self.num_iters if num_iters is None else num_iters
             batch.fit(n, hyper, flags | 4)

@@ -192,6 +192,10 @@ int bf_scan_grid_lists(const bf_scan *s, int32_t *tri_num, int32_t *tri_idx, int
 /* MeshGridSearcher.nearest_points / search_nearest_point (mesh_grid.cpp:54-72): points[n,3] ->
  * face_ids[n] int32, nearest[n,3], bary[n,3] (any output may be NULL) */
 int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, float *nearest, float *bary);
+/* MeshGridSearcher.inside_mesh / search_inside_mesh (utils/mesh_grid_searcher.py:86-91, mesh_grid.cpp:74-90,
+ * mesh_grid_kernel.cu:569-641): signs[n] = +1 inside (odd number of triangles crossed by the axis ray towards the
+ * nearest grid wall), -1 outside or off the grid. */
+int bf_scan_inside(bf_scan *s, int n, const float *points, float *signs);
 /* use_mesh=True: scans[F], one per frame (NULL detaches).  Sets each frame's constant scale to
  * scan_height / 1.7 (smplify.py:156); bf_fit then adds 5 * point_cloud_loss / scan_height * imsize for
  * iterations i > n_iters // 3 (smplify.py:205-210). */
@@ -201,8 +205,13 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans);
  * view among the V views (smplify.py:141-142); per (frame, mask view) contour_count[F*M] contour points,
  * concatenated as (x, y) pairs in contour_xy (what extract_countours returns, loss.py:73-83).  bf_fit then
  * adds 5 * multview_mask_loss for iterations i > n_iters // 3 (smplify.py:197-199,210).  n_masks = 0 detaches. */
+/* contour_count == NULL (and contour_xy == NULL): the contours are extracted from the masks on the device - Suzuki-Abe
+ * border following = cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_NONE), the longest external border per mask. */
 int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
                        const int32_t *contour_count, const float *contour_xy);
+/* extract_countours (smplify/loss.py:73-83) on its own: masks[n,H,W] uint8 (non-zero = foreground) -> counts[n] and,
+ * when xy != NULL, the (x, y) points of the n contours concatenated (sum(counts) pairs; call with xy == NULL first). */
+int bf_extract_contours(int device, int n, int H, int W, const uint8_t *masks, int32_t *counts, float *xy);
 /* one evaluation of multview_mask_loss (loss.py:85-130) at the current parameters: loss[F] and its gradient
  * w.r.t. body_vertices, dverts[F,NV,3] (either may be NULL) */
 int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *dverts);

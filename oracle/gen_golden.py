@@ -214,9 +214,9 @@ def scan_goldens():
 
 
 def install_cv2_contour_stub():
-    """cv2.findContours (OpenCV-3 three-value API, as loss.py:79 unpacks it) backed by bodyfitting_amd.contours."""
+    """cv2.findContours (OpenCV-3 three-value API, as loss.py:79 unpacks it) backed by oracle.contour_oracle.border_pixels_rowmajor."""
     import cv2
-    from bodyfitting_amd.contours import extract_contour
+    from oracle.contour_oracle import border_pixels_rowmajor as extract_contour
 
     def findContours(img, mode, method):
         c = extract_contour(np.asarray(img) > 0).astype(np.int32)
@@ -232,7 +232,7 @@ def mask_goldens():
     import torch
     import smplx
     from bodyfitting_amd import synthetic as S
-    from bodyfitting_amd.contours import extract_contours
+    from oracle.contour_oracle import border_pixels_rowmajor_all as extract_contours
     from oracle import smplify_oracle as O
 
     model = S.make_model("smpl", seed=0)

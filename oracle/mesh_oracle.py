@@ -3,6 +3,7 @@
 Restates, in numpy / torch:
   * MeshGridSearcher.set_mesh grid parameters      reference utils/mesh_grid_searcher.py:56-79
   * insert_grid_surface (cell lists of the grid)    thirdparty/mesh_grid/mesh_grid_kernel.cu:110-157,178-236
+  * MeshGridSearcher.inside_mesh (axis-ray parity)   thirdparty/mesh_grid/mesh_grid_kernel.cu:461-641
   * the per-triangle closest-point rule             thirdparty/mesh_grid/mesh_grid_kernel.cu:12-109
     (KKT solve for the barycentric coefficients; if one is negative, fall back to the edge opposite
     the MOST NEGATIVE coefficient and clamp to its end points - which is not the exact closest point
@@ -67,6 +68,73 @@ def insert_grid_surface(verts, faces, step, origin, num):
     order = np.lexsort((ids, cells))
     tri_num = np.cumsum(np.bincount(cells, minlength=int(num.prod()))).astype(np.int32)
     return tri_num, ids[order].astype(np.int32)
+
+
+def axis_ray_hits(q, axis, plus, tri):
+    """intersect_tri for three dimensions (mesh_grid_kernel.cu:461-567): does the ray from q along +-axis cross the
+    triangle?  q float32[3], tri float32[3,3].  (1) a corner strictly ahead; (2) crossing parity of the projected
+    edges with the 2-D ray towards -u; (3) sign pattern of the cofactors of the corners' axis coordinate."""
+    f = np.float32
+    q = np.asarray(q, f)
+    tri = np.asarray(tri, f)
+    a, u, w = axis, (axis + 1) % 3, (axis + 2) % 3
+    if not any((tri[i, a] > q[a]) if plus else (tri[i, a] < q[a]) for i in range(3)):
+        return False
+    crossings = 0
+    for d in range(3):
+        A, B = tri[(d + 1) % 3], tri[(d + 2) % 3]
+        if not (A[u] < q[u] or B[u] < q[u]):
+            continue
+        au, aw, bu, bw = f(A[u] - q[u]), f(A[w] - q[w]), f(B[u] - q[u]), f(B[w] - q[w])
+        det = f(f(au * bw) - f(aw * bu))
+        if det == 0:
+            continue
+        if det > 0:
+            crossings += int((not bw >= 0) and (not -aw >= 0))
+        else:
+            crossings += int(bw >= 0 and -aw >= 0)
+    if crossings % 2 == 0:
+        return False
+    r = tri - q
+    c = [f(f(r[(i + 1) % 3, u] * r[(i + 2) % 3, w]) - f(r[(i + 1) % 3, w] * r[(i + 2) % 3, u])) for i in range(3)]
+    det = f(f(f(c[0] * r[0, a]) + f(c[1] * r[1, a])) + f(c[2] * r[2, a]))
+    if det == 0:
+        return False
+    want_negative = (det > 0) != bool(plus)
+    return all(want_negative == bool(ci < 0) for ci in c)
+
+
+def inside_mesh(verts, faces, queries, step, origin, num, tri_num, tri_idx):
+    """search_inside_mesh_kernel (mesh_grid_kernel.cu:569-641): +1 when the axis ray towards the nearest grid wall crosses
+    an odd number of distinct triangles (distinct among the last 15 hits, the kernel's `visited[16]`), -1 otherwise and
+    for queries off the grid.  tri_num / tri_idx as insert_grid_surface returns them.  Pure-Python loops: small cases."""
+    f = np.float32
+    v = np.asarray(verts, f)
+    fa = np.asarray(faces, np.int64).reshape(-1, 3)
+    num = [int(n) for n in num]
+    org = np.asarray(origin, f)
+    start = np.concatenate([[0], np.asarray(tri_num, np.int64)])
+    out = np.empty(len(queries), f)
+    for qi, q in enumerate(np.asarray(queries, f)):
+        xf = (q - org) / f(step)
+        if np.any(xf < 0) or np.any(xf >= np.asarray(num, f)):
+            out[qi] = -1
+            continue
+        x = [int(t) for t in xf]
+        to_end = [x[0], num[0] - 1 - x[0], x[1], num[1] - 1 - x[1], x[2], num[2] - 1 - x[2]]
+        direction = int(np.argmin(to_end))                    # first minimum, as the strict `<` scan of the kernel
+        a, plus = direction // 2, direction % 2 == 1
+        seen, hits = [], 0
+        for _ in range(to_end[direction] + 1):
+            cell = (x[0] * num[1] + x[1]) * num[2] + x[2]
+            for t in np.asarray(tri_idx[start[cell]:start[cell + 1]], np.int64) - 1:
+                if not axis_ray_hits(q, a, plus, v[fa[t]]) or t in seen:
+                    continue
+                seen = (seen + [t])[-15:]
+                hits += 1
+            x[a] += 1 if plus else -1
+        out[qi] = 1 if hits % 2 else -1
+    return out
 
 
 def closest_rule(p0, p1, p2):

@@ -6,7 +6,7 @@ import torch
 from conftest import load_golden
 from bodyfitting_amd import native as N
 from bodyfitting_amd import synthetic as S
-from bodyfitting_amd.contours import extract_contours
+from oracle.contour_oracle import border_pixels_rowmajor_all as extract_contours      # what the goldens were made with
 from oracle import smplify_oracle as O
 from test_mask_oracle import MASK_FRAMES, mask_inputs
 
@@ -76,3 +76,50 @@ def test_mask_fit_first_steps_and_progress(dev_model, smpl_model, gmm_bufs):
     for n in PARAMS:
         np.testing.assert_allclose(got[n], g[f"it11_{n}"], rtol=0, atol=1e-4)
     p.close()
+
+
+def _blobs(seed, shape):
+    from scipy import ndimage
+    rng = np.random.default_rng(seed)
+    m = ndimage.gaussian_filter(rng.normal(size=shape), 2.5) > 0.02
+    m[shape[0] // 2:shape[0] // 2 + 3, 5:shape[1] - 9] = True        # a bar and a one-pixel-wide spur
+    m[5, 10:30] = True
+    return m
+
+
+@pytest.mark.parametrize("shape", [(48, 64), (100, 37), (512, 512), (700, 1100)])
+def test_device_contours_equal_border_following_oracle(shape):
+    """bf_extract_contours (one wave per mask, bit planes in LDS; global planes for the 700 x 1100 case) returns the
+    points of oracle/contour_oracle.extract_contour - Suzuki-Abe border following, longest external border -
+    in the same order, repeated pixels included"""
+    from bodyfitting_amd.contours import extract_contours as device_contours
+    from oracle import contour_oracle as CO
+    masks = np.stack([_blobs(s, shape) for s in range(3)] + [np.zeros(shape, bool)])
+    masks[2, :, :] = False
+    masks[2, 3:9, 4:12] = True; masks[2, 5:7, 6:10] = False; masks[2, 5, 7] = True     # box with a hole and an island in it
+    masks[2, 0, 0] = masks[2, -1, -1] = True                                            # single pixels in the corners
+    got = device_contours(masks)
+    for m, c in zip(masks, got):
+        want = CO.extract_contour(m)
+        np.testing.assert_array_equal(c, want)
+    assert len(got[3]) == 0 and len(got[2]) == 2 * (6 + 8) - 4 and len(got[0]) > 50
+
+
+def test_set_masks_extracts_the_contours_itself(dev_model, smpl_model):
+    """bf_batch_set_masks with contour_count == NULL: same loss and gradient, bit for bit, as with the contours
+    of bf_extract_contours passed in explicitly"""
+    from bodyfitting_amd.contours import extract_contours as device_contours
+    prob = S.make_problem(smpl_model, frame=0, n_views=8, mask_frames=MASK_FRAMES)
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
+    masks = np.array(prob["masks"])[None]
+    view_index = [prob["use_frames"].index(f) for f in prob["mask_frames"]]
+    out = []
+    for contours in (None, [device_contours(masks[0] > 128)]):
+        b = N.FrameBatch(dev_model, 1, c2w.shape[1])
+        b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+        b.set_masks(masks, view_index, contours)
+        out.append(b.mask_loss())
+        b.close()
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    assert np.isfinite(out[0][0]).all() and out[0][0][0] > 0

@@ -55,6 +55,23 @@ def test_device_grid_lists_match_insert_grid_surface(small, big):
     again.close(); scan.close()
 
 
+def test_inside_mesh_matches_the_restated_rule(small):
+    """MeshGridSearcher.inside_mesh on the device vs oracle/mesh_oracle.inside_mesh (same float32 tests, same cell walk)"""
+    model, _ = small
+    _, sv, sf = S.make_scan_problem(model, 3)
+    scan = N.Scan(sv, sf)
+    dims, origin, step = scan.grid_info()
+    tri_num, tri_idx = scan.grid_lists()
+    rng = np.random.default_rng(9)
+    q = np.concatenate([sv[rng.integers(0, len(sv), 150)] + rng.normal(0, 0.03, (150, 3)),
+                        rng.uniform(sv.min(0) - 0.1, sv.max(0) + 0.1, (100, 3))]).astype(np.float32)
+    got = scan.inside_mesh(q)
+    want = MO.inside_mesh(sv, sf, q, step, origin, dims, tri_num, tri_idx)
+    np.testing.assert_array_equal(got, want)
+    assert (got > 0).sum() > 20 and (got < 0).sum() > 20
+    scan.close()
+
+
 @pytest.mark.parametrize("spread", [0.01, 0.2, 3.0])
 def test_nearest_points_match_bruteforce_rule(small, spread):
     """near, far and way-outside-the-grid queries against the oracle's brute-force search"""

