@@ -119,6 +119,7 @@ if __name__ == "__main__":
     ap.add_argument("--cfg3", action="store_true"); ap.add_argument("--cfg5", action="store_true")
     ap.add_argument("--cfg5x", action="store_true")
     ap.add_argument("--frames", type=int, default=8); ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--iters", type=int, default=300, help="cfg5x: iterations of the fit and of the SMPL+D stage")
     a = ap.parse_args()
     if not (a.cfg3 or a.cfg5 or a.cfg5x):
         a.cfg3 = a.cfg5 = True
@@ -127,4 +128,4 @@ if __name__ == "__main__":
     if a.cfg5:
         print(json.dumps(cfg5(a.reps, frames=a.frames)), flush=True)
     if a.cfg5x:
-        print(json.dumps(cfg5x(a.reps, frames=a.frames)), flush=True)
+        print(json.dumps(cfg5x(a.reps, frames=a.frames, iters=a.iters, disp_iters=a.iters)), flush=True)
