@@ -429,9 +429,11 @@ SMPLX_PARAMS = ("global_transl", "scale", "pose", "betas", "global_orient", "ley
                 "left_hand_pose", "right_hand_pose")                                   # smplify.py:167-173
 
 
-def fit_smplx(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=(), mask_pairwise="exact"):
+def fit_smplx(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=(), mask_pairwise="exact", scan=None):
     """The reference loop for smpl_type='smplx' (smplify.py:103-226): body_pose = init[:, 3:66], zero eyes / hand
-    PCA, jaw and expression never optimised, hands + face keypoints in the loss (use_hand_face)."""
+    PCA, jaw and expression never optimised, hands + face keypoints in the loss (use_hand_face).  scan = (verts,
+    faces): use_mesh=True - constant scale scan_height / 1.7 and the point-cloud loss after num_iters // 3
+    (smplify.py:146-156,205-210), as in fit()."""
     from bodyfitting_amd.synthetic import pack_keypoints_smplx
     m = to_torch_model(model, dtype)
     gmm = to_torch_gmm(gmm_bufs, dtype)
@@ -441,6 +443,12 @@ def fit_smplx(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snap
     kps = [None if k is None else torch.as_tensor(pack_keypoints_smplx(k)).to(dtype) for k in problem["keypoints"]]
     n_use = len(problem["use_frames"])
     c = float(problem.get("constant_scale", 0.3))
+    scan_height = None
+    if scan is not None:                                                         # smplify.py:146-156
+        from oracle import mesh_oracle as MO
+        scan_v, scan_f = np.asarray(scan[0], np.float64), np.asarray(scan[1])
+        scan_height = float((scan_v.max(0) - scan_v.min(0))[1])
+        c = scan_height / 1.7
     init_pose = torch.as_tensor(problem["init_pose"], dtype=torch.float32).to(dtype)
     P = {"global_transl": torch.zeros(1, 3, dtype=dtype), "scale": torch.ones(1, 1, dtype=dtype),
          "pose": init_pose[:, 3:66].clone(), "betas": torch.as_tensor(problem["init_betas"], dtype=torch.float32).to(dtype).clone(),
@@ -467,6 +475,9 @@ def fit_smplx(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snap
         if mask_in is not None and i > (num_iters // 3):
             loss = loss + 5 * multview_mask_loss(mask_in[0], mask_in[1], bv[0], mask_in[2], mask_in[3], imsize=problem["imsize"],
                                                  pairwise=mask_pairwise)
+        if scan is not None and i > (num_iters // 3):                             # smplify.py:205-210
+            _, cpts, _ = MO.nearest_bruteforce(scan_v, scan_f, bv.detach().numpy()[0])
+            loss = loss + 5 * (MO.point_cloud_loss(bv, torch.as_tensor(cpts, dtype=dtype)) / scan_height * problem["imsize"])
         opt.zero_grad()
         loss.backward()
         opt.step()
