@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--events", action="store_true", help="keep the HIP event records inside the timed steps (4 per step, ~13 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (dense schedule, batched shards)")
-    ap.add_argument("--cpu-frames", type=int, default=3)
+    ap.add_argument("--cpu-frames", type=int, default=12)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (validation on a box with fewer GPUs than ranks)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (validation of the N>1 code path on a 1-GPU box)")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed spin before the W warmup steps (clock ramp, page-in)")

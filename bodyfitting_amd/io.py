@@ -70,3 +70,27 @@ def load_obj_mesh(mesh_file):
                 if len(idx) > 3:
                     faces.append([idx[2], idx[3], idx[0]])
     return np.array(verts), np.array(faces) - 1
+
+
+def load_genebody_cameras(annots, views, crops=None, load_size=512):
+    """GeneBody `annots.npy` camera dict -> (Ks [V,3,3] float32, c2ws [V,4,4] float32) for the listed views, as
+    apps/genebody_fitting.py:75,134-140 prepares them: `annots` is the file path or the loaded dict (its 'cams' entry
+    or the cams dict itself: 'K'[n,3,3], 'RT'[n,4,4] = camera-to-world); view i of `views` reads entry i of the
+    arrays (the app enumerates its view list); `crops[i]` = (top, left, bottom, right) of the square crop that was
+    resized to load_size: the principal point moves by (left, top) and both rows are rescaled."""
+    if isinstance(annots, (str, bytes)) or hasattr(annots, "__fspath__"):
+        annots = np.load(annots, allow_pickle=True).item()
+    cams = annots["cams"] if "cams" in annots else annots
+    Ks, Rts = [], []
+    for i, _view in enumerate(views):
+        K = np.array(cams["K"][i], dtype=np.float64, copy=True)
+        Rt = np.array(cams["RT"][i], dtype=np.float64, copy=True)
+        if crops is not None:
+            top, left, bottom, right = crops[i]
+            K[0, 2] -= left
+            K[1, 2] -= top
+            K[0, :] *= load_size / float(right - left)
+            K[1, :] *= load_size / float(bottom - top)
+        Ks.append(K.astype(np.float32))
+        Rts.append(Rt.astype(np.float32))
+    return np.stack(Ks), np.stack(Rts)

@@ -68,3 +68,18 @@ def test_openpose_reader(tmp_path):
     np.testing.assert_allclose(got["pose"], pose)  # the higher-scoring person wins
     p.write_text(json.dumps({"people": []}))
     assert io.load_openpose(str(p)) is None
+
+
+def test_genebody_camera_dict(tmp_path):
+    """annots.npy -> Ks / c2ws with the crop adjustment of apps/genebody_fitting.py:134-140"""
+    rng = np.random.default_rng(0)
+    K = np.tile(np.array([[1200.0, 0, 640], [0, 1190.0, 360], [0, 0, 1]]), (3, 1, 1))
+    RT = np.tile(np.eye(4), (3, 1, 1)); RT[:, :3, 3] = rng.normal(size=(3, 3))
+    path = tmp_path / "annots.npy"
+    np.save(path, {"cams": {"K": K, "RT": RT}}, allow_pickle=True)
+    Ks, c2ws = io.load_genebody_cameras(str(path), views=[0, 5, 9], crops=[(100, 200, 612, 712)] * 3, load_size=256)
+    assert Ks.dtype == np.float32 and Ks.shape == (3, 3, 3) and c2ws.shape == (3, 4, 4)
+    np.testing.assert_allclose(Ks[0], [[600.0, 0, 220.0], [0, 595.0, 130.0], [0, 0, 1]], rtol=1e-6)
+    np.testing.assert_allclose(c2ws, RT.astype(np.float32))
+    Ks2, _ = io.load_genebody_cameras({"K": K, "RT": RT}, views=[0])
+    np.testing.assert_allclose(Ks2[0], K[0])
