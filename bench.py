@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (dense schedule, batched shards)")
     ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--no-configs", action="store_true", help="skip the config-3 / config-5 legs of `extra`")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (validation on a box with fewer GPUs than ranks)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (validation of the N>1 code path on a 1-GPU box)")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed spin before the W warmup steps (clock ramp, page-in)")
@@ -258,6 +259,15 @@ def main():
             extra[f"batch_{fb}_frames"] = {"value": fb * n / w, "unit": "frames/s", "ms_per_step": w / n * 1e3,
                                            "device_fit_ms": e["fit_ms"] / e["calls"], "device_mesh_ms": e["mesh_ms"] / e["calls"]}
             bb.close()
+        # the dense-loss configurations of BASELINE.json (3 and 5 as stated) on this GPU: tools/bench_configs.py
+        if not a.no_configs:
+            try:
+                sys.path.insert(0, os.path.join(REPO, "tools"))
+                import bench_configs as BC
+                extra["config_3"] = BC.cfg3(2)
+                extra["config_5"] = BC.cfg5x(2)
+            except Exception as exc:                       # (never let a side leg take the headline line down)
+                extra["configs_error"] = repr(exc)
         out["extra"] = extra
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, gmm, a.cpu_frames, a.views, a.iters)
