@@ -219,7 +219,6 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     up_f(m->v_template, d->v_template, (size_t)nv * 3);
     up_f(m->shapedirs, d->shapedirs, (size_t)nv * 3 * nb);
     up_f(m->posedirs, d->posedirs, (size_t)npf * 3 * nv);
-    m->posedirs_host.assign(d->posedirs, d->posedirs + (size_t)npf * 3 * nv);
     if (d->n_faces > 0 && d->faces) {
         for (int i = 0; i < d->n_faces * 3; ++i)
             if (d->faces[i] < 0 || d->faces[i] >= nv) { delete m; return fail(BF_ERR_INVALID, "bf_model_create: face index out of range"); }

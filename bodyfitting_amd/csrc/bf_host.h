@@ -66,7 +66,6 @@ struct bf_model {
     DevBuf<int> v_nzj;            // sparse skinning rows (MeshTab::v_nnz)
     DevBuf<float> v_nzw;
     DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass
-    std::vector<float> posedirs_host;
     std::vector<int> faces_host;  // body-model topology (for the SMPL+D stage), optional
     DevBuf<int> faces_d, adj_start, adj;   // faces and the vertex -> (face, corner) lists, built on first use
 };

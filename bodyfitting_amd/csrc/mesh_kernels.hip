@@ -833,3 +833,21 @@ bf_mesh_epilogue_kernel(MeshTab M, const float *__restrict__ state, const float 
         }
     }
 }
+
+// out[c][r] = in[r][c]: posedirs [npf][3NV] -> posedirsT [3NV][npf] for the reverse pass, once per model.  32 x 32 tiles through
+// LDS (padded row: no bank conflicts), both sides coalesced.  grid (ceil(cols / 32), ceil(rows / 32)), 256 threads.
+extern "C" __global__ void __launch_bounds__(256) bf_transpose_kernel(const float *__restrict__ in, int rows, int cols, float *__restrict__ out) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + k * 8, c = c0 + tx;
+        tile[ty + k * 8][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + k * 8, r = r0 + tx;
+        if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][ty + k * 8];
+    }
+}

@@ -16,6 +16,7 @@ extern "C" __global__ void bf_grid_fill_kernel(ScanDev, int *, int *);
 extern "C" __global__ void bf_grid_pack_kernel(ScanDev, const int *, int *, float4 *, int);
 extern "C" __global__ void bf_face_normal_kernel(const float *, const int *, int, float *);
 extern "C" __global__ void bf_inside_mesh_kernel(ScanDev, const float *, int, float *);
+extern "C" __global__ void bf_transpose_kernel(const float *, int, int, float *);
 extern "C" __global__ void bf_contour_kernel(const unsigned char *, int, int, int, float *, int *, unsigned *);
 extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const float *, float *, float *, float *);
 extern "C" __global__ void bf_mask_contour_kernel(MaskIO, const float *, int *, float *, float *);
@@ -174,12 +175,12 @@ int bf_ensure_dense_buffers(bf_batch *b) {
         HIP_TRY(hipMemset(b->ext.p, 0, b->ext.n * sizeof(float)));
     }
     if (!m->posedirsT.p) {
-        // [3NV][npf] transpose for the reverse pass (thread = pose-feature row, contiguous reads)
-        const size_t ncols = nv3, npf = m->npf;
-        std::vector<float> t(ncols * npf);
-        for (size_t p = 0; p < npf; ++p)
-            for (size_t c = 0; c < ncols; ++c) t[c * npf + p] = m->posedirs_host[p * ncols + c];
-        HIP_TRY(m->posedirsT.upload(t));
+        // [3NV][npf] transpose for the reverse pass (thread = pose-feature row, contiguous reads), built on the device
+        HIP_TRY(m->posedirsT.alloc((size_t)nv3 * m->npf));
+        hipLaunchKernelGGL(bf_transpose_kernel, dim3((nv3 + 31) / 32, (m->npf + 31) / 32), dim3(256), 0, b->stream,
+                           (const float *)m->posedirs.p, m->npf, (int)nv3, m->posedirsT.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(b->stream));          // (once per model; other batches of the model use other streams)
     }
     return BF_OK;
 }
