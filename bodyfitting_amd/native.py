@@ -248,6 +248,10 @@ class FrameBatch:
         xy = _f32(np.concatenate(flat, 0)) if sum(len(c) for c in flat) else np.zeros((1, 2), np.float32)
         _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, mp, _lib.iptr(counts), _lib.fptr(xy)), "bf_batch_set_masks")
 
+    def clear_masks(self):
+        """detach the silhouettes (use_mask=False for the next fit)"""
+        _lib.check(self._lib.bf_batch_set_masks(self._h, 0, None, 0, 0, None, None, None), "bf_batch_set_masks")
+
     def mask_loss(self, hyper=None):
         loss = np.empty(self.F, np.float32)
         dv = np.empty((self.F, self.model.n_verts, 3), np.float32)

@@ -53,6 +53,27 @@ class SMPLify:
         self._dev = assets.get_device_model(smpl_type, gender, self.device)
         model = assets.get_model(smpl_type, gender)
         self.smpl_faces = np.asarray(model["faces"]).astype(np.int32).reshape(1, -1, 3)    # smplify.py:82
+        self._batches = {}                  # (frames, views) -> FrameBatch: device buffers, stream and pinned mirrors are kept between calls
+
+    def _batch(self, F, V):
+        """The reference builds everything anew per frame (body_fitting.py:82); creating and destroying the device side of a
+        batch costs ~9 ms - 17x the 100-iteration fit itself - so a batch is kept per shape and re-armed by set_init."""
+        b = self._batches.get((F, V))
+        if b is None:
+            b = self._batches[(F, V)] = FrameBatch(self._dev, F, V)
+            b._had_scans = b._had_masks = False
+        return b
+
+    def close(self):
+        for b in self._batches.values():
+            b.close()
+        self._batches.clear()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------------------------------
     def fit_frames(self, init_betas, init_poses, c2ws, Ks, keypoints, n_use_frames=None, imsize=512,
@@ -70,19 +91,28 @@ class SMPLify:
         F = init_betas.shape[0]
         c2ws = np.asarray(c2ws, np.float32).reshape(F, -1, 4, 4)
         V = c2ws.shape[1]
-        batch = FrameBatch(self._dev, F, V)
+        batch = self._batch(F, V)
         dev_scans = []
         disp = None
+        ok = False
         try:
+            if batch._had_scans and scans is None:
+                batch.set_scans(None)
+                batch._had_scans = False
+            if batch._had_masks and masks is None:
+                batch.clear_masks()
+                batch._had_masks = False
             batch.set_cameras(c2ws, Ks)
             batch.set_keypoints(keypoints, n_use_frames)
             batch.set_init(init_betas, init_poses)
             if scans is not None:
                 dev_scans = [Scan(v, f, device=self.device) for v, f in scans]
                 batch.set_scans(dev_scans)
+                batch._had_scans = True
             if masks is not None:
                 masks = np.asarray(masks, np.uint8).reshape(F, -1, *np.asarray(masks).shape[-2:])
                 batch.set_masks(masks, mask_view_index, None)      # contours on the device (loss.py:73-83)
+                batch._had_masks = True
             hyper = make_hyper(imsize=imsize, constant_scale=constant_scale)
             n = self.num_iters if num_iters is None else num_iters
             batch.fit(n, hyper, flags | 4)
@@ -91,10 +121,16 @@ class SMPLify:
             if displacement and scans is not None:
                 batch.fit_displacement(n, hyper)
                 disp = batch.get_displacement()
+            ok = True
         finally:
-            batch.close()
+            if dev_scans:
+                batch.set_scans(None)          # the scans of this call go away with it
+                batch._had_scans = False
             for sc in dev_scans:
                 sc.close()
+            if not ok:                         # do not keep a batch in an unknown state
+                self._batches.pop((F, V), None)
+                batch.close()
         out = []
         for f in range(F):
             p = split_params(params[f], self._dev.n_joints, self._dev.n_betas)

@@ -203,6 +203,25 @@ def test_python_mirror_end_to_end(smpl_model, gmm, tmp_path):
     assert first == "v %.4f %.4f %.4f" % tuple(res["vertices"][0])
 
 
+def test_smplify_mirror_reuses_its_batch_between_frames(smpl_model, gmm):
+    """one SMPLify instance, frame after frame (apps/genebody_fitting.py:183-192): the device batch is kept and re-armed,
+    results are those of the goldens for each frame, whatever was fitted before"""
+    from bodyfitting_amd import assets
+    from bodyfitting_amd.smplify import SMPLify
+    assets.register_model(smpl_model, "smpl", "neutral")
+    assets.register_gmm(gmm)
+    fitter = SMPLify(smpl_type="smpl", num_iters=100, gender="neutral", device=0, debug=False)
+    for frame in (1, 0, 1):
+        g = load_golden(f"cfg2_48view_100it_f{frame}.npz")
+        p = S.make_problem(smpl_model, frame=frame, n_views=48)
+        res = fitter((p["init_betas"], p["init_pose"]), p["c2ws"], p["Ks"], p["keypoints"], use_frames=p["use_frames"], imsize=512)
+        for key, want in (("pose", "it100_pose"), ("betas", "it100_betas"), ("global_orient", "it100_global_orient"),
+                          ("scale", "it100_scale"), ("joints", "joints")):
+            np.testing.assert_allclose(res[key], g[want], atol=FIT_TOL, err_msg=f"frame {frame} {key}")
+    assert len(fitter._batches) == 1
+    fitter.close()
+
+
 def test_batched_mfma_pose_blend_matches_per_frame_path(dev_model, smpl_model):
     """>= 16 frames: the pose blend runs as one fp32-MFMA GEMM over the batch; same vertices as frame by frame"""
     rng = np.random.default_rng(11)
