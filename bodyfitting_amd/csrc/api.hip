@@ -482,8 +482,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
     const size_t F = n_frames, np = m->np;
     bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
     b->ring.assign((size_t)bf_batch::kRing * 4, nullptr);
-    for (auto &e : b->ring) ok = ok && hipEventCreate(&e) == hipSuccess;
-    b->ev = b->ring.data();
+    b->ev = b->ring.data();          // (the events of a slot are created when the slot is first used: 4096 creations cost 4 ms)
     ok = ok && b->params0.alloc(F * np) == hipSuccess;
     {
         auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };          // 256-byte slices
@@ -749,6 +748,8 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (dense_losses) flags &= ~BF_FIT_DENSE;
     const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES), fetch = flags & BF_FIT_FETCH;
     b->ev = b->ring.data() + (size_t)(b->ring_n % bf_batch::kRing) * 4;
+    for (int k = 0; k < 4; ++k)
+        if (!b->ev[k]) HIP_TRY(hipEventCreate(&b->ev[k]));
     const size_t fb = sizeof(float);
     // (a small fetch is cheaper as a copy node inside the graph than as a second stream with two event hand-offs)
     const bool big_fetch = (want_v ? b->res.n : b->res_small) * sizeof(float) >= (size_t)512 * 1024;
