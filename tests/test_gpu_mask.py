@@ -123,3 +123,25 @@ def test_set_masks_extracts_the_contours_itself(dev_model, smpl_model):
     np.testing.assert_array_equal(out[0][0], out[1][0])
     np.testing.assert_array_equal(out[0][1], out[1][1])
     assert np.isfinite(out[0][0]).all() and out[0][0][0] > 0
+
+
+def test_two_frames_device_contours_match_single_frames(dev_model, smpl_model):
+    """F = 2 with different silhouettes, contours extracted on the device for all F x M masks in one launch:
+    each frame's loss and gradient are bit for bit those of the frame alone"""
+    probs = [S.make_problem(smpl_model, frame=f, n_views=8, mask_frames=MASK_FRAMES) for f in (0, 1)]
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem(probs)
+    masks = np.stack([np.array(p["masks"]) for p in probs])
+    view_index = [probs[0]["use_frames"].index(f) for f in MASK_FRAMES]
+    b = N.FrameBatch(dev_model, 2, 8)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose); b.set_masks(masks, view_index, None)
+    loss2, dv2 = b.mask_loss()
+    b.close()
+    for i in range(2):
+        b1 = N.FrameBatch(dev_model, 1, 8)
+        b1.set_cameras(c2w[i:i + 1], K[i:i + 1]); b1.set_keypoints(kp[i:i + 1], ndiv[i:i + 1]); b1.set_init(betas[i:i + 1], pose[i:i + 1])
+        b1.set_masks(masks[i:i + 1], view_index, None)
+        loss1, dv1 = b1.mask_loss()
+        b1.close()
+        np.testing.assert_array_equal(loss2[i], loss1[0])
+        np.testing.assert_array_equal(dv2[i], dv1[0])
+    assert loss2[0] != loss2[1]
