@@ -5,7 +5,7 @@ extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const Hyper
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
 extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *, const float *);
 extern "C" int bf_mesh_use_multi(int npf, int n);
-extern "C" int bf_mesh_multi_launch(const MeshTab *, const float *, int, float *, float *, float *, float *, hipStream_t);
+extern "C" int bf_mesh_multi_launch(const MeshTab *, const float *, int, float *, float *, float *, float *, float *, hipStream_t);
 extern "C" __global__ void bf_mesh_epilogue_kernel(MeshTab, const float *, const float *, float *, float *, float *, float *);
 extern "C" hipError_t bf_poseblend_launch(const MeshTab *M, const float *state, int n, float *featT, int kpad, int fpad, float *pose_off, hipStream_t stream);
 extern "C" __global__ void bf_mesh_epilogue_batch_kernel(MeshTab M, const float *state, const float *pose_off, int n_frames, float *vraw, float *vout, float *xpart);
@@ -369,7 +369,8 @@ int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
 
 int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw, int *lmk_vid,
-                   float *lmk_w) {
+                   float *lmk_w, float *dvzero, bool *zeroed) {
+    if (zeroed) *zeroed = false;
     dim3 grid(m->mesh.n_tiles, n);
     const float *pose_off = nullptr;
     if (n >= BF_MFMA_MIN_FRAMES) {
@@ -396,7 +397,9 @@ int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, floa
         hipLaunchKernelGGL(bf_mesh_epilogue_kernel, grid, dim3(128), 0, stream, m->mesh, state_dev, pose_off, vraw, vout,
                            (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed);
     } else if (bf_mesh_use_multi(m->npf, n)) {
-        const int e = bf_mesh_multi_launch(&m->mesh, state_dev, n, vraw, vout, (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed, stream);
+        const int e = bf_mesh_multi_launch(&m->mesh, state_dev, n, vraw, vout, (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed,
+                                           dvzero, stream);
+        if (zeroed && dvzero) *zeroed = true;
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     } else
     hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, m->mesh,

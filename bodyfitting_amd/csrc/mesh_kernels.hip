@@ -262,7 +262,7 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
 template <int FPW>
 __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
 bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, float *__restrict__ vraw, float *__restrict__ vout,
-                     float *__restrict__ xpart, float *__restrict__ vposed) {
+                     float *__restrict__ xpart, float *__restrict__ vposed, float *__restrict__ dvzero) {
     static_assert(FPW == 1 || FPW == 2 || FPW == 4 || FPW == 8, "frames per workgroup");
     constexpr int COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
@@ -385,6 +385,7 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
         if (vraw) vraw[o] = r;
         if (vout) vout[o] = (r + sb[k]) * sb[3] * sb[4];
         if (vposed) vposed[o] = vp[k];
+        if (dvzero) dvzero[o] = 0.f;                          // dL/dvertices starts the iteration at zero: saves a memset launch
     }
     if (xpart) {
         // this tile's share of J_regressor_extra . vertices (models/smpl.py:72), per frame
@@ -407,7 +408,7 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
 }
 
 extern "C" int bf_mesh_multi_launch(const MeshTab *M, const float *state, int n, float *vraw, float *vout, float *xpart, float *vposed,
-                                    hipStream_t stream) {
+                                    float *dvzero, hipStream_t stream) {
     constexpr int COLS = BF_MESH_TILE * 3;
     const int fpw = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
     const int rows = (M->npf + BF_MESH_RG - 1) / BF_MESH_RG;
@@ -421,10 +422,10 @@ extern "C" int bf_mesh_multi_launch(const MeshTab *M, const float *state, int n,
         if (e != hipSuccess) return (int)e;
     }
     switch (fpw) {
-    case 1: hipLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed); break;
-    case 2: hipLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed); break;
-    case 4: hipLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed); break;
-    default: hipLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed); break;
+    case 1: hipLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero); break;
+    case 2: hipLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero); break;
+    case 4: hipLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero); break;
+    default: hipLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero); break;
     }
     return (int)hipGetLastError();
 }

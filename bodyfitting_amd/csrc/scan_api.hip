@@ -260,10 +260,12 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
                        (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
     HIP_TRY(hipGetLastError());
+    bool zeroed = false;                      // dL/dvertices = 0 before the keypoint / silhouette kernels add into it
     int rc = bf_launch_mesh(m, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
-                            b->vposed.p, kp ? b->jraw.p : nullptr, kp ? b->lmk_vid.p : nullptr, kp ? b->lmk_w.p : nullptr);
+                            b->vposed.p, kp ? b->jraw.p : nullptr, kp ? b->lmk_vid.p : nullptr, kp ? b->lmk_w.p : nullptr,
+                            (kp || masks) ? b->dvout.p : nullptr, &zeroed);
     if (rc) return rc;
-    if (kp || masks) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
+    if ((kp || masks) && !zeroed) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
     if (kp) { rc = launch_kp(b, h); if (rc) return rc; }
     if (masks) { rc = launch_mask_kernels(b, mask_weight, false); if (rc) return rc; }
     if (scans) {
