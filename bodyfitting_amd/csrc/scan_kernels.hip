@@ -543,20 +543,27 @@ bf_kp_loss_kernel(KpIO Q, const float *__restrict__ jraw, const float *__restric
         for (int q = Q.cj_start[cj]; q < Q.cj_start[cj + 1]; ++q) acc += s_g[Q.cj_list[q] * 4 + k];
         e[EXT_G + i] = acc * sc;
     }
-    if (tid < 4) {
-        // d/dt, d/ds through the chain-joint-based loss joints only (the vertex-based ones go through dvout)
-        float acc = 0.f;
-        for (int q = 0; q < nl; ++q) {
-            if (Q.joint_map[q] >= Q.nj) continue;
-            if (tid < 3) acc += s_g[q * 4 + tid];
-            else acc += s_g[q * 4] * (s_x[q * 3] + t0) + s_g[q * 4 + 1] * (s_x[q * 3 + 1] + t1) + s_g[q * 4 + 2] * (s_x[q * 3 + 2] + t2);
+    {
+        // d/dt, d/ds through the chain-joint-based loss joints only (the vertex-based ones go through dvout), and the loss value:
+        // five sums over the loss joints, one WAVE each (waves 3..7; lane l takes joints l, l + 64, ... in order, then a fixed
+        // xor tree) - a single thread walking 135 LDS entries per sum was a third of this kernel's time
+        const int wv = tid >> 6, lane = tid & 63, which = wv - 3;
+        if (which >= 0 && which < 5) {
+            float acc = 0.f;
+            for (int q = lane; q < nl; q += 64) {
+                const bool chain = Q.joint_map[q] < Q.nj;
+                if (which < 3) acc += chain ? s_g[q * 4 + which] : 0.f;
+                else if (which == 3) acc += chain ? s_g[q * 4] * (s_x[q * 3] + t0) + s_g[q * 4 + 1] * (s_x[q * 3 + 1] + t1) + s_g[q * 4 + 2] * (s_x[q * 3 + 2] + t2) : 0.f;
+                else acc += s_g[q * 4 + 3];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) {
+                if (which < 3) e[EXT_K + which] = acc * sc;
+                else if (which == 3) e[EXT_K + 3] = acc * cs;
+                else terms[(size_t)f * 4] = acc / ndiv_f;
+            }
         }
-        e[EXT_K + tid] = tid < 3 ? acc * sc : acc * cs;
-    }
-    if (tid == 4) {
-        float acc = 0.f;
-        for (int q = 0; q < nl; ++q) acc += s_g[q * 4 + 3];
-        terms[(size_t)f * 4] = acc / ndiv_f;
     }
     // vertex-based joints: their vertices may coincide, so the order of the additions matters.  Every (joint, corner)
     // item gets its rank among the earlier items on the same vertex (one batched scan of the item list in LDS); round r
