@@ -243,7 +243,7 @@ static int launch_kp(bf_batch *b, const bf_hyper &h) {
     KpIO K = m->kp;
     K.n_views = b->V; K.sigma2 = h.sigma * h.sigma; K.coeff = h.imsize / 1024.0f;
     const int NLP = (K.nl + 31) & ~31, slots = std::max(1, 512 / NLP);
-    const size_t smem = sizeof(float) * ((size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + (size_t)K.nl * 18);    // (+ item list)
+    const size_t smem = sizeof(float) * ((size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + 1024 + (size_t)K.nl * 3 + 16);   // (+ sort keys, item weights)
     hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), smem, b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
                        (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
                        (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p);

@@ -565,62 +565,59 @@ bf_kp_loss_kernel(KpIO Q, const float *__restrict__ jraw, const float *__restric
             }
         }
     }
-    // vertex-based joints: their vertices may coincide, so the order of the additions matters.  Every (joint, corner)
-    // item gets its rank among the earlier items on the same vertex (one batched scan of the item list in LDS); round r
-    // applies the items of rank r, so each vertex receives its additions in joint order - typically in one or two rounds
-    // instead of one barrier + global round trip per joint.
+    // vertex-based joints: their vertices may coincide, so the order of the additions matters.  The (joint, corner) items
+    // are SORTED by (vertex, item index) - a bitonic network over keys in LDS - so the items of a vertex become one run in
+    // joint order; the thread at the start of a run adds them up in that order and applies the total with a single
+    // read-modify-write (dL/dvertices is zero when this kernel starts, so the bits are those of adding item by item).
+    // (The first version ranked every item against all earlier ones: O(n^2) LDS reads, 15 of this kernel's 26 us.)
     float *dv = dvout + (size_t)f * Q.nv * 3;
     const int n_ori = Q.nj + Q.n_selector;
-    int *s_vid = (int *)(s_x + nl * 3 + 8);               // [nl * 3]
-    int *s_max = s_vid + nl * 3;
-    const int n_items = nl * 3;
+    int *s_key = (int *)(s_x + nl * 3 + 8);               // [N] (vertex << 10 | item), 0x7fffffff = no vertex
+    float *s_w = (float *)(s_key + 1024);                 // [n_items] weight of the item
+    const int n_items = nl * 3, N = n_items <= 512 ? 512 : 1024;
     __syncthreads();
-    if (tid == 0) *s_max = 0;
-    for (int i = tid; i < n_items; i += 512) {
-        const int q = i / 3, c = i - q * 3, src = Q.joint_map[q];
-        int vid = -1;
-        if (src >= Q.nj) {
-            if (src < n_ori) { if (c == 0) vid = Q.selector_ids[src - Q.nj]; }
-            else vid = lmk_vid[((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c];
-        }
-        s_vid[i] = vid;
-    }
-    __syncthreads();
-    int my_rank[2] = {-1, -1}, my_vid[2] = {-1, -1};
-    float my_w[2] = {0.f, 0.f};
-#pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int i = tid + 512 * rr;
+    for (int i = tid; i < N; i += 512) {
+        int key = 0x7fffffff;
         if (i < n_items) {
-            const int vid = s_vid[i];
-            if (vid >= 0) {
-                int rank = 0;
-                for (int j0 = 0; j0 < i; j0 += 16) {
-                    int t[16];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) t[u] = s_vid[min(j0 + u, n_items - 1)];
-#pragma unroll
-                    for (int u = 0; u < 16; ++u) rank += (j0 + u < i && t[u] == vid) ? 1 : 0;
+            const int q = i / 3, c = i - q * 3, src = Q.joint_map[q];
+            int vid = -1;
+            float w = 1.f;
+            if (src >= Q.nj) {
+                if (src < n_ori) { if (c == 0) vid = Q.selector_ids[src - Q.nj]; }
+                else {
+                    const size_t l = ((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c;
+                    vid = lmk_vid[l];
+                    w = lmk_w[l];
                 }
-                const int q = i / 3, c = i - q * 3, src = Q.joint_map[q];
-                my_rank[rr] = rank; my_vid[rr] = vid;
-                my_w[rr] = src < n_ori ? 1.f : lmk_w[((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c];
-                atomicMax(s_max, rank);
             }
+            s_w[i] = w;
+            if (vid >= 0) key = (vid << 10) | i;
         }
+        s_key[i] = key;
     }
     __syncthreads();
-    const int n_rounds = *s_max + 1;
-    for (int r = 0; r < n_rounds; ++r) {
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            if (my_rank[rr] == r) {
-                const int q = (tid + 512 * rr) / 3;
-                float *o = dv + (size_t)my_vid[rr] * 3;
-                o[0] += my_w[rr] * s_g[q * 4]; o[1] += my_w[rr] * s_g[q * 4 + 1]; o[2] += my_w[rr] * s_g[q * 4 + 2];
+    for (int k = 2; k <= N; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int t = tid; t < N / 2; t += 512) {
+                const int lo = ((t / jj) * jj * 2) + (t % jj), hi = lo + jj;
+                const int a = s_key[lo], b2 = s_key[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b2) == up) { s_key[lo] = b2; s_key[hi] = a; }
             }
+            __syncthreads();
         }
-        __threadfence_block();
-        __syncthreads();
+    for (int p = tid; p < N; p += 512) {
+        const int key = s_key[p];
+        if (key == 0x7fffffff) continue;
+        const int vid = key >> 10;
+        if (p > 0 && (s_key[p - 1] >> 10) == vid) continue;            // not the start of its vertex's run
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int r = p; r < N && (s_key[r] >> 10) == vid && s_key[r] != 0x7fffffff; ++r) {
+            const int item = s_key[r] & 1023, q = item / 3;
+            const float w = s_w[item];
+            a0 += w * s_g[q * 4]; a1 += w * s_g[q * 4 + 1]; a2 += w * s_g[q * 4 + 2];
+        }
+        float *o = dv + (size_t)vid * 3;
+        o[0] += a0; o[1] += a1; o[2] += a2;
     }
 }
