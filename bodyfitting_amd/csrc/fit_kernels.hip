@@ -1584,10 +1584,13 @@ extern "C" hipError_t bf_fit_launch(const FitTab *T, const FrameIO *io, const Hy
                                     const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
     const bool smpl = T->nj == 24 && T->nb == 10 && T->ns == 11 && T->nl == 25;
     const bool ext = io->ext != nullptr;
+    // SMPL-X in the dense schedule (keypoints through bf_kp_loss_kernel: no selector vertices, no loss joints here): sizes fixed
+    // at compile time like SMPL's, the phases stay the table-driven ones
+    const bool smplx_dense = ext && T->nj == 55 && T->nb == 10 && T->ns == 0 && T->nl == 0;
     auto kern = smpl ? (ext ? fit_kernel<24, 10, 11, 25, true> : fit_kernel<24, 10, 11, 25, false>)
-                     : (ext ? fit_kernel<0, 0, 0, 0, true> : fit_kernel<0, 0, 0, 0, false>);
-    static size_t attr[4] = {0, 0, 0, 0};
-    size_t &have = attr[(smpl ? 2 : 0) + (ext ? 1 : 0)];
+                     : (smplx_dense ? fit_kernel<55, 10, 0, 0, true> : (ext ? fit_kernel<0, 0, 0, 0, true> : fit_kernel<0, 0, 0, 0, false>));
+    static size_t attr[5] = {0, 0, 0, 0, 0};
+    size_t &have = attr[smplx_dense ? 4 : (smpl ? 2 : 0) + (ext ? 1 : 0)];
     if (smem > 64 * 1024 && smem > have) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
