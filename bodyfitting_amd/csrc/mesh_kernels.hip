@@ -48,8 +48,11 @@ bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__r
                      const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
                      const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all) {
     __shared__ float R[64 * 9], J[64 * 3], GR[64 * 9], Gt[64 * 3];
+    __shared__ int s_ls[66], s_lj[64], s_par[64];          // tree levels and parents: read once, not once per level (dependent global loads)
     const int tid = threadIdx.x, nt = 128, f = blockIdx.x;
     const int nj = T.nj, nb = T.nb, npf = T.npf;
+    if (tid < nj) { s_lj[tid] = T.level_joints[tid]; s_par[tid] = T.parents[tid]; }
+    if (tid <= T.n_levels && tid < 66) s_ls[tid] = T.level_start[tid];
     const float *pk = packed ? packed + (size_t)f * T.np : nullptr;
     const float *beta = pk ? pk + T.off_beta : betas + (size_t)f * nb;
     StateView st = bf_state_view(state + (size_t)f * bf_state_stride(nj, npf, nb), nj, npf, nb);
@@ -75,9 +78,9 @@ bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__r
     if (tid >= 64 && tid < 67) Gt[tid - 64] = J[tid - 64];
     __syncthreads();
     for (int lev = 1; lev < T.n_levels; ++lev) {
-        int ls = T.level_start[lev], cnt = (T.level_start[lev + 1] - ls) * 3;
+        int ls = s_ls[lev], cnt = (s_ls[lev + 1] - ls) * 3;
         for (int idx = tid; idx < cnt; idx += nt) {
-            int i = T.level_joints[ls + idx / 3], r = idx % 3, p = T.parents[i];
+            int i = s_lj[ls + idx / 3], r = idx % 3, p = s_par[i];
             float g0 = GR[p * 9 + r * 3], g1 = GR[p * 9 + r * 3 + 1], g2 = GR[p * 9 + r * 3 + 2];
             const float *Ri = R + i * 9;
             GR[i * 9 + r * 3 + 0] = g0 * Ri[0] + g1 * Ri[3] + g2 * Ri[6];
