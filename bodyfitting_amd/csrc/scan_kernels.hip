@@ -408,13 +408,27 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
 #pragma unroll
         for (int f = 0; f < FPW; ++f) if (f < nf) out0[f * fstride + p] = acc[f];
     }
-    // (b) chain-matrix partials: item (f, j, row a, col b): sum_v w_vj dv_a [vp_b | 1]
-    for (int i = 511 - tid; i < nf * nj * 12; i += 512) {
-        const int f = i / (nj * 12), r = i - f * nj * 12, j = r / 12, e = r - j * 12, a = e / 4, b = e - a * 4;
+    // (b) chain-matrix partials: item (f, j) = all twelve entries sum_v w_vj dv_a [vp_b | 1] of a joint: per vertex one weight,
+    // three dv and three vp reads feed twelve products (the entry-per-thread version issued 36 LDS reads for them and was
+    // LDS-issue bound: 16 of this kernel's 46 us)
+    for (int i = 511 - tid; i < nf * nj; i += 512) {
+        const int f = i / nj, j = i - f * nj;
         const float *dv = s_dv + f * COLS, *vp = s_vp + f * COLS;
-        float acc = 0.f;
-        for (int vl = 0; vl < TV; ++vl) acc += s_w[vl * nj + j] * dv[vl * 3 + a] * (b < 3 ? vp[vl * 3 + b] : 1.f);
-        out0[f * fstride + npf + r] = acc;
+        float acc[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+        for (int vl = 0; vl < TV; ++vl) {
+            const float w = s_w[vl * nj + j];
+            const float d0 = dv[vl * 3], d1 = dv[vl * 3 + 1], d2 = dv[vl * 3 + 2];
+            const float p0 = vp[vl * 3], p1 = vp[vl * 3 + 1], p2 = vp[vl * 3 + 2];
+            const float t0 = w * d0, t1 = w * d1, t2 = w * d2;
+            acc[0] += t0 * p0; acc[1] += t0 * p1; acc[2] += t0 * p2; acc[3] += t0 * 1.f;
+            acc[4] += t1 * p0; acc[5] += t1 * p1; acc[6] += t1 * p2; acc[7] += t1 * 1.f;
+            acc[8] += t2 * p0; acc[9] += t2 * p1; acc[10] += t2 * p2; acc[11] += t2 * 1.f;
+        }
+        float *o = out0 + f * fstride + npf + j * 12;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) o[e] = acc[e];
     }
     // (c) betas (item (f, l)), transl, scale (item (f, 0..3))
     for (int i = tid; i < nf * nb; i += 512) {
