@@ -363,16 +363,30 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
         s_ts[(f * 2 + 1) * COLS + c] = ok ? g * (vraw[o] + s_sim[f * 8 + c % 3]) * s_sim[f * 8 + 4] : 0.f;   // d/ds = sum dvout . (v + t) c
     }
     __syncthreads();
-    // dvp = T_v.R^T dv : item (f, vl, b)
-    for (int i = tid; i < FPW * COLS; i += 512) {
-        const int f = i / COLS, c = i - f * COLS, vl = c / 3, b = c - vl * 3;
+    // dvp = T_v.R^T dv : item (f, vl), its three components together; with sparse skinning rows (MeshTab::v_nnz = 4 or 8
+    // non-zero weights per vertex, the rest exact zeros) only those joints are visited - 4 instead of 55 for SMPL-X
+    for (int i = tid; i < FPW * TV; i += 512) {
+        const int f = i / TV, vl = i - f * TV;
         const float *A = s_A + f * nj * 12, *dv = s_dv + f * COLS + vl * 3;
-        float acc = 0.f;
-        for (int j = 0; j < nj; ++j) {
-            const float w = s_w[vl * nj + j];
-            acc += w * (A[j * 12 + b] * dv[0] + A[j * 12 + 4 + b] * dv[1] + A[j * 12 + 8 + b] * dv[2]);
+        const float d0 = dv[0], d1 = dv[1], d2 = dv[2];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        auto add = [&](int j, float w) {
+            const float4 r0 = *(const float4 *)(A + j * 12), r1 = *(const float4 *)(A + j * 12 + 4), r2 = *(const float4 *)(A + j * 12 + 8);
+            a0 += w * (r0.x * d0 + r1.x * d1 + r2.x * d2);
+            a1 += w * (r0.y * d0 + r1.y * d1 + r2.y * d2);
+            a2 += w * (r0.z * d0 + r1.z * d1 + r2.z * d2);
+        };
+        if (M.v_nnz) {
+            const int nnz = M.v_nnz;
+            if (vl < nvt)
+                for (int q = 0; q < nnz; ++q) {
+                    const float w = M.v_nzw[(size_t)(v0 + vl) * nnz + q];
+                    if (w != 0.f) add(M.v_nzj[(size_t)(v0 + vl) * nnz + q], w);
+                }
+        } else {
+            for (int j = 0; j < nj; ++j) add(j, s_w[vl * nj + j]);
         }
-        s_dvpT[c * FPW + f] = acc;
+        s_dvpT[(vl * 3) * FPW + f] = a0; s_dvpT[(vl * 3 + 1) * FPW + f] = a1; s_dvpT[(vl * 3 + 2) * FPW + f] = a2;
     }
     __syncthreads();
     const int EXT = npf + nj * 12 + nb + 4;
