@@ -295,13 +295,13 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
         s_feat[i] = (p < npf && f < nf) ? bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).feat[p] : 0.f;
     }
     for (int i = tid; i < FPW * nj * 12; i += nt) {
-        const int f = i / (nj * 12), r = i - f * nj * 12, j = r / 12, e = r % 12, a = e / 4, b = e % 4;
+        const int f = i % FPW, r = i / FPW, j = r / 12, e = r - j * 12, a = e >> 2, b = e & 3;       // (FPW, 12: compile-time divisors)
         float x = 0.f;
         if (f < nf) {
             StateView st = bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb);
             x = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
         }
-        s_A[i] = x;
+        s_A[f * nj * 12 + r] = x;
     }
     for (int i = tid; i < FPW * 32; i += nt) {
         const int f = i >> 5, l = i & 31;

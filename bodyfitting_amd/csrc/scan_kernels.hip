@@ -331,13 +331,13 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
     const size_t sstride = bf_state_stride(nj, npf, nb);
     const int nvt = min(TV, nv - v0);
     for (int i = tid; i < FPW * nj * 12; i += 512) {
-        const int f = i / (nj * 12), r = i - f * nj * 12, j = r / 12, e = r % 12, a = e / 4, b = e % 4;
+        const int f = i % FPW, r = i / FPW, j = r / 12, e = r - j * 12, a = e >> 2, b = e & 3;       // (FPW, 12: compile-time divisors)
         float x = 0.f;
         if (f < nf) {
             StateView st = bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb);
             x = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
         }
-        s_A[i] = x;
+        s_A[f * nj * 12 + r] = x;
     }
     for (int i = tid; i < TV * nj; i += 512) s_w[i] = i < nvt * nj ? M.lbs_weights[(size_t)v0 * nj + i] : 0.f;
     for (int i = tid; i < COLS * nb; i += 512) s_sd[i] = i < nvt * 3 * nb ? M.shapedirs[(size_t)v0 * 3 * nb + i] : 0.f;
