@@ -82,9 +82,12 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
     const float4 *rec = (const float4 *)uvi + (size_t)vm * K.ns;
     float best = 3.0e38f, bu = 0.f, bv = 0.f;
     int bidx = -1;
+    // (the next tile's record is requested before this tile is scanned: one memory latency per tile was most of this kernel)
+    float4 nxt = (int)threadIdx.x < K.ns ? rec[threadIdx.x] : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < K.ns; base += 256) {
-        int s = base + threadIdx.x;
-        tile[threadIdx.x] = s < K.ns ? rec[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        tile[threadIdx.x] = nxt;
+        const int s2 = base + 256 + threadIdx.x;
+        nxt = s2 < K.ns ? rec[s2] : make_float4(0.f, 0.f, 0.f, 0.f);
         __syncthreads();
         int lim = min(256, K.ns - base);
         for (int i = sub; i < lim; i += 16) {
@@ -135,10 +138,15 @@ bf_mask_gather_kernel(MaskIO K, const float *__restrict__ proj_all, const float 
     const int vm = f * K.n_masks + m;
     const int cnt = K.contour_count[vm];
     float du = 0.f, dv = 0.f;
+    // (the next tile of the contour is requested before this one is scanned)
+    int ch_n = (int)threadIdx.x < cnt ? choice[(size_t)vm * K.cmax + threadIdx.x] : -1;
+    float2 g_n = (int)threadIdx.x < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + threadIdx.x] : make_float2(0.f, 0.f);
     for (int base = 0; base < cnt; base += 256) {
-        int c = base + threadIdx.x;
-        s_choice[threadIdx.x] = c < cnt ? choice[(size_t)vm * K.cmax + c] : -1;
-        s_grad[threadIdx.x] = c < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + c] : make_float2(0.f, 0.f);
+        s_choice[threadIdx.x] = ch_n;
+        s_grad[threadIdx.x] = g_n;
+        const int c2 = base + 256 + threadIdx.x;
+        ch_n = c2 < cnt ? choice[(size_t)vm * K.cmax + c2] : -1;
+        g_n = c2 < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + c2] : make_float2(0.f, 0.f);
         __syncthreads();
         const int i0 = sub * 64;
 #pragma unroll 8
