@@ -10,8 +10,8 @@
 //   bf_mask_project_kernel   thread = sampled vertex x view: uv, inside flag, binary term + d/duv
 //   bf_mask_contour_kernel   thread = contour point: exact nearest inside vertex (first minimum, like
 //                            torch.min), its weight, the unit direction
-//   bf_mask_gather_kernel    thread = (sampled vertex, view): gathers the contour points that chose it IN CONTOUR
-//                            ORDER (deterministic; no atomics), maps d/duv back through the projection
+//   bf_mask_gather_kernel    workgroup = (64 sampled vertices, view): lists the contour points that chose them IN CONTOUR
+//                            ORDER (deterministic; no atomics), sums per vertex, maps d/duv back through the projection
 //   bf_mask_gsum_kernel      adds the views in view order into dL/dvertex
 // Distances are exact (a - b)^2 sums; torch.cdist switches to the |a|^2+|b|^2-2ab form for these sizes,
 // which is noisier (about 1e-2 px at 512 px) - see DESIGN.md.
@@ -125,41 +125,57 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
     if (threadIdx.x == 0) loss_part[(size_t)vm * K.part_stride + K.proj_blocks + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
 }
 
-// grid (ceil(4 Ns/256), M, F).  gpart[f][m][s][3] = dL/dvertex 4 s from mask view m (one workgroup per view and block
-// of 64 vertices: the views run in parallel; bf_mask_gsum_kernel adds them in view order).  FOUR lanes per vertex: lane
-// q takes the q-th quarter of every 256-point tile of the contour, in contour order; the four partial sums are added
-// in quarter order (a fixed association: deterministic).
+// grid (ceil(Ns/64), M, F), 256 threads.  gpart[f][m][s][3] = dL/dvertex 4 s from mask view m (one workgroup per view and
+// block of 64 sampled vertices: the views run in parallel; bf_mask_gsum_kernel adds them in view order).  The workgroup
+// walks the contour 256 points at a time; a point that chose one of ITS vertices is appended - in contour order, by ballot
+// ranks - to a short list in LDS (a block of 64 vertices is chosen by ~70 of the ~3000 points), and the 64 vertex lanes add
+// up their entries of the list in list order = contour order (deterministic; no atomics).  The first version compared every
+// point with every vertex of the block: 64 compares per point instead of one.
 extern "C" __global__ void __launch_bounds__(256)
 bf_mask_gather_kernel(MaskIO K, const float *__restrict__ proj_all, const float *__restrict__ uvi, const float *__restrict__ duvb,
                       const int *__restrict__ choice, const float *__restrict__ cgrad, float *__restrict__ gpart) {
-    __shared__ int s_choice[256];
-    __shared__ float2 s_grad[256];
-    const int gid = blockIdx.x * 256 + threadIdx.x, s = gid >> 2, sub = gid & 3, m = blockIdx.y, f = blockIdx.z;
+    constexpr int CAP = 1024;
+    __shared__ int s_v[CAP];                               // vertex (0..63 inside the block) of a listed point
+    __shared__ float2 s_g[CAP];
+    __shared__ int s_wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, s0 = blockIdx.x * 64, m = blockIdx.y, f = blockIdx.z;
     const int vm = f * K.n_masks + m;
     const int cnt = K.contour_count[vm];
-    float du = 0.f, dv = 0.f;
-    // (the next tile of the contour is requested before this one is scanned)
-    int ch_n = (int)threadIdx.x < cnt ? choice[(size_t)vm * K.cmax + threadIdx.x] : -1;
-    float2 g_n = (int)threadIdx.x < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + threadIdx.x] : make_float2(0.f, 0.f);
+    float du = 0.f, dv = 0.f;                              // (vertex lanes: tid < 64)
+    int n = 0;                                             // (uniform) entries in the list
+    auto drain = [&]() {
+        if (tid < 64)
+            for (int i = 0; i < n; ++i)
+                if (s_v[i] == tid) { du += s_g[i].x; dv += s_g[i].y; }
+        n = 0;
+        __syncthreads();
+    };
+    // (the next tile of the contour is requested before this one is handled)
+    int ch_n = tid < cnt ? choice[(size_t)vm * K.cmax + tid] : -1;
+    float2 g_n = tid < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + tid] : make_float2(0.f, 0.f);
     for (int base = 0; base < cnt; base += 256) {
-        s_choice[threadIdx.x] = ch_n;
-        s_grad[threadIdx.x] = g_n;
-        const int c2 = base + 256 + threadIdx.x;
+        const int ch = ch_n;
+        const float2 g = g_n;
+        const int c2 = base + 256 + tid;
         ch_n = c2 < cnt ? choice[(size_t)vm * K.cmax + c2] : -1;
         g_n = c2 < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + c2] : make_float2(0.f, 0.f);
+        const bool mine = ch >= s0 && ch < s0 + 64;
+        const unsigned long long mk = __ballot(mine);
+        if (lane == 0) s_wcnt[wv] = __popcll(mk);
         __syncthreads();
-        const int i0 = sub * 64;
-#pragma unroll 8
-        for (int i = i0; i < i0 + 64; ++i)
-            if (s_choice[i] == s) { du += s_grad[i].x; dv += s_grad[i].y; }          // in contour order
+        int off = n;
+        for (int w = 0; w < wv; ++w) off += s_wcnt[w];
+        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        if (mine) { const int o = off + __popcll(mk & ((1ull << lane) - 1ull)); s_v[o] = ch - s0; s_g[o] = g; }
+        n += total;
         __syncthreads();
+        if (n > CAP - 256) drain();
     }
-    // quarter sums -> lane 0 of the quad, in quarter order
-    const float du1 = __shfl_down(du, 1), dv1 = __shfl_down(dv, 1), du2 = __shfl_down(du, 2), dv2 = __shfl_down(dv, 2),
-                du3 = __shfl_down(du, 3), dv3 = __shfl_down(dv, 3);
-    if (s < K.ns && sub == 0) {
+    drain();
+    const int s = s0 + tid;
+    if (tid < 64 && s < K.ns) {
         float tu = duvb[((size_t)vm * K.ns + s) * 2], tv = duvb[((size_t)vm * K.ns + s) * 2 + 1];
-        tu += du; tv += dv; tu += du1; tv += dv1; tu += du2; tv += dv2; tu += du3; tv += dv3;
+        tu += du; tv += dv;
         float4 r = ((const float4 *)uvi)[(size_t)vm * K.ns + s];
         const float *P = proj_all + ((size_t)f * K.n_views + K.view_index[m]) * 12;
         float q0 = tu * r.w, q1 = tv * r.w, q2 = -(tu * r.x + tv * r.y) * r.w;

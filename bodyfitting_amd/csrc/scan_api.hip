@@ -219,7 +219,7 @@ static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss) {
                        (const float *)b->proj.p, b->mk_uvi.p, b->mk_duvb.p, b->mk_part.p);
     hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax * 16 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
                        (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p);
-    hipLaunchKernelGGL(bf_mask_gather_kernel, dim3((K.ns * 4 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->proj.p,
+    hipLaunchKernelGGL(bf_mask_gather_kernel, dim3((K.ns + 63) / 64, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->proj.p,
                        (const float *)b->mk_uvi.p, (const float *)b->mk_duvb.p, (const int *)b->mk_choice.p,
                        (const float *)b->mk_cgrad.p, b->mk_gpart.p);
     hipLaunchKernelGGL(bf_mask_gsum_kernel, dim3(K.proj_blocks, F), dim3(256), 0, b->stream, K, (const float *)b->mk_gpart.p, b->dvout.p);
