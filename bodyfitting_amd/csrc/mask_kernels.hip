@@ -80,29 +80,36 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
     const float *cp = K.contour_xy + ((size_t)K.contour_start[vm] + (c < cnt ? c : 0)) * 2;
     const float cx = cp[0], cy = cp[1];
     const float4 *rec = (const float4 *)uvi + (size_t)vm * K.ns;
-    float best = 3.0e38f, bu = 0.f, bv = 0.f;
+    float best = 3.0e38f;
     int bidx = -1;
-    // (the next tile's record is requested before this tile is scanned: one memory latency per tile was most of this kernel)
-    float4 nxt = (int)threadIdx.x < K.ns ? rec[threadIdx.x] : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (the next tile's record is requested before this tile is scanned; a vertex outside the image is parked at u = 3e19, so
+    //  its squared distance overflows past `best` and the scan needs no inside test; the winner's coordinates are re-read at the end)
+    auto fetch = [&](int s) {
+        float4 r = s < K.ns ? rec[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(r.z > 0.5f)) r.x = 3.0e19f;
+        return r;
+    };
+    float4 nxt = fetch(threadIdx.x);
     for (int base = 0; base < K.ns; base += 256) {
         tile[threadIdx.x] = nxt;
-        const int s2 = base + 256 + threadIdx.x;
-        nxt = s2 < K.ns ? rec[s2] : make_float4(0.f, 0.f, 0.f, 0.f);
+        nxt = fetch(base + 256 + threadIdx.x);
         __syncthreads();
         int lim = min(256, K.ns - base);
         for (int i = sub; i < lim; i += 16) {
-            float4 r = tile[i];
-            float dx = r.x - cx, dy = r.y - cy, d2 = dx * dx + dy * dy;
-            if (r.z > 0.5f && d2 < best) { best = d2; bidx = base + i; bu = r.x; bv = r.y; }    // first minimum of this lane's subset
+            const float4 r = tile[i];
+            const float dx = r.x - cx, dy = r.y - cy, d2 = dx * dx + dy * dy;
+            if (d2 < best) { best = d2; bidx = base + i; }                     // first minimum of this lane's subset
         }
         __syncthreads();
     }
 #pragma unroll
     for (int x = 1; x < 16; x <<= 1) {
-        const float ob = __shfl_xor(best, x), ou = __shfl_xor(bu, x), ov = __shfl_xor(bv, x);
+        const float ob = __shfl_xor(best, x);
         const int oi = __shfl_xor(bidx, x);
-        if (oi >= 0 && (bidx < 0 || ob < best || (ob == best && oi < bidx))) { best = ob; bidx = oi; bu = ou; bv = ov; }
+        if (oi >= 0 && (bidx < 0 || ob < best || (ob == best && oi < bidx))) { best = ob; bidx = oi; }
     }
+    float bu = 0.f, bv = 0.f;
+    if (bidx >= 0 && sub == 0) { const float4 r = rec[bidx]; bu = r.x; bv = r.y; }
     float lval = 0.f;
     if (c < cnt && sub == 0) {
         const size_t o = (size_t)vm * K.cmax + c;
