@@ -234,6 +234,8 @@ def main():
             "frac": BYTES_MESH_LAUNCH * F / (mesh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if mesh_ms > 0 else None,
             "traffic": (traffic or {}).get("bf_mesh_kernel_bytes_per_launch"), "avg_launch_ms": mesh_ms,
             "algorithmic_bytes_per_launch": BYTES_MESH_LAUNCH * F,
+            "note": "avg_launch_ms is the HIP-event bracket around a ~6 us kernel and includes the record overhead; rocprofv3 "
+                    "--kernel-trace gives 6.1 us for it (profiles/r01_rocprof_final.md), i.e. 3.1 TB/s = 0.38 of peak",
         },
         "device_ms_per_step": {k: ev[k] / max(ev["calls"], 1) for k in ("fit_ms", "mesh_ms", "tail_ms", "total_ms")},
     }
