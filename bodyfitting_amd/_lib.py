@@ -77,6 +77,7 @@ SIGNATURES = {
     "bf_scan_grid_info": (C.c_int, [_VP, _IP, _FP]),
     "bf_scan_grid_lists": (C.c_int, [_VP, _IP, _IP, _IP]),
     "bf_scan_inside": (C.c_int, [_VP, C.c_int, _FP, _FP]),
+    "bf_scan_intersects": (C.c_int, [_VP, C.c_int, _FP, _FP, C.POINTER(C.c_uint8)]),
     "bf_scan_nearest": (C.c_int, [_VP, C.c_int, _FP, _IP, _FP, _FP]),
     "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
     "bf_batch_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP]),

@@ -214,3 +214,73 @@ extern "C" __global__ void __launch_bounds__(256) bf_inside_mesh_kernel(ScanDev 
     }
     sign[id] = (hits & 1) ? 1.f : -1.f;
 }
+
+// ---- MeshGridSearcher.intersects_any (utils/mesh_grid_searcher.py:93-99 -> search_intersect, kernel.cu:1029-1231) ---------------
+// Does the ray origin + t direction, t >= 0, hit any triangle?  The per-triangle test is the reference's regular branch
+// (intersect_tri2, kernel.cu:742-780): solve [va - o | vb - o | vc - o | -d ; 1 1 1 0] by cofactors, hit iff |det| > 1e-9 and the
+// three barycentric numerators and the ray parameter, signed by det, are >= -1e-9.  Its branches for |det| <= 1e-9 (ray in the
+// triangle's plane, zero direction) are not reproduced: such a pair counts as no hit.  The answer is an OR over triangles, so the
+// order of the reference's cell walk does not matter: one thread per ray walks the cells its ray crosses (3-D DDA from the
+// ray's entry into the grid) and stops at the first hit.
+__device__ inline bool ray_hits_triangle(const float o[3], const float d[3], const float *va, const float *vb, const float *vc) {
+    const float A0 = va[0] - o[0], A1 = vb[0] - o[0], A2 = vc[0] - o[0], A3 = -d[0];
+    const float A4 = va[1] - o[1], A5 = vb[1] - o[1], A6 = vc[1] - o[1], A7 = -d[1];
+    const float A8 = va[2] - o[2], A9 = vb[2] - o[2], A10 = vc[2] - o[2], A11 = -d[2];
+    const float i0 = A5 * A10 - A6 * A9, i1 = A2 * A9 - A1 * A10, i2 = A1 * A6 - A2 * A5;
+    const float i3 = A6 * A8 - A4 * A10, i4 = A0 * A10 - A2 * A8, i5 = A2 * A4 - A0 * A6;
+    const float i6 = A4 * A9 - A5 * A8, i7 = A1 * A8 - A0 * A9, i8 = A0 * A5 - A1 * A4;
+    float n0 = -A3 * i0 - A7 * i1 - A11 * i2, n1 = -A3 * i3 - A7 * i4 - A11 * i5, n2 = -A3 * i6 - A7 * i7 - A11 * i8;
+    float n3 = A0 * i0 + A4 * i1 + A8 * i2;
+    float det = n0 + n1 + n2;
+    const float prec = 1e-9f;
+    if (!(det > prec || det < -prec)) return false;
+    if (det < 0.f) { n0 = -n0; n1 = -n1; n2 = -n2; n3 = -n3; }
+    return n0 >= -prec && n1 >= -prec && n2 >= -prec && n3 >= -prec;
+}
+
+extern "C" __global__ void __launch_bounds__(256) bf_intersect_kernel(ScanDev S, const float *__restrict__ origins,
+                                                                     const float *__restrict__ directions, int n,
+                                                                     unsigned char *__restrict__ hit) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const float o[3] = {origins[id * 3], origins[id * 3 + 1], origins[id * 3 + 2]};
+    const float d[3] = {directions[id * 3], directions[id * 3 + 1], directions[id * 3 + 2]};
+    hit[id] = 0;
+    if (d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < 1e-9f) return;             // (kernel.cu:1062-1065: a zero direction hits nothing)
+    const float org[3] = {S.ox, S.oy, S.oz};
+    const int num[3] = {S.nx, S.ny, S.nz};
+    // entry parameter into the grid's box (slab test); t0 = 0 when the origin is inside
+    float t0 = 0.f, t1 = 3.0e38f;
+    for (int k = 0; k < 3; ++k) {
+        const float lo = org[k], hi = org[k] + S.step * num[k];
+        if (d[k] == 0.f) { if (o[k] < lo || o[k] > hi) return; }
+        else {
+            float a = (lo - o[k]) / d[k], b = (hi - o[k]) / d[k];
+            if (a > b) { const float t = a; a = b; b = t; }
+            t0 = fmaxf(t0, a); t1 = fminf(t1, b);
+        }
+    }
+    if (t0 > t1) return;
+    int c[3], stp[3];
+    float tmax[3], tdel[3];
+    for (int k = 0; k < 3; ++k) {
+        const float p = o[k] + d[k] * t0;
+        c[k] = min(max((int)floorf((p - org[k]) / S.step), 0), num[k] - 1);
+        stp[k] = d[k] > 0.f ? 1 : (d[k] < 0.f ? -1 : 0);
+        const float edge = org[k] + S.step * (c[k] + (stp[k] > 0 ? 1 : 0));
+        tmax[k] = stp[k] ? (edge - o[k]) / d[k] : 3.0e38f;
+        tdel[k] = stp[k] ? S.step / fabsf(d[k]) : 3.0e38f;
+    }
+    for (int guard = 0; guard < S.nx + S.ny + S.nz + 3; ++guard) {
+        const int cell = (c[0] * S.ny + c[1]) * S.nz + c[2];
+        for (int e = S.cell_start[cell]; e < S.cell_start[cell + 1]; ++e) {
+            const int t = S.cell_tris[e];
+            if (ray_hits_triangle(o, d, S.verts + (size_t)S.faces[t * 3] * 3, S.verts + (size_t)S.faces[t * 3 + 1] * 3,
+                                  S.verts + (size_t)S.faces[t * 3 + 2] * 3)) { hit[id] = 1; return; }
+        }
+        const int k = tmax[0] <= tmax[1] ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
+        c[k] += stp[k];
+        if (stp[k] == 0 || c[k] < 0 || c[k] >= num[k]) return;
+        tmax[k] += tdel[k];
+    }
+}

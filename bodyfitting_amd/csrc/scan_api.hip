@@ -16,6 +16,7 @@ extern "C" __global__ void bf_grid_fill_kernel(ScanDev, int *, int *);
 extern "C" __global__ void bf_grid_pack_kernel(ScanDev, const int *, int *, float4 *, int);
 extern "C" __global__ void bf_face_normal_kernel(const float *, const int *, int, float *);
 extern "C" __global__ void bf_inside_mesh_kernel(ScanDev, const float *, int, float *);
+extern "C" __global__ void bf_intersect_kernel(ScanDev, const float *, const float *, int, unsigned char *);
 extern "C" __global__ void bf_transpose_kernel(const float *, int, int, float *);
 extern "C" __global__ void bf_contour_kernel(const unsigned char *, int, int, int, float *, int *, unsigned *);
 extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const float *, float *, float *, float *);
@@ -137,6 +138,21 @@ int bf_scan_inside(bf_scan *s, int n, const float *points, float *signs) {
     hipLaunchKernelGGL(bf_inside_mesh_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, s->dev, (const float *)d_p.p, n, d_s.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(signs, d_s.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+// MeshGridSearcher.intersects_any (utils/mesh_grid_searcher.py:93-99 -> search_intersect, mesh_grid.cpp:92-110)
+int bf_scan_intersects(bf_scan *s, int n, const float *origins, const float *directions, uint8_t *hit) {
+    if (!s || n <= 0 || !origins || !directions || !hit) return fail(BF_ERR_INVALID, "bf_scan_intersects: bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf<float> d_o, d_d;
+    DevBuf<unsigned char> d_h;
+    HIP_TRY(d_o.upload(std::vector<float>(origins, origins + (size_t)n * 3)));
+    HIP_TRY(d_d.upload(std::vector<float>(directions, directions + (size_t)n * 3)));
+    HIP_TRY(d_h.alloc(n));
+    hipLaunchKernelGGL(bf_intersect_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, s->dev, (const float *)d_o.p, (const float *)d_d.p, n, d_h.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(hit, d_h.p, (size_t)n, hipMemcpyDeviceToHost));
     return BF_OK;
 }
 

@@ -163,6 +163,15 @@ class Scan:
         _lib.check(self._lib.bf_scan_inside(self._h, len(p), _lib.fptr(p), _lib.fptr(sign)), "bf_scan_inside")
         return sign
 
+    def intersects_any(self, origins, directions):
+        """-> bool[n]: does the ray origin + t direction (t >= 0) hit the scan surface (MeshGridSearcher.intersects_any)"""
+        o = _f32(origins, (-1, 3))
+        d = _f32(directions, (len(o), 3))
+        hit = np.empty(len(o), np.uint8)
+        _lib.check(self._lib.bf_scan_intersects(self._h, len(o), _lib.fptr(o), _lib.fptr(d), hit.ctypes.data_as(C.POINTER(C.c_uint8))),
+                   "bf_scan_intersects")
+        return hit.astype(bool)
+
     def nearest_points(self, points):
         """-> (nearest points [n,3], face ids [n], barycentrics [n,3]) like MeshGridSearcher.nearest_points"""
         p = _f32(points, (-1, 3))

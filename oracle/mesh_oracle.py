@@ -4,6 +4,7 @@ Restates, in numpy / torch:
   * MeshGridSearcher.set_mesh grid parameters      reference utils/mesh_grid_searcher.py:56-79
   * insert_grid_surface (cell lists of the grid)    thirdparty/mesh_grid/mesh_grid_kernel.cu:110-157,178-236
   * MeshGridSearcher.inside_mesh (axis-ray parity)   thirdparty/mesh_grid/mesh_grid_kernel.cu:461-641
+  * MeshGridSearcher.intersects_any (any-hit rays)   thirdparty/mesh_grid/mesh_grid_kernel.cu:742-780,1029-1231
   * the per-triangle closest-point rule             thirdparty/mesh_grid/mesh_grid_kernel.cu:12-109
     (KKT solve for the barycentric coefficients; if one is negative, fall back to the edge opposite
     the MOST NEGATIVE coefficient and clamp to its end points - which is not the exact closest point
@@ -134,6 +135,38 @@ def inside_mesh(verts, faces, queries, step, origin, num, tri_num, tri_idx):
                 hits += 1
             x[a] += 1 if plus else -1
         out[qi] = 1 if hits % 2 else -1
+    return out
+
+
+def intersects_any(verts, faces, origins, directions):
+    """search_intersect's answer (mesh_grid_kernel.cu:1029-1231) by brute force: a ray hits iff SOME triangle passes the
+    regular branch of intersect_tri2 (kernel.cu:742-780: |det| > 1e-9, the three barycentric numerators and the ray
+    parameter, signed by det, >= -1e-9), evaluated in float32 in the kernel's order.  The OR over triangles does not depend
+    on the order of the reference's cell walk; its coplanar / zero-direction branches are not restated (no hit)."""
+    f32 = np.float32
+    v = np.asarray(verts, f32)
+    tri = v[np.asarray(faces, np.int64).reshape(-1, 3)]                 # [T,3,3]
+    out = np.zeros(len(origins), bool)
+    prec = f32(1e-9)
+    for r, (o, d) in enumerate(zip(np.asarray(origins, f32), np.asarray(directions, f32))):
+        if f32(d @ d) < prec:
+            continue
+        a = tri - o                                                       # rows: va-o, vb-o, vc-o
+        A0, A1, A2 = a[:, 0, 0], a[:, 1, 0], a[:, 2, 0]
+        A4, A5, A6 = a[:, 0, 1], a[:, 1, 1], a[:, 2, 1]
+        A8, A9, A10 = a[:, 0, 2], a[:, 1, 2], a[:, 2, 2]
+        A3, A7, A11 = -d[0], -d[1], -d[2]
+        i0, i1, i2 = A5 * A10 - A6 * A9, A2 * A9 - A1 * A10, A1 * A6 - A2 * A5
+        i3, i4, i5 = A6 * A8 - A4 * A10, A0 * A10 - A2 * A8, A2 * A4 - A0 * A6
+        i6, i7, i8 = A4 * A9 - A5 * A8, A1 * A8 - A0 * A9, A0 * A5 - A1 * A4
+        n0 = -A3 * i0 - A7 * i1 - A11 * i2
+        n1 = -A3 * i3 - A7 * i4 - A11 * i5
+        n2 = -A3 * i6 - A7 * i7 - A11 * i8
+        n3 = A0 * i0 + A4 * i1 + A8 * i2
+        det = n0 + n1 + n2
+        ok = (det > prec) | (det < -prec)
+        sg = np.where(det < 0, f32(-1), f32(1))
+        out[r] = bool(np.any(ok & (n0 * sg >= -prec) & (n1 * sg >= -prec) & (n2 * sg >= -prec) & (n3 * sg >= -prec)))
     return out
 
 

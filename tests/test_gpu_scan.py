@@ -72,6 +72,26 @@ def test_inside_mesh_matches_the_restated_rule(small):
     scan.close()
 
 
+def test_intersects_any_matches_the_bruteforce_rule(small):
+    """MeshGridSearcher.intersects_any: the 3-D DDA over the grid finds a hit exactly when some triangle passes the
+    reference's test (oracle: brute force over all triangles); rays from inside, outside and off the grid"""
+    model, _ = small
+    _, sv, sf = S.make_scan_problem(model, 4)
+    scan = N.Scan(sv, sf)
+    rng = np.random.default_rng(11)
+    lo, hi = sv.min(0), sv.max(0)
+    o = np.concatenate([rng.uniform(lo - 0.3, hi + 0.3, (200, 3)), sv[rng.integers(0, len(sv), 100)] + rng.normal(0, 0.05, (100, 3)),
+                        rng.uniform(lo - 3, lo - 1, (60, 3))]).astype(np.float32)
+    d = rng.normal(size=o.shape).astype(np.float32)
+    d[-30:] = sv[sf[rng.integers(0, len(sf), 30)]].mean(1) - o[-30:]        # far rays aimed at the middle of a triangle
+    got = scan.intersects_any(o, d)
+    want = MO.intersects_any(sv, sf, o, d)
+    assert np.mean(got == want) > 0.995                                  # (a grazing ray may differ by a float32 rounding in the walk)
+    assert want[-30:].all() and got[-30:].all() and 0.2 < want.mean() < 0.95
+    assert not scan.intersects_any(o[:4], np.zeros((4, 3), np.float32)).any()
+    scan.close()
+
+
 @pytest.mark.parametrize("spread", [0.01, 0.2, 3.0])
 def test_nearest_points_match_bruteforce_rule(small, spread):
     """near, far and way-outside-the-grid queries against the oracle's brute-force search"""

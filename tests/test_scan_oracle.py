@@ -103,6 +103,23 @@ def test_inside_mesh_rule_on_a_closed_ellipsoid():
     assert not MO.axis_ray_hits([0.8, 0.8, 0.0], 2, True, tri) and not MO.axis_ray_hits([0.2, 0.2, 2.0], 2, True, tri)
 
 
+def test_intersects_any_on_a_closed_ellipsoid():
+    """search_intersect restated (any-hit rays): rays from outside towards / away from the centre, and from inside"""
+    v, f = _octa_sphere(2)
+    c = np.array([0.1, -0.2, 0.05])
+    rng = np.random.default_rng(4)
+    dirs = rng.normal(size=(60, 3)); dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    outside = c + dirs * 3.0
+    assert MO.intersects_any(v, f, outside, -dirs).all()                 # aimed at the centre
+    assert not MO.intersects_any(v, f, outside, dirs).any()              # aimed away
+    assert MO.intersects_any(v, f, np.tile(c, (60, 1)), dirs).all()      # from inside, any direction
+    assert not MO.intersects_any(v, f, outside[:3], np.zeros((3, 3))).any()
+    tri = np.array([[0, 0, 1], [1, 0, 1], [0, 1, 1]], np.float32)
+    one = [[0, 1, 2]]
+    assert MO.intersects_any(tri, one, [[0.2, 0.2, 0.0]], [[0, 0, 1]])[0] and not MO.intersects_any(tri, one, [[0.2, 0.2, 0.0]], [[0, 0, -1]])[0]
+    assert not MO.intersects_any(tri, one, [[0.8, 0.8, 0.0]], [[0, 0, 1]])[0]
+
+
 def test_oracle_scan_fit_matches_reference_golden(small_model, gmm_bufs):
     torch.set_num_threads(1)
     g = load_golden("scan_nv690_30it.npz")
