@@ -1,25 +1,29 @@
 #!/usr/bin/env python3
 """frames fitted / sec on synthetic 48-view SMPL (6890 v), 100 Adam iterations (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W                        one process drives N GPUs (bf_group)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   one rank per GPU (bf_comm)
 
-One "step" = one complete fit of this rank's frames: re-arm the batch on the device, 100 iterations
-of reference smplify/smplify.py:177-213, the final full-mesh forward, the joints, and the copy of
-parameters / vertices / joints into pinned host memory (the rtn_dict of smplify.py:216-226).
-Inputs (cameras, keypoints, initial estimate, model) are already resident in HBM when the timed
-region starts.  N=1 default workload = BASELINE config 2 (1 frame per GPU per step); frames are
-independent, so for N>1 every rank fits its own frames (weak scaling, no data-path collective) and
-the packed parameters are all-gathered over RCCL once per job (after the K timed steps, inside the timed region).
+One "step" = one complete fit of every GPU's frames: re-arm the batch on the device, 100 iterations of reference
+smplify/smplify.py:177-213, the final full-mesh forward, the joints, and the copy of parameters / vertices / joints into
+pinned host memory (the rtn_dict of smplify.py:216-226).  Inputs (cameras, keypoints, initial estimate, model) are already
+resident in HBM when the timed region starts.  Default workload = BASELINE config 2 (1 frame per GPU per step); frames are
+independent, so with N GPUs every GPU fits its own frames (weak scaling, no data-path collective) and the packed
+parameters are all-gathered over RCCL once per job - after the K steps, inside the timed region.
 
-PyTorch appears here only for torch.distributed (barrier, RCCL all-gather) and - in the clearly
-separated `cpu_baseline` leg - to execute the oracle; the measured path is numpy + ctypes + HIP.
+No PyTorch on the measured path, in either launch mode: the host side is numpy + ctypes, RCCL is driven from inside
+libbodyfit (csrc/group.hip), and the ranks of a launcher-started job find each other through the file system
+(bodyfitting_amd/shard.py).  torch is imported only by the clearly separated `cpu_baseline` leg, to execute the oracle.
+
+The K-step bracket (barrier + device sync on both sides, max over ranks) is repeated --repeats times; `value` and
+`ms_per_step` are the MEDIAN bracket, the spread is reported next to them.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -28,15 +32,17 @@ import numpy as np
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-from bodyfitting_amd import _lib, native as N, synthetic as S   # noqa: E402
+from bodyfitting_amd import _lib, native as N, shard, synthetic as S   # noqa: E402
 
-# algorithmic bytes per frame-iteration of the SMPL forward the reference
-# evaluates every iteration (posedirs + shapedirs + lbs_weights + J_regressor + J_regressor_extra +
-# v_template, each streamed once).
+# algorithmic bytes per frame-iteration of the SMPL forward the reference evaluates every
+# iteration (posedirs + shapedirs + lbs_weights + J_regressor + J_regressor_extra + v_template, each streamed once).
 BYTES_PER_FRAME_ITER = 17_114_760 + 826_800 + 661_440 + 661_440 + 248_040 + 82_680   # 19,595,160
 # what ONE launch of the full-mesh kernel must read + write per frame (no J_regressor: pre-contracted)
 BYTES_MESH_LAUNCH = 17_114_760 + 826_800 + 661_440 + 82_680 + 2 * 82_680
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+ENGINE_CLOCK_GHZ = 2.4       # MI355X peak engine clock (the fit kernel is a one-CU latency chain: cycles are its natural unit)
+# dependent-chain lower bound of one fit iteration (per phase, dependent LDS round trips x ~90 cycles + s_barrier)
+CHAIN_BOUND_CYCLES = 5 * 20 + 24 * 90
 
 
 def parse():
@@ -44,56 +50,74 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--repeats", type=int, default=5, help="how many times the K-step bracket is timed (median reported)")
     ap.add_argument("--frames-per-gpu", type=int, default=1, help="1 = BASELINE config 2; 32 = config 4's per-GPU shard")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--views", type=int, default=48)
     ap.add_argument("--dense", action="store_true", help="full mesh every iteration (reference-literal schedule)")
     ap.add_argument("--graph", action="store_true", help="replay one hipGraph per step instead of issuing the step's four kernels from the host")
-    ap.add_argument("--no-graph", action="store_true", help="(default since the step is four kernels and nothing else; kept for old command lines)")
     ap.add_argument("--events", action="store_true", help="keep the HIP event records inside the timed steps (4 per step, ~13 us)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the auxiliary legs (dense schedule, batched shards)")
     ap.add_argument("--cpu-frames", type=int, default=12)
     ap.add_argument("--no-configs", action="store_true", help="skip the config-3 / config-5 legs of `extra`")
-    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (validation on a box with fewer GPUs than ranks)")
-    ap.add_argument("--same-device", action="store_true", help="every rank uses GPU 0 (validation of the N>1 code path on a 1-GPU box)")
     ap.add_argument("--prewarm-s", type=float, default=0.4, help="untimed spin before the W warmup steps (clock ramp, page-in)")
     return ap.parse_args()
 
 
+def pack(model, frames, n_views):
+    return N.pack_problem([S.make_problem(model, frame=f, n_views=n_views) for f in frames])
+
+
 def build_batch(dev, model, frames, n_views):
-    probs = [S.make_problem(model, frame=f, n_views=n_views) for f in frames]
-    c2w, K, kp, ndiv, betas, pose = N.pack_problem(probs)
+    c2w, K, kp, ndiv, betas, pose = pack(model, frames, n_views)
     b = N.FrameBatch(dev, len(frames), n_views)
     b.set_cameras(c2w, K)
     b.set_keypoints(kp, ndiv)
     b.set_init(betas, pose)
-    return b, probs
+    return b
 
 
-def run_steps(batch, steps, iters, flags, finish=None):
+def run_steps(job, steps, iters, flags, finish=None):
     for _ in range(steps):
-        batch.fit(iters, flags=flags | _lib.FIT_RESET)       # re-arm + fit + mesh + joints + fetch, one call
-    batch.sync()
+        job.fit(iters, flags=flags | _lib.FIT_RESET)         # re-arm + fit + mesh + joints + fetch, one call (per device)
     if finish is not None:
-        finish()                                             # the job's one collective: gather of the fitted parameters
+        return finish()                                      # the job's one collective: gather of the fitted parameters
+    job.sync()
+    return None
 
 
-def timed_leg(batch, steps, warmup, iters, flags, barrier=lambda: None, finish=None):
-    run_steps(batch, warmup, iters, flags, finish)
+def timed_brackets(job, steps, warmup, iters, flags, repeats, barrier, finish=None, reduce_max=lambda x: x):
+    """W untimed steps, then `repeats` brackets of exactly K steps: barrier + device sync | K steps (+ the gather) | barrier."""
+    run_steps(job, warmup, iters, flags, finish)
+    walls, last = [], None
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        last = run_steps(job, steps, iters, flags, finish)
+        barrier()
+        walls.append(reduce_max(time.perf_counter() - t0))
+    return walls, last
+
+
+def event_leg(batch, steps, iters, flags):
+    """per-kernel device times of the same steps from HIP events on the batch's own stream (bf_batch_timing_sum)"""
+    run_steps(batch, 2, iters, flags)
     batch.timing_reset()
-    barrier()
-    batch.sync()
-    t0 = time.perf_counter()
-    run_steps(batch, steps, iters, flags, finish)
-    barrier()
-    t1 = time.perf_counter()
-    return t1 - t0, batch.timing_sum()
+    run_steps(batch, steps, iters, flags)
+    return batch.timing_sum()
+
+
+def spread(xs):
+    return {"median": statistics.median(xs), "min": min(xs), "max": max(xs), "n": len(xs)}
 
 
 def cpu_baseline(model, gmm, n_frames, n_views, iters):
-    """The oracle (torch-CPU restatement of the reference loop: same ops, autograd, Adam) timed on
-    this host; 1 thread, which is the faster setting for this dispatch-bound loop."""
+    """Two CPU figures, both one thread (the faster setting for this dispatch-bound loop):
+    * `value` (kind "port"): oracle/smplify_oracle.py - the torch-CPU restatement of the reference loop (same ops, autograd,
+      Adam) - timed HERE, on this host;
+    * `reference`: the unmodified reference imported from /root/reference, timed in the build container when the goldens were
+      generated (tests/golden/reference_timing.json - the reference cannot travel to the GPU box)."""
     import torch
     from oracle import smplify_oracle as O
     torch.set_num_threads(1)
@@ -104,16 +128,23 @@ def cpu_baseline(model, gmm, n_frames, n_views, iters):
     for p in probs:
         O.fit(model, gb, p, iters)
     dt = time.perf_counter() - t0
-    return {"value": n_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"{n_frames} frames x {n_views} views x {iters} iters, oracle/smplify_oracle.py (torch "
-                      f"{torch.__version__} CPU, autograd + Adam), {dt:.1f} s"}
+    out = {"value": n_frames / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": f"{n_frames} frames x {n_views} views x {iters} iters, oracle/smplify_oracle.py (torch "
+                     f"{torch.__version__} CPU, autograd + Adam), {dt:.1f} s on this host ({os.cpu_count()} logical CPUs)"}
+    try:
+        with open(os.path.join(REPO, "tests", "golden", "reference_timing.json")) as f:
+            ref = json.load(f)
+        out["reference"] = {"value": ref["frames_per_s"], "unit": "frames/s", "cores": ref["threads"], "kind": "reference",
+                            "sample": f"{len(ref['wall_s_per_frame'])} frames, {ref['what']}", "host": ref["host"], "where": ref["where"]}
+    except (OSError, ValueError, KeyError):
+        pass
+    return out
 
 
 def pmc_traffic():
     """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes, or None."""
-    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     try:
-        with open(path) as f:
+        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
             return json.load(f)
     except (OSError, ValueError):
         return None
@@ -121,164 +152,186 @@ def pmc_traffic():
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    gather = None
-    if a.same_device:
-        local = 0
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if a.dist_backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(a.dist_backend)
-    if a.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")) if env_world > 1 else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) if env_world > 1 else 0
+    mode = "ranks" if env_world > 1 else ("group" if a.gpus > 1 else "single")
+    n_gpus = env_world if mode == "ranks" else a.gpus
+    if mode == "ranks" and a.gpus != env_world and rank == 0:
+        print(f"warning: --gpus {a.gpus} but WORLD_SIZE {env_world}: using {env_world}", file=sys.stderr)
+    have = _lib.load().bf_device_count()
+    if (mode == "group" and a.gpus > have) or (mode == "ranks" and local >= have):
+        raise SystemExit(f"bench.py: {a.gpus} GPU(s) requested but {have} visible - refusing to run a smaller job under that name")
 
     model, gmm = S.make_model("smpl", seed=0), S.make_gmm(seed=0)
-    dev = N.DeviceModel(model, gmm, device=local)
     F = a.frames_per_gpu
-    frames = list(range(rank * F, rank * F + F))          # distinct frames on every rank
-    batch, _ = build_batch(dev, model, frames, a.views)
-    a.no_graph = not a.graph
-    a.no_events = not a.events and a.no_graph and not a.dense
-    flags = _lib.FIT_FETCH | (_lib.FIT_DENSE if a.dense else 0) | (0 if a.no_graph else _lib.FIT_GRAPH) | (_lib.FIT_NOTIME if a.no_events else 0)
+    n_total = F * n_gpus
+    graph = a.graph
+    no_events = not a.events and not graph and not a.dense
+    flags = _lib.FIT_FETCH | (_lib.FIT_DENSE if a.dense else 0) | (_lib.FIT_GRAPH if graph else 0) | (_lib.FIT_NOTIME if no_events else 0)
 
-    barrier = (lambda: None)
-    after = None
-    if world > 1 and a.dist_backend == "nccl":
-        import torch
-        send = torch.empty(F * dev.n_params, dtype=torch.float32, device=f"cuda:{local}")
-        recv = torch.empty(world * F * dev.n_params, dtype=torch.float32, device=f"cuda:{local}")
-
-        def barrier():
-            dist.barrier()
-            torch.cuda.synchronize()
-
-        def after():          # the one collective of the path: final gather of the fitted parameters, once per job
-            batch.export_params_dev(send.data_ptr())
-            batch.sync()      # (the export runs on the batch's stream, the collective on torch's)
-            dist.all_gather_into_tensor(recv, send)
-            torch.cuda.synchronize()
-        gather = recv
-    elif world > 1:
-        import torch
-        recv = torch.empty(world * F * dev.n_params, dtype=torch.float32)
-
-        def barrier():
-            batch.sync()
-            dist.barrier()
-
-        def after():          # same gather through host memory (gloo)
-            dist.all_gather_into_tensor(recv, torch.from_numpy(batch.get_params().reshape(-1)))
-        gather = recv
+    comm = group = None
+    rccl_ranks = 1
+    if mode == "group":
+        # one process, N devices: model + batch + stream per device inside libbodyfit, ncclCommInitAll
+        group = shard.Group(model, gmm, n_frames=n_total, n_views=a.views, n_devices=n_gpus)
+        c2w, K, kp, ndiv, betas, pose = pack(model, range(n_total), a.views)
+        group.set_cameras(c2w, K); group.set_keypoints(kp, ndiv); group.set_init(betas, pose)
+        rccl_ranks = group.comm_size()
+        job, batch, dev = group, group.batches[0], group.models[0]
+        barrier = group.sync
+        finish = group.gather_params
+        reduce_max = (lambda x: x)
+    else:
+        dev = N.DeviceModel(model, gmm, device=local)
+        lo, hi = shard.shard_range(n_total, rank, n_gpus)          # distinct frames on every rank
+        batch = build_batch(dev, model, list(range(lo, hi)), a.views)
+        job = batch
+        if mode == "ranks":
+            comm = shard.Comm(rank, n_gpus, local)
+            rccl_ranks = comm.size()
+            barrier = comm.barrier                                 # device idle + all-reduce over the ranks
+            finish = (lambda: comm.gather_params(batch, n_total))
+            reduce_max = comm.max
+        else:
+            barrier = batch.sync
+            finish = None
+            reduce_max = (lambda x: x)
 
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < a.prewarm_s:      # not part of W: lets clocks and page-in settle
-        run_steps(batch, 5, a.iters, flags)
+        run_steps(job, 5, a.iters, flags)
+        job.sync()
 
-    wall, ev = timed_leg(batch, a.steps, a.warmup, a.iters, flags, barrier, after)
-    if world > 1:
-        import torch
-        t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{local}" if a.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    walls, gathered = timed_brackets(job, a.steps, a.warmup, a.iters, flags, a.repeats, barrier, finish, reduce_max)
+    wall = statistics.median(walls)
 
-    # sanity: the timed path really produced a fit (and the gather really carried every rank's frames)
-    p = N.split_params(batch.get_params()[0])
-    assert np.isfinite(batch.get_params()).all() and abs(float(p["scale"][0]) - 1.0) > 1e-3
-    if gather is not None:
-        allp = gather.cpu().numpy().reshape(world, F, dev.n_params)
-        assert np.array_equal(allp[rank], batch.get_params())
+    # sanity: the timed path really produced a fit (and the gather really carried every GPU's frames)
+    mine = batch.get_params()
+    assert np.isfinite(mine).all() and abs(float(N.split_params(mine[0])["scale"][0]) - 1.0) > 1e-3
+    if gathered is not None:
+        lo, hi = (group.shards[0][1], group.shards[0][1] + group.shards[0][2]) if group else shard.shard_range(n_total, rank, n_gpus)
+        assert gathered.shape == (n_total, dev.n_params) and np.array_equal(gathered[lo:hi], mine)
+        assert np.isfinite(gathered).all() and len(np.unique(gathered[:, 4:14], axis=0)) == n_total     # every frame is a different fit
 
-    total_frames = world * F * a.steps
-    value = total_frames / wall
-    if (not a.no_graph or a.no_events) and not a.dense:
-        # inside a hipGraph (or with the event records switched off) the kernels are not bracketed by events: per-kernel
-        # device times come from the same steps issued command by command, with events, right after the timed region
-        _, ev = timed_leg(batch, max(10, a.steps // 4), 2, a.iters, flags & ~(_lib.FIT_GRAPH | _lib.FIT_NOTIME))
+    per_step = [w / a.steps * 1e3 for w in walls]
+    value = n_total * a.steps / wall
+    ev = event_leg(batch, max(10, a.steps // 4), a.iters, (flags & ~(_lib.FIT_GRAPH | _lib.FIT_NOTIME)))
     fit_ms = ev["fit_ms"] / max(ev["calls"], 1)
     mesh_ms = ev["mesh_ms"] / max(ev["calls"], 1)
-    traffic = pmc_traffic()
+    traffic = pmc_traffic() or {}
+    fit_traffic = traffic.get("bf_fit_kernel_bytes_per_launch")
+    how = {"single": "1 GPU", "group": f"frames sharded over {n_gpus} GPUs driven by one process (bf_group: ncclCommInitAll), one RCCL all-gather "
+                                       f"of the fitted parameters per job",
+           "ranks": f"frames sharded over {n_gpus} GPUs, one process per GPU (bf_comm: ncclCommInitRank, id exchanged through the file system), "
+                    f"one RCCL all-gather of the fitted parameters per job"}[mode]
     out = {
         "metric": "frames fitted/sec (100 iters, 48 views, SMPL 6890v)",
-        "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "repeats": {"brackets": len(walls), "ms_per_step": spread(per_step),
+                    "value": spread([n_total * a.steps / w for w in walls])},
         "config": {"workload": (f"{F} frame(s) per GPU per step x {a.views} views x {a.iters} Adam iters, SMPL-shaped "
                                 f"synthetic model (6890 v, 24 joints), keypoint-only loss"
                                 + (" = BASELINE config 2" if F == 1 else "")
                                 + (" = BASELINE config 4 shard" if F == 32 else "")),
                    "frames_per_gpu": F, "views": a.views, "iters": a.iters,
                    "schedule": "dense (full mesh every iteration)" if a.dense else "sparse (gradient-carrying vertices only) + one final full mesh",
-                   "submission": ("host-issued: 4 kernels per step (fit, mesh, joints, publish)" + (", no event records in the timed steps" if a.no_events else ""))
-                                 if (a.no_graph or a.dense) else "one hipGraph launch per step",
-                   "parallelism": f"frames sharded over {world} GPU(s), one RCCL all-gather of the fitted parameters per job" if world > 1 else "1 GPU"},
+                   "submission": ("one hipGraph launch per step" if graph and not a.dense else
+                                  "host-issued: 4 kernels per step (fit, mesh, joints, publish)" + (", no event records in the timed steps" if no_events else "")),
+                   "parallelism": how, "launch_mode": mode, "rccl_ranks": rccl_ranks, "torch_on_measured_path": "torch" in sys.modules},
         "roofline": {
             "bound": "hbm", "kernel": "bf_fit_kernel" if not a.dense else "bf_fit_kernel+bf_mesh_kernel (per iteration)",
             "achieved": BYTES_PER_FRAME_ITER * a.iters * F / (fit_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": BYTES_PER_FRAME_ITER * a.iters * F / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": (traffic or {}).get("bf_fit_kernel_bytes_per_launch"),
+            "traffic": fit_traffic,
             "avg_launch_ms": fit_ms,
             "algorithmic_bytes_per_launch": BYTES_PER_FRAME_ITER * a.iters * F,
             "note": "nominal bytes = SURVEY 8(d) dense forward stream (19,595,160 B per frame-iteration) x iters x frames; "
                     "the sparse kernel keeps its working set in LDS, see DESIGN.md",
+            # what the kernel really is: a latency chain on one CU per frame - report it in its own units too
+            "real_hbm_gbs": (fit_traffic / (fit_ms * 1e-3) / 1e9) if fit_traffic else None,
+            "latency": {"cycles_per_iteration": fit_ms * 1e-3 * ENGINE_CLOCK_GHZ * 1e9 / a.iters, "clock_ghz": ENGINE_CLOCK_GHZ,
+                        "dependent_chain_bound_cycles": CHAIN_BOUND_CYCLES,
+                        "frac_of_chain_bound": CHAIN_BOUND_CYCLES / (fit_ms * 1e-3 * ENGINE_CLOCK_GHZ * 1e9 / a.iters),
+                        "note": "one workgroup = one frame; bound = dependent LDS round trips x ~90 cycles + 5 s_barriers per iteration (DESIGN.md 4.1)"},
         },
         "roofline_mesh": {
             "bound": "hbm", "kernel": "bf_mesh_kernel", "achieved": BYTES_MESH_LAUNCH * F / (mesh_ms * 1e-3) / 1e9 if mesh_ms > 0 else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": BYTES_MESH_LAUNCH * F / (mesh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if mesh_ms > 0 else None,
-            "traffic": (traffic or {}).get("bf_mesh_kernel_bytes_per_launch"), "avg_launch_ms": mesh_ms,
+            "traffic": traffic.get("bf_mesh_kernel_bytes_per_launch"), "avg_launch_ms": mesh_ms,
             "algorithmic_bytes_per_launch": BYTES_MESH_LAUNCH * F,
             "note": "avg_launch_ms is the HIP-event bracket around a ~6 us kernel and includes the record overhead; rocprofv3 "
-                    "--kernel-trace gives 6.1 us for it (profiles/r01_rocprof_final.md), i.e. 3.1 TB/s = 0.38 of peak",
+                    "--kernel-trace gives the kernel alone (profiles/)",
         },
         "device_ms_per_step": {k: ev[k] / max(ev["calls"], 1) for k in ("fit_ms", "mesh_ms", "tail_ms", "total_ms")},
     }
 
-    if rank == 0 and world == 1 and not a.no_extra:
+    if rank == 0 and not a.no_extra:
         extra = {}
-        # the reference-literal schedule on the same workload
-        if not a.dense:
-            w, e = timed_leg(batch, max(4, a.steps // 5), 2, a.iters, _lib.FIT_FETCH | _lib.FIT_DENSE)
-            n = max(4, a.steps // 5)
-            extra["dense_schedule"] = {"value": F * n / w, "unit": "frames/s", "ms_per_step": w / n * 1e3,
-                                       "device_fit_ms": e["fit_ms"] / e["calls"]}
-        # config 4's per-GPU shard and a CU-filling batch: frames are independent workgroups
-        for fb in (32, 256, 1024):
-            if fb == F:
-                continue
-            bb, _ = build_batch(dev, model, list(range(fb)), a.views)
-            n = 10
-            _, e = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH)                                  # (with events: device times)
-            w, _ = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_RESET | _lib.FIT_NOTIME)
-            wg, _ = timed_leg(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_GRAPH)        # (pipelined fetch from 8 frames on)
-            w = min(w, wg)
-            extra[f"batch_{fb}_frames"] = {"value": fb * n / w, "unit": "frames/s", "ms_per_step": w / n * 1e3,
-                                           "device_fit_ms": e["fit_ms"] / e["calls"], "device_mesh_ms": e["mesh_ms"] / e["calls"]}
-            bb.close()
-        # the dense-loss configurations of BASELINE.json (3 and 5 as stated) on this GPU: tools/bench_configs.py
-        if not a.no_configs:
+        if mode == "single":
+            # the reference-literal schedule on the same workload
+            if not a.dense:
+                n = max(4, a.steps // 5)
+                w, _ = timed_brackets(batch, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_DENSE, 1, batch.sync)
+                e = event_leg(batch, n, a.iters, _lib.FIT_FETCH | _lib.FIT_DENSE)
+                extra["dense_schedule"] = {"value": F * n / w[0], "unit": "frames/s", "ms_per_step": w[0] / n * 1e3,
+                                           "device_fit_ms": e["fit_ms"] / e["calls"]}
+            # config 4's per-GPU shard and a CU-filling batch: frames are independent workgroups
+            for fb in (32, 256, 1024):
+                if fb == F:
+                    continue
+                bb = build_batch(dev, model, list(range(fb)), a.views)
+                n = 10
+                e = event_leg(bb, n, a.iters, _lib.FIT_FETCH)                                  # (with events: device times)
+                w, _ = timed_brackets(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_NOTIME, 3, bb.sync)
+                wg, _ = timed_brackets(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_GRAPH, 3, bb.sync)   # (pipelined fetch from 8 frames on)
+                w = min(statistics.median(w), statistics.median(wg))
+                extra[f"batch_{fb}_frames"] = {"value": fb * n / w, "unit": "frames/s", "ms_per_step": w / n * 1e3,
+                                               "device_fit_ms": e["fit_ms"] / e["calls"], "device_mesh_ms": e["mesh_ms"] / e["calls"]}
+                bb.close()
+            # the dense-loss configurations of BASELINE.json (3 and 5 as stated) on this GPU: tools/bench_configs.py
+            if not a.no_configs:
+                try:
+                    sys.path.insert(0, os.path.join(REPO, "tools"))
+                    import bench_configs as BC
+                    extra["config_3"] = BC.cfg3(2)
+                    extra["config_5"] = BC.cfg5x(2)
+                except Exception as exc:                       # (never let a side leg take the headline line down)
+                    extra["configs_error"] = repr(exc)
+        elif mode == "group" and F != 32:
+            # BASELINE config 4 as stated: 32 frames per GPU, sharded by the same group API
             try:
-                sys.path.insert(0, os.path.join(REPO, "tools"))
-                import bench_configs as BC
-                extra["config_3"] = BC.cfg3(2)
-                extra["config_5"] = BC.cfg5x(2)
-            except Exception as exc:                       # (never let a side leg take the headline line down)
-                extra["configs_error"] = repr(exc)
-        out["extra"] = extra
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+                g4 = shard.Group(model, gmm, n_frames=32 * n_gpus, n_views=a.views, n_devices=n_gpus)
+                c2w, K, kp, ndiv, betas, pose = pack(model, range(32 * n_gpus), a.views)
+                g4.set_cameras(c2w, K); g4.set_keypoints(kp, ndiv); g4.set_init(betas, pose)
+                n = 10
+                w, full = timed_brackets(g4, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_GRAPH, 3, g4.sync, g4.gather_params)
+                assert full.shape[0] == 32 * n_gpus and np.isfinite(full).all()
+                wm = statistics.median(w)
+                extra["config_4"] = {"workload": f"{32 * n_gpus} frames = 32 per GPU x {n_gpus} GPUs, 48 views, 100 iters, one RCCL all-gather per job",
+                                     "value": 32 * n_gpus * n / wm, "unit": "frames/s", "ms_per_step": wm / n * 1e3,
+                                     "ms_per_step_spread": spread([x / n * 1e3 for x in w])}
+                g4.close()
+            except Exception as exc:
+                extra["config_4_error"] = repr(exc)
+        if extra:
+            out["extra"] = extra
+    if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, gmm, a.cpu_frames, a.views, a.iters)
-    batch.close()
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.barrier()
+        comm.rendezvous.cleanup()
+        comm.close()
+    if group is not None:
+        group.close()
+    else:
+        batch.close()
+        dev.close()
 
 
 if __name__ == "__main__":

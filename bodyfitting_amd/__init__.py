@@ -7,7 +7,5 @@
 Importing the package never touches the GPU; the HIP library is loaded on first use and its absence
 is an error (there is no CPU implementation of the product path).
 """
-from . import synthetic  # noqa: F401
-
-__all__ = ["synthetic"]
+# (`bodyfitting_amd.synthetic` - the generator of test / benchmark inputs - is imported by the tests and bench.py only)
 __version__ = "0.1"

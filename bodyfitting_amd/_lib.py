@@ -88,6 +88,30 @@ SIGNATURES = {
     "bf_batch_last_timing": (C.c_int, [_VP, _FP]),
     "bf_batch_timing_reset": (C.c_int, [_VP]),
     "bf_batch_timing_sum": (C.c_int, [_VP, _FP, _IP]),
+    "bf_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _IP, _IP]),
+    "bf_shard_capacity": (C.c_int, [C.c_int, C.c_int]),
+    "bf_shard_unpack": (C.c_int, [_FP, C.c_int, C.c_int, C.c_int, _FP]),
+    "bf_group_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, _IP, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "bf_group_destroy": (None, [_VP]),
+    "bf_group_n_devices": (C.c_int, [_VP]),
+    "bf_group_n_params": (C.c_int, [_VP]),
+    "bf_group_shard": (C.c_int, [_VP, C.c_int, _IP, _IP, _IP]),
+    "bf_group_batch": (_VP, [_VP, C.c_int]),
+    "bf_group_model": (_VP, [_VP, C.c_int]),
+    "bf_group_set_cameras": (C.c_int, [_VP, _FP, _FP]),
+    "bf_group_set_keypoints": (C.c_int, [_VP, _FP, _IP]),
+    "bf_group_set_init": (C.c_int, [_VP, _FP, _FP]),
+    "bf_group_fit": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper), C.c_uint32]),
+    "bf_group_sync": (C.c_int, [_VP]),
+    "bf_group_comm_size": (C.c_int, [_VP]),
+    "bf_group_gather_params": (C.c_int, [_VP, _FP, C.c_int]),
+    "bf_comm_unique_id": (C.c_int, [C.POINTER(C.c_uint8)]),
+    "bf_comm_create": (C.c_int, [C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int, C.POINTER(_VP)]),
+    "bf_comm_destroy": (None, [_VP]),
+    "bf_comm_size": (C.c_int, [_VP]),
+    "bf_comm_barrier": (C.c_int, [_VP]),
+    "bf_comm_allreduce": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int]),
+    "bf_comm_gather_params": (C.c_int, [_VP, _VP, C.c_int, _FP]),
     "bf_batch_debug_dump": (C.c_int, [_VP, _FP, C.c_int]),
     "bf_batch_debug_disp_moment": (C.c_int, [_VP, _FP]),
 }

@@ -71,6 +71,21 @@ def get_gmm(prior_folder="data", num_gaussians=8):
     return _GMM["gmm"]
 
 
+def gmm_buffers(gmm):
+    """The three buffers the merged GMM NLL uses (reference smplify/prior.py:143-160).
+
+    Returns float32 ``means[M,D]``, ``precisions[M,D,D]`` and ``nll_weights[M]`` computed in
+    float64 and rounded once, exactly as the reference constructor does.
+    """
+    means = np.asarray(gmm["means"], dtype=np.float32)
+    covs32 = np.asarray(gmm["covars"], dtype=np.float32)
+    precisions = np.stack([np.linalg.inv(c) for c in covs32]).astype(np.float32)
+    sqrdets = np.array([np.sqrt(np.linalg.det(c)) for c in gmm["covars"]])
+    const = (2.0 * np.pi) ** (69 / 2.0)
+    nll_weights = np.asarray(gmm["weights"] / (const * (sqrdets / sqrdets.min())))
+    return means, precisions, nll_weights.astype(np.float32)
+
+
 def get_device_model(model_type="smpl", gender="neutral", device=0):
     """The HIP-resident model, created once per (type, gender, device)."""
     from .native import DeviceModel

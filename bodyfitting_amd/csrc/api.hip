@@ -367,7 +367,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
 void bf_model_destroy(bf_model *m) { delete m; }
 int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
 
-int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
+int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw, int *lmk_vid,
                    float *lmk_w, float *dvzero, bool *zeroed) {
     if (zeroed) *zeroed = false;
@@ -377,18 +377,20 @@ int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, floa
         // batched pose blend on the matrix cores (posedirs streamed once for up to 256 frames), then the per-frame
         // shape / skinning part only
         const size_t ncols = (size_t)m->nv * 3;
-        if (m->pose_off.n < (size_t)n * ncols) {
-            if (m->pose_off.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(m->pose_off.p); m->pose_off.p = nullptr; }
-            HIP_TRY(m->pose_off.alloc((size_t)n * ncols));
+        if (!scr) return fail(BF_ERR_INVALID, "bf_launch_mesh: the batched path needs a scratch owner");
+        // (the scratch belongs to this stream's owner, so draining this stream is enough before a buffer is replaced)
+        if (scr->pose_off.n < (size_t)n * ncols) {
+            if (scr->pose_off.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(scr->pose_off.p); scr->pose_off.p = nullptr; }
+            HIP_TRY(scr->pose_off.alloc((size_t)n * ncols));
         }
         // A operand of the GEMM: the pose features of the batch, frame-minor and zero padded
         const int kpad = ((m->npf + 2 * BF_GEMM_KB - 1) / (2 * BF_GEMM_KB)) * 2 * BF_GEMM_KB, fpad = ((n + 127) / 128) * 128;
-        if (m->featT.n < (size_t)kpad * fpad) {
-            if (m->featT.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(m->featT.p); m->featT.p = nullptr; }
-            HIP_TRY(m->featT.alloc((size_t)kpad * fpad));
+        if (scr->featT.n < (size_t)kpad * fpad) {
+            if (scr->featT.p) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(scr->featT.p); scr->featT.p = nullptr; }
+            HIP_TRY(scr->featT.alloc((size_t)kpad * fpad));
         }
-        HIP_TRY(bf_poseblend_launch(&m->mesh, state_dev, n, m->featT.p, kpad, fpad, m->pose_off.p, stream));
-        pose_off = m->pose_off.p;
+        HIP_TRY(bf_poseblend_launch(&m->mesh, state_dev, n, scr->featT.p, kpad, fpad, scr->pose_off.p, stream));
+        pose_off = scr->pose_off.p;
         if (m->mesh.v_nnz == 4 && m->nb <= 10 && !vposed) {
             hipLaunchKernelGGL(bf_mesh_epilogue_batch_kernel, dim3((m->nv + 127) / 128, (n + BF_EPI_FRAMES - 1) / BF_EPI_FRAMES), dim3(128),
                                (size_t)BF_EPI_FRAMES * (m->nj * 12 + 128 * 3) * sizeof(float), stream, m->mesh, state_dev, pose_off, n, vraw, vout,
@@ -421,6 +423,7 @@ int bf_smpl_forward(bf_model *m, int n, const float *betas, const float *global_
     const int nj = m->nj, nb = m->nb, nv = m->nv;
     const size_t stride = bf_state_stride(nj, m->npf, nb);
     DevBuf<float> d_beta, d_or, d_bp, d_state, d_vraw, d_j, d_jo, d_xp;
+    MeshScratch scratch;
     HIP_TRY(d_beta.upload(std::vector<float>(betas, betas + (size_t)n * nb)));
     HIP_TRY(d_or.upload(std::vector<float>(global_orient, global_orient + (size_t)n * 3)));
     HIP_TRY(d_bp.upload(std::vector<float>(body_pose, body_pose + (size_t)n * 3 * (nj - 1))));
@@ -433,7 +436,7 @@ int bf_smpl_forward(bf_model *m, int n, const float *betas, const float *global_
                        (const float *)d_or.p, (const float *)d_bp.p, (const float *)nullptr, d_state.p,
                        (const float *)nullptr, (const float *)nullptr, 1.0f);
     HIP_TRY(hipGetLastError());
-    int rc = bf_launch_mesh(m, n, d_state.p, d_vraw.p, nullptr, d_xp.p, d_j.p, d_jo.p, 0, nullptr, nullptr);
+    int rc = bf_launch_mesh(m, &scratch, n, d_state.p, d_vraw.p, nullptr, d_xp.p, d_j.p, d_jo.p, 0, nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     if (vertices) HIP_TRY(hipMemcpy(vertices, d_vraw.p, (size_t)n * nv * 3 * sizeof(float), hipMemcpyDeviceToHost));
@@ -524,7 +527,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
              hipMemset(b->debug.p, 0, 8192 * sizeof(float)) == hipSuccess;
     }
     if (!ok) { bf_batch_destroy(b); return fail(BF_ERR_HIP, "bf_batch_create: device allocation failed"); }
-    m->fit_smem = smem;
+    b->fit_smem = smem;
     *out = b;
     return BF_OK;
 }
@@ -537,6 +540,7 @@ void bf_batch_destroy(bf_batch *b) {
     for (auto &e : b->ring) if (e) (void)hipEventDestroy(e);
     if (b->h_res) (void)hipHostFree(b->h_res);
     if (b->h_res_b) (void)hipHostFree(b->h_res_b);
+    if (b->h_pc_weight) (void)hipHostFree(b->h_pc_weight);
     for (int k = 0; k < 2; ++k) {
         if (b->graph_pipe[k]) (void)hipGraphExecDestroy(b->graph_pipe[k]);
         if (b->ev_done[k]) (void)hipEventDestroy(b->ev_done[k]);
@@ -582,6 +586,8 @@ int bf_batch_set_cameras(bf_batch *b, const float *c2w, const float *K) {
                 proj[i * 12 + r * 4 + c] =
                     (float)((double)k[r * 3] * w2c[c] + (double)k[r * 3 + 1] * w2c[4 + c] + (double)k[r * 3 + 2] * w2c[8 + c]);
     }
+    // bf_fit is asynchronous on the batch's own (non-blocking) stream: a fit still in flight reads these inputs
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     HIP_TRY(hipMemcpy(b->proj.p, proj.data(), proj.size() * sizeof(float), hipMemcpyHostToDevice));
     return BF_OK;
 }
@@ -589,13 +595,14 @@ int bf_batch_set_cameras(bf_batch *b, const float *c2w, const float *K) {
 int bf_batch_set_keypoints(bf_batch *b, const float *keypoints, const int32_t *n_use_frames) {
     if (!b || !keypoints) return fail(BF_ERR_INVALID, "bf_batch_set_keypoints: null argument");
     HIP_TRY(hipSetDevice(b->m->device));
-    HIP_TRY(hipMemcpy(b->keypoints.p, keypoints, b->keypoints.n * sizeof(float), hipMemcpyHostToDevice));
     std::vector<int> nd(b->F, b->V);
     if (n_use_frames)
         for (int f = 0; f < b->F; ++f) {
             if (n_use_frames[f] <= 0) return fail(BF_ERR_INVALID, "bf_batch_set_keypoints: n_use_frames must be positive");
             nd[f] = n_use_frames[f];
         }
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }      // (a fit still in flight reads the old keypoints)
+    HIP_TRY(hipMemcpy(b->keypoints.p, keypoints, b->keypoints.n * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->ndiv.p, nd.data(), nd.size() * sizeof(int), hipMemcpyHostToDevice));
     return BF_OK;
 }
@@ -714,10 +721,10 @@ static int enqueue_plain(bf_batch *b, int n_iters, const HyperDev &hd, const Fra
     const size_t fb = sizeof(float);
     FrameIO io2 = io;
     if (reset) io2.params0 = b->params0.p;      // re-arm inside the fit kernel: no copy / memset commands
-    HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, adam_t0, m->fit_smem, b->stream));
+    HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, adam_t0, b->fit_smem, b->stream));
     if (ev) HIP_TRY(hipEventRecord(ev[1], b->stream));
     if (want_v) {
-        int rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream,
+        int rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream,
                                 ev ? ev[2] : nullptr, nullptr);
         if (rc) return rc;
     } else if (ev) HIP_TRY(hipEventRecord(ev[2], b->stream));
@@ -764,9 +771,9 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if ((flags & BF_FIT_GRAPH) && reset && !dense_losses && !dense) {
         // the whole call as one hipGraph launch: the host issues a single command per fit
         // the MFMA batch path may grow its scratch buffer: make sure that happened before capturing
-        if (want_v && b->F >= BF_MFMA_MIN_FRAMES && m->pose_off.n < (size_t)b->F * m->nv * 3) {
+        if (want_v && b->F >= BF_MFMA_MIN_FRAMES && b->scratch.pose_off.n < (size_t)b->F * m->nv * 3) {
             { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
-            rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
+            rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
             if (rc) return rc;
             { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
         }
@@ -851,14 +858,14 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
             if (rc) return rc;
             HIP_TRY(hipEventRecord(b->ev[1], b->stream));
             if (want_v) {
-                rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, b->ev[2], nullptr);
+                rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, b->ev[2], nullptr);
                 if (rc) return rc;
             } else HIP_TRY(hipEventRecord(b->ev[2], b->stream));
         } else {
             // reference-literal schedule: every iteration evaluates the whole mesh (smplify.py:179-190)
             for (int it = 0; it < n_iters; ++it) {
-                HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
-                rc = bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
+                HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, b->fit_smem, b->stream));
+                rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
                 if (rc) return rc;
             }
             HIP_TRY(hipEventRecord(b->ev[1], b->stream));
@@ -891,7 +898,7 @@ int bf_loss_grad(bf_batch *b, const bf_hyper *hyper, float *terms, float *grads)
     if (rc) return rc;
     FrameIO io = bf_frame_io(b, true);
     if (m->kp_dense) { rc = bf_dense_loss_grad(b, h, hd, io); if (rc) return rc; }
-    else HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, m->fit_smem, b->stream));
+    else HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, b->fit_smem, b->stream));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (terms) HIP_TRY(hipMemcpy(terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));
     if (grads) HIP_TRY(hipMemcpy(grads, b->grads.p, b->grads.n * sizeof(float), hipMemcpyDeviceToHost));

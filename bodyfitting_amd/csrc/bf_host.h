@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -39,13 +40,20 @@ struct DevBuf {
     ~DevBuf() { if (p && !view) (void)hipFree(p); }
 };
 
+// Scratch of the MFMA batch path of the full-mesh forward (>= BF_MFMA_MIN_FRAMES frames).  Owned by whoever owns the stream
+// the forward runs on (a bf_batch, or a one-off forward call): two batches of one model never share it.
+struct MeshScratch {
+    DevBuf<float> pose_off;       // [F][3NV] batched pose-blend result, grown on demand
+    DevBuf<float> featT;          // [K padded][F padded] pose features of a batch, frame-minor (the GEMM's A operand)
+};
+
 struct bf_model {
     int device = 0;
     int nv = 0, nj = 0, nb = 0, npf = 0, ns = 0, nl = 0, np = 0, n_levels = 0;
     int n_selector = 0, n_extra = 0, n_joint_map = 0;
     FitTab fit{};
     MeshTab mesh{};
-    size_t fit_smem = 0, mesh_smem = 0;
+    size_t mesh_smem = 0;
     DevBuf<float> v_template, shapedirs, posedirs, lbs_weights, j_extra;
     DevBuf<int> selector_ids, joint_map;
     DevBuf<int> depth_d, sel_nzj;
@@ -61,11 +69,10 @@ struct bf_model {
     DevBuf<int> th_kind, th_off, p_kind, p_a, p_b, faces_lm, lmk_faces, dyn_faces, kp_jm, cj_start, cj_list;
     DevBuf<float> pose_mean, hand_comp, lmk_bary, dyn_bary;
     KpIO kp{};
-    DevBuf<float> pose_off;       // [F][3NV] batched pose-blend result (MFMA path), grown on demand
-    DevBuf<float> featT;          // [K padded][F padded] pose features of a batch, frame-minor (the GEMM's A operand)
     DevBuf<int> v_nzj;            // sparse skinning rows (MeshTab::v_nnz)
     DevBuf<float> v_nzw;
-    DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass
+    DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass (under `lazy`, device-synchronised)
+    std::mutex lazy;              // guards the build-on-first-use tables (posedirsT, faces_d / adj)
     std::vector<int> faces_host;  // body-model topology (for the SMPL+D stage), optional
     DevBuf<int> faces_d, adj_start, adj;   // faces and the vertex -> (face, corner) lists, built on first use
 };
@@ -75,6 +82,8 @@ struct bf_graph_key { int n_iters; uint32_t flags; int arena; bf_hyper h; };    
 struct bf_batch {
     bf_model *m = nullptr;
     int F = 0, V = 0;
+    size_t fit_smem = 0;            // dynamic LDS of the fit kernel for THIS batch's view count (the carve depends on V)
+    MeshScratch scratch;            // pose_off / featT of the MFMA batch path, used on this batch's stream only
     hipStream_t stream = nullptr;
     static constexpr int kRing = 1024;
     std::vector<hipEvent_t> ring;   // kRing x 4 events: | fit | mesh | joints + fetch |
@@ -110,6 +119,7 @@ struct bf_batch {
     // dense vertex losses (use_mesh, smplify.py:146-156,205-206)
     std::vector<struct bf_scan *> scans;
     DevBuf<ScanDev> scan_dev;
+    float *h_pc_weight = nullptr;   // pinned staging of pc_weight
     DevBuf<float> cscale, pc_weight, pc_partial, pc_loss, dvout, vposed, cpts, ext_part, ext;
     DevBuf<int> cface, lmk_vid;
     bool cface_valid = false;       // cface holds the faces of an earlier closest-point call for these scans (warm start)
@@ -138,7 +148,7 @@ struct bf_scan {
 
 // shared between api.hip and scan_api.hip
 extern "C" {
-int bf_launch_mesh(bf_model *m, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
+int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw = nullptr,
                    int *lmk_vid = nullptr, float *lmk_w = nullptr, float *dvzero = nullptr, bool *zeroed = nullptr);
 // (dvzero: a [n][NV][3] buffer the forward pass should zero while it is at it - only the 1..15-frame kernel does, *zeroed says so)

@@ -1589,8 +1589,12 @@ extern "C" hipError_t bf_fit_launch(const FitTab *T, const FrameIO *io, const Hy
     const bool smplx_dense = ext && T->nj == 55 && T->nb == 10 && T->ns == 0 && T->nl == 0;
     auto kern = smpl ? (ext ? fit_kernel<24, 10, 11, 25, true> : fit_kernel<24, 10, 11, 25, false>)
                      : (smplx_dense ? fit_kernel<55, 10, 0, 0, true> : (ext ? fit_kernel<0, 0, 0, 0, true> : fit_kernel<0, 0, 0, 0, false>));
-    static size_t attr[5] = {0, 0, 0, 0, 0};
-    size_t &have = attr[smplx_dense ? 4 : (smpl ? 2 : 0) + (ext ? 1 : 0)];
+    // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: the cache of what was set is keyed by device
+    static size_t attr[16][5] = {};
+    static size_t none = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    size_t &have = (dev >= 0 && dev < 16) ? attr[dev][smplx_dense ? 4 : (smpl ? 2 : 0) + (ext ? 1 : 0)] : (none = 0);
     if (smem > 64 * 1024 && smem > have) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;

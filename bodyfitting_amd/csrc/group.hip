@@ -1,0 +1,409 @@
+// Frame sharding over the GPUs of one node inside libbodyfit: no PyTorch anywhere on this path.
+//
+// Frames are independent (the reference fits them in a serial loop, apps/genebody_fitting.py:183-192), so a job of F frames
+// is cut into contiguous blocks, one per GPU; the body model and the cameras are replicated; nothing is exchanged during the
+// fit.  The ONE collective of the path is the final gather of the packed parameters [frames_per_gpu, n_params]: an
+// ncclAllGather over RCCL (xGMI inside the node).
+//
+//   bf_group  - ONE process drives n devices: one bf_model + bf_batch + stream per device, ncclCommInitAll, grouped all-gather.
+//   bf_comm   - one process PER device (torchrun-style launch): ncclCommInitRank from a 128-byte id the ranks exchange through
+//               the host (bodyfitting_amd/shard.py does that through the file system), the same all-gather, plus the barrier
+//               and the max-over-ranks reduction the benchmark contract needs.
+//
+// librccl (570 MB of code objects) is opened lazily with dlopen the first time a communicator is needed: the single-GPU
+// product path never pays for it.
+#include "bf_host.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl *rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+            R.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (R.handle) break;
+        }
+        if (!R.handle) { R.error = std::string("dlopen(librccl.so.1): ") + dlerror(); return; }
+        auto sym = [&](const char *n) {
+            void *p = dlsym(R.handle, n);
+            if (!p && R.error.empty()) R.error = std::string("librccl has no symbol ") + n;
+            return p;
+        };
+        R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+        R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+        R.CommInitAll = (decltype(R.CommInitAll))sym("ncclCommInitAll");
+        R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+        R.CommCount = (decltype(R.CommCount))sym("ncclCommCount");
+        R.AllGather = (decltype(R.AllGather))sym("ncclAllGather");
+        R.AllReduce = (decltype(R.AllReduce))sym("ncclAllReduce");
+        R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
+        R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
+        R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    });
+    return &R;
+}
+
+#define RCCL_TRY(expr)                                                                                      \
+    do {                                                                                                    \
+        ncclResult_t r_ = (expr);                                                                           \
+        if (r_ != ncclSuccess) return fail(BF_ERR_HIP, std::string(#expr) + ": " + rccl()->GetErrorString(r_)); \
+    } while (0)
+
+int need_rccl() {
+    Rccl *R = rccl();
+    if (!R->error.empty()) return fail(BF_ERR_UNSUPPORTED, "RCCL is not usable: " + R->error);
+    return BF_OK;
+}
+
+}  // namespace
+
+struct bf_group_peer {
+    int device = 0, first = 0, count = 0;
+    bf_model *model = nullptr;
+    bf_batch *batch = nullptr;
+    ncclComm_t comm = nullptr;
+    DevBuf<float> send, recv;      // [cap][np], [n][cap][np]
+};
+
+struct bf_group {
+    int n = 0, F = 0, V = 0, np = 0, nl = 0, nb = 0, cap = 0;
+    std::vector<bf_group_peer> peers;
+    bool comm_ready = false;
+    std::vector<float> host;       // [n][cap][np] staging of the gathered block
+};
+
+struct bf_comm {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    DevBuf<float> send, recv;
+    DevBuf<double> scalar;
+    std::vector<float> host;
+};
+
+extern "C" {
+
+// Contiguous block of frames owned by shard `shard` of `n_shards`: blocks differ by at most one frame, earlier shards take
+// the remainder.  Host arithmetic only (no device needed) - the one place the partition is defined.
+int bf_shard_range(int n_frames, int n_shards, int shard, int32_t *first, int32_t *count) {
+    if (n_frames < 0 || n_shards <= 0 || shard < 0 || shard >= n_shards || !first || !count)
+        return fail(BF_ERR_INVALID, "bf_shard_range: bad argument");
+    const int base = n_frames / n_shards, rem = n_frames % n_shards;
+    *first = shard * base + std::min(shard, rem);
+    *count = base + (shard < rem ? 1 : 0);
+    return BF_OK;
+}
+
+// frames per shard the all-gather is padded to (the largest block)
+int bf_shard_capacity(int n_frames, int n_shards) {
+    if (n_frames < 0 || n_shards <= 0) return 0;
+    return (n_frames + n_shards - 1) / n_shards;
+}
+
+// What an all-gather of per-shard blocks padded to bf_shard_capacity() leaves behind, gathered[n_shards][cap][width], to the
+// dense [n_frames][width] array in frame order.  Host arithmetic only.
+int bf_shard_unpack(const float *gathered, int n_frames, int n_shards, int width, float *out) {
+    if (!gathered || !out || n_frames < 0 || n_shards <= 0 || width <= 0) return fail(BF_ERR_INVALID, "bf_shard_unpack: bad argument");
+    const int cap = bf_shard_capacity(n_frames, n_shards);
+    for (int s = 0; s < n_shards; ++s) {
+        int32_t first, count;
+        bf_shard_range(n_frames, n_shards, s, &first, &count);
+        std::memcpy(out + (size_t)first * width, gathered + (size_t)s * cap * width, (size_t)count * width * sizeof(float));
+    }
+    return BF_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// one process, n devices
+// ---------------------------------------------------------------------------------------------------------------------------
+void bf_group_destroy(bf_group *g) {
+    if (!g) return;
+    for (auto &p : g->peers) {
+        (void)hipSetDevice(p.device);
+        if (p.batch) (void)bf_batch_sync(p.batch);
+        if (p.comm) (void)rccl()->CommDestroy(p.comm);
+        if (p.send.p) { (void)hipFree(p.send.p); p.send.p = nullptr; }
+        if (p.recv.p) { (void)hipFree(p.recv.p); p.recv.p = nullptr; }
+        if (p.batch) bf_batch_destroy(p.batch);
+        if (p.model) bf_model_destroy(p.model);
+    }
+    delete g;
+}
+
+int bf_group_create(const bf_model_desc *desc, int n_devices, const int32_t *devices, int n_frames, int n_views, bf_group **out) {
+    if (!desc || !out || n_devices <= 0 || n_frames < n_devices || n_views <= 0)
+        return fail(BF_ERR_INVALID, "bf_group_create: need a model, >= 1 device and at least one frame per device");
+    *out = nullptr;
+    const int have = bf_device_count();
+    for (int i = 0; i < n_devices; ++i) {
+        const int d = devices ? devices[i] : i;
+        if (d < 0 || d >= have)
+            return fail(BF_ERR_NO_DEVICE, "bf_group_create: device " + std::to_string(d) + " requested, " + std::to_string(have) + " visible");
+        for (int k = 0; k < i; ++k)
+            if ((devices ? devices[k] : k) == d) return fail(BF_ERR_INVALID, "bf_group_create: a device is listed twice");
+    }
+    auto *g = new bf_group();
+    g->n = n_devices; g->F = n_frames; g->V = n_views; g->cap = bf_shard_capacity(n_frames, n_devices);
+    g->peers.resize(n_devices);
+    for (int i = 0; i < n_devices; ++i) {
+        bf_group_peer &p = g->peers[i];
+        p.device = devices ? devices[i] : i;
+        int32_t first, count;
+        bf_shard_range(n_frames, n_devices, i, &first, &count);
+        p.first = first; p.count = count;
+        int rc = bf_model_create(desc, p.device, &p.model);
+        if (!rc) rc = bf_batch_create(p.model, p.count, n_views, &p.batch);
+        if (rc) { std::string keep = bf_err_slot(); bf_group_destroy(g); return fail(rc, keep); }
+    }
+    g->np = g->peers[0].model->np; g->nl = g->peers[0].model->nl_loss; g->nb = g->peers[0].model->nb;
+    *out = g;
+    return BF_OK;
+}
+
+int bf_group_n_devices(const bf_group *g) { return g ? g->n : 0; }
+int bf_group_n_params(const bf_group *g) { return g ? g->np : 0; }
+
+int bf_group_shard(const bf_group *g, int i, int32_t *device, int32_t *first, int32_t *count) {
+    if (!g || i < 0 || i >= g->n) return fail(BF_ERR_INVALID, "bf_group_shard: bad argument");
+    if (device) *device = g->peers[i].device;
+    if (first) *first = g->peers[i].first;
+    if (count) *count = g->peers[i].count;
+    return BF_OK;
+}
+
+bf_batch *bf_group_batch(bf_group *g, int i) { return (g && i >= 0 && i < g->n) ? g->peers[i].batch : nullptr; }
+bf_model *bf_group_model(bf_group *g, int i) { return (g && i >= 0 && i < g->n) ? g->peers[i].model : nullptr; }
+
+// The setters take the arrays of the WHOLE job, [F, ...] in frame order, and hand every device its block.
+int bf_group_set_cameras(bf_group *g, const float *c2w, const float *K) {
+    if (!g || !c2w || !K) return fail(BF_ERR_INVALID, "bf_group_set_cameras: null argument");
+    for (auto &p : g->peers) {
+        int rc = bf_batch_set_cameras(p.batch, c2w + (size_t)p.first * g->V * 16, K + (size_t)p.first * g->V * 9);
+        if (rc) return rc;
+    }
+    return BF_OK;
+}
+
+int bf_group_set_keypoints(bf_group *g, const float *keypoints, const int32_t *n_use_frames) {
+    if (!g || !keypoints) return fail(BF_ERR_INVALID, "bf_group_set_keypoints: null argument");
+    for (auto &p : g->peers) {
+        int rc = bf_batch_set_keypoints(p.batch, keypoints + (size_t)p.first * g->V * g->nl * 3, n_use_frames ? n_use_frames + p.first : nullptr);
+        if (rc) return rc;
+    }
+    return BF_OK;
+}
+
+int bf_group_set_init(bf_group *g, const float *init_betas, const float *init_pose) {
+    if (!g || !init_betas || !init_pose) return fail(BF_ERR_INVALID, "bf_group_set_init: null argument");
+    for (auto &p : g->peers) {
+        int rc = bf_batch_set_init(p.batch, init_betas + (size_t)p.first * g->nb, init_pose + (size_t)p.first * 72);
+        if (rc) return rc;
+    }
+    return BF_OK;
+}
+
+// bf_fit on every device's block: the calls return as soon as the work is queued on each device's own stream, so the n
+// devices run side by side.  No communication.
+int bf_group_fit(bf_group *g, int n_iters, const bf_hyper *hyper, uint32_t flags) {
+    if (!g) return fail(BF_ERR_INVALID, "bf_group_fit: null group");
+    for (auto &p : g->peers) {
+        int rc = bf_fit(p.batch, n_iters, hyper, flags);
+        if (rc) return rc;
+    }
+    return BF_OK;
+}
+
+int bf_group_sync(bf_group *g) {
+    if (!g) return fail(BF_ERR_INVALID, "bf_group_sync: null group");
+    for (auto &p : g->peers) {
+        int rc = bf_batch_sync(p.batch);
+        if (rc) return rc;
+    }
+    return BF_OK;
+}
+
+static int group_comm(bf_group *g) {
+    if (g->comm_ready) return BF_OK;
+    int rc = need_rccl();
+    if (rc) return rc;
+    std::vector<int> devs(g->n);
+    std::vector<ncclComm_t> comms(g->n, nullptr);
+    for (int i = 0; i < g->n; ++i) devs[i] = g->peers[i].device;
+    RCCL_TRY(rccl()->CommInitAll(comms.data(), g->n, devs.data()));
+    const size_t blk = (size_t)g->cap * g->np;
+    for (int i = 0; i < g->n; ++i) {
+        bf_group_peer &p = g->peers[i];
+        p.comm = comms[i];
+        HIP_TRY(hipSetDevice(p.device));
+        HIP_TRY(p.send.alloc(blk));
+        HIP_TRY(p.recv.alloc(blk * g->n));
+        HIP_TRY(hipMemset(p.send.p, 0, blk * sizeof(float)));
+    }
+    g->host.resize(blk * g->n);
+    g->comm_ready = true;
+    return BF_OK;
+}
+
+// number of ranks of the RCCL communicator (creates it on first use): what the benchmark prints as evidence
+int bf_group_comm_size(bf_group *g) {
+    if (!g) return fail(BF_ERR_INVALID, "bf_group_comm_size: null group");
+    int rc = group_comm(g);
+    if (rc) return rc;
+    int n = 0;
+    RCCL_TRY(rccl()->CommCount(g->peers[0].comm, &n));
+    return n;
+}
+
+// The path's one collective.  Every device copies its block of fitted parameters into its send buffer and the n devices
+// all-gather over RCCL, each on its batch's own stream (stream-ordered behind the fit: no host synchronisation before the
+// collective).  params[F][n_params] (host) receives the copy that landed on device `from_peer`.
+int bf_group_gather_params(bf_group *g, float *params, int from_peer) {
+    if (!g || !params || from_peer < 0 || from_peer >= g->n) return fail(BF_ERR_INVALID, "bf_group_gather_params: bad argument");
+    int rc = group_comm(g);
+    if (rc) return rc;
+    const size_t blk = (size_t)g->cap * g->np;
+    for (auto &p : g->peers) {
+        HIP_TRY(hipSetDevice(p.device));
+        rc = bf_guard_arena(p.batch);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(p.send.p, p.batch->params.p, (size_t)p.count * g->np * sizeof(float), hipMemcpyDeviceToDevice, p.batch->stream));
+    }
+    RCCL_TRY(rccl()->GroupStart());
+    for (auto &p : g->peers) {
+        ncclResult_t r = rccl()->AllGather(p.send.p, p.recv.p, blk, ncclFloat, p.comm, p.batch->stream);
+        if (r != ncclSuccess) { (void)rccl()->GroupEnd(); return fail(BF_ERR_HIP, std::string("ncclAllGather: ") + rccl()->GetErrorString(r)); }
+    }
+    RCCL_TRY(rccl()->GroupEnd());
+    bf_group_peer &src = g->peers[from_peer];
+    HIP_TRY(hipSetDevice(src.device));
+    HIP_TRY(hipMemcpyAsync(g->host.data(), src.recv.p, blk * g->n * sizeof(float), hipMemcpyDeviceToHost, src.batch->stream));
+    for (auto &p : g->peers) {                     // the collective is finished when every participant's stream has drained
+        HIP_TRY(hipSetDevice(p.device));
+        HIP_TRY(hipStreamSynchronize(p.batch->stream));
+    }
+    return bf_shard_unpack(g->host.data(), g->F, g->n, g->np, params);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// one process per device
+// ---------------------------------------------------------------------------------------------------------------------------
+int bf_comm_unique_id(uint8_t id[128]) {
+    if (!id) return fail(BF_ERR_INVALID, "bf_comm_unique_id: null argument");
+    int rc = need_rccl();
+    if (rc) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+    ncclUniqueId u;
+    RCCL_TRY(rccl()->GetUniqueId(&u));
+    std::memcpy(id, &u, 128);
+    return BF_OK;
+}
+
+void bf_comm_destroy(bf_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)rccl()->CommDestroy(c->comm);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int bf_comm_create(const uint8_t id[128], int rank, int world, int device, bf_comm **out) {
+    if (!id || !out || world <= 0 || rank < 0 || rank >= world) return fail(BF_ERR_INVALID, "bf_comm_create: bad argument");
+    *out = nullptr;
+    if (device < 0 || device >= bf_device_count()) return fail(BF_ERR_NO_DEVICE, "bf_comm_create: no such HIP device");
+    int rc = need_rccl();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    auto *c = new bf_comm();
+    c->rank = rank; c->world = world; c->device = device;
+    ncclUniqueId u;
+    std::memcpy(&u, id, 128);
+    ncclResult_t r = rccl()->CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) { delete c; return fail(BF_ERR_HIP, std::string("ncclCommInitRank: ") + rccl()->GetErrorString(r)); }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || c->scalar.alloc(2) != hipSuccess) {
+        bf_comm_destroy(c);
+        return fail(BF_ERR_HIP, "bf_comm_create: stream / buffer allocation failed");
+    }
+    *out = c;
+    return BF_OK;
+}
+
+int bf_comm_size(const bf_comm *c) {
+    if (!c) return 0;
+    int n = 0;
+    if (rccl()->CommCount(c->comm, &n) != ncclSuccess) return 0;
+    return n;
+}
+
+// in-place max / sum over the ranks of one double (op: 0 = sum, 1 = max)
+int bf_comm_allreduce(bf_comm *c, double *value, int op) {
+    if (!c || !value || (op != 0 && op != 1)) return fail(BF_ERR_INVALID, "bf_comm_allreduce: bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->scalar.p, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
+    RCCL_TRY(rccl()->AllReduce(c->scalar.p, c->scalar.p + 1, 1, ncclDouble, op ? ncclMax : ncclSum, c->comm, c->stream));
+    HIP_TRY(hipMemcpyAsync(value, c->scalar.p + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return BF_OK;
+}
+
+// every rank has reached this point and this rank's device is idle
+int bf_comm_barrier(bf_comm *c) {
+    if (!c) return fail(BF_ERR_INVALID, "bf_comm_barrier: null communicator");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    double one = 1.0;
+    int rc = bf_comm_allreduce(c, &one, 0);
+    if (rc) return rc;
+    if ((int)(one + 0.5) != c->world) return fail(BF_ERR_HIP, "bf_comm_barrier: the all-reduce did not see every rank");
+    return BF_OK;
+}
+
+// The final gather when every rank owns one device: this rank's batch holds block `rank` of the bf_shard_range partition of
+// n_frames; params[n_frames][n_params] (host) receives everybody's.  Runs on the batch's stream, behind the fit.
+int bf_comm_gather_params(bf_comm *c, bf_batch *b, int n_frames, float *params) {
+    if (!c || !b || !params || n_frames < c->world) return fail(BF_ERR_INVALID, "bf_comm_gather_params: bad argument");
+    int32_t first, count;
+    bf_shard_range(n_frames, c->world, c->rank, &first, &count);
+    if (count != b->F) return fail(BF_ERR_INVALID, "bf_comm_gather_params: the batch does not hold this rank's block of the partition");
+    if (b->m->device != c->device) return fail(BF_ERR_INVALID, "bf_comm_gather_params: batch and communicator live on different devices");
+    HIP_TRY(hipSetDevice(c->device));
+    const int np = b->m->np;
+    const size_t blk = (size_t)bf_shard_capacity(n_frames, c->world) * np;
+    if (c->send.n != blk) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->send.p) { (void)hipFree(c->send.p); c->send.p = nullptr; }
+        if (c->recv.p) { (void)hipFree(c->recv.p); c->recv.p = nullptr; }
+        HIP_TRY(c->send.alloc(blk));
+        HIP_TRY(c->recv.alloc(blk * c->world));
+        HIP_TRY(hipMemset(c->send.p, 0, blk * sizeof(float)));
+        c->host.resize(blk * c->world);
+    }
+    int rc = bf_guard_arena(b);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(c->send.p, b->params.p, (size_t)count * np * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    RCCL_TRY(rccl()->AllGather(c->send.p, c->recv.p, blk, ncclFloat, c->comm, b->stream));
+    HIP_TRY(hipMemcpyAsync(c->host.data(), c->recv.p, blk * c->world * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return bf_shard_unpack(c->host.data(), n_frames, c->world, np, params);
+}
+
+}  // extern "C"

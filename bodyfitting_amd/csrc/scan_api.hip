@@ -190,13 +190,19 @@ int bf_ensure_dense_buffers(bf_batch *b) {
         if (!ok) return fail(BF_ERR_HIP, "dense-loss buffers: device allocation failed");
         HIP_TRY(hipMemset(b->ext.p, 0, b->ext.n * sizeof(float)));
     }
-    if (!m->posedirsT.p) {
-        // [3NV][npf] transpose for the reverse pass (thread = pose-feature row, contiguous reads), built on the device
-        HIP_TRY(m->posedirsT.alloc((size_t)nv3 * m->npf));
-        hipLaunchKernelGGL(bf_transpose_kernel, dim3((nv3 + 31) / 32, (m->npf + 31) / 32), dim3(256), 0, b->stream,
-                           (const float *)m->posedirs.p, m->npf, (int)nv3, m->posedirsT.p);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(b->stream));          // (once per model; other batches of the model use other streams)
+    {
+        // [3NV][npf] transpose for the reverse pass (thread = pose-feature row, contiguous reads), built on the device once per
+        // model: under the model's lock and finished before anybody can see the pointer (batches of the model run on other streams)
+        std::lock_guard<std::mutex> g(m->lazy);
+        if (!m->posedirsT.p) {
+            DevBuf<float> t;
+            HIP_TRY(t.alloc((size_t)nv3 * m->npf));
+            hipLaunchKernelGGL(bf_transpose_kernel, dim3((nv3 + 31) / 32, (m->npf + 31) / 32), dim3(256), 0, b->stream,
+                               (const float *)m->posedirs.p, m->npf, (int)nv3, t.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            m->posedirsT.p = t.p; m->posedirsT.n = t.n; t.p = nullptr;
+        }
     }
     return BF_OK;
 }
@@ -251,7 +257,7 @@ static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
                        (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
                        (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
     HIP_TRY(hipGetLastError());
-    return bf_launch_mesh(m, b->F, b->state.p, b->vraw.p, b->vout.p, nullptr, nullptr, nullptr, b->stream, nullptr, b->vposed.p);
+    return bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, nullptr, nullptr, nullptr, b->stream, nullptr, b->vposed.p);
 }
 
 static int launch_kp(bf_batch *b, const bf_hyper &h) {
@@ -277,7 +283,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
                        (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
     HIP_TRY(hipGetLastError());
     bool zeroed = false;                      // dL/dvertices = 0 before the keypoint / silhouette kernels add into it
-    int rc = bf_launch_mesh(m, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
+    int rc = bf_launch_mesh(m, &b->scratch, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
                             b->vposed.p, kp ? b->jraw.p : nullptr, kp ? b->lmk_vid.p : nullptr, kp ? b->lmk_w.p : nullptr,
                             (kp || masks) ? b->dvout.p : nullptr, &zeroed);
     if (rc) return rc;
@@ -312,23 +318,29 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     bf_model *m = b->m;
     const int F = b->F, thr = n_iters / 3;
     const int n_plain = m->kp_dense ? 0 : std::min(n_iters, thr + 1);
-    if (!b->scans.empty() && b->pc_weight.n != (size_t)F) {
-        std::vector<float> w(F);
-        for (int f = 0; f < F; ++f) w[f] = 5.0f * h.imsize / b->scans[f]->dev.height;      // smplify.py:206,210
-        if (b->pc_weight.p) { (void)hipFree(b->pc_weight.p); b->pc_weight.p = nullptr; }
-        HIP_TRY(b->pc_weight.upload(w));
+    if (!b->scans.empty()) {
+        // 5 * imsize / scan_height (smplify.py:206,210) of the scans attached NOW and of THIS call's imsize: F floats, staged in
+        // pinned memory and copied on the batch's stream (a reused batch gets new scans on every SMPLify.__call__)
+        if (b->pc_weight.n != (size_t)F) {
+            if (b->pc_weight.p) { HIP_TRY(hipStreamSynchronize(b->stream)); (void)hipFree(b->pc_weight.p); b->pc_weight.p = nullptr; }
+            HIP_TRY(b->pc_weight.alloc(F));
+        }
+        if (!b->h_pc_weight) HIP_TRY(hipHostMalloc((void **)&b->h_pc_weight, (size_t)F * sizeof(float)));
+        else HIP_TRY(hipStreamSynchronize(b->stream));      // (an earlier call's copy may still be reading the staging buffer)
+        for (int f = 0; f < F; ++f) b->h_pc_weight[f] = 5.0f * h.imsize / b->scans[f]->dev.height;
+        HIP_TRY(hipMemcpyAsync(b->pc_weight.p, b->h_pc_weight, (size_t)F * sizeof(float), hipMemcpyHostToDevice, b->stream));
     }
     if (b->has_masks) b->mask.imsize = h.imsize;
     int rc = bf_ensure_dense_buffers(b);
     if (rc) return rc;
     if (n_plain > 0)
-        HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, m->fit_smem, b->stream));
+        HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream));
     for (int it = n_plain; it < n_iters; ++it) {
         rc = dense_pass(b, h, hd, it > thr, 5.0f);                                     // smplify.py:210
         if (rc) return rc;
         FrameIO io2 = io;
         io2.ext = b->ext.p;
-        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, m->fit_smem, b->stream));
+        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, b->fit_smem, b->stream));
     }
     return BF_OK;
 }
@@ -340,7 +352,7 @@ int bf_dense_loss_grad(bf_batch *b, const bf_hyper &h, const HyperDev &hd, Frame
     rc = dense_pass(b, h, hd, false, 5.0f);
     if (rc) return rc;
     io.ext = b->ext.p;
-    HIP_TRY(bf_fit_launch(&b->m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, b->m->fit_smem, b->stream));
+    HIP_TRY(bf_fit_launch(&b->m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, b->fit_smem, b->stream));
     return BF_OK;
 }
 
@@ -349,6 +361,7 @@ int bf_model_forward(bf_model *m, int n, const float *params, float *vertices, f
     if (!m || n <= 0 || !params) return fail(BF_ERR_INVALID, "bf_model_forward: bad argument");
     HIP_TRY(hipSetDevice(m->device));
     DevBuf<float> d_p, d_state, d_vraw, d_j, d_xp;
+    MeshScratch scratch;
     HIP_TRY(d_p.upload(std::vector<float>(params, params + (size_t)n * m->np)));
     HIP_TRY(d_state.alloc((size_t)n * bf_state_stride(m->nj, m->npf, m->nb)));
     HIP_TRY(d_vraw.alloc((size_t)n * m->nv * 3));
@@ -362,7 +375,7 @@ int bf_model_forward(bf_model *m, int n, const float *params, float *vertices, f
     hipLaunchKernelGGL(bf_pose_state_kernel, dim3(n), dim3(128), 0, 0, m->fit, (const float *)nullptr, (const float *)nullptr,
                        (const float *)nullptr, (const float *)nullptr, d_state.p, (const float *)d_p.p, (const float *)nullptr, 1.0f);
     HIP_TRY(hipGetLastError());
-    int rc = bf_launch_mesh(m, n, d_state.p, d_vraw.p, nullptr, d_xp.p, d_j.p, nullptr, 0, nullptr, nullptr);
+    int rc = bf_launch_mesh(m, &scratch, n, d_state.p, d_vraw.p, nullptr, d_xp.p, d_j.p, nullptr, 0, nullptr, nullptr);
     if (rc) return rc;
     HIP_TRY(hipDeviceSynchronize());
     if (vertices) HIP_TRY(hipMemcpy(vertices, d_vraw.p, d_vraw.n * sizeof(float), hipMemcpyDeviceToHost));
@@ -515,6 +528,7 @@ int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
     if (hyper) h = *hyper; else bf_hyper_default(&h);
     const int F = b->F, nv = m->nv, nf = (int)m->faces_host.size() / 3;
     { int rg_ = bf_guard_arena(b); if (rg_) return rg_; }
+    std::unique_lock<std::mutex> lazy(m->lazy);
     if (!m->faces_d.p) {
         // vertex -> (face, corner) lists in the order compute_normal_torch adds them: corner by corner, faces ascending
         std::vector<int> start(nv + 1, 0), adj(m->faces_host.size());
@@ -523,10 +537,11 @@ int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
         std::vector<int> fill(start.begin(), start.end() - 1);
         for (int c = 0; c < 3; ++c)
             for (int f = 0; f < nf; ++f) adj[fill[m->faces_host[f * 3 + c]]++] = f * 4 + c;
-        HIP_TRY(m->faces_d.upload(m->faces_host));
         HIP_TRY(m->adj_start.upload(start));
         HIP_TRY(m->adj.upload(adj));
+        HIP_TRY(m->faces_d.upload(m->faces_host));        // (blocking uploads; faces_d last: it is the "built" flag)
     }
+    lazy.unlock();
     const size_t nv3 = (size_t)F * nv * 3;
     if (!b->disp.p) {
         bool ok = b->disp.alloc(nv3) == hipSuccess && b->disp_m.alloc(nv3) == hipSuccess && b->disp_v.alloc(nv3) == hipSuccess &&

@@ -9,7 +9,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .synthetic import gmm_buffers, pack_keypoints_smplx
+from .assets import gmm_buffers
+from .keypoints import pack_keypoints_smplx
 
 N_LOSS_JOINTS = 25   # SKELETON_LENGTH, reference smplify/loss.py:17
 
@@ -25,6 +26,59 @@ def _i32(a):
     return np.ascontiguousarray(np.asarray(a), dtype=np.int32)
 
 
+def model_desc(model, gmm):
+    """-> (ModelDesc for bf_model_create / bf_group_create, dict of the model's sizes, the arrays the descriptor points into -
+    keep them alive until the call returned)."""
+    model_type = model.get("model_type", "smpl")
+    means, prec, nllw = gmm_buffers(gmm) if isinstance(gmm, dict) else gmm
+    smplx = model_type == "smplx"
+    n_betas = 10 if smplx else np.asarray(model["shapedirs"]).shape[2]     # expression dirs stay unused (never optimised)
+    if "J_regressor_extra" not in model:
+        model = dict(model, J_regressor_extra=np.zeros((0, np.asarray(model["v_template"]).shape[0]), np.float32))
+    keep = {
+        "v_template": _f32(model["v_template"]), "shapedirs": _f32(np.asarray(model["shapedirs"])[:, :, :n_betas]),
+        "posedirs": _f32(model["posedirs"]), "j_regressor": _f32(model["J_regressor"]),
+        "lbs_weights": _f32(model["lbs_weights"]), "parents": _i32(model["parents"]),
+        "selector_ids": _i32(model["selector_ids"]),
+        "j_regressor_extra": _f32(model["J_regressor_extra"]), "joint_map": _i32(model["joint_map"]),
+        "gmm_means": _f32(means), "gmm_precisions": _f32(prec), "gmm_nll_weights": _f32(nllw),
+    }
+    info = {"model_type": model_type}
+    info["n_verts"], info["n_joints"] = keep["lbs_weights"].shape
+    info["n_betas"] = keep["shapedirs"].shape[2]
+    info["n_selector"] = len(keep["selector_ids"])
+    info["n_joint_map"] = len(keep["joint_map"])
+    info["faces"] = _i32(model["faces"]) if "faces" in model else None
+    if keep["posedirs"].shape != (9 * (info["n_joints"] - 1), 3 * info["n_verts"]):
+        raise ValueError("posedirs must be [9(NJ-1), 3NV] as smplx stores it")
+    d = _lib.ModelDesc()
+    d.n_verts, d.n_joints, d.n_betas = info["n_verts"], info["n_joints"], info["n_betas"]
+    for name in ("v_template", "shapedirs", "posedirs", "j_regressor", "lbs_weights", "j_regressor_extra",
+                 "gmm_means", "gmm_precisions", "gmm_nll_weights"):
+        setattr(d, name, _lib.fptr(keep[name]))
+    for name in ("parents", "selector_ids", "joint_map"):
+        setattr(d, name, _lib.iptr(keep[name]))
+    d.n_selector, d.n_extra = info["n_selector"], keep["j_regressor_extra"].shape[0]
+    info["n_loss_joints"] = 135 if smplx else N_LOSS_JOINTS               # loss.py:17-19: 25 (+ 42 hands + 68 face)
+    d.n_joint_map, d.n_loss_joints = info["n_joint_map"], info["n_loss_joints"]
+    if smplx:
+        keep.update(pose_mean=_f32(model["pose_mean"]), lhc=_f32(model["left_hand_components"]),
+                    rhc=_f32(model["right_hand_components"]), lmk_f=_i32(model["lmk_faces_idx"]),
+                    lmk_b=_f32(model["lmk_bary_coords"]), dyn_f=_i32(model["dynamic_lmk_faces_idx"]),
+                    dyn_b=_f32(model["dynamic_lmk_bary_coords"]))
+        d.model_kind, d.pose_mean, d.n_hand_pca = 1, _lib.fptr(keep["pose_mean"]), keep["lhc"].shape[0]
+        d.left_hand_components, d.right_hand_components = _lib.fptr(keep["lhc"]), _lib.fptr(keep["rhc"])
+        d.n_lmk_static, d.lmk_faces_idx, d.lmk_bary_coords = len(keep["lmk_f"]), _lib.iptr(keep["lmk_f"]), _lib.fptr(keep["lmk_b"])
+        d.n_dyn_rows, d.n_lmk_dynamic = keep["dyn_f"].shape
+        d.dynamic_lmk_faces_idx, d.dynamic_lmk_bary_coords = _lib.iptr(keep["dyn_f"]), _lib.fptr(keep["dyn_b"])
+        d.neck_joint = int(np.asarray(model["neck_kin_chain"])[0])
+    d.gmm_components, d.gmm_dim = keep["gmm_means"].shape
+    if info["faces"] is not None:
+        keep["faces"] = _i32(info["faces"].reshape(-1, 3))
+        d.n_faces, d.faces = len(keep["faces"]), _lib.iptr(keep["faces"])
+    return d, info, keep
+
+
 class DeviceModel:
     """Body model + GMM prior uploaded once to one GPU (replaces the per-frame construction at
     reference smplify/body_fitting.py:82 -> smplify/smplify.py:46-56)."""
@@ -32,54 +86,11 @@ class DeviceModel:
     def __init__(self, model, gmm, device=0):
         lib = _lib.load()
         self._lib = lib
-        self.model_type = model.get("model_type", "smpl")
-        means, prec, nllw = gmm_buffers(gmm) if isinstance(gmm, dict) else gmm
-        smplx = self.model_type == "smplx"
-        n_betas = 10 if smplx else np.asarray(model["shapedirs"]).shape[2]     # expression dirs stay unused (never optimised)
-        if "J_regressor_extra" not in model:
-            model = dict(model, J_regressor_extra=np.zeros((0, np.asarray(model["v_template"]).shape[0]), np.float32))
-        keep = {
-            "v_template": _f32(model["v_template"]), "shapedirs": _f32(np.asarray(model["shapedirs"])[:, :, :n_betas]),
-            "posedirs": _f32(model["posedirs"]), "j_regressor": _f32(model["J_regressor"]),
-            "lbs_weights": _f32(model["lbs_weights"]), "parents": _i32(model["parents"]),
-            "selector_ids": _i32(model["selector_ids"]),
-            "j_regressor_extra": _f32(model["J_regressor_extra"]), "joint_map": _i32(model["joint_map"]),
-            "gmm_means": _f32(means), "gmm_precisions": _f32(prec), "gmm_nll_weights": _f32(nllw),
-        }
-        self.n_verts, self.n_joints = keep["lbs_weights"].shape
-        self.n_betas = keep["shapedirs"].shape[2]
-        self.n_selector = len(keep["selector_ids"])
-        self.n_joint_map = len(keep["joint_map"])
-        self.faces = _i32(model["faces"]) if "faces" in model else None
-        if keep["posedirs"].shape != (9 * (self.n_joints - 1), 3 * self.n_verts):
-            raise ValueError("posedirs must be [9(NJ-1), 3NV] as smplx stores it")
-        d = _lib.ModelDesc()
-        d.n_verts, d.n_joints, d.n_betas = self.n_verts, self.n_joints, self.n_betas
-        for name in ("v_template", "shapedirs", "posedirs", "j_regressor", "lbs_weights", "j_regressor_extra",
-                     "gmm_means", "gmm_precisions", "gmm_nll_weights"):
-            setattr(d, name, _lib.fptr(keep[name]))
-        for name in ("parents", "selector_ids", "joint_map"):
-            setattr(d, name, _lib.iptr(keep[name]))
-        d.n_selector, d.n_extra = self.n_selector, keep["j_regressor_extra"].shape[0]
-        self.n_loss_joints = 135 if smplx else N_LOSS_JOINTS               # loss.py:17-19: 25 (+ 42 hands + 68 face)
-        d.n_joint_map, d.n_loss_joints = self.n_joint_map, self.n_loss_joints
-        if smplx:
-            keep.update(pose_mean=_f32(model["pose_mean"]), lhc=_f32(model["left_hand_components"]),
-                        rhc=_f32(model["right_hand_components"]), lmk_f=_i32(model["lmk_faces_idx"]),
-                        lmk_b=_f32(model["lmk_bary_coords"]), dyn_f=_i32(model["dynamic_lmk_faces_idx"]),
-                        dyn_b=_f32(model["dynamic_lmk_bary_coords"]))
-            d.model_kind, d.pose_mean, d.n_hand_pca = 1, _lib.fptr(keep["pose_mean"]), keep["lhc"].shape[0]
-            d.left_hand_components, d.right_hand_components = _lib.fptr(keep["lhc"]), _lib.fptr(keep["rhc"])
-            d.n_lmk_static, d.lmk_faces_idx, d.lmk_bary_coords = len(keep["lmk_f"]), _lib.iptr(keep["lmk_f"]), _lib.fptr(keep["lmk_b"])
-            d.n_dyn_rows, d.n_lmk_dynamic = keep["dyn_f"].shape
-            d.dynamic_lmk_faces_idx, d.dynamic_lmk_bary_coords = _lib.iptr(keep["dyn_f"]), _lib.fptr(keep["dyn_b"])
-            d.neck_joint = int(np.asarray(model["neck_kin_chain"])[0])
-        d.gmm_components, d.gmm_dim = keep["gmm_means"].shape
-        if self.faces is not None:
-            keep["faces"] = _i32(self.faces.reshape(-1, 3))
-            d.n_faces, d.faces = len(keep["faces"]), _lib.iptr(keep["faces"])
+        d, info, keep = model_desc(model, gmm)
+        self.__dict__.update(info)
         self._h = C.c_void_p()
         _lib.check(lib.bf_model_create(C.byref(d), int(device), C.byref(self._h)), "bf_model_create")
+        del keep
         self.device = int(device)
         self.n_params = lib.bf_model_n_params(self._h)
 

@@ -1,48 +1,251 @@
-"""Frame sharding over the GPUs of one node.
+"""Frame sharding over the GPUs of one node - numpy + ctypes over libbodyfit, no PyTorch.
 
-Frames are independent (the reference fits them in a serial Python loop,
-apps/genebody_fitting.py:183-192), so frame f goes to rank f // ceil(F/world) in contiguous blocks,
-model and cameras are replicated, and nothing is exchanged during the fit.  The single collective is
-the final all-gather of the packed parameters [frames_per_rank, n_params] - RCCL over xGMI when the
-process group is "nccl", gloo on CPU in the tests.  torch.distributed is plumbing here; the fit
-itself never sees torch.
+Frames are independent (the reference fits them in a serial Python loop, apps/genebody_fitting.py:183-192), so frame f
+goes to shard f // ceil(F / n) in contiguous blocks, model and cameras are replicated, and nothing is exchanged during
+the fit.  The single collective is the final all-gather of the packed parameters [frames_per_gpu, n_params], done by
+RCCL inside libbodyfit (csrc/group.hip).  Two ways to drive it:
+
+* `Group`  - ONE process, n devices (bf_group_*: ncclCommInitAll, grouped all-gather).  `python bench.py --gpus N`.
+* `Comm`   - one process PER device, started by a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE (the benchmark
+  contract's `python -m torch.distributed.run ... bench.py`): rank 0 creates the RCCL unique id and the ranks exchange
+  it through `FileRendezvous` (all ranks are on one node), then ncclCommInitRank.
+
+The partition itself (`shard_range`, `shard_capacity`, `unpack`) is host arithmetic inside the library and needs no GPU.
 """
 from __future__ import annotations
 
+import ctypes as C
+import os
+import tempfile
+import time
+
 import numpy as np
 
+from . import _lib
+from .native import FrameBatch, _f32, _i32
 
+
+# ---- the partition (host arithmetic in libbodyfit) -----------------------------------------------------------------
 def shard_range(n_frames, rank, world):
     """Contiguous block [lo, hi) of frames owned by `rank`; blocks differ by at most one frame."""
-    base, rem = divmod(n_frames, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    first, count = C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.load().bf_shard_range(int(n_frames), int(world), int(rank), C.byref(first), C.byref(count)), "bf_shard_range")
+    return first.value, first.value + count.value
 
 
 def shard_sizes(n_frames, world):
-    return [shard_range(n_frames, r, world)[1] - shard_range(n_frames, r, world)[0] for r in range(world)]
+    return [hi - lo for lo, hi in (shard_range(n_frames, r, world) for r in range(world))]
 
 
-def gather_params(local, n_frames, dist=None, device=None, batch=None):
-    """All-gather the per-rank parameter blocks into the full [n_frames, n_params] array on every rank.
+def shard_capacity(n_frames, world):
+    """frames per shard the all-gather is padded to"""
+    return int(_lib.load().bf_shard_capacity(int(n_frames), int(world)))
 
-    `local` is this rank's [frames_here, n_params] numpy block.  With `batch` (a native.FrameBatch)
-    and a CUDA `device`, the send buffer is filled device-to-device straight from the library
-    (bf_batch_export_params_dev) and the gather runs over RCCL."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return np.asarray(local, dtype=np.float32)
-    import torch
-    world, rank = dist.get_world_size(), dist.get_rank()
-    sizes = shard_sizes(n_frames, world)
-    n_params = np.asarray(local).shape[1] if batch is None else batch.model.n_params
-    cap = max(sizes)                                   # ragged shards are padded to the largest
-    dev = device if device is not None else "cpu"
-    send = torch.zeros(cap * n_params, dtype=torch.float32, device=dev)
-    if batch is not None and str(dev).startswith("cuda"):
-        batch.export_params_dev(send.data_ptr())
-    else:
-        send[: sizes[rank] * n_params] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.float32).reshape(-1))
-    recv = torch.empty(world * cap * n_params, dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(recv, send)
-    full = recv.cpu().numpy().reshape(world, cap, n_params)
-    return np.concatenate([full[r, : sizes[r]] for r in range(world)], 0)
+
+def pad_block(local, n_frames, world):
+    """this rank's [frames_here, width] block zero-padded to the [capacity, width] send buffer of the all-gather"""
+    local = _f32(local)
+    out = np.zeros((shard_capacity(n_frames, world), local.shape[1]), np.float32)
+    out[: len(local)] = local
+    return out
+
+
+def unpack(gathered, n_frames, world):
+    """gathered[world, capacity, width] (what the all-gather leaves on every rank) -> [n_frames, width] in frame order"""
+    g = _f32(gathered)
+    width = g.shape[-1]
+    assert g.size == world * shard_capacity(n_frames, world) * width
+    out = np.empty((n_frames, width), np.float32)
+    _lib.check(_lib.load().bf_shard_unpack(_lib.fptr(g), int(n_frames), int(world), int(width), _lib.fptr(out)), "bf_shard_unpack")
+    return out
+
+
+# ---- one process, n devices -----------------------------------------------------------------------------------------
+class _BorrowedBatch(FrameBatch):
+    """a device's block of a Group, seen through the ordinary FrameBatch interface (the group owns the handle)"""
+
+    def __init__(self, group, i):                      # noqa: super().__init__ would create a batch
+        self._lib = group._lib
+        self.model = group.models[i]
+        self._h = C.c_void_p(self._lib.bf_group_batch(group._h, i))
+        self.V = group.V
+        self.F = group.shards[i][2]
+
+    def close(self):
+        self._h = None
+
+
+class _BorrowedModel:
+    def __init__(self, template, handle, device):
+        self.__dict__.update({k: v for k, v in template.__dict__.items() if k not in ("_h", "device")})
+        self._h, self.device = handle, device
+
+    def close(self):
+        self._h = None
+
+
+class Group:
+    """F frames sharded over n GPUs driven by this process (bf_group).  `model_desc` comes from native.model_desc()."""
+
+    def __init__(self, model, gmm, n_frames, n_views, n_devices=None, devices=None):
+        from .native import model_desc
+        lib = self._lib = _lib.load()
+        if n_devices is None:
+            n_devices = len(devices) if devices is not None else lib.bf_device_count()
+        desc, info, keep = model_desc(model, gmm)
+        devs = None if devices is None else _i32(devices)
+        self._h = C.c_void_p()
+        _lib.check(lib.bf_group_create(C.byref(desc), int(n_devices), _lib.iptr(devs), int(n_frames), int(n_views), C.byref(self._h)),
+                   "bf_group_create")
+        del keep
+        self.n, self.F, self.V = int(n_devices), int(n_frames), int(n_views)
+        self.n_params = lib.bf_group_n_params(self._h)
+        self.info = info
+        self.shards = []
+        for i in range(self.n):
+            d, f, c = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+            _lib.check(lib.bf_group_shard(self._h, i, C.byref(d), C.byref(f), C.byref(c)), "bf_group_shard")
+            self.shards.append((d.value, f.value, c.value))
+        template = type("Info", (), {})()
+        template.__dict__.update(info, _lib=lib, n_params=self.n_params)
+        self.models = [_BorrowedModel(template, C.c_void_p(lib.bf_group_model(self._h, i)), self.shards[i][0]) for i in range(self.n)]
+        self.batches = [_BorrowedBatch(self, i) for i in range(self.n)]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bf_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_cameras(self, c2ws, Ks):
+        c2w, K = _f32(c2ws, (self.F, self.V, 4, 4)), _f32(Ks, (self.F, self.V, 3, 3))
+        _lib.check(self._lib.bf_group_set_cameras(self._h, _lib.fptr(c2w), _lib.fptr(K)), "bf_group_set_cameras")
+
+    def set_keypoints(self, keypoints, n_use_frames=None):
+        kp = _f32(keypoints, (self.F, self.V, self.info["n_loss_joints"], 3))
+        nd = None if n_use_frames is None else _i32(np.broadcast_to(np.asarray(n_use_frames), (self.F,)))
+        _lib.check(self._lib.bf_group_set_keypoints(self._h, _lib.fptr(kp), _lib.iptr(nd)), "bf_group_set_keypoints")
+
+    def set_init(self, init_betas, init_pose):
+        b = _f32(init_betas, (self.F, self.info["n_betas"]))
+        p = _f32(np.asarray(init_pose).reshape(self.F, -1)[:, :72], (self.F, 72))
+        _lib.check(self._lib.bf_group_set_init(self._h, _lib.fptr(b), _lib.fptr(p)), "bf_group_set_init")
+
+    def fit(self, n_iters, hyper=None, flags=_lib.FIT_DEFAULT):
+        hp = C.byref(hyper) if hyper is not None else None
+        _lib.check(self._lib.bf_group_fit(self._h, int(n_iters), hp, int(flags)), "bf_group_fit")
+
+    def sync(self):
+        _lib.check(self._lib.bf_group_sync(self._h), "bf_group_sync")
+
+    def comm_size(self):
+        n = self._lib.bf_group_comm_size(self._h)
+        if n < 0:
+            _lib.check(n, "bf_group_comm_size")
+        return n
+
+    def gather_params(self, from_peer=0):
+        """the one collective of the path: -> [F, n_params] as it arrived on device `from_peer`"""
+        out = np.empty((self.F, self.n_params), np.float32)
+        _lib.check(self._lib.bf_group_gather_params(self._h, _lib.fptr(out), int(from_peer)), "bf_group_gather_params")
+        return out
+
+
+# ---- one process per device -----------------------------------------------------------------------------------------
+class FileRendezvous:
+    """Ranks of ONE node hand each other small byte strings through the file system (atomic rename, polling).  Stands in
+    for the store a launcher would offer, without importing it: the ranks of `torch.distributed.run --nnodes=1` share
+    MASTER_PORT, TORCHELASTIC_RUN_ID and their parent process, which together name the directory."""
+
+    def __init__(self, rank, world, key=None, root=None, timeout=300.0):
+        self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
+        if key is None:
+            key = "-".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
+        self.dir = os.path.join(root or tempfile.gettempdir(), f"bodyfit-rdzv-{os.getuid()}-{key}")
+        os.makedirs(self.dir, exist_ok=True)
+
+    def _path(self, name, rank):
+        return os.path.join(self.dir, f"{name}.{rank}")
+
+    def put(self, name, data: bytes):
+        tmp = self._path(name, self.rank) + f".tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, self._path(name, self.rank))
+
+    def get(self, name, rank) -> bytes:
+        path, t0 = self._path(name, rank), time.monotonic()
+        while not os.path.exists(path):
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError(f"rendezvous: rank {rank} never published {name!r} in {self.dir}")
+            time.sleep(0.005)
+        with open(path, "rb") as f:
+            return f.read()
+
+    def broadcast(self, name, data=None, root=0) -> bytes:
+        if self.rank == root:
+            self.put(name, data)
+            return data
+        return self.get(name, root)
+
+    def all_gather(self, name, data: bytes):
+        self.put(name, data)
+        return [self.get(name, r) for r in range(self.world)]
+
+    def barrier(self, name):
+        self.all_gather("barrier-" + name, b"1")
+
+    def cleanup(self):
+        """after a final barrier: every rank removes its own files, the last one the directory"""
+        self.barrier("cleanup")
+        for f in os.listdir(self.dir):
+            if f.endswith(f".{self.rank}") and not f.startswith("barrier-cleanup"):
+                try:
+                    os.remove(os.path.join(self.dir, f))
+                except OSError:
+                    pass
+
+
+class Comm:
+    """This rank's end of the RCCL communicator (bf_comm): barrier, max over ranks, final gather of the parameters."""
+
+    def __init__(self, rank, world, device, rendezvous=None):
+        lib = self._lib = _lib.load()
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        rdzv = rendezvous or FileRendezvous(rank, world)
+        uid = None
+        if rank == 0:
+            buf = (C.c_uint8 * 128)()
+            _lib.check(lib.bf_comm_unique_id(buf), "bf_comm_unique_id")
+            uid = bytes(buf)
+        uid = rdzv.broadcast("rccl-unique-id", uid)
+        self._h = C.c_void_p()
+        _lib.check(lib.bf_comm_create((C.c_uint8 * 128).from_buffer_copy(uid), self.rank, self.world, self.device, C.byref(self._h)),
+                   "bf_comm_create")
+        self.rendezvous = rdzv
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bf_comm_destroy(self._h)
+            self._h = None
+
+    def size(self):
+        return int(self._lib.bf_comm_size(self._h))
+
+    def barrier(self):
+        _lib.check(self._lib.bf_comm_barrier(self._h), "bf_comm_barrier")
+
+    def max(self, value):
+        v = C.c_double(float(value))
+        _lib.check(self._lib.bf_comm_allreduce(self._h, C.byref(v), 1), "bf_comm_allreduce")
+        return v.value
+
+    def gather_params(self, batch, n_frames):
+        out = np.empty((int(n_frames), batch.model.n_params), np.float32)
+        _lib.check(self._lib.bf_comm_gather_params(self._h, batch._h, int(n_frames), _lib.fptr(out)), "bf_comm_gather_params")
+        return out

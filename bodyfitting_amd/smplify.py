@@ -16,7 +16,7 @@ import numpy as np
 from . import assets
 from .io import load_obj_mesh
 from .native import FrameBatch, Scan, make_hyper, split_params
-from .synthetic import pack_keypoints_smplx
+from .keypoints import pack_keypoints_smplx
 
 
 def _np(x):

@@ -27,6 +27,9 @@ import hashlib
 
 import numpy as np
 
+from .assets import gmm_buffers                                   # noqa: F401  (product code; re-exported for the tests)
+from .keypoints import FACE_MAPPING, pack_keypoints_smplx          # noqa: F401
+
 # kinematic trees (smplx 0.1.13 semantics)
 SMPL_PARENTS = np.array(
     [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21],
@@ -181,21 +184,6 @@ def make_gmm(seed=0, n_comp=8, dim=69):
     weights = rng.uniform(0.5, 1.5, size=n_comp)
     weights /= weights.sum()
     return {"means": means, "covars": covars, "weights": weights}
-
-
-def gmm_buffers(gmm):
-    """The three buffers the merged GMM NLL uses (reference smplify/prior.py:143-160).
-
-    Returns float32 ``means[M,D]``, ``precisions[M,D,D]`` and ``nll_weights[M]`` computed in
-    float64 and rounded once, exactly as the reference constructor does.
-    """
-    means = np.asarray(gmm["means"], dtype=np.float32)
-    covs32 = np.asarray(gmm["covars"], dtype=np.float32)
-    precisions = np.stack([np.linalg.inv(c) for c in covs32]).astype(np.float32)
-    sqrdets = np.array([np.sqrt(np.linalg.det(c)) for c in gmm["covars"]])
-    const = (2.0 * np.pi) ** (69 / 2.0)
-    nll_weights = np.asarray(gmm["weights"] / (const * (sqrdets / sqrdets.min())))
-    return means, precisions, nll_weights.astype(np.float32)
 
 
 def make_model(model_type="smpl", seed=0, nv=None):
@@ -530,9 +518,6 @@ def subdivide_mesh(verts, faces, times=1):
     return v, f.astype(np.int32)
 
 
-FACE_MAPPING = list(range(17, 17 + 51)) + list(range(0, 17))       # reference smplify/loss.py:20
-
-
 def smplx_full_pose(model, global_orient, body_pose, leye, reye, lhand_pca, rhand_pca, jaw=None):
     """[165] axis-angle vector smplx feeds to lbs: PCA hands, plus pose_mean."""
     jaw = np.zeros(3) if jaw is None else np.asarray(jaw, np.float64).reshape(3)
@@ -559,31 +544,6 @@ def smplx_joints64(model, betas, full_pose):
     lm = np.einsum("lfi,lf->li", verts[model["faces"][fidx]], bary)
     joints = np.concatenate([j76, lm], 0)
     return verts, joints[model["joint_map"]], y
-
-
-def pack_keypoints_smplx(k, part_sum_confidence=True):
-    """OpenPose dict {'pose'[25,3], 'hand_left'[21,3], 'hand_right'[21,3], 'face'[70,3]} -> [135,3] in the order the
-    model joints are compared (loss.py:163-181: body | left hand | right hand | face[FACE_MAPPING]); missing parts
-    get confidence 0.
-
-    part_sum_confidence reproduces a reference quirk: for the hands and the face the confidence column is NOT
-    squeezed (loss.py:168,173,179 vs :162), so `conf**2 * err.sum(-1)` broadcasts to an outer product and every
-    joint of a part ends up weighted by the SUM of the part's squared confidences.  The packed confidence of
-    those joints is therefore sqrt(sum conf^2) of their part, which makes the ordinary conf_j^2 * rho_j identical."""
-    out = np.zeros((135, 3), np.float32)
-    if k is None:
-        return out
-    out[:25] = np.asarray(k["pose"], np.float32)[:25]
-    if "hand_left" in k:
-        out[25:46] = np.asarray(k["hand_left"], np.float32)
-    if "hand_right" in k:
-        out[46:67] = np.asarray(k["hand_right"], np.float32)
-    if "face" in k:
-        out[67:135] = np.asarray(k["face"], np.float32)[FACE_MAPPING]
-    if part_sum_confidence:
-        for a, b in ((25, 46), (46, 67), (67, 135)):
-            out[a:b, 2] = np.sqrt(np.sum(out[a:b, 2].astype(np.float64) ** 2))
-    return out
 
 
 def make_problem_smplx(model, frame=0, n_views=48, imsize=512, constant_scale=0.3, pose_noise=0.08, mask_frames=None):

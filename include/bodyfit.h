@@ -226,6 +226,53 @@ int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *d
 int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper);
 int bf_batch_get_displacement(bf_batch *b, float *displacement /*[F,NV,3]*/);
 
+
+/* ---- frames sharded over the GPUs of one node (BASELINE config 4 / 5) -----------------------------------
+ * Replaces the serial `for frame` loop of apps/genebody_fitting.py:183-192: frames are independent, so frame f goes to
+ * shard f // ceil(F / n) in contiguous blocks, model and cameras are replicated, nothing is exchanged during the fit, and
+ * the fitted parameters are all-gathered ONCE over RCCL (xGMI) at the end.  No PyTorch on this path; librccl is opened
+ * lazily the first time a communicator is needed. */
+/* host arithmetic, no device: the partition (blocks differ by at most one frame), the per-shard capacity the all-gather is
+ * padded to, and the unpacking of a gathered [n_shards][capacity][width] block into [n_frames][width] */
+int bf_shard_range(int n_frames, int n_shards, int shard, int32_t *first, int32_t *count);
+int bf_shard_capacity(int n_frames, int n_shards);
+int bf_shard_unpack(const float *gathered, int n_frames, int n_shards, int width, float *out);
+
+/* ONE process driving n devices: a bf_model + bf_batch + stream per device (devices == NULL -> 0..n-1),
+ * ncclCommInitAll on first use.  The setters take the arrays of the whole job [F, ...] (layouts of the bf_batch_set_*
+ * counterparts) and hand every device its block; bf_group_fit queues bf_fit on every device and returns. */
+typedef struct bf_group bf_group;
+int bf_group_create(const bf_model_desc *desc, int n_devices, const int32_t *devices, int n_frames, int n_views, bf_group **out);
+void bf_group_destroy(bf_group *g);
+int bf_group_n_devices(const bf_group *g);
+int bf_group_n_params(const bf_group *g);
+int bf_group_shard(const bf_group *g, int i, int32_t *device, int32_t *first, int32_t *count);
+bf_batch *bf_group_batch(bf_group *g, int i);      /* device i's block as an ordinary batch (masks, scans, results, timing) */
+bf_model *bf_group_model(bf_group *g, int i);
+int bf_group_set_cameras(bf_group *g, const float *c2w, const float *K);
+int bf_group_set_keypoints(bf_group *g, const float *keypoints, const int32_t *n_use_frames);
+int bf_group_set_init(bf_group *g, const float *init_betas, const float *init_pose);
+int bf_group_fit(bf_group *g, int n_iters, const bf_hyper *hyper, uint32_t flags);
+int bf_group_sync(bf_group *g);
+/* ranks of the group's RCCL communicator (created on first use) */
+int bf_group_comm_size(bf_group *g);
+/* the path's one collective: grouped ncclAllGather of the packed parameters, stream-ordered behind the fits;
+ * params[F][n_params] (host) = the copy that arrived on device `from_peer` */
+int bf_group_gather_params(bf_group *g, float *params, int from_peer);
+
+/* One process PER device (launched like `torch.distributed.run`: RANK / LOCAL_RANK / WORLD_SIZE in the environment):
+ * rank 0 calls bf_comm_unique_id and hands the 128 bytes to the other ranks through the host (bodyfitting_amd/shard.py
+ * uses the file system), every rank calls bf_comm_create (ncclCommInitRank). */
+typedef struct bf_comm bf_comm;
+int bf_comm_unique_id(uint8_t id[128]);
+int bf_comm_create(const uint8_t id[128], int rank, int world, int device, bf_comm **out);
+void bf_comm_destroy(bf_comm *c);
+int bf_comm_size(const bf_comm *c);
+int bf_comm_barrier(bf_comm *c);                              /* device idle + every rank arrived */
+int bf_comm_allreduce(bf_comm *c, double *value, int op);    /* in place over the ranks; op 0 = sum, 1 = max */
+/* the batch holds block `rank` of bf_shard_range(n_frames, world, .); params[n_frames][n_params] (host) on every rank */
+int bf_comm_gather_params(bf_comm *c, bf_batch *b, int n_frames, float *params);
+
 /* Device time of the kernels of the last bf_fit on this batch, from HIP events on the batch's
  * stream: ms[0] = fit loop kernel(s), ms[1] = final full-mesh forward kernel, ms[2] = joints kernel +
  * result fetch, ms[3] = whole call.  (With BF_FIT_DENSE every iteration's mesh pass is inside ms[0].) */

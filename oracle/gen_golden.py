@@ -339,6 +339,41 @@ def smplx_goldens():
         print(tag, "done")
 
 
+def reference_timing(frames=(0, 1, 2)):
+    """Wall time of the UNMODIFIED reference loop (SMPLify.__call__, smplify.py:84-250: 48 views, 100 iterations, torch CPU,
+    1 thread = its faster setting) on this build container, per frame, without the snapshot hook: the reference-side CPU figure
+    bench.py quotes beside its own port's (the reference cannot travel to the GPU box)."""
+    import json
+    import platform
+    import torch
+    import smplx
+    from bodyfitting_amd import synthetic as S
+
+    model, gmm = S.make_model("smpl", seed=0), S.make_gmm(seed=0)
+    smplx.MODEL_REGISTRY["smpl"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_golden_time_")
+    write_data_dir(tmp, model, gmm)
+    os.chdir(tmp)
+    run_reference_fit(S.make_problem(model, frame=0, n_views=48), 5)           # warm imports / allocator
+    walls = []
+    for f in frames:
+        _, _, wall = run_reference_fit(S.make_problem(model, frame=f, n_views=48), 100)
+        walls.append(wall)
+    cpu = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
+    out = {"what": "reference SMPLify.__call__ imported from /root/reference, torch CPU, config 2 (1 frame x 48 views x 100 iterations)",
+           "wall_s_per_frame": walls, "frames_per_s": len(walls) / sum(walls), "threads": torch.get_num_threads(),
+           "host": {"cpu": cpu, "logical_cpus": os.cpu_count(), "machine": platform.machine()}, "torch": torch.__version__,
+           "where": "build container (the GPU box has no /root/reference)"}
+    with open(os.path.join(GOLDEN, "reference_timing.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("reference timing", out["frames_per_s"], "frames/s", walls)
+
+
 def flat_snaps(snaps):
     out = {}
     for k, d in snaps.items():
@@ -410,6 +445,9 @@ if __name__ == "__main__":
     elif "--smplx-only" in sys.argv:
         install_reference_imports()
         smplx_goldens()
+    elif "--timing-only" in sys.argv:
+        install_reference_imports()
+        reference_timing()
     elif "--mask-only" in sys.argv:
         install_reference_imports()
         mask_goldens()
@@ -418,3 +456,4 @@ if __name__ == "__main__":
         scan_goldens()
         mask_goldens()
         smplx_goldens()
+        reference_timing()

@@ -434,7 +434,7 @@ def fit_smplx(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snap
     PCA, jaw and expression never optimised, hands + face keypoints in the loss (use_hand_face).  scan = (verts,
     faces): use_mesh=True - constant scale scan_height / 1.7 and the point-cloud loss after num_iters // 3
     (smplify.py:146-156,205-210), as in fit()."""
-    from bodyfitting_amd.synthetic import pack_keypoints_smplx
+    from bodyfitting_amd.keypoints import pack_keypoints_smplx
     m = to_torch_model(model, dtype)
     gmm = to_torch_gmm(gmm_bufs, dtype)
     c2w = torch.as_tensor(np.asarray(problem["c2ws"]), dtype=torch.float32).to(dtype)
@@ -491,7 +491,7 @@ def fit_smplx(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snap
 
 def smplx_loss_and_grad(model, gmm_bufs, problem, params, dtype=torch.float64):
     """objective + autograd gradient at `params` (dict over SMPLX_PARAMS) for smpl_type='smplx'"""
-    from bodyfitting_amd.synthetic import pack_keypoints_smplx
+    from bodyfitting_amd.keypoints import pack_keypoints_smplx
     m = to_torch_model(model, dtype)
     gmm = to_torch_gmm(gmm_bufs, dtype)
     w2cs = torch.inverse(torch.as_tensor(np.asarray(problem["c2ws"]), dtype=torch.float32).to(dtype))

@@ -1,7 +1,9 @@
-"""The N>1 path on CPU: world-size-2 gloo run of the frame partition and the final gather."""
+"""The N>1 path on CPU.  The partition and the gather's pad / unpack bookkeeping are host arithmetic inside libbodyfit
+(bf_shard_range / bf_shard_capacity / bf_shard_unpack, csrc/group.hip) - the same functions bf_group_gather_params and
+bf_comm_gather_params use around their ncclAllGather.  Here two CPU processes run that bookkeeping with gloo standing in
+for RCCL as the transport, and exchange the RCCL-id-sized blob through the file rendezvous the ranks use on the GPU box."""
 import os
 import socket
-import sys
 
 import numpy as np
 import pytest
@@ -10,21 +12,51 @@ from bodyfitting_amd import shard
 
 
 def test_partition_covers_every_frame_once():
-    for n, w in ((256, 8), (64, 8), (7, 2), (3, 4), (1, 2)):
+    for n, w in ((256, 8), (64, 8), (7, 2), (3, 4), (1, 2), (32, 1), (9, 8)):
         blocks = [shard.shard_range(n, r, w) for r in range(w)]
         assert blocks[0][0] == 0 and blocks[-1][1] == n
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(w - 1))
-        assert max(b[1] - b[0] for b in blocks) - min(b[1] - b[0] for b in blocks) <= 1
+        sizes = [b[1] - b[0] for b in blocks]
+        assert max(sizes) - min(sizes) <= 1 and max(sizes) == shard.shard_capacity(n, w)
+        assert sizes == sorted(sizes, reverse=True)             # earlier shards take the remainder
+    # BASELINE configs 4 and 5: 256 -> 32 per GPU, 64 -> 8 per GPU
+    assert shard.shard_sizes(256, 8) == [32] * 8 and shard.shard_sizes(64, 8) == [8] * 8
+
+
+def test_unpack_drops_the_padding_of_ragged_shards():
+    n, w, width = 7, 2, 5
+    cap = shard.shard_capacity(n, w)
+    full = np.arange(n * width, dtype=np.float32).reshape(n, width)
+    gathered = np.full((w, cap, width), -1.0, np.float32)
+    for r in range(w):
+        lo, hi = shard.shard_range(n, r, w)
+        gathered[r] = shard.pad_block(full[lo:hi], n, w)
+    np.testing.assert_array_equal(shard.unpack(gathered, n, w), full)
+
+
+def _params(frames, width=86):
+    return np.stack([np.arange(width, dtype=np.float32) + 1000.0 * f for f in frames]) if len(frames) else np.zeros((0, width), np.float32)
 
 
 def _worker(rank, world, port, n_frames, out):
+    import torch
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="pytest")
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    # what a rank does around the collective (csrc/group.hip: bf_comm_gather_params), gloo instead of RCCL in between
     lo, hi = shard.shard_range(n_frames, rank, world)
-    local = np.stack([np.arange(86, dtype=np.float32) + 1000.0 * f for f in range(lo, hi)]) if hi > lo else np.zeros((0, 86), np.float32)
-    full = shard.gather_params(local, n_frames, dist=dist)
+    send = torch.from_numpy(shard.pad_block(_params(range(lo, hi)), n_frames, world))
+    recv = torch.empty(world * send.numel())
+    dist.all_gather_into_tensor(recv, send.reshape(-1))
+    full = shard.unpack(recv.numpy().reshape(world, *send.shape), n_frames, world)
     np.save(os.path.join(out, f"r{rank}.npy"), full)
+    # the 128-byte RCCL id travels through the file rendezvous; so do the timings' max and the barriers
+    rdzv = shard.FileRendezvous(rank, world, key=f"pytest-{port}", root=out)
+    uid = rdzv.broadcast("rccl-unique-id", bytes(range(128)) if rank == 0 else None)
+    assert uid == bytes(range(128))
+    walls = rdzv.all_gather("wall", repr(1.0 + rank).encode())
+    assert max(float(w) for w in walls) == float(world)
+    rdzv.cleanup()
     dist.barrier()
     dist.destroy_process_group()
 
@@ -37,6 +69,6 @@ def test_gather_world2_gloo(tmp_path, n_frames):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(2, port, n_frames, str(tmp_path)), nprocs=2, join=True)
-    want = np.stack([np.arange(86, dtype=np.float32) + 1000.0 * f for f in range(n_frames)])
+    want = _params(range(n_frames))
     for r in range(2):
         np.testing.assert_array_equal(np.load(tmp_path / f"r{r}.npy"), want)
