@@ -39,7 +39,7 @@ class ModelDesc(C.Structure):
 class Hyper(C.Structure):
     _fields_ = [(n, C.c_float) for n in (
         "sigma", "pose_prior_weight", "angle_prior_weight", "shape_prior_weight", "constant_scale",
-        "imsize", "lr", "lr_transl_scale", "adam_beta1", "adam_beta2", "adam_eps", "lr_displacement")]
+        "imsize", "lr", "lr_transl_scale", "adam_beta1", "adam_beta2", "adam_eps", "lr_displacement", "mask_cdist_form", "dense_after")]
 
 
 FIT_DEFAULT, FIT_DENSE, FIT_NO_VERTICES, FIT_FETCH, FIT_RESET, FIT_GRAPH, FIT_NOTIME = 0, 1, 2, 4, 8, 16, 32

@@ -41,6 +41,8 @@ void bf_hyper_default(bf_hyper *h) {
     h->adam_beta2 = 0.999f;
     h->adam_eps = 1e-8f;
     h->lr_displacement = 5e-2f;
+    h->mask_cdist_form = 1.f;
+    h->dense_after = -1.f;
 }
 
 int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {

@@ -139,6 +139,7 @@ struct ScanDev {
 // Silhouette-loss inputs of one batch (device pointers).
 struct MaskIO {
     int nv, ns, n_views, n_masks, H, W, cmax, part_stride, proj_blocks;
+    int cdist;                            // 1 = distances in torch.cdist's expanded fp32 form (loss.py:108), 0 = exact
     float imsize, eps, weight;            // weight = 5 (smplify.py:210)
     const int *view_index;                // [M] index of each mask view among the V views
     const unsigned char *masks;           // [F][M][H][W], 1 = foreground (already > 128, smplify.py:139)

@@ -84,9 +84,15 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
     int bidx = -1;
     // (the next tile's record is requested before this tile is scanned; a vertex outside the image is parked at u = 3e19, so
     //  its squared distance overflows past `best` and the scan needs no inside test; the winner's coordinates are re-read at the end)
+    // cdist form (torch.cdist for more than 25 points, loss.py:108): dist^2 = x1_ . x2_ with x1_ = (-2u, -2v, |uv|^2, 1) and
+    // x2_ = (cx, cy, 1, |c|^2), accumulated k = 0..3 as ONE fma chain (what the CPU sgemm does for K = 4), clamped at 0; the
+    // norms are sums of individually rounded squares (pow(2).sum(-1)).  The tile carries |uv|^2 in .z.
+    const bool cdist = K.cdist != 0;
+    const float n2 = __fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy));
     auto fetch = [&](int s) {
         float4 r = s < K.ns ? rec[s] : make_float4(0.f, 0.f, 0.f, 0.f);
         if (!(r.z > 0.5f)) r.x = 3.0e19f;
+        r.z = __fadd_rn(__fmul_rn(r.x, r.x), __fmul_rn(r.y, r.y));
         return r;
     };
     float4 nxt = fetch(threadIdx.x);
@@ -97,7 +103,17 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
         int lim = min(256, K.ns - base);
         for (int i = sub; i < lim; i += 16) {
             const float4 r = tile[i];
-            const float dx = r.x - cx, dy = r.y - cy, d2 = dx * dx + dy * dy;
+            float d2;
+            if (cdist) {
+                float acc = __fmul_rn(cx, -2.f * r.x);
+                acc = __fmaf_rn(cy, -2.f * r.y, acc);
+                acc = __fadd_rn(acc, r.z);
+                acc = __fadd_rn(acc, n2);
+                d2 = fmaxf(acc, 0.f);                                          // clamp_min(0); a parked vertex gives +inf
+            } else {
+                const float dx = r.x - cx, dy = r.y - cy;
+                d2 = dx * dx + dy * dy;
+            }
             if (d2 < best) { best = d2; bidx = base + i; }                     // first minimum of this lane's subset
         }
         __syncthreads();

@@ -316,8 +316,9 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
 // is state -> mesh -> losses -> reverse mesh pass -> one fit-kernel iteration (smplify.py:197-210).
 int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDev &hd, FrameIO io) {
     bf_model *m = b->m;
-    const int F = b->F, thr = n_iters / 3;
-    const int n_plain = m->kp_dense ? 0 : std::min(n_iters, thr + 1);
+    // iterations of THIS call that run before the dense losses switch on: local index it <= thr
+    const int F = b->F, thr = h.dense_after < 0.f ? n_iters / 3 : (int)h.dense_after - b->steps_done;
+    const int n_plain = m->kp_dense ? 0 : std::max(0, std::min(n_iters, thr + 1));
     if (!b->scans.empty()) {
         // 5 * imsize / scan_height (smplify.py:206,210) of the scans attached NOW and of THIS call's imsize: F floats, staged in
         // pinned memory and copied on the batch's stream (a reused batch gets new scans on every SMPLify.__call__)
@@ -330,7 +331,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
         for (int f = 0; f < F; ++f) b->h_pc_weight[f] = 5.0f * h.imsize / b->scans[f]->dev.height;
         HIP_TRY(hipMemcpyAsync(b->pc_weight.p, b->h_pc_weight, (size_t)F * sizeof(float), hipMemcpyHostToDevice, b->stream));
     }
-    if (b->has_masks) b->mask.imsize = h.imsize;
+    if (b->has_masks) { b->mask.imsize = h.imsize; b->mask.cdist = h.mask_cdist_form != 0.f; }
     int rc = bf_ensure_dense_buffers(b);
     if (rc) return rc;
     if (n_plain > 0)
@@ -488,7 +489,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     HIP_TRY(b->mk_part.alloc(fm * stride)); HIP_TRY(b->mk_loss.alloc(F));
     MaskIO &K = b->mask;
     K.nv = nv; K.ns = ns; K.n_views = b->V; K.n_masks = n_masks; K.H = H; K.W = W; K.cmax = cmax;
-    K.part_stride = stride; K.proj_blocks = pblocks; K.imsize = 512.f; K.eps = 10.f; K.weight = 5.f;
+    K.part_stride = stride; K.proj_blocks = pblocks; K.cdist = 1; K.imsize = 512.f; K.eps = 10.f; K.weight = 5.f;
     K.view_index = b->mk_view.p; K.masks = b->mk_masks.p; K.contour_start = b->mk_cstart.p;
     K.contour_count = b->mk_ccount.p; K.contour_xy = b->mk_cxy.p;
     b->has_masks = true;
@@ -504,6 +505,7 @@ int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *d
     if (hyper) h = *hyper; else bf_hyper_default(&h);
     HyperDev hd = bf_to_dev(h);
     b->mask.imsize = h.imsize;
+    b->mask.cdist = h.mask_cdist_form != 0.f;
     int rc = bf_guard_arena(b);
     if (rc) return rc;
     rc = launch_state_and_mesh(b, hd);

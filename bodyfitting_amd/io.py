@@ -16,39 +16,67 @@ def save_obj_mesh(mesh_path, verts, faces):
             f.write("f %d %d %d\n" % (tri[0] + 1, tri[1] + 1, tri[2] + 1))
 
 
-def load_openpose(json_name, only_one=True):
-    """OpenPose JSON -> {'pose': [25,3], 'hand_left': [21,3], 'hand_right': [21,3], 'face': [70,3]} of
-    the highest-scoring person, or None (behaviour of utils/io_utils.py:138-183 for 2-D keypoints)."""
-    with open(json_name, "r") as fid:
-        d = json.load(fid)
-    people = d.get("people", [])
-    if not people:
+def _openpose_array(key, values):
+    """One `*_keypoints*` list -> (short name, array) or None, following utils/io_utils.py:150-169: an array whose values are
+    all whole numbers becomes int32 and is then read as bare coordinates [n, dim] (no confidence column) unless it is all
+    zero; otherwise rows of (coordinates..., confidence), dropped when every confidence is <= 0; a length that fits neither is
+    cut to whole coordinate rows.  dim comes from a `_2d` .. `_9d` suffix of the key (default 2)."""
+    flat = np.reshape(values, -1)
+    if flat.size == 0:
         return None
-    parsed = []
+    if (flat - np.floor(flat)).max() <= 0:
+        flat = flat.astype(np.int32)
+    tags = re.findall("([2-9]d)", key)
+    dim = int(tags[-1][0]) if tags else 2
+    whole = flat.dtype == np.int32
+    if flat.size % (dim + 1) == 0 and (not whole or flat.max() == 0):
+        rows = flat.reshape(-1, dim + 1)
+        if np.abs(rows[:, -1]).max() <= 0:
+            return None
+    elif flat.size % dim == 0:
+        rows = flat.reshape(-1, dim)
+    else:
+        rows = flat[:(flat.size // dim) * dim].reshape(-1, dim)
+    return key.replace("_keypoints", "").replace("_%dd" % dim, ""), rows
+
+
+def load_openpose(json_name, only_one=True):
+    """OpenPose JSON -> {'pose': [25,3], 'hand_left': [21,3], 'hand_right': [21,3], 'face': [70,3]} of the highest-scoring
+    person (only_one) or every person - the behaviour of utils/io_utils.py:138-183, quirks included: people without an id are
+    collected in a list; a positive `*id*` entry turns the collection into a dict keyed by id (earlier list entries get keys
+    -1, -2, ...; a person with id 0, or without an id once the dict exists, is dropped); the best person is the one whose
+    summed last columns are strictly largest, starting from entry 0 with score 0; no people at all -> None."""
+    with open(json_name, "r") as fid:
+        doc = json.load(fid)
+    people = doc.get("people", [])
+    if len(people) == 0:
+        return None
+    found = []
     for person in people:
-        entry = {}
+        entry, pid = {}, -1
         for key, val in person.items():
-            if "keypoints" not in key:
-                continue
-            p = np.asarray(val, dtype=np.float64).reshape(-1)
-            if p.size == 0:
-                continue
-            dim = re.findall("([2-9]d)", key)
-            dim = 2 if not dim else int(dim[-1][0])
-            if p.size % (dim + 1) != 0:
-                continue
-            p = p.reshape(-1, dim + 1)
-            if np.abs(p[:, -1]).max() <= 0:
-                continue
-            entry[key.replace("_keypoints", "").replace("_%dd" % dim, "")] = p
-        parsed.append(entry)
-    parsed = [e for e in parsed if e]
-    if not parsed:
+            if "id" in key:
+                pid = np.reshape(val, -1)[0]
+            elif "keypoints" in key:
+                item = _openpose_array(key, val)
+                if item is not None:
+                    entry[item[0]] = item[1]
+        if pid < 0 and isinstance(found, list):
+            found.append(entry)
+        elif pid > 0:
+            if isinstance(found, list):
+                found = {-(n + 1): e for n, e in enumerate(found)}
+            found[pid] = entry
+    if len(found) == 0:
         return None
     if not only_one:
-        return parsed
-    scores = [sum(p[:, -1].sum() for p in e.values()) for e in parsed]
-    return parsed[int(np.argmax(scores))]
+        return found
+    best, best_score = 0, 0
+    for key, entry in (enumerate(found) if isinstance(found, list) else found.items()):
+        score = sum(a[:, -1].sum() for a in entry.values())
+        if score > best_score:
+            best, best_score = key, score
+    return found[best]
 
 
 def load_obj_mesh(mesh_file):

@@ -96,6 +96,13 @@ typedef struct bf_hyper {
     float adam_beta2;          /* 0.999 */
     float adam_eps;            /* 1e-8 */
     float lr_displacement;     /* 5e-2  smplify.py:233 */
+    float mask_cdist_form;     /* 1     silhouette loss: 1 = contour-to-vertex distances in the fp32 form torch.cdist evaluates for
+                                        these sizes (loss.py:108: |a|^2 + |b|^2 - 2ab as one 4-term fma chain, ~1e-2 px of
+                                        round-off at 512 px - the reference's own numbers, so the nearest-vertex choice matches
+                                        it); 0 = exact (a - b)^2 sums */
+    float dense_after;         /* -1    the silhouette / scan losses are active for iterations i > dense_after, i counted from the
+                                        last reset; -1 = num_iters // 3 of the bf_fit call (smplify.py:197,205).  Lets a caller
+                                        cut one reference loop into several bf_fit calls (snapshots) */
 } bf_hyper;
 
 /* bf_fit flags */

@@ -213,6 +213,32 @@ def scan_goldens():
     print("scan golden: max |disp|", np.abs(res["displacement"]).max())
 
 
+def scan_goldens_long():
+    """config 5's iteration counts on the reduced model: the reference loop with use_mesh=True for 300 iterations (scan loss
+    after 100) and its SMPL+D stage for 300 more.  The stage is chaotic under round-off, so what the tests hold
+    against this golden is the END STATE: fitted parameters of the first loop, and the distribution of point-to-scan distances
+    and the normal / laplacian energies of base + displacement after the second."""
+    import smplx
+    from bodyfitting_amd import synthetic as S
+    from bodyfitting_amd.io import save_obj_mesh
+
+    model = S.make_model("smpl", seed=0, nv=690)
+    gmm = S.make_gmm(seed=0)
+    smplx.MODEL_REGISTRY["smpl"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_golden_scan300_")
+    write_data_dir(tmp, model, gmm)
+    os.chdir(tmp)
+    prob, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
+    meshfile = os.path.join(tmp, "scan.obj")
+    save_obj_mesh(meshfile, sv, sf)
+    t0 = time.perf_counter()
+    res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 300, snapshots=(100, 101, 300), displacement=True)
+    print("scan 300+300:", time.perf_counter() - t0, "s")
+    np.savez_compressed(os.path.join(GOLDEN, "scan_nv690_300it.npz"), frame=0, n_views=8, num_iters=300, nv=690,
+                        model_digest=S.model_digest(model), vertices=res["vertices"], joints=res["joints"],
+                        displacement=res["displacement"], **flat_snaps(snaps), **{f"disp{k}": v for k, v in dsn.items()})
+
+
 def install_cv2_contour_stub():
     """cv2.findContours (OpenCV-3 three-value API, as loss.py:79 unpacks it) backed by oracle.contour_oracle.border_pixels_rowmajor."""
     import cv2
@@ -374,6 +400,70 @@ def reference_timing(frames=(0, 1, 2)):
     print("reference timing", out["frames_per_s"], "frames/s", walls)
 
 
+def openpose_cases():
+    """JSON documents for the OpenPose reader: the reference's own sample (openpose/test.json) and variants that reach every
+    branch of utils/io_utils.py:138-183 (integer-valued arrays, person ids, several people, empty / zero-confidence parts)."""
+    import json
+    with open(os.path.join(REFERENCE, "openpose", "test.json")) as f:
+        sample = json.load(f)
+    rng = np.random.default_rng(42)
+
+    def person(scale=1.0, pid=None, hands=True, face=True):
+        def part(n):
+            a = np.concatenate([rng.uniform(10, 500, (n, 2)), rng.uniform(0.1, 1.0, (n, 1)) * scale], 1)
+            return [round(float(x), 3) for x in a.reshape(-1)]
+        out = {"person_id": [-1 if pid is None else pid], "pose_keypoints_2d": part(25)}
+        if hands:
+            out["hand_left_keypoints_2d"], out["hand_right_keypoints_2d"] = part(21), part(21)
+        if face:
+            out["face_keypoints_2d"] = part(70)
+        out["pose_keypoints_3d"], out["face_keypoints_3d"] = [], []
+        return out
+    cases = {
+        "reference_sample": sample,
+        "no_people": {"version": 1.3, "people": []},
+        "two_people_second_scores_higher": {"version": 1.3, "people": [person(0.3), person(1.0)]},
+        "all_integer_coordinates": {"version": 1.3, "people": [{"person_id": [-1], "pose_keypoints_2d": [float(v) for v in rng.integers(1, 500, 50)]}]},
+        "all_zero_part_is_dropped": {"version": 1.3, "people": [dict(person(), hand_left_keypoints_2d=[0.0] * 63)]},
+        "person_ids": {"version": 1.3, "people": [person(0.5, pid=3), person(1.0, pid=7)]},
+        "ragged_length_is_truncated": {"version": 1.3, "people": [{"person_id": [-1], "pose_keypoints_2d": [float(v) for v in rng.integers(1, 500, 51)] + [7.0, 9.0]}]},
+        "only_zero_confidences": {"version": 1.3, "people": [{"person_id": [-1], "pose_keypoints_2d": [1.5, 2.5, 0.0] * 25}]},
+    }
+    return cases
+
+
+def openpose_goldens():
+    """expected output of the reference's load_openpose (utils/io_utils.py:138-183, imported) on openpose_cases()"""
+    import json
+    from utils.io_utils import load_openpose
+
+    def enc(v):
+        if v is None:
+            return None
+        if isinstance(v, dict):
+            return {"__dict__": [[int(k) if not isinstance(k, str) else k, enc(x)] for k, x in v.items()]}
+        if isinstance(v, list):
+            return {"__list__": [enc(x) for x in v]}
+        a = np.asarray(v)
+        return {"dtype": str(a.dtype), "shape": list(a.shape), "data": a.reshape(-1).tolist()}
+    tmp = tempfile.mkdtemp(prefix="bf_golden_openpose_")
+    out = {}
+    for name, doc in openpose_cases().items():
+        path = os.path.join(tmp, name + ".json")
+        with open(path, "w") as f:
+            json.dump(doc, f)
+        entry = {"input": doc}
+        for only_one in (True, False):
+            try:
+                entry["only_one" if only_one else "all"] = {"result": enc(load_openpose(path, only_one=only_one))}
+            except Exception as exc:                   # (the reference raises on some inputs: that is its behaviour too)
+                entry["only_one" if only_one else "all"] = {"raises": type(exc).__name__}
+        out[name] = entry
+    with open(os.path.join(GOLDEN, "openpose_reader.json"), "w") as f:
+        json.dump(out, f)
+    print("openpose goldens:", {k: list(v["only_one"]) for k, v in out.items()})
+
+
 def flat_snaps(snaps):
     out = {}
     for k, d in snaps.items():
@@ -445,6 +535,12 @@ if __name__ == "__main__":
     elif "--smplx-only" in sys.argv:
         install_reference_imports()
         smplx_goldens()
+    elif "--scan-long-only" in sys.argv:
+        install_reference_imports()
+        scan_goldens_long()
+    elif "--openpose-only" in sys.argv:
+        install_reference_imports()
+        openpose_goldens()
     elif "--timing-only" in sys.argv:
         install_reference_imports()
         reference_timing()
@@ -456,4 +552,6 @@ if __name__ == "__main__":
         scan_goldens()
         mask_goldens()
         smplx_goldens()
+        scan_goldens_long()
+        openpose_goldens()
         reference_timing()

@@ -12,6 +12,9 @@ from test_mask_oracle import MASK_FRAMES, mask_inputs
 
 pytestmark = pytest.mark.gpu
 PARAMS = ("global_transl", "scale", "pose", "betas", "global_orient")
+MASK_FIRST_STEP_TOL = 1e-4     # north-star tolerance, held for the first iteration that carries the silhouette loss (observed 1e-5)
+MASK_LOOP_TOL = 0.08           # after 19 such iterations (observed 0.037): a flipped nearest-vertex choice is amplified by Adam - the
+                               # END STATE is what is asserted against the reference (silhouette loss / keypoint terms within 1 %)
 
 
 def _batch(dev_model, prob):
@@ -25,14 +28,16 @@ def _batch(dev_model, prob):
 
 
 def test_mask_loss_value_and_gradient(dev_model, smpl_model):
-    """bf_batch_mask_loss vs the fp64 oracle (exact distances) and vs the reference golden (noisy cdist)"""
+    """bf_batch_mask_loss in both distance forms: mask_cdist_form = 0 (exact (a-b)^2) vs the fp64 oracle, and the default
+    (torch.cdist's expanded fp32 form, loss.py:108) vs the fp32 oracle evaluating torch.cdist literally and vs the
+    golden of the imported reference"""
     g = load_golden("mask_loss_f0.npz")
     prob, contours, masks, w2cs, Ks = mask_inputs(smpl_model, torch.float64)
     b = _batch(dev_model, prob)
     params = {"global_transl": g["transl"], "scale": np.array([float(g["scale"])]), "pose": prob["init_pose"][0, 3:],
               "betas": prob["init_betas"][0], "global_orient": prob["init_pose"][0, :3]}
     b.set_params(N.pack_params(params)[None])
-    loss, dv = b.mask_loss()
+    loss, dv = b.mask_loss(N.make_hyper(mask_cdist_form=0))
     # same vertices on the oracle side (fp64 forward of the same parameters)
     m = O.to_torch_model(smpl_model, torch.float64)
     out = O.smpl_forward(m, torch.tensor(prob["init_betas"], dtype=torch.float64), torch.tensor(prob["init_pose"][:, :3], dtype=torch.float64),
@@ -41,33 +46,75 @@ def test_mask_loss_value_and_gradient(dev_model, smpl_model):
     want = O.multview_mask_loss(contours, masks, verts, w2cs, Ks, imsize=512)
     want.backward()
     assert float(loss[0]) == pytest.approx(float(want), rel=2e-5)
-    assert float(loss[0]) == pytest.approx(float(g["loss"]), rel=5e-5)
     gw = verts.grad.numpy()
     assert np.all(dv[0].reshape(-1, 3)[np.arange(6890) % 4 != 0] == 0)          # only every 4th vertex (loss.py:99)
     err = np.abs(dv[0] - gw)
     assert np.mean(err < 1e-4 * np.abs(gw).max()) > 0.998                        # (an argmin tie may flip a few)
-    assert np.mean(np.abs(dv[0][::4] - g["grad_sampled"]) < 2e-3 * np.abs(gw).max()) > 0.99
+    # the reference's own form (default): the golden of the imported reference, value and gradient
+    # (the golden was evaluated on torch's fp32 vertices, these on the HIP forward's: ~1e-4 px apart, which moves a few of the
+    #  nearest-vertex choices and 1 <-> 10 weights - each flipped weight is ~10 units of the loss = 5e-5 of it)
+    loss_c, dv_c = b.mask_loss()
+    assert float(loss_c[0]) == pytest.approx(float(g["loss"]), rel=2e-4)
+    assert np.mean(np.abs(dv_c[0][::4] - g["grad_sampled"]) < 1e-4 * np.abs(gw).max()) > 0.985
+    # and it is closer to the reference than the exact form is (that is the point of the option)
+    assert np.abs(dv_c[0][::4] - g["grad_sampled"]).sum() < np.abs(dv[0][::4] - g["grad_sampled"]).sum()
     b.close()
 
 
-def test_mask_fit_first_steps_and_progress(dev_model, smpl_model, gmm_bufs):
+def _end_state(dev_model, prob, params):
+    """size-independent end-state metrics of a silhouette fit: the (unweighted) mask loss and the keypoint loss terms at
+    `params`, evaluated by the HIP path with exact distances"""
+    b = _batch(dev_model, prob)
+    b.set_params(params[None])
+    mask = float(b.mask_loss(N.make_hyper(mask_cdist_form=0))[0][0])
+    terms, _ = b.loss_grad()
+    b.close()
+    return mask, terms[0]
+
+
+def test_mask_fit_loop_against_the_reference(dev_model, smpl_model, gmm_bufs):
+    """The use_mask=True loop (smplify.py:138-144,197-199), 30 iterations of which 19 carry 5 x the silhouette loss.
+    Keypoint-only prefix: exact.  With the distances in the reference's own fp32 form the trajectory follows the golden of
+    the imported reference far more closely than with exact distances; the objective stays discontinuous (nearest-vertex
+    choice, 1 <-> 10 weights), so beyond the per-parameter tolerance the END STATE is asserted: silhouette loss, keypoint
+    terms and joints after the 30 steps within a stated percentage of the reference's."""
     g = load_golden("mask_fit_8view_30it.npz")
     prob = S.make_problem(smpl_model, frame=0, n_views=8, mask_frames=MASK_FRAMES)
     b = _batch(dev_model, prob)
     l0 = b.mask_loss()[0][0]
+    # the reference loop cut at the golden's snapshots: dense_after = 10 = 30 // 3 keeps the switch-on iteration of ONE call
+    done, drift = 0, {}
+    for k in (1, 11, 12, 20, 30):
+        b.fit(k - done, N.make_hyper(dense_after=10))
+        done = k
+        got = N.split_params(b.get_params()[0])
+        drift[k] = max(float(np.abs(got[n] - g[f"it{k}_{n}"]).max()) for n in PARAMS)
+    print("mask loop, distances in the reference's fp32 form: max |param - reference| per snapshot =", drift)
+    assert drift[1] < 1e-6 and drift[11] < 1e-5                 # keypoint-only prefix
+    assert drift[12] < MASK_FIRST_STEP_TOL                      # the first silhouette iteration holds the north-star tolerance
+    assert drift[30] < MASK_LOOP_TOL                            # afterwards the discontinuous objective amplifies single flips
+    verts, joints, _, _ = b.get_result()
+    np.testing.assert_allclose(joints[0], g["joints"], atol=MASK_LOOP_TOL)
+    assert b.mask_loss()[0][0] < 0.7 * l0                    # the silhouette term really went down
+    b.close()
+    b = _batch(dev_model, prob)                              # one call of 30 == the five calls above, bit for bit
     b.fit(30)
-    got = N.split_params(b.get_params()[0])
-    # the silhouette loop is ill-conditioned (tests/test_mask_oracle.py): trajectories agree to ~1e-1 at 30 steps
-    res = O.fit(smpl_model, gmm_bufs, prob, 30)
-    for n in PARAMS:
-        assert np.abs(got[n] - res[n if n != "global_transl" else "raw_transl"]).max() < 0.3, n
-    assert np.isfinite(b.get_params()).all()
-    assert b.mask_loss()[0][0] < 0.7 * l0                    # and the silhouette term really went down
+    np.testing.assert_array_equal(N.pack_params(N.split_params(b.get_params()[0])), N.pack_params(got))
     b.close()
-    # keypoint-only prefix is exact: 11 steps of 30 == golden
+    # end state vs the reference's end state (parameters of the golden, evaluated by the same HIP kernels)
+    ref_params = N.pack_params({n: g[f"it30_{n}"] for n in PARAMS})
+    mask_ref, terms_ref = _end_state(dev_model, prob, ref_params)
+    mask_got, terms_got = _end_state(dev_model, prob, N.pack_params(got))
+    assert mask_got == pytest.approx(mask_ref, rel=0.01)                       # silhouette loss within 1 %
+    assert float(terms_got.sum()) == pytest.approx(float(terms_ref.sum()), rel=0.01)
+    # exact distances: a chosen deviation that drifts from the reference (documented in DESIGN.md), same quality of fit
     b = _batch(dev_model, prob)
-    b.fit(33 // 3)          # n_iters = 11 -> threshold 3: iterations 4..10 would use the mask; use the plain batch instead
+    b.fit(30, N.make_hyper(mask_cdist_form=0))
+    got_x = N.split_params(b.get_params()[0])
     b.close()
+    mask_x, terms_x = _end_state(dev_model, prob, N.pack_params(got_x))
+    assert mask_x == pytest.approx(mask_ref, rel=0.05) and float(terms_x.sum()) == pytest.approx(float(terms_ref.sum()), rel=0.05)
+    # keypoint-only prefix is exact: 11 steps == golden
     c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
     p = N.FrameBatch(dev_model, 1, 8)
     p.set_cameras(c2w, K); p.set_keypoints(kp, ndiv); p.set_init(betas, pose)

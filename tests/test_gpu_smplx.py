@@ -9,6 +9,8 @@ from bodyfitting_amd import synthetic as S
 from oracle import smplify_oracle as O
 
 pytestmark = pytest.mark.gpu
+SMPLX_MASK_LOOP_TOL = 5e-4     # 15 iterations, 10 with the silhouette loss, distances in the reference's own fp32 form (the
+                               # default, bf_hyper.mask_cdist_form = 1): observed 1.2e-4; with exact distances 3e-2
 
 
 @pytest.fixture(scope="module")
@@ -110,8 +112,9 @@ def test_smplx_with_masks_runs_and_improves(sx):
     assert b.mask_loss()[0][0] < l0
     g = load_golden("smplx_mask_8view_15it.npz")
     got = N.split_params(b.get_params()[0])
-    for n in O.SMPLX_PARAMS:
-        assert np.abs(got[n] - g[f"it15_{n}"]).max() < 0.1, n
+    worst = max(float(np.abs(got[n] - g[f"it15_{n}"]).max()) for n in O.SMPLX_PARAMS)
+    print("smplx mask loop: max |param - reference| after 15 steps =", worst)
+    assert worst < SMPLX_MASK_LOOP_TOL
     b.close()
 
 

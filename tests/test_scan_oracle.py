@@ -44,6 +44,54 @@ def test_known_answers_for_the_rule():
     assert d2[0] == pytest.approx(1.0)
 
 
+def test_rule_on_adversarial_triangles_against_exact_geometry():
+    """The restated rule (mesh_grid_kernel.cu:12-109) pinned by independent exact geometry (Ericson regions) where the reference
+    extension cannot be run: needle / sliver / obtuse / regular triangles, queries in all seven Voronoi regions.
+    * never closer than the exact closest point, and ON the triangle;
+    * exact for every non-obtuse triangle, however thin, and in the face region of every triangle;
+    * inexact only around the obtuse corner: the fallback edge (opposite the most negative coefficient, kernel.cu:74-101) is
+      then the wrong one and the rule answers with the obtuse VERTEX although edge CA or vertex A is closer."""
+    from oracle import adversarial as ADV
+    d = ADV.soup(seed=0)
+    kinds = np.array(d["kind"])[d["owner"]]
+    assert set(d["region"].tolist()) == {"A", "B", "C", "AB", "BC", "CA", "F"}
+    d_rule, d_exact = ADV.rule_vs_exact(d)
+    assert np.all(d_rule >= d_exact * (1 - 1e-9) - 1e-14)
+    V = d["verts"].astype(np.float64)
+    tri = V[d["faces"][d["owner"]]]
+    q = d["queries"].astype(np.float64)
+    coeff, _ = MO.closest_rule(tri[:, 0] - q, tri[:, 1] - q, tri[:, 2] - q)
+    assert coeff.min() >= 0 and np.allclose(coeff.sum(1), 1.0, atol=1e-12)
+    inexact = d_rule > d_exact * (1 + 1e-6) + 1e-12
+    obtuse = np.char.startswith(kinds, "obtuse")
+    assert not inexact[~obtuse].any() and not inexact[d["region"] == "F"].any()
+    np.testing.assert_allclose(d_rule[~inexact], d_exact[~inexact], rtol=1e-6, atol=1e-12)
+    # where it is inexact: the answer is the obtuse corner (vertex 2 of these shapes), the truth lies on CA or at A
+    assert inexact.sum() > 30
+    assert np.all(coeff[inexact].argmax(1) == 2) and np.all(coeff[inexact].max(1) == 1.0)
+    assert set(d["region"][inexact].tolist()) <= {"CA", "A"}
+    ratio = np.sqrt(d_rule[inexact] / d_exact[inexact])
+    print("inexact %d of %d obtuse queries; distance excess: median x%.2f, max x%.2f" % (inexact.sum(), obtuse.sum(), np.median(ratio), ratio.max()))
+    assert ratio.max() < 12.0
+    # the independent point routine and the independent distance routine agree with each other
+    pe = np.array([ADV.exact_point(t_, q_) for t_, q_ in zip(tri[:200], q[:200])])
+    np.testing.assert_allclose(((pe - q[:200]) ** 2).sum(1), d_exact[:200], rtol=1e-9, atol=1e-15)
+
+
+def test_rule_known_answer_where_the_fallback_is_inexact():
+    """hand-computed: A = (0,0,0), B = (4,0,0), C = (1,.25,0) (165 deg at C), q = (-2,1.25,0).  Plane coordinates of q:
+    v = 1.25 / .25 = 5, u = (-2 - 5) / 4 = -1.75, so (c_A, c_B, c_C) = (-2.25, -1.75, 5): most negative c_A -> edge BC;
+    t = (q - B).(C - B) / |C - B|^2 = (18 + .3125) / 9.0625 = 2.02 > 1 -> clamped to C: |q - C|^2 = 9 + 1 = 10.
+    The closest point of the triangle is A: |q - A|^2 = 4 + 1.5625 = 5.5625."""
+    from oracle import adversarial as ADV
+    A, B, C, q = np.array([0.0, 0, 0]), np.array([4.0, 0, 0]), np.array([1.0, 0.25, 0]), np.array([-2.0, 1.25, 0])
+    c, d2 = MO.closest_rule((A - q)[None], (B - q)[None], (C - q)[None])
+    np.testing.assert_array_equal(c[0], [0.0, 0.0, 1.0])
+    assert d2[0] == pytest.approx(10.0, rel=1e-12)
+    assert MO.closest_exact((A - q)[None], (B - q)[None], (C - q)[None])[0] == pytest.approx(5.5625, rel=1e-12)
+    assert ADV.voronoi_region([A, B, C], q) == "A"
+
+
 def test_insert_grid_surface_known_answer_and_bbox_property(small_model):
     """mesh_grid_kernel.cu:110-157: one triangle in a 4x4x4 unit grid, then every cell list of a body scan"""
     v = np.array([[0.5, 0.5, 0.5], [2.5, 0.5, 0.5], [0.5, 1.5, 0.5], [9, 9, 9]], np.float32)
