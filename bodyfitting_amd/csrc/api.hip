@@ -686,9 +686,9 @@ static int ensure_adam_tab(bf_batch *b, const bf_hyper &h, int upto) {
                 b->adam_hyper.adam_beta1 == h.adam_beta1 && b->adam_hyper.adam_beta2 == h.adam_beta2;
     if (same) return BF_OK;
     int cap = std::max(upto, 1024);
-    std::vector<float> tab((size_t)cap * 3);
+    std::vector<float> tab((size_t)(cap + 1) * 3);            // (+1: a kernel may look one step ahead)
     const double b1 = (double)h.adam_beta1, b2 = (double)h.adam_beta2;
-    for (int t = 1; t <= cap; ++t) {
+    for (int t = 1; t <= cap + 1; ++t) {
         double bc1 = 1.0 - std::pow(b1, t), bc2 = 1.0 - std::pow(b2, t);
         tab[(size_t)(t - 1) * 3 + 0] = (float)((double)h.lr_transl_scale / bc1);
         tab[(size_t)(t - 1) * 3 + 1] = (float)((double)h.lr / bc1);
@@ -712,6 +712,7 @@ FrameIO bf_frame_io(bf_batch *b, bool want_grads) {
     io.debug = b->debug.p;
     io.cscale = b->cscale.p;          // null unless scans are attached
     io.ext = nullptr;
+    io.emit_next = 0;
     return io;
 }
 

@@ -172,6 +172,7 @@ struct FrameIO {
     float *state;             // [F][state_stride]
     float *debug;             // optional dump of the first iteration's intermediates
     const float *cscale;      // [F] per-frame constant scale (scan_height / 1.7, smplify.py:156) or null
+    int emit_next;            // (with ext) leave the pose state of the STEPPED parameters instead of the last forward's
     const float *ext;         // [F][npf + nj*12 + nb + 4 + nj*3] gradients arriving from the dense losses (dfeat | per joint
                               //  rows of sum w dv (x) [vp|1] | dbeta | dt ds | dL/d(chain joint positions)), or null
 };

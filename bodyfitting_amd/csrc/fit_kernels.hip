@@ -28,6 +28,7 @@
 // N_i = D_i GR_i^T + t_i (Gt_i - Gt_parent)^T, dL/dGR_p = (D_p GR_p^T + sum_{i in strict subtree} N_i) GR_p,
 // i.e. two subtree sums instead of one barrier per tree level.  All reductions have a fixed order.
 #include "bf_internal.h"
+#include "pose_state_body.h"
 #include <type_traits>
 
 // Diagnostic build only (-DBF_STAMP, libbodyfit_stamp.so): thread 0 stamps the shader clock after every
@@ -220,6 +221,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int npf = 9 * (nj - 1), np = T.np, V = io.n_views, ns3 = ns * 3, nj3 = nj * 3;
     FitSmem S;
     fit_smem_carve(S, smem_raw, nj, nb, npf, ns, nl, np, V);
+    // EXT launches (one iteration of the dense schedule) may end with the pose state of the parameters they just stepped - the
+    // arithmetic of bf_pose_state_kernel, bit for bit - so that the next iteration's mesh pass needs no launch in between
+    const bool emit = EXT && mode == 0 && io.emit_next;
 
     // ---- one-off loads --------------------------------------------------------------------
     copy_f(S.Jt, T.Jt, nj3, tid, nt);
@@ -1571,6 +1575,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         io.params[(size_t)frame * np + tid] = Pcur[tid];
         io.adam_m[(size_t)frame * np + tid] = S.am[tid];
         io.adam_v[(size_t)frame * np + tid] = S.av[tid];
+    }
+    if constexpr (EXT) {
+        if (emit) {                                   // (block-uniform)
+            __syncthreads();                          // the stepped parameters above are visible to the whole workgroup
+            // (every LDS buffer of the fit is dead by now: its first bytes are the scratch)
+            bf_pose_state_body<true>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nt, smem_raw);
+        }
     }
 }
 

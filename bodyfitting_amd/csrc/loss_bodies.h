@@ -1,0 +1,235 @@
+// Device bodies shared by the stand-alone loss kernels and the fused launch (bf_kp_contour_kernel, scan_kernels.hip) that runs
+// the dense keypoint loss beside the silhouette loss's nearest-vertex scan: both only read the projected mesh, so one launch
+// hides the keypoint workgroup's ~20 us latency chain under the scan's arithmetic.
+#pragma once
+#include "bf_internal.h"
+
+namespace {
+__device__ inline float lb_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+}  // namespace
+
+// Dense keypoint loss (more than 32 loss joints, i.e. SMPL-X with hands + face): multiview_keypoint_loss
+// (smplify/loss.py:139-203) over nl joints x V views from the all-joints array of bf_joints_kernel, and the
+// routing of its gradient: chain joints -> ext's dGt / dt / ds blocks, vertex-based joints (selector vertices,
+// barycentric face landmarks) -> dL/dvout, added in joint order by one workgroup per frame (deterministic).
+// grid (F), 512 threads.
+__device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const float *__restrict__ jraw, const float *__restrict__ state, const float *__restrict__ proj_all,
+                  const float *__restrict__ keypoints, const int *__restrict__ ndiv, const int *__restrict__ lmk_vid,
+                  const float *__restrict__ lmk_w, float *__restrict__ ext, float *__restrict__ dvout, float *__restrict__ terms) {
+    const int tid = threadIdx.x, nl = Q.nl, V = Q.n_views;
+    const int NLP = (nl + 31) & ~31, slots = max(1, 512 / NLP);
+    float *s_part = sm;                       // [slots][NLP][4]
+    float *s_g = s_part + slots * NLP * 4;    // [nl][4]  dL/dXw and the loss share
+    float *s_x = s_g + nl * 4;                // [nl][3]  model-space joint
+    StateView st = bf_state_view(const_cast<float *>(state) + (size_t)f * bf_state_stride(Q.nj, Q.npf, Q.nb), Q.nj, Q.npf, Q.nb);
+    const float t0 = st.t[0], t1 = st.t[1], t2 = st.t[2], cs = st.sc[1], sc = st.sc[0] * cs;
+    const float ndiv_f = (float)ndiv[f], icoeff = 1.0f / Q.coeff, kscale = -1.0f / (Q.coeff * ndiv_f), s2 = Q.sigma2;
+    const int j = tid % NLP, vs = tid / NLP;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, ls = 0.f;
+    if (vs < slots && j < nl) {
+        const float *x = jraw + ((size_t)f * Q.n_all + Q.joint_map[j]) * 3;
+        const float y0 = x[0] + t0, y1 = x[1] + t1, y2 = x[2] + t2;
+        const float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
+        if (vs == 0) { s_x[j * 3] = x[0]; s_x[j * 3 + 1] = x[1]; s_x[j * 3 + 2] = x[2]; }
+        for (int v = vs; v < V; v += slots) {
+            const float *P = proj_all + ((size_t)f * V + v) * 12;
+            const float *kp = keypoints + (((size_t)f * V + v) * nl + j) * 3;
+            float c2 = kp[2] * kp[2];
+            float p0 = P[0] * x0 + P[1] * x1 + P[2] * x2 + P[3];
+            float p1 = P[4] * x0 + P[5] * x1 + P[6] * x2 + P[7];
+            float p2 = P[8] * x0 + P[9] * x1 + P[10] * x2 + P[11];
+            float ip2 = 1.0f / p2, u = p0 * ip2, w = p1 * ip2;
+            float rx = (kp[0] - u) * icoeff, ry = (kp[1] - w) * icoeff;
+            float ix = 1.0f / (s2 + rx * rx), iy = 1.0f / (s2 + ry * ry);
+            ls += c2 * (s2 * rx * rx * ix + s2 * ry * ry * iy);
+            float k = c2 * kscale;
+            float du = k * (2.f * s2 * s2 * rx * ix * ix), dw = k * (2.f * s2 * s2 * ry * iy * iy);
+            float q0 = du * ip2, q1 = dw * ip2, q2 = -(du * u + dw * w) * ip2;
+            g0 += P[0] * q0 + P[4] * q1 + P[8] * q2;
+            g1 += P[1] * q0 + P[5] * q1 + P[9] * q2;
+            g2 += P[2] * q0 + P[6] * q1 + P[10] * q2;
+        }
+    }
+    if (vs < slots && j < NLP) { float4 pr = {g0, g1, g2, ls}; ((float4 *)s_part)[vs * NLP + j] = pr; }
+    __syncthreads();
+    if (tid < nl) {
+        float4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < slots; ++q) { float4 p = ((float4 *)s_part)[q * NLP + tid]; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+        ((float4 *)s_g)[tid] = a;
+    }
+    __syncthreads();
+    const int EXT_T = Q.npf + Q.nj * 12 + Q.nb, EXT_G = EXT_T + 4, EXT_K = EXT_G + Q.nj * 3, EXT = EXT_K + 4;
+    float *e = ext + (size_t)f * EXT;
+    // chain joints: pull the loss joints that map to each (CSR), in loss-joint order
+    for (int i = tid; i < Q.nj * 3; i += 512) {
+        int cj = i / 3, k = i - cj * 3;
+        float acc = 0.f;
+        for (int q = Q.cj_start[cj]; q < Q.cj_start[cj + 1]; ++q) acc += s_g[Q.cj_list[q] * 4 + k];
+        e[EXT_G + i] = acc * sc;
+    }
+    {
+        // d/dt, d/ds through the chain-joint-based loss joints only (the vertex-based ones go through dvout), and the loss value:
+        // five sums over the loss joints, one WAVE each (waves 3..7; lane l takes joints l, l + 64, ... in order, then a fixed
+        // xor tree) - a single thread walking 135 LDS entries per sum was a third of this kernel's time
+        const int wv = tid >> 6, lane = tid & 63, which = wv - 3;
+        if (which >= 0 && which < 5) {
+            float acc = 0.f;
+            for (int q = lane; q < nl; q += 64) {
+                const bool chain = Q.joint_map[q] < Q.nj;
+                if (which < 3) acc += chain ? s_g[q * 4 + which] : 0.f;
+                else if (which == 3) acc += chain ? s_g[q * 4] * (s_x[q * 3] + t0) + s_g[q * 4 + 1] * (s_x[q * 3 + 1] + t1) + s_g[q * 4 + 2] * (s_x[q * 3 + 2] + t2) : 0.f;
+                else acc += s_g[q * 4 + 3];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+            if (lane == 0) {
+                if (which < 3) e[EXT_K + which] = acc * sc;
+                else if (which == 3) e[EXT_K + 3] = acc * cs;
+                else terms[(size_t)f * 4] = acc / ndiv_f;
+            }
+        }
+    }
+    // vertex-based joints: their vertices may coincide, so the order of the additions matters.  The (joint, corner) items
+    // are SORTED by (vertex, item index) - a bitonic network over keys in LDS - so the items of a vertex become one run in
+    // joint order; the thread at the start of a run adds them up in that order and applies the total with a single
+    // read-modify-write (dL/dvertices is zero when this kernel starts, so the bits are those of adding item by item).
+    // (The first version ranked every item against all earlier ones: O(n^2) LDS reads, 15 of this kernel's 26 us.)
+    float *dv = dvout + (size_t)f * Q.nv * 3;
+    const int n_ori = Q.nj + Q.n_selector;
+    int *s_key = (int *)(s_x + nl * 3 + 8);               // [N] (vertex << 10 | item), 0x7fffffff = no vertex
+    float *s_w = (float *)(s_key + 1024);                 // [n_items] weight of the item
+    const int n_items = nl * 3, N = n_items <= 512 ? 512 : 1024;
+    __syncthreads();
+    for (int i = tid; i < N; i += 512) {
+        int key = 0x7fffffff;
+        if (i < n_items) {
+            const int q = i / 3, c = i - q * 3, src = Q.joint_map[q];
+            int vid = -1;
+            float w = 1.f;
+            if (src >= Q.nj) {
+                if (src < n_ori) { if (c == 0) vid = Q.selector_ids[src - Q.nj]; }
+                else {
+                    const size_t l = ((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c;
+                    vid = lmk_vid[l];
+                    w = lmk_w[l];
+                }
+            }
+            s_w[i] = w;
+            if (vid >= 0) key = (vid << 10) | i;
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int t = tid; t < N / 2; t += 512) {
+                const int lo = ((t / jj) * jj * 2) + (t % jj), hi = lo + jj;
+                const int a = s_key[lo], b2 = s_key[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b2) == up) { s_key[lo] = b2; s_key[hi] = a; }
+            }
+            __syncthreads();
+        }
+    for (int p = tid; p < N; p += 512) {
+        const int key = s_key[p];
+        if (key == 0x7fffffff) continue;
+        const int vid = key >> 10;
+        if (p > 0 && (s_key[p - 1] >> 10) == vid) continue;            // not the start of its vertex's run
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int r = p; r < N && (s_key[r] >> 10) == vid && s_key[r] != 0x7fffffff; ++r) {
+            const int item = s_key[r] & 1023, q = item / 3;
+            const float w = s_w[item];
+            a0 += w * s_g[q * 4]; a1 += w * s_g[q * 4 + 1]; a2 += w * s_g[q * 4 + 2];
+        }
+        float *o = dv + (size_t)vid * 3;
+        o[0] += a0; o[1] += a1; o[2] += a2;
+    }
+}
+
+// grid (ceil(16 Cmax/256), M, F).  For contour point c: choice[F][M][Cmax] = sampled vertex (or -1),
+// cgrad[F][M][Cmax][2] = weight * coeff * (uv - c) / |uv - c|.  SIXTEEN lanes per contour point, each scanning every 16th
+// sampled vertex; the group is merged with the lexicographic (distance, index) minimum = torch.min's first minimum.
+template <int NT>
+__device__ __forceinline__ void bf_mask_contour_body(int bx, int m, int f, float4 *tile, float *sred, MaskIO K, const float *__restrict__ uvi, int *__restrict__ choice, float *__restrict__ cgrad,
+                       float *__restrict__ loss_part) {
+    const int gid = bx * NT + threadIdx.x, c = gid >> 4, sub = gid & 15;
+    const int vm = f * K.n_masks + m;
+    const int cnt = K.contour_count[vm];
+    const float *cp = K.contour_xy + ((size_t)K.contour_start[vm] + (c < cnt ? c : 0)) * 2;
+    const float cx = cp[0], cy = cp[1];
+    const float4 *rec = (const float4 *)uvi + (size_t)vm * K.ns;
+    float best = 3.0e38f;
+    int bidx = -1;
+    // (the next tile's record is requested before this tile is scanned; a vertex outside the image is parked at u = 3e19, so
+    //  its squared distance overflows past `best` and the scan needs no inside test; the winner's coordinates are re-read at the end)
+    // cdist form (torch.cdist for more than 25 points, loss.py:108): dist^2 = x1_ . x2_ with x1_ = (-2u, -2v, |uv|^2, 1) and
+    // x2_ = (cx, cy, 1, |c|^2), accumulated k = 0..3 as ONE fma chain (what the CPU sgemm does for K = 4), clamped at 0; the
+    // norms are sums of individually rounded squares (pow(2).sum(-1)).  The tile carries |uv|^2 in .z.
+    const bool cdist = K.cdist != 0;
+    const float n2 = __fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy));
+    auto fetch = [&](int s) {
+        float4 r = s < K.ns ? rec[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(r.z > 0.5f)) r.x = 3.0e19f;
+        r.z = __fadd_rn(__fmul_rn(r.x, r.x), __fmul_rn(r.y, r.y));
+        return r;
+    };
+    float4 nxt = fetch(threadIdx.x);
+    for (int base = 0; base < K.ns; base += NT) {
+        tile[threadIdx.x] = nxt;
+        nxt = fetch(base + NT + threadIdx.x);
+        __syncthreads();
+        int lim = min(NT, K.ns - base);
+        for (int i = sub; i < lim; i += 16) {
+            const float4 r = tile[i];
+            float d2;
+            if (cdist) {
+                float acc = __fmul_rn(cx, -2.f * r.x);
+                acc = __fmaf_rn(cy, -2.f * r.y, acc);
+                acc = __fadd_rn(acc, r.z);
+                acc = __fadd_rn(acc, n2);
+                d2 = fmaxf(acc, 0.f);                                          // clamp_min(0); a parked vertex gives +inf
+            } else {
+                const float dx = r.x - cx, dy = r.y - cy;
+                d2 = dx * dx + dy * dy;
+            }
+            if (d2 < best) { best = d2; bidx = base + i; }                     // first minimum of this lane's subset
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int x = 1; x < 16; x <<= 1) {
+        const float ob = __shfl_xor(best, x);
+        const int oi = __shfl_xor(bidx, x);
+        if (oi >= 0 && (bidx < 0 || ob < best || (ob == best && oi < bidx))) { best = ob; bidx = oi; }
+    }
+    float bu = 0.f, bv = 0.f;
+    if (bidx >= 0 && sub == 0) { const float4 r = rec[bidx]; bu = r.x; bv = r.y; }
+    float lval = 0.f;
+    if (c < cnt && sub == 0) {
+        const size_t o = (size_t)vm * K.cmax + c;
+        float gx = 0.f, gy = 0.f;
+        if (bidx >= 0) {
+            float d = sqrtf(best);
+            int px = (int)bu, py = (int)bv;                                    // .long() truncation (loss.py:114)
+            const unsigned char *mk = K.masks + (size_t)vm * K.H * K.W;
+            float mval = (px >= 0 && px < K.W && py >= 0 && py < K.H) ? (float)mk[(size_t)py * K.W + px] : 0.f;
+            float coeff = mval < 0.1f ? K.eps : 1.f;                            // (eps - 1) * outside + 1
+            lval = coeff * d;
+            if (d > 0.f) { gx = K.weight * coeff * (bu - cx) / d; gy = K.weight * coeff * (bv - cy) / d; }
+        }
+        choice[o] = bidx;
+        cgrad[o * 2] = gx; cgrad[o * 2 + 1] = gy;
+    }
+    lval = lb_wave_sum(lval);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lval;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < NT / 64; ++w) tot += sred[w];
+        loss_part[(size_t)vm * K.part_stride + K.proj_blocks + bx] = tot;
+    }
+}

@@ -16,6 +16,7 @@
 // Distances are exact (a - b)^2 sums; torch.cdist switches to the |a|^2+|b|^2-2ab form for these sizes,
 // which is noisier (about 1e-2 px at 512 px) - see DESIGN.md.
 #include "bf_internal.h"
+#include "loss_bodies.h"
 
 namespace {
 __device__ inline float mk_wave_sum(float v) {
@@ -74,78 +75,7 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
                        float *__restrict__ loss_part) {
     __shared__ float4 tile[256];
     __shared__ float sred[4];
-    const int gid = blockIdx.x * 256 + threadIdx.x, c = gid >> 4, sub = gid & 15, m = blockIdx.y, f = blockIdx.z;
-    const int vm = f * K.n_masks + m;
-    const int cnt = K.contour_count[vm];
-    const float *cp = K.contour_xy + ((size_t)K.contour_start[vm] + (c < cnt ? c : 0)) * 2;
-    const float cx = cp[0], cy = cp[1];
-    const float4 *rec = (const float4 *)uvi + (size_t)vm * K.ns;
-    float best = 3.0e38f;
-    int bidx = -1;
-    // (the next tile's record is requested before this tile is scanned; a vertex outside the image is parked at u = 3e19, so
-    //  its squared distance overflows past `best` and the scan needs no inside test; the winner's coordinates are re-read at the end)
-    // cdist form (torch.cdist for more than 25 points, loss.py:108): dist^2 = x1_ . x2_ with x1_ = (-2u, -2v, |uv|^2, 1) and
-    // x2_ = (cx, cy, 1, |c|^2), accumulated k = 0..3 as ONE fma chain (what the CPU sgemm does for K = 4), clamped at 0; the
-    // norms are sums of individually rounded squares (pow(2).sum(-1)).  The tile carries |uv|^2 in .z.
-    const bool cdist = K.cdist != 0;
-    const float n2 = __fadd_rn(__fmul_rn(cx, cx), __fmul_rn(cy, cy));
-    auto fetch = [&](int s) {
-        float4 r = s < K.ns ? rec[s] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(r.z > 0.5f)) r.x = 3.0e19f;
-        r.z = __fadd_rn(__fmul_rn(r.x, r.x), __fmul_rn(r.y, r.y));
-        return r;
-    };
-    float4 nxt = fetch(threadIdx.x);
-    for (int base = 0; base < K.ns; base += 256) {
-        tile[threadIdx.x] = nxt;
-        nxt = fetch(base + 256 + threadIdx.x);
-        __syncthreads();
-        int lim = min(256, K.ns - base);
-        for (int i = sub; i < lim; i += 16) {
-            const float4 r = tile[i];
-            float d2;
-            if (cdist) {
-                float acc = __fmul_rn(cx, -2.f * r.x);
-                acc = __fmaf_rn(cy, -2.f * r.y, acc);
-                acc = __fadd_rn(acc, r.z);
-                acc = __fadd_rn(acc, n2);
-                d2 = fmaxf(acc, 0.f);                                          // clamp_min(0); a parked vertex gives +inf
-            } else {
-                const float dx = r.x - cx, dy = r.y - cy;
-                d2 = dx * dx + dy * dy;
-            }
-            if (d2 < best) { best = d2; bidx = base + i; }                     // first minimum of this lane's subset
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int x = 1; x < 16; x <<= 1) {
-        const float ob = __shfl_xor(best, x);
-        const int oi = __shfl_xor(bidx, x);
-        if (oi >= 0 && (bidx < 0 || ob < best || (ob == best && oi < bidx))) { best = ob; bidx = oi; }
-    }
-    float bu = 0.f, bv = 0.f;
-    if (bidx >= 0 && sub == 0) { const float4 r = rec[bidx]; bu = r.x; bv = r.y; }
-    float lval = 0.f;
-    if (c < cnt && sub == 0) {
-        const size_t o = (size_t)vm * K.cmax + c;
-        float gx = 0.f, gy = 0.f;
-        if (bidx >= 0) {
-            float d = sqrtf(best);
-            int px = (int)bu, py = (int)bv;                                    // .long() truncation (loss.py:114)
-            const unsigned char *mk = K.masks + (size_t)vm * K.H * K.W;
-            float mval = (px >= 0 && px < K.W && py >= 0 && py < K.H) ? (float)mk[(size_t)py * K.W + px] : 0.f;
-            float coeff = mval < 0.1f ? K.eps : 1.f;                            // (eps - 1) * outside + 1
-            lval = coeff * d;
-            if (d > 0.f) { gx = K.weight * coeff * (bu - cx) / d; gy = K.weight * coeff * (bv - cy) / d; }
-        }
-        choice[o] = bidx;
-        cgrad[o * 2] = gx; cgrad[o * 2 + 1] = gy;
-    }
-    lval = mk_wave_sum(lval);
-    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lval;
-    __syncthreads();
-    if (threadIdx.x == 0) loss_part[(size_t)vm * K.part_stride + K.proj_blocks + blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+    bf_mask_contour_body<256>(blockIdx.x, blockIdx.y, blockIdx.z, tile, sred, K, uvi, choice, cgrad, loss_part);
 }
 
 // grid (ceil(Ns/64), M, F), 256 threads.  gpart[f][m][s][3] = dL/dvertex 4 s from mask view m (one workgroup per view and

@@ -1,0 +1,101 @@
+// The pose state of one parameter set (theta, beta -> chain matrices A_j, pose feature): the body of bf_pose_state_kernel, also run
+// at the end of a dense-schedule fit launch for the parameters it just stepped (fit_kernels.hip), so that both produce the same bits.
+#pragma once
+#include "bf_internal.h"
+
+#define BF_POSE_STATE_LDS (64 * 9 + 64 * 3 + 64 * 9 + 64 * 3 + 66 + 64 + 64)
+
+namespace {
+__device__ inline void m_rodrigues(float tx, float ty, float tz, float *R) {
+    float ux = tx + 1e-8f, uy = ty + 1e-8f, uz = tz + 1e-8f;
+    float a = sqrtf(ux * ux + uy * uy + uz * uz);
+    float nx = tx / a, ny = ty / a, nz = tz / a;
+    float s = sinf(a), c = cosf(a), oc = 1.0f - c;
+    R[0] = 1.0f + oc * (-nz * nz - ny * ny);
+    R[1] = s * (-nz) + oc * (nx * ny);
+    R[2] = s * ny + oc * (nx * nz);
+    R[3] = s * nz + oc * (nx * ny);
+    R[4] = 1.0f + oc * (-nz * nz - nx * nx);
+    R[5] = s * (-nx) + oc * (ny * nz);
+    R[6] = s * (-ny) + oc * (nx * nz);
+    R[7] = s * nx + oc * (ny * nz);
+    R[8] = 1.0f + oc * (-ny * ny - nx * nx);
+}
+}  // namespace
+
+// One 128-thread workgroup per parameter set.  betas[n][nb], orient[n][3], body_pose[n][3(nj-1)];
+// transl / scale are taken as (0,0,0) / 1 / 1 when `sim` is null, else sim[n][5] = t, s, c.
+// `packed` != null: read everything from the optimiser-order parameter block packed[n][np] instead
+// (transl, scale from it; constant scale from cscale[n] or cscale_all).
+// Called by EVERY thread of the workgroup (it synchronises); `nt` = the workgroup's thread count.
+template <bool PACKED>
+__device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float *__restrict__ betas, const float *__restrict__ orient,
+                                                   const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
+                                                   const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all,
+                                                   const int f, const int tid, const int nt, float *lds) {
+    // lds: BF_POSE_STATE_LDS floats of workgroup-shared scratch
+    float *R = lds, *J = R + 64 * 9, *GR = J + 64 * 3, *Gt = GR + 64 * 9;
+    int *s_ls = (int *)(Gt + 64 * 3), *s_lj = s_ls + 66, *s_par = s_lj + 64;   // tree levels and parents: read once, not once per level (dependent global loads)
+    const int nj = T.nj, nb = T.nb, npf = T.npf;
+    if (tid < nj) { s_lj[tid] = T.level_joints[tid]; s_par[tid] = T.parents[tid]; }
+    if (tid <= T.n_levels && tid < 66) s_ls[tid] = T.level_start[tid];
+    const float *pk = PACKED ? packed + (size_t)f * T.np : nullptr;
+    const float *beta;
+    if constexpr (PACKED) beta = pk + T.off_beta; else beta = betas + (size_t)f * nb;
+    StateView st = bf_state_view(state + (size_t)f * bf_state_stride(nj, npf, nb), nj, npf, nb);
+    if (tid < nj) {
+        float th[3];
+        if constexpr (PACKED) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) th[k] = bf_theta(pk, tid, k, T.th_kind, T.th_off, T.pose_mean, T.hand_comp, T.n_pca, T.off_lh, T.off_rh);
+        } else {
+            const float *src = tid == 0 ? orient + (size_t)f * 3 : body_pose + (size_t)f * 3 * (nj - 1) + 3 * (tid - 1);
+            th[0] = src[0]; th[1] = src[1]; th[2] = src[2];
+        }
+        m_rodrigues(th[0], th[1], th[2], R + tid * 9);
+        st.theta[tid * 3] = th[0]; st.theta[tid * 3 + 1] = th[1]; st.theta[tid * 3 + 2] = th[2];
+    }
+    for (int i = tid; i < nj * 3; i += nt) {
+        float acc = 0.f;
+        for (int l = 0; l < nb; ++l) acc += T.Jd[i * nb + l] * beta[l];
+        J[i] = T.Jt[i] + acc;
+    }
+    __syncthreads();
+    if (tid < 9) GR[tid] = R[tid];
+    if (tid >= 64 && tid < 67) Gt[tid - 64] = J[tid - 64];
+    __syncthreads();
+    for (int lev = 1; lev < T.n_levels; ++lev) {
+        int ls = s_ls[lev], cnt = (s_ls[lev + 1] - ls) * 3;
+        for (int idx = tid; idx < cnt; idx += nt) {
+            int i = s_lj[ls + idx / 3], r = idx % 3, p = s_par[i];
+            float g0 = GR[p * 9 + r * 3], g1 = GR[p * 9 + r * 3 + 1], g2 = GR[p * 9 + r * 3 + 2];
+            const float *Ri = R + i * 9;
+            GR[i * 9 + r * 3 + 0] = g0 * Ri[0] + g1 * Ri[3] + g2 * Ri[6];
+            GR[i * 9 + r * 3 + 1] = g0 * Ri[1] + g1 * Ri[4] + g2 * Ri[7];
+            GR[i * 9 + r * 3 + 2] = g0 * Ri[2] + g1 * Ri[5] + g2 * Ri[8];
+            float r0 = J[i * 3] - J[p * 3], r1 = J[i * 3 + 1] - J[p * 3 + 1], r2 = J[i * 3 + 2] - J[p * 3 + 2];
+            Gt[i * 3 + r] = g0 * r0 + g1 * r1 + g2 * r2 + Gt[p * 3 + r];
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nj * 9; i += nt) st.GR[i] = GR[i];
+    for (int i = tid; i < nj * 3; i += nt) {
+        int j = i / 3, a = i % 3;
+        const float *g = GR + j * 9 + a * 3;
+        st.At[i] = Gt[i] - (g[0] * J[j * 3] + g[1] * J[j * 3 + 1] + g[2] * J[j * 3 + 2]);
+        st.Gt[i] = Gt[i];
+    }
+    for (int p = tid; p < npf; p += nt) {
+        int j = 1 + p / 9, e = p % 9;
+        st.feat[p] = R[j * 9 + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+    }
+    if (tid < nb) st.beta[tid] = beta[tid];
+    if constexpr (PACKED) {
+        if (tid < 3) st.t[tid] = pk[tid];
+        if (tid == 3) { st.sc[0] = pk[3]; st.sc[1] = cscale ? cscale[f] : cscale_all; }
+    } else {
+        if (tid < 3) st.t[tid] = sim ? sim[(size_t)f * 5 + tid] : 0.f;
+        if (tid == 3) { st.sc[0] = sim ? sim[(size_t)f * 5 + 3] : 1.f; st.sc[1] = sim ? sim[(size_t)f * 5 + 4] : 1.f; }
+    }
+}
+

@@ -6,7 +6,8 @@ extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const flo
 extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int, int *, float *, float *, int);
 extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
 extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
-extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const float *, int, const float *, const float *, const float *, float *, hipStream_t);
+extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const float *, int, const float *, const float *, const float *, float *, hipStream_t,
+                                        const float *, int, int);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int);
 extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
                                              const float *, float *, float *, float *);
@@ -19,6 +20,8 @@ extern "C" __global__ void bf_inside_mesh_kernel(ScanDev, const float *, int, fl
 extern "C" __global__ void bf_intersect_kernel(ScanDev, const float *, const float *, int, unsigned char *);
 extern "C" __global__ void bf_transpose_kernel(const float *, int, int, float *);
 extern "C" __global__ void bf_contour_kernel(const unsigned char *, int, int, int, float *, int *, unsigned *);
+extern "C" __global__ void bf_kp_contour_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
+                                                const float *, float *, float *, float *, MaskIO, const float *, int *, float *, float *);
 extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const float *, float *, float *, float *);
 extern "C" __global__ void bf_mask_contour_kernel(MaskIO, const float *, int *, float *, float *);
 extern "C" __global__ void bf_mask_gather_kernel(MaskIO, const float *, const float *, const float *, const int *, const float *, float *);
@@ -233,18 +236,45 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
     return bf_ensure_dense_buffers(b);
 }
 
-static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss) {
+static size_t kp_smem(const KpIO &K) {
+    const int NLP = (K.nl + 31) & ~31, slots = std::max(1, 512 / NLP);
+    return sizeof(float) * ((size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + 1024 + (size_t)K.nl * 3 + 16);   // (+ sort keys, item weights)
+}
+static KpIO kp_io(bf_batch *b, const bf_hyper &h) {
+    KpIO K = b->m->kp;
+    K.n_views = b->V; K.sigma2 = h.sigma * h.sigma; K.coeff = h.imsize / 1024.0f;
+    return K;
+}
+static int launch_kp(bf_batch *b, const bf_hyper &h) {
+    const KpIO K = kp_io(b, h);
+    hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), kp_smem(K), b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
+                       (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
+                       (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p);
+    HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+// `with_kp`: the dense keypoint loss rides in the contour launch (bf_kp_contour_kernel) instead of a launch of its own
+static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss, bool sum_views = true, const bf_hyper *with_kp = nullptr) {
     MaskIO K = b->mask;
     K.weight = weight;
     const int F = b->F;
     hipLaunchKernelGGL(bf_mask_project_kernel, dim3(K.proj_blocks, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->vout.p,
                        (const float *)b->proj.p, b->mk_uvi.p, b->mk_duvb.p, b->mk_part.p);
+    if (with_kp) {
+        const KpIO Q = kp_io(b, *with_kp);
+        hipLaunchKernelGGL(bf_kp_contour_kernel, dim3((K.cmax * 16 + 511) / 512 + 1, K.n_masks, F), dim3(512), kp_smem(Q), b->stream, Q,
+                           (const float *)b->jraw.p, (const float *)b->state.p, (const float *)b->proj.p, (const float *)b->keypoints.p,
+                           (const int *)b->ndiv.p, (const int *)b->lmk_vid.p, (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p,
+                           K, (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p);
+    } else
     hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax * 16 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
                        (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p);
     hipLaunchKernelGGL(bf_mask_gather_kernel, dim3((K.ns + 63) / 64, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->proj.p,
                        (const float *)b->mk_uvi.p, (const float *)b->mk_duvb.p, (const int *)b->mk_choice.p,
                        (const float *)b->mk_cgrad.p, b->mk_gpart.p);
-    hipLaunchKernelGGL(bf_mask_gsum_kernel, dim3(K.proj_blocks, F), dim3(256), 0, b->stream, K, (const float *)b->mk_gpart.p, b->dvout.p);
+    // (sum_views = false: the reverse mesh pass adds the views itself while it loads dL/dvertices)
+    if (sum_views) hipLaunchKernelGGL(bf_mask_gsum_kernel, dim3(K.proj_blocks, F), dim3(256), 0, b->stream, K, (const float *)b->mk_gpart.p, b->dvout.p);
     // (the loss VALUE is a serial sum over the partial blocks: only when somebody reads it - the fit loop needs the gradient)
     if (want_loss) hipLaunchKernelGGL(bf_mask_loss_kernel, dim3(F), dim3(64), 0, b->stream, K, (const float *)b->mk_part.p, b->mk_loss.p);
     HIP_TRY(hipGetLastError());
@@ -260,36 +290,27 @@ static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
     return bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, nullptr, nullptr, nullptr, b->stream, nullptr, b->vposed.p);
 }
 
-static int launch_kp(bf_batch *b, const bf_hyper &h) {
-    bf_model *m = b->m;
-    KpIO K = m->kp;
-    K.n_views = b->V; K.sigma2 = h.sigma * h.sigma; K.coeff = h.imsize / 1024.0f;
-    const int NLP = (K.nl + 31) & ~31, slots = std::max(1, 512 / NLP);
-    const size_t smem = sizeof(float) * ((size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + 1024 + (size_t)K.nl * 3 + 16);   // (+ sort keys, item weights)
-    hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), smem, b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
-                       (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
-                       (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p);
-    HIP_TRY(hipGetLastError());
-    return BF_OK;
-}
-
 // one dense iteration's forward + loss + reverse passes up to `ext` (everything except the fit kernel itself)
-static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight) {
+static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight, bool have_state = false) {
     bf_model *m = b->m;
     const int F = b->F, nv = m->nv, nblk = (nv + 255) / 256;
     const bool scans = late && !b->scans.empty(), masks = late && b->has_masks, kp = m->kp_dense;
-    hipLaunchKernelGGL(bf_pose_state_kernel, dim3(F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
-                       (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
-                       (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
-    HIP_TRY(hipGetLastError());
+    if (!have_state) {               // (inside the loop the previous iteration's fit launch left the state of the parameters it stepped)
+        hipLaunchKernelGGL(bf_pose_state_kernel, dim3(F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
+                           (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
+                           (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
+        HIP_TRY(hipGetLastError());
+    }
     bool zeroed = false;                      // dL/dvertices = 0 before the keypoint / silhouette kernels add into it
     int rc = bf_launch_mesh(m, &b->scratch, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
                             b->vposed.p, kp ? b->jraw.p : nullptr, kp ? b->lmk_vid.p : nullptr, kp ? b->lmk_w.p : nullptr,
                             (kp || masks) ? b->dvout.p : nullptr, &zeroed);
     if (rc) return rc;
     if ((kp || masks) && !zeroed) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
-    if (kp) { rc = launch_kp(b, h); if (rc) return rc; }
-    if (masks) { rc = launch_mask_kernels(b, mask_weight, false); if (rc) return rc; }
+    if (kp && !masks) { rc = launch_kp(b, h); if (rc) return rc; }
+    // with a scan as well, bf_pc_grad_kernel adds onto (keypoints + silhouette): keep that order of additions
+    const bool fold_views = masks && !scans;
+    if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr); if (rc) return rc; }
     if (scans) {
         hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv + 3) / 4, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
                            (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);   // (one wave per query; warm start from the previous call's faces)
@@ -302,7 +323,8 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     }
     const int EXT = m->npf + m->nj * 12 + m->nb + 4;
     {
-        const int e = bf_mesh_bwd_multi_launch(&m->mesh, m->posedirsT.p, b->state.p, F, b->dvout.p, b->vposed.p, b->vraw.p, b->ext_part.p, b->stream);
+        const int e = bf_mesh_bwd_multi_launch(&m->mesh, m->posedirsT.p, b->state.p, F, b->dvout.p, b->vposed.p, b->vraw.p, b->ext_part.p, b->stream,
+                                               fold_views ? (const float *)b->mk_gpart.p : nullptr, b->mask.n_masks, b->mask.ns);
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_bwd_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     }
     hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 31) / 32, F), dim3(256), 0, b->stream,
@@ -337,10 +359,11 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     if (n_plain > 0)
         HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream));
     for (int it = n_plain; it < n_iters; ++it) {
-        rc = dense_pass(b, h, hd, it > thr, 5.0f);                                     // smplify.py:210
+        rc = dense_pass(b, h, hd, it > thr, 5.0f, it > n_plain);                       // smplify.py:210
         if (rc) return rc;
         FrameIO io2 = io;
         io2.ext = b->ext.p;
+        io2.emit_next = it + 1 < n_iters;             // (the last launch leaves the state of the last forward: the result mesh)
         HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, b->fit_smem, b->stream));
     }
     return BF_OK;

@@ -14,6 +14,7 @@
 // utils/mesh_grid_searcher.py:56-79) is built once per scan by grid_kernels.hip, with triangles in face
 // order inside every cell (the reference fills its lists with atomicCAS in arbitrary order).
 #include "bf_internal.h"
+#include "loss_bodies.h"
 
 namespace {
 
@@ -314,7 +315,7 @@ template <int FPW>
 __global__ void __launch_bounds__(512)
 bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const float *__restrict__ state, int n_frames,
                          const float *__restrict__ dvout, const float *__restrict__ vposed, const float *__restrict__ vraw,
-                         float *__restrict__ part) {
+                         float *__restrict__ part, const float *__restrict__ gpart, int n_masks, int n_sampled) {
     constexpr int TV = BF_MESH_TILE, COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
@@ -356,7 +357,15 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
         const bool ok = f < nf && c < nvt * 3;
         const size_t o = ((size_t)(fbase + f) * nv + v0) * 3 + c;
         const float sc = s_sim[f * 8 + 3] * s_sim[f * 8 + 4];
-        const float g = ok ? dvout[o] : 0.f;
+        float g = ok ? dvout[o] : 0.f;
+        if (gpart && ok && ((v0 + c / 3) & 3) == 0) {
+            // the silhouette gradient of every 4th vertex (loss.py:99) is still per mask view: add the views here, in view order,
+            // exactly as bf_mask_gsum_kernel would have (sum of the views first, then onto dL/dvertex) - one launch less
+            const int sidx = (v0 + c / 3) >> 2;
+            float gs = 0.f;
+            for (int m = 0; m < n_masks; ++m) gs += gpart[(((size_t)(fbase + f) * n_masks + m) * n_sampled + sidx) * 3 + c % 3];
+            g += gs;
+        }
         s_dv[i] = g * sc;
         s_vp[i] = ok ? vposed[o] : 0.f;
         s_ts[(f * 2) * COLS + c] = g * sc;                                                          // d/dt_k = sum dvout * s c
@@ -461,7 +470,8 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
 }
 
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT, const float *state, int n, const float *dvout,
-                                        const float *vposed, const float *vraw, float *part, hipStream_t stream) {
+                                        const float *vposed, const float *vraw, float *part, hipStream_t stream,
+                                        const float *gpart, int n_masks, int n_sampled) {
     constexpr int COLS = BF_MESH_TILE * 3;
     const int fpw = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
     const size_t smem = sizeof(float) * ((size_t)COLS * fpw + (size_t)fpw * M->nj * 12 + (size_t)BF_MESH_TILE * M->nj + 2 * (size_t)fpw * COLS +
@@ -469,10 +479,10 @@ extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT
     const dim3 grid(M->n_tiles, (n + fpw - 1) / fpw), block(512);
     if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
     switch (fpw) {
-    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part); break;
-    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part); break;
-    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part); break;
-    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part); break;
+    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled); break;
+    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled); break;
+    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled); break;
+    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled); break;
     }
     return (int)hipGetLastError();
 }
@@ -510,142 +520,29 @@ bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float
 }
 
 
-// Dense keypoint loss (more than 32 loss joints, i.e. SMPL-X with hands + face): multiview_keypoint_loss
-// (smplify/loss.py:139-203) over nl joints x V views from the all-joints array of bf_joints_kernel, and the
-// routing of its gradient: chain joints -> ext's dGt / dt / ds blocks, vertex-based joints (selector vertices,
-// barycentric face landmarks) -> dL/dvout, added in joint order by one workgroup per frame (deterministic).
-// grid (F), 512 threads.
 extern "C" __global__ void __launch_bounds__(512)
 bf_kp_loss_kernel(KpIO Q, const float *__restrict__ jraw, const float *__restrict__ state, const float *__restrict__ proj_all,
                   const float *__restrict__ keypoints, const int *__restrict__ ndiv, const int *__restrict__ lmk_vid,
                   const float *__restrict__ lmk_w, float *__restrict__ ext, float *__restrict__ dvout, float *__restrict__ terms) {
     extern __shared__ __align__(16) float sm[];
-    const int tid = threadIdx.x, f = blockIdx.x, nl = Q.nl, V = Q.n_views;
-    const int NLP = (nl + 31) & ~31, slots = max(1, 512 / NLP);
-    float *s_part = sm;                       // [slots][NLP][4]
-    float *s_g = s_part + slots * NLP * 4;    // [nl][4]  dL/dXw and the loss share
-    float *s_x = s_g + nl * 4;                // [nl][3]  model-space joint
-    StateView st = bf_state_view(const_cast<float *>(state) + (size_t)f * bf_state_stride(Q.nj, Q.npf, Q.nb), Q.nj, Q.npf, Q.nb);
-    const float t0 = st.t[0], t1 = st.t[1], t2 = st.t[2], cs = st.sc[1], sc = st.sc[0] * cs;
-    const float ndiv_f = (float)ndiv[f], icoeff = 1.0f / Q.coeff, kscale = -1.0f / (Q.coeff * ndiv_f), s2 = Q.sigma2;
-    const int j = tid % NLP, vs = tid / NLP;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f, ls = 0.f;
-    if (vs < slots && j < nl) {
-        const float *x = jraw + ((size_t)f * Q.n_all + Q.joint_map[j]) * 3;
-        const float y0 = x[0] + t0, y1 = x[1] + t1, y2 = x[2] + t2;
-        const float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
-        if (vs == 0) { s_x[j * 3] = x[0]; s_x[j * 3 + 1] = x[1]; s_x[j * 3 + 2] = x[2]; }
-        for (int v = vs; v < V; v += slots) {
-            const float *P = proj_all + ((size_t)f * V + v) * 12;
-            const float *kp = keypoints + (((size_t)f * V + v) * nl + j) * 3;
-            float c2 = kp[2] * kp[2];
-            float p0 = P[0] * x0 + P[1] * x1 + P[2] * x2 + P[3];
-            float p1 = P[4] * x0 + P[5] * x1 + P[6] * x2 + P[7];
-            float p2 = P[8] * x0 + P[9] * x1 + P[10] * x2 + P[11];
-            float ip2 = 1.0f / p2, u = p0 * ip2, w = p1 * ip2;
-            float rx = (kp[0] - u) * icoeff, ry = (kp[1] - w) * icoeff;
-            float ix = 1.0f / (s2 + rx * rx), iy = 1.0f / (s2 + ry * ry);
-            ls += c2 * (s2 * rx * rx * ix + s2 * ry * ry * iy);
-            float k = c2 * kscale;
-            float du = k * (2.f * s2 * s2 * rx * ix * ix), dw = k * (2.f * s2 * s2 * ry * iy * iy);
-            float q0 = du * ip2, q1 = dw * ip2, q2 = -(du * u + dw * w) * ip2;
-            g0 += P[0] * q0 + P[4] * q1 + P[8] * q2;
-            g1 += P[1] * q0 + P[5] * q1 + P[9] * q2;
-            g2 += P[2] * q0 + P[6] * q1 + P[10] * q2;
-        }
+    bf_kp_loss_body(blockIdx.x, sm, Q, jraw, state, proj_all, keypoints, ndiv, lmk_vid, lmk_w, ext, dvout, terms);
+}
+
+// The dense keypoint loss and the silhouette loss's contour scan in ONE launch.  grid (contour blocks + 1, M, F), 512 threads:
+// block x < gridDim.x - 1 is a contour block (32 contour points, 16 lanes each: bf_mask_contour_kernel's arithmetic, same
+// results); block (gridDim.x - 1, 0, f) is frame f's keypoint workgroup.
+extern "C" __global__ void __launch_bounds__(512)
+bf_kp_contour_kernel(KpIO Q, const float *__restrict__ jraw, const float *__restrict__ state, const float *__restrict__ proj_all,
+                     const float *__restrict__ keypoints, const int *__restrict__ ndiv, const int *__restrict__ lmk_vid,
+                     const float *__restrict__ lmk_w, float *__restrict__ ext, float *__restrict__ dvout, float *__restrict__ terms,
+                     MaskIO K, const float *__restrict__ uvi, int *__restrict__ choice, float *__restrict__ cgrad,
+                     float *__restrict__ loss_part) {
+    extern __shared__ __align__(16) float sm[];
+    __shared__ float4 tile[512];
+    __shared__ float sred[8];
+    if (blockIdx.x == gridDim.x - 1) {
+        if (blockIdx.y == 0) bf_kp_loss_body(blockIdx.z, sm, Q, jraw, state, proj_all, keypoints, ndiv, lmk_vid, lmk_w, ext, dvout, terms);
+        return;
     }
-    if (vs < slots && j < NLP) { float4 pr = {g0, g1, g2, ls}; ((float4 *)s_part)[vs * NLP + j] = pr; }
-    __syncthreads();
-    if (tid < nl) {
-        float4 a = {0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < slots; ++q) { float4 p = ((float4 *)s_part)[q * NLP + tid]; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
-        ((float4 *)s_g)[tid] = a;
-    }
-    __syncthreads();
-    const int EXT_T = Q.npf + Q.nj * 12 + Q.nb, EXT_G = EXT_T + 4, EXT_K = EXT_G + Q.nj * 3, EXT = EXT_K + 4;
-    float *e = ext + (size_t)f * EXT;
-    // chain joints: pull the loss joints that map to each (CSR), in loss-joint order
-    for (int i = tid; i < Q.nj * 3; i += 512) {
-        int cj = i / 3, k = i - cj * 3;
-        float acc = 0.f;
-        for (int q = Q.cj_start[cj]; q < Q.cj_start[cj + 1]; ++q) acc += s_g[Q.cj_list[q] * 4 + k];
-        e[EXT_G + i] = acc * sc;
-    }
-    {
-        // d/dt, d/ds through the chain-joint-based loss joints only (the vertex-based ones go through dvout), and the loss value:
-        // five sums over the loss joints, one WAVE each (waves 3..7; lane l takes joints l, l + 64, ... in order, then a fixed
-        // xor tree) - a single thread walking 135 LDS entries per sum was a third of this kernel's time
-        const int wv = tid >> 6, lane = tid & 63, which = wv - 3;
-        if (which >= 0 && which < 5) {
-            float acc = 0.f;
-            for (int q = lane; q < nl; q += 64) {
-                const bool chain = Q.joint_map[q] < Q.nj;
-                if (which < 3) acc += chain ? s_g[q * 4 + which] : 0.f;
-                else if (which == 3) acc += chain ? s_g[q * 4] * (s_x[q * 3] + t0) + s_g[q * 4 + 1] * (s_x[q * 3 + 1] + t1) + s_g[q * 4 + 2] * (s_x[q * 3 + 2] + t2) : 0.f;
-                else acc += s_g[q * 4 + 3];
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-            if (lane == 0) {
-                if (which < 3) e[EXT_K + which] = acc * sc;
-                else if (which == 3) e[EXT_K + 3] = acc * cs;
-                else terms[(size_t)f * 4] = acc / ndiv_f;
-            }
-        }
-    }
-    // vertex-based joints: their vertices may coincide, so the order of the additions matters.  The (joint, corner) items
-    // are SORTED by (vertex, item index) - a bitonic network over keys in LDS - so the items of a vertex become one run in
-    // joint order; the thread at the start of a run adds them up in that order and applies the total with a single
-    // read-modify-write (dL/dvertices is zero when this kernel starts, so the bits are those of adding item by item).
-    // (The first version ranked every item against all earlier ones: O(n^2) LDS reads, 15 of this kernel's 26 us.)
-    float *dv = dvout + (size_t)f * Q.nv * 3;
-    const int n_ori = Q.nj + Q.n_selector;
-    int *s_key = (int *)(s_x + nl * 3 + 8);               // [N] (vertex << 10 | item), 0x7fffffff = no vertex
-    float *s_w = (float *)(s_key + 1024);                 // [n_items] weight of the item
-    const int n_items = nl * 3, N = n_items <= 512 ? 512 : 1024;
-    __syncthreads();
-    for (int i = tid; i < N; i += 512) {
-        int key = 0x7fffffff;
-        if (i < n_items) {
-            const int q = i / 3, c = i - q * 3, src = Q.joint_map[q];
-            int vid = -1;
-            float w = 1.f;
-            if (src >= Q.nj) {
-                if (src < n_ori) { if (c == 0) vid = Q.selector_ids[src - Q.nj]; }
-                else {
-                    const size_t l = ((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c;
-                    vid = lmk_vid[l];
-                    w = lmk_w[l];
-                }
-            }
-            s_w[i] = w;
-            if (vid >= 0) key = (vid << 10) | i;
-        }
-        s_key[i] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= N; k <<= 1)
-        for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int t = tid; t < N / 2; t += 512) {
-                const int lo = ((t / jj) * jj * 2) + (t % jj), hi = lo + jj;
-                const int a = s_key[lo], b2 = s_key[hi];
-                const bool up = (lo & k) == 0;
-                if ((a > b2) == up) { s_key[lo] = b2; s_key[hi] = a; }
-            }
-            __syncthreads();
-        }
-    for (int p = tid; p < N; p += 512) {
-        const int key = s_key[p];
-        if (key == 0x7fffffff) continue;
-        const int vid = key >> 10;
-        if (p > 0 && (s_key[p - 1] >> 10) == vid) continue;            // not the start of its vertex's run
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-        for (int r = p; r < N && (s_key[r] >> 10) == vid && s_key[r] != 0x7fffffff; ++r) {
-            const int item = s_key[r] & 1023, q = item / 3;
-            const float w = s_w[item];
-            a0 += w * s_g[q * 4]; a1 += w * s_g[q * 4 + 1]; a2 += w * s_g[q * 4 + 2];
-        }
-        float *o = dv + (size_t)vid * 3;
-        o[0] += a0; o[1] += a1; o[2] += a2;
-    }
+    bf_mask_contour_body<512>(blockIdx.x, blockIdx.y, blockIdx.z, tile, sred, K, uvi, choice, cgrad, loss_part);
 }
