@@ -5,7 +5,7 @@ extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const Hyper
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
 extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *, const float *);
 extern "C" int bf_mesh_use_multi(int npf, int n);
-extern "C" int bf_mesh_multi_launch(const MeshTab *, const float *, int, float *, float *, float *, float *, float *, hipStream_t);
+extern "C" int bf_mesh_multi_launch(const MeshTab *, const float *, int, float *, float *, float *, float *, float *, hipStream_t, const MaskProj *);
 extern "C" __global__ void bf_mesh_epilogue_kernel(MeshTab, const float *, const float *, float *, float *, float *, float *);
 extern "C" hipError_t bf_poseblend_launch(const MeshTab *M, const float *state, int n, float *featT, int kpad, int fpad, float *pose_off, hipStream_t stream);
 extern "C" __global__ void bf_mesh_epilogue_batch_kernel(MeshTab M, const float *state, const float *pose_off, int n_frames, float *vraw, float *vout, float *xpart);
@@ -371,8 +371,10 @@ int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
 
 int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw, int *lmk_vid,
-                   float *lmk_w, float *dvzero, bool *zeroed) {
+                   float *lmk_w, float *dvzero, bool *zeroed, bool want_xpart, const MaskProj *mproj, bool *projected) {
     if (zeroed) *zeroed = false;
+    if (projected) *projected = false;
+    const bool need_x = joints || joints_ori || jraw || want_xpart;
     dim3 grid(m->mesh.n_tiles, n);
     const float *pose_off = nullptr;
     if (n >= BF_MFMA_MIN_FRAMES) {
@@ -396,18 +398,19 @@ int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev,
         if (m->mesh.v_nnz == 4 && m->nb <= 10 && !vposed) {
             hipLaunchKernelGGL(bf_mesh_epilogue_batch_kernel, dim3((m->nv + 127) / 128, (n + BF_EPI_FRAMES - 1) / BF_EPI_FRAMES), dim3(128),
                                (size_t)BF_EPI_FRAMES * (m->nj * 12 + 128 * 3) * sizeof(float), stream, m->mesh, state_dev, pose_off, n, vraw, vout,
-                               (joints || joints_ori || jraw) ? xpart : (float *)nullptr);
+                               need_x ? xpart : (float *)nullptr);
         } else
         hipLaunchKernelGGL(bf_mesh_epilogue_kernel, grid, dim3(128), 0, stream, m->mesh, state_dev, pose_off, vraw, vout,
-                           (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed);
+                           need_x ? xpart : (float *)nullptr, vposed);
     } else if (bf_mesh_use_multi(m->npf, n)) {
-        const int e = bf_mesh_multi_launch(&m->mesh, state_dev, n, vraw, vout, (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed,
-                                           dvzero, stream);
+        const int e = bf_mesh_multi_launch(&m->mesh, state_dev, n, vraw, vout, need_x ? xpart : (float *)nullptr, vposed,
+                                           dvzero, stream, mproj);
+        if (projected && mproj) *projected = true;
         if (zeroed && dvzero) *zeroed = true;
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     } else
     hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, m->mesh,
-                       state_dev, vraw, vout, (joints || joints_ori || jraw) ? xpart : (float *)nullptr, vposed, pose_off);
+                       state_dev, vraw, vout, need_x ? xpart : (float *)nullptr, vposed, pose_off);
     HIP_TRY(hipGetLastError());
     if (after_mesh) HIP_TRY(hipEventRecord(after_mesh, stream));
     if (joints || joints_ori || jraw) {

@@ -150,8 +150,11 @@ struct bf_scan {
 extern "C" {
 int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw = nullptr,
-                   int *lmk_vid = nullptr, float *lmk_w = nullptr, float *dvzero = nullptr, bool *zeroed = nullptr);
-// (dvzero: a [n][NV][3] buffer the forward pass should zero while it is at it - only the 1..15-frame kernel does, *zeroed says so)
+                   int *lmk_vid = nullptr, float *lmk_w = nullptr, float *dvzero = nullptr, bool *zeroed = nullptr, bool want_xpart = false,
+                   const MaskProj *mproj = nullptr, bool *projected = nullptr);
+// (dvzero: a [n][NV][3] buffer the forward pass should zero while it is at it - only the 1..15-frame kernel does, *zeroed says so;
+//  want_xpart: fill xpart although no joints are asked for here - the caller forms them itself;
+//  mproj: project the sampled vertices into the mask views as well - only the 1..15-frame kernel does, *projected says so)
 int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDev &hd, FrameIO io);
 int bf_dense_loss_grad(bf_batch *b, const bf_hyper &h, const HyperDev &hd, FrameIO io);
 int bf_ensure_dense_buffers(bf_batch *b);

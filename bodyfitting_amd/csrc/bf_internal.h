@@ -148,6 +148,14 @@ struct MaskIO {
     const float *contour_xy;              // [sum][2] (x, y) contour points (loss.py:73-83)
 };
 
+// What the forward mesh pass needs to project its sampled vertices into the mask views (on = 0: nothing to do).
+struct MaskProj {
+    int on;
+    MaskIO K;
+    const float *proj;        // [F][V][12]
+    float *uvi, *duvb;        // bf_mask_project_kernel's outputs
+};
+
 // Dense keypoint loss inputs (device pointers / sizes).
 struct KpIO {
     int nl, n_views, nj, npf, nb, nv, n_all, n_selector, n_extra, n_lmk;

@@ -35,30 +35,7 @@ bf_mask_project_kernel(MaskIO K, const float *__restrict__ vout, const float *__
     float lval = 0.f;
     if (s < K.ns) {
         const float *X = vout + ((size_t)f * K.nv + (size_t)s * 4) * 3;
-        const float *P = proj_all + ((size_t)f * K.n_views + K.view_index[m]) * 12;
-        float p0 = P[0] * X[0] + P[1] * X[1] + P[2] * X[2] + P[3];
-        float p1 = P[4] * X[0] + P[5] * X[1] + P[6] * X[2] + P[7];
-        float p2 = P[8] * X[0] + P[9] * X[1] + P[10] * X[2] + P[11];
-        float u = p0 / p2, v = p1 / p2;
-        bool inside = u < K.imsize && u >= 0.f && v < K.imsize && v >= 0.f;
-        // grid_sample(1 - mask, uv / imsize * 2 - 1): ix = ((x + 1) W - 1) / 2
-        const float sx = (float)K.W / K.imsize, sy = (float)K.H / K.imsize;
-        float ix = ((u / K.imsize * 2.f - 1.f + 1.f) * K.W - 1.f) * 0.5f, iy = ((v / K.imsize * 2.f - 1.f + 1.f) * K.H - 1.f) * 0.5f;
-        float fx = floorf(ix), fy = floorf(iy);
-        int x0 = (int)fx, y0 = (int)fy;
-        float wx1 = ix - fx, wx0 = 1.f - wx1, wy1 = iy - fy, wy0 = 1.f - wy1;
-        const unsigned char *mk = K.masks + ((size_t)f * K.n_masks + m) * K.H * K.W;
-        auto at = [&](int y, int x) -> float {
-            return (x >= 0 && x < K.W && y >= 0 && y < K.H) ? 1.f - (float)mk[(size_t)y * K.W + x] : 0.f;   // zeros padding
-        };
-        float v00 = at(y0, x0), v01 = at(y0, x0 + 1), v10 = at(y0 + 1, x0), v11 = at(y0 + 1, x0 + 1);
-        lval = K.eps * (v00 * wx0 * wy0 + v01 * wx1 * wy0 + v10 * wx0 * wy1 + v11 * wx1 * wy1);
-        float gx = ((v01 - v00) * wy0 + (v11 - v10) * wy1) * sx, gy = ((v10 - v00) * wx0 + (v11 - v01) * wx1) * sy;
-        const size_t o = ((size_t)f * K.n_masks + m) * K.ns + s;
-        float4 rec = {u, v, inside ? 1.f : 0.f, 1.f / p2};
-        ((float4 *)uvi)[o] = rec;
-        duvb[o * 2] = K.weight * K.eps * gx;
-        duvb[o * 2 + 1] = K.weight * K.eps * gy;
+        lval = bf_mask_project_one(K, X[0], X[1], X[2], proj_all, f, m, s, uvi, duvb);
     }
     lval = mk_wave_sum(lval);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lval;

@@ -16,6 +16,9 @@
 // matrices (1.1 KB) and the 207-float pose feature sit in LDS.
 #include "bf_internal.h"
 #include "pose_state_body.h"
+#include "joints_body.h"
+#include "loss_bodies.h"
+#include <cstring>
 
 namespace {
 __device__ inline float m_wave_sum(float v) {
@@ -188,7 +191,7 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
 template <int FPW>
 __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
 bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, float *__restrict__ vraw, float *__restrict__ vout,
-                     float *__restrict__ xpart, float *__restrict__ vposed, float *__restrict__ dvzero) {
+                     float *__restrict__ xpart, float *__restrict__ vposed, float *__restrict__ dvzero, MaskProj mp) {
     static_assert(FPW == 1 || FPW == 2 || FPW == 4 || FPW == 8, "frames per workgroup");
     constexpr int COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
@@ -313,6 +316,24 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
         if (vposed) vposed[o] = vp[k];
         if (dvzero) dvzero[o] = 0.f;                          // dL/dvertices starts the iteration at zero: saves a memset launch
     }
+    if (mp.on) {
+        // silhouette loss: the tile's sampled vertices (every 4th, loss.py:99) projected into every mask view while they are at hand -
+        // bf_mask_project_kernel's arithmetic on the value just stored to vout (no launch of its own)
+        __syncthreads();                                     // (s_red is free: every sum above has been taken)
+        if (mine) {
+            const float *sb = s_beta + f * 32 + nb;
+            s_red[f * COLS + col] = ok ? (r + sb[k]) * sb[3] * sb[4] : 0.f;
+        }
+        __syncthreads();
+        if (mine)
+            for (int idx = col; idx < (BF_MESH_TILE / 4) * mp.K.n_masks; idx += COLS) {
+                const int sv = idx % (BF_MESH_TILE / 4), m = idx / (BF_MESH_TILE / 4), vv = tile * BF_MESH_TILE + sv * 4;
+                if (vv < nv) {
+                    const float *X = s_red + f * COLS + sv * 12;
+                    (void)bf_mask_project_one(mp.K, X[0], X[1], X[2], mp.proj, fbase + f, m, vv >> 2, mp.uvi, mp.duvb);
+                }
+            }
+    }
     if (xpart) {
         // this tile's share of J_regressor_extra . vertices (models/smpl.py:72), per frame
         const int ne3 = M.n_extra * 3;
@@ -334,7 +355,9 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
 }
 
 extern "C" int bf_mesh_multi_launch(const MeshTab *M, const float *state, int n, float *vraw, float *vout, float *xpart, float *vposed,
-                                    float *dvzero, hipStream_t stream) {
+                                    float *dvzero, hipStream_t stream, const MaskProj *mproj) {
+    MaskProj mp;
+    if (mproj) mp = *mproj; else { std::memset(&mp, 0, sizeof mp); }
     constexpr int COLS = BF_MESH_TILE * 3;
     const int fpw = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
     const int rows = (M->npf + BF_MESH_RG - 1) / BF_MESH_RG;
@@ -348,10 +371,10 @@ extern "C" int bf_mesh_multi_launch(const MeshTab *M, const float *state, int n,
         if (e != hipSuccess) return (int)e;
     }
     switch (fpw) {
-    case 1: hipLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero); break;
-    case 2: hipLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero); break;
-    case 4: hipLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero); break;
-    default: hipLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero); break;
+    case 1: hipLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp); break;
+    case 2: hipLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp); break;
+    case 4: hipLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp); break;
+    default: hipLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp); break;
     }
     return (int)hipGetLastError();
 }
@@ -374,72 +397,8 @@ extern "C" __global__ void __launch_bounds__(256)
 bf_joints_kernel(MeshTab M, const float *__restrict__ state, const float *__restrict__ vraw,
                  const float *__restrict__ xpart, float *__restrict__ joints, float *__restrict__ joints_ori,
                  float *__restrict__ jraw, int *__restrict__ lmk_vid, float *__restrict__ lmk_w) {
-    __shared__ float s_extra[32 * 3];
-    __shared__ float s_all[256 * 3];
-    __shared__ int s_row;
-    const int tid = threadIdx.x, frame = blockIdx.x;
-    const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv, ne = M.n_extra, nsel = M.n_selector;
-    const int nlm = M.n_lmk_static + M.n_lmk_dyn;
-    StateView st = bf_state_view(const_cast<float *>(state) + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
-    const float *vr = vraw + (size_t)frame * nv * 3;
-    const float t0 = st.t[0], t1 = st.t[1], t2 = st.t[2], sc = st.sc[0] * st.sc[1];
-    const int ne3 = ne * 3, nt8 = M.n_tiles;
-    // extra-regressor joints: sum the mesh kernel's per-tile partials; 32 lanes per output, each lane's loads issued
-    // together (a serial loop over the tiles costs one memory latency per tile), fixed xor tree
-    for (int base = 0; base < ne3 * 32; base += 256) {
-        const int idx = base + tid, o = idx >> 5, sl = idx & 31;
-        float acc = 0.f;
-        if (o < ne3) {
-            const float *p = xpart + (size_t)frame * nt8 * ne3 + o;
-            float v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const int t = sl + 32 * q; v[q] = t < nt8 ? p[(size_t)t * ne3] : 0.f; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) acc += v[q];
-            for (int t = sl + 256; t < nt8; t += 32) acc += p[(size_t)t * ne3];
-        }
-        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
-        acc += __shfl_xor(acc, 16);
-        if (o < ne3 && sl == 0) s_extra[o] = acc;
-    }
-    if (tid == 0 && M.n_lmk_dyn > 0) {
-        // find_dynamic_lmk_idx_and_bcoords: y = round(clamp(-yaw * 180 / pi, max = 39)), negatives folded to 39 - y / 78
-        const float *G = st.GR + M.neck_joint * 9;
-        float yaw = atan2f(-G[6], sqrtf(G[0] * G[0] + G[3] * G[3]));
-        int y = (int)rintf(fminf(-yaw * 180.0f / 3.14159265358979323846f, 39.f));
-        if (y < 0) y = y < -39 ? 78 : 39 - y;
-        s_row = y;
-    }
-    __syncthreads();
-    const int n_ori = nj + nsel, n_all = n_ori + ne + nlm;
-    for (int i = tid; i < n_all * 3; i += 256) {
-        int j = i / 3, k = i - j * 3;
-        float x;
-        if (j < nj) x = st.Gt[j * 3 + k];
-        else if (j < n_ori) x = vr[(size_t)M.selector_ids[j - nj] * 3 + k];
-        else if (j < n_ori + ne) x = s_extra[(j - n_ori) * 3 + k];
-        else {
-            int l = j - n_ori - ne;
-            int face = l < M.n_lmk_static ? M.lmk_faces[l] : M.dyn_faces[s_row * M.n_lmk_dyn + (l - M.n_lmk_static)];
-            const float *bw = l < M.n_lmk_static ? M.lmk_bary + l * 3 : M.dyn_bary + ((size_t)s_row * M.n_lmk_dyn + (l - M.n_lmk_static)) * 3;
-            const int *fv = M.faces + (size_t)face * 3;
-            x = bw[0] * vr[(size_t)fv[0] * 3 + k] + bw[1] * vr[(size_t)fv[1] * 3 + k] + bw[2] * vr[(size_t)fv[2] * 3 + k];
-            if (k == 0 && lmk_vid) {
-                int *vo = lmk_vid + ((size_t)frame * nlm + l) * 3;
-                float *wo = lmk_w + ((size_t)frame * nlm + l) * 3;
-                vo[0] = fv[0]; vo[1] = fv[1]; vo[2] = fv[2]; wo[0] = bw[0]; wo[1] = bw[1]; wo[2] = bw[2];
-            }
-        }
-        if (jraw) jraw[(size_t)frame * n_all * 3 + i] = x;
-        float tk = k == 0 ? t0 : (k == 1 ? t1 : t2);
-        s_all[i] = (x + tk) * sc;
-    }
-    __syncthreads();
-    if (joints_ori)
-        for (int i = tid; i < n_ori * 3; i += 256) joints_ori[(size_t)frame * n_ori * 3 + i] = s_all[i];
-    if (joints)
-        for (int i = tid; i < M.n_joint_map * 3; i += 256)
-            joints[(size_t)frame * M.n_joint_map * 3 + i] = s_all[M.joint_map[i / 3] * 3 + i % 3];
+    __shared__ float lds[BF_JOINTS_LDS];
+    bf_joints_body<256>(M, state, vraw, xpart, joints, joints_ori, jraw, lmk_vid, lmk_w, blockIdx.x, lds);
 }
 
 

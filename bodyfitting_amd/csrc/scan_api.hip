@@ -10,7 +10,7 @@ extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const fl
                                         const float *, int, int);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int);
 extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
-                                             const float *, float *, float *, float *);
+                                             const float *, float *, float *, float *, MeshTab, const float *, const float *);
 extern "C" __global__ void bf_grid_count_kernel(ScanDev, int *);
 extern "C" __global__ void bf_grid_scan_kernel(int *, int *, int);
 extern "C" __global__ void bf_grid_fill_kernel(ScanDev, int *, int *);
@@ -21,7 +21,8 @@ extern "C" __global__ void bf_intersect_kernel(ScanDev, const float *, const flo
 extern "C" __global__ void bf_transpose_kernel(const float *, int, int, float *);
 extern "C" __global__ void bf_contour_kernel(const unsigned char *, int, int, int, float *, int *, unsigned *);
 extern "C" __global__ void bf_kp_contour_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
-                                                const float *, float *, float *, float *, MaskIO, const float *, int *, float *, float *);
+                                                const float *, float *, float *, float *, MaskIO, const float *, int *, float *, float *,
+                                                MeshTab, const float *, const float *);
 extern "C" __global__ void bf_mask_project_kernel(MaskIO, const float *, const float *, float *, float *, float *);
 extern "C" __global__ void bf_mask_contour_kernel(MaskIO, const float *, int *, float *, float *);
 extern "C" __global__ void bf_mask_gather_kernel(MaskIO, const float *, const float *, const float *, const int *, const float *, float *);
@@ -238,35 +239,41 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
 
 static size_t kp_smem(const KpIO &K) {
     const int NLP = (K.nl + 31) & ~31, slots = std::max(1, 512 / NLP);
-    return sizeof(float) * ((size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + 1024 + (size_t)K.nl * 3 + 16);   // (+ sort keys, item weights)
+    // (the joints prologue's scratch, 32*3 + 256*3 + 4 floats, fits the head of this)
+    return sizeof(float) * std::max<size_t>(1024, (size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + 1024 + (size_t)K.nl * 3 + 16);   // (+ sort keys, item weights)
+
 }
 static KpIO kp_io(bf_batch *b, const bf_hyper &h) {
     KpIO K = b->m->kp;
     K.n_views = b->V; K.sigma2 = h.sigma * h.sigma; K.coeff = h.imsize / 1024.0f;
     return K;
 }
+// (the keypoint workgroup computes the joints itself from the mesh pass's vraw / xpart: no bf_joints_kernel launch)
 static int launch_kp(bf_batch *b, const bf_hyper &h) {
     const KpIO K = kp_io(b, h);
     hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), kp_smem(K), b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
                        (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
-                       (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p);
+                       (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p, b->m->mesh, (const float *)b->vraw.p, (const float *)b->xpart.p);
     HIP_TRY(hipGetLastError());
     return BF_OK;
 }
 
 // `with_kp`: the dense keypoint loss rides in the contour launch (bf_kp_contour_kernel) instead of a launch of its own
-static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss, bool sum_views = true, const bf_hyper *with_kp = nullptr) {
+static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss, bool sum_views = true, const bf_hyper *with_kp = nullptr,
+                               bool projected = false) {
     MaskIO K = b->mask;
     K.weight = weight;
     const int F = b->F;
-    hipLaunchKernelGGL(bf_mask_project_kernel, dim3(K.proj_blocks, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->vout.p,
+    // (projected: the forward mesh pass already wrote uvi / duvb for its sampled vertices)
+    if (!projected) hipLaunchKernelGGL(bf_mask_project_kernel, dim3(K.proj_blocks, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->vout.p,
                        (const float *)b->proj.p, b->mk_uvi.p, b->mk_duvb.p, b->mk_part.p);
     if (with_kp) {
         const KpIO Q = kp_io(b, *with_kp);
         hipLaunchKernelGGL(bf_kp_contour_kernel, dim3((K.cmax * 16 + 511) / 512 + 1, K.n_masks, F), dim3(512), kp_smem(Q), b->stream, Q,
                            (const float *)b->jraw.p, (const float *)b->state.p, (const float *)b->proj.p, (const float *)b->keypoints.p,
                            (const int *)b->ndiv.p, (const int *)b->lmk_vid.p, (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p,
-                           K, (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p);
+                           K, (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p, b->m->mesh, (const float *)b->vraw.p,
+                           (const float *)b->xpart.p);
     } else
     hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax * 16 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
                        (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p);
@@ -302,15 +309,21 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         HIP_TRY(hipGetLastError());
     }
     bool zeroed = false;                      // dL/dvertices = 0 before the keypoint / silhouette kernels add into it
+    // (kp: the mesh pass leaves the extra-regressor partials in xpart; the joints are formed by the keypoint workgroup)
+    MaskProj mp;
+    bool projected = false;
+    if (masks) {
+        mp.on = 1; mp.K = b->mask; mp.K.weight = mask_weight; mp.proj = b->proj.p; mp.uvi = b->mk_uvi.p; mp.duvb = b->mk_duvb.p;
+    }
     int rc = bf_launch_mesh(m, &b->scratch, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
-                            b->vposed.p, kp ? b->jraw.p : nullptr, kp ? b->lmk_vid.p : nullptr, kp ? b->lmk_w.p : nullptr,
-                            (kp || masks) ? b->dvout.p : nullptr, &zeroed);
+                            b->vposed.p, nullptr, nullptr, nullptr, (kp || masks) ? b->dvout.p : nullptr, &zeroed, kp, masks ? &mp : nullptr,
+                            &projected);
     if (rc) return rc;
     if ((kp || masks) && !zeroed) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
     if (kp && !masks) { rc = launch_kp(b, h); if (rc) return rc; }
     // with a scan as well, bf_pc_grad_kernel adds onto (keypoints + silhouette): keep that order of additions
     const bool fold_views = masks && !scans;
-    if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr); if (rc) return rc; }
+    if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr, projected); if (rc) return rc; }
     if (scans) {
         hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv + 3) / 4, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
                            (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);   // (one wave per query; warm start from the previous call's faces)

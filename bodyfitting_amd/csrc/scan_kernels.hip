@@ -15,6 +15,7 @@
 // order inside every cell (the reference fills its lists with atomicCAS in arbitrary order).
 #include "bf_internal.h"
 #include "loss_bodies.h"
+#include "joints_body.h"
 
 namespace {
 
@@ -523,8 +524,14 @@ bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float
 extern "C" __global__ void __launch_bounds__(512)
 bf_kp_loss_kernel(KpIO Q, const float *__restrict__ jraw, const float *__restrict__ state, const float *__restrict__ proj_all,
                   const float *__restrict__ keypoints, const int *__restrict__ ndiv, const int *__restrict__ lmk_vid,
-                  const float *__restrict__ lmk_w, float *__restrict__ ext, float *__restrict__ dvout, float *__restrict__ terms) {
+                  const float *__restrict__ lmk_w, float *__restrict__ ext, float *__restrict__ dvout, float *__restrict__ terms,
+                  MeshTab M, const float *__restrict__ vraw, const float *__restrict__ xpart) {
     extern __shared__ __align__(16) float sm[];
+    if (vraw) {           // the joints first (bf_joints_kernel's body: jraw / lmk_vid / lmk_w are then OUTPUTS of this workgroup)
+        bf_joints_body<512>(M, state, vraw, xpart, nullptr, nullptr, const_cast<float *>(jraw), const_cast<int *>(lmk_vid), const_cast<float *>(lmk_w),
+                            blockIdx.x, sm);
+        __syncthreads();
+    }
     bf_kp_loss_body(blockIdx.x, sm, Q, jraw, state, proj_all, keypoints, ndiv, lmk_vid, lmk_w, ext, dvout, terms);
 }
 
@@ -536,12 +543,19 @@ bf_kp_contour_kernel(KpIO Q, const float *__restrict__ jraw, const float *__rest
                      const float *__restrict__ keypoints, const int *__restrict__ ndiv, const int *__restrict__ lmk_vid,
                      const float *__restrict__ lmk_w, float *__restrict__ ext, float *__restrict__ dvout, float *__restrict__ terms,
                      MaskIO K, const float *__restrict__ uvi, int *__restrict__ choice, float *__restrict__ cgrad,
-                     float *__restrict__ loss_part) {
+                     float *__restrict__ loss_part, MeshTab M, const float *__restrict__ vraw, const float *__restrict__ xpart) {
     extern __shared__ __align__(16) float sm[];
     __shared__ float4 tile[512];
     __shared__ float sred[8];
     if (blockIdx.x == gridDim.x - 1) {
-        if (blockIdx.y == 0) bf_kp_loss_body(blockIdx.z, sm, Q, jraw, state, proj_all, keypoints, ndiv, lmk_vid, lmk_w, ext, dvout, terms);
+        if (blockIdx.y == 0) {
+            if (vraw) {
+                bf_joints_body<512>(M, state, vraw, xpart, nullptr, nullptr, const_cast<float *>(jraw), const_cast<int *>(lmk_vid),
+                                    const_cast<float *>(lmk_w), blockIdx.z, sm);
+                __syncthreads();
+            }
+            bf_kp_loss_body(blockIdx.z, sm, Q, jraw, state, proj_all, keypoints, ndiv, lmk_vid, lmk_w, ext, dvout, terms);
+        }
         return;
     }
     bf_mask_contour_body<512>(blockIdx.x, blockIdx.y, blockIdx.z, tile, sred, K, uvi, choice, cgrad, loss_part);

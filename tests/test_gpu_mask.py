@@ -198,3 +198,26 @@ def test_two_frames_device_contours_match_single_frames(dev_model, smpl_model):
         np.testing.assert_array_equal(loss2[i], loss1[0])
         np.testing.assert_array_equal(dv2[i], dv1[0])
     assert loss2[0] != loss2[1]
+
+
+def test_sixteen_frames_with_masks_take_the_batched_mesh_path(dev_model, smpl_model):
+    """>= 16 frames: the dense schedule's forward mesh is the fp32-MFMA pose-blend GEMM + batched epilogue (the sampled vertices are
+    then projected by bf_mask_project_kernel, not inside the mesh pass) - the first silhouette iteration of every frame agrees
+    with the frame fitted alone"""
+    probs = [S.make_problem(smpl_model, frame=f % 2, n_views=8, mask_frames=MASK_FRAMES) for f in range(17)]
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem(probs)
+    masks = np.stack([np.array(p["masks"]) for p in probs])
+    view_index = [probs[0]["use_frames"].index(f) for f in MASK_FRAMES]
+    b = N.FrameBatch(dev_model, 17, 8)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose); b.set_masks(masks, view_index, None)
+    b.fit(12, N.make_hyper(dense_after=10))
+    together = b.get_params()
+    b.close()
+    for i in (0, 1, 16):
+        b1 = N.FrameBatch(dev_model, 1, 8)
+        b1.set_cameras(c2w[i:i + 1], K[i:i + 1]); b1.set_keypoints(kp[i:i + 1], ndiv[i:i + 1]); b1.set_init(betas[i:i + 1], pose[i:i + 1])
+        b1.set_masks(masks[i:i + 1], view_index, None)
+        b1.fit(12, N.make_hyper(dense_after=10))
+        np.testing.assert_allclose(together[i], b1.get_params()[0], atol=2e-3)      # (one iteration of a discontinuous loss on 2e-6-different meshes)
+        b1.close()
+    np.testing.assert_array_equal(together[0], together[16])                        # same frame, same batch: same bits
