@@ -41,8 +41,10 @@ BYTES_PER_FRAME_ITER = 17_114_760 + 826_800 + 661_440 + 661_440 + 248_040 + 82_6
 BYTES_MESH_LAUNCH = 17_114_760 + 826_800 + 661_440 + 82_680 + 2 * 82_680
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 ENGINE_CLOCK_GHZ = 2.4       # MI355X peak engine clock (the fit kernel is a one-CU latency chain: cycles are its natural unit)
-# dependent-chain lower bound of one fit iteration (per phase, dependent LDS round trips x ~90 cycles + s_barrier)
-CHAIN_BOUND_CYCLES = 5 * 20 + 24 * 90
+# dependent-chain lower bound of one fit iteration, DESIGN.md 4.1: 20 dependent LDS round trips (A 6, B 3, D 3, F 3, I 4 + 1) x ~90
+# cycles + 5 s_barriers x ~20 + the dependent arithmetic no layout removes (Rodrigues forward / reverse, the chain rounds,
+# projection + GMoF, Adam's sqrt / rcp chains: ~1,400 cycles at the measured dependent-issue costs)
+CHAIN_BOUND_CYCLES = 20 * 90 + 5 * 20 + 1400
 
 
 def parse():
@@ -255,7 +257,7 @@ def main():
             "latency": {"cycles_per_iteration": fit_ms * 1e-3 * ENGINE_CLOCK_GHZ * 1e9 / a.iters, "clock_ghz": ENGINE_CLOCK_GHZ,
                         "dependent_chain_bound_cycles": CHAIN_BOUND_CYCLES,
                         "frac_of_chain_bound": CHAIN_BOUND_CYCLES / (fit_ms * 1e-3 * ENGINE_CLOCK_GHZ * 1e9 / a.iters),
-                        "note": "one workgroup = one frame; bound = dependent LDS round trips x ~90 cycles + 5 s_barriers per iteration (DESIGN.md 4.1)"},
+                        "note": "one workgroup = one frame; bound = 20 dependent LDS round trips x ~90 cycles + 5 s_barriers + ~1,400 cycles of dependent arithmetic per iteration (an estimate, DESIGN.md 4.1)"},
         },
         "roofline_mesh": {
             "bound": "hbm", "kernel": "bf_mesh_kernel", "achieved": BYTES_MESH_LAUNCH * F / (mesh_ms * 1e-3) / 1e9 if mesh_ms > 0 else None,

@@ -12,7 +12,7 @@
 #define BF_SEL_NNZ 8         // compacted skinning weights per selector vertex (real SMPL has <= 4)
 #define BF_MFMA_MIN_FRAMES 16
 #define BF_EPI_FRAMES 8      // frames one workgroup of the batched mesh epilogue walks over (its tile's tables stay in registers)
-#define BF_GEMM_KB 52        // K pairs per register block of the pose-blend GEMM (A operand resident in VGPRs)  // from this batch size on the pose blend runs as one fp32-MFMA GEMM for all frames
+#define BF_GEMM_KB 26        // K pairs per register block of the pose-blend GEMM (A operand resident in VGPRs)  // from this batch size on the pose blend runs as one fp32-MFMA GEMM for all frames
 #define BF_MESH_TILE 32     // vertices per workgroup of the full-mesh forward
 #define BF_MESH_RG 8        // pose-feature row groups per workgroup (split-K inside the workgroup)
 

@@ -423,7 +423,7 @@ bf_pack_feat_kernel(MeshTab M, const float *__restrict__ state, int n_frames, in
 // buffered: the global loads of block k + 1 (float2, coalesced 256-byte rows, 13 per thread) are in flight while the
 // MFMAs of block k run, and every posedirs element is fetched once per 128 frames.  The A operand (the frames' pose
 // features, frame-minor featT) sits in VGPRs, one block at a time with the next prefetched.
-extern "C" __global__ void __launch_bounds__(256, 2)
+extern "C" __global__ void __launch_bounds__(256, 3)
 bf_poseblend_gemm_kernel(MeshTab M, const float *__restrict__ featT, int kpad, int fpad, int n_frames, float *__restrict__ pose_off) {
     constexpr int KB = BF_GEMM_KB, ROWS = 2 * KB, NLD = (ROWS * 32 + 255) / 256;      // float2 loads per thread and block
     __shared__ __align__(16) float s_b[2][ROWS][64];
