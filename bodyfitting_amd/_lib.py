@@ -42,6 +42,7 @@ class Hyper(C.Structure):
         "imsize", "lr", "lr_transl_scale", "adam_beta1", "adam_beta2", "adam_eps", "lr_displacement", "mask_cdist_form", "dense_after")]
 
 
+CONTOUR_OPENCV_FIRST, CONTOUR_RASTER_FIRST, CONTOUR_LONGEST = 0, 1, 2
 FIT_DEFAULT, FIT_DENSE, FIT_NO_VERTICES, FIT_FETCH, FIT_RESET, FIT_GRAPH, FIT_NOTIME = 0, 1, 2, 4, 8, 16, 32
 
 # every entry point include/bodyfit.h declares: name -> (restype, argtypes)
@@ -79,9 +80,10 @@ SIGNATURES = {
     "bf_scan_inside": (C.c_int, [_VP, C.c_int, _FP, _FP]),
     "bf_scan_intersects": (C.c_int, [_VP, C.c_int, _FP, _FP, C.POINTER(C.c_uint8)]),
     "bf_scan_nearest": (C.c_int, [_VP, C.c_int, _FP, _IP, _FP, _FP]),
+    "bf_scan_nearest_backward": (C.c_int, [_VP, C.c_int, _IP, _FP, _FP, _FP]),
     "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
-    "bf_batch_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP]),
-    "bf_extract_contours": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP]),
+    "bf_batch_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),
+    "bf_extract_contours": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),
     "bf_batch_mask_loss": (C.c_int, [_VP, C.POINTER(Hyper), _FP, _FP]),
     "bf_fit_displacement": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper)]),
     "bf_batch_get_displacement": (C.c_int, [_VP, _FP]),

@@ -284,3 +284,39 @@ extern "C" __global__ void __launch_bounds__(256) bf_intersect_kernel(ScanDev S,
         tmax[k] += tdel[k];
     }
 }
+
+
+// d(nearest point)/d(query), applied to an incoming gradient: thread per query.  The region the closest point lies in is read
+// off the barycentric coefficients the search returned (the per-triangle rule sets clamped coefficients to exact zeros): none
+// zero = the triangle's face, the closest point is the projection onto its plane, J = I - n n^T; one zero = the edge between the
+// other two corners, J = d d^T / |d|^2; two zeros = a corner, J = 0.  dpoints = J^T dnearest (J is symmetric).
+// (The reference's own backward, mesh_grid_kernel.cu:354-382 + the commented-out SurfaceNearest.backward of
+// utils/mesh_grid_searcher.py:17-49, was never finished - its kernel leaves the KKT inverse as a TODO and multiplies by the
+// un-inverted matrix - so this is the gradient it set out to compute, not a restatement of what it computes.)
+extern "C" __global__ void __launch_bounds__(256) bf_nearest_backward_kernel(ScanDev S, int n, const int *__restrict__ face_ids,
+                                                                            const float *__restrict__ bary, const float *__restrict__ dnearest,
+                                                                            float *__restrict__ dpoints) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int f = face_ids[i];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    if (f >= 0 && f < S.nf) {
+        const float *v[3] = {S.verts + (size_t)S.faces[f * 3] * 3, S.verts + (size_t)S.faces[f * 3 + 1] * 3, S.verts + (size_t)S.faces[f * 3 + 2] * 3};
+        const float b[3] = {bary[i * 3], bary[i * 3 + 1], bary[i * 3 + 2]};
+        const float d0 = dnearest[i * 3], d1 = dnearest[i * 3 + 1], d2 = dnearest[i * 3 + 2];
+        const int zeros = (b[0] == 0.f) + (b[1] == 0.f) + (b[2] == 0.f);
+        if (zeros == 0) {
+            const float ux = v[1][0] - v[0][0], uy = v[1][1] - v[0][1], uz = v[1][2] - v[0][2];
+            const float wx = v[2][0] - v[0][0], wy = v[2][1] - v[0][1], wz = v[2][2] - v[0][2];
+            const float nx = uy * wz - uz * wy, ny = uz * wx - ux * wz, nz = ux * wy - uy * wx, nn = nx * nx + ny * ny + nz * nz;
+            const float k = nn > 0.f ? (nx * d0 + ny * d1 + nz * d2) / nn : 0.f;
+            g0 = d0 - nx * k; g1 = d1 - ny * k; g2 = d2 - nz * k;
+        } else if (zeros == 1) {
+            const int z = b[0] == 0.f ? 0 : (b[1] == 0.f ? 1 : 2), j = (z + 1) % 3, k2 = (z + 2) % 3;
+            const float ex = v[k2][0] - v[j][0], ey = v[k2][1] - v[j][1], ez = v[k2][2] - v[j][2], ee = ex * ex + ey * ey + ez * ez;
+            const float k = ee > 0.f ? (ex * d0 + ey * d1 + ez * d2) / ee : 0.f;
+            g0 = ex * k; g1 = ey * k; g2 = ez * k;
+        }
+    }
+    dpoints[i * 3] = g0; dpoints[i * 3 + 1] = g1; dpoints[i * 3 + 2] = g2;
+}

@@ -216,7 +216,7 @@ __device__ int contour_follow(ContourPlanes &P, int x0, int y0, float *out, int 
 // exceeds cap: the caller retries with more room), count[n + m] = which half of xy[m][2][cap][2] holds its points (x, y).  planes_global: 3 * H * wpr words per mask,
 // or null when the planes fit the dynamic LDS given to the launch.
 extern "C" __global__ void __launch_bounds__(64)
-bf_contour_kernel(const unsigned char *__restrict__ masks, int H, int W, int cap, float *__restrict__ xy, int *__restrict__ count,
+bf_contour_kernel(const unsigned char *__restrict__ masks, int H, int W, int cap, int select, float *__restrict__ xy, int *__restrict__ count,
                   unsigned *planes_global) {
     extern __shared__ unsigned s_planes[];
     const int m = blockIdx.x, lane = threadIdx.x;
@@ -249,7 +249,7 @@ bf_contour_kernel(const unsigned char *__restrict__ masks, int H, int W, int cap
     // Outer-border starts are rare (one per component, plus the skipped ones next to holes), so the words are screened 64
     // at a time - lane l looks at word base + l - and only a word with a start is handled, serially.  A walk changes marks,
     // so the screen is repeated from the handled word on.  Points are written while walking, into the half of the slab that
-    // does not hold the longest border so far.
+    // does not hold the border kept so far.
     int best_len = 0, best_half = 0;
     float *slab = xy + (size_t)m * 2 * cap * 2;
     for (int base = 0; base < plane; base += 64) {
@@ -283,7 +283,9 @@ bf_contour_kernel(const unsigned char *__restrict__ masks, int H, int W, int cap
                 pos = b + 1;
                 if (inside) continue;                      // inside a hole of a traced component: not external
                 const int len = contour_follow(P, wi * 32 + b, y, slab + (size_t)(1 - best_half) * cap * 2, cap, true);
-                if (len > best_len) { best_len = len; best_half = 1 - best_half; }
+                // which external border is kept (bf_contour_select): the last one the scan meets (0), the first (1), the longest (2)
+                const bool keep = select == 0 ? true : (select == 1 ? best_len == 0 : len > best_len);
+                if (keep) { best_len = len; best_half = 1 - best_half; }
                 inside = !((P.ng[w] >> b) & 1u);           // the start pixel carries a mark now
             }
         }

@@ -18,8 +18,9 @@ extern "C" __global__ void bf_grid_pack_kernel(ScanDev, const int *, int *, floa
 extern "C" __global__ void bf_face_normal_kernel(const float *, const int *, int, float *);
 extern "C" __global__ void bf_inside_mesh_kernel(ScanDev, const float *, int, float *);
 extern "C" __global__ void bf_intersect_kernel(ScanDev, const float *, const float *, int, unsigned char *);
+extern "C" __global__ void bf_nearest_backward_kernel(ScanDev, int, const int *, const float *, const float *, float *);
 extern "C" __global__ void bf_transpose_kernel(const float *, int, int, float *);
-extern "C" __global__ void bf_contour_kernel(const unsigned char *, int, int, int, float *, int *, unsigned *);
+extern "C" __global__ void bf_contour_kernel(const unsigned char *, int, int, int, int, float *, int *, unsigned *);
 extern "C" __global__ void bf_kp_contour_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
                                                 const float *, float *, float *, float *, MaskIO, const float *, int *, float *, float *,
                                                 MeshTab, const float *, const float *);
@@ -177,6 +178,24 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
     if (face_ids) HIP_TRY(hipMemcpy(face_ids, d_f.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
     if (nearest) HIP_TRY(hipMemcpy(nearest, d_c.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (bary) HIP_TRY(hipMemcpy(bary, d_b.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+// SurfaceNearest.backward with respect to the query points (utils/mesh_grid_searcher.py:17-49, unfinished in the reference):
+// dpoints = (d nearest / d points)^T dnearest for the faces / coefficients bf_scan_nearest returned
+int bf_scan_nearest_backward(bf_scan *s, int n, const int32_t *face_ids, const float *bary, const float *dnearest, float *dpoints) {
+    if (!s || n <= 0 || !face_ids || !bary || !dnearest || !dpoints) return fail(BF_ERR_INVALID, "bf_scan_nearest_backward: bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf<int> d_f;
+    DevBuf<float> d_b, d_g, d_o;
+    HIP_TRY(d_f.upload(std::vector<int>(face_ids, face_ids + n)));
+    HIP_TRY(d_b.upload(std::vector<float>(bary, bary + (size_t)n * 3)));
+    HIP_TRY(d_g.upload(std::vector<float>(dnearest, dnearest + (size_t)n * 3)));
+    HIP_TRY(d_o.alloc((size_t)n * 3));
+    hipLaunchKernelGGL(bf_nearest_backward_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, s->dev, n, (const int *)d_f.p, (const float *)d_b.p,
+                       (const float *)d_g.p, d_o.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(dpoints, d_o.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     return BF_OK;
 }
 
@@ -427,7 +446,7 @@ int bf_model_forward(bf_model *m, int n, const float *params, float *vertices, f
 // Contours of n binary masks on the device (bf_contour_kernel).  d_bin[n][H][W] -> counts (host), d_xy[n][2][cap][2] (device slab;
 // half[i] says which half holds mask i's contour).
 // The slab is grown and the kernel re-run when a contour is longer than the first guess.
-static int contours_on_device(const unsigned char *d_bin, int n, int H, int W, std::vector<int> &counts, std::vector<int> &half,
+static int contours_on_device(const unsigned char *d_bin, int n, int H, int W, int select, std::vector<int> &counts, std::vector<int> &half,
                               DevBuf<float> &d_xy, int &cap) {
     const int wpr = (W + 31) / 32;
     const size_t plane_bytes = (size_t)3 * H * wpr * sizeof(unsigned);
@@ -443,7 +462,7 @@ static int contours_on_device(const unsigned char *d_bin, int n, int H, int W, s
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (d_xy.p) { (void)hipFree(d_xy.p); d_xy.p = nullptr; }
         HIP_TRY(d_xy.alloc((size_t)n * 2 * cap * 2));
-        hipLaunchKernelGGL(bf_contour_kernel, dim3(n), dim3(64), in_lds ? plane_bytes : 0, 0, d_bin, H, W, cap, d_xy.p, d_cnt.p,
+        hipLaunchKernelGGL(bf_contour_kernel, dim3(n), dim3(64), in_lds ? plane_bytes : 0, 0, d_bin, H, W, cap, select, d_xy.p, d_cnt.p,
                            in_lds ? (unsigned *)nullptr : planes.p);
         HIP_TRY(hipGetLastError());
         std::vector<int> both(2 * (size_t)n);
@@ -460,8 +479,8 @@ static int contours_on_device(const unsigned char *d_bin, int n, int H, int W, s
 // extract_countours (smplify/loss.py:73-83): masks[n][H][W] uint8, non-zero = foreground (the reference passes
 // (mask > 128) * 255) -> counts[n] and, when xy != NULL, the contours' (x, y) points concatenated (sum(counts) pairs,
 // which the caller learns from a first call with xy == NULL).
-int bf_extract_contours(int device, int n, int H, int W, const uint8_t *masks, int32_t *counts, float *xy) {
-    if (n <= 0 || H <= 0 || W <= 0 || !masks || !counts) return fail(BF_ERR_INVALID, "bf_extract_contours: bad argument");
+int bf_extract_contours(int device, int n, int H, int W, const uint8_t *masks, int32_t *counts, float *xy, int select) {
+    if (n <= 0 || H <= 0 || W <= 0 || !masks || !counts || select < 0 || select > 2) return fail(BF_ERR_INVALID, "bf_extract_contours: bad argument");
     if (bf_device_count() <= device || device < 0) return fail(BF_ERR_NO_DEVICE, "bf_extract_contours: no such HIP device");
     HIP_TRY(hipSetDevice(device));
     DevBuf<unsigned char> d_bin;
@@ -469,7 +488,7 @@ int bf_extract_contours(int device, int n, int H, int W, const uint8_t *masks, i
     std::vector<int> cnt, half;
     DevBuf<float> d_xy;
     int cap = 0;
-    int rc = contours_on_device(d_bin.p, n, H, W, cnt, half, d_xy, cap);
+    int rc = contours_on_device(d_bin.p, n, H, W, select, cnt, half, d_xy, cap);
     if (rc) return rc;
     size_t o = 0;
     for (int i = 0; i < n; ++i) {
@@ -481,8 +500,8 @@ int bf_extract_contours(int device, int n, int H, int W, const uint8_t *masks, i
 }
 
 int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
-                       const int32_t *contour_count, const float *contour_xy) {
-    if (!b) return fail(BF_ERR_INVALID, "bf_batch_set_masks: null batch");
+                       const int32_t *contour_count, const float *contour_xy, int contour_select) {
+    if (!b || contour_select < 0 || contour_select > 2) return fail(BF_ERR_INVALID, "bf_batch_set_masks: null batch / bad contour_select");
     HIP_TRY(hipSetDevice(b->m->device));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (n_masks <= 0 || !masks) { b->has_masks = false; return BF_OK; }
@@ -499,7 +518,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     DevBuf<float> slab;                       // contours found on the device (contour_count == NULL): [F*M][cap][2]
     int cap = 0;
     if (contour_count) count.assign(contour_count, contour_count + (size_t)F * n_masks);
-    else { int rc = contours_on_device(b->mk_masks.p, F * n_masks, H, W, count, half, slab, cap); if (rc) return rc; }
+    else { int rc = contours_on_device(b->mk_masks.p, F * n_masks, H, W, contour_select, count, half, slab, cap); if (rc) return rc; }
     int total = 0, cmax = 1;
     for (size_t i = 0; i < count.size(); ++i) {
         if (count[i] < 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: negative contour count");

@@ -194,6 +194,18 @@ class Scan:
         return pts, ids, bary
 
 
+    def nearest_points_backward(self, face_ids, bary, dnearest):
+        """dL/d(query points) from dL/d(nearest points): SurfaceNearest.backward w.r.t. its first argument (point-to-plane
+        where the closest point lies on a face, along the edge on an edge, zero at a corner)"""
+        ids = _i32(face_ids)
+        b = _f32(bary, (len(ids), 3))
+        g = _f32(dnearest, (len(ids), 3))
+        out = np.empty((len(ids), 3), np.float32)
+        _lib.check(self._lib.bf_scan_nearest_backward(self._h, len(ids), _lib.iptr(ids), _lib.fptr(b), _lib.fptr(g), _lib.fptr(out)),
+                   "bf_scan_nearest_backward")
+        return out
+
+
 def make_hyper(**kw):
     h = _lib.Hyper()
     _lib.load().bf_hyper_default(C.byref(h))
@@ -252,25 +264,26 @@ class FrameBatch:
         _lib.check(self._lib.bf_batch_set_scans(self._h, arr), "bf_batch_set_scans")
         self._scans = list(scans)          # keep them alive
 
-    def set_masks(self, masks, view_index, contours=None):
+    def set_masks(self, masks, view_index, contours=None, contour_select=_lib.CONTOUR_OPENCV_FIRST):
         """masks uint8[F,M,H,W] as loaded; view_index[M]; contours: F lists of M arrays [C,2] (x, y), or None to have them
-        extracted from the masks on the device (use_mask=True, smplify.py:138-144)"""
+        extracted from the masks on the device (use_mask=True, smplify.py:138-144); contour_select: which external border of a
+        mask with several components is kept then (include/bodyfit.h, BF_CONTOUR_*)"""
         masks = np.ascontiguousarray(masks, dtype=np.uint8)
         F, M, H, W = masks.shape
         assert F == self.F
         vi = _i32(view_index)
         mp = masks.ctypes.data_as(C.POINTER(C.c_uint8))
         if contours is None:
-            _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, mp, None, None), "bf_batch_set_masks")
+            _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, mp, None, None, int(contour_select)), "bf_batch_set_masks")
             return
         counts = _i32([[len(c) for c in per_frame] for per_frame in contours]).reshape(-1)
         flat = [np.asarray(c, np.float32).reshape(-1, 2) for per_frame in contours for c in per_frame]
         xy = _f32(np.concatenate(flat, 0)) if sum(len(c) for c in flat) else np.zeros((1, 2), np.float32)
-        _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, mp, _lib.iptr(counts), _lib.fptr(xy)), "bf_batch_set_masks")
+        _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, mp, _lib.iptr(counts), _lib.fptr(xy), 0), "bf_batch_set_masks")
 
     def clear_masks(self):
         """detach the silhouettes (use_mask=False for the next fit)"""
-        _lib.check(self._lib.bf_batch_set_masks(self._h, 0, None, 0, 0, None, None, None), "bf_batch_set_masks")
+        _lib.check(self._lib.bf_batch_set_masks(self._h, 0, None, 0, 0, None, None, None, 0), "bf_batch_set_masks")
 
     def mask_loss(self, hyper=None):
         loss = np.empty(self.F, np.float32)

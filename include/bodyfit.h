@@ -199,6 +199,11 @@ int bf_scan_grid_lists(const bf_scan *s, int32_t *tri_num, int32_t *tri_idx, int
 /* MeshGridSearcher.nearest_points / search_nearest_point (mesh_grid.cpp:54-72): points[n,3] ->
  * face_ids[n] int32, nearest[n,3], bary[n,3] (any output may be NULL) */
 int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, float *nearest, float *bary);
+/* SurfaceNearest.backward with respect to the query points (utils/mesh_grid_searcher.py:17-49; search_nearest_point_backward,
+ * mesh_grid.cpp:120-128, mesh_grid_kernel.cu:354-382 - left unfinished in the reference: its kernel never inverts the KKT matrix).
+ * face_ids[n], bary[n,3] as bf_scan_nearest returned them, dnearest[n,3] = dL/d(nearest point) -> dpoints[n,3] = dL/d(query):
+ * the projection onto the plane (I - n n^T), the edge (d d^T / |d|^2) or the corner (0) the closest point lies on. */
+int bf_scan_nearest_backward(bf_scan *s, int n, const int32_t *face_ids, const float *bary, const float *dnearest, float *dpoints);
 /* MeshGridSearcher.inside_mesh / search_inside_mesh (utils/mesh_grid_searcher.py:86-91, mesh_grid.cpp:74-90,
  * mesh_grid_kernel.cu:569-641): signs[n] = +1 inside (odd number of triangles crossed by the axis ray towards the
  * nearest grid wall), -1 outside or off the grid. */
@@ -217,12 +222,20 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans);
  * concatenated as (x, y) pairs in contour_xy (what extract_countours returns, loss.py:73-83).  bf_fit then
  * adds 5 * multview_mask_loss for iterations i > n_iters // 3 (smplify.py:197-199,210).  n_masks = 0 detaches. */
 /* contour_count == NULL (and contour_xy == NULL): the contours are extracted from the masks on the device - Suzuki-Abe
- * border following = cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_NONE), the longest external border per mask. */
+ * border following = cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_NONE) - and ONE external border per mask is kept, chosen by
+ * contour_select (ignored when the caller passes contours).  The reference keeps
+ * `contour[np.argmax([a.shape[1] for a in contour])]` (loss.py:80); every OpenCV contour has shape [C,1,2], so the argmax
+ * runs over ones and returns OpenCV's FIRST listed contour.  OpenCV lists external borders in the reverse of the order its
+ * raster scan meets them (each new contour is inserted as the first child of the frame), so that is the border whose start
+ * pixel comes LAST in raster order: BF_CONTOUR_OPENCV_FIRST, the default.  For a one-component silhouette all three coincide. */
+#define BF_CONTOUR_OPENCV_FIRST 0   /* the last external border the raster scan meets = contours[0] of OpenCV = what loss.py:80 keeps */
+#define BF_CONTOUR_RASTER_FIRST 1   /* the first external border the raster scan meets */
+#define BF_CONTOUR_LONGEST      2   /* the longest external border (first on ties): the evident intent of loss.py:80 */
 int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
-                       const int32_t *contour_count, const float *contour_xy);
+                       const int32_t *contour_count, const float *contour_xy, int contour_select);
 /* extract_countours (smplify/loss.py:73-83) on its own: masks[n,H,W] uint8 (non-zero = foreground) -> counts[n] and,
  * when xy != NULL, the (x, y) points of the n contours concatenated (sum(counts) pairs; call with xy == NULL first). */
-int bf_extract_contours(int device, int n, int H, int W, const uint8_t *masks, int32_t *counts, float *xy);
+int bf_extract_contours(int device, int n, int H, int W, const uint8_t *masks, int32_t *counts, float *xy, int select);
 /* one evaluation of multview_mask_loss (loss.py:85-130) at the current parameters: loss[F] and its gradient
  * w.r.t. body_vertices, dverts[F,NV,3] (either may be NULL) */
 int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *dverts);

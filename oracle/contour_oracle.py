@@ -18,9 +18,11 @@ CVGIP 30 (1985), Algorithm 1, which OpenCV's contour scanner implements - in pla
     (we are between the left and the right edge of a traced border); hole borders are not followed at all.
 
 Which contour the reference keeps: `contour[np.argmax([a.shape[1] for a in contour])]` - every OpenCV contour has
-shape [C, 1, 2], so the argmax is over ones and the expression returns OpenCV's FIRST contour, although the
-evident intent (and SURVEY.md's reading) is "the longest".  For a silhouette with one component - every GeneBody
-mask - the two coincide.  The build keeps the LONGEST external border (the first one on ties).
+shape [C, 1, 2], so the argmax is over ones and the expression returns OpenCV's FIRST listed contour, although the
+evident intent (and SURVEY.md's reading) is "the longest".  OpenCV's list runs against the raster order (a new contour
+becomes the first child of the frame node), so that is the external border whose start pixel comes LAST in the scan:
+`extract_contour(mask)` returns it by default; "raster_first" and "longest" are the alternatives the library also offers.
+For a silhouette with one component - every GeneBody mask - all three coincide.
 
 PARITY PINNING: unpinned against OpenCV itself (absent).  Pinned by known answers that are common knowledge of
 what findContours returns (a single pixel -> 1 point; an n-pixel line -> 2n - 2 points; a filled rectangle -> its
@@ -99,11 +101,19 @@ def find_external_contours(mask):
     return out
 
 
-def extract_contour(mask):
-    """The contour the build feeds to the silhouette loss: the longest external border, float32[C, 2] of (x, y)."""
+def extract_contour(mask, select="opencv_first"):
+    """The ONE contour the silhouette loss gets, float32[C, 2] of (x, y).  select: "opencv_first" = what loss.py:80 keeps
+    (`contour[argmax(ones)]` = OpenCV's first listed contour; OpenCV inserts every new contour as the FIRST child of the frame
+    node - cvInsertNodeIntoTree - so its list runs against the raster order and contours[0] is the border met LAST),
+    "raster_first" = the first border the raster scan meets, "longest" = the longest (first on ties)."""
     cs = find_external_contours(mask)
     if not cs:
         return np.zeros((0, 2), np.float32)
+    if select == "opencv_first":
+        return cs[-1].astype(np.float32)
+    if select == "raster_first":
+        return cs[0].astype(np.float32)
+    assert select == "longest"
     return cs[int(np.argmax([len(c) for c in cs]))].astype(np.float32)
 
 

@@ -299,3 +299,28 @@ def normal_laplacian_smoothness(norms, faces):
     na, nb, nc = norms[faces[:, 0]], norms[faces[:, 1]], norms[faces[:, 2]]
     mse = lambda x, y: torch.sum((x - y) ** 2, dim=-1)   # noqa: E731
     return torch.mean(mse(na, nb) + mse(nc, na) + mse(nb, nc))
+
+
+def nearest_backward(verts, faces, points, face_ids, bary, dnearest):
+    """dL/d(points) through the closest point, by torch.autograd (float64) of the closed form of the region each answer lies
+    in - read off the zeros of `bary` like the device kernel does: face -> projection onto the plane, edge -> onto the edge's
+    line, corner -> constant.  (What SurfaceNearest.backward, utils/mesh_grid_searcher.py:17-49, set out to compute; the
+    reference's kernel for it is unfinished, mesh_grid_kernel.cu:371-372.)"""
+    V = torch.as_tensor(np.asarray(verts, np.float64))
+    tri = V[torch.as_tensor(np.asarray(faces, np.int64))[torch.as_tensor(np.asarray(face_ids, np.int64))]]      # [Q,3,3]
+    p = torch.tensor(np.asarray(points, np.float64), requires_grad=True)
+    b = np.asarray(bary)
+    zeros = (b == 0).sum(1)
+    a, e1, e2 = tri[:, 0], tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    n = torch.cross(e1, e2, dim=1)
+    c_face = p - n * ((p - a) * n).sum(1, keepdim=True) / (n * n).sum(1, keepdim=True)
+    z = np.where(b[:, 0] == 0, 0, np.where(b[:, 1] == 0, 1, 2))
+    ar = torch.arange(len(b))
+    vj, vk = tri[ar, torch.as_tensor((z + 1) % 3)], tri[ar, torch.as_tensor((z + 2) % 3)]
+    d = vk - vj
+    c_edge = vj + d * ((p - vj) * d).sum(1, keepdim=True) / (d * d).sum(1, keepdim=True)
+    c_corner = (torch.as_tensor(b, dtype=torch.float64)[:, :, None] * tri).sum(1)
+    zt = torch.as_tensor(zeros)[:, None]
+    c = torch.where(zt == 0, c_face, torch.where(zt == 1, c_edge, c_corner))
+    (c * torch.as_tensor(np.asarray(dnearest, np.float64))).sum().backward()
+    return p.grad.numpy()

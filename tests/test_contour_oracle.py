@@ -45,7 +45,30 @@ def test_hole_and_nested_component():
                 ".........."])
     c = CO.find_external_contours(two)
     assert [a[0].tolist() for a in c] == [[1, 1], [7, 1]]    # discovery order = raster order of the start pixels
-    assert CO.extract_contour(two).shape == (4, 2)           # the longest; on ties the first (the box: 4 points, the plus sign: 4 rim points)
+    # which ONE the loss gets (loss.py:80 keeps OpenCV's first listed contour = the border met LAST by the scan)
+    assert CO.extract_contour(two)[0].tolist() == [7, 1] and CO.extract_contour(two, "raster_first")[0].tolist() == [1, 1]
+    assert CO.extract_contour(two, "longest").shape == (4, 2) and CO.extract_contour(two, "longest")[0].tolist() == [1, 1]   # a tie: the first
+
+
+def test_concave_shape_in_opencv_order():
+    """hand-computed: the point sequence cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_NONE) produces for a small concave shape.
+    A "U" (two 3-pixel prongs joined by a 5-pixel base):
+
+        . . . . . . .        Border following starts at the first foreground pixel of the raster scan, (1, 1), whose left
+        . # . . . # .        neighbour is background.  OpenCV walks an outer border with the inside on its left hand: from
+        . # . . . # .        (1,1) down the left prong to (1,3), along the base to (5,3), up the right prong to (5,1), back
+        . # # # # # .        down it (a one-pixel-wide prong is passed twice) to (5,2), then along the top of the base -
+        . . . . . . .        (4,3), (3,3), (2,3): the base is one pixel thick, its pixels are passed twice too - and up the
+                             left prong through (1,2) back to the start."""
+    u = _img([".......", ".#...#.", ".#...#.", ".#####.", "......."])
+    want = [[1, 1], [1, 2], [1, 3], [2, 3], [3, 3], [4, 3], [5, 3], [5, 2], [5, 1], [5, 2], [4, 3], [3, 3], [2, 3], [1, 2]]
+    c = CO.find_external_contours(u)
+    assert len(c) == 1 and c[0].tolist() == want
+    # the same shape two pixels thick: every rim pixel once, counter-clockwise on the screen (y down) from the top-left pixel
+    v = _img(["..........", ".##....##.", ".##....##.", ".########.", ".########.", ".........."])
+    want = ([[1, 1], [1, 2], [1, 3], [1, 4]] + [[x, 4] for x in range(2, 9)] + [[8, 3], [8, 2], [8, 1], [7, 1], [7, 2]] +
+            [[6, 3], [5, 3], [4, 3], [3, 3]] + [[2, 2], [2, 1]])
+    assert CO.find_external_contours(v)[0].tolist() == want
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])

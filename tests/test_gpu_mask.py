@@ -151,11 +151,45 @@ def test_device_contours_equal_border_following_oracle(shape):
     masks[2, :, :] = False
     masks[2, 3:9, 4:12] = True; masks[2, 5:7, 6:10] = False; masks[2, 5, 7] = True     # box with a hole and an island in it
     masks[2, 0, 0] = masks[2, -1, -1] = True                                            # single pixels in the corners
-    got = device_contours(masks)
-    for m, c in zip(masks, got):
-        want = CO.extract_contour(m)
-        np.testing.assert_array_equal(c, want)
-    assert len(got[3]) == 0 and len(got[2]) == 2 * (6 + 8) - 4 and len(got[0]) > 50
+    from bodyfitting_amd import _lib
+    for select, name in ((_lib.CONTOUR_OPENCV_FIRST, "opencv_first"), (_lib.CONTOUR_RASTER_FIRST, "raster_first"), (_lib.CONTOUR_LONGEST, "longest")):
+        got = device_contours(masks, select=select)
+        for m, c in zip(masks, got):
+            np.testing.assert_array_equal(c, CO.extract_contour(m, name), err_msg=name)
+        assert len(got[3]) == 0 and len(got[0]) > 0
+        # mask 2 = single pixels in two corners + a box with a hole and an island: three external borders
+        want_len = {"opencv_first": 1, "raster_first": 1, "longest": 2 * (6 + 8) - 4}[name]
+        assert len(got[2]) == want_len
+        if name != "longest":
+            assert got[2][0].tolist() == ([shape[1] - 1, shape[0] - 1] if name == "opencv_first" else [0, 0])
+
+
+def test_two_component_mask_feeds_the_loss_the_border_the_reference_keeps(dev_model, smpl_model):
+    """a silhouette with a second, smaller component further down the image: loss.py:80 keeps OpenCV's first listed contour,
+    which is the border met LAST by the raster scan - here the small blob, not the body.  bf_batch_set_masks(contour_select)
+    follows that by default and offers the other two readings; each equals passing that contour explicitly."""
+    from bodyfitting_amd import _lib
+    from bodyfitting_amd.contours import extract_contours as device_contours
+    prob = S.make_problem(smpl_model, frame=0, n_views=8, mask_frames=MASK_FRAMES)
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
+    masks = np.array(prob["masks"])[None].copy()
+    masks[:, :, 500:506, 20:30] = 255                                          # a 6 x 10 blob near the bottom-left corner
+    view_index = [prob["use_frames"].index(f) for f in prob["mask_frames"]]
+    losses = {}
+    for select in (_lib.CONTOUR_OPENCV_FIRST, _lib.CONTOUR_RASTER_FIRST, _lib.CONTOUR_LONGEST):
+        out = []
+        for contours in (None, [device_contours(masks[0] > 128, select=select)]):
+            b = N.FrameBatch(dev_model, 1, c2w.shape[1])
+            b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+            b.set_masks(masks, view_index, contours, contour_select=select)
+            out.append(b.mask_loss())
+            b.close()
+        np.testing.assert_array_equal(out[0][0], out[1][0])
+        np.testing.assert_array_equal(out[0][1], out[1][1])
+        losses[select] = float(out[0][0][0])
+    first = device_contours(masks[0] > 128, select=_lib.CONTOUR_OPENCV_FIRST)
+    assert all(len(c) == 2 * (6 + 10) - 4 for c in first)                       # the blob's rim: that is what the reference would fit to
+    assert losses[_lib.CONTOUR_RASTER_FIRST] == losses[_lib.CONTOUR_LONGEST] != losses[_lib.CONTOUR_OPENCV_FIRST]
 
 
 def test_set_masks_extracts_the_contours_itself(dev_model, smpl_model):

@@ -184,6 +184,35 @@ def test_nearest_at_config5_size_against_bruteforce():
     scan.close()
 
 
+def test_nearest_points_backward_matches_autograd(small):
+    """SurfaceNearest.backward w.r.t. the query points (unfinished in the reference): point-to-plane on faces, along the edge on
+    edges, zero at corners - against torch.autograd of the same closed forms, and against central differences of the search"""
+    model, _ = small
+    _, sv, sf = S.make_scan_problem(model, 1)
+    rng = np.random.default_rng(3)
+    q = (sv[rng.integers(0, len(sv), 600)] + rng.normal(0, 0.03, (600, 3))).astype(np.float32)
+    scan = N.Scan(sv, sf)
+    pts, ids, bary = scan.nearest_points(q)
+    g = rng.normal(size=q.shape).astype(np.float32)
+    got = scan.nearest_points_backward(ids, bary, g)
+    want = MO.nearest_backward(sv, sf, q, ids, bary, g)
+    np.testing.assert_allclose(got, want, atol=2e-5 * np.abs(want).max())
+    zeros = (bary == 0).sum(1)
+    assert (zeros == 0).sum() > 50 and (zeros == 1).sum() > 50 and (zeros == 2).sum() > 5         # faces, edges and corners all occur
+    assert np.all(got[zeros == 2] == 0)
+    # the search itself, differenced: d(pts . g)/dq along a random direction, where the region does not change under the step
+    h, v = 1e-3, rng.normal(size=q.shape)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    pp, ip, bp = scan.nearest_points((q + h * v).astype(np.float32))
+    pm, im, bm = scan.nearest_points((q - h * v).astype(np.float32))
+    same = (ip == ids) & (im == ids) & np.all((bp == 0) == (bary == 0), 1) & np.all((bm == 0) == (bary == 0), 1)
+    fd = ((pp - pm).astype(np.float64) * g).sum(1) / (2 * h)
+    an = (got.astype(np.float64) * v).sum(1)
+    assert same.sum() > 200
+    np.testing.assert_allclose(an[same], fd[same], atol=2e-2 * np.abs(fd[same]).max())
+    scan.close()
+
+
 def test_scan_fit_matches_reference_golden(small):
     """smplify.py loop with use_mesh=True: 11 keypoint-only iterations, then 19 with the point-cloud
     loss, against the imported reference (stand-in searcher)."""
