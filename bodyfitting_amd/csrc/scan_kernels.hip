@@ -33,7 +33,10 @@ __device__ __forceinline__ float closest_rule(const float *p0, const float *p1, 
     const bool ok = det > 1e-12f * a11 * a22 && det > 0.f;
     int i;
     if (ok) {
-        const float u = (b1 * a22 - b2 * a12) / det, v = (a11 * b2 - a12 * b1) / det;
+        // (v_rcp_f32, 1 ulp, instead of two IEEE divisions: ~20 of the rule's ~110 instructions; the barycentrics are fp32-noisy
+        //  at that level anyway - the in-plane solve loses digits with the triangle's aspect ratio)
+        const float idet = __builtin_amdgcn_rcpf(det);
+        const float u = (b1 * a22 - b2 * a12) * idet, v = (a11 * b2 - a12 * b1) * idet;
         const float c0 = 1.f - u - v;
         i = c0 > u ? 1 : 0;
         const float ci = i ? u : c0;
@@ -58,7 +61,7 @@ __device__ __forceinline__ float closest_rule(const float *p0, const float *p1, 
     const float pkx = i0 ? p2[0] : (i1 ? p0[0] : p1[0]), pky = i0 ? p2[1] : (i1 ? p0[1] : p1[1]), pkz = i0 ? p2[2] : (i1 ? p0[2] : p1[2]);
     const float dx = pkx - pjx, dy = pky - pjy, dz = pkz - pjz;
     const float dd = dx * dx + dy * dy + dz * dz;
-    const float t = dd > 0.f ? -(pjx * dx + pjy * dy + pjz * dz) / dd : 0.5f;
+    const float t = dd > 0.f ? -(pjx * dx + pjy * dy + pjz * dz) * __builtin_amdgcn_rcpf(dd) : 0.5f;
     float cj = 1.f - t, ck = t;
     if (cj < 0.f) { cj = 0.f; ck = 1.f; }                 // same test order as the reference (:89-98)
     else if (ck < 0.f) { cj = 1.f; ck = 0.f; }
@@ -146,18 +149,26 @@ bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ p
                 for (int i = lane; i < n0; i += 64) test_record(s0 + i);
             }
         } else {
-            int total = 0;
-            for (unsigned long long m = cells; m; m &= m - 1) total += __builtin_amdgcn_readlane(cnt, __ffsll((long long)m) - 1);
+            // up to six lists end to end: their bounds once, as wave-uniform values (base[c] = start - offset of list c), so that the
+            // entry -> record map of a pass is five compare / select steps instead of a readlane pair per cell and pass
+            int base[6], off[7];
+            off[0] = 0;
+            unsigned long long m = cells;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const int src = m ? __ffsll((long long)m) - 1 : 0;
+                const int n0 = m ? __builtin_amdgcn_readlane(cnt, src) : 0;
+                base[c] = __builtin_amdgcn_readlane(st, src) - off[c];
+                off[c + 1] = off[c] + n0;
+                m &= m - 1;
+            }
+            const int total = off[6];
             for (int e0 = 0; e0 < total; e0 += 64) {
                 const int e = e0 + lane;
-                int rec = -1, off = 0;
-                for (unsigned long long m = cells; m; m &= m - 1) {      // which cell's list entry e falls into
-                    const int src = __ffsll((long long)m) - 1;
-                    const int s0 = __builtin_amdgcn_readlane(st, src), n0 = __builtin_amdgcn_readlane(cnt, src);
-                    rec = (e >= off && e < off + n0) ? s0 + (e - off) : rec;
-                    off += n0;
-                }
-                if (rec >= 0) test_record(rec);
+                int rec = e + base[0];
+#pragma unroll
+                for (int c = 1; c < 6; ++c) rec = e >= off[c] ? e + base[c] : rec;
+                if (e < total) test_record(rec);
             }
         }
         gbest = fminf(gbest, nn_wave_min_f(best));
