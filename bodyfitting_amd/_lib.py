@@ -114,6 +114,13 @@ SIGNATURES = {
     "bf_comm_barrier": (C.c_int, [_VP]),
     "bf_comm_allreduce": (C.c_int, [_VP, C.POINTER(C.c_double), C.c_int]),
     "bf_comm_gather_params": (C.c_int, [_VP, _VP, C.c_int, _FP]),
+    "bf_texfit_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _FP, C.c_int, C.POINTER(_VP)]),
+    "bf_texfit_destroy": (None, [_VP]),
+    "bf_texfit_set_mesh": (C.c_int, [_VP, C.c_int, C.c_int, _FP, C.c_int, _IP, _FP]),
+    "bf_texfit_render": (C.c_int, [_VP, C.c_int, _FP, _FP, _FP, C.c_float, _FP]),
+    "bf_texfit_step": (C.c_int, [_VP, _FP, _FP, _FP, C.c_float, C.c_float, C.POINTER(C.c_double)]),
+    "bf_texfit_loss_grad": (C.c_int, [_VP, _FP, _FP, _FP, C.c_float, C.POINTER(C.c_double), _FP]),
+    "bf_texfit_get_textures": (C.c_int, [_VP, _FP]),
     "bf_batch_debug_dump": (C.c_int, [_VP, _FP, C.c_int]),
     "bf_batch_debug_disp_moment": (C.c_int, [_VP, _FP]),
 }

@@ -37,6 +37,7 @@ struct DevBuf {
         if (e != hipSuccess) return e;
         return h.empty() ? hipSuccess : hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     }
+    void release() { if (p && !view) (void)hipFree(p); p = nullptr; n = 0; view = false; }
     ~DevBuf() { if (p && !view) (void)hipFree(p); }
 };
 

@@ -1,0 +1,210 @@
+// Host side of the texture-fitting loop (reference smplify/texture_fitting.py:240-275; kernels: tex_kernels.hip).
+#include "bf_host.h"
+
+struct TexView { float R[9], t[3], K[9], orig; };
+extern "C" __global__ void bf_tex_project_kernel(int, const float *, TexView, float *);
+extern "C" __global__ void bf_tex_face_kernel(int, const int *, const float *, int, int, float *, int *, int *, int *, int);
+extern "C" __global__ void bf_tex_raster_kernel(int, int, const float *, const int *, const int *, const float *, int, float, float, float, float,
+                                                float, float *, float *);
+extern "C" __global__ void bf_tex_compose_kernel(int, int, const float *, float *);
+extern "C" __global__ void bf_tex_loss_kernel(int, const float *, const float *, float *, double *);
+extern "C" __global__ void bf_tex_backward_kernel(int, int, int, const float *, const float *, int, const float *, float *);
+extern "C" __global__ void bf_tex_adam_kernel(size_t, float *, float *, float *, float *, float, float, float, float, float, float);
+extern "C" __global__ void bf_grid_scan_kernel(int *, int *, int);
+
+#define BF_TEX_TILE 8
+
+struct bf_texmesh {
+    int nv = 0, nf = 0;
+    DevBuf<float> verts, tex, pv, frec, pix, rgb, m, v, grad;
+    DevBuf<int> faces, tile_start, cursor, tile_list;
+    bool adam = false;
+    void release() {
+        verts.release(); tex.release(); pv.release(); frec.release(); pix.release(); rgb.release(); m.release(); v.release(); grad.release();
+        faces.release(); tile_start.release(); cursor.release(); tile_list.release();
+        nv = nf = 0; adam = false;
+    }
+};
+
+struct bf_texfit {
+    int device = 0, out = 0, is = 0, tiles = 0, ts = 0, aa = 1, steps = 0;
+    float near = 0.f, far = 100.f, bg[3] = {1.f, 1.f, 1.f};
+    hipStream_t stream = nullptr;
+    bf_texmesh mesh[2];
+    DevBuf<float> image[2], grad_image;
+    DevBuf<double> partial;
+};
+
+static TexView make_view(const float *R, const float *t, const float *K, float orig) {
+    TexView V;
+    std::memcpy(V.R, R, sizeof V.R); std::memcpy(V.t, t, sizeof V.t); std::memcpy(V.K, K, sizeof V.K);
+    V.orig = orig;
+    return V;
+}
+
+// renders mesh `which` from the view into image[which] (device); leaves pix / frec of the mesh for the backward pass
+static int tex_render(bf_texfit *x, int which, const TexView &V) {
+    bf_texmesh &M = x->mesh[which];
+    if (!M.nf) return fail(BF_ERR_INVALID, "bf_texfit: no mesh set for this slot");
+    const int is = x->is, tiles = x->tiles, ntile = tiles * tiles;
+    hipLaunchKernelGGL(bf_tex_project_kernel, dim3((M.nv + 255) / 256), dim3(256), 0, x->stream, M.nv, (const float *)M.verts.p, V, M.pv.p);
+    HIP_TRY(hipMemsetAsync(M.tile_start.p, 0, (size_t)(ntile + 1) * sizeof(int), x->stream));
+    hipLaunchKernelGGL(bf_tex_face_kernel, dim3((M.nf + 255) / 256), dim3(256), 0, x->stream, M.nf, (const int *)M.faces.p, (const float *)M.pv.p,
+                       is, tiles, M.frec.p, M.tile_start.p, (int *)nullptr, (int *)nullptr, 0);
+    hipLaunchKernelGGL(bf_grid_scan_kernel, dim3(1), dim3(1024), 0, x->stream, M.tile_start.p, M.cursor.p, ntile + 1);
+    HIP_TRY(hipGetLastError());
+    int total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, M.tile_start.p + ntile, sizeof(int), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    if ((size_t)total > M.tile_list.n) {
+        M.tile_list.release();
+        HIP_TRY(M.tile_list.alloc((size_t)total + total / 2 + 1024));
+    }
+    hipLaunchKernelGGL(bf_tex_face_kernel, dim3((M.nf + 255) / 256), dim3(256), 0, x->stream, M.nf, (const int *)M.faces.p, (const float *)M.pv.p,
+                       is, tiles, M.frec.p, M.tile_start.p, M.cursor.p, M.tile_list.p, 1);
+    hipLaunchKernelGGL(bf_tex_raster_kernel, dim3((ntile + 3) / 4), dim3(256), 0, x->stream, is, tiles, (const float *)M.frec.p,
+                       (const int *)M.tile_start.p, (const int *)M.tile_list.p, (const float *)M.tex.p, x->ts, x->near, x->far, x->bg[0], x->bg[1],
+                       x->bg[2], M.pix.p, M.rgb.p);
+    hipLaunchKernelGGL(bf_tex_compose_kernel, dim3((3 * x->out * x->out + 255) / 256), dim3(256), 0, x->stream, x->out, x->aa,
+                       (const float *)M.rgb.p, x->image[which].p);
+    HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+// renders both meshes, the loss partials and the texture gradient of mesh 1 (accumulated into M.grad, which is zero between calls)
+static int tex_loss_backward(bf_texfit *x, const TexView &V) {
+    int rc = tex_render(x, 0, V);
+    if (!rc) rc = tex_render(x, 1, V);
+    if (rc) return rc;
+    bf_texmesh &M = x->mesh[1];
+    const int n = 3 * x->out * x->out, nb = (n + 255) / 256;
+    hipLaunchKernelGGL(bf_tex_loss_kernel, dim3(nb), dim3(256), 0, x->stream, n, (const float *)x->image[0].p, (const float *)x->image[1].p,
+                       x->grad_image.p, x->partial.p);
+    hipLaunchKernelGGL(bf_tex_backward_kernel, dim3((x->is * x->is + 255) / 256), dim3(256), 0, x->stream, x->is, x->out, x->aa,
+                       (const float *)M.pix.p, (const float *)M.frec.p, x->ts, (const float *)x->grad_image.p, M.grad.p);
+    HIP_TRY(hipGetLastError());
+    return BF_OK;
+}
+
+static int tex_read_loss(bf_texfit *x, double *loss) {
+    const int nb = (3 * x->out * x->out + 255) / 256;
+    std::vector<double> part(nb);
+    HIP_TRY(hipMemcpyAsync(part.data(), x->partial.p, nb * sizeof(double), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    double tot = 0.0;
+    for (double p : part) tot += p;
+    *loss = tot;
+    return BF_OK;
+}
+
+extern "C" {
+
+void bf_texfit_destroy(bf_texfit *x) {
+    if (!x) return;
+    (void)hipSetDevice(x->device);
+    if (x->stream) { (void)hipStreamSynchronize(x->stream); (void)hipStreamDestroy(x->stream); }
+    delete x;
+}
+
+int bf_texfit_create(int device, int image_size, int texture_size, float near, float far, const float *background, int anti_aliasing,
+                     bf_texfit **out) {
+    if (!out || image_size <= 0 || image_size > 4096 || texture_size < 2 || texture_size > 16) return fail(BF_ERR_INVALID, "bf_texfit_create: bad argument");
+    *out = nullptr;
+    if (device < 0 || device >= bf_device_count()) return fail(BF_ERR_NO_DEVICE, "bf_texfit_create: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    auto *x = new bf_texfit();
+    x->device = device; x->out = image_size; x->aa = anti_aliasing ? 1 : 0; x->is = image_size * (x->aa ? 2 : 1); x->ts = texture_size;
+    x->tiles = (x->is + BF_TEX_TILE - 1) / BF_TEX_TILE;
+    x->near = near; x->far = far;
+    if (background) std::memcpy(x->bg, background, sizeof x->bg);
+    const size_t n = (size_t)3 * image_size * image_size;
+    bool ok = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) == hipSuccess && x->image[0].alloc(n) == hipSuccess &&
+              x->image[1].alloc(n) == hipSuccess && x->grad_image.alloc(n) == hipSuccess && x->partial.alloc((n + 255) / 256) == hipSuccess;
+    if (!ok) { bf_texfit_destroy(x); return fail(BF_ERR_HIP, "bf_texfit_create: device allocation failed"); }
+    *out = x;
+    return BF_OK;
+}
+
+// which: 0 = the target (the textured scan), 1 = the mesh whose textures are fitted (SMPL+D).  textures[nf][ts][ts][ts][3]
+// (neural_renderer's per-face texture cubes, load_obj.py / load_textures).  Setting mesh 1 resets the Adam state.
+int bf_texfit_set_mesh(bf_texfit *x, int which, int n_verts, const float *verts, int n_faces, const int32_t *faces, const float *textures) {
+    if (!x || which < 0 || which > 1 || n_verts <= 0 || n_faces <= 0 || !verts || !faces || !textures)
+        return fail(BF_ERR_INVALID, "bf_texfit_set_mesh: bad argument");
+    for (int i = 0; i < n_faces * 3; ++i)
+        if (faces[i] < 0 || faces[i] >= n_verts) return fail(BF_ERR_INVALID, "bf_texfit_set_mesh: face index out of range");
+    HIP_TRY(hipSetDevice(x->device));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    bf_texmesh &M = x->mesh[which];
+    M.release();
+    M.nv = n_verts; M.nf = n_faces;
+    const size_t ntex = (size_t)n_faces * x->ts * x->ts * x->ts * 3, npx = (size_t)x->is * x->is, ntile = (size_t)x->tiles * x->tiles;
+    HIP_TRY(M.verts.upload(std::vector<float>(verts, verts + (size_t)n_verts * 3)));
+    HIP_TRY(M.faces.upload(std::vector<int>(faces, faces + (size_t)n_faces * 3)));
+    HIP_TRY(M.tex.upload(std::vector<float>(textures, textures + ntex)));
+    HIP_TRY(M.pv.alloc((size_t)n_verts * 3)); HIP_TRY(M.frec.alloc((size_t)n_faces * 18));
+    HIP_TRY(M.pix.alloc(npx * 5)); HIP_TRY(M.rgb.alloc(npx * 3));
+    HIP_TRY(M.tile_start.alloc(ntile + 1)); HIP_TRY(M.cursor.alloc(ntile + 1));
+    if (which == 1) {
+        HIP_TRY(M.m.alloc(ntex)); HIP_TRY(M.v.alloc(ntex)); HIP_TRY(M.grad.alloc(ntex));
+        HIP_TRY(hipMemset(M.m.p, 0, ntex * sizeof(float))); HIP_TRY(hipMemset(M.v.p, 0, ntex * sizeof(float)));
+        HIP_TRY(hipMemset(M.grad.p, 0, ntex * sizeof(float)));
+        M.adam = true;
+        x->steps = 0;
+    }
+    return BF_OK;
+}
+
+// Renderer.render_rgb (neural_renderer/renderer.py:174-232, camera_mode='projection', ambient light 1, fill_back=False):
+// R[9], t[3] world-to-camera, K[9], orig_size -> rgb[3][image_size][image_size] (host)
+int bf_texfit_render(bf_texfit *x, int which, const float *R, const float *t, const float *K, float orig_size, float *rgb) {
+    if (!x || which < 0 || which > 1 || !R || !t || !K || !rgb) return fail(BF_ERR_INVALID, "bf_texfit_render: bad argument");
+    HIP_TRY(hipSetDevice(x->device));
+    int rc = tex_render(x, which, make_view(R, t, K, orig_size));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(rgb, x->image[which].p, x->image[which].n * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    return BF_OK;
+}
+
+// One iteration of texture_fitting.py:262-270: render both meshes from the view, loss = sum |scan_img - smpl_img|, backward to
+// the fitted mesh's textures, one Adam step (lr; torch defaults otherwise).  *loss receives the loss of THIS view before the step.
+int bf_texfit_step(bf_texfit *x, const float *R, const float *t, const float *K, float orig_size, float lr, double *loss) {
+    if (!x || !R || !t || !K) return fail(BF_ERR_INVALID, "bf_texfit_step: bad argument");
+    if (!x->mesh[1].adam) return fail(BF_ERR_INVALID, "bf_texfit_step: set the mesh to fit (slot 1) first");
+    HIP_TRY(hipSetDevice(x->device));
+    int rc = tex_loss_backward(x, make_view(R, t, K, orig_size));
+    if (rc) return rc;
+    bf_texmesh &M = x->mesh[1];
+    x->steps += 1;
+    const double b1 = 0.9, b2 = 0.999;
+    const float step_size = (float)((double)lr / (1.0 - std::pow(b1, x->steps))), bc2_sqrt = (float)std::sqrt(1.0 - std::pow(b2, x->steps));
+    const size_t ntex = M.tex.n;
+    hipLaunchKernelGGL(bf_tex_adam_kernel, dim3((unsigned)((ntex + 255) / 256)), dim3(256), 0, x->stream, ntex, M.tex.p, M.m.p, M.v.p, M.grad.p,
+                       step_size, bc2_sqrt, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), 1e-8f);
+    HIP_TRY(hipGetLastError());
+    return loss ? tex_read_loss(x, loss) : BF_OK;
+}
+
+// loss and dL/dtextures of the fitted mesh from this view, no step (what `loss.backward()` leaves in smpl_t.grad, :266-269)
+int bf_texfit_loss_grad(bf_texfit *x, const float *R, const float *t, const float *K, float orig_size, double *loss, float *grad) {
+    if (!x || !R || !t || !K || !grad) return fail(BF_ERR_INVALID, "bf_texfit_loss_grad: bad argument");
+    if (!x->mesh[1].adam) return fail(BF_ERR_INVALID, "bf_texfit_loss_grad: set the mesh to fit (slot 1) first");
+    HIP_TRY(hipSetDevice(x->device));
+    int rc = tex_loss_backward(x, make_view(R, t, K, orig_size));
+    if (rc) return rc;
+    bf_texmesh &M = x->mesh[1];
+    HIP_TRY(hipMemcpyAsync(grad, M.grad.p, M.grad.n * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+    HIP_TRY(hipMemsetAsync(M.grad.p, 0, M.grad.n * sizeof(float), x->stream));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    return loss ? tex_read_loss(x, loss) : BF_OK;
+}
+
+int bf_texfit_get_textures(bf_texfit *x, float *textures) {
+    if (!x || !textures || !x->mesh[1].nf) return fail(BF_ERR_INVALID, "bf_texfit_get_textures: bad argument");
+    HIP_TRY(hipSetDevice(x->device));
+    HIP_TRY(hipStreamSynchronize(x->stream));
+    HIP_TRY(hipMemcpy(textures, x->mesh[1].tex.p, x->mesh[1].tex.n * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
+}  // extern "C"

@@ -293,6 +293,27 @@ int bf_comm_allreduce(bf_comm *c, double *value, int op);    /* in place over th
 /* the batch holds block `rank` of bf_shard_range(n_frames, world, .); params[n_frames][n_params] (host) on every rank */
 int bf_comm_gather_params(bf_comm *c, bf_batch *b, int n_frames, float *params);
 
+/* ---- texture fitting (smplify/texture_fitting.py:220-301) -------------------------------------------------------
+ * The loop of TextureFitting.__call__ (:240-275): per iteration both meshes are rendered from one view with neural_renderer
+ * (Renderer.render_rgb, camera_mode='projection', ambient light only, anti-aliasing by 2 x 2 super-sampling), the loss is
+ * sum |scan_img - smpl_img| and Adam steps the per-face texture cubes of the SMPL+D mesh; only the textures are differentiated.
+ * The rasteriser, texture sampling and backward_textures of thirdparty/neural_renderer (cuda/rasterize_cuda_kernel.cu:24-252,
+ * 498-540) are restated as HIP kernels; file formats (OBJ / MTL / texture images), the inpainting CNN and the UV-space texture
+ * image of :281-289 are out of scope. */
+typedef struct bf_texfit bf_texfit;
+int bf_texfit_create(int device, int image_size, int texture_size, float near, float far, const float *background /*[3] or NULL = white*/,
+                     int anti_aliasing, bf_texfit **out);
+void bf_texfit_destroy(bf_texfit *x);
+/* which: 0 = target (textured scan), 1 = the mesh whose textures are fitted; textures[n_faces][ts][ts][ts][3] */
+int bf_texfit_set_mesh(bf_texfit *x, int which, int n_verts, const float *verts, int n_faces, const int32_t *faces, const float *textures);
+/* Renderer.render_rgb: R[9], t[3] (world to camera), K[9], orig_size -> rgb[3][image_size][image_size] */
+int bf_texfit_render(bf_texfit *x, int which, const float *R, const float *t, const float *K, float orig_size, float *rgb);
+/* one iteration (:262-270) from this view; *loss (may be NULL) = the loss before the step */
+int bf_texfit_step(bf_texfit *x, const float *R, const float *t, const float *K, float orig_size, float lr, double *loss);
+/* loss and d loss / d textures [n_faces][ts][ts][ts][3] of the fitted mesh from this view, without a step */
+int bf_texfit_loss_grad(bf_texfit *x, const float *R, const float *t, const float *K, float orig_size, double *loss, float *grad);
+int bf_texfit_get_textures(bf_texfit *x, float *textures);
+
 /* Device time of the kernels of the last bf_fit on this batch, from HIP events on the batch's
  * stream: ms[0] = fit loop kernel(s), ms[1] = final full-mesh forward kernel, ms[2] = joints kernel +
  * result fetch, ms[3] = whole call.  (With BF_FIT_DENSE every iteration's mesh pass is inside ms[0].) */
