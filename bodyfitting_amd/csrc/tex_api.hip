@@ -8,11 +8,13 @@ extern "C" __global__ void bf_tex_raster_kernel(int, int, const float *, const i
                                                 float, float *, float *);
 extern "C" __global__ void bf_tex_compose_kernel(int, int, const float *, float *);
 extern "C" __global__ void bf_tex_loss_kernel(int, const float *, const float *, float *, double *);
-extern "C" __global__ void bf_tex_backward_kernel(int, int, int, const float *, const float *, int, const float *, float *);
-extern "C" __global__ void bf_tex_adam_kernel(size_t, float *, float *, float *, float *, float, float, float, float, float, float);
+extern "C" __global__ void bf_tex_backward_kernel(int, int, int, int, const float *, const float *, int, const float *, float *);
+extern "C" __global__ void bf_tex_backward_large_kernel(int, int, int, const float *, const float *, int, const float *, float *);
+extern "C" __global__ void bf_tex_adam_kernel(size_t, float *, float *, float *, const float *, float, float, float, float, float, float);
 extern "C" __global__ void bf_grid_scan_kernel(int *, int *, int);
 
 #define BF_TEX_TILE 8
+#define BF_TEX_REC 20
 
 struct bf_texmesh {
     int nv = 0, nf = 0;
@@ -71,7 +73,7 @@ static int tex_render(bf_texfit *x, int which, const TexView &V) {
     return BF_OK;
 }
 
-// renders both meshes, the loss partials and the texture gradient of mesh 1 (accumulated into M.grad, which is zero between calls)
+// renders both meshes, the loss partials and the texture gradient of mesh 1 (M.grad is fully rewritten)
 static int tex_loss_backward(bf_texfit *x, const TexView &V) {
     int rc = tex_render(x, 0, V);
     if (!rc) rc = tex_render(x, 1, V);
@@ -80,7 +82,9 @@ static int tex_loss_backward(bf_texfit *x, const TexView &V) {
     const int n = 3 * x->out * x->out, nb = (n + 255) / 256;
     hipLaunchKernelGGL(bf_tex_loss_kernel, dim3(nb), dim3(256), 0, x->stream, n, (const float *)x->image[0].p, (const float *)x->image[1].p,
                        x->grad_image.p, x->partial.p);
-    hipLaunchKernelGGL(bf_tex_backward_kernel, dim3((x->is * x->is + 255) / 256), dim3(256), 0, x->stream, x->is, x->out, x->aa,
+    hipLaunchKernelGGL(bf_tex_backward_kernel, dim3(M.nf), dim3(64), (size_t)x->ts * x->ts * x->ts * 3 * sizeof(float), x->stream, M.nf, x->is,
+                       x->out, x->aa, (const float *)M.pix.p, (const float *)M.frec.p, x->ts, (const float *)x->grad_image.p, M.grad.p);
+    hipLaunchKernelGGL(bf_tex_backward_large_kernel, dim3((x->is * x->is + 255) / 256), dim3(256), 0, x->stream, x->is, x->out, x->aa,
                        (const float *)M.pix.p, (const float *)M.frec.p, x->ts, (const float *)x->grad_image.p, M.grad.p);
     HIP_TRY(hipGetLastError());
     return BF_OK;
@@ -141,13 +145,12 @@ int bf_texfit_set_mesh(bf_texfit *x, int which, int n_verts, const float *verts,
     HIP_TRY(M.verts.upload(std::vector<float>(verts, verts + (size_t)n_verts * 3)));
     HIP_TRY(M.faces.upload(std::vector<int>(faces, faces + (size_t)n_faces * 3)));
     HIP_TRY(M.tex.upload(std::vector<float>(textures, textures + ntex)));
-    HIP_TRY(M.pv.alloc((size_t)n_verts * 3)); HIP_TRY(M.frec.alloc((size_t)n_faces * 18));
+    HIP_TRY(M.pv.alloc((size_t)n_verts * 3)); HIP_TRY(M.frec.alloc((size_t)n_faces * BF_TEX_REC));
     HIP_TRY(M.pix.alloc(npx * 5)); HIP_TRY(M.rgb.alloc(npx * 3));
     HIP_TRY(M.tile_start.alloc(ntile + 1)); HIP_TRY(M.cursor.alloc(ntile + 1));
     if (which == 1) {
         HIP_TRY(M.m.alloc(ntex)); HIP_TRY(M.v.alloc(ntex)); HIP_TRY(M.grad.alloc(ntex));
         HIP_TRY(hipMemset(M.m.p, 0, ntex * sizeof(float))); HIP_TRY(hipMemset(M.v.p, 0, ntex * sizeof(float)));
-        HIP_TRY(hipMemset(M.grad.p, 0, ntex * sizeof(float)));
         M.adam = true;
         x->steps = 0;
     }
@@ -194,7 +197,6 @@ int bf_texfit_loss_grad(bf_texfit *x, const float *R, const float *t, const floa
     if (rc) return rc;
     bf_texmesh &M = x->mesh[1];
     HIP_TRY(hipMemcpyAsync(grad, M.grad.p, M.grad.n * sizeof(float), hipMemcpyDeviceToHost, x->stream));
-    HIP_TRY(hipMemsetAsync(M.grad.p, 0, M.grad.n * sizeof(float), x->stream));
     HIP_TRY(hipStreamSynchronize(x->stream));
     return loss ? tex_read_loss(x, loss) : BF_OK;
 }

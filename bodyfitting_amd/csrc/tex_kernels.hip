@@ -20,6 +20,8 @@
 #include "bf_internal.h"
 
 #define BF_TEX_TILE 8
+#define BF_TEX_REC 20            // floats per face record
+#define BF_TEX_GATHER_MAX 4096   // faces whose pixel box is larger go through the per-pixel atomic path of the backward pass
 
 struct TexView { float R[9], t[3], K[9], orig; };
 
@@ -41,45 +43,45 @@ bf_tex_project_kernel(int nv, const float *__restrict__ verts, TexView V, float 
     pv[i * 3] = u; pv[i * 3 + 1] = w; pv[i * 3 + 2] = z;
 }
 
-// face record: fv[18] = nine projected coordinates (x0 y0 z0 x1 y1 z1 x2 y2 z2) | nine entries of the inverted triangle
-// pass 0: count the tiles of the face's pixel bounding box; pass 1: write the face into their lists (cursor = running start)
+// face record (BF_TEX_REC floats): nine projected coordinates (x0 y0 z0 x1 y1 z1 x2 y2 z2) | nine entries of the inverted
+// triangle | the pixel box that holds every pixel the face can own: x0 | x1 << 16, y0 | y1 << 16 (empty: x1 < x0)
+// pass 0: the record + count the tiles of the box; pass 1: write the face into their lists (cursor = running start)
 extern "C" __global__ void __launch_bounds__(256)
 bf_tex_face_kernel(int nf, const int *__restrict__ faces, const float *__restrict__ pv, int is, int tiles, float *__restrict__ frec,
                    int *__restrict__ tile_count, int *__restrict__ cursor, int *__restrict__ tile_list, int pass) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nf) return;
+    float *rec = frec + (size_t)i * BF_TEX_REC;
     float f[9];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float *v = pv + (size_t)faces[i * 3 + c] * 3;
         f[c * 3] = v[0]; f[c * 3 + 1] = v[1]; f[c * 3 + 2] = v[2];
     }
-    if ((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0])) {          // back side: never drawn
-        if (pass == 0) { frec[(size_t)i * 18] = 0.f; frec[(size_t)i * 18 + 1] = 0.f; frec[(size_t)i * 18 + 3] = 0.f; frec[(size_t)i * 18 + 4] = 0.f;
-                         frec[(size_t)i * 18 + 6] = 0.f; frec[(size_t)i * 18 + 7] = 0.f; }
-        return;
-    }
+    if (pass == 0) { rec[18] = __int_as_float(1); rec[19] = __int_as_float(1); }          // (empty box until shown otherwise)
+    if ((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0])) return;            // back side: never drawn
     float p[3][2];
 #pragma unroll
     for (int n = 0; n < 3; ++n)
 #pragma unroll
         for (int d = 0; d < 2; ++d) p[n][d] = 0.5f * (f[3 * n + d] * is + is - 1);
+    // pixels whose centre can pass the three edge tests lie inside the triangle's pixel-space bounding box (one pixel of slack)
+    const float xmin = fminf(p[0][0], fminf(p[1][0], p[2][0])), xmax = fmaxf(p[0][0], fmaxf(p[1][0], p[2][0]));
+    const float ymin = fminf(p[0][1], fminf(p[1][1], p[2][1])), ymax = fmaxf(p[0][1], fmaxf(p[1][1], p[2][1]));
+    if (!(xmax >= -1.f && ymax >= -1.f && xmin <= (float)is && ymin <= (float)is)) return;       // (also drops NaN boxes)
+    const int x0 = max((int)floorf(fmaxf(xmin, 0.f)) - 1, 0), x1 = min((int)ceilf(fminf(xmax, (float)is)) + 1, is - 1);
+    const int y0 = max((int)floorf(fmaxf(ymin, 0.f)) - 1, 0), y1 = min((int)ceilf(fminf(ymax, (float)is)) + 1, is - 1);
     if (pass == 0) {
         float inv[9] = {p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
                         p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
                         p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
         const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { frec[(size_t)i * 18 + k] = f[k]; frec[(size_t)i * 18 + 9 + k] = inv[k] / den; }
+        for (int k = 0; k < 9; ++k) { rec[k] = f[k]; rec[9 + k] = inv[k] / den; }
+        rec[18] = __int_as_float(x0 | (x1 << 16)); rec[19] = __int_as_float(y0 | (y1 << 16));
     }
-    // pixels whose centre can pass the three edge tests lie inside the triangle's pixel-space bounding box (one pixel of slack)
-    const float xmin = fminf(p[0][0], fminf(p[1][0], p[2][0])), xmax = fmaxf(p[0][0], fmaxf(p[1][0], p[2][0]));
-    const float ymin = fminf(p[0][1], fminf(p[1][1], p[2][1])), ymax = fmaxf(p[0][1], fmaxf(p[1][1], p[2][1]));
-    if (!(xmax >= -1.f && ymax >= -1.f && xmin <= (float)is && ymin <= (float)is)) return;       // (also drops NaN boxes)
-    const int x0 = max((int)floorf(xmin) - 1, 0) / BF_TEX_TILE, x1 = min((int)ceilf(xmax) + 1, is - 1) / BF_TEX_TILE;
-    const int y0 = max((int)floorf(ymin) - 1, 0) / BF_TEX_TILE, y1 = min((int)ceilf(ymax) + 1, is - 1) / BF_TEX_TILE;
-    for (int ty = y0; ty <= y1; ++ty)
-        for (int tx = x0; tx <= x1; ++tx) {
+    for (int ty = y0 / BF_TEX_TILE; ty <= y1 / BF_TEX_TILE; ++ty)
+        for (int tx = x0 / BF_TEX_TILE; tx <= x1 / BF_TEX_TILE; ++tx) {
             const int tile = ty * tiles + tx;
             if (pass == 0) atomicAdd(tile_count + tile + 1, 1);
             else tile_list[atomicAdd(cursor + tile, 1)] = i;
@@ -131,7 +133,7 @@ bf_tex_raster_kernel(int is, int tiles, const float *__restrict__ frec, const in
         __builtin_amdgcn_wave_barrier();
         if (lane < n) {
             const int fn = tile_list[base + lane];
-            const float *src = frec + (size_t)fn * 18;
+            const float *src = frec + (size_t)fn * BF_TEX_REC;
 #pragma unroll
             for (int k = 0; k < 18; ++k) s_f[wv][lane][k] = src[k];
             s_f[wv][lane][18] = __int_as_float(fn);
@@ -167,7 +169,7 @@ bf_tex_raster_kernel(int is, int tiles, const float *__restrict__ frec, const in
     if (fmin >= 0) {
         int idx[8];
         float wt[8];
-        tex_corners(wmin, depth_min, frec + (size_t)fmin * 18, ts, idx, wt);
+        tex_corners(wmin, depth_min, frec + (size_t)fmin * BF_TEX_REC, ts, idx, wt);
         const float *tex = textures + (size_t)fmin * ts * ts * ts * 3;
         float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -211,24 +213,68 @@ bf_tex_loss_kernel(int n, const float *__restrict__ a, const float *__restrict__
     if (threadIdx.x == 0) partial[blockIdx.x] = s[0];
 }
 
-// per high-resolution pixel of the fitted mesh: dL/drgb (through pooling, flip and the background mask) onto the 8 texels
-extern "C" __global__ void __launch_bounds__(256)
-bf_tex_backward_kernel(int is, int out, int aa, const float *__restrict__ pix, const float *__restrict__ frec, int ts,
+// dL/drgb of one super-sampled pixel, through the pooling and the flip
+__device__ __forceinline__ void tex_pixel_grad(int yi, int xi, int is, int out, int aa, const float *__restrict__ grad_image, float g[3]) {
+    const int yf = is - 1 - yi, oy = aa ? yf >> 1 : yf, ox = aa ? xi >> 1 : xi;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] = grad_image[((size_t)c * out + oy) * out + ox] * (aa ? 0.25f : 1.f);
+}
+
+// backward_textures, gathered per face: one wave per face walks the face's pixel box, adds the pixels it owns into the face's
+// texture cube in LDS and stores the cube (every texel of every face is written: no clearing pass, no global atomics).
+// Dynamic LDS: ts^3 * 3 floats.  Faces with a box above BF_TEX_GATHER_MAX pixels store zeros and are left to
+// bf_tex_backward_large_kernel.
+extern "C" __global__ void __launch_bounds__(64)
+bf_tex_backward_kernel(int nf, int is, int out, int aa, const float *__restrict__ pix, const float *__restrict__ frec, int ts,
                        const float *__restrict__ grad_image, float *__restrict__ grad_tex) {
+    extern __shared__ float cube[];
+    const int fn = blockIdx.x, lane = threadIdx.x, n = ts * ts * ts * 3;
+    const float *rec = frec + (size_t)fn * BF_TEX_REC;
+    for (int i = lane; i < n; i += 64) cube[i] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const int bx = __float_as_int(rec[18]), by = __float_as_int(rec[19]);
+    const int x0 = bx & 0xffff, x1 = bx >> 16, y0 = by & 0xffff, y1 = by >> 16, W = x1 - x0 + 1, H = y1 - y0 + 1;
+    if (W > 0 && H > 0 && W * H <= BF_TEX_GATHER_MAX) {
+        for (int p = lane; p < W * H; p += 64) {
+            const int yi = y0 + p / W, xi = x0 + p % W;
+            const float *pp = pix + ((size_t)yi * is + xi) * 5;
+            if (__float_as_int(pp[4]) != fn) continue;
+            float g[3];
+            tex_pixel_grad(yi, xi, is, out, aa, grad_image, g);
+            const float w[3] = {pp[0], pp[1], pp[2]};
+            int idx[8];
+            float wt[8];
+            tex_corners(w, pp[3], rec, ts, idx, wt);
+#pragma unroll
+            for (int pn = 0; pn < 8; ++pn)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) atomicAdd(cube + idx[pn] * 3 + c, wt[pn] * g[c]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float *gt = grad_tex + (size_t)fn * n;
+    for (int i = lane; i < n; i += 64) gt[i] = cube[i];
+}
+
+// the faces the gather kernel left out (box above BF_TEX_GATHER_MAX pixels): per pixel, atomicAdd as the reference does
+extern "C" __global__ void __launch_bounds__(256)
+bf_tex_backward_large_kernel(int is, int out, int aa, const float *__restrict__ pix, const float *__restrict__ frec, int ts,
+                             const float *__restrict__ grad_image, float *__restrict__ grad_tex) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= is * is) return;
     const float *pp = pix + (size_t)i * 5;
     const int fn = __float_as_int(pp[4]);
     if (fn < 0) return;
-    const int yi = i / is, xi = i - yi * is, yf = is - 1 - yi;
-    const int oy = aa ? yf >> 1 : yf, ox = aa ? xi >> 1 : xi;
+    const float *rec = frec + (size_t)fn * BF_TEX_REC;
+    const int bx = __float_as_int(rec[18]), by = __float_as_int(rec[19]);
+    if (((bx >> 16) - (bx & 0xffff) + 1) * ((by >> 16) - (by & 0xffff) + 1) <= BF_TEX_GATHER_MAX) return;
+    const int yi = i / is, xi = i - yi * is;
     float g[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) g[c] = grad_image[((size_t)c * out + oy) * out + ox] * (aa ? 0.25f : 1.f);
+    tex_pixel_grad(yi, xi, is, out, aa, grad_image, g);
     const float w[3] = {pp[0], pp[1], pp[2]};
     int idx[8];
     float wt[8];
-    tex_corners(w, pp[3], frec + (size_t)fn * 18, ts, idx, wt);
+    tex_corners(w, pp[3], rec, ts, idx, wt);
     float *gt = grad_tex + (size_t)fn * ts * ts * ts * 3;
 #pragma unroll
     for (int pn = 0; pn < 8; ++pn)
@@ -236,9 +282,9 @@ bf_tex_backward_kernel(int is, int out, int aa, const float *__restrict__ pix, c
         for (int c = 0; c < 3; ++c) atomicAdd(gt + idx[pn] * 3 + c, wt[pn] * g[c]);
 }
 
-// torch.optim.Adam, single-tensor form; the gradient buffer is cleared for the next step
+// torch.optim.Adam, single-tensor form
 extern "C" __global__ void __launch_bounds__(256)
-bf_tex_adam_kernel(size_t n, float *__restrict__ p, float *__restrict__ m, float *__restrict__ v, float *__restrict__ g,
+bf_tex_adam_kernel(size_t n, float *__restrict__ p, float *__restrict__ m, float *__restrict__ v, const float *__restrict__ g,
                    float step_size, float bc2_sqrt, float omb1, float beta2, float omb2, float eps) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -247,5 +293,5 @@ bf_tex_adam_kernel(size_t n, float *__restrict__ p, float *__restrict__ m, float
     const float vi = v[i] * beta2 + gi * gi * omb2;
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     p[i] = p[i] - step_size * (mi / denom);
-    m[i] = mi; v[i] = vi; g[i] = 0.f;
+    m[i] = mi; v[i] = vi;
 }

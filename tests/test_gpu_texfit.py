@@ -119,6 +119,34 @@ def test_full_size_render_properties():
     r.close()
 
 
+def test_faces_with_a_large_pixel_box_take_the_per_pixel_path():
+    """two triangles that fill the view (boxes far above BF_TEX_GATHER_MAX = 4096 pixels) next to a fan of small ones"""
+    rng = np.random.default_rng(5)
+    big_v = np.array([[-0.9, -0.9, 2.0], [0.9, -0.9, 2.0], [0.9, 0.9, 2.0], [-0.9, 0.9, 2.0]], np.float32)
+    small_v, small_f = icosphere(1)
+    v = np.concatenate([big_v, small_v * 0.3 + np.array([0, 0, 1.5], np.float32)]).astype(np.float32)
+    f = np.concatenate([np.array([[0, 1, 2], [0, 2, 3]], np.int32), small_f + 4])
+    K = np.array([[64, 0, 32], [0, 64, 32], [0, 0, 1]], np.float32)
+    pv = TO.project(v, K, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 64)[f]
+    back = (pv[:, 2, 1] - pv[:, 0, 1]) * (pv[:, 1, 0] - pv[:, 0, 0]) < (pv[:, 1, 1] - pv[:, 0, 1]) * (pv[:, 2, 0] - pv[:, 0, 0])
+    f[:2][back[:2]] = f[:2][back[:2]][:, ::-1]                       # the two big ones face the camera; the sphere keeps its winding
+    ts = 3
+    tex_a = rng.uniform(0, 1, (len(f), ts, ts, ts, 3)).astype(np.float32)
+    tex_b = rng.uniform(0, 1, (len(f), ts, ts, ts, 3)).astype(np.float32)
+    r = TF.Renderer(64, ts, near=0.0, far=10.0)
+    r.set_mesh(r.TARGET, (v, f, tex_a)); r.set_mesh(r.FITTED, (v, f, tex_b))
+    loss, grad = r.loss_grad(np.eye(4))
+    keep = {}
+    a = TO.render(v, f, tex_a, K, np.eye(3), np.zeros(3), 64, 64, 0.0, 10.0)
+    b = TO.render(v, f, tex_b, K, np.eye(3), np.zeros(3), 64, 64, 0.0, 10.0, keep=keep)
+    np.testing.assert_array_equal(r.render_rgb(r.FITTED, np.eye(4)), b)
+    want = TO.texture_grad(np.sign(b - a).astype(np.float32), keep, len(f), ts, 64)
+    assert np.abs(want[:2]).max() > 10 and np.abs(want[2:]).max() > 0.1          # both kinds of face own pixels
+    np.testing.assert_allclose(grad, want, atol=2e-4, rtol=1e-5)                  # (sums of thousands of terms on the big faces)
+    assert loss == pytest.approx(float(np.abs(a - b).astype(np.float64).sum()), rel=1e-12)
+    r.close()
+
+
 def test_nothing_in_front_of_the_camera_renders_the_background():
     r, scan, fit, views, dist = _setup()
     away = views[0].copy()
