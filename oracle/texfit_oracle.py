@@ -201,14 +201,8 @@ class TextureFit:
         self.m = np.zeros_like(self.mesh[2])
         self.v = np.zeros_like(self.mesh[2])
 
-    def step(self, K, R, t, orig_size):
-        keep = {}
-        a = render(*self.target, K, R, t, orig_size, **self.cfg)
-        b = render(*self.mesh, K, R, t, orig_size, keep=keep, **self.cfg)
-        loss = float(np.abs(a - b).astype(np.float64).sum())
-        g = texture_grad(np.sign(b - a).astype(F32), keep, len(self.mesh[1]), self.mesh[2].shape[1], self.cfg["image_size"],
-                         self.cfg["anti_aliasing"])
-        # torch.optim.Adam, single-tensor form (betas 0.9 / 0.999, eps 1e-8), bias corrections in double like torch's python floats
+    def adam(self, g):
+        """torch.optim.Adam, single-tensor form (betas 0.9 / 0.999, eps 1e-8), bias corrections in double like torch's python floats"""
         self.step_no += 1
         b1, b2, eps = 0.9, 0.999, 1e-8
         self.m = (self.m + (g - self.m) * F32(1 - b1)).astype(F32)
@@ -217,4 +211,13 @@ class TextureFit:
         denom = (np.sqrt(self.v) / F32(np.sqrt(bc2)) + F32(eps)).astype(F32)
         tex = (self.mesh[2] - F32(self.lr / bc1) * (self.m / denom)).astype(F32)
         self.mesh = (self.mesh[0], self.mesh[1], tex)
+
+    def step(self, K, R, t, orig_size):
+        keep = {}
+        a = render(*self.target, K, R, t, orig_size, **self.cfg)
+        b = render(*self.mesh, K, R, t, orig_size, keep=keep, **self.cfg)
+        loss = float(np.abs(a - b).astype(np.float64).sum())
+        g = texture_grad(np.sign(b - a).astype(F32), keep, len(self.mesh[1]), self.mesh[2].shape[1], self.cfg["image_size"],
+                         self.cfg["anti_aliasing"])
+        self.adam(g)
         return loss, a, b

@@ -126,3 +126,20 @@ def test_fit_reduces_the_loss():
     Kk = np.array([[8.0, 0, 4], [0, 8.0, 4], [0, 0, 1]], np.float32)
     losses = [fit.step(Kk, EYE, np.zeros(3), 8)[0] for _ in range(12)]
     assert losses[-1] < 0.3 * losses[0]
+
+
+def test_adam_update_is_torch_adam():
+    """TextureFit's update against torch.optim.Adam (lr 1e-2, defaults) fed the same gradients: float32 rounding apart
+    (torch's CPU kernels fuse some multiply-adds)"""
+    import torch
+    rng = np.random.default_rng(0)
+    p0 = rng.uniform(0, 1, (5, 4, 4, 4, 3)).astype(np.float32)
+    grads = [rng.standard_normal(p0.shape).astype(np.float32) * s for s in (1.0, 1e-3, 10.0, 0.0, 1e-6)]
+    tp = torch.tensor(p0.copy(), requires_grad=True)
+    opt = torch.optim.Adam([tp], lr=1e-2)
+    fit = TO.TextureFit(None, (None, None, p0.copy()), 16, 0.0, 10.0, lr=1e-2)
+    for g in grads:
+        opt.zero_grad(); tp.grad = torch.tensor(g); opt.step()
+        fit.adam(g)
+        np.testing.assert_allclose(fit.mesh[2], tp.detach().numpy(), atol=2e-7, rtol=0)
+    assert np.abs(fit.mesh[2] - p0).max() > 0.03
