@@ -14,6 +14,8 @@ The partition itself (`shard_range`, `shard_capacity`, `unpack`) is host arithme
 """
 from __future__ import annotations
 
+import contextlib
+import sys
 import ctypes as C
 import os
 import tempfile
@@ -61,6 +63,21 @@ def unpack(gathered, n_frames, world):
 
 
 # ---- one process, n devices -----------------------------------------------------------------------------------------
+
+@contextlib.contextmanager
+def _quiet_stdout():
+    """RCCL may print a version banner to STDOUT when a communicator comes up; callers that print a machine-read line on
+    stdout (bench.py) must not have it mixed in, so file descriptor 1 points at stderr for the duration of the call."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class _BorrowedBatch(FrameBatch):
     """a device's block of a Group, seen through the ordinary FrameBatch interface (the group owns the handle)"""
 
@@ -95,8 +112,9 @@ class Group:
         desc, info, keep = model_desc(model, gmm)
         devs = None if devices is None else _i32(devices)
         self._h = C.c_void_p()
-        _lib.check(lib.bf_group_create(C.byref(desc), int(n_devices), _lib.iptr(devs), int(n_frames), int(n_views), C.byref(self._h)),
-                   "bf_group_create")
+        with _quiet_stdout():
+            rc = lib.bf_group_create(C.byref(desc), int(n_devices), _lib.iptr(devs), int(n_frames), int(n_views), C.byref(self._h))
+        _lib.check(rc, "bf_group_create")
         del keep
         self.n, self.F, self.V = int(n_devices), int(n_frames), int(n_views)
         self.n_params = lib.bf_group_n_params(self._h)
@@ -225,8 +243,9 @@ class Comm:
             uid = bytes(buf)
         uid = rdzv.broadcast("rccl-unique-id", uid)
         self._h = C.c_void_p()
-        _lib.check(lib.bf_comm_create((C.c_uint8 * 128).from_buffer_copy(uid), self.rank, self.world, self.device, C.byref(self._h)),
-                   "bf_comm_create")
+        with _quiet_stdout():
+            rc = lib.bf_comm_create((C.c_uint8 * 128).from_buffer_copy(uid), self.rank, self.world, self.device, C.byref(self._h))
+        _lib.check(rc, "bf_comm_create")
         self.rendezvous = rdzv
 
     def close(self):
