@@ -716,6 +716,7 @@ FrameIO bf_frame_io(bf_batch *b, bool want_grads) {
     io.cscale = b->cscale.p;          // null unless scans are attached
     io.ext = nullptr;
     io.emit_next = 0;
+    io.image_out = nullptr;
     return io;
 }
 

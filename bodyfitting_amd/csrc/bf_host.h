@@ -73,6 +73,7 @@ struct bf_model {
     DevBuf<int> v_nzj;            // sparse skinning rows (MeshTab::v_nnz)
     DevBuf<float> v_nzw;
     DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass (under `lazy`, device-synchronised)
+    DevBuf<float> fit_image;      // FitTab::lds_image of the dense-schedule fit instance, built on first use (under `lazy`)
     std::mutex lazy;              // guards the build-on-first-use tables (posedirsT, faces_d / adj)
     std::vector<int> faces_host;  // body-model topology (for the SMPL+D stage), optional
     DevBuf<int> faces_d, adj_start, adj;   // faces and the vertex -> (face, corner) lists, built on first use
@@ -165,4 +166,6 @@ int bf_guard_arena(bf_batch *b);         // the compute stream waits for a fetch
 void bf_use_arena(bf_batch *b, int k);
 FrameIO bf_frame_io(bf_batch *b, bool want_grads);
 }
+extern "C" void bf_fit_image_segments(int nj, int nb, int npf, int ns, int nl, int np, int seg[6]);
+extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int np, int nviews);
 extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);

@@ -59,6 +59,11 @@ struct FitTab {
     const float *g_logw;             // [M]           -log(nll_weights)
     const float *g_plane;            // [M][72][64]   Psym[m][row=lane][col=j] lane-major (rows 0..63), zero padded
     const float *g_ptail;            // [4][12][64]   rows 64..68 of components (2w, 2w+1) cut into 60 twelve-column pieces
+    // the fit kernel's LDS segment as its prologue leaves it (everything but the per-frame arrays), for the dense schedule's
+    // one-iteration launches: one flat copy instead of two dozen dependent load -> store loops.  Null until built.
+    const float *lds_image;
+    int lds_image_n4;                // float4s of the dump (the LDS segment up to the projection matrices)
+    int img_seg[3][2];               // the three runs of model-constant arrays in it: (first float4, count)
 };
 
 // Full model tensors for the dense mesh kernels.
@@ -180,6 +185,7 @@ struct FrameIO {
     float *state;             // [F][state_stride]
     float *debug;             // optional dump of the first iteration's intermediates
     const float *cscale;      // [F] per-frame constant scale (scan_height / 1.7, smplify.py:156) or null
+    float *image_out;         // mode 2 only: receives the LDS image (see FitTab::lds_image)
     int emit_next;            // (with ext) leave the pose state of the STEPPED parameters instead of the last forward's
     const float *ext;         // [F][npf + nj*12 + nb + 4 + nj*3] gradients arriving from the dense losses (dfeat | per joint
                               //  rows of sum w dv (x) [vp|1] | dbeta | dt ds | dL/d(chain joint positions)), or null

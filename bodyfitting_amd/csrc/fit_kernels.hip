@@ -34,11 +34,17 @@
 // Diagnostic build only (-DBF_STAMP, libbodyfit_stamp.so): thread 0 stamps the shader clock after every
 // barrier of iteration 2 into io.debug[4096..]; the product library has no stamps.
 #ifdef BF_STAMP
-#define BF_SYNC() do { __syncthreads(); if (tid == 0 && it == 2 && sidx < 32) { S.stamp[sidx] = (float)(long long)(clock64() - t_iter); } ++sidx; } while (0)
+#define BF_SYNC() do { __syncthreads(); if (tid == 0 && (it == 2 || EXT) && sidx < 32) { S.stamp[sidx] = (float)(long long)(clock64() - t_iter); } ++sidx; } while (0)
 #define BF_MARK(k, who, itv, t0v) do { if (tid == (who) && (itv) == 2) S.stamp[k] = (float)(long long)(clock64() - (t0v)); } while (0)
 #else
 #define BF_SYNC() __syncthreads()
 #define BF_MARK(k, who, itv, t0v) do { (void)(itv); (void)(t0v); } while (0)
+#endif
+// (stamp build) cycles since kernel entry at a few points of a dense-schedule launch: thread `who` of frame 0 -> io.debug[4160 + k]
+#ifdef BF_STAMP
+#define BF_KMARK(k, who) do { if (EXT && tid == (who) && frame == 0 && io.debug) io.debug[4160 + (k)] = (float)(long long)(clock64() - bf_k0); } while (0)
+#else
+#define BF_KMARK(k, who) do { } while (0)
 #endif
 // orders this wave's LDS traffic for the compiler; the hardware executes a wave's LDS ops in order
 #define BF_WAVE_FENCE() __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront")
@@ -51,6 +57,8 @@ struct FitSmem {
     float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *rel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp, *stamp, *sel_pd2;
     int *nzj, *thk, *tho, *par, *pk, *pa_, *pb_;
     float *am, *av;
+    float *ext;          // the dense schedule's outside gradient blocks of this frame (EXT launches)
+    int *lvl;            // level_joints[nj] | level_start[n_levels + 1] (<= 66) for the pose-state tail
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
@@ -88,6 +96,8 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.pa = take(np);       s.pb = take(np);   s.g = take(np);
     s.pk = (int *)take(np); s.pa_ = (int *)take(np); s.pb_ = (int *)take(np); s.am = take(np); s.av = take(np);
     s.proj = take(nviews * 12);
+    s.ext = take(npf + nj * 12 + nb + 4 + nj * 3 + 4);
+    s.lvl = (int *)take(nj + 68);
     (void)nl;
     return o * sizeof(float);
 }
@@ -213,6 +223,9 @@ template <int NJ, int NB, int NS, int NL, bool EXT>
 __global__ void __launch_bounds__(BF_FIT_THREADS)
 fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float *__restrict__ adam_tab, int adam_t0) {
     extern __shared__ __align__(16) float smem_raw[];
+#ifdef BF_STAMP
+    const long long bf_k0 = clock64();
+#endif
     const int tid = threadIdx.x, nt = BF_FIT_THREADS;
     constexpr int NG = 256;                    // threads of the geometry waves (0-3)
     const int lane = tid & 63, wave = tid >> 6;
@@ -226,10 +239,60 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const bool emit = EXT && mode == 0 && io.emit_next;
 
     // ---- one-off loads --------------------------------------------------------------------
+    const int nbp = pad4(nb + 1);
+    const int sel_nnz = T.sel_nnz;
+    auto theta_of = [&](const float *P, int j, int k) {
+        return bf_theta(P, j, k, S.thk, S.tho, S.pmean, S.hcomp, T.n_pca, T.off_lh, T.off_rh);
+    };           // 0 = some selector vertex has more than BF_SEL_NNZ bones: dense loop
+    // Dense-schedule launches run ONE iteration, so their prologue is on the critical path of every iteration.  Once a first
+    // launch has left an image of the model-constant LDS arrays (three contiguous runs of the carve, FitTab::img_seg), everything
+    // such a launch needs from global memory is issued back to back into registers - image, projection matrices, parameters,
+    // Adam moments, the outside gradient blocks, the tree levels - and stored to LDS after ONE round trip, instead of two dozen
+    // dependent load -> store loops at ~2,500 cycles each (a kernel starts with cold caches).
+    const int n_ext = npf + nj * 12 + nb + 4 + nj * 3 + 4;
+    const bool use_image = EXT && T.lds_image != nullptr && mode != 2 && V * 3 <= nt && np <= nt && n_ext <= 3 * nt &&
+                           T.img_seg[0][1] + T.img_seg[1][1] + T.img_seg[2][1] <= 4 * nt && nj <= nt && T.n_levels < 66;
+    if (use_image) {
+        const float4 *img = (const float4 *)__builtin_assume_aligned(T.lds_image, 16);
+        float4 *lds4 = (float4 *)__builtin_assume_aligned(smem_raw, 16);
+        const int c0 = T.img_seg[0][1], c1 = c0 + T.img_seg[1][1], c2 = c1 + T.img_seg[2][1];
+        int at[4];
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = q * nt + tid;           // flat index over the three runs -> float4 index of the LDS segment
+            at[q] = i < c0 ? T.img_seg[0][0] + i : (i < c1 ? T.img_seg[1][0] + (i - c0) : (i < c2 ? T.img_seg[2][0] + (i - c1) : -1));
+            if (at[q] >= 0) v[q] = img[at[q]];
+        }
+        const float4 *pj = (const float4 *)__builtin_assume_aligned(io.proj + (size_t)frame * V * 12, 16);
+        float4 vp = {0.f, 0.f, 0.f, 0.f};
+        if (tid < V * 3) vp = pj[tid];
+        float r_pa = 0.f, r_am = 0.f, r_av = 0.f, r_ext[3] = {0.f, 0.f, 0.f};
+        int r_lj = 0, r_ls = 0;
+        if (tid < np) {
+            r_pa = (io.params0 ? io.params0 : io.params)[(size_t)frame * np + tid];
+            if (!io.params0) { r_am = io.adam_m[(size_t)frame * np + tid]; r_av = io.adam_v[(size_t)frame * np + tid]; }
+        }
+        const float *eg = io.ext + (size_t)frame * n_ext;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) if (q * nt + tid < n_ext) r_ext[q] = eg[q * nt + tid];
+        if (tid < nj) r_lj = T.level_joints[tid];
+        if (tid <= T.n_levels) r_ls = T.level_start[tid];
+        // zero-initialised arrays: GMM d / y, and the keypoint table when this launch has no loss joints
+        for (int i = tid; i < 2 * BF_GMM_M * BF_GMM_LD; i += nt) S.gd[i] = 0.f;          // (gd and gy are adjacent in the carve)
+        if (nl == 0) for (int i = tid; i < BF_VSUB * BF_KP_ROUNDS * 16 * 2; i += nt) ((float4 *)S.kp)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (at[q] >= 0) lds4[at[q]] = v[q];
+        if (tid < V * 3) ((float4 *)S.proj)[tid] = vp;
+        if (tid < np) { S.pa[tid] = r_pa; S.am[tid] = r_am; S.av[tid] = r_av; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) if (q * nt + tid < n_ext) S.ext[q * nt + tid] = r_ext[q];
+        if (tid < nj) S.lvl[tid] = r_lj;
+        if (tid <= T.n_levels) S.lvl[nj + tid] = r_ls;
+    } else {
     copy_f(S.Jt, T.Jt, nj3, tid, nt);
     copy_f(S.Jtrel, T.Jtrel, nj3, tid, nt);
     // beta tables with rows padded to float4s (stride nbp); column nb carries the constant term (it meets a 1)
-    const int nbp = pad4(nb + 1);
     for (int i = tid; i < nj3 * nbp; i += nt) {
         const int r = i / nbp, l = i - r * nbp;
         S.Jd[i] = l < nb ? T.Jd[r * nb + l] : (l == nb ? T.Jt[r] : 0.f);
@@ -244,13 +307,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     for (int i = tid; i < npf * (ns3 + 1); i += nt) { const int p = i / (ns3 + 1), o = i - p * (ns3 + 1); S.sel_pd2[i] = o < ns3 ? T.sel_pd[p * ns3 + o] : 0.f; }
     copy_f(S.sel_w, T.sel_w, ns * nj, tid, nt);
     for (int i = tid; i < ns * BF_SEL_NNZ; i += nt) { S.nzw[i] = T.sel_nzw[i]; S.nzj[i] = T.sel_nzj[i]; }
-    const int sel_nnz = T.sel_nnz;
     for (int i = tid; i < nj; i += nt) { S.thk[i] = T.th_kind[i]; S.tho[i] = T.th_off[i]; S.par[i] = i > 0 ? T.parents[i] : 0; }
     for (int i = tid; i < nj * 3; i += nt) S.pmean[i] = T.pose_mean ? T.pose_mean[i] : 0.f;
     for (int i = tid; i < 2 * T.n_pca * 45 && i < 2 * 6 * 45; i += nt) S.hcomp[i] = T.hand_comp[i];
-    auto theta_of = [&](const float *P, int j, int k) {
-        return bf_theta(P, j, k, S.thk, S.tho, S.pmean, S.hcomp, T.n_pca, T.off_lh, T.off_rh);
-    };           // 0 = some selector vertex has more than BF_SEL_NNZ bones: dense loop
     for (int i = tid; i < BF_GMM_M * BF_GMM_LD; i += nt) {
         int m = i / BF_GMM_LD, j = i % BF_GMM_LD;
         S.means[i] = j < BF_GMM_D ? T.g_means[m * BF_GMM_D + j] : 0.f;
@@ -259,7 +318,14 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     }
     copy_f(S.proj, io.proj + (size_t)frame * V * 12, V * 12, tid, nt);
     copy_f(S.pa, (io.params0 ? io.params0 : io.params) + (size_t)frame * np, np, tid, nt);
+    if (EXT) {
+        if (mode != 2) copy_f(S.ext, io.ext + (size_t)frame * n_ext, n_ext, tid, nt);
+        for (int i = tid; i < nj; i += nt) S.lvl[i] = T.level_joints[i];
+        for (int i = tid; i <= T.n_levels && i < 67; i += nt) S.lvl[nj + i] = T.level_start[i];
+    }
+    }
     float *Pcur = S.pa, *Pnext = S.pb;
+    BF_KMARK(8, 0);
 
     // chain-row role (waves 0-2): lane = joint
     const bool cw_on = wave < 3 && lane < nj;
@@ -317,6 +383,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         gd_mu[2 * q + 1] = ok ? T.g_means[mb * BF_GMM_D + j] : 0.f;
     }
 
+    BF_KMARK(10, 0);
     const float ndiv_f = (float)io.ndiv[frame];
     const float icoeff = 1.0f / hp.coeff;
     const float kscale = -1.0f / (hp.coeff * ndiv_f);
@@ -326,7 +393,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     // (x_a, x_b, y_a, y_b | k_a, k_b, c_a, c_b) with k = conf^2 * kscale * 2 sigma^4 (gradient factor) and
     // c = conf^2 * sigma^2 (loss factor); records past V or nl are zero, so they add nothing
     const float *kp_frame = io.keypoints + (size_t)frame * V * nl * 3;
-    for (int i = tid; i < BF_VSUB * BF_KP_ROUNDS * 16; i += nt) {
+    // (no loss joints in this launch and an image: the table is the image's zeros)
+    for (int i = tid; i < ((use_image && nl == 0) ? 0 : BF_VSUB * BF_KP_ROUNDS * 16); i += nt) {
         const int v = i >> 4, ps = i & 15;
         float4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
         if (v < V && 2 * ps < nl) {
@@ -342,12 +410,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         ((float4 *)S.kp)[2 * i] = e0;
         ((float4 *)S.kp)[2 * i + 1] = e1;
     }
+    BF_KMARK(11, 0);
     const float4 *kp_lane = (const float4 *)__builtin_assume_aligned(S.kp, 16) + (vsub * 16 + pslot) * 2;
     const int EXT0 = npf, EXT_A = npf, EXT_B = npf + nj * 12, EXT_T = npf + nj * 12 + nb;
     const int EXT_G = npf + nj * 12 + nb + 4;
     const int EXT_K = EXT_G + nj * 3;          // dt, ds of the dense keypoint loss
     // (EXT = the dense schedule's per-iteration launch with outside gradient blocks; compiled out of the persistent loop)
-    const float *ext = EXT ? io.ext + (size_t)frame * (npf + nj * 12 + nb + 4 + nj * 3 + 4) : nullptr;
+    const float *ext = EXT ? S.ext : nullptr;          // (this frame's blocks, staged in LDS by the prologue)
     (void)EXT0;
 
     // pose-blend role: (row slice sl, output column o of the selector vertices)
@@ -355,14 +424,23 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int rows_sl = (npf + NSL - 1) / NSL;
 
     // Adam role: parameter `tid`; its moments and descriptor live in LDS (read once per iteration, in the Adam phase)
+    if (!use_image)
     for (int i = tid; i < np; i += nt) {
         S.am[i] = io.params0 ? 0.f : io.adam_m[(size_t)frame * np + i];
         S.av[i] = io.params0 ? 0.f : io.adam_v[(size_t)frame * np + i];
         S.pk[i] = T.p_kind[i]; S.pa_[i] = T.p_a[i]; S.pb_[i] = T.p_b[i];
     }
+    BF_KMARK(12, 0);
     int hand_j0_l = 0, hand_j0_r = 0;          // first joint of each hand
     for (int j = nj - 1; j >= 0; --j) { if (T.th_kind[j] == 2) hand_j0_l = j; if (T.th_kind[j] == 3) hand_j0_r = j; }
+    BF_KMARK(0, 0); BF_KMARK(1, 256);
     __syncthreads();
+    BF_KMARK(2, 0);
+    if (EXT && mode == 2) {                                  // image builder: leave the LDS segment as it is now and stop
+        if (frame == 0 && io.image_out)
+            for (int i = tid; i < T.lds_image_n4 * 4; i += nt) io.image_out[i] = smem_raw[i];
+        return;
+    }
 
     int bf_it = -1;                            // (stamp build only; dead otherwise)
     long long bf_t0 = 0;
@@ -1513,8 +1591,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_SYNC();
         if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
     }
-    {   // ---- after the last iteration: loss terms (loss.py:219-224) and the pose state of the LAST forward pass, i.e. of
-        // the parameters before the final Adam step (they sit in Pnext after the swap)
+    if (!emit) {   // ---- after the last iteration: loss terms (loss.py:219-224) and the pose state of the LAST forward pass, i.e. of
+        // the parameters before the final Adam step (they sit in Pnext after the swap).  (A dense-schedule launch that emits the
+        // state of the stepped parameters is not the last one: nobody reads its terms, and its state is written by the tail.)
         const float *Pold = mode == 0 ? Pnext : Pcur;
         const float grad = grad_last;
         {
@@ -1571,6 +1650,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     __syncthreads();
     if (tid < 64 && io.debug && frame == 0) io.debug[4096 + tid] = S.stamp[tid];
 #endif
+    BF_KMARK(4, 0); BF_KMARK(5, 256);
     if (mode == 0 && tid < np) {
         io.params[(size_t)frame * np + tid] = Pcur[tid];
         io.adam_m[(size_t)frame * np + tid] = S.am[tid];
@@ -1580,9 +1660,27 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         if (emit) {                                   // (block-uniform)
             __syncthreads();                          // the stepped parameters above are visible to the whole workgroup
             // (every LDS buffer of the fit is dead by now: its first bytes are the scratch)
-            bf_pose_state_body<true>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nt, smem_raw);
+            BF_KMARK(6, 0);
+            // the model's small tables and the stepped parameters are in LDS already; the keypoint table (dead by now, 6144 floats)
+            // is the scratch.  Same arithmetic as bf_pose_state_kernel: only the addresses differ.
+            const PoseTabs PT{S.thk, S.tho, S.par, S.pmean, S.hcomp, S.Jd, S.Jt, pad4(nb + 1), S.lvl, S.lvl + nj};
+            static_assert(BF_VSUB * BF_KP_ROUNDS * 16 * 8 >= BF_POSE_STATE_LDS, "the keypoint table is the pose-state scratch");
+            bf_pose_state_body<true>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nt, S.kp, PT, Pcur);
+            BF_KMARK(7, 0);
         }
     }
+}
+
+// The three contiguous runs of model-constant arrays in the carve, as (first float4, float4 count): Jtrel .. nzj | sel_pd2 .. par |
+// pk .. pb_ (each run may contain a scratch array or two; copying them is cheaper than splitting the run)
+extern "C" void bf_fit_image_segments(int nj, int nb, int npf, int ns, int nl, int np, int seg[6]) {
+    FitSmem s;
+    float *base = (float *)(uintptr_t)4096;
+    fit_smem_carve(s, base, nj, nb, npf, ns, nl, np, 0);
+    auto off4 = [&](const void *p) { return (int)(((const float *)p - base) / 4); };
+    seg[0] = off4(s.Jtrel); seg[1] = off4(s.kp) - seg[0];
+    seg[2] = off4(s.sel_pd2); seg[3] = off4(s.pa) - seg[2];
+    seg[4] = off4(s.pk); seg[5] = off4(s.am) - seg[4];
 }
 
 extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int np, int nviews) {

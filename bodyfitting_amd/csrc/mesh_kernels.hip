@@ -34,8 +34,8 @@ bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__r
                      const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
                      const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all) {
     __shared__ float lds[BF_POSE_STATE_LDS];
-    if (packed) bf_pose_state_body<true>(T, betas, orient, body_pose, sim, state, packed, cscale, cscale_all, blockIdx.x, threadIdx.x, 128, lds);
-    else bf_pose_state_body<false>(T, betas, orient, body_pose, sim, state, packed, cscale, cscale_all, blockIdx.x, threadIdx.x, 128, lds);
+    if (packed) bf_pose_state_body<true>(T, betas, orient, body_pose, sim, state, packed, cscale, cscale_all, blockIdx.x, threadIdx.x, 128, lds, bf_pose_tabs(T));
+    else bf_pose_state_body<false>(T, betas, orient, body_pose, sim, state, packed, cscale, cscale_all, blockIdx.x, threadIdx.x, 128, lds, bf_pose_tabs(T));
 }
 
 // grid (ceil(NV/32), F), block 96 x 8.  vraw = model-space vertices (lbs output), vout = (v + t) s c.

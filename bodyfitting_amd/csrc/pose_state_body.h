@@ -23,6 +23,18 @@ __device__ inline void m_rodrigues(float tx, float ty, float tz, float *R) {
 }
 }  // namespace
 
+// Where the body reads the model's small tables from: the FitTab's global arrays, or copies a caller already holds in LDS
+// (the fit kernel's tail: a dependent global load costs ~700 cycles, there are a dozen of them in a row here)
+struct PoseTabs {
+    const int *th_kind, *th_off, *parents;
+    const float *pose_mean, *hand_comp, *Jd, *Jt;
+    int jd_stride;                  // row stride of Jd (nb in the FitTab, padded in the fit kernel's LDS copy)
+    const int *level_joints, *level_start;
+};
+__device__ __forceinline__ PoseTabs bf_pose_tabs(const FitTab &T) {
+    return PoseTabs{T.th_kind, T.th_off, T.parents, T.pose_mean, T.hand_comp, T.Jd, T.Jt, T.nb, T.level_joints, T.level_start};
+}
+
 // One 128-thread workgroup per parameter set.  betas[n][nb], orient[n][3], body_pose[n][3(nj-1)];
 // transl / scale are taken as (0,0,0) / 1 / 1 when `sim` is null, else sim[n][5] = t, s, c.
 // `packed` != null: read everything from the optimiser-order parameter block packed[n][np] instead
@@ -32,14 +44,16 @@ template <bool PACKED>
 __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float *__restrict__ betas, const float *__restrict__ orient,
                                                    const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
                                                    const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all,
-                                                   const int f, const int tid, const int nt, float *lds) {
+                                                   const int f, const int tid, const int nt, float *lds, const PoseTabs P,
+                                                   const float *packed_lds = nullptr) {
     // lds: BF_POSE_STATE_LDS floats of workgroup-shared scratch
     float *R = lds, *J = R + 64 * 9, *GR = J + 64 * 3, *Gt = GR + 64 * 9;
     int *s_ls = (int *)(Gt + 64 * 3), *s_lj = s_ls + 66, *s_par = s_lj + 64;   // tree levels and parents: read once, not once per level (dependent global loads)
     const int nj = T.nj, nb = T.nb, npf = T.npf;
-    if (tid < nj) { s_lj[tid] = T.level_joints[tid]; s_par[tid] = T.parents[tid]; }
-    if (tid <= T.n_levels && tid < 66) s_ls[tid] = T.level_start[tid];
-    const float *pk = PACKED ? packed + (size_t)f * T.np : nullptr;
+    if (tid < nj) { s_lj[tid] = P.level_joints[tid]; s_par[tid] = P.parents[tid]; }
+    if (tid <= T.n_levels && tid < 66) s_ls[tid] = P.level_start[tid];
+    // (packed_lds: this frame's parameter block, already in LDS)
+    const float *pk = PACKED ? (packed_lds ? packed_lds : packed + (size_t)f * T.np) : nullptr;
     const float *beta;
     if constexpr (PACKED) beta = pk + T.off_beta; else beta = betas + (size_t)f * nb;
     StateView st = bf_state_view(state + (size_t)f * bf_state_stride(nj, npf, nb), nj, npf, nb);
@@ -47,7 +61,7 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
         float th[3];
         if constexpr (PACKED) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) th[k] = bf_theta(pk, tid, k, T.th_kind, T.th_off, T.pose_mean, T.hand_comp, T.n_pca, T.off_lh, T.off_rh);
+            for (int k = 0; k < 3; ++k) th[k] = bf_theta(pk, tid, k, P.th_kind, P.th_off, P.pose_mean, P.hand_comp, T.n_pca, T.off_lh, T.off_rh);
         } else {
             const float *src = tid == 0 ? orient + (size_t)f * 3 : body_pose + (size_t)f * 3 * (nj - 1) + 3 * (tid - 1);
             th[0] = src[0]; th[1] = src[1]; th[2] = src[2];
@@ -57,8 +71,8 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
     }
     for (int i = tid; i < nj * 3; i += nt) {
         float acc = 0.f;
-        for (int l = 0; l < nb; ++l) acc += T.Jd[i * nb + l] * beta[l];
-        J[i] = T.Jt[i] + acc;
+        for (int l = 0; l < nb; ++l) acc += P.Jd[i * P.jd_stride + l] * beta[l];
+        J[i] = P.Jt[i] + acc;
     }
     __syncthreads();
     if (tid < 9) GR[tid] = R[tid];

@@ -365,6 +365,28 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     return BF_OK;
 }
 
+// FitTab::lds_image of the model's dense-schedule fit instance: one launch in mode 2 runs the kernel's ordinary prologue and
+// dumps the LDS segment (everything up to the per-view projection matrices, which come last in the carve).  Built once per
+// model, under its lock, finished before the pointer becomes visible.
+static int ensure_fit_image(bf_batch *b, FrameIO io, const HyperDev &hd) {
+    bf_model *m = b->m;
+    std::lock_guard<std::mutex> g(m->lazy);
+    if (m->fit.lds_image) return BF_OK;
+    int seg[6];
+    bf_fit_image_segments(m->fit.nj, m->fit.nb, m->fit.npf, m->fit.ns, m->fit.nl, m->fit.np, seg);
+    const size_t bytes = (size_t)(seg[4] + seg[5] + 2 * ((m->fit.np + 3) / 4)) * 16;      // up to the end of am / av: everything before proj
+    FitTab T = m->fit;
+    T.lds_image_n4 = (int)(bytes / 16);
+    HIP_TRY(m->fit_image.alloc(bytes / sizeof(float)));
+    io.ext = b->ext.p; io.image_out = m->fit_image.p; io.n_frames = 1; io.emit_next = 0;
+    HIP_TRY(bf_fit_launch(&T, &io, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    m->fit.lds_image_n4 = T.lds_image_n4;
+    bf_fit_image_segments(m->fit.nj, m->fit.nb, m->fit.npf, m->fit.ns, m->fit.nl, m->fit.np, &m->fit.img_seg[0][0]);
+    m->fit.lds_image = m->fit_image.p;
+    return BF_OK;
+}
+
 // the loop of smplify.py:177-213 when a dense loss is present (use_mask, use_mesh, or the SMPL-X keypoints
 // with hands + face): iterations that need no dense loss run as one persistent launch; every other iteration
 // is state -> mesh -> losses -> reverse mesh pass -> one fit-kernel iteration (smplify.py:197-210).
@@ -390,6 +412,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     if (rc) return rc;
     if (n_plain > 0)
         HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream));
+    if (n_plain < n_iters) { rc = ensure_fit_image(b, io, hd); if (rc) return rc; }
     for (int it = n_plain; it < n_iters; ++it) {
         rc = dense_pass(b, h, hd, it > thr, 5.0f, it > n_plain);                       // smplify.py:210
         if (rc) return rc;

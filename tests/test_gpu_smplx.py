@@ -9,8 +9,9 @@ from bodyfitting_amd import synthetic as S
 from oracle import smplify_oracle as O
 
 pytestmark = pytest.mark.gpu
-SMPLX_MASK_LOOP_TOL = 5e-4     # 15 iterations, 10 with the silhouette loss, distances in the reference's own fp32 form (the
-                               # default, bf_hyper.mask_cdist_form = 1): observed 1.2e-4; with exact distances 3e-2
+SMPLX_MASK_LOOP_TOL = 2e-3     # 15 iterations, 10 with the silhouette loss, distances in the reference's own fp32 form (the
+                               # default, bf_hyper.mask_cdist_form = 1): observed 1.2e-4 - 8.1e-4 from build to build (fused
+                               # multiply-adds move); with exact distances 3e-2
 
 
 @pytest.fixture(scope="module")
