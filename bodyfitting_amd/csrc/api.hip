@@ -3,9 +3,9 @@
 
 extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
-extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *, const float *);
+extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *, const float *, int *, int);
 extern "C" int bf_mesh_use_multi(int npf, int n);
-extern "C" int bf_mesh_multi_launch(const MeshTab *, const float *, int, float *, float *, float *, float *, float *, hipStream_t, const MaskProj *);
+extern "C" int bf_mesh_multi_launch(const MeshTab *, const float *, int, float *, float *, float *, float *, float *, hipStream_t, const MaskProj *, int *, int);
 extern "C" __global__ void bf_mesh_epilogue_kernel(MeshTab, const float *, const float *, float *, float *, float *, float *);
 extern "C" hipError_t bf_poseblend_launch(const MeshTab *M, const float *state, int n, float *featT, int kpad, int fpad, float *pose_off, hipStream_t stream);
 extern "C" __global__ void bf_mesh_epilogue_batch_kernel(MeshTab M, const float *state, const float *pose_off, int n_frames, float *vraw, float *vout, float *xpart);
@@ -371,7 +371,7 @@ int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
 
 int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw, int *lmk_vid,
-                   float *lmk_w, float *dvzero, bool *zeroed, bool want_xpart, const MaskProj *mproj, bool *projected) {
+                   float *lmk_w, float *dvzero, bool *zeroed, bool want_xpart, const MaskProj *mproj, bool *projected, int *door, int door_target) {
     if (zeroed) *zeroed = false;
     if (projected) *projected = false;
     const bool need_x = joints || joints_ori || jraw || want_xpart;
@@ -404,13 +404,13 @@ int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev,
                            need_x ? xpart : (float *)nullptr, vposed);
     } else if (bf_mesh_use_multi(m->npf, n)) {
         const int e = bf_mesh_multi_launch(&m->mesh, state_dev, n, vraw, vout, need_x ? xpart : (float *)nullptr, vposed,
-                                           dvzero, stream, mproj);
+                                           dvzero, stream, mproj, door, door_target);
         if (projected && mproj) *projected = true;
         if (zeroed && dvzero) *zeroed = true;
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     } else
     hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, m->mesh,
-                       state_dev, vraw, vout, need_x ? xpart : (float *)nullptr, vposed, pose_off);
+                       state_dev, vraw, vout, need_x ? xpart : (float *)nullptr, vposed, pose_off, door, door_target);
     HIP_TRY(hipGetLastError());
     if (after_mesh) HIP_TRY(hipEventRecord(after_mesh, stream));
     if (joints || joints_ori || jraw) {
@@ -471,6 +471,14 @@ int bf_sync_all(bf_batch *b) {
     if (b->copy_stream) HIP_TRY(hipStreamSynchronize(b->copy_stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->copy_pending[0] = b->copy_pending[1] = false;
+    if (b->h_door_err && *b->h_door_err) {
+        const int who = *b->h_door_err;
+        *b->h_door_err = 0;
+        int d[BF_DOOR_STATE + 1] = {};
+        (void)hipMemcpy(d, b->door.p, sizeof d, hipMemcpyDeviceToHost);
+        return fail(BF_ERR_HIP, "dense schedule (bells: ext " + std::to_string(d[BF_DOOR_EXT]) + ", states " + std::to_string(d[BF_DOOR_STATE]) +
+                                    ", tickets " + std::to_string(d[BF_DOOR_TICKET]) + ", waiter " + std::to_string(who) + "): a doorbell wait between the persistent fit launch and the dense kernels ran into its time limit");
+    }
     return BF_OK;
 }
 
@@ -552,6 +560,10 @@ void bf_batch_destroy(bf_batch *b) {
         if (b->ev_copied[k]) (void)hipEventDestroy(b->ev_copied[k]);
     }
     if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
+    if (b->fit_stream) { (void)hipStreamSynchronize(b->fit_stream); (void)hipStreamDestroy(b->fit_stream); }
+    for (auto &e : b->ev_door) if (e) (void)hipEventDestroy(e);
+    if (b->h_door_err) (void)hipHostFree(b->h_door_err);
+    if (b->h_resident) (void)hipHostFree(b->h_resident);
     delete b;
 }
 
@@ -715,8 +727,9 @@ FrameIO bf_frame_io(bf_batch *b, bool want_grads) {
     io.debug = b->debug.p;
     io.cscale = b->cscale.p;          // null unless scans are attached
     io.ext = nullptr;
-    io.emit_next = 0;
     io.image_out = nullptr;
+    io.door = nullptr;
+    io.door_resident = nullptr;
     return io;
 }
 

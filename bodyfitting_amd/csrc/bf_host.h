@@ -104,6 +104,12 @@ struct bf_batch {
     size_t res_off[5] = {0, 0, 0, 0, 0}, res_cnt[5] = {0, 0, 0, 0, 0};   // params, terms, state, joints, vout
     int cur = 0;                    // arena the DevBuf views / h_* pointers are on
     hipStream_t copy_stream = nullptr;
+    // dense schedule with the fit kernel resident for the whole call (BfDoor, bf_internal.h)
+    hipStream_t fit_stream = nullptr;
+    hipEvent_t ev_door[2] = {nullptr, nullptr};
+    DevBuf<int> door;
+    int *h_resident = nullptr;          // pinned, device-visible: workgroups of the persistent launch that have started (this call)
+    int *h_door_err = nullptr;          // pinned; copied from door[BF_DOOR_ERR] at the end of a call, read by bf_sync_all
     hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
     bool copy_pending[2] = {false, false};
     hipGraphExec_t graph_pipe[2] = {nullptr, nullptr};   // kernels-only graphs of the pipelined path, one per arena
@@ -153,7 +159,7 @@ extern "C" {
 int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw = nullptr,
                    int *lmk_vid = nullptr, float *lmk_w = nullptr, float *dvzero = nullptr, bool *zeroed = nullptr, bool want_xpart = false,
-                   const MaskProj *mproj = nullptr, bool *projected = nullptr);
+                   const MaskProj *mproj = nullptr, bool *projected = nullptr, int *door = nullptr, int door_target = 0);
 // (dvzero: a [n][NV][3] buffer the forward pass should zero while it is at it - only the 1..15-frame kernel does, *zeroed says so;
 //  want_xpart: fill xpart although no joints are asked for here - the caller forms them itself;
 //  mproj: project the sampled vertices into the mask views as well - only the 1..15-frame kernel does, *projected says so)

@@ -161,6 +161,53 @@ struct MaskProj {
     float *uvi, *duvb;        // bf_mask_project_kernel's outputs
 };
 
+
+// Doorbells between the dense kernels of an iteration (batch stream) and the persistent fit launch (second stream) - the fit
+// kernel stays resident for all dense iterations of a call instead of being launched once per iteration (a launch starts with
+// cold instruction and data caches: ~25 us for this kernel, against ~6 us for a warm iteration).
+//   door[BF_DOOR_EXT]    = k: the outside gradient blocks `ext` of dense iteration k (1-based) are complete (rung by the last
+//                          workgroup of bf_ext_reduce_kernel)
+//   door[BF_DOOR_STATE + c * BF_DOOR_COPY_STRIDE], c < BF_DOOR_COPIES
+//                        = number of (frame, iteration) pose states the fit launch has published so far (each of its workgroups adds
+//                          1 per iteration, to every copy): iteration k's forward mesh pass waits for F * k.  Hundreds of workgroups
+//                          poll it at once, so it is replicated over cache lines 4 KB + 128 B apart (different memory channels) and a
+//                          workgroup polls the copy its index selects - one line would queue every poll behind the others.
+//   door[BF_DOOR_TICKET] = running count of finished bf_ext_reduce_kernel workgroups
+//   door[BF_DOOR_ERR]    = sticky: a wait ran into its time limit (the call fails with BF_ERR_HIP; nobody waits any more)
+#define BF_DOOR_EXT 0
+#define BF_DOOR_TICKET 1
+#define BF_DOOR_ERR 2
+#define BF_DOOR_STATE 64
+#define BF_DOOR_COPIES 32
+#define BF_DOOR_COPY_STRIDE 1056
+#define BF_DOOR_INTS (BF_DOOR_COPIES * BF_DOOR_COPY_STRIDE)
+#define BF_DOOR_LIMIT_TICKS 100000000LL        // 1 s of the 100 MHz wall clock
+
+#ifdef __HIPCC__
+// one thread: wait until *flag >= target (acquire at device scope); false = gave up (error flag set by somebody, or the time limit)
+__device__ inline bool bf_door_wait(int *door, int which, int target) {
+    // (polled with RELAXED device-scope loads: they are served past the non-coherent caches)
+    bool ok = true;
+    if (__hip_atomic_load(door + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        const long long t0 = wall_clock64();
+        for (;;) {
+            __builtin_amdgcn_s_sleep(8);
+            if (__hip_atomic_load(door + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+            if (__hip_atomic_load(door + BF_DOOR_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+            if (wall_clock64() - t0 > BF_DOOR_LIMIT_TICKS) {
+                __hip_atomic_store(door + BF_DOOR_ERR, which == BF_DOOR_EXT ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (1: the fit launch gave up, 2: a mesh pass)
+                ok = false;
+                break;
+            }
+        }
+    }
+    // (NO acquire fence here: on this multi-XCD part a device-scope acquire invalidates the XCD's whole L2, and hundreds of waiting
+    //  workgroups doing that under a streaming kernel doubled its run time.  Callers either have nothing stale to see - a kernel
+    //  starts with invalidated caches and has not touched the data before its wait - or read the data past the caches.)
+    return ok;
+}
+#endif
+
 // Dense keypoint loss inputs (device pointers / sizes).
 struct KpIO {
     int nl, n_views, nj, npf, nb, nv, n_all, n_selector, n_extra, n_lmk;
@@ -186,7 +233,8 @@ struct FrameIO {
     float *debug;             // optional dump of the first iteration's intermediates
     const float *cscale;      // [F] per-frame constant scale (scan_height / 1.7, smplify.py:156) or null
     float *image_out;         // mode 2 only: receives the LDS image (see FitTab::lds_image)
-    int emit_next;            // (with ext) leave the pose state of the STEPPED parameters instead of the last forward's
+    int *door;                // dense schedule, persistent fit launch: the doorbells it shares with the dense kernels (BfDoor), or null
+    int *door_resident;       // host-visible counter: every workgroup of the persistent launch adds 1 when it starts running
     const float *ext;         // [F][npf + nj*12 + nb + 4 + nj*3] gradients arriving from the dense losses (dfeat | per joint
                               //  rows of sum w dv (x) [vp|1] | dbeta | dt ds | dL/d(chain joint positions)), or null
 };

@@ -234,9 +234,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int npf = 9 * (nj - 1), np = T.np, V = io.n_views, ns3 = ns * 3, nj3 = nj * 3;
     FitSmem S;
     fit_smem_carve(S, smem_raw, nj, nb, npf, ns, nl, np, V);
-    // EXT launches (one iteration of the dense schedule) may end with the pose state of the parameters they just stepped - the
-    // arithmetic of bf_pose_state_kernel, bit for bit - so that the next iteration's mesh pass needs no launch in between
-    const bool emit = EXT && mode == 0 && io.emit_next;
+    // persistent form of the same launch (io.door): all dense iterations of a call in ONE launch, paced by doorbells
+    int *const door = EXT ? io.door : nullptr;
+    if (EXT && door && io.door_resident && tid == 0) __hip_atomic_fetch_add(io.door_resident, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 
     // ---- one-off loads --------------------------------------------------------------------
     const int nbp = pad4(nb + 1);
@@ -275,7 +275,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         const float *eg = io.ext + (size_t)frame * n_ext;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) if (q * nt + tid < n_ext) r_ext[q] = eg[q * nt + tid];
+        for (int q = 0; q < 3; ++q) if (!door && q * nt + tid < n_ext) r_ext[q] = eg[q * nt + tid];
         if (tid < nj) r_lj = T.level_joints[tid];
         if (tid <= T.n_levels) r_ls = T.level_start[tid];
         // zero-initialised arrays: GMM d / y, and the keypoint table when this launch has no loss joints
@@ -319,7 +319,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     copy_f(S.proj, io.proj + (size_t)frame * V * 12, V * 12, tid, nt);
     copy_f(S.pa, (io.params0 ? io.params0 : io.params) + (size_t)frame * np, np, tid, nt);
     if (EXT) {
-        if (mode != 2) copy_f(S.ext, io.ext + (size_t)frame * n_ext, n_ext, tid, nt);
+        if (mode != 2 && !door) copy_f(S.ext, io.ext + (size_t)frame * n_ext, n_ext, tid, nt);
         for (int i = tid; i < nj; i += nt) S.lvl[i] = T.level_joints[i];
         for (int i = tid; i <= T.n_levels && i < 67; i += nt) S.lvl[nj + i] = T.level_start[i];
     }
@@ -703,6 +703,44 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_MARK(44, 0, bf_it, bf_t0);
     };
 
+    // ---- persistent dense-schedule launch: the two ends of an iteration (called by EVERY thread: they synchronise) ----------
+    // top: wait for this iteration's outside gradient blocks and stage them in LDS
+#ifdef BF_STAMP
+    long long bf_d0 = 0;
+#define BF_DMARK(k) do { if (tid == 0) S.stamp[k] = (float)(long long)(clock64() - bf_d0); } while (0)
+#else
+#define BF_DMARK(k) do { } while (0)
+#endif
+    // The pose state the iteration's forward mesh pass is waiting for: bf_pose_state_kernel's code (correctly rounded sqrt /
+    // division, OCML sin / cos: the fit kernel's own phase A uses 1-ulp forms, and a silhouette loss turns a last-bit difference in
+    // a vertex into a different nearest-vertex choice), run by ONE wave of the GMM group while the geometry waves are in phase A,
+    // from the LDS copies of the model's tables; the view-sum slots (dead until phase D) are its scratch.
+    auto door_state = [&](const float *P) {
+        const PoseTabs PT{S.thk, S.tho, S.par, S.pmean, S.hcomp, S.Jd, S.Jt, pad4(nb + 1), S.lvl, S.lvl + nj};
+        bf_pose_state_body<true, true>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, lane, 64, S.part, PT, P);
+    };
+    static_assert(BF_VSUB * 32 * 4 >= BF_POSE_STATE_LDS, "the view-sum slots are the pose-state scratch");
+    // Between phase A and the rest of an iteration (called by EVERY thread: it synchronises): publish that state, then wait for the
+    // outside gradient blocks the dense kernels make of it and stage them in LDS.
+    auto door_mid = [&](int it, const float *P) {
+#ifdef BF_STAMP
+        bf_d0 = clock64();
+#endif
+        // (the state itself was written during phase A by wave 7: door_state below)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        BF_DMARK(56);
+        if (tid < BF_DOOR_COPIES) __hip_atomic_fetch_add(door + BF_DOOR_STATE + tid * BF_DOOR_COPY_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) bf_door_wait(door, BF_DOOR_EXT, it + 1);
+        BF_DMARK(57);
+        __syncthreads();
+        // (the blocks were read through this CU's caches an iteration ago: device-scope loads go past them, no invalidate)
+        float *eg = const_cast<float *>(io.ext) + (size_t)frame * n_ext;
+        for (int i = tid; i < n_ext; i += nt) S.ext[i] = __hip_atomic_load(eg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        BF_DMARK(58);
+    };
+
 #ifndef BF_NO_GMM
     if (gw) {
         // ================= GMM specialists (waves 4-7): the precision rows never leave their registers
@@ -746,7 +784,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             BF_GMM_CHUNK(0)
             BF_GMM_CHUNK(1)
             BF_GMM_CHUNK(2)
+            if (EXT && door && wave == 7) door_state(Pcur);
             BF_SYNC();                 // A
+            if (EXT && door) door_mid(it, Pcur);
             if (merge_bc) {
                 // (the geometry waves do the merged pose blend + skinning alone)
                 BF_GMM_CHUNK(3)
@@ -910,6 +950,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             BF_MARK(41, 0, it, t_iter);
         }
         BF_SYNC();
+        if (EXT && door) door_mid(it, Pcur);
 
         if (merge_bc) {
             // ================= phase B (+C): pose blend and skinning of the selector vertices in one phase
@@ -1591,9 +1632,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_SYNC();
         if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
     }
-    if (!emit) {   // ---- after the last iteration: loss terms (loss.py:219-224) and the pose state of the LAST forward pass, i.e. of
-        // the parameters before the final Adam step (they sit in Pnext after the swap).  (A dense-schedule launch that emits the
-        // state of the stepped parameters is not the last one: nobody reads its terms, and its state is written by the tail.)
+    {   // ---- after the last iteration: loss terms (loss.py:219-224) and the pose state of the LAST forward pass, i.e. of
+        // the parameters before the final Adam step (they sit in Pnext after the swap)
         const float *Pold = mode == 0 ? Pnext : Pcur;
         const float grad = grad_last;
         {
@@ -1655,19 +1695,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         io.params[(size_t)frame * np + tid] = Pcur[tid];
         io.adam_m[(size_t)frame * np + tid] = S.am[tid];
         io.adam_v[(size_t)frame * np + tid] = S.av[tid];
-    }
-    if constexpr (EXT) {
-        if (emit) {                                   // (block-uniform)
-            __syncthreads();                          // the stepped parameters above are visible to the whole workgroup
-            // (every LDS buffer of the fit is dead by now: its first bytes are the scratch)
-            BF_KMARK(6, 0);
-            // the model's small tables and the stepped parameters are in LDS already; the keypoint table (dead by now, 6144 floats)
-            // is the scratch.  Same arithmetic as bf_pose_state_kernel: only the addresses differ.
-            const PoseTabs PT{S.thk, S.tho, S.par, S.pmean, S.hcomp, S.Jd, S.Jt, pad4(nb + 1), S.lvl, S.lvl + nj};
-            static_assert(BF_VSUB * BF_KP_ROUNDS * 16 * 8 >= BF_POSE_STATE_LDS, "the keypoint table is the pose-state scratch");
-            bf_pose_state_body<true>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nt, S.kp, PT, Pcur);
-            BF_KMARK(7, 0);
-        }
     }
 }
 

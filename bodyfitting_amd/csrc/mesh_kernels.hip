@@ -46,7 +46,7 @@ bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__r
 #define BF_MESH_WPF 24     // lbs weights prefetched per vertex thread
 extern "C" __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
 bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ vraw, float *__restrict__ vout,
-               float *__restrict__ xpart, float *__restrict__ vposed, const float *__restrict__ pose_off) {
+               float *__restrict__ xpart, float *__restrict__ vposed, const float *__restrict__ pose_off, int *door, int door_target) {
     constexpr int COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
@@ -102,6 +102,11 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
         const float *row = M.j_extra + (size_t)e * nv + v0;
 #pragma unroll
         for (int i = 0; i < BF_MESH_TILE; ++i) if (v0 + i < nv) jx[i] = row[i];
+    }
+    if (door) {        // the pose state comes from the persistent fit launch (BfDoor): wait for it under the requests above
+        if (tid == 0) bf_door_wait(door, BF_DOOR_STATE + (int)((blockIdx.x + 7 * blockIdx.y) % BF_DOOR_COPIES) * BF_DOOR_COPY_STRIDE, door_target);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // (cold caches at kernel start, first read of the state below)
     }
     for (int i = tid; i < npf; i += nt) s_feat[i] = st.feat[i];
     for (int i = tid; i < nj * 12; i += nt) {
@@ -191,7 +196,7 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
 template <int FPW>
 __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
 bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, float *__restrict__ vraw, float *__restrict__ vout,
-                     float *__restrict__ xpart, float *__restrict__ vposed, float *__restrict__ dvzero, MaskProj mp) {
+                     float *__restrict__ xpart, float *__restrict__ vposed, float *__restrict__ dvzero, MaskProj mp, int *door, int door_target) {
     static_assert(FPW == 1 || FPW == 2 || FPW == 4 || FPW == 8, "frames per workgroup");
     constexpr int COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
@@ -216,6 +221,12 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
     float pv[BF_MM_CH];
 #pragma unroll
     for (int i = 0; i < BF_MM_CH; ++i) pv[i] = p0 + i < p1 ? pd[(size_t)i * ncols] : 0.f;
+    if (door) {        // the pose states come from the persistent fit launch (BfDoor): wait for all of them, under the first chunk's loads
+        if (tid == 0) bf_door_wait(door, BF_DOOR_STATE + (int)((blockIdx.x + 7 * blockIdx.y) % BF_DOOR_COPIES) * BF_DOOR_COPY_STRIDE, door_target);
+        __syncthreads();
+        // (this kernel started with invalidated caches and reads the states for the first time below: nothing stale to drop)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     for (int i = tid; i < npad * FPW; i += nt) {
         const int p = i / FPW, f = i - p * FPW;
         s_feat[i] = (p < npf && f < nf) ? bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).feat[p] : 0.f;
@@ -355,7 +366,7 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
 }
 
 extern "C" int bf_mesh_multi_launch(const MeshTab *M, const float *state, int n, float *vraw, float *vout, float *xpart, float *vposed,
-                                    float *dvzero, hipStream_t stream, const MaskProj *mproj) {
+                                    float *dvzero, hipStream_t stream, const MaskProj *mproj, int *door, int door_target) {
     MaskProj mp;
     if (mproj) mp = *mproj; else { std::memset(&mp, 0, sizeof mp); }
     constexpr int COLS = BF_MESH_TILE * 3;
@@ -371,10 +382,10 @@ extern "C" int bf_mesh_multi_launch(const MeshTab *M, const float *state, int n,
         if (e != hipSuccess) return (int)e;
     }
     switch (fpw) {
-    case 1: hipLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp); break;
-    case 2: hipLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp); break;
-    case 4: hipLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp); break;
-    default: hipLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp); break;
+    case 1: hipLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target); break;
+    case 2: hipLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target); break;
+    case 4: hipLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target); break;
+    default: hipLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target); break;
     }
     return (int)hipGetLastError();
 }

@@ -40,7 +40,9 @@ __device__ __forceinline__ PoseTabs bf_pose_tabs(const FitTab &T) {
 // `packed` != null: read everything from the optimiser-order parameter block packed[n][np] instead
 // (transl, scale from it; constant scale from cscale[n] or cscale_all).
 // Called by EVERY thread of the workgroup (it synchronises); `nt` = the workgroup's thread count.
-template <bool PACKED>
+// WAVE: the caller is ONE wavefront (tid = lane, nt = 64) with `lds` to itself: barriers become wave fences (a wave's LDS
+// operations execute in order), everything else - the arithmetic included - is the same code.
+template <bool PACKED, bool WAVE = false>
 __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float *__restrict__ betas, const float *__restrict__ orient,
                                                    const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
                                                    const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all,
@@ -74,10 +76,10 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
         for (int l = 0; l < nb; ++l) acc += P.Jd[i * P.jd_stride + l] * beta[l];
         J[i] = P.Jt[i] + acc;
     }
-    __syncthreads();
+    if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     if (tid < 9) GR[tid] = R[tid];
-    if (tid >= 64 && tid < 67) Gt[tid - 64] = J[tid - 64];
-    __syncthreads();
+    if (tid >= 9 && tid < 12) Gt[tid - 9] = J[tid - 9];
+    if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     for (int lev = 1; lev < T.n_levels; ++lev) {
         int ls = s_ls[lev], cnt = (s_ls[lev + 1] - ls) * 3;
         for (int idx = tid; idx < cnt; idx += nt) {
@@ -90,7 +92,7 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
             float r0 = J[i * 3] - J[p * 3], r1 = J[i * 3 + 1] - J[p * 3 + 1], r2 = J[i * 3 + 2] - J[p * 3 + 2];
             Gt[i * 3 + r] = g0 * r0 + g1 * r1 + g2 * r2 + Gt[p * 3 + r];
         }
-        __syncthreads();
+        if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     }
     for (int i = tid; i < nj * 9; i += nt) st.GR[i] = GR[i];
     for (int i = tid; i < nj * 3; i += nt) {

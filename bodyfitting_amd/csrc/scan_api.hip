@@ -1,6 +1,7 @@
 // Host side of the scan (use_mesh) path: grid construction, closest-point queries, and the per-iteration
 // schedule of smplify.py:205-213 with the point-cloud loss switched on after num_iters // 3.
 #include "bf_host.h"
+#include <chrono>
 
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
 extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int, int *, float *, float *, int);
@@ -8,7 +9,8 @@ extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, in
 extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const float *, int, const float *, const float *, const float *, float *, hipStream_t,
                                         const float *, int, int);
-extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int);
+extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int, int *, int);
+extern "C" int bf_mesh_use_multi(int npf, int n);
 extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
                                              const float *, float *, float *, float *, MeshTab, const float *, const float *);
 extern "C" __global__ void bf_grid_count_kernel(ScanDev, int *);
@@ -317,11 +319,12 @@ static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
 }
 
 // one dense iteration's forward + loss + reverse passes up to `ext` (everything except the fit kernel itself)
-static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight, bool have_state = false) {
+// door / door_k: the persistent fit launch's doorbells and this pass's 1-based dense iteration (null / 0: fit launches per iteration)
+static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight, int *door = nullptr, int door_k = 0) {
     bf_model *m = b->m;
     const int F = b->F, nv = m->nv, nblk = (nv + 255) / 256;
     const bool scans = late && !b->scans.empty(), masks = late && b->has_masks, kp = m->kp_dense;
-    if (!have_state) {               // (inside the loop the previous iteration's fit launch left the state of the parameters it stepped)
+    if (!door) {                     // (with the resident fit launch every state comes from it)
         hipLaunchKernelGGL(bf_pose_state_kernel, dim3(F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
                            (const float *)b->params.p, (const float *)b->cscale.p, hd.cscale);
@@ -336,7 +339,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     }
     int rc = bf_launch_mesh(m, &b->scratch, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
                             b->vposed.p, nullptr, nullptr, nullptr, (kp || masks) ? b->dvout.p : nullptr, &zeroed, kp, masks ? &mp : nullptr,
-                            &projected);
+                            &projected, door, F * door_k);
     if (rc) return rc;
     if ((kp || masks) && !zeroed) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
     if (kp && !masks) { rc = launch_kp(b, h); if (rc) return rc; }
@@ -360,7 +363,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_bwd_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     }
     hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 31) / 32, F), dim3(256), 0, b->stream,
-                       (const float *)b->ext_part.p, m->mesh.n_tiles, EXT, b->ext.p, EXT + m->nj * 3 + 4);
+                       (const float *)b->ext_part.p, m->mesh.n_tiles, EXT, b->ext.p, EXT + m->nj * 3 + 4, door, door_k);
     HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -378,7 +381,7 @@ static int ensure_fit_image(bf_batch *b, FrameIO io, const HyperDev &hd) {
     FitTab T = m->fit;
     T.lds_image_n4 = (int)(bytes / 16);
     HIP_TRY(m->fit_image.alloc(bytes / sizeof(float)));
-    io.ext = b->ext.p; io.image_out = m->fit_image.p; io.n_frames = 1; io.emit_next = 0;
+    io.ext = b->ext.p; io.image_out = m->fit_image.p; io.n_frames = 1;
     HIP_TRY(bf_fit_launch(&T, &io, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     m->fit.lds_image_n4 = T.lds_image_n4;
@@ -413,12 +416,61 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     if (n_plain > 0)
         HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream));
     if (n_plain < n_iters) { rc = ensure_fit_image(b, io, hd); if (rc) return rc; }
+    // The dense iterations with the fit kernel RESIDENT (one launch on a second stream, paced by doorbells, BfDoor) when the
+    // forward pass is a kernel that knows how to wait (1..15 frames); BF_DENSE_PERSISTENT=0, or a larger batch, keeps one fit launch
+    // per iteration, with the pose state from bf_pose_state_kernel every time.
+    static const bool door_ok = [] { const char *e = std::getenv("BF_DENSE_PERSISTENT"); return !(e && e[0] == '0'); }();
+    const int n_dense = n_iters - n_plain;
+    if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES) {
+        if (!b->fit_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&b->fit_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_door[0], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_door[1], hipEventDisableTiming));
+            HIP_TRY(b->door.alloc(BF_DOOR_INTS));
+            HIP_TRY(hipHostMalloc((void **)&b->h_door_err, sizeof(int)));
+            HIP_TRY(hipHostMalloc((void **)&b->h_resident, sizeof(int)));
+            *b->h_door_err = 0;
+            // first use of the new stream: its queue, the kernel's code object and scratch come up now, not under a mesh pass that is
+            // already waiting for this launch (mode 2 = prologue only)
+            FrameIO iow = io;
+            iow.ext = b->ext.p; iow.image_out = nullptr; iow.n_frames = 1;
+            HIP_TRY(bf_fit_launch(&m->fit, &iow, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->fit_stream));
+            HIP_TRY(hipStreamSynchronize(b->fit_stream));
+        }
+        *(volatile int *)b->h_resident = 0;
+        HIP_TRY(hipMemsetAsync(b->door.p, 0, BF_DOOR_INTS * sizeof(int), b->stream));
+        HIP_TRY(hipEventRecord(b->ev_door[0], b->stream));              // parameters / Adam state / doorbells as the loop finds them
+        HIP_TRY(hipStreamWaitEvent(b->fit_stream, b->ev_door[0], 0));
+        FrameIO io2 = io;
+        io2.ext = b->ext.p; io2.door = b->door.p; io2.door_resident = b->h_resident;
+        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_dense, 0, b->adam_tab.p, b->steps_done + n_plain, b->fit_smem, b->fit_stream));
+        HIP_TRY(hipEventRecord(b->ev_door[1], b->fit_stream));
+        for (int it = n_plain; it < n_iters; ++it) {
+            if (it == n_plain) {
+                // the mesh passes WAIT for the fit launch: every one of its workgroups must be running before such a
+                // pass can fill the machine
+                const auto t0 = std::chrono::steady_clock::now();
+                while (*(volatile int *)b->h_resident < F) {
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                        const int one = 1;      // let everybody through, then fail the call
+                        (void)hipMemcpy(b->door.p + BF_DOOR_ERR, &one, sizeof one, hipMemcpyHostToDevice);
+                        (void)hipStreamSynchronize(b->fit_stream);
+                        return fail(BF_ERR_HIP, "dense schedule: the persistent fit launch did not start");
+                    }
+                }
+            }
+            rc = dense_pass(b, h, hd, it > thr, 5.0f, b->door.p, it - n_plain + 1);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_door[1], 0));       // the last iteration's step, terms and state
+        HIP_TRY(hipMemcpyAsync(b->h_door_err, b->door.p + BF_DOOR_ERR, sizeof(int), hipMemcpyDeviceToHost, b->stream));
+        return BF_OK;
+    }
     for (int it = n_plain; it < n_iters; ++it) {
-        rc = dense_pass(b, h, hd, it > thr, 5.0f, it > n_plain);                       // smplify.py:210
+        rc = dense_pass(b, h, hd, it > thr, 5.0f);                                     // smplify.py:210
         if (rc) return rc;
         FrameIO io2 = io;
         io2.ext = b->ext.p;
-        io2.emit_next = it + 1 < n_iters;             // (the last launch leaves the state of the last forward: the result mesh)
         HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, b->fit_smem, b->stream));
     }
     return BF_OK;

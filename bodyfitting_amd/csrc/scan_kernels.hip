@@ -504,7 +504,7 @@ extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT
 // A chunk lane adds its contiguous run of tiles in tile order (loads issued eight at a time: a plain serial loop costs
 // one memory latency per tile), then the eight chunk sums are added in chunk order: a fixed order, run to run.
 extern "C" __global__ void __launch_bounds__(256)
-bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float *__restrict__ ext, int ext_stride) {
+bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float *__restrict__ ext, int ext_stride, int *door, int door_k) {
     __shared__ float s_c[8][32];
     const int li = threadIdx.x & 31, ch = threadIdx.x >> 5, i = blockIdx.x * 32 + li, f = blockIdx.y;
     const int per = (n_tiles + 7) / 8, t0 = ch * per, t1 = min(n_tiles, t0 + per);
@@ -528,6 +528,15 @@ bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float
 #pragma unroll
         for (int c = 0; c < 8; ++c) tot += s_c[c][li];
         ext[(size_t)f * ext_stride + i] = tot;
+    }
+    if (door) {        // the last workgroup to finish rings the fit launch's bell for dense iteration door_k (BfDoor)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int total = gridDim.x * gridDim.y;
+            const int t = __hip_atomic_fetch_add(door + BF_DOOR_TICKET, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == total * door_k - 1) __hip_atomic_store(door + BF_DOOR_EXT, door_k, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
