@@ -362,6 +362,61 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         K.joint_map = m->kp_jm.p; K.selector_ids = m->selector_ids.p; K.cj_start = m->cj_start.p; K.cj_list = m->cj_list.p;
     }
     m->mesh_smem = bf_mesh_smem_bytes(nj, npf, nb);
+    {
+        // ---- sampled-first sub-model (bf_model::Sub) ------------------------------------------------------------------
+        std::vector<int> pos(nv, -1), S;
+        for (int v = 0; v < nv; v += 4) { pos[v] = (int)S.size(); S.push_back(v); }
+        const int n_samp = (int)S.size();
+        std::vector<char> extra(nv, 0);
+        for (int i = 0; i < d->n_selector; ++i) extra[d->selector_ids[i]] = 1;
+        if (smplx) {
+            auto face = [&](int fidx) { if (fidx >= 0 && fidx < d->n_faces) for (int c = 0; c < 3; ++c) extra[d->faces[(size_t)fidx * 3 + c]] = 1; };
+            for (int i = 0; i < d->n_lmk_static; ++i) face(d->lmk_faces_idx[i]);
+            for (size_t i = 0; i < (size_t)d->n_dyn_rows * d->n_lmk_dynamic; ++i) face(d->dynamic_lmk_faces_idx[i]);
+        }
+        for (int v = 0; v < nv; ++v) if (extra[v] && pos[v] < 0) { pos[v] = (int)S.size(); S.push_back(v); }
+        const int sv = (int)S.size();
+        if (sv * 10 <= nv * 6) {
+            bf_model::Sub &U = m->sub;
+            std::vector<float> vt((size_t)sv * 3), sd((size_t)sv * 3 * nb), pd((size_t)npf * 3 * sv), lw((size_t)sv * nj), jx((size_t)std::max(d->n_extra, 0) * sv);
+            const int nnz = m->mesh.v_nnz;
+            std::vector<int> zj((size_t)sv * std::max(nnz, 1), 0), sel(d->n_selector), fc;
+            std::vector<float> zw((size_t)sv * std::max(nnz, 1), 0.f);
+            for (int i = 0; i < sv; ++i) {
+                const int v = S[i];
+                for (int k = 0; k < 3; ++k) {
+                    vt[(size_t)i * 3 + k] = d->v_template[(size_t)v * 3 + k];
+                    for (int l = 0; l < nb; ++l) sd[((size_t)i * 3 + k) * nb + l] = d->shapedirs[((size_t)v * 3 + k) * nb + l];
+                    for (int p = 0; p < npf; ++p) pd[(size_t)p * 3 * sv + (size_t)i * 3 + k] = d->posedirs[(size_t)p * 3 * nv + (size_t)v * 3 + k];
+                }
+                int c = 0;
+                for (int j = 0; j < nj; ++j) {
+                    const float w = d->lbs_weights[(size_t)v * nj + j];
+                    lw[(size_t)i * nj + j] = w;
+                    if (nnz && w != 0.f) { zj[(size_t)i * nnz + c] = j; zw[(size_t)i * nnz + c] = w; ++c; }
+                }
+                for (int e = 0; e < d->n_extra; ++e) jx[(size_t)e * sv + i] = d->j_regressor_extra[(size_t)e * nv + v];
+            }
+            for (int i = 0; i < d->n_selector; ++i) sel[i] = pos[d->selector_ids[i]];
+            if (smplx) {            // faces re-indexed; a corner outside the sub-model belongs to a face no landmark uses
+                fc.resize((size_t)d->n_faces * 3);
+                for (size_t i = 0; i < fc.size(); ++i) fc[i] = std::max(pos[d->faces[i]], 0);
+            }
+            bool up = U.v_template.upload(vt) == hipSuccess && U.shapedirs.upload(sd) == hipSuccess && U.posedirs.upload(pd) == hipSuccess &&
+                      U.lbs_weights.upload(lw) == hipSuccess && U.j_extra.upload(jx) == hipSuccess && U.v_nzj.upload(zj) == hipSuccess &&
+                      U.v_nzw.upload(zw) == hipSuccess && U.selector_ids.upload(sel) == hipSuccess && U.faces.upload(fc) == hipSuccess;
+            if (!up) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (sub-model)"); }
+            U.mesh = m->mesh;
+            U.mesh.nv = sv; U.mesh.n_tiles = (sv + BF_MESH_TILE - 1) / BF_MESH_TILE;
+            U.mesh.v_template = U.v_template.p; U.mesh.shapedirs = U.shapedirs.p; U.mesh.posedirs = U.posedirs.p;
+            U.mesh.lbs_weights = U.lbs_weights.p; U.mesh.j_extra = U.j_extra.p; U.mesh.selector_ids = U.selector_ids.p;
+            U.mesh.v_nzj = U.v_nzj.p; U.mesh.v_nzw = U.v_nzw.p;
+            if (smplx) U.mesh.faces = U.faces.p;
+            U.kp = m->kp; U.kp.nv = sv; U.kp.selector_ids = U.selector_ids.p;
+            U.ns = n_samp;
+            U.on = true;
+        }
+    }
     *out = m;
     return BF_OK;
 }
@@ -371,13 +426,15 @@ int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
 
 int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw, int *lmk_vid,
-                   float *lmk_w, float *dvzero, bool *zeroed, bool want_xpart, const MaskProj *mproj, bool *projected, int *door, int door_target) {
+                   float *lmk_w, float *dvzero, bool *zeroed, bool want_xpart, const MaskProj *mproj, bool *projected, int *door, int door_target,
+                   const MeshTab *tab) {
     if (zeroed) *zeroed = false;
     if (projected) *projected = false;
     const bool need_x = joints || joints_ori || jraw || want_xpart;
-    dim3 grid(m->mesh.n_tiles, n);
+    const MeshTab &Q = tab ? *tab : m->mesh;          // (the sampled-first sub-model inside a dense loop without scans)
+    dim3 grid(Q.n_tiles, n);
     const float *pose_off = nullptr;
-    if (n >= BF_MFMA_MIN_FRAMES) {
+    if (n >= BF_MFMA_MIN_FRAMES && !tab) {
         // batched pose blend on the matrix cores (posedirs streamed once for up to 256 frames), then the per-frame
         // shape / skinning part only
         const size_t ncols = (size_t)m->nv * 3;
@@ -403,18 +460,18 @@ int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev,
         hipLaunchKernelGGL(bf_mesh_epilogue_kernel, grid, dim3(128), 0, stream, m->mesh, state_dev, pose_off, vraw, vout,
                            need_x ? xpart : (float *)nullptr, vposed);
     } else if (bf_mesh_use_multi(m->npf, n)) {
-        const int e = bf_mesh_multi_launch(&m->mesh, state_dev, n, vraw, vout, need_x ? xpart : (float *)nullptr, vposed,
+        const int e = bf_mesh_multi_launch(&Q, state_dev, n, vraw, vout, need_x ? xpart : (float *)nullptr, vposed,
                                            dvzero, stream, mproj, door, door_target);
         if (projected && mproj) *projected = true;
         if (zeroed && dvzero) *zeroed = true;
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     } else
-    hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, m->mesh,
+    hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, Q,
                        state_dev, vraw, vout, need_x ? xpart : (float *)nullptr, vposed, pose_off, door, door_target);
     HIP_TRY(hipGetLastError());
     if (after_mesh) HIP_TRY(hipEventRecord(after_mesh, stream));
     if (joints || joints_ori || jraw) {
-        hipLaunchKernelGGL(bf_joints_kernel, dim3(n), dim3(256), 0, stream, m->mesh, state_dev, (const float *)vraw,
+        hipLaunchKernelGGL(bf_joints_kernel, dim3(n), dim3(256), 0, stream, Q, state_dev, (const float *)vraw,
                            (const float *)xpart, joints, joints_ori, jraw, lmk_vid, lmk_w);
         HIP_TRY(hipGetLastError());
     }

@@ -72,6 +72,18 @@ struct bf_model {
     KpIO kp{};
     DevBuf<int> v_nzj;            // sparse skinning rows (MeshTab::v_nnz)
     DevBuf<float> v_nzw;
+    // The sampled-first sub-model: the vertices the dense losses of a fit WITHOUT scans can touch - every 4th vertex (the
+    // silhouette loss, loss.py:99) first, then the selector and landmark vertices of the dense keypoint loss - with the model's
+    // tables gathered for them.  The loop's forward / reverse mesh passes then stream ~30 % of posedirs; the result mesh after
+    // the loop is the full model's.
+    struct Sub {
+        bool on = false;
+        int ns = 0;                   // sampled vertices = the first ns of the sub-model
+        MeshTab mesh{};
+        KpIO kp{};
+        DevBuf<float> v_template, shapedirs, posedirs, lbs_weights, j_extra, v_nzw, posedirsT;
+        DevBuf<int> v_nzj, selector_ids, faces;
+    } sub;
     DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass (under `lazy`, device-synchronised)
     DevBuf<float> fit_image;      // FitTab::lds_image of the dense-schedule fit instance, built on first use (under `lazy`)
     std::mutex lazy;              // guards the build-on-first-use tables (posedirsT, faces_d / adj)
@@ -159,7 +171,8 @@ extern "C" {
 int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw = nullptr,
                    int *lmk_vid = nullptr, float *lmk_w = nullptr, float *dvzero = nullptr, bool *zeroed = nullptr, bool want_xpart = false,
-                   const MaskProj *mproj = nullptr, bool *projected = nullptr, int *door = nullptr, int door_target = 0);
+                   const MaskProj *mproj = nullptr, bool *projected = nullptr, int *door = nullptr, int door_target = 0,
+                   const MeshTab *tab = nullptr);
 // (dvzero: a [n][NV][3] buffer the forward pass should zero while it is at it - only the 1..15-frame kernel does, *zeroed says so;
 //  want_xpart: fill xpart although no joints are asked for here - the caller forms them itself;
 //  mproj: project the sampled vertices into the mask views as well - only the 1..15-frame kernel does, *projected says so)

@@ -145,6 +145,7 @@ struct ScanDev {
 struct MaskIO {
     int nv, ns, n_views, n_masks, H, W, cmax, part_stride, proj_blocks;
     int cdist;                            // 1 = distances in torch.cdist's expanded fp32 form (loss.py:108), 0 = exact
+    int sstride;                          // the sampled vertices are vertices s * sstride: 4 on the model (loss.py:99), 1 on the sampled-first sub-model
     float imsize, eps, weight;            // weight = 5 (smplify.py:210)
     const int *view_index;                // [M] index of each mask view among the V views
     const unsigned char *masks;           // [F][M][H][W], 1 = foreground (already > 128, smplify.py:139)

@@ -35,7 +35,7 @@
 // barrier of iteration 2 into io.debug[4096..]; the product library has no stamps.
 #ifdef BF_STAMP
 #define BF_SYNC() do { __syncthreads(); if (tid == 0 && (it == 2 || EXT) && sidx < 32) { S.stamp[sidx] = (float)(long long)(clock64() - t_iter); } ++sidx; } while (0)
-#define BF_MARK(k, who, itv, t0v) do { if (tid == (who) && (itv) == 2) S.stamp[k] = (float)(long long)(clock64() - (t0v)); } while (0)
+#define BF_MARK(k, who, itv, t0v) do { if (tid == (who) && ((itv) == 2 || EXT)) S.stamp[k] = (float)(long long)(clock64() - (t0v)); } while (0)
 #else
 #define BF_SYNC() __syncthreads()
 #define BF_MARK(k, who, itv, t0v) do { (void)(itv); (void)(t0v); } while (0)
@@ -713,11 +713,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #endif
     // The pose state the iteration's forward mesh pass is waiting for: bf_pose_state_kernel's code (correctly rounded sqrt /
     // division, OCML sin / cos: the fit kernel's own phase A uses 1-ulp forms, and a silhouette loss turns a last-bit difference in
-    // a vertex into a different nearest-vertex choice), run by ONE wave of the GMM group while the geometry waves are in phase A,
+    // a vertex into a different nearest-vertex choice), run by wave 3 - idle in phase A - while waves 0-2 form the chain,
     // from the LDS copies of the model's tables; the view-sum slots (dead until phase D) are its scratch.
     auto door_state = [&](const float *P) {
         const PoseTabs PT{S.thk, S.tho, S.par, S.pmean, S.hcomp, S.Jd, S.Jt, pad4(nb + 1), S.lvl, S.lvl + nj};
-        bf_pose_state_body<true, true>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, lane, 64, S.part, PT, P);
+        bf_pose_state_body<true, true, false>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, lane, 64, S.part, PT, P);
     };
     static_assert(BF_VSUB * 32 * 4 >= BF_POSE_STATE_LDS, "the view-sum slots are the pose-state scratch");
     // Between phase A and the rest of an iteration (called by EVERY thread: it synchronises): publish that state, then wait for the
@@ -726,7 +726,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #ifdef BF_STAMP
         bf_d0 = clock64();
 #endif
-        // (the state itself was written during phase A by wave 7: door_state below)
+        // (wave 3 left the rotations, chain matrices and joints of the state in the scratch during phase A: everybody writes the record)
+        bf_pose_state_emit<true>(T, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nt, S.part, nullptr, P);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __syncthreads();
         BF_DMARK(56);
@@ -784,7 +785,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             BF_GMM_CHUNK(0)
             BF_GMM_CHUNK(1)
             BF_GMM_CHUNK(2)
-            if (EXT && door && wave == 7) door_state(Pcur);
             BF_SYNC();                 // A
             if (EXT && door) door_mid(it, Pcur);
             if (merge_bc) {
@@ -948,6 +948,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             // A_j translation row: Gt_j - GR_j J_j (J of this pass was formed with the betas, in the Adam phase)
             if (cw_on) S.At[wjq * 3 + wave] = row.w - (row.x * jj0 + row.y * jj1 + row.z * jj2);
             BF_MARK(41, 0, it, t_iter);
+        } else if (EXT && door) {         // wave 3 has nothing of its own in this phase
+            door_state(Pcur);
+            BF_MARK(59, 192, it, t_iter);
         }
         BF_SYNC();
         if (EXT && door) door_mid(it, Pcur);

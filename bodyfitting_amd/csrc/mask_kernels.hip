@@ -34,7 +34,7 @@ bf_mask_project_kernel(MaskIO K, const float *__restrict__ vout, const float *__
     const int s = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y, f = blockIdx.z;
     float lval = 0.f;
     if (s < K.ns) {
-        const float *X = vout + ((size_t)f * K.nv + (size_t)s * 4) * 3;
+        const float *X = vout + ((size_t)f * K.nv + (size_t)s * K.sstride) * 3;
         lval = bf_mask_project_one(K, X[0], X[1], X[2], proj_all, f, m, s, uvi, duvb);
     }
     lval = mk_wave_sum(lval);
@@ -126,7 +126,7 @@ bf_mask_gsum_kernel(MaskIO K, const float *__restrict__ gpart, float *__restrict
         const float *p = gpart + (((size_t)f * K.n_masks + m) * K.ns + s) * 3;
         g0 += p[0]; g1 += p[1]; g2 += p[2];
     }
-    float *o = dvout + ((size_t)f * K.nv + (size_t)s * 4) * 3;
+    float *o = dvout + ((size_t)f * K.nv + (size_t)s * K.sstride) * 3;
     o[0] += g0; o[1] += g1; o[2] += g2;
 }
 

@@ -336,14 +336,16 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
             s_red[f * COLS + col] = ok ? (r + sb[k]) * sb[3] * sb[4] : 0.f;
         }
         __syncthreads();
-        if (mine)
-            for (int idx = col; idx < (BF_MESH_TILE / 4) * mp.K.n_masks; idx += COLS) {
-                const int sv = idx % (BF_MESH_TILE / 4), m = idx / (BF_MESH_TILE / 4), vv = tile * BF_MESH_TILE + sv * 4;
-                if (vv < nv) {
-                    const float *X = s_red + f * COLS + sv * 12;
-                    (void)bf_mask_project_one(mp.K, X[0], X[1], X[2], mp.proj, fbase + f, m, vv >> 2, mp.uvi, mp.duvb);
+        if (mine) {
+            const int sst = mp.K.sstride, spt = BF_MESH_TILE / sst;        // samples of a tile: every 4th vertex, or (sub-model) all that are samples
+            for (int idx = col; idx < spt * mp.K.n_masks; idx += COLS) {
+                const int sv = idx % spt, m = idx / spt, vv = tile * BF_MESH_TILE + sv * sst, sidx = sst == 4 ? vv >> 2 : vv;
+                if (vv < nv && sidx < mp.K.ns) {
+                    const float *X = s_red + f * COLS + sv * sst * 3;
+                    (void)bf_mask_project_one(mp.K, X[0], X[1], X[2], mp.proj, fbase + f, m, sidx, mp.uvi, mp.duvb);
                 }
             }
+        }
     }
     if (xpart) {
         // this tile's share of J_regressor_extra . vertices (models/smpl.py:72), per frame

@@ -35,6 +35,39 @@ __device__ __forceinline__ PoseTabs bf_pose_tabs(const FitTab &T) {
     return PoseTabs{T.th_kind, T.th_off, T.parents, T.pose_mean, T.hand_comp, T.Jd, T.Jt, T.nb, T.level_joints, T.level_start};
 }
 
+// The outputs of bf_pose_state_body from what it left in `lds` (R, J, GR, Gt): GR, A_j translations, Gt, the pose feature, betas
+// and the similarity.  Separate so that a caller whose body ran on one wave can write the record with all its threads.
+template <bool PACKED>
+__device__ __forceinline__ void bf_pose_state_emit(const FitTab &T, const float *__restrict__ sim, float *state, const float *__restrict__ packed,
+                                                   const float *__restrict__ cscale, float cscale_all, const int f, const int tid, const int nt,
+                                                   const float *lds, const float *__restrict__ betas, const float *packed_lds) {
+    const float *R = lds, *J = R + 64 * 9, *GR = J + 64 * 3, *Gt = GR + 64 * 9;
+    const int nj = T.nj, nb = T.nb, npf = T.npf;
+    const float *pk = PACKED ? (packed_lds ? packed_lds : packed + (size_t)f * T.np) : nullptr;
+    const float *beta;
+    if constexpr (PACKED) beta = pk + T.off_beta; else beta = betas + (size_t)f * nb;
+    StateView st = bf_state_view(state + (size_t)f * bf_state_stride(nj, npf, nb), nj, npf, nb);
+    for (int i = tid; i < nj * 9; i += nt) st.GR[i] = GR[i];
+    for (int i = tid; i < nj * 3; i += nt) {
+        int j = i / 3, a = i % 3;
+        const float *g = GR + j * 9 + a * 3;
+        st.At[i] = Gt[i] - (g[0] * J[j * 3] + g[1] * J[j * 3 + 1] + g[2] * J[j * 3 + 2]);
+        st.Gt[i] = Gt[i];
+    }
+    for (int p = tid; p < npf; p += nt) {
+        int j = 1 + p / 9, e = p % 9;
+        st.feat[p] = R[j * 9 + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
+    }
+    if (tid < nb) st.beta[tid] = beta[tid];
+    if constexpr (PACKED) {
+        if (tid < 3) st.t[tid] = pk[tid];
+        if (tid == 3) { st.sc[0] = pk[3]; st.sc[1] = cscale ? cscale[f] : cscale_all; }
+    } else {
+        if (tid < 3) st.t[tid] = sim ? sim[(size_t)f * 5 + tid] : 0.f;
+        if (tid == 3) { st.sc[0] = sim ? sim[(size_t)f * 5 + 3] : 1.f; st.sc[1] = sim ? sim[(size_t)f * 5 + 4] : 1.f; }
+    }
+}
+
 // One 128-thread workgroup per parameter set.  betas[n][nb], orient[n][3], body_pose[n][3(nj-1)];
 // transl / scale are taken as (0,0,0) / 1 / 1 when `sim` is null, else sim[n][5] = t, s, c.
 // `packed` != null: read everything from the optimiser-order parameter block packed[n][np] instead
@@ -42,7 +75,7 @@ __device__ __forceinline__ PoseTabs bf_pose_tabs(const FitTab &T) {
 // Called by EVERY thread of the workgroup (it synchronises); `nt` = the workgroup's thread count.
 // WAVE: the caller is ONE wavefront (tid = lane, nt = 64) with `lds` to itself: barriers become wave fences (a wave's LDS
 // operations execute in order), everything else - the arithmetic included - is the same code.
-template <bool PACKED, bool WAVE = false>
+template <bool PACKED, bool WAVE = false, bool EMIT = true>
 __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float *__restrict__ betas, const float *__restrict__ orient,
                                                    const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
                                                    const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all,
@@ -94,24 +127,6 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
         }
         if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     }
-    for (int i = tid; i < nj * 9; i += nt) st.GR[i] = GR[i];
-    for (int i = tid; i < nj * 3; i += nt) {
-        int j = i / 3, a = i % 3;
-        const float *g = GR + j * 9 + a * 3;
-        st.At[i] = Gt[i] - (g[0] * J[j * 3] + g[1] * J[j * 3 + 1] + g[2] * J[j * 3 + 2]);
-        st.Gt[i] = Gt[i];
-    }
-    for (int p = tid; p < npf; p += nt) {
-        int j = 1 + p / 9, e = p % 9;
-        st.feat[p] = R[j * 9 + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
-    }
-    if (tid < nb) st.beta[tid] = beta[tid];
-    if constexpr (PACKED) {
-        if (tid < 3) st.t[tid] = pk[tid];
-        if (tid == 3) { st.sc[0] = pk[3]; st.sc[1] = cscale ? cscale[f] : cscale_all; }
-    } else {
-        if (tid < 3) st.t[tid] = sim ? sim[(size_t)f * 5 + tid] : 0.f;
-        if (tid == 3) { st.sc[0] = sim ? sim[(size_t)f * 5 + 3] : 1.f; st.sc[1] = sim ? sim[(size_t)f * 5 + 4] : 1.f; }
-    }
+    if constexpr (EMIT) bf_pose_state_emit<PACKED>(T, sim, state, packed, cscale, cscale_all, f, tid, nt, lds, betas, packed_lds);
 }
 

@@ -8,7 +8,7 @@ extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int
 extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
 extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const float *, int, const float *, const float *, const float *, float *, hipStream_t,
-                                        const float *, int, int);
+                                        const float *, int, int, int);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int, int *, int);
 extern "C" int bf_mesh_use_multi(int npf, int n);
 extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
@@ -228,6 +228,16 @@ int bf_ensure_dense_buffers(bf_batch *b) {
             HIP_TRY(hipStreamSynchronize(b->stream));
             m->posedirsT.p = t.p; m->posedirsT.n = t.n; t.p = nullptr;
         }
+        if (m->sub.on && !m->sub.posedirsT.p) {
+            const size_t sv3 = (size_t)m->sub.mesh.nv * 3;
+            DevBuf<float> t;
+            HIP_TRY(t.alloc(sv3 * m->npf));
+            hipLaunchKernelGGL(bf_transpose_kernel, dim3((sv3 + 31) / 32, (m->npf + 31) / 32), dim3(256), 0, b->stream,
+                               (const float *)m->sub.posedirs.p, m->npf, (int)sv3, t.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            m->sub.posedirsT.p = t.p; m->sub.posedirsT.n = t.n; t.p = nullptr;
+        }
     }
     return BF_OK;
 }
@@ -264,36 +274,38 @@ static size_t kp_smem(const KpIO &K) {
     return sizeof(float) * std::max<size_t>(1024, (size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + 1024 + (size_t)K.nl * 3 + 16);   // (+ sort keys, item weights)
 
 }
-static KpIO kp_io(bf_batch *b, const bf_hyper &h) {
-    KpIO K = b->m->kp;
+static KpIO kp_io(bf_batch *b, const bf_hyper &h, bool sub = false) {
+    KpIO K = sub ? b->m->sub.kp : b->m->kp;
     K.n_views = b->V; K.sigma2 = h.sigma * h.sigma; K.coeff = h.imsize / 1024.0f;
     return K;
 }
 // (the keypoint workgroup computes the joints itself from the mesh pass's vraw / xpart: no bf_joints_kernel launch)
-static int launch_kp(bf_batch *b, const bf_hyper &h) {
-    const KpIO K = kp_io(b, h);
+static int launch_kp(bf_batch *b, const bf_hyper &h, bool sub = false) {
+    const KpIO K = kp_io(b, h, sub);
     hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), kp_smem(K), b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
                        (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
-                       (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p, b->m->mesh, (const float *)b->vraw.p, (const float *)b->xpart.p);
+                       (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p, sub ? b->m->sub.mesh : b->m->mesh, (const float *)b->vraw.p,
+                       (const float *)b->xpart.p);
     HIP_TRY(hipGetLastError());
     return BF_OK;
 }
 
 // `with_kp`: the dense keypoint loss rides in the contour launch (bf_kp_contour_kernel) instead of a launch of its own
 static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss, bool sum_views = true, const bf_hyper *with_kp = nullptr,
-                               bool projected = false) {
+                               bool projected = false, bool sub = false) {
     MaskIO K = b->mask;
     K.weight = weight;
+    if (sub) { K.nv = b->m->sub.mesh.nv; K.sstride = 1; }
     const int F = b->F;
     // (projected: the forward mesh pass already wrote uvi / duvb for its sampled vertices)
     if (!projected) hipLaunchKernelGGL(bf_mask_project_kernel, dim3(K.proj_blocks, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->vout.p,
                        (const float *)b->proj.p, b->mk_uvi.p, b->mk_duvb.p, b->mk_part.p);
     if (with_kp) {
-        const KpIO Q = kp_io(b, *with_kp);
+        const KpIO Q = kp_io(b, *with_kp, sub);
         hipLaunchKernelGGL(bf_kp_contour_kernel, dim3((K.cmax * 16 + 511) / 512 + 1, K.n_masks, F), dim3(512), kp_smem(Q), b->stream, Q,
                            (const float *)b->jraw.p, (const float *)b->state.p, (const float *)b->proj.p, (const float *)b->keypoints.p,
                            (const int *)b->ndiv.p, (const int *)b->lmk_vid.p, (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p,
-                           K, (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p, b->m->mesh, (const float *)b->vraw.p,
+                           K, (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p, sub ? b->m->sub.mesh : b->m->mesh, (const float *)b->vraw.p,
                            (const float *)b->xpart.p);
     } else
     hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax * 16 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
@@ -320,9 +332,12 @@ static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
 
 // one dense iteration's forward + loss + reverse passes up to `ext` (everything except the fit kernel itself)
 // door / door_k: the persistent fit launch's doorbells and this pass's 1-based dense iteration (null / 0: fit launches per iteration)
-static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight, int *door = nullptr, int door_k = 0) {
+// sub: run the mesh passes on the sampled-first sub-model (bf_model::Sub; fit loops without scans)
+static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight, int *door = nullptr, int door_k = 0,
+                      bool sub = false) {
     bf_model *m = b->m;
-    const int F = b->F, nv = m->nv, nblk = (nv + 255) / 256;
+    const MeshTab &Q = sub ? m->sub.mesh : m->mesh;
+    const int F = b->F, nv = Q.nv, nblk = (nv + 255) / 256;
     const bool scans = late && !b->scans.empty(), masks = late && b->has_masks, kp = m->kp_dense;
     if (!door) {                     // (with the resident fit launch every state comes from it)
         hipLaunchKernelGGL(bf_pose_state_kernel, dim3(F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
@@ -336,16 +351,17 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     bool projected = false;
     if (masks) {
         mp.on = 1; mp.K = b->mask; mp.K.weight = mask_weight; mp.proj = b->proj.p; mp.uvi = b->mk_uvi.p; mp.duvb = b->mk_duvb.p;
+        if (sub) { mp.K.nv = nv; mp.K.sstride = 1; }
     }
     int rc = bf_launch_mesh(m, &b->scratch, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
                             b->vposed.p, nullptr, nullptr, nullptr, (kp || masks) ? b->dvout.p : nullptr, &zeroed, kp, masks ? &mp : nullptr,
-                            &projected, door, F * door_k);
+                            &projected, door, F * door_k, sub ? &Q : nullptr);
     if (rc) return rc;
     if ((kp || masks) && !zeroed) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
-    if (kp && !masks) { rc = launch_kp(b, h); if (rc) return rc; }
+    if (kp && !masks) { rc = launch_kp(b, h, sub); if (rc) return rc; }
     // with a scan as well, bf_pc_grad_kernel adds onto (keypoints + silhouette): keep that order of additions
     const bool fold_views = masks && !scans;
-    if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr, projected); if (rc) return rc; }
+    if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr, projected, sub); if (rc) return rc; }
     if (scans) {
         hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv + 3) / 4, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
                            (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);   // (one wave per query; warm start from the previous call's faces)
@@ -358,12 +374,12 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     }
     const int EXT = m->npf + m->nj * 12 + m->nb + 4;
     {
-        const int e = bf_mesh_bwd_multi_launch(&m->mesh, m->posedirsT.p, b->state.p, F, b->dvout.p, b->vposed.p, b->vraw.p, b->ext_part.p, b->stream,
-                                               fold_views ? (const float *)b->mk_gpart.p : nullptr, b->mask.n_masks, b->mask.ns);
+        const int e = bf_mesh_bwd_multi_launch(&Q, sub ? m->sub.posedirsT.p : m->posedirsT.p, b->state.p, F, b->dvout.p, b->vposed.p, b->vraw.p, b->ext_part.p,
+                                               b->stream, fold_views ? (const float *)b->mk_gpart.p : nullptr, b->mask.n_masks, b->mask.ns, sub ? 1 : 4);
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_bwd_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     }
     hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 31) / 32, F), dim3(256), 0, b->stream,
-                       (const float *)b->ext_part.p, m->mesh.n_tiles, EXT, b->ext.p, EXT + m->nj * 3 + 4, door, door_k);
+                       (const float *)b->ext_part.p, Q.n_tiles, EXT, b->ext.p, EXT + m->nj * 3 + 4, door, door_k);
     HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -419,6 +435,8 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     // The dense iterations with the fit kernel RESIDENT (one launch on a second stream, paced by doorbells, BfDoor) when the
     // forward pass is a kernel that knows how to wait (1..15 frames); BF_DENSE_PERSISTENT=0, or a larger batch, keeps one fit launch
     // per iteration, with the pose state from bf_pose_state_kernel every time.
+    static const bool sub_ok = [] { const char *e = std::getenv("BF_DENSE_SUBMODEL"); return !(e && e[0] == '0'); }();
+    const bool sub = sub_ok && m->sub.on && b->scans.empty();
     static const bool door_ok = [] { const char *e = std::getenv("BF_DENSE_PERSISTENT"); return !(e && e[0] == '0'); }();
     const int n_dense = n_iters - n_plain;
     if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES) {
@@ -459,7 +477,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
                     }
                 }
             }
-            rc = dense_pass(b, h, hd, it > thr, 5.0f, b->door.p, it - n_plain + 1);
+            rc = dense_pass(b, h, hd, it > thr, 5.0f, b->door.p, it - n_plain + 1, sub);
             if (rc) return rc;
         }
         HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_door[1], 0));       // the last iteration's step, terms and state
@@ -467,7 +485,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
         return BF_OK;
     }
     for (int it = n_plain; it < n_iters; ++it) {
-        rc = dense_pass(b, h, hd, it > thr, 5.0f);                                     // smplify.py:210
+        rc = dense_pass(b, h, hd, it > thr, 5.0f, nullptr, 0, sub);                    // smplify.py:210
         if (rc) return rc;
         FrameIO io2 = io;
         io2.ext = b->ext.p;
@@ -619,7 +637,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     HIP_TRY(b->mk_part.alloc(fm * stride)); HIP_TRY(b->mk_loss.alloc(F));
     MaskIO &K = b->mask;
     K.nv = nv; K.ns = ns; K.n_views = b->V; K.n_masks = n_masks; K.H = H; K.W = W; K.cmax = cmax;
-    K.part_stride = stride; K.proj_blocks = pblocks; K.cdist = 1; K.imsize = 512.f; K.eps = 10.f; K.weight = 5.f;
+    K.part_stride = stride; K.proj_blocks = pblocks; K.cdist = 1; K.sstride = 4; K.imsize = 512.f; K.eps = 10.f; K.weight = 5.f;
     K.view_index = b->mk_view.p; K.masks = b->mk_masks.p; K.contour_start = b->mk_cstart.p;
     K.contour_count = b->mk_ccount.p; K.contour_xy = b->mk_cxy.p;
     b->has_masks = true;

@@ -327,7 +327,7 @@ template <int FPW>
 __global__ void __launch_bounds__(512)
 bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const float *__restrict__ state, int n_frames,
                          const float *__restrict__ dvout, const float *__restrict__ vposed, const float *__restrict__ vraw,
-                         float *__restrict__ part, const float *__restrict__ gpart, int n_masks, int n_sampled) {
+                         float *__restrict__ part, const float *__restrict__ gpart, int n_masks, int n_sampled, int samp_stride) {
     constexpr int TV = BF_MESH_TILE, COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
@@ -370,10 +370,10 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
         const size_t o = ((size_t)(fbase + f) * nv + v0) * 3 + c;
         const float sc = s_sim[f * 8 + 3] * s_sim[f * 8 + 4];
         float g = ok ? dvout[o] : 0.f;
-        if (gpart && ok && ((v0 + c / 3) & 3) == 0) {
+        if (gpart && ok && (samp_stride == 4 ? ((v0 + c / 3) & 3) == 0 : v0 + c / 3 < n_sampled)) {
             // the silhouette gradient of every 4th vertex (loss.py:99) is still per mask view: add the views here, in view order,
             // exactly as bf_mask_gsum_kernel would have (sum of the views first, then onto dL/dvertex) - one launch less
-            const int sidx = (v0 + c / 3) >> 2;
+            const int sidx = samp_stride == 4 ? (v0 + c / 3) >> 2 : v0 + c / 3;
             float gs = 0.f;
             for (int m = 0; m < n_masks; ++m) gs += gpart[(((size_t)(fbase + f) * n_masks + m) * n_sampled + sidx) * 3 + c % 3];
             g += gs;
@@ -483,7 +483,7 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
 
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT, const float *state, int n, const float *dvout,
                                         const float *vposed, const float *vraw, float *part, hipStream_t stream,
-                                        const float *gpart, int n_masks, int n_sampled) {
+                                        const float *gpart, int n_masks, int n_sampled, int samp_stride) {
     constexpr int COLS = BF_MESH_TILE * 3;
     const int fpw = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
     const size_t smem = sizeof(float) * ((size_t)COLS * fpw + (size_t)fpw * M->nj * 12 + (size_t)BF_MESH_TILE * M->nj + 2 * (size_t)fpw * COLS +
@@ -491,10 +491,10 @@ extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT
     const dim3 grid(M->n_tiles, (n + fpw - 1) / fpw), block(512);
     if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
     switch (fpw) {
-    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled); break;
-    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled); break;
-    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled); break;
-    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled); break;
+    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride); break;
+    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride); break;
+    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride); break;
+    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride); break;
     }
     return (int)hipGetLastError();
 }

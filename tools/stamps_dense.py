@@ -22,7 +22,7 @@ for rep in range(2):
     d = np.where(np.abs(d) > 1e7, 0.0, d)
     st = d[:12]
     print("rep", rep, "per-barrier cumulative cycles of the iteration:", [int(x) for x in st])
-    print("  door marks (cycles since phase A ended): state written", int(d[56]), " ext bell seen", int(d[57]), " ext staged", int(d[58]))
+    print("  door marks (cycles since phase A ended): state written", int(d[56]), " ext bell seen", int(d[57]), " ext staged", int(d[58]), "| wave 7 pose state done at", int(d[59]), "cycles of the iteration")
     k = d[64:72]
     print("  kernel entry -> prologue done (t0, t256):", int(k[0]), int(k[1]), " after its barrier:", int(k[2]))
     k2 = d[72:80]
