@@ -58,7 +58,7 @@ struct FitSmem {
     int *nzj, *thk, *tho, *par, *pk, *pa_, *pb_;
     float *am, *av;
     float *ext;          // the dense schedule's outside gradient blocks of this frame (EXT launches)
-    int *lvl;            // level_joints[nj] | level_start[n_levels + 1] (<= 66) for the pose-state tail
+    int *lvl;            // level_joints[nj] | level_start[n_levels + 1] (<= 67) | depth[nj], for the pose state a dense launch publishes
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
@@ -97,7 +97,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.pk = (int *)take(np); s.pa_ = (int *)take(np); s.pb_ = (int *)take(np); s.am = take(np); s.av = take(np);
     s.proj = take(nviews * 12);
     s.ext = take(npf + nj * 12 + nb + 4 + nj * 3 + 4);
-    s.lvl = (int *)take(nj + 68);
+    s.lvl = (int *)take(2 * nj + 68);
     (void)nl;
     return o * sizeof(float);
 }
@@ -268,7 +268,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         float4 vp = {0.f, 0.f, 0.f, 0.f};
         if (tid < V * 3) vp = pj[tid];
         float r_pa = 0.f, r_am = 0.f, r_av = 0.f, r_ext[3] = {0.f, 0.f, 0.f};
-        int r_lj = 0, r_ls = 0;
+        int r_lj = 0, r_ls = 0, r_dp = 0;
         if (tid < np) {
             r_pa = (io.params0 ? io.params0 : io.params)[(size_t)frame * np + tid];
             if (!io.params0) { r_am = io.adam_m[(size_t)frame * np + tid]; r_av = io.adam_v[(size_t)frame * np + tid]; }
@@ -276,7 +276,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         const float *eg = io.ext + (size_t)frame * n_ext;
 #pragma unroll
         for (int q = 0; q < 3; ++q) if (!door && q * nt + tid < n_ext) r_ext[q] = eg[q * nt + tid];
-        if (tid < nj) r_lj = T.level_joints[tid];
+        if (tid < nj) { r_lj = T.level_joints[tid]; r_dp = T.depth[tid]; }
         if (tid <= T.n_levels) r_ls = T.level_start[tid];
         // zero-initialised arrays: GMM d / y, and the keypoint table when this launch has no loss joints
         for (int i = tid; i < 2 * BF_GMM_M * BF_GMM_LD; i += nt) S.gd[i] = 0.f;          // (gd and gy are adjacent in the carve)
@@ -287,7 +287,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         if (tid < np) { S.pa[tid] = r_pa; S.am[tid] = r_am; S.av[tid] = r_av; }
 #pragma unroll
         for (int q = 0; q < 3; ++q) if (q * nt + tid < n_ext) S.ext[q * nt + tid] = r_ext[q];
-        if (tid < nj) S.lvl[tid] = r_lj;
+        if (tid < nj) { S.lvl[tid] = r_lj; S.lvl[nj + 67 + tid] = r_dp; }
         if (tid <= T.n_levels) S.lvl[nj + tid] = r_ls;
     } else {
     copy_f(S.Jt, T.Jt, nj3, tid, nt);
@@ -320,7 +320,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     copy_f(S.pa, (io.params0 ? io.params0 : io.params) + (size_t)frame * np, np, tid, nt);
     if (EXT) {
         if (mode != 2 && !door) copy_f(S.ext, io.ext + (size_t)frame * n_ext, n_ext, tid, nt);
-        for (int i = tid; i < nj; i += nt) S.lvl[i] = T.level_joints[i];
+        for (int i = tid; i < nj; i += nt) { S.lvl[i] = T.level_joints[i]; S.lvl[nj + 67 + i] = T.depth[i]; }
         for (int i = tid; i <= T.n_levels && i < 67; i += nt) S.lvl[nj + i] = T.level_start[i];
     }
     }
@@ -716,7 +716,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     // a vertex into a different nearest-vertex choice), run by wave 3 - idle in phase A - while waves 0-2 form the chain,
     // from the LDS copies of the model's tables; the view-sum slots (dead until phase D) are its scratch.
     auto door_state = [&](const float *P) {
-        const PoseTabs PT{S.thk, S.tho, S.par, S.pmean, S.hcomp, S.Jd, S.Jt, pad4(nb + 1), S.lvl, S.lvl + nj};
+        const PoseTabs PT{S.thk, S.tho, S.par, S.pmean, S.hcomp, S.Jd, S.Jt, pad4(nb + 1), S.lvl, S.lvl + nj, S.lvl + nj + 67};
         bf_pose_state_body<true, true, false>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, lane, 64, S.part, PT, P);
     };
     static_assert(BF_VSUB * 32 * 4 >= BF_POSE_STATE_LDS, "the view-sum slots are the pose-state scratch");

@@ -29,10 +29,10 @@ struct PoseTabs {
     const int *th_kind, *th_off, *parents;
     const float *pose_mean, *hand_comp, *Jd, *Jt;
     int jd_stride;                  // row stride of Jd (nb in the FitTab, padded in the fit kernel's LDS copy)
-    const int *level_joints, *level_start;
+    const int *level_joints, *level_start, *depth;
 };
 __device__ __forceinline__ PoseTabs bf_pose_tabs(const FitTab &T) {
-    return PoseTabs{T.th_kind, T.th_off, T.parents, T.pose_mean, T.hand_comp, T.Jd, T.Jt, T.nb, T.level_joints, T.level_start};
+    return PoseTabs{T.th_kind, T.th_off, T.parents, T.pose_mean, T.hand_comp, T.Jd, T.Jt, T.nb, T.level_joints, T.level_start, T.depth};
 }
 
 // The outputs of bf_pose_state_body from what it left in `lds` (R, J, GR, Gt): GR, A_j translations, Gt, the pose feature, betas
@@ -104,6 +104,22 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
         m_rodrigues(th[0], th[1], th[2], R + tid * 9);
         st.theta[tid * 3] = th[0]; st.theta[tid * 3 + 1] = th[1]; st.theta[tid * 3 + 2] = th[2];
     }
+    if (nb <= 16) {
+        // (all of a row's operands requested before the first multiply-add: the chain below is the same sum, l ascending)
+        float bb[16];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) bb[l] = l < nb ? beta[l] : 0.f;
+        for (int i = tid; i < nj * 3; i += nt) {
+            float jd[16];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) jd[l] = l < nb ? P.Jd[i * P.jd_stride + l] : 0.f;
+            const float jt = P.Jt[i];
+            float acc = 0.f;
+#pragma unroll
+            for (int l = 0; l < 16; ++l) if (l < nb) acc += jd[l] * bb[l];
+            J[i] = jt + acc;
+        }
+    } else
     for (int i = tid; i < nj * 3; i += nt) {
         float acc = 0.f;
         for (int l = 0; l < nb; ++l) acc += P.Jd[i * P.jd_stride + l] * beta[l];
@@ -113,6 +129,36 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
     if (tid < 9) GR[tid] = R[tid];
     if (tid >= 9 && tid < 12) Gt[tid - 9] = J[tid - 9];
     if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
+    if constexpr (WAVE) {
+        // one wave: lane = joint, all three rows of its transform when its level comes up (the parent's rows through LDS, its own
+        // rotation straight from the Rodrigues registers' LDS copy, requested once) - per element the same expressions as below
+        const int dep = tid < nj ? P.depth[tid] : 0;
+        const int i = tid < nj ? tid : 0, p = s_par[i];
+        float Ri[9], rj[3];
+#pragma unroll
+        for (int e = 0; e < 9; ++e) Ri[e] = R[i * 9 + e];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) rj[e] = J[i * 3 + e] - J[p * 3 + e];
+        for (int lev = 1; lev < T.n_levels; ++lev) {
+            if (tid < nj && dep == lev) {
+                float g[9], gt[3];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) g[e] = GR[p * 9 + e];
+#pragma unroll
+                for (int e = 0; e < 3; ++e) gt[e] = Gt[p * 3 + e];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const float g0 = g[r * 3], g1 = g[r * 3 + 1], g2 = g[r * 3 + 2];
+                    GR[i * 9 + r * 3 + 0] = g0 * Ri[0] + g1 * Ri[3] + g2 * Ri[6];
+                    GR[i * 9 + r * 3 + 1] = g0 * Ri[1] + g1 * Ri[4] + g2 * Ri[7];
+                    GR[i * 9 + r * 3 + 2] = g0 * Ri[2] + g1 * Ri[5] + g2 * Ri[8];
+                    const float r0 = rj[0], r1 = rj[1], r2 = rj[2];
+                    Gt[i * 3 + r] = g0 * r0 + g1 * r1 + g2 * r2 + gt[r];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    } else
     for (int lev = 1; lev < T.n_levels; ++lev) {
         int ls = s_ls[lev], cnt = (s_ls[lev + 1] - ls) * 3;
         for (int idx = tid; idx < cnt; idx += nt) {
