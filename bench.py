@@ -154,6 +154,11 @@ def pmc_traffic():
 
 def main():
     a = parse()
+    # stdout carries ONE line, the result.  Libraries underneath (RCCL prints a version banner there) write to file descriptor 1
+    # whenever they like, so it points at stderr for the whole run and the result goes out through a saved copy at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0")) if env_world > 1 else 0
     local = int(os.environ.get("LOCAL_RANK", "0")) if env_world > 1 else 0
@@ -324,7 +329,7 @@ def main():
     if rank == 0 and n_gpus == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model, gmm, a.cpu_frames, a.views, a.iters)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:
         comm.barrier()
         comm.rendezvous.cleanup()
