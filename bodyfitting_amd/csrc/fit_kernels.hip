@@ -728,8 +728,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #endif
         // (wave 3 left the rotations, chain matrices and joints of the state in the scratch during phase A: everybody writes the record)
         bf_pose_state_emit<true>(T, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nt, S.part, nullptr, P);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
+        __syncthreads();                                       // the record's stores have reached the XCD's L2
+        if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // one device-scope release (L2 write-back) for the workgroup
         BF_DMARK(56);
         if (tid < BF_DOOR_COPIES) __hip_atomic_fetch_add(door + BF_DOOR_STATE + tid * BF_DOOR_COPY_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid == 0) bf_door_wait(door, BF_DOOR_EXT, it + 1);

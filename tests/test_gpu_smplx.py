@@ -162,3 +162,48 @@ def test_smplx_scan_fit_and_displacement_stage(gmm_bufs):
     err = np.abs(m1[0] / 0.1 - g) / np.abs(g).max()        # (observed: 2e-4 relative to the largest entry; fp32 normals; a vertex whose
     assert np.mean(err < 3e-4) > 0.995 and err.max() < 2e-2   # closest face flips between the fp32 and fp64 base mesh differs by more)
     b.close(); scan.close(); dev.close()
+
+
+def _fit_in_subprocess(env, n_iters=12, masks=False):
+    """the fitted parameters of a small SMPL-X problem from a fresh process with `env` set (the launch-form switches are read once per process)"""
+    import json, os, subprocess, sys
+    code = f"""
+import json, sys
+import numpy as np
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from bodyfitting_amd import native as N, synthetic as S
+model, gmm = S.make_model("smplx", seed=0), S.make_gmm(seed=0)
+dev = N.DeviceModel(model, gmm, device=0)
+mf = [1, 3, 5, 7] if {masks!r} else None
+prob = S.make_problem_smplx(model, frame=0, n_views=8, mask_frames=mf)
+c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
+b = N.FrameBatch(dev, 1, 8)
+b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+if mf: b.set_masks(np.array(prob["masks"])[None], mf, None)
+b.fit({n_iters})
+print("RESULT " + json.dumps(b.get_params()[0].astype(float).tolist()))
+"""
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    return np.asarray(json.loads(line[7:]), np.float32)
+
+
+def test_resident_fit_launch_equals_one_launch_per_iteration():
+    """the dense schedule with the fit kernel resident (doorbells) against one fit launch per iteration: the pose state
+    both consume is bf_pose_state_kernel's arithmetic, so the fitted parameters are the same bits"""
+    a = _fit_in_subprocess({"BF_DENSE_PERSISTENT": "1"})
+    b = _fit_in_subprocess({"BF_DENSE_PERSISTENT": "0"})
+    assert np.isfinite(a).all() and np.abs(a).sum() > 1
+    np.testing.assert_array_equal(a, b)
+
+
+def test_sub_model_loop_matches_the_full_model_loop():
+    """mesh passes on the sampled-first sub-model (a third of the vertices) against the full model: same vertices, same per-vertex
+    arithmetic, different tile sums - float32 summation order, before the silhouette's discontinuities can amplify it (kp-only loop)"""
+    a = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "1"})
+    b = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "0"})
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
+    a = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "1"}, n_iters=6, masks=True)          # 2 keypoint-only + 4 silhouette iterations
+    b = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "0"}, n_iters=6, masks=True)
+    np.testing.assert_allclose(a, b, rtol=0, atol=2e-3)                              # (a near-tie flip away at most, cf. MASK_FIRST_STEP_TOL)

@@ -24,6 +24,7 @@ done
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_cfg2" -- $P > "$OUT/pmc_fetch_cfg2.log" 2>&1; echo "pmc_fetch_cfg2 rc=$?"
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write_cfg2" -- $P > "$OUT/pmc_write_cfg2.log" 2>&1; echo "pmc_write_cfg2 rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg35" -- python3 $ROOT/tools/bench_configs.py --cfg3 --cfg5x --reps 1 > "$OUT/trace_cfg35.log" 2>&1; echo "trace_cfg35 rc=$?"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_texfit" -- python3 $ROOT/tools/bench_texfit.py > "$OUT/trace_texfit.log" 2>&1; echo "trace_texfit rc=$?"
 cd "$ROOT"
 find "$OUT" -name "*.db" -delete
 python3 tools/summarize_round2.py "$OUT" > "$OUT/summary.md" 2> "$OUT/summary.err"; echo "summary rc=$?"
