@@ -216,26 +216,103 @@ extern "C" __global__ void __launch_bounds__(256) bf_inside_mesh_kernel(ScanDev 
 }
 
 // ---- MeshGridSearcher.intersects_any (utils/mesh_grid_searcher.py:93-99 -> search_intersect, kernel.cu:1029-1231) ---------------
-// Does the ray origin + t direction, t >= 0, hit any triangle?  The per-triangle test is the reference's regular branch
-// (intersect_tri2, kernel.cu:742-780): solve [va - o | vb - o | vc - o | -d ; 1 1 1 0] by cofactors, hit iff |det| > 1e-9 and the
-// three barycentric numerators and the ray parameter, signed by det, are >= -1e-9.  Its branches for |det| <= 1e-9 (ray in the
-// triangle's plane, zero direction) are not reproduced: such a pair counts as no hit.  The answer is an OR over triangles, so the
-// order of the reference's cell walk does not matter: one thread per ray walks the cells its ray crosses (3-D DDA from the
-// ray's entry into the grid) and stops at the first hit.
+// Does the ray origin + t direction, t >= 0, hit any triangle?  The per-triangle test is the reference's intersect_tri2
+// (kernel.cu:742-1026, both_direction = false, precision 1e-9) in float32 and in its operation order (no fused multiply-adds: the
+// tests against 1e-9 are decided by the last bit):
+//   regular (|det| > 1e-9)   solve [va - o | vb - o | vc - o | -d ; 1 1 1 0] by cofactors; hit iff the three barycentric numerators and
+//                            the ray parameter, signed by det, are >= -1e-9                                   (:742-780)
+//   ray in the triangle's plane (|det| <= 1e-9, triangle area^2 > 1e-9)   the origin must lie in the plane (|volume| <= 1e-9); then by the
+//                            barycentric numerators of the origin: inside -> hit; outside one edge -> the ray must cross that edge
+//                            going in; outside two edges -> it must cross one of the two                     (:912-1023)
+//   degenerate triangle (area^2 <= 1e-9)   a segment (longest edge^2 > 1e-9): coplanarity + the ray crossing it; a point: the origin-to-
+//                            point vector parallel to the ray and not behind it                               (:849-911)
+// (A zero direction is rejected by the caller, kernel.cu:1062-1065, so the norm <= 1e-9 branches :793-848 are never reached.)
+// The answer is an OR over triangles, so the order of the reference's cell walk does not matter: one thread per ray walks the cells
+// its ray crosses (3-D DDA from the ray's entry into the grid) and stops at the first hit.
 __device__ inline bool ray_hits_triangle(const float o[3], const float d[3], const float *va, const float *vb, const float *vc) {
-    const float A0 = va[0] - o[0], A1 = vb[0] - o[0], A2 = vc[0] - o[0], A3 = -d[0];
-    const float A4 = va[1] - o[1], A5 = vb[1] - o[1], A6 = vc[1] - o[1], A7 = -d[1];
-    const float A8 = va[2] - o[2], A9 = vb[2] - o[2], A10 = vc[2] - o[2], A11 = -d[2];
-    const float i0 = A5 * A10 - A6 * A9, i1 = A2 * A9 - A1 * A10, i2 = A1 * A6 - A2 * A5;
-    const float i3 = A6 * A8 - A4 * A10, i4 = A0 * A10 - A2 * A8, i5 = A2 * A4 - A0 * A6;
-    const float i6 = A4 * A9 - A5 * A8, i7 = A1 * A8 - A0 * A9, i8 = A0 * A5 - A1 * A4;
-    float n0 = -A3 * i0 - A7 * i1 - A11 * i2, n1 = -A3 * i3 - A7 * i4 - A11 * i5, n2 = -A3 * i6 - A7 * i7 - A11 * i8;
-    float n3 = A0 * i0 + A4 * i1 + A8 * i2;
-    float det = n0 + n1 + n2;
+#pragma clang fp contract(off)
     const float prec = 1e-9f;
-    if (!(det > prec || det < -prec)) return false;
-    if (det < 0.f) { n0 = -n0; n1 = -n1; n2 = -n2; n3 = -n3; }
-    return n0 >= -prec && n1 >= -prec && n2 >= -prec && n3 >= -prec;
+    // A = [va - o | vb - o | vc - o | -d] by rows x, y, z: A[r * 4 + c]
+    const float A[12] = {va[0] - o[0], vb[0] - o[0], vc[0] - o[0], -d[0],
+                         va[1] - o[1], vb[1] - o[1], vc[1] - o[1], -d[1],
+                         va[2] - o[2], vb[2] - o[2], vc[2] - o[2], -d[2]};
+    const float I[9] = {A[5] * A[10] - A[6] * A[9], A[2] * A[9] - A[1] * A[10], A[1] * A[6] - A[2] * A[5],
+                        A[6] * A[8] - A[4] * A[10], A[0] * A[10] - A[2] * A[8], A[2] * A[4] - A[0] * A[6],
+                        A[4] * A[9] - A[5] * A[8], A[1] * A[8] - A[0] * A[9], A[0] * A[5] - A[1] * A[4]};
+    float N[4] = {-A[3] * I[0] - A[7] * I[1] - A[11] * I[2], -A[3] * I[3] - A[7] * I[4] - A[11] * I[5],
+                  -A[3] * I[6] - A[7] * I[7] - A[11] * I[8], A[0] * I[0] + A[4] * I[1] + A[8] * I[2]};
+    float det = N[0] + N[1] + N[2];
+    if (det > prec || det < -prec) {
+        if (det < 0.f) { N[0] = -N[0]; N[1] = -N[1]; N[2] = -N[2]; N[3] = -N[3]; }
+        return N[0] >= -prec && N[1] >= -prec && N[2] >= -prec && N[3] >= -prec;
+    }
+    // ---- |det| <= 1e-9 (the direction is not degenerate here)
+    const float Sx = I[0] + I[3] + I[6], Sy = I[1] + I[4] + I[7], Sz = I[2] + I[5] + I[8];
+    const float area = Sx * Sx + Sy * Sy + Sz * Sz;
+    auto col = [&](int c, int r) { return A[r * 4 + c]; };                       // component r of column c
+    auto cross_d = [&](int c, float out[3]) {                                    // (column c) x (-d)
+        out[0] = col(c, 1) * A[11] - col(c, 2) * A[7];
+        out[1] = col(c, 2) * A[3] - col(c, 0) * A[11];
+        out[2] = col(c, 0) * A[7] - col(c, 1) * A[3];
+    };
+    if (area <= prec) {
+        const float e[9] = {vc[0] - vb[0], vc[1] - vb[1], vc[2] - vb[2], va[0] - vc[0], va[1] - vc[1], va[2] - vc[2],
+                            vb[0] - va[0], vb[1] - va[1], vb[2] - va[2]};
+        const float l[3] = {e[0] * e[0] + e[1] * e[1] + e[2] * e[2], e[3] * e[3] + e[4] * e[4] + e[5] * e[5], e[6] * e[6] + e[7] * e[7] + e[8] * e[8]};
+        int i = l[0] < l[1] ? 1 : 0;
+        i = l[i] < l[2] ? 2 : i;
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        if (l[i] <= prec) {                                  // the triangle is a point
+            float cr[3];
+            cross_d(i, cr);
+            const float n_i = cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2];
+            const float n3 = -col(i, 0) * A[3] - col(i, 1) * A[7] - col(i, 2) * A[11];
+            return n_i <= prec && n3 >= -prec;
+        }
+        // the triangle is a segment (its longest edge e_i, from corner j to corner k)
+        const float norm_ = I[3 * i] * I[3 * i] + I[3 * i + 1] * I[3 * i + 1] + I[3 * i + 2] * I[3 * i + 2];
+        float nj, nk, n3;
+        if (norm_ > prec) {
+            float cj[3], ck[3];
+            cross_d(j, cj); cross_d(k, ck);
+            nj = I[3 * i] * ck[0] + I[3 * i + 1] * ck[1] + I[3 * i + 2] * ck[2];
+            nk = -I[3 * i] * cj[0] - I[3 * i + 1] * cj[1] - I[3 * i + 2] * cj[2];
+            n3 = nj + nk;
+        } else {                                             // the origin is on the segment's line
+            nj = col(k, 0) * e[3 * i] + col(k, 1) * e[3 * i + 1] + col(k, 2) * e[3 * i + 2];
+            nk = -col(j, 0) * e[3 * i] - col(j, 1) * e[3 * i + 1] - col(j, 2) * e[3 * i + 2];
+            n3 = l[i];
+        }
+        return N[i] >= -prec && N[i] <= prec && nj >= -prec && nk >= -prec && n3 > prec;
+    }
+    // ---- the ray is parallel to the triangle's plane
+    float B[3] = {I[0] * Sx + I[1] * Sy + I[2] * Sz, I[3] * Sx + I[4] * Sy + I[5] * Sz, I[6] * Sx + I[7] * Sy + I[8] * Sz};
+    int i = B[0] < B[1] ? 0 : 1;
+    i = B[i] < B[2] ? i : 2;
+    int j = (i + 1) % 3, k = (i + 2) % 3;
+    if (B[k] < -prec) { k = j; j = i; i = 3 - j - k; }
+    const bool in_plane = N[3] >= -prec && N[3] <= prec;
+    if (B[j] < -prec) {                                      // outside two edges: the ray has to come in through one of them
+        float ci[3], cj[3], ck[3];
+        cross_d(i, ci); cross_d(j, cj); cross_d(k, ck);
+        const float d0 = I[3 * i] * ck[0] + I[3 * i + 1] * ck[1] + I[3 * i + 2] * ck[2];
+        const float d1 = -I[3 * i] * cj[0] - I[3 * i + 1] * cj[1] - I[3 * i + 2] * cj[2];
+        const float d2 = I[3 * j] * ci[0] + I[3 * j + 1] * ci[1] + I[3 * j + 2] * ci[2];
+        const float d3 = -I[3 * j] * ck[0] - I[3 * j + 1] * ck[1] - I[3 * j + 2] * ck[2];
+        const float ni = I[3 * i] * I[3 * i] + I[3 * i + 1] * I[3 * i + 1] + I[3 * i + 2] * I[3 * i + 2];
+        const float nj = I[3 * j] * I[3 * j] + I[3 * j + 1] * I[3 * j + 1] + I[3 * j + 2] * I[3 * j + 2];
+        const bool v0 = d0 >= -prec && d1 >= -prec && ni > prec, v1 = d2 >= -prec && d3 >= -prec && nj > prec;
+        return (v0 || v1) && in_plane;
+    }
+    if (B[i] < -prec) {                                      // outside one edge
+        float cj[3], ck[3];
+        cross_d(j, cj); cross_d(k, ck);
+        const float nj = I[3 * i] * ck[0] + I[3 * i + 1] * ck[1] + I[3 * i + 2] * ck[2];
+        const float nk = -I[3 * i] * cj[0] - I[3 * i + 1] * cj[1] - I[3 * i + 2] * cj[2];
+        const float ni = nj + nk;
+        return nj >= -prec && nk >= -prec && in_plane && ni > prec;
+    }
+    return B[i] >= -prec && in_plane;                        // the origin is inside the triangle
 }
 
 extern "C" __global__ void __launch_bounds__(256) bf_intersect_kernel(ScanDev S, const float *__restrict__ origins,

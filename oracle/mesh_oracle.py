@@ -4,7 +4,7 @@ Restates, in numpy / torch:
   * MeshGridSearcher.set_mesh grid parameters      reference utils/mesh_grid_searcher.py:56-79
   * insert_grid_surface (cell lists of the grid)    thirdparty/mesh_grid/mesh_grid_kernel.cu:110-157,178-236
   * MeshGridSearcher.inside_mesh (axis-ray parity)   thirdparty/mesh_grid/mesh_grid_kernel.cu:461-641
-  * MeshGridSearcher.intersects_any (any-hit rays)   thirdparty/mesh_grid/mesh_grid_kernel.cu:742-780,1029-1231
+  * MeshGridSearcher.intersects_any (any-hit rays)   thirdparty/mesh_grid/mesh_grid_kernel.cu:742-1026,1029-1231
   * the per-triangle closest-point rule             thirdparty/mesh_grid/mesh_grid_kernel.cu:12-109
     (KKT solve for the barycentric coefficients; if one is negative, fall back to the edge opposite
     the MOST NEGATIVE coefficient and clamp to its end points - which is not the exact closest point
@@ -138,18 +138,120 @@ def inside_mesh(verts, faces, queries, step, origin, num, tri_num, tri_idx):
     return out
 
 
+def intersect_tri2(src, direction, va, vb, vc, both_direction=False, precision=1e-9):
+    """intersect_tri2 (mesh_grid_kernel.cu:742-1026) for one ray and one triangle, float32 scalars in the kernel's operation order
+    (every product and sum rounded: numpy scalars do not fuse).  -> bool.  `coeff` is not returned, but the two places where the
+    kernel's coeff != NULL path rewrites a numerator before the final test (:900-901, :1004-1005) are followed, as
+    search_ray_grid_kernel always passes coeff (:1077-1081)."""
+    F = np.float32
+    p = F(precision)
+    src, direction, va, vb, vc = (np.asarray(x, F) for x in (src, direction, va, vb, vc))
+    A = [va[0] - src[0], vb[0] - src[0], vc[0] - src[0], -direction[0],
+         va[1] - src[1], vb[1] - src[1], vc[1] - src[1], -direction[1],
+         va[2] - src[2], vb[2] - src[2], vc[2] - src[2], -direction[2]]
+    I = [A[5] * A[10] - A[6] * A[9], A[2] * A[9] - A[1] * A[10], A[1] * A[6] - A[2] * A[5],
+         A[6] * A[8] - A[4] * A[10], A[0] * A[10] - A[2] * A[8], A[2] * A[4] - A[0] * A[6],
+         A[4] * A[9] - A[5] * A[8], A[1] * A[8] - A[0] * A[9], A[0] * A[5] - A[1] * A[4]]
+    N = [-A[3] * I[0] - A[7] * I[1] - A[11] * I[2], -A[3] * I[3] - A[7] * I[4] - A[11] * I[5],
+         -A[3] * I[6] - A[7] * I[7] - A[11] * I[8], A[0] * I[0] + A[4] * I[1] + A[8] * I[2]]
+    det = N[0] + N[1] + N[2]
+    if det > p or det < -p:                                               # :768-780
+        if det < 0:
+            N = [-x for x in N]
+        return bool(N[0] >= -p and N[1] >= -p and N[2] >= -p and (both_direction or N[3] >= -p))
+    norm = A[3] * A[3] + A[7] * A[7] + A[11] * A[11]                      # :782
+    S = [I[0] + I[3] + I[6], I[1] + I[4] + I[7], I[2] + I[5] + I[8]]
+    area = S[0] * S[0] + S[1] * S[1] + S[2] * S[2]
+
+    def edges():
+        e = [vc[0] - vb[0], vc[1] - vb[1], vc[2] - vb[2], va[0] - vc[0], va[1] - vc[1], va[2] - vc[2],
+             vb[0] - va[0], vb[1] - va[1], vb[2] - va[2]]
+        l = [e[0] * e[0] + e[1] * e[1] + e[2] * e[2], e[3] * e[3] + e[4] * e[4] + e[5] * e[5], e[6] * e[6] + e[7] * e[7] + e[8] * e[8]]
+        i = 1 if l[0] < l[1] else 0
+        i = 2 if l[i] < l[2] else i
+        return e, l, i, (i + 1) % 3, (i + 2) % 3
+
+    def cross_d(c):                                                        # (column c of A) x (-direction), :862-865 and friends
+        return [A[c + 4] * A[11] - A[c + 8] * A[7], A[c + 8] * A[3] - A[c] * A[11], A[c] * A[7] - A[c + 4] * A[3]]
+
+    def dot3(u, w):
+        return u[0] * w[0] + u[1] * w[1] + u[2] * w[2]
+
+    if norm <= p:                                                          # :789-848 direction degenerate to a point
+        if area > p:
+            B = [dot3(I[0:3], S), dot3(I[3:6], S), dot3(I[6:9], S)]
+            return bool(B[0] >= -p and B[1] >= -p and B[2] >= -p and -p <= N[3] <= p)
+        e, l, i, j, k = edges()
+        if l[i] > p:
+            ni = dot3(I[3 * i:3 * i + 3], I[3 * i:3 * i + 3])
+            nj = A[k] * e[3 * i] + A[k + 4] * e[3 * i + 1] + A[k + 8] * e[3 * i + 2]
+            nk = -A[j] * e[3 * i] - A[j + 4] * e[3 * i + 1] - A[j + 8] * e[3 * i + 2]
+            return bool(ni <= p and nj >= -p and nk >= -p and -p <= N[3] <= p)
+        ni = A[i] * A[i] + A[i + 4] * A[i + 4] + A[i + 8] * A[i + 8]
+        return bool(ni <= p and -p <= N[3] <= p)
+    if area <= p:                                                          # :850-911 degenerate triangle
+        e, l, i, j, k = edges()
+        if l[i] <= p:                                                      # a point
+            cr = cross_d(i)
+            ni = dot3(cr, cr)
+            n3 = -A[i] * A[3] - A[i + 4] * A[7] - A[i + 8] * A[11]
+            return bool(ni <= p and (both_direction or n3 >= -p))
+        norm_ = dot3(I[3 * i:3 * i + 3], I[3 * i:3 * i + 3])               # a segment
+        if norm_ > p:
+            cj, ck = cross_d(j), cross_d(k)
+            nj = dot3(I[3 * i:3 * i + 3], ck)
+            nk = -I[3 * i] * cj[0] - I[3 * i + 1] * cj[1] - I[3 * i + 2] * cj[2]
+            n3 = nj + nk
+        else:
+            nj = A[k] * e[3 * i] + A[k + 4] * e[3 * i + 1] + A[k + 8] * e[3 * i + 2]
+            nk = -A[j] * e[3 * i] - A[j + 4] * e[3 * i + 1] - A[j + 8] * e[3 * i + 2]
+            n3 = l[i]
+        if -p <= n3 <= p:                                                  # (coeff != NULL, :900-901)
+            n3 = p
+        return bool(-p <= N[i] <= p and nj >= -p and nk >= -p and (both_direction or n3 > p))
+    # :912-1023 direction parallel to the triangle
+    B = [dot3(I[0:3], S), dot3(I[3:6], S), dot3(I[6:9], S)]
+    i = 0 if B[0] < B[1] else 1
+    i = i if B[i] < B[2] else 2
+    j, k = (i + 1) % 3, (i + 2) % 3
+    if B[k] < -p:
+        k = j; j = i; i = 3 - j - k
+    in_plane = -p <= N[3] <= p
+    if B[j] < -p:
+        ci, cj, ck = cross_d(i), cross_d(j), cross_d(k)
+        Ii, Ij = I[3 * i:3 * i + 3], I[3 * j:3 * j + 3]
+        d0 = dot3(Ii, ck)
+        d1 = -Ii[0] * cj[0] - Ii[1] * cj[1] - Ii[2] * cj[2]
+        d2 = dot3(Ij, ci)
+        d3 = -Ij[0] * ck[0] - Ij[1] * ck[1] - Ij[2] * ck[2]
+        v0 = d0 >= -p and d1 >= -p and (both_direction or dot3(Ii, Ii) > p)
+        v1 = d2 >= -p and d3 >= -p and (both_direction or dot3(Ij, Ij) > p)
+        return bool((v0 or v1) and in_plane)
+    if B[i] < -p:
+        cj, ck = cross_d(j), cross_d(k)
+        Ii = I[3 * i:3 * i + 3]
+        nj = dot3(Ii, ck)
+        nk = -Ii[0] * cj[0] - Ii[1] * cj[1] - Ii[2] * cj[2]
+        ni = nj + nk
+        if -p <= ni <= p:                                                  # (coeff != NULL, :1004-1005)
+            ni = p
+        return bool(nj >= -p and nk >= -p and in_plane and (both_direction or ni > p))
+    return bool(B[i] >= -p and in_plane)
+
+
 def intersects_any(verts, faces, origins, directions):
-    """search_intersect's answer (mesh_grid_kernel.cu:1029-1231) by brute force: a ray hits iff SOME triangle passes the
-    regular branch of intersect_tri2 (kernel.cu:742-780: |det| > 1e-9, the three barycentric numerators and the ray
-    parameter, signed by det, >= -1e-9), evaluated in float32 in the kernel's order.  The OR over triangles does not depend
-    on the order of the reference's cell walk; its coplanar / zero-direction branches are not restated (no hit)."""
+    """search_intersect's answer (mesh_grid_kernel.cu:1029-1231) by brute force: a ray hits iff SOME triangle passes
+    intersect_tri2 (above).  The regular branch is evaluated for all triangles at once (float32, the kernel's order); the pairs with
+    |det| <= 1e-9 go through the scalar restatement of the degenerate branches.  The OR over triangles does not depend on the
+    order of the reference's cell walk."""
     f32 = np.float32
     v = np.asarray(verts, f32)
-    tri = v[np.asarray(faces, np.int64).reshape(-1, 3)]                 # [T,3,3]
+    fc = np.asarray(faces, np.int64).reshape(-1, 3)
+    tri = v[fc]                                                           # [T,3,3]
     out = np.zeros(len(origins), bool)
     prec = f32(1e-9)
     for r, (o, d) in enumerate(zip(np.asarray(origins, f32), np.asarray(directions, f32))):
-        if f32(d @ d) < prec:
+        if f32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < prec:           # kernel.cu:1062-1065
             continue
         a = tri - o                                                       # rows: va-o, vb-o, vc-o
         A0, A1, A2 = a[:, 0, 0], a[:, 1, 0], a[:, 2, 0]
@@ -166,7 +268,13 @@ def intersects_any(verts, faces, origins, directions):
         det = n0 + n1 + n2
         ok = (det > prec) | (det < -prec)
         sg = np.where(det < 0, f32(-1), f32(1))
-        out[r] = bool(np.any(ok & (n0 * sg >= -prec) & (n1 * sg >= -prec) & (n2 * sg >= -prec) & (n3 * sg >= -prec)))
+        hit = bool(np.any(ok & (n0 * sg >= -prec) & (n1 * sg >= -prec) & (n2 * sg >= -prec) & (n3 * sg >= -prec)))
+        if not hit:
+            for t in np.nonzero(~ok)[0]:
+                if intersect_tri2(o, d, tri[t, 0], tri[t, 1], tri[t, 2]):
+                    hit = True
+                    break
+        out[r] = hit
     return out
 
 

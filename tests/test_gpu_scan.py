@@ -87,9 +87,35 @@ def test_intersects_any_matches_the_bruteforce_rule(small):
     d[-30:] = sv[sf[rng.integers(0, len(sf), 30)]].mean(1) - o[-30:]        # far rays aimed at the middle of a triangle
     got = scan.intersects_any(o, d)
     want = MO.intersects_any(sv, sf, o, d)
+    print("intersects_any: rays that differ from the brute force", int((got != want).sum()), "of", len(got))
     assert np.mean(got == want) > 0.995                                  # (a grazing ray may differ by a float32 rounding in the walk)
     assert want[-30:].all() and got[-30:].all() and 0.2 < want.mean() < 0.95
     assert not scan.intersects_any(o[:4], np.zeros((4, 3), np.float32)).any()
+    scan.close()
+
+
+def test_intersects_any_coplanar_and_degenerate_cases():
+    """intersect_tri2's branches for rays in a triangle's plane and for degenerate triangles (mesh_grid_kernel.cu:781-1023), on integer
+    coordinates so that every decision against 1e-9 is exact: the HIP walk agrees with the oracle's brute force on every ray"""
+    v = np.array([[0, 0, 0], [4, 0, 0], [0, 4, 0],                       # a triangle in the plane z = 0
+                  [0, 10, 0], [2, 10, 0], [4, 10, 0],                    # a triangle that is a segment
+                  [8, 8, 3], [8, 8, 3], [8, 8, 3],                       # a triangle that is a point
+                  [-6, -6, -5], [12, -6, -5], [-6, 14, -5], [0, 0, 9]], np.float32)   # a tetrahedron around them (a 3-D bounding box)
+    f = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11], [9, 10, 12], [10, 11, 12], [11, 9, 12]], np.int32)
+    rng = np.random.default_rng(3)
+    n = 900
+    o = np.stack([rng.integers(-5, 12, n), rng.integers(-5, 13, n), rng.choice([0, 0, 0, 1, 3], n)], 1).astype(np.float32)
+    d = np.stack([rng.integers(-3, 4, n), rng.integers(-3, 4, n), rng.choice([0, 0, 0, 1, -1], n)], 1).astype(np.float32)
+    d[:40] = np.array([8, 8, 3], np.float32) - o[:40]                    # aimed at the point triangle
+    o[40:80, 1] = 10; d[40:80, 1] = 0; d[40:80, 2] = 0; d[40:80, 0] = rng.choice([-1, 1], 40)      # along the segment's line
+    scan = N.Scan(v, f)
+    got = scan.intersects_any(o, d)
+    want = MO.intersects_any(v, f, o, d)
+    np.testing.assert_array_equal(got, want)
+    only_first = MO.intersects_any(v, f[:3], o, d)                       # hits that exist only through the degenerate branches
+    assert only_first[:40].all() and 30 < only_first.sum() < n - 30
+    planar = (o[:, 2] == 0) & (d[:, 2] == 0)
+    assert only_first[planar].any() and (~only_first[planar]).any()
     scan.close()
 
 

@@ -186,3 +186,30 @@ def test_oracle_scan_fit_matches_reference_golden(small_model, gmm_bufs):
     np.testing.assert_allclose(res["disp_snapshots"][1], g["disp1"], atol=1e-6)
     d11 = np.abs(res["disp_snapshots"][11] - g["disp11"])
     assert np.mean(d11 < 1e-4) > 0.6
+
+
+def test_intersect_tri2_degenerate_branches_known_answers():
+    """intersect_tri2's branches for |det| <= 1e-9 (mesh_grid_kernel.cu:781-1023) on integer coordinates - every product and sum
+    is exact, so the answer is the geometric one: rays IN the triangle's plane, a triangle that is a segment, one that is a point"""
+    A, B, C = (0, 0, 0), (4, 0, 0), (0, 4, 0)
+    hit = lambda o, d, tri=(A, B, C): MO.intersect_tri2(o, d, *tri)
+    # ray in the plane z = 0
+    assert hit((1, 1, 0), (1, 0, 0)) and hit((1, 1, 0), (-1, -1, 0))              # origin inside: any in-plane direction
+    assert hit((-2, 1, 0), (1, 0, 0)) and not hit((-2, 1, 0), (-1, 0, 0))          # outside edge CA: towards / away
+    assert not hit((-2, 1, 0), (0, 1, 0))                                          # outside edge CA, parallel to it
+    assert hit((1, -3, 0), (0, 1, 0)) and not hit((5, -3, 0), (0, 1, 0))           # outside edge AB: into the triangle / past corner B
+    assert hit((-1, -1, 0), (1, 1, 0)) and not hit((-1, -1, 0), (1, -1, 0))        # outside two edges (corner A): through it / missing it
+    assert hit((6, 6, 0), (-1, -1, 0)) and not hit((6, 6, 0), (1, 1, 0))           # outside the hypotenuse BC
+    assert not hit((1, 1, 1), (1, 0, 0)) and not hit((1, 1, -2), (0, 1, 0))        # parallel to the plane but off it
+    assert hit((1, 1, 1), (0, 0, -1)) and not hit((1, 1, 1), (0, 0, 1))            # (the regular branch, for contrast)
+    # a triangle that is a segment from (0,0,0) to (4,0,0)
+    seg = ((0, 0, 0), (2, 0, 0), (4, 0, 0))
+    assert hit((1, -1, 0), (0, 1, 0), seg) and not hit((1, -1, 0), (0, -1, 0), seg)
+    assert not hit((5, -1, 0), (0, 1, 0), seg)                                     # crosses the line beyond the end
+    assert not hit((1, -1, 1), (0, 1, 0), seg)                                     # not coplanar with the segment
+    assert hit((3, 2, 2), (0, -1, -1), seg)                                        # an oblique ray through (3, 0, 0)
+    # a triangle that is a point
+    pt = ((1, 1, 1), (1, 1, 1), (1, 1, 1))
+    assert hit((0, 0, 0), (1, 1, 1), pt) and not hit((0, 0, 0), (-1, -1, -1), pt) and not hit((0, 0, 0), (1, 0, 0), pt)
+    # zero direction (reachable only when intersect_tri2 is called directly): the origin must be ON the triangle
+    assert hit((1, 1, 0), (0, 0, 0)) and not hit((5, 5, 0), (0, 0, 0)) and not hit((1, 1, 1), (0, 0, 0))
