@@ -209,8 +209,8 @@ int bf_scan_nearest_backward(bf_scan *s, int n, const int32_t *face_ids, const f
  * nearest grid wall), -1 outside or off the grid. */
 int bf_scan_inside(bf_scan *s, int n, const float *points, float *signs);
 /* MeshGridSearcher.intersects_any / search_intersect (utils/mesh_grid_searcher.py:93-99, mesh_grid.cpp:92-110,
- * mesh_grid_kernel.cu:742-780,1029-1231): hit[n] = 1 when the ray origins[i] + t directions[i], t >= 0, meets a triangle
- * (the reference's regular per-triangle test; its branches for rays inside a triangle's plane are not reproduced). */
+ * mesh_grid_kernel.cu:742-1026,1029-1231): hit[n] = 1 when the ray origins[i] + t directions[i], t >= 0, meets a triangle by the
+ * reference's per-triangle test intersect_tri2, its branches for rays inside a triangle's plane and for degenerate triangles included. */
 int bf_scan_intersects(bf_scan *s, int n, const float *origins, const float *directions, uint8_t *hit);
 /* use_mesh=True: scans[F], one per frame (NULL detaches).  Sets each frame's constant scale to
  * scan_height / 1.7 (smplify.py:156); bf_fit then adds 5 * point_cloud_loss / scan_height * imsize for
