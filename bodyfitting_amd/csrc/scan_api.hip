@@ -11,6 +11,8 @@ extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const fl
                                         const float *, int, int, int);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int, int *, int);
 extern "C" int bf_mesh_use_multi(int npf, int n);
+extern "C" __global__ void bf_door_probe_kernel(int *);
+extern "C" __global__ void bf_door_ring_kernel(int *);
 extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
                                              const float *, float *, float *, float *, MeshTab, const float *, const float *);
 extern "C" __global__ void bf_grid_count_kernel(ScanDev, int *);
@@ -439,9 +441,14 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     const bool sub = sub_ok && m->sub.on && b->scans.empty();
     static const bool door_ok = [] { const char *e = std::getenv("BF_DENSE_PERSISTENT"); return !(e && e[0] == '0'); }();
     const int n_dense = n_iters - n_plain;
-    if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES) {
+    if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES && (!b->fit_stream || b->door_usable)) {
         if (!b->fit_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&b->fit_stream, hipStreamNonBlocking));
+            // the fit stream gets the highest priority: the runtime keeps a pool of hardware queues per priority, so it does not end
+            // up on the queue of this (or another) batch's ordinary stream - where the dense kernels would queue up BEHIND the
+            // resident launch that is waiting for them
+            int least = 0, greatest = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIP_TRY(hipStreamCreateWithPriority(&b->fit_stream, hipStreamNonBlocking, greatest));
             HIP_TRY(hipEventCreateWithFlags(&b->ev_door[0], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&b->ev_door[1], hipEventDisableTiming));
             HIP_TRY(b->door.alloc(BF_DOOR_INTS));
@@ -454,7 +461,20 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
             iow.ext = b->ext.p; iow.image_out = nullptr; iow.n_frames = 1;
             HIP_TRY(bf_fit_launch(&m->fit, &iow, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->fit_stream));
             HIP_TRY(hipStreamSynchronize(b->fit_stream));
+            // ... and checked: do the two streams really run side by side? (bf_door_probe_kernel)
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            HIP_TRY(hipMemset(b->door.p, 0, BF_DOOR_STATE * sizeof(int)));
+            hipLaunchKernelGGL(bf_door_probe_kernel, dim3(1), dim3(64), 0, b->fit_stream, b->door.p);
+            hipLaunchKernelGGL(bf_door_ring_kernel, dim3(1), dim3(64), 0, b->stream, b->door.p);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(b->fit_stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            int verdict = 0;
+            HIP_TRY(hipMemcpy(&verdict, b->door.p + BF_DOOR_TICKET, sizeof(int), hipMemcpyDeviceToHost));
+            b->door_usable = verdict == 1;
         }
+    }
+    if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES && b->door_usable) {
         *(volatile int *)b->h_resident = 0;
         HIP_TRY(hipMemsetAsync(b->door.p, 0, BF_DOOR_INTS * sizeof(int), b->stream));
         HIP_TRY(hipEventRecord(b->ev_door[0], b->stream));              // parameters / Adam state / doorbells as the loop finds them

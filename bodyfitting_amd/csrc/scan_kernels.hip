@@ -501,6 +501,21 @@ extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT
 
 
 // grid (ceil(EXT/32), F), 256 threads = 32 outputs x 8 tile chunks: ext[f][i] = sum over the tiles of part[f][tile][i].
+// Self-test of the two streams the resident fit launch needs (scan_api.hip): `probe` on the fit stream waits (bounded) for a
+// bell that `ring` on the batch stream sets.  If the runtime has put both streams on one hardware queue the ring cannot start while
+// the probe runs, and the probe reports 2 instead of 1: the batch then keeps one fit launch per iteration.
+extern "C" __global__ void bf_door_probe_kernel(int *door) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    int seen = 0;
+    while (!(seen = __hip_atomic_load(door + BF_DOOR_EXT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < 2000000LL)   // 20 ms
+        __builtin_amdgcn_s_sleep(8);
+    __hip_atomic_store(door + BF_DOOR_TICKET, seen ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+extern "C" __global__ void bf_door_ring_kernel(int *door) {
+    if (threadIdx.x == 0) __hip_atomic_store(door + BF_DOOR_EXT, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // A chunk lane adds its contiguous run of tiles in tile order (loads issued eight at a time: a plain serial loop costs
 // one memory latency per tile), then the eight chunk sums are added in chunk order: a fixed order, run to run.
 extern "C" __global__ void __launch_bounds__(256)
