@@ -831,6 +831,8 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (rc) return rc;
     HyperDev hd = bf_to_dev(h);
     FrameIO io = bf_frame_io(b, false);
+    rc = bf_ensure_fit_image(b, io, hd);          // (once per model: the fit kernel's batched prologue, before any graph captures a launch)
+    if (rc) return rc;
     const bool dense_losses = !b->scans.empty() || b->has_masks || m->kp_dense;
     if (dense_losses) flags &= ~BF_FIT_DENSE;
     const bool dense = flags & BF_FIT_DENSE, want_v = !(flags & BF_FIT_NO_VERTICES), fetch = flags & BF_FIT_FETCH;

@@ -169,6 +169,7 @@ struct bf_scan {
 
 // shared between api.hip and scan_api.hip
 extern "C" {
+int bf_ensure_fit_image(struct bf_batch *b, FrameIO io, const HyperDev &hd);
 int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw = nullptr,
                    int *lmk_vid = nullptr, float *lmk_w = nullptr, float *dvzero = nullptr, bool *zeroed = nullptr, bool want_xpart = false,

@@ -244,13 +244,14 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     auto theta_of = [&](const float *P, int j, int k) {
         return bf_theta(P, j, k, S.thk, S.tho, S.pmean, S.hcomp, T.n_pca, T.off_lh, T.off_rh);
     };           // 0 = some selector vertex has more than BF_SEL_NNZ bones: dense loop
-    // Dense-schedule launches run ONE iteration, so their prologue is on the critical path of every iteration.  Once a first
+    // Dense-schedule launches run ONE iteration, so their prologue is on the critical path of every iteration (and a sparse-schedule
+    // launch of 100 iterations still spends 2 % of its time in it).  Once a first
     // launch has left an image of the model-constant LDS arrays (three contiguous runs of the carve, FitTab::img_seg), everything
     // such a launch needs from global memory is issued back to back into registers - image, projection matrices, parameters,
     // Adam moments, the outside gradient blocks, the tree levels - and stored to LDS after ONE round trip, instead of two dozen
     // dependent load -> store loops at ~2,500 cycles each (a kernel starts with cold caches).
     const int n_ext = npf + nj * 12 + nb + 4 + nj * 3 + 4;
-    const bool use_image = EXT && T.lds_image != nullptr && mode != 2 && V * 3 <= nt && np <= nt && n_ext <= 3 * nt &&
+    const bool use_image = T.lds_image != nullptr && mode != 2 && V * 3 <= nt && np <= nt && n_ext <= 3 * nt &&
                            T.img_seg[0][1] + T.img_seg[1][1] + T.img_seg[2][1] <= 4 * nt && nj <= nt && T.n_levels < 66;
     if (use_image) {
         const float4 *img = (const float4 *)__builtin_assume_aligned(T.lds_image, 16);
@@ -273,11 +274,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             r_pa = (io.params0 ? io.params0 : io.params)[(size_t)frame * np + tid];
             if (!io.params0) { r_am = io.adam_m[(size_t)frame * np + tid]; r_av = io.adam_v[(size_t)frame * np + tid]; }
         }
-        const float *eg = io.ext + (size_t)frame * n_ext;
+        if (EXT) {
+            const float *eg = io.ext + (size_t)frame * n_ext;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) if (!door && q * nt + tid < n_ext) r_ext[q] = eg[q * nt + tid];
-        if (tid < nj) { r_lj = T.level_joints[tid]; r_dp = T.depth[tid]; }
-        if (tid <= T.n_levels) r_ls = T.level_start[tid];
+            for (int q = 0; q < 3; ++q) if (!door && q * nt + tid < n_ext) r_ext[q] = eg[q * nt + tid];
+            if (tid < nj) { r_lj = T.level_joints[tid]; r_dp = T.depth[tid]; }
+            if (tid <= T.n_levels) r_ls = T.level_start[tid];
+        }
         // zero-initialised arrays: GMM d / y, and the keypoint table when this launch has no loss joints
         for (int i = tid; i < 2 * BF_GMM_M * BF_GMM_LD; i += nt) S.gd[i] = 0.f;          // (gd and gy are adjacent in the carve)
         if (nl == 0) for (int i = tid; i < BF_VSUB * BF_KP_ROUNDS * 16 * 2; i += nt) ((float4 *)S.kp)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -285,10 +288,12 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         for (int q = 0; q < 4; ++q) if (at[q] >= 0) lds4[at[q]] = v[q];
         if (tid < V * 3) ((float4 *)S.proj)[tid] = vp;
         if (tid < np) { S.pa[tid] = r_pa; S.am[tid] = r_am; S.av[tid] = r_av; }
+        if (EXT) {
 #pragma unroll
-        for (int q = 0; q < 3; ++q) if (q * nt + tid < n_ext) S.ext[q * nt + tid] = r_ext[q];
-        if (tid < nj) { S.lvl[tid] = r_lj; S.lvl[nj + 67 + tid] = r_dp; }
-        if (tid <= T.n_levels) S.lvl[nj + tid] = r_ls;
+            for (int q = 0; q < 3; ++q) if (q * nt + tid < n_ext) S.ext[q * nt + tid] = r_ext[q];
+            if (tid < nj) { S.lvl[tid] = r_lj; S.lvl[nj + 67 + tid] = r_dp; }
+            if (tid <= T.n_levels) S.lvl[nj + tid] = r_ls;
+        }
     } else {
     copy_f(S.Jt, T.Jt, nj3, tid, nt);
     copy_f(S.Jtrel, T.Jtrel, nj3, tid, nt);
@@ -436,7 +441,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     BF_KMARK(0, 0); BF_KMARK(1, 256);
     __syncthreads();
     BF_KMARK(2, 0);
-    if (EXT && mode == 2) {                                  // image builder: leave the LDS segment as it is now and stop
+    if (mode == 2) {                                         // image builder: leave the LDS segment as it is now and stop
         if (frame == 0 && io.image_out)
             for (int i = tid; i < T.lds_image_n4 * 4; i += nt) io.image_out[i] = smem_raw[i];
         return;

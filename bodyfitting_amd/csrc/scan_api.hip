@@ -389,7 +389,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
 // FitTab::lds_image of the model's dense-schedule fit instance: one launch in mode 2 runs the kernel's ordinary prologue and
 // dumps the LDS segment (everything up to the per-view projection matrices, which come last in the carve).  Built once per
 // model, under its lock, finished before the pointer becomes visible.
-static int ensure_fit_image(bf_batch *b, FrameIO io, const HyperDev &hd) {
+int bf_ensure_fit_image(bf_batch *b, FrameIO io, const HyperDev &hd) {
     bf_model *m = b->m;
     std::lock_guard<std::mutex> g(m->lazy);
     if (m->fit.lds_image) return BF_OK;
@@ -399,7 +399,7 @@ static int ensure_fit_image(bf_batch *b, FrameIO io, const HyperDev &hd) {
     FitTab T = m->fit;
     T.lds_image_n4 = (int)(bytes / 16);
     HIP_TRY(m->fit_image.alloc(bytes / sizeof(float)));
-    io.ext = b->ext.p; io.image_out = m->fit_image.p; io.n_frames = 1;
+    io.ext = nullptr; io.image_out = m->fit_image.p; io.n_frames = 1;      // (the carve, hence the image, is the same for every instance of the model's sizes)
     HIP_TRY(bf_fit_launch(&T, &io, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     m->fit.lds_image_n4 = T.lds_image_n4;
@@ -433,7 +433,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     if (rc) return rc;
     if (n_plain > 0)
         HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream));
-    if (n_plain < n_iters) { rc = ensure_fit_image(b, io, hd); if (rc) return rc; }
+    if (n_plain < n_iters) { rc = bf_ensure_fit_image(b, io, hd); if (rc) return rc; }
     // The dense iterations with the fit kernel RESIDENT (one launch on a second stream, paced by doorbells, BfDoor) when the
     // forward pass is a kernel that knows how to wait (1..15 frames); BF_DENSE_PERSISTENT=0, or a larger batch, keeps one fit launch
     // per iteration, with the pose state from bf_pose_state_kernel every time.
