@@ -1,6 +1,7 @@
 // Host side of the scan (use_mesh) path: grid construction, closest-point queries, and the per-iteration
 // schedule of smplify.py:205-213 with the point-cloud loss switched on after num_iters // 3.
 #include "bf_host.h"
+#include <atomic>
 #include <chrono>
 
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
@@ -404,6 +405,7 @@ int bf_ensure_fit_image(bf_batch *b, FrameIO io, const HyperDev &hd) {
     HIP_TRY(hipStreamSynchronize(b->stream));
     m->fit.lds_image_n4 = T.lds_image_n4;
     bf_fit_image_segments(m->fit.nj, m->fit.nb, m->fit.npf, m->fit.ns, m->fit.nl, m->fit.np, &m->fit.img_seg[0][0]);
+    std::atomic_thread_fence(std::memory_order_release);      // (launches on other threads copy m->fit without the lock: sizes before the pointer)
     m->fit.lds_image = m->fit_image.p;
     return BF_OK;
 }
@@ -498,7 +500,12 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
                 }
             }
             rc = dense_pass(b, h, hd, it > thr, 5.0f, b->door.p, it - n_plain + 1, sub);
-            if (rc) return rc;
+            if (rc) {               // do not leave the resident launch waiting for bells that will not ring
+                const int one = 1;
+                (void)hipMemcpy(b->door.p + BF_DOOR_ERR, &one, sizeof one, hipMemcpyHostToDevice);
+                (void)hipStreamSynchronize(b->fit_stream);
+                return rc;
+            }
         }
         HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_door[1], 0));       // the last iteration's step, terms and state
         HIP_TRY(hipMemcpyAsync(b->h_door_err, b->door.p + BF_DOOR_ERR, sizeof(int), hipMemcpyDeviceToHost, b->stream));
