@@ -843,7 +843,12 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     // (a small fetch is cheaper as a copy node inside the graph than as a second stream with two event hand-offs)
     const bool big_fetch = (want_v ? b->res.n : b->res_small) * sizeof(float) >= (size_t)512 * 1024;
     const bool pipelined = (flags & BF_FIT_GRAPH) && reset && !dense_losses && !dense && fetch && big_fetch;
-    if (!pipelined) {                // (a pipelined fetch may still be reading the arena this call writes)
+    // Small batches issued back to back without timing records (frame after frame, as the reference's loop does): the fit kernel of one
+    // call is a single-workgroup latency chain, so the mesh / joints / result hand-over of a call runs on the second stream UNDER the
+    // next call's fit kernel; the two result arenas alternate as in the pipelined fetch.
+    const bool tail_aside = (flags & BF_FIT_NOTIME) && !(flags & BF_FIT_GRAPH) && reset && !dense_losses && !dense && fetch && want_v &&
+                            !big_fetch && b->F < BF_MFMA_MIN_FRAMES;
+    if (!pipelined && !tail_aside) {                // (a pipelined fetch may still be reading the arena this call writes)
         rc = bf_guard_arena(b);
         if (rc) return rc;
     }
@@ -914,6 +919,28 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
         return BF_OK;
     }
     const bool notime = (flags & BF_FIT_NOTIME) && !dense_losses && !dense;
+    if (tail_aside) {
+        const int k = b->cur ^ 1;
+        if (b->copy_pending[k]) { HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_copied[k], 0)); b->copy_pending[k] = false; }
+        bf_use_arena(b, k);
+        FrameIO io2 = bf_frame_io(b, false);
+        io2.params0 = b->params0.p;                  // re-arm inside the fit kernel
+        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream));
+        HIP_TRY(hipEventRecord(b->ev_done[k], b->stream));
+        HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_done[k], 0));
+        rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->copy_stream, nullptr, nullptr);
+        if (rc) return rc;
+        const size_t n4 = b->res.n / 4;
+        hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->copy_stream,
+                           (const float4 *)(k ? b->res_b.p : b->res.p), (float4 *)(k ? b->h_res_b : b->h_res), n4);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(b->ev_copied[k], b->copy_stream));
+        b->copy_pending[k] = true;
+        b->fetched = true;
+        b->steps_done += n_iters;
+        b->have_result = true;
+        return BF_OK;
+    }
     if (notime) {
         rc = enqueue_plain(b, n_iters, hd, io, reset, want_v, fetch, b->steps_done, nullptr);
         if (rc) return rc;

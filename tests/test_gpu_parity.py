@@ -301,6 +301,41 @@ def test_pipelined_fetch_alternates_result_arenas(dev_model, smpl_model):
     b.close()
 
 
+def test_back_to_back_fits_hand_their_tail_to_the_second_stream(dev_model, smpl_model):
+    """Frame after frame without timing records (RESET | FETCH | NOTIME, small batch): the mesh / joints / result hand-over of a call
+    runs on the second stream under the next call's fit kernel and the two result arenas alternate.  The results are those of the
+    plain call, whichever call is read back, also when the inputs change between calls and when a continuing call follows."""
+    from bodyfitting_amd import _lib
+    pa, pb = S.make_problem(smpl_model, frame=0, n_views=12), S.make_problem(smpl_model, frame=1, n_views=12)
+    ref = {}
+    for name, pr in (("a", pa), ("b", pb)):
+        r = _batch(dev_model, [pr])
+        r.fit(12, flags=_lib.FIT_FETCH)
+        ref[name] = (r.get_params(), r.get_result())
+        r.fit(5, flags=_lib.FIT_FETCH)
+        ref[name + "+5"] = (r.get_params(), r.get_result())
+        r.close()
+    fast = _lib.FIT_FETCH | _lib.FIT_RESET | _lib.FIT_NOTIME
+    b = _batch(dev_model, [pa])
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([pb])
+    for rep in range(3):
+        for _ in range(3):                                                   # back to back, no sync in between
+            b.fit(12, flags=fast)
+        np.testing.assert_array_equal(b.get_params(), ref["a"][0])
+        for x, y in zip(b.get_result(), ref["a"][1]):
+            np.testing.assert_array_equal(x, y)
+    # other inputs, then a continuing (non-reset) call straight behind a hand-over that may still be running
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+    b.fit(12, flags=fast)
+    b.fit(12, flags=fast)
+    np.testing.assert_array_equal(b.get_params(), ref["b"][0])
+    b.fit(5, flags=_lib.FIT_FETCH)
+    np.testing.assert_array_equal(b.get_params(), ref["b+5"][0])
+    for x, y in zip(b.get_result(), ref["b+5"][1]):
+        np.testing.assert_array_equal(x, y)
+    b.close()
+
+
 def test_more_than_48_views_streams_the_rest(dev_model, smpl_model, gmm_bufs):
     """Views past the 48 staged in LDS are streamed from global memory by the projection phase: 60 views against the
     fp64 oracle (gradient) and the fp64 analytic loop (a short fit)."""
