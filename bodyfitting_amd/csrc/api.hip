@@ -569,7 +569,14 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
         ok = ok && b->res.alloc(total) == hipSuccess && b->res_b.alloc(total) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&b->h_res, total * sizeof(float)) == hipSuccess;
         ok = ok && hipHostMalloc((void **)&b->h_res_b, total * sizeof(float)) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking) == hipSuccess;
+        {
+            // the second stream on the LOWEST priority: the runtime keeps a pool of hardware queues per priority, so it never shares a
+            // queue with a batch's main stream (streams that share one run in order, and the hand-over of a call would no longer run
+            // under the next call's fit kernel - observed with two live batches)
+            int least = 0, greatest = 0;
+            ok = ok && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess &&
+                 hipStreamCreateWithPriority(&b->copy_stream, hipStreamNonBlocking, least) == hipSuccess;
+        }
         for (int k = 0; k < 2; ++k)
             ok = ok && hipEventCreateWithFlags(&b->ev_done[k], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&b->ev_copied[k], hipEventDisableTiming) == hipSuccess;
@@ -843,11 +850,10 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     // (a small fetch is cheaper as a copy node inside the graph than as a second stream with two event hand-offs)
     const bool big_fetch = (want_v ? b->res.n : b->res_small) * sizeof(float) >= (size_t)512 * 1024;
     const bool pipelined = (flags & BF_FIT_GRAPH) && reset && !dense_losses && !dense && fetch && big_fetch;
-    // Small batches issued back to back without timing records (frame after frame, as the reference's loop does): the fit kernel of one
-    // call is a single-workgroup latency chain, so the mesh / joints / result hand-over of a call runs on the second stream UNDER the
+    // Calls issued back to back without timing records (frame after frame, as the reference's loop does): the fit kernel is a
+    // latency chain of one workgroup per frame, so the mesh / joints / result hand-over of a call runs on the second stream UNDER the
     // next call's fit kernel; the two result arenas alternate as in the pipelined fetch.
-    const bool tail_aside = (flags & BF_FIT_NOTIME) && !(flags & BF_FIT_GRAPH) && reset && !dense_losses && !dense && fetch && want_v &&
-                            !big_fetch && b->F < BF_MFMA_MIN_FRAMES;
+    const bool tail_aside = (flags & BF_FIT_NOTIME) && !(flags & BF_FIT_GRAPH) && reset && !dense_losses && !dense && fetch && want_v;
     if (!pipelined && !tail_aside) {                // (a pipelined fetch may still be reading the arena this call writes)
         rc = bf_guard_arena(b);
         if (rc) return rc;
@@ -921,7 +927,10 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     const bool notime = (flags & BF_FIT_NOTIME) && !dense_losses && !dense;
     if (tail_aside) {
         const int k = b->cur ^ 1;
-        if (b->copy_pending[k]) { HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_copied[k], 0)); b->copy_pending[k] = false; }
+        if (b->copy_pending[k]) {      // (arena k's hand-over of two calls ago: normally long done - then no wait packet goes into the stream)
+            if (hipEventQuery(b->ev_copied[k]) != hipSuccess) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_copied[k], 0));
+            b->copy_pending[k] = false;
+        }
         bf_use_arena(b, k);
         FrameIO io2 = bf_frame_io(b, false);
         io2.params0 = b->params0.p;                  // re-arm inside the fit kernel
@@ -930,10 +939,14 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
         HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_done[k], 0));
         rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->copy_stream, nullptr, nullptr);
         if (rc) return rc;
-        const size_t n4 = b->res.n / 4;
-        hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->copy_stream,
-                           (const float4 *)(k ? b->res_b.p : b->res.p), (float4 *)(k ? b->h_res_b : b->h_res), n4);
-        HIP_TRY(hipGetLastError());
+        if (big_fetch) {
+            HIP_TRY(hipMemcpyAsync(k ? b->h_res_b : b->h_res, k ? b->res_b.p : b->res.p, b->res.n * fb, hipMemcpyDeviceToHost, b->copy_stream));
+        } else {
+            const size_t n4 = b->res.n / 4;
+            hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->copy_stream,
+                               (const float4 *)(k ? b->res_b.p : b->res.p), (float4 *)(k ? b->h_res_b : b->h_res), n4);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(b->ev_copied[k], b->copy_stream));
         b->copy_pending[k] = true;
         b->fetched = true;

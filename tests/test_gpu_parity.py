@@ -334,6 +334,16 @@ def test_back_to_back_fits_hand_their_tail_to_the_second_stream(dev_model, smpl_
     for x, y in zip(b.get_result(), ref["b+5"][1]):
         np.testing.assert_array_equal(x, y)
     b.close()
+    # the same with a batch on the MFMA mesh path and a result above the 512 KB that leave the publish kernel for a copy
+    probs = [S.make_problem(smpl_model, frame=f % 4, n_views=12) for f in range(20)]
+    r, b = _batch(dev_model, probs), _batch(dev_model, probs)
+    r.fit(12, flags=_lib.FIT_FETCH)
+    for _ in range(3):
+        b.fit(12, flags=fast)
+    np.testing.assert_array_equal(b.get_params(), r.get_params())
+    for x, y in zip(b.get_result(), r.get_result()):
+        np.testing.assert_array_equal(x, y)
+    r.close(); b.close()
 
 
 def test_more_than_48_views_streams_the_rest(dev_model, smpl_model, gmm_bufs):
