@@ -626,6 +626,7 @@ void bf_batch_destroy(bf_batch *b) {
     if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
     if (b->fit_stream) { (void)hipStreamSynchronize(b->fit_stream); (void)hipStreamDestroy(b->fit_stream); }
     for (auto &e : b->ev_door) if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->ev_aux) if (e) (void)hipEventDestroy(e);
     if (b->h_door_err) (void)hipHostFree(b->h_door_err);
     if (b->h_resident) (void)hipHostFree(b->h_resident);
     delete b;

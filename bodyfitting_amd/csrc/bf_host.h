@@ -118,6 +118,7 @@ struct bf_batch {
     hipStream_t copy_stream = nullptr;
     // dense schedule with the fit kernel resident for the whole call (BfDoor, bf_internal.h)
     hipStream_t fit_stream = nullptr;
+    hipEvent_t ev_aux[2] = {nullptr, nullptr};   // fork / join of the dense keypoint loss on the second stream
     bool door_usable = false;           // the self-test at first use found the fit stream running beside the batch stream
     hipEvent_t ev_door[2] = {nullptr, nullptr};
     DevBuf<int> door;

@@ -283,9 +283,9 @@ static KpIO kp_io(bf_batch *b, const bf_hyper &h, bool sub = false) {
     return K;
 }
 // (the keypoint workgroup computes the joints itself from the mesh pass's vraw / xpart: no bf_joints_kernel launch)
-static int launch_kp(bf_batch *b, const bf_hyper &h, bool sub = false) {
+static int launch_kp(bf_batch *b, const bf_hyper &h, bool sub = false, hipStream_t on = nullptr) {
     const KpIO K = kp_io(b, h, sub);
-    hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), kp_smem(K), b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
+    hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), kp_smem(K), on ? on : b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
                        (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
                        (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p, sub ? b->m->sub.mesh : b->m->mesh, (const float *)b->vraw.p,
                        (const float *)b->xpart.p);
@@ -361,7 +361,22 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
                             &projected, door, F * door_k, sub ? &Q : nullptr);
     if (rc) return rc;
     if ((kp || masks) && !zeroed) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
-    if (kp && !masks) { rc = launch_kp(b, h, sub); if (rc) return rc; }
+    // The dense keypoint loss and the closest-point search both only read the mesh: with scans attached the keypoint workgroups (one
+    // per frame, a ~25 us latency chain) run on the batch's second stream UNDER the search - that stream is idle during a dense loop
+    // and, being on another priority, has a hardware queue of its own - and are joined before bf_pc_grad_kernel adds onto their
+    // dL/dvertices.
+    const bool kp_aside = kp && !masks && scans && b->copy_stream;
+    if (kp_aside) {
+        if (!b->ev_aux[0]) {
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_aux[0], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_aux[1], hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(b->ev_aux[0], b->stream));
+        HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_aux[0], 0));
+        rc = launch_kp(b, h, sub, b->copy_stream);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(b->ev_aux[1], b->copy_stream));
+    } else if (kp && !masks) { rc = launch_kp(b, h, sub); if (rc) return rc; }
     // with a scan as well, bf_pc_grad_kernel adds onto (keypoints + silhouette): keep that order of additions
     const bool fold_views = masks && !scans;
     if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr, projected, sub); if (rc) return rc; }
@@ -371,6 +386,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         b->cface_valid = true;
         hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, b->pc_partial.p);
+        if (kp_aside) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_aux[1], 0));
         hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, (const float *)b->pc_partial.p, (const float *)b->pc_weight.p,
                            b->dvout.p, b->pc_loss.p, (kp || masks) ? 1 : 0);
