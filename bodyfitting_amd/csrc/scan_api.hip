@@ -365,6 +365,8 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     // per frame, a ~25 us latency chain) run on the batch's second stream UNDER the search - that stream is idle during a dense loop
     // and, being on another priority, has a hardware queue of its own - and are joined before bf_pc_grad_kernel adds onto their
     // dL/dvertices.
+    // (With a silhouette loss instead the keypoint workgroups ride in the contour launch: taking them out onto the second stream was
+    //  measured slower - 0.093 vs 0.085 ms per iteration - the fork / join costs more than the 7 us the merged launch waits for them.)
     const bool kp_aside = kp && !masks && scans && b->copy_stream;
     if (kp_aside) {
         if (!b->ev_aux[0]) {
