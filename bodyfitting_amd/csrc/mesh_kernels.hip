@@ -192,7 +192,7 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
 // Arithmetic and its order per frame are those of bf_mesh_kernel (rows ascending inside a row group, row groups
 // ascending, template + shape offset first, pose offset added to it), so a frame's result does not depend on the
 // batch it was in.
-#define BF_MM_CH 32
+#define BF_MM_CH 64
 template <int FPW>
 __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
 bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, float *__restrict__ vraw, float *__restrict__ vout,
