@@ -723,6 +723,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     auto door_state = [&](const float *P) {
         const PoseTabs PT{S.thk, S.tho, S.par, S.pmean, S.hcomp, S.Jd, S.Jt, pad4(nb + 1), S.lvl, S.lvl + nj, S.lvl + nj + 67};
         bf_pose_state_body<true, true, false>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, lane, 64, S.part, PT, P);
+#ifdef BF_STAMP
+        if (lane == 0) { const long long *mk = (const long long *)(S.part + 1740); for (int k = 1; k < 5; ++k) S.stamp[48 + k] = (float)(mk[k] - mk[0]); }
+#endif
     };
     static_assert(BF_VSUB * 32 * 4 >= BF_POSE_STATE_LDS, "the view-sum slots are the pose-state scratch");
     // Between phase A and the rest of an iteration (called by EVERY thread: it synchronises): publish that state, then wait for the

@@ -10,7 +10,9 @@ __device__ inline void m_rodrigues(float tx, float ty, float tz, float *R) {
     float ux = tx + 1e-8f, uy = ty + 1e-8f, uz = tz + 1e-8f;
     float a = sqrtf(ux * ux + uy * uy + uz * uz);
     float nx = tx / a, ny = ty / a, nz = tz / a;
-    float s = sinf(a), c = cosf(a), oc = 1.0f - c;
+    float s, c;
+    sincosf(a, &s, &c);            // (one argument reduction for both; the same values as sinf / cosf)
+    const float oc = 1.0f - c;
     R[0] = 1.0f + oc * (-nz * nz - ny * ny);
     R[1] = s * (-nz) + oc * (nx * ny);
     R[2] = s * ny + oc * (nx * nz);
@@ -82,6 +84,13 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
                                                    const int f, const int tid, const int nt, float *lds, const PoseTabs P,
                                                    const float *packed_lds = nullptr) {
     // lds: BF_POSE_STATE_LDS floats of workgroup-shared scratch
+#ifdef BF_STAMP
+    long long *bf_marks = (long long *)(lds + 1740);
+#define BF_PMARK(k) do { if (WAVE && tid == 0) bf_marks[k] = clock64(); } while (0)
+#else
+#define BF_PMARK(k) do { } while (0)
+#endif
+    BF_PMARK(0);
     float *R = lds, *J = R + 64 * 9, *GR = J + 64 * 3, *Gt = GR + 64 * 9;
     int *s_ls = (int *)(Gt + 64 * 3), *s_lj = s_ls + 66, *s_par = s_lj + 64;   // tree levels and parents: read once, not once per level (dependent global loads)
     const int nj = T.nj, nb = T.nb, npf = T.npf;
@@ -101,7 +110,9 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
             const float *src = tid == 0 ? orient + (size_t)f * 3 : body_pose + (size_t)f * 3 * (nj - 1) + 3 * (tid - 1);
             th[0] = src[0]; th[1] = src[1]; th[2] = src[2];
         }
+        BF_PMARK(1);
         m_rodrigues(th[0], th[1], th[2], R + tid * 9);
+        BF_PMARK(2);
         st.theta[tid * 3] = th[0]; st.theta[tid * 3 + 1] = th[1]; st.theta[tid * 3 + 2] = th[2];
     }
     if (nb <= 16) {
@@ -126,6 +137,7 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
         J[i] = P.Jt[i] + acc;
     }
     if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
+    BF_PMARK(3);
     if (tid < 9) GR[tid] = R[tid];
     if (tid >= 9 && tid < 12) Gt[tid - 9] = J[tid - 9];
     if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
@@ -173,6 +185,7 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
         }
         if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     }
+    BF_PMARK(4);
     if constexpr (EMIT) bf_pose_state_emit<PACKED>(T, sim, state, packed, cscale, cscale_all, f, tid, nt, lds, betas, packed_lds);
 }
 

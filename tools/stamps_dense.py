@@ -23,6 +23,7 @@ for rep in range(2):
     st = d[:12]
     print("rep", rep, "per-barrier cumulative cycles of the iteration:", [int(x) for x in st])
     print("  door marks (cycles since phase A ended): state written", int(d[56]), " ext bell seen", int(d[57]), " ext staged", int(d[58]), "| wave 7 pose state done at", int(d[59]), "cycles of the iteration")
+    print("  pose state on wave 3 (cycles from its start): theta assembled", int(d[49]), " rotations", int(d[50]), " rest joints", int(d[51]), " chain", int(d[52]))
     k = d[64:72]
     print("  kernel entry -> prologue done (t0, t256):", int(k[0]), int(k[1]), " after its barrier:", int(k[2]))
     k2 = d[72:80]
