@@ -48,7 +48,7 @@ bf_tex_project_kernel(int nv, const float *__restrict__ verts, TexView V, float 
 // pass 0: the record + count the tiles of the box; pass 1: write the face into their lists (cursor = running start)
 extern "C" __global__ void __launch_bounds__(256)
 bf_tex_face_kernel(int nf, const int *__restrict__ faces, const float *__restrict__ pv, int is, int tiles, float *__restrict__ frec,
-                   int *__restrict__ tile_count, int *__restrict__ cursor, int *__restrict__ tile_list, int pass) {
+                   int *__restrict__ tile_count, int *__restrict__ cursor, int *__restrict__ tile_list, int pass, int cap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nf) return;
     float *rec = frec + (size_t)i * BF_TEX_REC;
@@ -84,7 +84,7 @@ bf_tex_face_kernel(int nf, const int *__restrict__ faces, const float *__restric
         for (int tx = x0 / BF_TEX_TILE; tx <= x1 / BF_TEX_TILE; ++tx) {
             const int tile = ty * tiles + tx;
             if (pass == 0) atomicAdd(tile_count + tile + 1, 1);
-            else tile_list[atomicAdd(cursor + tile, 1)] = i;
+            else { const int slot = atomicAdd(cursor + tile, 1); if (slot < cap) tile_list[slot] = i; }      // (cap: the host re-runs the pass with a larger list when the total said so)
         }
 }
 
@@ -118,7 +118,7 @@ __device__ __forceinline__ void tex_corners(const float w[3], float depth, const
 extern "C" __global__ void __launch_bounds__(256)
 bf_tex_raster_kernel(int is, int tiles, const float *__restrict__ frec, const int *__restrict__ tile_start, const int *__restrict__ tile_list,
                      const float *__restrict__ textures, int ts, float near, float far, float bg0, float bg1, float bg2,
-                     float *__restrict__ pix, float *__restrict__ rgb) {
+                     float *__restrict__ pix, float *__restrict__ rgb, int cap) {
     __shared__ float s_f[4][64][19];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, tile = blockIdx.x * 4 + wv;
     if (tile >= tiles * tiles) return;                     // (wave-uniform)
@@ -127,7 +127,7 @@ bf_tex_raster_kernel(int is, int tiles, const float *__restrict__ frec, const in
     const float yp = (2.f * yi + 1 - is) / is, xp = (2.f * xi + 1 - is) / is;
     float depth_min = far, wmin[3] = {0.f, 0.f, 0.f};
     int fmin = -1;
-    const int s0 = tile_start[tile], s1 = tile_start[tile + 1];
+    const int s0 = min(tile_start[tile], cap), s1 = min(tile_start[tile + 1], cap);
     for (int base = s0; base < s1; base += 64) {
         const int n = min(64, s1 - base);
         __builtin_amdgcn_wave_barrier();

@@ -147,6 +147,27 @@ def test_faces_with_a_large_pixel_box_take_the_per_pixel_path():
     r.close()
 
 
+def test_tile_lists_grow_when_a_render_needs_more_than_the_first_guess():
+    """two faces that cover all 4,096 tiles of a 256 x 256 render (8,192 list entries against a first capacity of ~5,100): the
+    render is repeated with larger lists behind the caller's back and comes out complete"""
+    v = np.array([[-3, -3, 2.0], [3, -3, 2.0], [3, 3, 2.0], [-3, 3, 2.0]], np.float32)
+    f = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    K = np.array([[256, 0, 128], [0, 256, 128], [0, 0, 1]], np.float32)
+    pv = TO.project(v, K, np.eye(3, dtype=np.float32), np.zeros(3, np.float32), 256)[f]
+    back = (pv[:, 2, 1] - pv[:, 0, 1]) * (pv[:, 1, 0] - pv[:, 0, 0]) < (pv[:, 1, 1] - pv[:, 0, 1]) * (pv[:, 2, 0] - pv[:, 0, 0])
+    f[back] = f[back][:, ::-1]
+    tex = np.broadcast_to(np.array([0.25, 0.5, 0.75], np.float32), (2, 4, 4, 4, 3)).copy()
+    r = TF.Renderer(256, 4, near=0.0, far=10.0)
+    r.set_mesh(r.TARGET, (v, f, tex)); r.set_mesh(r.FITTED, (v, f, 0 * tex))
+    img = r.render_rgb(r.TARGET, np.eye(4))
+    np.testing.assert_allclose(img, np.array([0.25, 0.5, 0.75], np.float32)[:, None, None] * np.ones((3, 256, 256), np.float32), atol=1e-6)
+    np.testing.assert_array_equal(r.render_rgb(r.TARGET, np.eye(4)), img)
+    loss = r.step(np.eye(4), 1e-2)                                   # the fitted mesh's lists overflow inside a step as well
+    assert loss == pytest.approx(256 * 256 * 1.5, rel=1e-6)
+    assert r.step(np.eye(4), 1e-2) < loss
+    r.close()
+
+
 def test_nothing_in_front_of_the_camera_renders_the_background():
     r, scan, fit, views, dist = _setup()
     away = views[0].copy()
