@@ -1,5 +1,6 @@
 // The pose state of one parameter set (theta, beta -> chain matrices A_j, pose feature): the body of bf_pose_state_kernel, also run
-// at the end of a dense-schedule fit launch for the parameters it just stepped (fit_kernels.hip), so that both produce the same bits.
+// by one wave of the resident dense-schedule fit launch for the parameters of every iteration (fit_kernels.hip: door_state), so that
+// both produce the same bits.
 #pragma once
 #include "bf_internal.h"
 
@@ -26,7 +27,7 @@ __device__ inline void m_rodrigues(float tx, float ty, float tz, float *R) {
 }  // namespace
 
 // Where the body reads the model's small tables from: the FitTab's global arrays, or copies a caller already holds in LDS
-// (the fit kernel's tail: a dependent global load costs ~700 cycles, there are a dozen of them in a row here)
+// (the resident dense-schedule fit launch: a dependent global load costs ~700 cycles, there are a dozen of them in a row here)
 struct PoseTabs {
     const int *th_kind, *th_off, *parents;
     const float *pose_mean, *hand_comp, *Jd, *Jt;
