@@ -1032,7 +1032,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_SYNC();
 
         // ================= phase D: similarity, multi-view projection, GMoF and its gradient
-        project(it == n_iters - 1 || mode == 1);
+        if (nl > 0) project(it == n_iters - 1 || mode == 1);      // (no loss joints in this launch - the dense keypoint path: nothing to project)
         BF_SYNC();
 
         // (this step's Adam constants: a global read, issued ahead of its use)
@@ -1062,7 +1062,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             float acc = 0.f;
 #pragma unroll
             for (int w = 0; w < 16; ++w) acc += pq[w];
-            S.scal[3 + q] = acc;
+            S.scal[3 + q] = nl > 0 ? acc : 0.f;               // (the slots are only written by the projection phase)
         }
         if (wave < 3) {
             constexpr int NSC = NS > 0 ? NS : 1;
@@ -1207,7 +1207,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             float acc = 0.f;
 #pragma unroll
             for (int w = 0; w < 16; ++w) acc += pq[w];
-            S.scal[3 + q] = acc;
+            S.scal[3 + q] = nl > 0 ? acc : 0.f;               // (the slots are only written by the projection phase)
         }
         for (int idx = NG - 1 - tq; idx < ns3; idx += NG) {   // taken from the far end of the geometry waves
             int sv = idx / 3, b = idx - sv * 3;
