@@ -55,8 +55,24 @@ bf_disp_vertex_kernel(const int *__restrict__ adj_start, const int *__restrict__
 extern "C" __global__ void __launch_bounds__(256)
 bf_disp_vgrad_kernel(const int *__restrict__ faces, const int *__restrict__ adj_start, const int *__restrict__ adj, int nf, int nv,
                      const float *__restrict__ vnorm, const float *const *__restrict__ scan_fn, const int *__restrict__ cface, const float *__restrict__ cscale,
-                     float *__restrict__ dvraw /*[F][nv][3]*/) {
+                     float *__restrict__ dvraw /*[F][nv][3]*/, const float *__restrict__ P, const float *__restrict__ C,
+                     float *__restrict__ pc_partial) {
     const int v = blockIdx.x * 256 + threadIdx.x, fr = blockIdx.y;
+    if (pc_partial) {
+        // this block's share of |P - C|^2 while it is here (bf_pc_partial_kernel's sums in its order: one launch less per iteration)
+        __shared__ float s_pc[4];
+        float a = 0.f;
+        if (v < nv) {
+            const float *p = P + ((size_t)fr * nv + v) * 3, *c = C + ((size_t)fr * nv + v) * 3;
+            const float d0 = p[0] - c[0], d1 = p[1] - c[1], d2 = p[2] - c[2];
+            a = d0 * d0 + d1 * d1 + d2 * d2;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if ((threadIdx.x & 63) == 0) s_pc[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) pc_partial[(size_t)fr * gridDim.x + blockIdx.x] = (s_pc[0] + s_pc[1]) + (s_pc[2] + s_pc[3]);
+    }
     if (v >= nv) return;
     const float w = cscale[fr] * 0.1f;                                  // smplify.py:242
     const float4 *vn = (const float4 *)vnorm + (size_t)fr * nv;

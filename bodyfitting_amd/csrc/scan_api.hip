@@ -37,7 +37,7 @@ extern "C" __global__ void bf_mask_gsum_kernel(MaskIO, const float *, float *);
 extern "C" __global__ void bf_disp_face_kernel(const int *, int, int, const float *, const float *, float *);
 extern "C" __global__ void bf_disp_vertex_kernel(const int *, const int *, int, int, const float *, const float *, const float *, float *, float *);
 extern "C" __global__ void bf_disp_vgrad_kernel(const int *, const int *, const int *, int, int, const float *, const float *const *,
-                                                const int *, const float *, float *);
+                                                const int *, const float *, float *, const float *, const float *, float *);
 extern "C" __global__ void bf_disp_fgrad_kernel(const int *, int, int, const float *, const float *, const float *, float *);
 extern "C" __global__ void bf_disp_adam_kernel(const int *, const int *, int, int, const float *, const float *, const float *, int,
                                                const float *, float *, float *, float *, float, float, float, float, float);
@@ -767,11 +767,10 @@ int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
         hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv + 3) / 4, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p, (const float *)b->disp_P.p, nv,
                            b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);
         b->cface_valid = true;
-        hipLaunchKernelGGL(bf_pc_partial_kernel, gv, dim3(256), 0, b->stream, (const float *)b->disp_P.p, (const float *)b->cpts.p, nv,
-                           b->pc_partial.p);
         hipLaunchKernelGGL(bf_disp_vgrad_kernel, gv, dim3(256), 0, b->stream, (const int *)m->faces_d.p, (const int *)m->adj_start.p,
                            (const int *)m->adj.p, nf, nv, (const float *)b->disp_vn.p, (const float *const *)b->scan_fn.p,
-                           (const int *)b->cface.p, (const float *)b->cscale.p, b->disp_dv.p);
+                           (const int *)b->cface.p, (const float *)b->cscale.p, b->disp_dv.p, (const float *)b->disp_P.p,
+                           (const float *)b->cpts.p, b->pc_partial.p);      // (+ the block sums of |P - C|^2: was bf_pc_partial_kernel)
         hipLaunchKernelGGL(bf_disp_fgrad_kernel, gf, dim3(256), 0, b->stream, (const int *)m->faces_d.p, nf, nv, (const float *)b->disp_P.p,
                            (const float *)b->disp_fn.p, (const float *)b->disp_dv.p, b->disp_dPf.p);
         const float step_size = (float)((double)h.lr_displacement / (1.0 - std::pow(b1, it)));
