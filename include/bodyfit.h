@@ -116,7 +116,9 @@ typedef struct bf_hyper {
                                     into a hipGraph once and replay it - one host command per fit (per-kernel device times are
                                     then not split: bf_batch_last_timing charges everything to ms[0]) */
 #define BF_FIT_NOTIME      32u   /* do not bracket the parts of this call with HIP events (bf_batch_last_timing / timing_sum skip it):
-                                     four event records per call are a measurable share of a 0.65 ms step */
+                                     four event records per call are a measurable share of a 0.65 ms step.  With BF_FIT_RESET |
+                                     BF_FIT_FETCH on the keypoint-only path the mesh / joints / result hand-over of the call then runs
+                                     on the batch's second stream, under the fit kernel of the NEXT call (frame after frame) */
 #define BF_FIT_FETCH        4u   /* queue the device->host copies of the result into the batch's pinned
                                     staging buffers behind the kernels (bf_batch_get_result then only
                                     waits for them) */
