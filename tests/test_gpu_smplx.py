@@ -207,3 +207,22 @@ def test_sub_model_loop_matches_the_full_model_loop():
     a = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "1"}, n_iters=6, masks=True)          # 2 keypoint-only + 4 silhouette iterations
     b = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "0"}, n_iters=6, masks=True)
     np.testing.assert_allclose(a, b, rtol=0, atol=2e-3)                              # (a near-tie flip away at most, cf. MASK_FIRST_STEP_TOL)
+
+
+def test_dense_fit_is_the_same_bits_run_to_run(sx):
+    """the resident fit launch and the dense kernels exchange doorbells, not data races: a silhouette + keypoint fit repeated on a
+    re-armed batch, and on a second batch, gives identical parameters and vertices"""
+    from bodyfitting_amd import _lib
+    model, dev = sx
+    prob = S.make_problem_smplx(model, frame=0, n_views=8, mask_frames=[1, 3, 5, 7])
+    runs = []
+    for _ in range(2):
+        b = _batch(dev, prob)
+        b.set_masks(np.array(prob["masks"])[None], [1, 3, 5, 7], None)
+        for _ in range(2):
+            b.fit(12, flags=_lib.FIT_RESET)
+            runs.append((b.get_params().copy(), b.get_result()[0].copy()))
+        b.close()
+    for p, v in runs[1:]:
+        np.testing.assert_array_equal(p, runs[0][0])
+        np.testing.assert_array_equal(v, runs[0][1])
