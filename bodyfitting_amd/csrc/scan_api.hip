@@ -428,6 +428,43 @@ int bf_ensure_fit_image(bf_batch *b, FrameIO io, const HyperDev &hd) {
     return BF_OK;
 }
 
+// First use of the resident fit launch on a batch: its stream (highest priority), events, doorbells, the warm-up launch and the
+// self-test that the fit stream really runs beside the batch stream (b->door_usable).
+static int ensure_fit_stream(bf_batch *b, const FrameIO &io, const HyperDev &hd) {
+    if (b->fit_stream) return BF_OK;
+    bf_model *m = b->m;
+    // the fit stream gets the highest priority: the runtime keeps a pool of hardware queues per priority, so it does not end
+    // up on the queue of this (or another) batch's ordinary stream - where the dense kernels would queue up BEHIND the
+    // resident launch that is waiting for them
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&b->fit_stream, hipStreamNonBlocking, greatest));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_door[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_door[1], hipEventDisableTiming));
+    HIP_TRY(b->door.alloc(BF_DOOR_INTS));
+    HIP_TRY(hipHostMalloc((void **)&b->h_door_err, sizeof(int)));
+    HIP_TRY(hipHostMalloc((void **)&b->h_resident, sizeof(int)));
+    *b->h_door_err = 0;
+    // first use of the new stream: its queue, the kernel's code object and scratch come up now, not under a mesh pass that is
+    // already waiting for this launch (mode 2 = prologue only)
+    FrameIO iow = io;
+    iow.ext = b->ext.p; iow.image_out = nullptr; iow.n_frames = 1;
+    HIP_TRY(bf_fit_launch(&m->fit, &iow, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->fit_stream));
+    HIP_TRY(hipStreamSynchronize(b->fit_stream));
+    // ... and checked: do the two streams really run side by side? (bf_door_probe_kernel)
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipMemset(b->door.p, 0, BF_DOOR_STATE * sizeof(int)));
+    hipLaunchKernelGGL(bf_door_probe_kernel, dim3(1), dim3(64), 0, b->fit_stream, b->door.p);
+    hipLaunchKernelGGL(bf_door_ring_kernel, dim3(1), dim3(64), 0, b->stream, b->door.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(b->fit_stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    int verdict = 0;
+    HIP_TRY(hipMemcpy(&verdict, b->door.p + BF_DOOR_TICKET, sizeof(int), hipMemcpyDeviceToHost));
+    b->door_usable = verdict == 1;
+    return BF_OK;
+}
+
 // the loop of smplify.py:177-213 when a dense loss is present (use_mask, use_mesh, or the SMPL-X keypoints
 // with hands + face): iterations that need no dense loss run as one persistent launch; every other iteration
 // is state -> mesh -> losses -> reverse mesh pass -> one fit-kernel iteration (smplify.py:197-210).
@@ -461,39 +498,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     const bool sub = sub_ok && m->sub.on && b->scans.empty();
     static const bool door_ok = [] { const char *e = std::getenv("BF_DENSE_PERSISTENT"); return !(e && e[0] == '0'); }();
     const int n_dense = n_iters - n_plain;
-    if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES && (!b->fit_stream || b->door_usable)) {
-        if (!b->fit_stream) {
-            // the fit stream gets the highest priority: the runtime keeps a pool of hardware queues per priority, so it does not end
-            // up on the queue of this (or another) batch's ordinary stream - where the dense kernels would queue up BEHIND the
-            // resident launch that is waiting for them
-            int least = 0, greatest = 0;
-            HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            HIP_TRY(hipStreamCreateWithPriority(&b->fit_stream, hipStreamNonBlocking, greatest));
-            HIP_TRY(hipEventCreateWithFlags(&b->ev_door[0], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&b->ev_door[1], hipEventDisableTiming));
-            HIP_TRY(b->door.alloc(BF_DOOR_INTS));
-            HIP_TRY(hipHostMalloc((void **)&b->h_door_err, sizeof(int)));
-            HIP_TRY(hipHostMalloc((void **)&b->h_resident, sizeof(int)));
-            *b->h_door_err = 0;
-            // first use of the new stream: its queue, the kernel's code object and scratch come up now, not under a mesh pass that is
-            // already waiting for this launch (mode 2 = prologue only)
-            FrameIO iow = io;
-            iow.ext = b->ext.p; iow.image_out = nullptr; iow.n_frames = 1;
-            HIP_TRY(bf_fit_launch(&m->fit, &iow, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->fit_stream));
-            HIP_TRY(hipStreamSynchronize(b->fit_stream));
-            // ... and checked: do the two streams really run side by side? (bf_door_probe_kernel)
-            HIP_TRY(hipStreamSynchronize(b->stream));
-            HIP_TRY(hipMemset(b->door.p, 0, BF_DOOR_STATE * sizeof(int)));
-            hipLaunchKernelGGL(bf_door_probe_kernel, dim3(1), dim3(64), 0, b->fit_stream, b->door.p);
-            hipLaunchKernelGGL(bf_door_ring_kernel, dim3(1), dim3(64), 0, b->stream, b->door.p);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(b->fit_stream));
-            HIP_TRY(hipStreamSynchronize(b->stream));
-            int verdict = 0;
-            HIP_TRY(hipMemcpy(&verdict, b->door.p + BF_DOOR_TICKET, sizeof(int), hipMemcpyDeviceToHost));
-            b->door_usable = verdict == 1;
-        }
-    }
+    if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES) { rc = ensure_fit_stream(b, io, hd); if (rc) return rc; }
     if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES && b->door_usable) {
         *(volatile int *)b->h_resident = 0;
         HIP_TRY(hipMemsetAsync(b->door.p, 0, BF_DOOR_INTS * sizeof(int), b->stream));
