@@ -64,6 +64,8 @@ SIGNATURES = {
     "bf_batch_set_cameras": (C.c_int, [_VP, _FP, _FP]),
     "bf_batch_set_keypoints": (C.c_int, [_VP, _FP, _IP]),
     "bf_batch_set_init": (C.c_int, [_VP, _FP, _FP]),
+    "bf_batch_stage_inputs": (C.c_int, [_VP, _FP, _IP, _FP, _FP]),
+    "bf_batch_get_previous": (C.c_int, [_VP, _FP, _FP, _FP, _FP, _FP]),
     "bf_batch_reset": (C.c_int, [_VP]),
     "bf_batch_set_params": (C.c_int, [_VP, _FP]),
     "bf_batch_get_params": (C.c_int, [_VP, _FP]),
@@ -93,6 +95,7 @@ SIGNATURES = {
     "bf_shard_range": (C.c_int, [C.c_int, C.c_int, C.c_int, _IP, _IP]),
     "bf_shard_capacity": (C.c_int, [C.c_int, C.c_int]),
     "bf_shard_unpack": (C.c_int, [_FP, C.c_int, C.c_int, C.c_int, _FP]),
+    "bf_shard_contour_offsets": (C.c_int, [C.c_int, C.c_int, C.c_int, _IP, C.POINTER(C.c_int64)]),
     "bf_group_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, _IP, C.c_int, C.c_int, C.POINTER(_VP)]),
     "bf_group_destroy": (None, [_VP]),
     "bf_group_n_devices": (C.c_int, [_VP]),
@@ -103,7 +106,11 @@ SIGNATURES = {
     "bf_group_set_cameras": (C.c_int, [_VP, _FP, _FP]),
     "bf_group_set_keypoints": (C.c_int, [_VP, _FP, _IP]),
     "bf_group_set_init": (C.c_int, [_VP, _FP, _FP]),
+    "bf_group_stage_inputs": (C.c_int, [_VP, _FP, _IP, _FP, _FP]),
+    "bf_group_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),
+    "bf_group_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
     "bf_group_fit": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper), C.c_uint32]),
+    "bf_group_fit_displacement": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper)]),
     "bf_group_sync": (C.c_int, [_VP]),
     "bf_group_comm_size": (C.c_int, [_VP]),
     "bf_group_gather_params": (C.c_int, [_VP, _FP, C.c_int]),

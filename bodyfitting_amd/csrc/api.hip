@@ -524,6 +524,23 @@ void bf_use_arena(bf_batch *b, int k) {
     b->cur = k;
 }
 
+// input arena k becomes the one `keypoints`, `params0`, `ndiv` point at (host = true: at its pinned staging buffer itself)
+void bf_use_inputs(bf_batch *b, int k, bool host) {
+    float *base = host ? b->h_in[k] : b->in_dev[k].p;
+    const bf_model *m = b->m;
+    b->keypoints.slice(base + b->in_off[0], (size_t)b->F * b->V * m->nl_loss * 3);
+    b->params0.slice(base + b->in_off[1], (size_t)b->F * m->np);
+    b->ndiv.slice((int *)(base + b->in_off[2]), (size_t)b->F);
+    b->in_cur = k;
+    b->in_host = host;
+}
+
+// a synchronous setter's write into the current input arena (the stream is idle)
+static hipError_t write_input(bf_batch *b, void *dst, const void *src, size_t bytes) {
+    if (b->in_host) { std::memcpy(dst, src, bytes); return hipSuccess; }
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
+}
+
 int bf_sync_all(bf_batch *b) {
     if (b->copy_stream) HIP_TRY(hipStreamSynchronize(b->copy_stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -531,6 +548,7 @@ int bf_sync_all(bf_batch *b) {
     if (b->h_door_err && *b->h_door_err) {
         const int who = *b->h_door_err;
         *b->h_door_err = 0;
+        b->door_usable = false;          // this batch keeps one fit launch per iteration from now on (same results): a second call does not run into the same wait
         int d[BF_DOOR_STATE + 1] = {};
         (void)hipMemcpy(d, b->door.p, sizeof d, hipMemcpyDeviceToHost);
         return fail(BF_ERR_HIP, "dense schedule (bells: ext " + std::to_string(d[BF_DOOR_EXT]) + ", states " + std::to_string(d[BF_DOOR_STATE]) +
@@ -559,7 +577,20 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
     bool ok = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess;
     b->ring.assign((size_t)bf_batch::kRing * 4, nullptr);
     b->ev = b->ring.data();          // (the events of a slot are created when the slot is first used: 4096 creations cost 4 ms)
-    ok = ok && b->params0.alloc(F * np) == hipSuccess;
+    {
+        auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };
+        const size_t n_kp = F * n_views * m->nl_loss * 3;
+        b->in_off[0] = 0; b->in_off[1] = up(n_kp); b->in_off[2] = b->in_off[1] + up(F * np);
+        b->in_total = b->in_off[2] + up(F);
+        if (const char *e = getenv("BF_STAGE_MODE")) b->stage_mode = !strcmp(e, "memcpy") ? 1 : (!strcmp(e, "zerocopy") ? 2 : (!strcmp(e, "aside") ? 3 : 0));
+        for (int k = 0; k < 2; ++k) {
+            ok = ok && b->in_dev[k].alloc(b->in_total) == hipSuccess && hipMemset(b->in_dev[k].p, 0, b->in_total * sizeof(float)) == hipSuccess;
+            ok = ok && hipHostMalloc((void **)&b->h_in[k], b->in_total * sizeof(float)) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&b->ev_in[k], hipEventDisableTiming) == hipSuccess;
+            if (ok) std::memset(b->h_in[k], 0, b->in_total * sizeof(float));
+        }
+        if (ok) bf_use_inputs(b, 0, false);
+    }
     {
         auto up = [](size_t n) { return (n + 63) & ~(size_t)63; };          // 256-byte slices
         const size_t n_par = F * np, n_terms = F * 4, n_state = F * bf_state_stride(m->nj, m->npf, m->nb),
@@ -589,8 +620,11 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
         }
     }
     ok = ok && b->proj.alloc(F * n_views * 12) == hipSuccess;
-    ok = ok && b->keypoints.alloc(F * n_views * m->nl_loss * 3) == hipSuccess;
-    ok = ok && b->ndiv.upload(std::vector<int>(F, n_views)) == hipSuccess;
+    if (ok) {
+        const std::vector<int> nd(F, n_views);
+        for (int k = 0; k < 2; ++k)
+            ok = ok && hipMemcpy(b->in_dev[k].p + b->in_off[2], nd.data(), F * sizeof(int), hipMemcpyHostToDevice) == hipSuccess;
+    }
     ok = ok && b->adam_m.alloc(F * np) == hipSuccess;
     ok = ok && b->adam_v.alloc(F * np) == hipSuccess && b->grads.alloc(F * np) == hipSuccess;
     ok = ok && b->vraw.alloc(F * m->nv * 3) == hipSuccess;
@@ -600,7 +634,6 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
         ok = hipMemset(b->adam_m.p, 0, F * np * sizeof(float)) == hipSuccess &&
              hipMemset(b->adam_v.p, 0, F * np * sizeof(float)) == hipSuccess &&
              hipMemset(b->params.p, 0, F * np * sizeof(float)) == hipSuccess &&
-             hipMemset(b->keypoints.p, 0, b->keypoints.n * sizeof(float)) == hipSuccess &&
              hipMemset(b->debug.p, 0, 8192 * sizeof(float)) == hipSuccess;
     }
     if (!ok) { bf_batch_destroy(b); return fail(BF_ERR_HIP, "bf_batch_create: device allocation failed"); }
@@ -619,6 +652,8 @@ void bf_batch_destroy(bf_batch *b) {
     if (b->h_res_b) (void)hipHostFree(b->h_res_b);
     if (b->h_pc_weight) (void)hipHostFree(b->h_pc_weight);
     for (int k = 0; k < 2; ++k) {
+        if (b->h_in[k]) (void)hipHostFree(b->h_in[k]);
+        if (b->ev_in[k]) (void)hipEventDestroy(b->ev_in[k]);
         if (b->graph_pipe[k]) (void)hipGraphExecDestroy(b->graph_pipe[k]);
         if (b->ev_done[k]) (void)hipEventDestroy(b->ev_done[k]);
         if (b->ev_copied[k]) (void)hipEventDestroy(b->ev_copied[k]);
@@ -684,13 +719,13 @@ int bf_batch_set_keypoints(bf_batch *b, const float *keypoints, const int32_t *n
             nd[f] = n_use_frames[f];
         }
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }      // (a fit still in flight reads the old keypoints)
-    HIP_TRY(hipMemcpy(b->keypoints.p, keypoints, b->keypoints.n * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(b->ndiv.p, nd.data(), nd.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(write_input(b, b->keypoints.p, keypoints, b->keypoints.n * sizeof(float)));
+    HIP_TRY(write_input(b, b->ndiv.p, nd.data(), nd.size() * sizeof(int)));
     return BF_OK;
 }
 
-static int reset_adam(bf_batch *b) {
-    HIP_TRY(hipMemcpy(b->params0.p, b->params.p, b->params.n * sizeof(float), hipMemcpyDeviceToDevice));
+static int reset_adam(bf_batch *b, const float *params_host) {
+    HIP_TRY(write_input(b, b->params0.p, params_host, b->params.n * sizeof(float)));
     HIP_TRY(hipMemset(b->adam_m.p, 0, b->adam_m.n * sizeof(float)));
     HIP_TRY(hipMemset(b->adam_v.p, 0, b->adam_v.n * sizeof(float)));
     b->steps_done = 0;
@@ -712,23 +747,85 @@ int bf_batch_reset(bf_batch *b) {
     return BF_OK;
 }
 
-int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_pose) {
-    if (!b || !init_betas || !init_pose) return fail(BF_ERR_INVALID, "bf_batch_set_init: null argument");
-    HIP_TRY(hipSetDevice(b->m->device));
+// net_output of smplify.py:103 -> the packed optimiser vector: transl = 0, scale = 1 (:126-128), body pose, betas, root orientation
+static void pack_init(const bf_batch *b, const float *init_betas, const float *init_pose, float *dst) {
     const bf_model *m = b->m;
     const int np = m->np, nb = m->nb;
     const int pose_stride = 72;                  // net_output poses are [F,72] for both model kinds (smplify.py:108-112)
-    std::vector<float> p((size_t)b->F * np, 0.f);
+    std::memset(dst, 0, (size_t)b->F * np * sizeof(float));
     for (int f = 0; f < b->F; ++f) {
-        float *q = p.data() + (size_t)f * np;
+        float *q = dst + (size_t)f * np;
         q[3] = 1.0f;                                                             // body_scale = 1, transl = 0
         std::memcpy(q + m->fit.off_pose, init_pose + (size_t)f * pose_stride + 3, sizeof(float) * m->fit.nbp);
         std::memcpy(q + m->fit.off_beta, init_betas + (size_t)f * nb, sizeof(float) * nb);
         std::memcpy(q + m->fit.off_orient, init_pose + (size_t)f * pose_stride, sizeof(float) * 3);
     }
+}
+
+/* The next frame's keypoints and initial estimate, WITHOUT draining the work in flight (apps/genebody_fitting.py:183-192 hands
+ * SMPLify a new frame's detections and HMR estimate every call; loss.py:160 re-uploads the keypoints every iteration).  The
+ * inputs are packed into the pinned staging buffer the fit in flight does not use and their transfer into the other device
+ * arena is queued on the batch stream, behind that fit; the next bf_fit - which must carry BF_FIT_RESET - reads them. */
+int bf_batch_stage_inputs(bf_batch *b, const float *keypoints, const int32_t *n_use_frames, const float *init_betas, const float *init_pose) {
+    if (!b || !keypoints || !init_betas || !init_pose) return fail(BF_ERR_INVALID, "bf_batch_stage_inputs: null argument");
+    if (n_use_frames)
+        for (int f = 0; f < b->F; ++f)
+            if (n_use_frames[f] <= 0) return fail(BF_ERR_INVALID, "bf_batch_stage_inputs: n_use_frames must be positive");
+    HIP_TRY(hipSetDevice(b->m->device));
+    const int k = b->in_cur ^ 1;
+    if (b->in_pending[k]) {                 // (the transfer of two stagings ago: behind a fit that has long finished)
+        HIP_TRY(hipEventSynchronize(b->ev_in[k]));
+        b->in_pending[k] = false;
+    }
+    float *h = b->h_in[k];
+    std::memcpy(h + b->in_off[0], keypoints, (size_t)b->F * b->V * b->m->nl_loss * 3 * sizeof(float));
+    pack_init(b, init_betas, init_pose, h + b->in_off[1]);
+    int *nd = (int *)(h + b->in_off[2]);
+    for (int f = 0; f < b->F; ++f) nd[f] = n_use_frames ? n_use_frames[f] : b->V;
+    if (b->stage_mode == 2) {
+        // zero-copy: the fit kernel's prologue reads the pinned buffer itself; bf_fit records ev_in[k] behind the fit that read it
+        bf_use_inputs(b, k, true);
+    } else {
+        const size_t n4 = b->in_total / 4;
+        if (b->stage_mode == 3) {
+            // the transfer on the batch's SECOND stream, under the fit in flight (the other arena is nobody's); the batch stream
+            // only waits for its event - long complete when the next fit's turn comes
+            hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->copy_stream,
+                               (const float4 *)h, (float4 *)b->in_dev[k].p, n4);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(b->ev_in[k], b->copy_stream));
+            HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_in[k], 0));
+            b->in_pending[k] = true;
+            bf_use_inputs(b, k, false);
+            b->staged = true;
+            return BF_OK;
+        }
+        if (b->stage_mode == 1) {
+            HIP_TRY(hipMemcpyAsync(b->in_dev[k].p, h, b->in_total * sizeof(float), hipMemcpyHostToDevice, b->stream));
+        } else {
+            // (a kernel that reads the pinned buffer over PCIe with coalesced 16-byte loads: one more dispatch on the queue the fit
+            //  kernel is on, no engine hand-over)
+            hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->stream,
+                               (const float4 *)h, (float4 *)b->in_dev[k].p, n4);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(b->ev_in[k], b->stream));
+        b->in_pending[k] = true;
+        bf_use_inputs(b, k, false);
+    }
+    b->staged = true;
+    return BF_OK;
+}
+
+int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_pose) {
+    if (!b || !init_betas || !init_pose) return fail(BF_ERR_INVALID, "bf_batch_set_init: null argument");
+    HIP_TRY(hipSetDevice(b->m->device));
+    const bf_model *m = b->m;
+    std::vector<float> p((size_t)b->F * m->np, 0.f);
+    pack_init(b, init_betas, init_pose, p.data());
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     HIP_TRY(hipMemcpy(b->params.p, p.data(), p.size() * sizeof(float), hipMemcpyHostToDevice));
-    return reset_adam(b);
+    return reset_adam(b, p.data());
 }
 
 int bf_batch_set_params(bf_batch *b, const float *params) {
@@ -736,7 +833,7 @@ int bf_batch_set_params(bf_batch *b, const float *params) {
     HIP_TRY(hipSetDevice(b->m->device));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     HIP_TRY(hipMemcpy(b->params.p, params, b->params.n * sizeof(float), hipMemcpyHostToDevice));
-    return reset_adam(b);
+    return reset_adam(b, params);
 }
 
 int bf_batch_get_params(bf_batch *b, float *params) {
@@ -827,8 +924,23 @@ static int enqueue_plain(bf_batch *b, int n_iters, const HyperDev &hd, const Fra
     return BF_OK;
 }
 
+static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags);
+
 int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (!b || n_iters <= 0) return fail(BF_ERR_INVALID, "bf_fit: bad argument");
+    if (b->staged && !(flags & BF_FIT_RESET))
+        return fail(BF_ERR_INVALID, "bf_fit: inputs were staged with bf_batch_stage_inputs - the fit of a new frame starts from its initial estimate (BF_FIT_RESET)");
+    int rc = fit_impl(b, n_iters, hyper, flags);
+    if (rc) return rc;
+    b->staged = false;
+    if (b->in_host) { HIP_TRY(hipEventRecord(b->ev_in[b->in_cur], b->stream)); b->in_pending[b->in_cur] = true; }   // (zero-copy: this fit read the pinned buffer)
+    b->arena_seq[b->cur] = b->fit_seq++;
+    b->arena_fetched[b->cur] = b->fetched;
+    b->arena_has_v[b->cur] = b->have_result;
+    return BF_OK;
+}
+
+static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     bf_model *m = b->m;
     HIP_TRY(hipSetDevice(m->device));
     bf_hyper h;
@@ -868,7 +980,7 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
             if (rc) return rc;
             { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
         }
-        bf_graph_key key{n_iters, flags, pipelined ? (b->cur ^ 1) : b->cur, h};
+        bf_graph_key key{n_iters, flags, (pipelined ? (b->cur ^ 1) : b->cur) | (b->in_cur << 4) | ((int)b->in_host << 5), h};   // (the captured nodes hold the arenas' addresses)
         if (pipelined) {
             // pipelined fetch: this fit writes the result arena the previous one did not use; its device-to-host copy
             // runs on the copy stream, under the kernels of whatever is enqueued next
@@ -1029,6 +1141,35 @@ int bf_batch_sync(bf_batch *b) {
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_sync: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
+    return BF_OK;
+}
+
+/* The result of the fit issued BEFORE the last one, while the last one is still running: frame i's rtn_dict is read under
+ * frame i+1's fit (the serial loop of apps/genebody_fitting.py:183-192 as a two-deep pipeline).  Needs both fits issued with
+ * BF_FIT_RESET | BF_FIT_FETCH | BF_FIT_NOTIME on the keypoint-only path (their results then alternate between the two arenas);
+ * waits only for that result's hand-over, never for the stream.  params[F,n_params] and the outputs of bf_batch_get_result. */
+int bf_batch_get_previous(bf_batch *b, float *params, float *vertices, float *joints, float *full_pose, float *loss_terms) {
+    if (!b) return fail(BF_ERR_INVALID, "bf_batch_get_previous: null batch");
+    const bf_model *m = b->m;
+    HIP_TRY(hipSetDevice(m->device));
+    const int k = b->cur ^ 1;
+    if (b->fit_seq < 2 || b->arena_seq[k] != b->fit_seq - 2 || b->arena_seq[b->cur] != b->fit_seq - 1 || !b->arena_fetched[k])
+        return fail(BF_ERR_INVALID, "bf_batch_get_previous: the previous fit's result is not held in the other arena (both fits need "
+                                    "BF_FIT_RESET | BF_FIT_FETCH | BF_FIT_NOTIME on the keypoint-only path)");
+    if ((vertices || joints) && !b->arena_has_v[k]) return fail(BF_ERR_INVALID, "bf_batch_get_previous: no mesh was evaluated");
+    HIP_TRY(hipEventSynchronize(b->ev_copied[k]));
+    const float *h = k ? b->h_res_b : b->h_res;
+    if (params) std::memcpy(params, h + b->res_off[0], b->res_cnt[0] * sizeof(float));
+    if (loss_terms) std::memcpy(loss_terms, h + b->res_off[1], b->res_cnt[1] * sizeof(float));
+    if (joints) std::memcpy(joints, h + b->res_off[3], b->res_cnt[3] * sizeof(float));
+    if (vertices) std::memcpy(vertices, h + b->res_off[4], b->res_cnt[4] * sizeof(float));
+    if (full_pose) {
+        const size_t stride = bf_state_stride(m->nj, m->npf, m->nb);
+        for (int f = 0; f < b->F; ++f) {
+            StateView v = bf_state_view(const_cast<float *>(h) + b->res_off[2] + (size_t)f * stride, m->nj, m->npf, m->nb);
+            std::memcpy(full_pose + (size_t)f * 3 * m->nj, v.theta, sizeof(float) * 3 * m->nj);
+        }
+    }
     return BF_OK;
 }
 

@@ -104,7 +104,23 @@ struct bf_batch {
     int ring_n = 0;                 // calls recorded since the last timing reset
     hipEvent_t *ev = nullptr;       // the triple of the last call
     bool timed = false;
-    DevBuf<float> params0;          // parameters of the last set_init / set_params
+    DevBuf<float> params0;          // parameters of the last set_init / set_params / stage_inputs (a view into the current input arena)
+    // Per-frame inputs [keypoints | params0 | ndiv] live in TWO device arenas, each fed from its own pinned staging buffer:
+    // bf_batch_stage_inputs packs the next frame's inputs into the staging buffer the fit in flight does not read and queues
+    // their transfer on the batch stream - the setter never drains the stream (the reference pays 48 keypoint host-to-device
+    // copies per ITERATION, loss.py:160).  `keypoints`, `ndiv`, `params0` are views into arena in_cur.
+    DevBuf<float> in_dev[2];
+    float *h_in[2] = {nullptr, nullptr};
+    size_t in_off[3] = {0, 0, 0}, in_total = 0;          // float offsets of keypoints, params0, ndiv inside an arena
+    hipEvent_t ev_in[2] = {nullptr, nullptr};            // the transfer out of staging buffer k has finished
+    bool in_pending[2] = {false, false};
+    int in_cur = 0;
+    bool in_host = false;           // the views point at the pinned staging buffer itself (BF_STAGE_MODE=zerocopy)
+    int stage_mode = 0;             // 0 = copy kernel reading pinned memory, 1 = hipMemcpyAsync, 2 = zero-copy
+    bool staged = false;            // inputs were staged since the last fit: the next bf_fit must carry BF_FIT_RESET
+    long long fit_seq = 0;          // fits issued so far; arena_seq[k] = the fit whose result result-arena k holds
+    long long arena_seq[2] = {-1, -1};
+    bool arena_fetched[2] = {false, false}, arena_has_v[2] = {false, false};
     // results live in ONE device arena [params | terms | state | joints | vout] mirrored by ONE pinned host arena, so a
     // fetch is a single device-to-host copy of the prefix that is wanted
     // Two such pairs: a fresh fit (BF_FIT_RESET + GRAPH + FETCH) writes the arena the previous fit did not use and its
@@ -186,6 +202,7 @@ HyperDev bf_to_dev(const bf_hyper &h);
 int bf_sync_all(bf_batch *b);            // copy stream, then compute stream
 int bf_guard_arena(bf_batch *b);         // the compute stream waits for a fetch still reading the current arena
 void bf_use_arena(bf_batch *b, int k);
+void bf_use_inputs(bf_batch *b, int k, bool host);
 FrameIO bf_frame_io(bf_batch *b, bool want_grads);
 }
 extern "C" void bf_fit_image_segments(int nj, int nb, int npf, int ns, int nl, int np, int seg[6]);

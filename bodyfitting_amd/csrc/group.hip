@@ -14,8 +14,11 @@
 // product path never pays for it.
 #include "bf_host.h"
 
+#include <condition_variable>
 #include <dlfcn.h>
+#include <functional>
 #include <rccl/rccl.h>
+#include <thread>
 
 namespace {
 
@@ -76,12 +79,59 @@ int need_rccl() {
 
 }  // namespace
 
+// One host thread per device of a group.  A dense bf_fit (silhouette / scan losses) enqueues a few launches per iteration for
+// hundreds of iterations and waits for its resident fit launch to be running before it returns (scan_api.hip): issued from ONE
+// thread, device k+1 would start after device k's whole sequence is queued.  Every device's calls therefore come from its own
+// thread; the caller's thread posts the job to all of them and waits until every one has returned.
+struct bf_worker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, quit = false;
+    int rc = 0;
+    std::string err;
+
+    void loop() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [&] { return has_job || quit; });
+            if (quit) return;
+            std::function<int()> j = std::move(job);
+            lk.unlock();
+            bf_err_slot().clear();
+            const int r = j();
+            std::string e = r ? bf_err_slot() : std::string();      // (the error message lives in THIS thread's slot: carry it over)
+            lk.lock();
+            rc = r; err = std::move(e);
+            has_job = false;
+            cv.notify_all();
+        }
+    }
+    void post(std::function<int()> j) {
+        std::lock_guard<std::mutex> lk(mu);
+        job = std::move(j); has_job = true; rc = 0;
+        cv.notify_all();
+    }
+    int wait(std::string *msg) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return !has_job; });
+        if (rc && msg) *msg = err;
+        return rc;
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+        if (th.joinable()) th.join();
+    }
+};
+
 struct bf_group_peer {
     int device = 0, first = 0, count = 0;
     bf_model *model = nullptr;
     bf_batch *batch = nullptr;
     ncclComm_t comm = nullptr;
     DevBuf<float> send, recv;      // [cap][np], [n][cap][np]
+    bf_worker *worker = nullptr;   // null in a one-device group (the caller's thread does the work)
 };
 
 struct bf_group {
@@ -90,6 +140,24 @@ struct bf_group {
     bool comm_ready = false;
     std::vector<float> host;       // [n][cap][np] staging of the gathered block
 };
+
+// fn(peer) on every device of the group, each from that device's own host thread, all running side by side; returns when every
+// one has returned, with the first failure (in device order) as this thread's error
+static int run_all(bf_group *g, const std::function<int(bf_group_peer &)> &fn) {
+    if (g->n == 1 || !g->peers[0].worker) {
+        for (auto &p : g->peers) { int rc = fn(p); if (rc) return rc; }
+        return BF_OK;
+    }
+    for (auto &p : g->peers) { bf_group_peer *pp = &p; p.worker->post([pp, &fn] { return fn(*pp); }); }
+    int first_rc = BF_OK;
+    std::string first_msg;
+    for (auto &p : g->peers) {
+        std::string msg;
+        const int rc = p.worker->wait(&msg);
+        if (rc && !first_rc) { first_rc = rc; first_msg = "device " + std::to_string(p.device) + ": " + msg; }
+    }
+    return first_rc ? fail(first_rc, first_msg) : BF_OK;
+}
 
 struct bf_comm {
     int rank = 0, world = 1, device = 0;
@@ -132,11 +200,33 @@ int bf_shard_unpack(const float *gathered, int n_frames, int n_shards, int width
     return BF_OK;
 }
 
+// Where every shard's block starts inside the per-job arrays the dense setters take.  contour_count[n_frames * n_masks] = points of
+// every (frame, mask view) contour, concatenated in contour_xy: xy_first[s] = (x, y) pairs in front of shard s's first contour,
+// xy_first[n_shards] = all of them.  Host arithmetic only.
+int bf_shard_contour_offsets(int n_frames, int n_shards, int n_masks, const int32_t *contour_count, int64_t *xy_first) {
+    if (n_frames < 0 || n_shards <= 0 || n_masks < 0 || !xy_first || (n_masks > 0 && n_frames > 0 && !contour_count))
+        return fail(BF_ERR_INVALID, "bf_shard_contour_offsets: bad argument");
+    int64_t acc = 0;
+    for (int s = 0; s < n_shards; ++s) {
+        int32_t first, count;
+        bf_shard_range(n_frames, n_shards, s, &first, &count);
+        xy_first[s] = acc;
+        for (int64_t q = (int64_t)first * n_masks; q < (int64_t)(first + count) * n_masks; ++q) {
+            if (contour_count[q] < 0) return fail(BF_ERR_INVALID, "bf_shard_contour_offsets: negative contour length");
+            acc += contour_count[q];
+        }
+    }
+    xy_first[n_shards] = acc;
+    return BF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------------
 // one process, n devices
 // ---------------------------------------------------------------------------------------------------------------------------
 void bf_group_destroy(bf_group *g) {
     if (!g) return;
+    for (auto &p : g->peers)
+        if (p.worker) { p.worker->stop(); delete p.worker; p.worker = nullptr; }
     for (auto &p : g->peers) {
         (void)hipSetDevice(p.device);
         if (p.batch) (void)bf_batch_sync(p.batch);
@@ -175,6 +265,12 @@ int bf_group_create(const bf_model_desc *desc, int n_devices, const int32_t *dev
         if (rc) { std::string keep = bf_err_slot(); bf_group_destroy(g); return fail(rc, keep); }
     }
     g->np = g->peers[0].model->np; g->nl = g->peers[0].model->nl_loss; g->nb = g->peers[0].model->nb;
+    if (n_devices > 1)
+        for (auto &p : g->peers) {
+            p.worker = new bf_worker();
+            bf_worker *w = p.worker;
+            w->th = std::thread([w] { w->loop(); });
+        }
     *out = g;
     return BF_OK;
 }
@@ -221,15 +317,64 @@ int bf_group_set_init(bf_group *g, const float *init_betas, const float *init_po
     return BF_OK;
 }
 
-// bf_fit on every device's block: the calls return as soon as the work is queued on each device's own stream, so the n
-// devices run side by side.  No communication.
-int bf_group_fit(bf_group *g, int n_iters, const bf_hyper *hyper, uint32_t flags) {
-    if (!g) return fail(BF_ERR_INVALID, "bf_group_fit: null group");
+/* bf_batch_stage_inputs for the whole job: keypoints[F,V,nl,3], n_use_frames[F] or NULL, init_betas[F,NB], init_pose[F,72] */
+int bf_group_stage_inputs(bf_group *g, const float *keypoints, const int32_t *n_use_frames, const float *init_betas, const float *init_pose) {
+    if (!g || !keypoints || !init_betas || !init_pose) return fail(BF_ERR_INVALID, "bf_group_stage_inputs: null argument");
     for (auto &p : g->peers) {
-        int rc = bf_fit(p.batch, n_iters, hyper, flags);
+        int rc = bf_batch_stage_inputs(p.batch, keypoints + (size_t)p.first * g->V * g->nl * 3, n_use_frames ? n_use_frames + p.first : nullptr,
+                                       init_betas + (size_t)p.first * g->nb, init_pose + (size_t)p.first * 72);
         if (rc) return rc;
     }
     return BF_OK;
+}
+
+/* bf_batch_set_masks for the whole job: masks[F,M,H,W]; contour_count[F*M] / contour_xy as bf_batch_set_masks takes them, or
+ * both NULL = extract the contours on the devices (every device its own frames, side by side) */
+int bf_group_set_masks(bf_group *g, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
+                       const int32_t *contour_count, const float *contour_xy, int contour_select) {
+    if (!g) return fail(BF_ERR_INVALID, "bf_group_set_masks: null group");
+    if (n_masks > 0 && !masks) return fail(BF_ERR_INVALID, "bf_group_set_masks: null masks");
+    std::vector<int64_t> xy_first(g->n + 1, 0);     // (float pairs in front of every device's block of contour points)
+    if (contour_count && n_masks > 0) {
+        int rc = bf_shard_contour_offsets(g->F, g->n, n_masks, contour_count, xy_first.data());
+        if (rc) return rc;
+    }
+    return run_all(g, [&](bf_group_peer &p) {
+        const size_t i = &p - g->peers.data();
+        return bf_batch_set_masks(p.batch, n_masks, view_index, H, W, n_masks > 0 ? masks + (size_t)p.first * n_masks * H * W : nullptr,
+                                  contour_count ? contour_count + (size_t)p.first * n_masks : nullptr,
+                                  contour_xy ? contour_xy + 2 * xy_first[i] : nullptr, contour_select);
+    });
+}
+
+/* bf_batch_set_scans for the whole job: scans[F], scan f created (bf_scan_create) on the device bf_group_shard reports for f's
+ * block; NULL detaches */
+int bf_group_set_scans(bf_group *g, bf_scan *const *scans) {
+    if (!g) return fail(BF_ERR_INVALID, "bf_group_set_scans: null group");
+    if (scans)
+        for (auto &p : g->peers)
+            for (int f = 0; f < p.count; ++f) {
+                const bf_scan *s = scans[p.first + f];
+                if (!s) return fail(BF_ERR_INVALID, "bf_group_set_scans: null scan");
+                if (s->device != p.device)
+                    return fail(BF_ERR_INVALID, "bf_group_set_scans: scan of frame " + std::to_string(p.first + f) + " lives on device " +
+                                                    std::to_string(s->device) + ", its block on device " + std::to_string(p.device));
+            }
+    return run_all(g, [&](bf_group_peer &p) { return bf_batch_set_scans(p.batch, scans ? scans + p.first : nullptr); });
+}
+
+// bf_fit on every device's block, each issued from the device's own host thread: the n devices run side by side also when a
+// call enqueues hundreds of launches (the dense losses).  Returns when every call has returned (= its work is queued).  No
+// communication.
+int bf_group_fit(bf_group *g, int n_iters, const bf_hyper *hyper, uint32_t flags) {
+    if (!g) return fail(BF_ERR_INVALID, "bf_group_fit: null group");
+    return run_all(g, [&](bf_group_peer &p) { return bf_fit(p.batch, n_iters, hyper, flags); });
+}
+
+/* bf_fit_displacement (the SMPL+D stage, smplify.py:228-247) on every device's block, side by side */
+int bf_group_fit_displacement(bf_group *g, int n_iters, const bf_hyper *hyper) {
+    if (!g) return fail(BF_ERR_INVALID, "bf_group_fit_displacement: null group");
+    return run_all(g, [&](bf_group_peer &p) { return bf_fit_displacement(p.batch, n_iters, hyper); });
 }
 
 int bf_group_sync(bf_group *g) {
@@ -250,14 +395,20 @@ static int group_comm(bf_group *g) {
     for (int i = 0; i < g->n; ++i) devs[i] = g->peers[i].device;
     RCCL_TRY(rccl()->CommInitAll(comms.data(), g->n, devs.data()));
     const size_t blk = (size_t)g->cap * g->np;
-    for (int i = 0; i < g->n; ++i) {
+    bool ok = true;
+    for (int i = 0; i < g->n && ok; ++i) {
         bf_group_peer &p = g->peers[i];
-        p.comm = comms[i];
-        HIP_TRY(hipSetDevice(p.device));
-        HIP_TRY(p.send.alloc(blk));
-        HIP_TRY(p.recv.alloc(blk * g->n));
-        HIP_TRY(hipMemset(p.send.p, 0, blk * sizeof(float)));
+        ok = hipSetDevice(p.device) == hipSuccess && p.send.alloc(blk) == hipSuccess && p.recv.alloc(blk * g->n) == hipSuccess &&
+             hipMemset(p.send.p, 0, blk * sizeof(float)) == hipSuccess;
     }
+    if (!ok) {                                    // (a retry must not find half a communicator)
+        for (int i = 0; i < g->n; ++i) {
+            (void)rccl()->CommDestroy(comms[i]);
+            g->peers[i].send.release(); g->peers[i].recv.release();
+        }
+        return fail(BF_ERR_HIP, "bf_group: allocating the all-gather buffers failed");
+    }
+    for (int i = 0; i < g->n; ++i) g->peers[i].comm = comms[i];
     g->host.resize(blk * g->n);
     g->comm_ready = true;
     return BF_OK;

@@ -29,6 +29,14 @@ __device__ inline float m_wave_sum(float v) {
 }  // namespace
 
 // One 128-thread workgroup per parameter set (body: pose_state_body.h).
+// A pose state published by the resident fit launch, read by a kernel that waited for its doorbell.  `coherent` (bit 30 of the
+// door target): device-scope loads that are served past this XCD's non-coherent caches - correctness then no longer rests on
+// no line of `state` having entered this XCD's L2 since the kernel started (measured cost in DESIGN.md 4.3).
+#define BF_DOOR_COHERENT_BIT 0x40000000
+__device__ __forceinline__ float bf_ld_state(const float *p, bool coherent) {
+    return coherent ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
 extern "C" __global__ void __launch_bounds__(128)
 bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__restrict__ orient,
                      const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
@@ -103,17 +111,18 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
 #pragma unroll
         for (int i = 0; i < BF_MESH_TILE; ++i) if (v0 + i < nv) jx[i] = row[i];
     }
+    const bool coh = door && (door_target & BF_DOOR_COHERENT_BIT);
     if (door) {        // the pose state comes from the persistent fit launch (BfDoor): wait for it under the requests above
-        if (tid == 0) bf_door_wait(door, BF_DOOR_STATE + (int)((blockIdx.x + 7 * blockIdx.y) % BF_DOOR_COPIES) * BF_DOOR_COPY_STRIDE, door_target);
+        if (tid == 0) bf_door_wait(door, BF_DOOR_STATE + (int)((blockIdx.x + 7 * blockIdx.y) % BF_DOOR_COPIES) * BF_DOOR_COPY_STRIDE, door_target & ~BF_DOOR_COHERENT_BIT);
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // (cold caches at kernel start, first read of the state below)
     }
-    for (int i = tid; i < npf; i += nt) s_feat[i] = st.feat[i];
+    for (int i = tid; i < npf; i += nt) s_feat[i] = bf_ld_state(st.feat + i, coh);
     for (int i = tid; i < nj * 12; i += nt) {
         int j = i / 12, e = i % 12, a = e / 4, b = e % 4;
-        s_A[i] = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
+        s_A[i] = bf_ld_state(b < 3 ? st.GR + j * 9 + a * 3 + b : st.At + j * 3 + a, coh);
     }
-    if (tid < nb + 5) s_beta[tid] = st.beta[tid];   // beta, t, sc are contiguous in the state record
+    if (tid < nb + 5) s_beta[tid] = bf_ld_state(st.beta + tid, coh);   // beta, t, sc are contiguous in the state record
     __syncthreads();
 
     // ---- pose blend: this row group's share, reduced through LDS -----------------------------------
@@ -221,28 +230,29 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
     float pv[BF_MM_CH];
 #pragma unroll
     for (int i = 0; i < BF_MM_CH; ++i) pv[i] = p0 + i < p1 ? pd[(size_t)i * ncols] : 0.f;
+    const bool coh = door && (door_target & BF_DOOR_COHERENT_BIT);
     if (door) {        // the pose states come from the persistent fit launch (BfDoor): wait for all of them, under the first chunk's loads
-        if (tid == 0) bf_door_wait(door, BF_DOOR_STATE + (int)((blockIdx.x + 7 * blockIdx.y) % BF_DOOR_COPIES) * BF_DOOR_COPY_STRIDE, door_target);
+        if (tid == 0) bf_door_wait(door, BF_DOOR_STATE + (int)((blockIdx.x + 7 * blockIdx.y) % BF_DOOR_COPIES) * BF_DOOR_COPY_STRIDE, door_target & ~BF_DOOR_COHERENT_BIT);
         __syncthreads();
         // (this kernel started with invalidated caches and reads the states for the first time below: nothing stale to drop)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     for (int i = tid; i < npad * FPW; i += nt) {
         const int p = i / FPW, f = i - p * FPW;
-        s_feat[i] = (p < npf && f < nf) ? bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).feat[p] : 0.f;
+        s_feat[i] = (p < npf && f < nf) ? bf_ld_state(bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).feat + p, coh) : 0.f;
     }
     for (int i = tid; i < FPW * nj * 12; i += nt) {
         const int f = i % FPW, r = i / FPW, j = r / 12, e = r - j * 12, a = e >> 2, b = e & 3;       // (FPW, 12: compile-time divisors)
         float x = 0.f;
         if (f < nf) {
             StateView st = bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb);
-            x = b < 3 ? st.GR[j * 9 + a * 3 + b] : st.At[j * 3 + a];
+            x = bf_ld_state(b < 3 ? st.GR + j * 9 + a * 3 + b : st.At + j * 3 + a, coh);
         }
         s_A[f * nj * 12 + r] = x;
     }
     for (int i = tid; i < FPW * 32; i += nt) {
         const int f = i >> 5, l = i & 31;
-        s_beta[i] = (f < nf && l < nb + 5) ? bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).beta[l] : 0.f;
+        s_beta[i] = (f < nf && l < nb + 5) ? bf_ld_state(bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).beta + l, coh) : 0.f;
     }
     __syncthreads();
 

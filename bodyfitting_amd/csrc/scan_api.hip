@@ -336,6 +336,9 @@ static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
 // one dense iteration's forward + loss + reverse passes up to `ext` (everything except the fit kernel itself)
 // door / door_k: the persistent fit launch's doorbells and this pass's 1-based dense iteration (null / 0: fit launches per iteration)
 // sub: run the mesh passes on the sampled-first sub-model (bf_model::Sub; fit loops without scans)
+// BF_DOOR_COHERENT=0: the kernels that wait for the resident fit launch read its pose states with plain loads (see bf_ld_state)
+static bool door_coherent() { const char *e = std::getenv("BF_DOOR_COHERENT"); return !(e && e[0] == '0'); }
+
 static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight, int *door = nullptr, int door_k = 0,
                       bool sub = false) {
     bf_model *m = b->m;
@@ -358,7 +361,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     }
     int rc = bf_launch_mesh(m, &b->scratch, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
                             b->vposed.p, nullptr, nullptr, nullptr, (kp || masks) ? b->dvout.p : nullptr, &zeroed, kp, masks ? &mp : nullptr,
-                            &projected, door, F * door_k, sub ? &Q : nullptr);
+                            &projected, door, (F * door_k) | (door_coherent() ? 0x40000000 : 0), sub ? &Q : nullptr);
     if (rc) return rc;
     if ((kp || masks) && !zeroed) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
     // The dense keypoint loss and the closest-point search both only read the mesh: with scans attached the keypoint workgroups (one
@@ -494,9 +497,10 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     // The dense iterations with the fit kernel RESIDENT (one launch on a second stream, paced by doorbells, BfDoor) when the
     // forward pass is a kernel that knows how to wait (1..15 frames); BF_DENSE_PERSISTENT=0, or a larger batch, keeps one fit launch
     // per iteration, with the pose state from bf_pose_state_kernel every time.
-    static const bool sub_ok = [] { const char *e = std::getenv("BF_DENSE_SUBMODEL"); return !(e && e[0] == '0'); }();
+    // (read on every call: a test switches them between two calls of one process)
+    const bool sub_ok = [] { const char *e = std::getenv("BF_DENSE_SUBMODEL"); return !(e && e[0] == '0'); }();
     const bool sub = sub_ok && m->sub.on && b->scans.empty();
-    static const bool door_ok = [] { const char *e = std::getenv("BF_DENSE_PERSISTENT"); return !(e && e[0] == '0'); }();
+    const bool door_ok = [] { const char *e = std::getenv("BF_DENSE_PERSISTENT"); return !(e && e[0] == '0'); }();
     const int n_dense = n_iters - n_plain;
     if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES) { rc = ensure_fit_stream(b, io, hd); if (rc) return rc; }
     if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES && b->door_usable) {

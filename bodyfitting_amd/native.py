@@ -253,6 +253,15 @@ class FrameBatch:
         p = _f32(np.asarray(init_pose).reshape(self.F, -1)[:, :72], (self.F, 72))
         _lib.check(self._lib.bf_batch_set_init(self._h, _lib.fptr(b), _lib.fptr(p)), "bf_batch_set_init")
 
+    def stage_inputs(self, keypoints, n_use_frames, init_betas, init_pose):
+        """the NEXT frame's keypoints + initial estimate without waiting for the fit in flight (bf_batch_stage_inputs); the next
+        fit() must carry FIT_RESET.  Arrays that already are C-contiguous float32 / int32 of the right shape are passed as they are."""
+        kp = _f32(keypoints, (self.F, self.V, self.model.n_loss_joints, 3))
+        nd = None if n_use_frames is None else _i32(np.broadcast_to(np.asarray(n_use_frames), (self.F,)))
+        b = _f32(init_betas, (self.F, self.model.n_betas))
+        p = _f32(np.asarray(init_pose).reshape(self.F, -1)[:, :72], (self.F, 72))
+        _lib.check(self._lib.bf_batch_stage_inputs(self._h, _lib.fptr(kp), _lib.iptr(nd), _lib.fptr(b), _lib.fptr(p)), "bf_batch_stage_inputs")
+
     def set_scans(self, scans):
         """one Scan per frame (use_mesh=True); None detaches"""
         if scans is None:
@@ -340,6 +349,19 @@ class FrameBatch:
         _lib.check(self._lib.bf_batch_get_result(self._h, _lib.fptr(verts), _lib.fptr(joints), _lib.fptr(full_pose),
                                                  _lib.fptr(terms)), "bf_batch_get_result")
         return verts, joints, full_pose, terms
+
+    def get_previous(self, vertices=True):
+        """(params, vertices, joints, full_pose, terms) of the fit issued BEFORE the last one, while the last one runs
+        (bf_batch_get_previous): the frame loop as a two-deep pipeline"""
+        m = self.model
+        params = np.empty((self.F, m.n_params), np.float32)
+        verts = np.empty((self.F, m.n_verts, 3), np.float32) if vertices else None
+        joints = np.empty((self.F, m.n_joint_map, 3), np.float32) if vertices else None
+        full_pose = np.empty((self.F, 3 * m.n_joints), np.float32)
+        terms = np.empty((self.F, 4), np.float32)
+        _lib.check(self._lib.bf_batch_get_previous(self._h, _lib.fptr(params), _lib.fptr(verts), _lib.fptr(joints), _lib.fptr(full_pose),
+                                                   _lib.fptr(terms)), "bf_batch_get_previous")
+        return params, verts, joints, full_pose, terms
 
     def export_params_dev(self, dev_ptr):
         _lib.check(self._lib.bf_batch_export_params_dev(self._h, C.c_void_p(int(dev_ptr))), "bf_batch_export_params_dev")

@@ -154,15 +154,60 @@ class Group:
         p = _f32(np.asarray(init_pose).reshape(self.F, -1)[:, :72], (self.F, 72))
         _lib.check(self._lib.bf_group_set_init(self._h, _lib.fptr(b), _lib.fptr(p)), "bf_group_set_init")
 
+    def stage_inputs(self, keypoints, n_use_frames, init_betas, init_pose):
+        """the whole job's NEXT frames, without draining the devices (bf_group_stage_inputs); the next fit() needs FIT_RESET"""
+        kp = _f32(keypoints, (self.F, self.V, self.info["n_loss_joints"], 3))
+        nd = None if n_use_frames is None else _i32(np.broadcast_to(np.asarray(n_use_frames), (self.F,)))
+        b = _f32(init_betas, (self.F, self.info["n_betas"]))
+        p = _f32(np.asarray(init_pose).reshape(self.F, -1)[:, :72], (self.F, 72))
+        _lib.check(self._lib.bf_group_stage_inputs(self._h, _lib.fptr(kp), _lib.iptr(nd), _lib.fptr(b), _lib.fptr(p)), "bf_group_stage_inputs")
+
+    def set_masks(self, masks, view_index, contours=None, contour_select=_lib.CONTOUR_OPENCV_FIRST):
+        """masks[F,M,H,W] uint8 of the whole job; contours = per (frame, mask view) arrays of (x, y) points, or None = extracted
+        on the devices (bf_group_set_masks hands every device its block; the devices work side by side)"""
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        F, M, H, W = masks.shape
+        assert F == self.F
+        vi = _i32(view_index)
+        cnt = xy = None
+        if contours is not None:
+            flat = [np.asarray(c, np.float32).reshape(-1, 2) for fr in contours for c in fr]
+            cnt = _i32([len(c) for c in flat])
+            xy = _f32(np.concatenate(flat) if flat else np.zeros((0, 2)))
+        _lib.check(self._lib.bf_group_set_masks(self._h, int(M), _lib.iptr(vi), int(H), int(W), masks.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                _lib.iptr(cnt), _lib.fptr(xy), int(contour_select)), "bf_group_set_masks")
+
+    def device_of_frame(self, f):
+        for d, first, count in self.shards:
+            if first <= f < first + count:
+                return d
+        raise IndexError(f)
+
+    def set_scans(self, scans):
+        """one native.Scan per frame of the job, each created on device_of_frame(f); None detaches"""
+        if scans is None:
+            _lib.check(self._lib.bf_group_set_scans(self._h, None), "bf_group_set_scans")
+            self._scans = None
+            return
+        assert len(scans) == self.F
+        arr = (C.c_void_p * self.F)(*[s._h for s in scans])
+        _lib.check(self._lib.bf_group_set_scans(self._h, arr), "bf_group_set_scans")
+        self._scans = list(scans)          # (keep them alive)
+
     def fit(self, n_iters, hyper=None, flags=_lib.FIT_DEFAULT):
         hp = C.byref(hyper) if hyper is not None else None
         _lib.check(self._lib.bf_group_fit(self._h, int(n_iters), hp, int(flags)), "bf_group_fit")
+
+    def fit_displacement(self, n_iters, hyper=None):
+        hp = C.byref(hyper) if hyper is not None else None
+        _lib.check(self._lib.bf_group_fit_displacement(self._h, int(n_iters), hp), "bf_group_fit_displacement")
 
     def sync(self):
         _lib.check(self._lib.bf_group_sync(self._h), "bf_group_sync")
 
     def comm_size(self):
-        n = self._lib.bf_group_comm_size(self._h)
+        with _quiet_stdout():              # (the communicator - and RCCL's banner on stdout - comes up on first use)
+            n = self._lib.bf_group_comm_size(self._h)
         if n < 0:
             _lib.check(n, "bf_group_comm_size")
         return n
@@ -170,22 +215,48 @@ class Group:
     def gather_params(self, from_peer=0):
         """the one collective of the path: -> [F, n_params] as it arrived on device `from_peer`"""
         out = np.empty((self.F, self.n_params), np.float32)
-        _lib.check(self._lib.bf_group_gather_params(self._h, _lib.fptr(out), int(from_peer)), "bf_group_gather_params")
+        with _quiet_stdout():
+            rc = self._lib.bf_group_gather_params(self._h, _lib.fptr(out), int(from_peer))
+        _lib.check(rc, "bf_group_gather_params")
         return out
 
 
 # ---- one process per device -----------------------------------------------------------------------------------------
+def _process_start_ticks(pid):
+    """start time of a process in clock ticks since boot (field 22 of /proc/<pid>/stat), or 0 where /proc is not available"""
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            return int(f.read().rsplit(")", 1)[1].split()[19])
+    except (OSError, ValueError, IndexError):
+        return 0
+
+
 class FileRendezvous:
     """Ranks of ONE node hand each other small byte strings through the file system (atomic rename, polling).  Stands in
-    for the store a launcher would offer, without importing it: the ranks of `torch.distributed.run --nnodes=1` share
-    MASTER_PORT, TORCHELASTIC_RUN_ID and their parent process, which together name the directory."""
+    for the store a launcher would offer, without importing it.
+
+    The directory is named by what the ranks of one `torch.distributed.run --nnodes=1` launch share and no other launch
+    does: MASTER_PORT, TORCHELASTIC_RUN_ID, TORCHELASTIC_RESTART_COUNT (a restarted worker group must not read the previous
+    group's RCCL id), and the launcher process itself - its pid AND its start time, so a recycled pid of a crashed job does
+    not lead to that job's leftovers.  It is created with mode 0700 and must belong to this user; the last barrier of
+    `cleanup` removes it."""
 
     def __init__(self, rank, world, key=None, root=None, timeout=300.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         if key is None:
-            key = "-".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.getppid()))
+            ppid = os.getppid()
+            key = "-".join(str(x) for x in (os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "none"),
+                                            os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"), ppid, _process_start_ticks(ppid)))
         self.dir = os.path.join(root or tempfile.gettempdir(), f"bodyfit-rdzv-{os.getuid()}-{key}")
-        os.makedirs(self.dir, exist_ok=True)
+        try:
+            os.mkdir(self.dir, 0o700)
+        except FileExistsError:
+            pass
+        st = os.lstat(self.dir)
+        import stat as _stat
+        if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            raise PermissionError(f"rendezvous directory {self.dir} is not a private directory of this user")
+        self._n_barrier = 0
 
     def _path(self, name, rank):
         return os.path.join(self.dir, f"{name}.{rank}")
@@ -216,17 +287,20 @@ class FileRendezvous:
         return [self.get(name, r) for r in range(self.world)]
 
     def barrier(self, name):
-        self.all_gather("barrier-" + name, b"1")
+        """every use of a barrier gets files of its own (a name used twice must not pass on the first use's files)"""
+        self._n_barrier += 1
+        self.all_gather(f"barrier-{name}-{self._n_barrier}", b"1")
 
     def cleanup(self):
-        """after a final barrier: every rank removes its own files, the last one the directory"""
+        """After a final barrier nobody reads anything but the `left` marks: every rank leaves one, rank 0 waits for all of
+        them and removes the directory."""
+        import shutil
         self.barrier("cleanup")
-        for f in os.listdir(self.dir):
-            if f.endswith(f".{self.rank}") and not f.startswith("barrier-cleanup"):
-                try:
-                    os.remove(os.path.join(self.dir, f))
-                except OSError:
-                    pass
+        self.put("left", b"1")
+        if self.rank == 0:
+            for r in range(self.world):
+                self.get("left", r)
+            shutil.rmtree(self.dir, ignore_errors=True)
 
 
 class Comm:

@@ -147,6 +147,51 @@ class SMPLify:
                 out[-1]["displacement"] = disp[f]
         return out
 
+    def _result_dict(self, params_f, verts_f, joints_f, full_pose_f):
+        p = split_params(params_f, self._dev.n_joints, self._dev.n_betas)
+        return {"vertices": verts_f, "joints": joints_f, "pose": p["pose"].copy(), "betas": p["betas"].copy(),
+                "global_orient": p["global_orient"].copy(), "faces": self.smpl_faces[0], "global_transl": p["global_transl"] * p["scale"],
+                "scale": p["scale"].copy(), "full_pose": full_pose_f}
+
+    def stream(self, frames, c2ws, Ks, use_frames=None, imsize=512):
+        """The frame loop of apps/genebody_fitting.py:183-192 for ONE capture (fixed cameras, keypoint-only, SMPL): `frames`
+        yields (net_output, keypoints) per frame - what BodyFitting hands `SMPLify.__call__` - and the results come back in
+        order, as a generator, one frame behind: frame i+1's inputs are uploaded and its fit is issued before frame i's result is
+        read, so uploads, fits and downloads of consecutive frames overlap (bf_batch_stage_inputs / bf_batch_get_previous).
+        Each result equals `__call__`'s for that frame bit for bit."""
+        from . import _lib
+        if self.use_hand_face:
+            raise NotImplementedError("stream(): the two-deep frame pipeline covers the keypoint-only SMPL path")
+        V = len(c2ws) if use_frames is None else len(use_frames)
+        c2w = np.stack([_np(c) for c in c2ws[:V]]).astype(np.float32)[None]
+        K = np.stack([_np(k) for k in Ks[:V]]).astype(np.float32)[None]
+        batch = self._batch(1, V)
+        if batch._had_scans:
+            batch.set_scans(None); batch._had_scans = False
+        if batch._had_masks:
+            batch.clear_masks(); batch._had_masks = False
+        batch.set_cameras(c2w, K)
+        hyper = make_hyper(imsize=imsize, constant_scale=0.3)
+        flags = _lib.FIT_RESET | _lib.FIT_FETCH | _lib.FIT_NOTIME
+        nl = self._dev.n_loss_joints
+        issued = 0
+        for net_output, keypoints in frames:
+            betas, poses = (_np(x) for x in net_output)
+            kp = np.zeros((1, V, nl, 3), np.float32)
+            for i in range(V):
+                if keypoints[i] is not None:
+                    kp[0, i] = np.asarray(keypoints[i]["pose"], np.float32)[:nl]
+            batch.stage_inputs(kp, [V], betas[:1], poses[:1])
+            batch.fit(self.num_iters, hyper, flags)
+            issued += 1
+            if issued > 1:
+                params, verts, joints, full_pose, _ = batch.get_previous()
+                yield self._result_dict(params[0], verts[0], joints[0], full_pose[0])
+        if issued:
+            params = batch.get_params()
+            verts, joints, full_pose, _ = batch.get_result()
+            yield self._result_dict(params[0], verts[0], joints[0], full_pose[0])
+
     def __call__(self, net_output, c2ws, Ks, keypoints, output_folder=None, use_mask=False, masks=None,
                  use_frames=[0], mask_frames=[0], keyframe=6, imsize=512, use_mesh=False, meshfile=None,
                  displacement=False):

@@ -24,6 +24,7 @@ the build box and on the GPU box (same image).  Seeds: 0 for the model,
 from __future__ import annotations
 
 import hashlib
+import os
 
 import numpy as np
 
@@ -94,74 +95,104 @@ def _smplx_rest():
     # five fingers x three phalanges per hand, fanned out from the wrist
     for side, wrist, base in ((1.0, 20, 25), (-1.0, 21, 40)):
         for f in range(5):
-            spread = (f - 2) * 0.018
             for k in range(3):
                 j = base + 3 * f + k
+                spread = (f - 2) * (0.019 + 0.006 * k)              # fanned: the fingers separate towards the tips
                 rest[j] = rest[wrist] + [side * (0.085 + 0.028 * k), -0.004 * f, spread]
                 radius[j] = 0.008
     return rest, radius
 
 
-def _ring_counts(weights, total, minimum=2):
-    """Integer ring counts per bone, at least `minimum` each, summing to `total`."""
-    w = np.asarray(weights, dtype=np.float64)
-    raw = w / w.sum() * total
-    counts = np.maximum(minimum, np.floor(raw).astype(np.int64))
-    # hand out / take back the remainder deterministically by largest fractional part
-    order = np.argsort(-(raw - np.floor(raw)), kind="stable")
-    i = 0
-    while counts.sum() < total:
-        counts[order[i % len(order)]] += 1
-        i += 1
-    i = 0
-    big = np.argsort(-counts, kind="stable")
-    while counts.sum() > total:
-        if counts[big[i % len(big)]] > minimum:
-            counts[big[i % len(big)]] -= 1
-        i += 1
-    return counts
+def body_primitives(model_type):
+    """The implicit body the template surface is cut from (tools/make_template.py) and the skinning weights are derived from:
+    [(a, b, ra, rb, k, joint)] = round cone from a (radius ra) to b (radius rb), blended into the rest with smooth-min width k,
+    moved by `joint` (the parent-side joint of the bone it wraps)."""
+    if model_type == "smpl":
+        J = _SMPL_REST.copy()
+    else:
+        J, _ = _smplx_rest()
+    P = []
+
+    def cone(joint, a, b, ra, rb, k=None):
+        a, b = np.asarray(a, float), np.asarray(b, float)
+        P.append((a, b, float(ra), float(rb), float(min(ra, rb) * 0.6 if k is None else k), int(joint)))
+
+    dx = np.array([0.055, 0.0, 0.0])
+    # torso: two columns side by side (elliptic cross-section), pelvis -> spine1 -> spine2 -> spine3 -> neck
+    spine = [0, 3, 6, 9, 12]
+    rad = [0.100, 0.098, 0.100, 0.098, 0.060]
+    for (i, j), (ri, rj) in zip(zip(spine[:-1], spine[1:]), zip(rad[:-1], rad[1:])):
+        w = 1.0 if j != 12 else 0.35
+        cone(i, J[i] + dx, J[j] + dx * w, ri, rj, 0.03)
+        cone(i, J[i] - dx, J[j] - dx * w, ri, rj, 0.03)
+    cone(0, J[0] + [0.0, -0.05, 0.0], J[0] + [0.0, -0.05, 0.0], 0.105, 0.105, 0.03)           # pelvis floor
+    for s, hip, knee, ankle, foot in ((1, 1, 4, 7, 10), (-1, 2, 5, 8, 11)):
+        cone(0, J[0] + [s * 0.05, -0.04, 0.0], J[hip], 0.100, 0.088, 0.03)
+        cone(hip, J[hip], J[knee], 0.086, 0.056, 0.03)
+        cone(knee, J[knee], J[ankle], 0.056, 0.040, 0.02)
+        cone(ankle, J[ankle], J[foot], 0.042, 0.034, 0.02)
+        cone(foot, J[foot], J[foot] + [s * 0.005, -0.012, 0.085], 0.032, 0.024, 0.015)            # toes
+        cone(ankle, J[ankle] + [0.0, -0.03, 0.0], J[ankle] + [0.0, -0.055, -0.045], 0.038, 0.036, 0.02)   # heel
+    for s, collar, shoulder, elbow, wrist in ((1, 13, 16, 18, 20), (-1, 14, 17, 19, 21)):
+        cone(9, J[9] + [s * 0.05, 0.06, 0.0], J[collar], 0.075, 0.062, 0.03)
+        cone(collar, J[collar], J[shoulder], 0.062, 0.056, 0.03)
+        cone(shoulder, J[shoulder], J[elbow], 0.052, 0.040, 0.02)
+        cone(elbow, J[elbow], J[wrist], 0.040, 0.029, 0.015)
+    cone(12, J[12], J[15], 0.056, 0.054, 0.02)                                                    # neck
+    cone(15, J[15] + [0.0, 0.05, 0.012], J[15] + [0.0, 0.105, 0.005], 0.090, 0.088, 0.02)         # skull
+    cone(22 if model_type == "smplx" else 15, J[15] + [0.0, 0.0, 0.045], J[15] + [0.0, -0.035, 0.075], 0.052, 0.040, 0.015)   # jaw / chin
+    cone(15, J[15] + [0.0, 0.03, 0.095], J[15] + [0.0, 0.015, 0.115], 0.016, 0.012, 0.008)        # nose
+    if model_type == "smpl":
+        for s, wrist, hand in ((1, 20, 22), (-1, 21, 23)):
+            cone(wrist, J[wrist], J[hand], 0.028, 0.030, 0.012)
+            for dz in (-0.018, 0.0, 0.018):                                                         # mitten
+                cone(hand, J[hand] + [0.0, 0.0, dz], J[hand] + [s * 0.085, -0.004, dz * 1.5], 0.020, 0.013, 0.008)
+            cone(hand, J[hand] + [s * -0.03, 0.0, 0.03], J[hand] + [s * 0.02, 0.0, 0.062], 0.015, 0.011, 0.008)   # thumb
+    else:
+        for s, wrist, base in ((1, 20, 25), (-1, 21, 40)):
+            for f in range(5):
+                j0, j1, j2 = base + 3 * f, base + 3 * f + 1, base + 3 * f + 2
+                cone(wrist, J[wrist], J[j0], 0.024, 0.0125, 0.010)                                   # palm rays
+                cone(j0, J[j0], J[j1], 0.0095, 0.0088, 0.004)
+                cone(j1, J[j1], J[j2], 0.0088, 0.0080, 0.004)
+                cone(j2, J[j2], J[j2] + (J[j2] - J[j1]) * 0.85, 0.0080, 0.0070, 0.004)
+    return P
 
 
-def _tube_mesh(rest, parents, radius, nv, seg):
-    """Vertices on rings around every bone p->j, faces between adjacent rings."""
-    nj = len(parents)
-    assert nv % seg == 0
-    bones = [(int(parents[j]), j) for j in range(1, nj)]
-    length = np.array([np.linalg.norm(rest[j] - rest[p]) for p, j in bones])
-    weight = np.maximum(length, 0.04) * np.maximum(radius[1:], 0.01) ** 0.5
-    rings = _ring_counts(weight, nv // seg)
-    verts, faces, bone_of, t_of = [], [], [], []
-    base = 0
-    ang = np.arange(seg) * (2.0 * np.pi / seg)
-    for b, (p, j) in enumerate(bones):
-        axis = rest[j] - rest[p]
-        ln = np.linalg.norm(axis)
-        axis = axis / ln
-        helper = np.array([0.0, 0.0, 1.0]) if abs(axis[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
-        e1 = np.cross(axis, helper)
-        e1 /= np.linalg.norm(e1)
-        e2 = np.cross(axis, e1)
-        nr = int(rings[b])
-        for k in range(nr):
-            t = (k + 0.5) / nr
-            # slightly bulging tube, rotated a little per ring so faces are not co-planar strips
-            r = radius[j] * (1.0 + 0.25 * np.sin(np.pi * t))
-            a = ang + 0.31 * k
-            ring = rest[p] + axis * (t * ln) + r * (np.cos(a)[:, None] * e1 + np.sin(a)[:, None] * e2)
-            verts.append(ring)
-            bone_of += [b] * seg
-            t_of += [t] * seg
-            if k + 1 < nr:
-                lo = base + k * seg
-                hi = lo + seg
-                for s in range(seg):
-                    s1 = (s + 1) % seg
-                    faces.append([lo + s, lo + s1, hi + s])
-                    faces.append([lo + s1, hi + s1, hi + s])
-        base += nr * seg
-    verts = np.concatenate(verts, 0)
-    assert verts.shape[0] == nv
-    return verts, np.asarray(faces, dtype=np.int32), np.asarray(bone_of), np.asarray(t_of), bones
+def load_template(model_type, nv):
+    """(verts float64 [nv,3], faces int32 [2nv-4,3]) of the committed closed genus-0 template (tools/make_template.py)"""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"template_{model_type}_{nv}.npz")
+    if not os.path.exists(path):
+        raise FileNotFoundError(f"{path} is missing: generate it with `python tools/make_template.py {model_type} {nv}`")
+    d = np.load(path)
+    return d["verts"].astype(np.float64), d["faces"].astype(np.int32)
+
+
+def skinning_weights(verts, prims, nj, top=4):
+    """[nv,nj] with `top` non-zeros per row: joint i's pull on a vertex falls off with the vertex's distance to the SURFACE of the
+    round cones joint i moves, measured against the nearest cone's - so a vertex of the inner left thigh belongs to the left leg
+    although the right leg's bone is as close - over a blend width of 0.3 x the local limb radius."""
+    nv = len(verts)
+    d = np.full((nv, nj), 1.0e3)
+    r_near = np.full(nv, 0.02)
+    d_near = np.full(nv, 1.0e3)
+    for a, b, ra, rb, _, j in prims:
+        ab = b - a
+        L2 = float(ab @ ab)
+        t = np.clip(((verts - a) @ ab) / L2, 0.0, 1.0) if L2 > 1e-12 else np.zeros(nv)
+        r = ra + t * (rb - ra)
+        dp = np.linalg.norm(verts - (a + t[:, None] * ab), axis=1) - r
+        d[:, j] = np.minimum(d[:, j], dp)
+        take = dp < d_near
+        d_near = np.where(take, dp, d_near)
+        r_near = np.where(take, r, r_near)
+    w = np.exp(-(d - d.min(1, keepdims=True)) / (0.3 * r_near)[:, None])
+    keep = np.argsort(-w, axis=1, kind="stable")[:, :top]
+    out = np.zeros_like(w)
+    np.put_along_axis(out, keep, np.take_along_axis(w, keep, 1), 1)
+    out[out < 1e-4] = 0.0
+    return out / out.sum(1, keepdims=True)
+
 
 
 def _nearest_vertex(verts, target, taken):
@@ -190,39 +221,22 @@ def make_model(model_type="smpl", seed=0, nv=None):
     """Synthetic body model with the tensor layout of smplx 0.1.13."""
     rng = np.random.default_rng(seed)
     if model_type == "smpl":
-        parents, rest, radius = SMPL_PARENTS, _SMPL_REST.copy(), _SMPL_RADIUS
+        parents, rest = SMPL_PARENTS, _SMPL_REST.copy()
         nv = 6890 if nv is None else nv
-        seg = 10
         nb = 10
     elif model_type == "smplx":
         parents = SMPLX_PARENTS
-        rest, radius = _smplx_rest()
+        rest, _ = _smplx_rest()
         nv = 10475 if nv is None else nv
-        seg = 5
         nb = 20  # 10 betas + 10 expression
     else:
         raise ValueError(f"unknown model type {model_type!r}")
     nj = len(parents)
-    while nv % seg:
-        seg -= 1
-    verts, faces, bone_of, t_of, bones = _tube_mesh(rest, parents, radius, nv, seg)
-    verts = verts + rng.normal(0.0, 0.0015, size=verts.shape)
-
-    # skinning weights: 4 non-zeros per row (bone owner, child, grand-parent, one stray joint)
-    lbs = np.zeros((nv, nj))
-    stray = rng.integers(0, nj, size=nv)
-    stray_w = rng.uniform(0.0, 0.04, size=nv)
-    for v in range(nv):
-        p, j = bones[bone_of[v]]
-        t = t_of[v]
-        gp = int(parents[p]) if parents[p] >= 0 else p
-        w_child = 0.02 + 0.5 * max(0.0, (t - 0.6) / 0.4) ** 2
-        w_gp = 0.02 + 0.5 * max(0.0, (0.4 - t) / 0.4) ** 2 if gp != p else 0.0
-        lbs[v, j] += w_child
-        lbs[v, gp] += w_gp
-        lbs[v, stray[v]] += stray_w[v]
-        lbs[v, p] += 1.0 - w_child - w_gp - stray_w[v]
-    lbs /= lbs.sum(1, keepdims=True)
+    # template: one closed genus-0 surface of a human's area with near-uniform triangles (tools/make_template.py)
+    verts, faces = load_template(model_type, nv)
+    prims = body_primitives(model_type)
+    # skinning weights: 4 non-zeros per row, smooth across the joints
+    lbs = skinning_weights(verts, prims, nj)
 
     # joint regressor: mean of the 32 template vertices nearest to each rest joint (dense storage)
     jreg = np.zeros((nj, nv))
@@ -433,8 +447,9 @@ def make_problem(model, frame=0, n_views=48, imsize=512, constant_scale=0.3, pos
     op25 = joints[model["joint_map"][:25]]
     world = (op25 + transl_gt) * scale_gt * constant_scale
 
-    c2ws, Ks = ring_cameras(n_views, imsize=imsize, focal=float(imsize),
-                            centre=(world.mean(0) * [1, 1, 1]).tolist())
+    # the camera ring belongs to the capture, not to the frame: every frame of the synthetic subject is seen by the same
+    # calibrated cameras (BASELINE config 4: "distinct GT poses / keypoints, shared cameras + model")
+    c2ws, Ks = ring_cameras(n_views, imsize=imsize, focal=float(imsize), centre=(0.0, 0.05, 0.0))
     keypoints = []
     for v in range(n_views):
         w2c = np.linalg.inv(c2ws[v].astype(np.float64))
@@ -464,6 +479,14 @@ def make_problem(model, frame=0, n_views=48, imsize=512, constant_scale=0.3, pos
     }
 
 
+def _scan_noise(points, rng):
+    """what separates a scan from the body under it, in units of `noise` (3 mm): smooth low-frequency relief (wavelengths of 25
+    and 16 cm, SURVEY.md 8d: "GT posed mesh + smooth noise") plus a tenth of that as white sensor noise"""
+    p = np.asarray(points, np.float64)
+    return (0.6 * np.sin(p * 25.0 + rng.uniform(0, 6.28, size=3)) + 0.4 * np.sin(p[:, [1, 2, 0]] * 40.0 + rng.uniform(0, 6.28, size=3))
+            + rng.normal(0.0, 0.1, size=p.shape))
+
+
 def make_scan_problem(model, frame=0, n_views=8, imsize=512, scan_scale=1.0, noise=0.003, pose_noise=0.1):
     """A frame with a scan mesh (use_mesh=True, reference smplify.py:146-156): the scan is the ground-
     truth posed body (the model's own topology) with smooth noise, in a world whose constant scale is
@@ -477,8 +500,7 @@ def make_scan_problem(model, frame=0, n_views=8, imsize=512, scan_scale=1.0, noi
     ext_y = verts[:, 1].max() - verts[:, 1].min()
     scale_gt = 1.7 / ext_y                     # => scan_height / 1.7 == scan_scale exactly
     scan = (verts + transl_gt) * scale_gt * scan_scale
-    bump = 0.5 * np.sin(scan * 9.0 + rng.uniform(0, 6.28, size=3)) + rng.normal(0.0, 0.3, size=scan.shape)
-    scan = scan + noise * scan_scale * bump
+    scan = scan + noise * scan_scale * _scan_noise(scan / scan_scale, rng)
     # the reference reads the scan from an OBJ written with 4 decimals (utils/io_utils.py:185-192)
     scan = np.round(scan, 4).astype(np.float32)
     cscale = float((scan[:, 1].max() - scan[:, 1].min()) / 1.7)
@@ -597,8 +619,7 @@ def make_scan_problem_smplx(model, frame=0, n_views=8, imsize=512, noise=0.003, 
     verts, joints, _ = smplx_joints64(model, np.concatenate([gt["betas"], np.zeros(10)]), fp)
     gt["scale"] = 1.7 / (verts[:, 1].max() - verts[:, 1].min())
     sv, sf = subdivide_mesh((verts + gt["transl"]) * gt["scale"], model["faces"], subdivide)
-    bump = 0.5 * np.sin(sv * 9.0 + rng.uniform(0, 6.28, size=3)) + rng.normal(0.0, 0.3, size=sv.shape)
-    sv = np.round(sv + noise * bump, 4).astype(np.float32)
+    sv = np.round(sv + noise * _scan_noise(sv, rng), 4).astype(np.float32)
     cscale = float((sv[:, 1].max() - sv[:, 1].min()) / 1.7)
     world = (joints + gt["transl"]) * gt["scale"]
     c2ws, Ks = ring_cameras(n_views, radius=3.2, imsize=imsize, focal=float(imsize), centre=world[:25].mean(0).tolist())

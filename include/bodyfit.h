@@ -161,6 +161,13 @@ int bf_batch_set_keypoints(bf_batch *b, const float *keypoints, const int32_t *n
 /* init_betas[F,NB], init_pose[F,72] = net_output of smplify.py:103 (SMPL-X takes [:, 3:66] as body pose,
  * :110-112; eyes / hand PCA start at 0, :118-122); transl=0, scale=1 (:126-128) */
 int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_pose);
+/* The NEXT frame's keypoints[F,V,n_loss_joints,3], n_use_frames[F] (NULL -> V), init_betas[F,NB], init_pose[F,72] (layouts of
+ * bf_batch_set_keypoints / bf_batch_set_init) without waiting for the work in flight: the frame loop of
+ * apps/genebody_fitting.py:183-192 hands SMPLify.__call__ new detections and a new HMR estimate every frame (and loss.py:160
+ * uploads the keypoints again every iteration).  The arrays are copied into pinned staging before the call returns; their
+ * transfer into the device arena the running fit does not read is queued on the batch's stream.  The next bf_fit must carry
+ * BF_FIT_RESET (anything else fails with BF_ERR_INVALID).  Cameras, masks and scans are not staged: they stay as set. */
+int bf_batch_stage_inputs(bf_batch *b, const float *keypoints, const int32_t *n_use_frames, const float *init_betas, const float *init_pose);
 /* Re-arm the batch for another fit of the same inputs without touching the host: restores the
  * parameters of the last bf_batch_set_init / bf_batch_set_params and clears the Adam state, as
  * stream-ordered device copies.  (The reference rebuilds everything per frame, body_fitting.py:82.) */
@@ -182,6 +189,11 @@ int bf_batch_sync(bf_batch *b);
  * (parameters before the final step, as in the reference); the stepped parameters come from
  * bf_batch_get_params.  loss_terms[F,4] are those of the last evaluated iteration. */
 int bf_batch_get_result(bf_batch *b, float *vertices, float *joints, float *full_pose, float *loss_terms);
+/* The result of the fit issued BEFORE the last one, without waiting for the last one: with bf_batch_stage_inputs this makes the
+ * frame loop a two-deep pipeline (frame i's rtn_dict, smplify.py:216-226, is read while frame i+1 is being fitted).  Both fits
+ * must have been issued with BF_FIT_RESET | BF_FIT_FETCH | BF_FIT_NOTIME on the keypoint-only path - their results then sit in
+ * the batch's two result arenas.  params[F,n_params] + the outputs of bf_batch_get_result; any pointer may be NULL. */
+int bf_batch_get_previous(bf_batch *b, float *params, float *vertices, float *joints, float *full_pose, float *loss_terms);
 /* packed [F,n_params] stepped parameters copied into a DEVICE buffer (e.g. the send buffer of the
  * final RCCL all-gather when frames are sharded over GPUs) */
 int bf_batch_export_params_dev(bf_batch *b, void *dst_dev);
@@ -259,6 +271,9 @@ int bf_batch_get_displacement(bf_batch *b, float *displacement /*[F,NV,3]*/);
 int bf_shard_range(int n_frames, int n_shards, int shard, int32_t *first, int32_t *count);
 int bf_shard_capacity(int n_frames, int n_shards);
 int bf_shard_unpack(const float *gathered, int n_frames, int n_shards, int width, float *out);
+/* block starts of the silhouette contours (bf_batch_set_masks' contour_count[n_frames * n_masks] / contour_xy) per shard:
+ * xy_first[n_shards + 1] = (x, y) pairs in front of every shard's first contour, then their total */
+int bf_shard_contour_offsets(int n_frames, int n_shards, int n_masks, const int32_t *contour_count, int64_t *xy_first);
 
 /* ONE process driving n devices: a bf_model + bf_batch + stream per device (devices == NULL -> 0..n-1),
  * ncclCommInitAll on first use.  The setters take the arrays of the whole job [F, ...] (layouts of the bf_batch_set_*
@@ -274,7 +289,17 @@ bf_model *bf_group_model(bf_group *g, int i);
 int bf_group_set_cameras(bf_group *g, const float *c2w, const float *K);
 int bf_group_set_keypoints(bf_group *g, const float *keypoints, const int32_t *n_use_frames);
 int bf_group_set_init(bf_group *g, const float *init_betas, const float *init_pose);
+/* the whole job's next frames without draining the devices (bf_batch_stage_inputs per device) */
+int bf_group_stage_inputs(bf_group *g, const float *keypoints, const int32_t *n_use_frames, const float *init_betas, const float *init_pose);
+/* masks[F,M,H,W] + optional contours of the whole job (bf_batch_set_masks per device; the devices extract their contours side by side) */
+int bf_group_set_masks(bf_group *g, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
+                       const int32_t *contour_count, const float *contour_xy, int contour_select);
+/* scans[F]: frame f's scan must have been created on the device of f's block (bf_group_shard); NULL detaches */
+int bf_group_set_scans(bf_group *g, bf_scan *const *scans);
+/* Every device's bf_fit is issued from a host thread of its own (created with the group), so the devices run side by side also
+ * when a call enqueues hundreds of launches (silhouette / scan losses); returns when all calls have returned. */
 int bf_group_fit(bf_group *g, int n_iters, const bf_hyper *hyper, uint32_t flags);
+int bf_group_fit_displacement(bf_group *g, int n_iters, const bf_hyper *hyper);
 int bf_group_sync(bf_group *g);
 /* ranks of the group's RCCL communicator (created on first use) */
 int bf_group_comm_size(bf_group *g);

@@ -365,6 +365,204 @@ def smplx_goldens():
         print(tag, "done")
 
 
+def _nudge(problem):
+    """the same problem with every entry of the initial pose moved to the next float32 (1 ulp)"""
+    q = dict(problem)
+    q["init_pose"] = np.nextafter(problem["init_pose"].astype(np.float32), np.float32(np.inf)).astype(np.float32)
+    return q
+
+
+def sensitivity_goldens():
+    """How far does the REFERENCE move from itself?  The dense-loss loops (silhouette: nearest-vertex choices and 1 <-> 10 weights;
+    scan: closest faces; SMPL+D: Adam's normalised steps) amplify round-off, so the parity bands of those loops in tests/ are
+    set from what the imported reference does under two perturbations that change no mathematics: torch running 8 intra-op
+    threads instead of 1 (other summation orders), and the initial pose moved by one float32 ulp.  Same problems, same
+    snapshots as mask_goldens / smplx_goldens / scan_goldens_long; the committed files hold the perturbed runs' outputs."""
+    import torch
+    import smplx
+    from bodyfitting_amd import synthetic as S
+    from bodyfitting_amd.io import save_obj_mesh
+
+    variants = (("threads8", 8, False), ("ulp", 1, True))
+    gmm = S.make_gmm(seed=0)
+
+    def capture(names, want, run):
+        snaps, counter = {}, {"n": 0, "d": 0}
+        orig_step = torch.optim.Adam.step
+
+        def step(self, *a, **k):
+            r = orig_step(self, *a, **k)
+            g = self.param_groups
+            if len(g) > 1:
+                counter["n"] += 1
+                if counter["n"] in want:
+                    snaps[counter["n"]] = {n: g[i]["params"][0].detach().numpy().reshape(-1).copy() for i, n in enumerate(names)}
+            return r
+        torch.optim.Adam.step = step
+        try:
+            res = run()
+        finally:
+            torch.optim.Adam.step = orig_step
+        return res, snaps
+
+    smpl_names = ("global_transl", "scale", "pose", "betas", "global_orient")
+    smplx_names = smpl_names + ("leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose")
+
+    # ---- silhouette loop, SMPL, 30 iterations (mask_goldens b) ------------------------------------------------------
+    model = S.make_model("smpl", seed=0)
+    smplx.MODEL_REGISTRY["smpl"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_sens_mask_")
+    write_data_dir(tmp, model, gmm)
+    os.chdir(tmp)
+    install_cv2_contour_stub()
+    from smplify.smplify import SMPLify
+    mask_frames = [1, 3, 5, 7]
+    base = S.make_problem(model, frame=0, n_views=8, mask_frames=mask_frames)
+    out = {}
+    for tag, threads, nudge in variants:
+        torch.set_num_threads(threads)
+        prob = _nudge(base) if nudge else base
+        fitter = SMPLify(smpl_type="smpl", num_iters=30, gender="neutral", device=torch.device("cpu"), debug=False)
+        res, snaps = capture(smpl_names, (1, 11, 12, 20, 30), lambda: fitter(
+            (torch.from_numpy(prob["init_betas"].copy()), torch.from_numpy(prob["init_pose"].copy())), prob["c2ws"], prob["Ks"],
+            prob["keypoints"], None, use_mask=True, masks=prob["masks"], use_frames=prob["use_frames"], mask_frames=mask_frames,
+            imsize=prob["imsize"]))
+        out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
+        out[f"{tag}_joints"] = res["joints"]
+    torch.set_num_threads(1)
+    np.savez_compressed(os.path.join(GOLDEN, "sens_mask_fit_8view_30it.npz"), model_digest=S.model_digest(model), **out)
+    print("sensitivity: mask loop done")
+
+    # ---- scan loop 300 + SMPL+D 300 on the reduced model (scan_goldens_long) -----------------------------------------
+    model = S.make_model("smpl", seed=0, nv=690)
+    smplx.MODEL_REGISTRY["smpl"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_sens_scan_")
+    write_data_dir(tmp, model, gmm)
+    os.chdir(tmp)
+    base, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
+    meshfile = os.path.join(tmp, "scan.obj")
+    save_obj_mesh(meshfile, sv, sf)
+    out = {}
+    for tag, threads, nudge in variants:
+        torch.set_num_threads(threads)
+        prob = _nudge(base) if nudge else base
+        res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 300, snapshots=(100, 101, 300), displacement=True)
+        out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
+        out[f"{tag}_vertices"], out[f"{tag}_joints"], out[f"{tag}_displacement"] = res["vertices"], res["joints"], res["displacement"]
+    torch.set_num_threads(1)
+    np.savez_compressed(os.path.join(GOLDEN, "sens_scan_nv690_300it.npz"), model_digest=S.model_digest(model), **out)
+    print("sensitivity: scan loop done")
+    out = {}
+    for tag, threads, nudge in variants:              # the 30 + 30-iteration run of scan_goldens, with its displacement snapshots
+        torch.set_num_threads(threads)
+        prob = _nudge(base) if nudge else base
+        res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 30, snapshots=(1, 11, 12, 20, 30), displacement=True)
+        out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
+        out.update({f"{tag}_disp{k}": v for k, v in dsn.items()})
+        out[f"{tag}_vertices"], out[f"{tag}_displacement"] = res["vertices"], res["displacement"]
+    torch.set_num_threads(1)
+    np.savez_compressed(os.path.join(GOLDEN, "sens_scan_nv690_30it.npz"), model_digest=S.model_digest(model), **out)
+    print("sensitivity: short scan loop done")
+
+    # ---- silhouette loop, SMPL-X, 15 iterations (smplx_goldens) ------------------------------------------------------
+    model = S.make_model("smplx", seed=0)
+    smplx.MODEL_REGISTRY["smplx"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_sens_smplx_")
+    os.makedirs(os.path.join(tmp, "data"), exist_ok=True)
+    with open(os.path.join(tmp, "data", "gmm_08.pkl"), "wb") as f:
+        pickle.dump(gmm, f)
+    os.chdir(tmp)
+    base = S.make_problem_smplx(model, frame=0, n_views=8, mask_frames=mask_frames)
+    out = {}
+    for tag, threads, nudge in variants:
+        torch.set_num_threads(threads)
+        prob = _nudge(base) if nudge else base
+        fitter = SMPLify(smpl_type="smplx", num_iters=15, gender="neutral", device=torch.device("cpu"), debug=False)
+        res, snaps = capture(smplx_names, (1, 2, 6, 10, 15), lambda: fitter(
+            (torch.from_numpy(prob["init_betas"].copy()), torch.from_numpy(prob["init_pose"].copy())), prob["c2ws"], prob["Ks"],
+            prob["keypoints"], None, use_frames=prob["use_frames"], imsize=prob["imsize"], use_mask=True, masks=prob["masks"],
+            mask_frames=mask_frames))
+        out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
+        out[f"{tag}_joints"] = res["joints"]
+    torch.set_num_threads(1)
+    np.savez_compressed(os.path.join(GOLDEN, "sens_smplx_mask_8view_15it.npz"), model_digest=S.model_digest(model), **out)
+    print("sensitivity: smplx mask loop done")
+
+
+def cfg3_goldens(variants=(("base", 1, False), ("threads8", 8, False), ("ulp", 1, True))):
+    """BASELINE config 3 AS STATED, run by the imported reference: SMPL-X (10,475 vertices, 55 joints, 135 output joints),
+    48 views with body + hands + face keypoints, 8 silhouette views at 512 x 512, 200 iterations (the silhouette loss is active
+    for i > 66, smplify.py:197).  Snapshots of the optimised parameters after iterations 1 / 66 / 67 / 68 / 200 and the loss values
+    the loop computed in those iterations (multiview_keypoint_loss's total + dict, loss.py:219-228; multview_mask_loss's value),
+    recorded by wrapping the functions the loop calls - the reference code itself is untouched.  The `threads8` and `ulp`
+    variants are the reference's own sensitivity at this size (see sensitivity_goldens)."""
+    import torch
+    import smplx
+    from bodyfitting_amd import synthetic as S
+
+    model = S.make_model("smplx", seed=0)
+    gmm = S.make_gmm(seed=0)
+    smplx.MODEL_REGISTRY["smplx"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_golden_cfg3_")
+    os.makedirs(os.path.join(tmp, "data"), exist_ok=True)
+    with open(os.path.join(tmp, "data", "gmm_08.pkl"), "wb") as f:
+        pickle.dump(gmm, f)
+    os.chdir(tmp)
+    install_cv2_contour_stub()
+    import smplify.smplify as RS
+    names = ("global_transl", "scale", "pose", "betas", "global_orient", "leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose")
+    mask_frames = list(range(0, 48, 6))
+    base = S.make_problem_smplx(model, frame=0, n_views=48, mask_frames=mask_frames)
+    want = (1, 66, 67, 68, 200)
+    for tag, threads, nudge in variants:
+        torch.set_num_threads(threads)
+        prob = _nudge(base) if nudge else base
+        snaps, losses, counter = {}, {}, {"n": 0}
+        orig_step, orig_kp, orig_mask = torch.optim.Adam.step, RS.multiview_keypoint_loss, RS.multview_mask_loss
+
+        def step(self, *a, **k):
+            r = orig_step(self, *a, **k)
+            counter["n"] += 1
+            if counter["n"] in want:
+                g = self.param_groups
+                snaps[counter["n"]] = {n: g[i]["params"][0].detach().numpy().reshape(-1).copy() for i, n in enumerate(names)}
+            return r
+
+        def kp_loss(*a, **k):
+            total, d = orig_kp(*a, **k)
+            it = counter["n"] + 1                      # (the iteration whose step comes next)
+            if it in want:
+                losses[it] = {"total": float(total), **{kk: float(np.asarray(v).reshape(-1)[0]) for kk, v in d.items()}}
+            return total, d
+
+        def mask_loss(*a, **k):
+            v = orig_mask(*a, **k)
+            it = counter["n"] + 1
+            if it in want:
+                losses[it]["mask_loss"] = float(v)
+            return v
+
+        torch.optim.Adam.step, RS.multiview_keypoint_loss, RS.multview_mask_loss = step, kp_loss, mask_loss
+        t0 = time.perf_counter()
+        try:
+            fitter = RS.SMPLify(smpl_type="smplx", num_iters=200, gender="neutral", device=torch.device("cpu"), debug=False)
+            res = fitter((torch.from_numpy(prob["init_betas"].copy()), torch.from_numpy(prob["init_pose"].copy())), prob["c2ws"],
+                         prob["Ks"], prob["keypoints"], None, use_frames=prob["use_frames"], imsize=prob["imsize"],
+                         use_mask=True, masks=prob["masks"], mask_frames=mask_frames)
+        finally:
+            torch.optim.Adam.step, RS.multiview_keypoint_loss, RS.multview_mask_loss = orig_step, orig_kp, orig_mask
+        wall = time.perf_counter() - t0
+        extra = {}
+        for it, d in losses.items():
+            for kk, v in d.items():
+                extra[f"it{it}_loss_{kk}"] = v
+        np.savez_compressed(os.path.join(GOLDEN, f"cfg3_smplx_48view_8mask_200it_{tag}.npz"), frame=0, n_views=48, num_iters=200,
+                            mask_frames=np.array(mask_frames), wall_s=wall, threads=threads, joints=res["joints"], full_pose=res["full_pose"],
+                            vertices_sample=res["vertices"][::53], model_digest=S.model_digest(model), **flat_snaps(snaps), **extra)
+        print("cfg3", tag, wall, "s", {it: d.get("mask_loss") for it, d in losses.items()})
+    torch.set_num_threads(1)
+
+
 def reference_timing(frames=(0, 1, 2)):
     """Wall time of the UNMODIFIED reference loop (SMPLify.__call__, smplify.py:84-250: 48 views, 100 iterations, torch CPU,
     1 thread = its faster setting) on this build container, per frame, without the snapshot hook: the reference-side CPU figure
@@ -529,7 +727,9 @@ def main():
 
 
 if __name__ == "__main__":
-    if "--scan-only" in sys.argv:
+    if "--main-only" in sys.argv:
+        main()
+    elif "--scan-only" in sys.argv:
         install_reference_imports()
         scan_goldens()
     elif "--smplx-only" in sys.argv:
@@ -541,6 +741,12 @@ if __name__ == "__main__":
     elif "--openpose-only" in sys.argv:
         install_reference_imports()
         openpose_goldens()
+    elif "--sensitivity-only" in sys.argv:
+        install_reference_imports()
+        sensitivity_goldens()
+    elif "--cfg3-only" in sys.argv:
+        install_reference_imports()
+        cfg3_goldens()
     elif "--timing-only" in sys.argv:
         install_reference_imports()
         reference_timing()
@@ -554,4 +760,6 @@ if __name__ == "__main__":
         smplx_goldens()
         scan_goldens_long()
         openpose_goldens()
+        sensitivity_goldens()
+        cfg3_goldens()
         reference_timing()

@@ -12,14 +12,17 @@ from test_mask_oracle import MASK_FRAMES, mask_inputs
 
 pytestmark = pytest.mark.gpu
 PARAMS = ("global_transl", "scale", "pose", "betas", "global_orient")
-MASK_FIRST_STEP_TOL = 1e-3     # first iteration that carries the silhouette loss: a tenth of one Adam step (lr 1e-2).  The loss picks, per
-                               # contour point, the nearest projected vertex by torch.cdist's expanded float32 distances, whose rounding
-                               # noise at 512-pixel coordinates is ~0.03 px^2: a last-bit difference in ONE projected vertex decides
-                               # near-ties, and each flipped choice moves the step by ~1e-3.  Observed 9e-6 (no flip) or 7.9e-4 (one)
-                               # depending on the build; the keypoint-only prefix before it holds 4e-6
-MASK_LOOP_TOL = 0.15           # after 19 such iterations (observed 0.037 - 0.084 from one build of the kernels to the next: which multiply-adds
-                               # the compiler fuses moves with it): a flipped nearest-vertex choice is amplified by Adam - the
-                               # END STATE is what is asserted against the reference's (silhouette loss / keypoint terms)
+# The silhouette loss is discontinuous (nearest-vertex choices, 1 <-> 10 weights, the inside filter) and ~10x the keypoint loss, so the
+# loop amplifies round-off.  How much is MEASURED on the reference itself (tests/golden/sens_mask_fit_8view_30it.npz: the imported
+# reference with 8 intra-op threads instead of 1, and with the initial pose moved by one float32 ulp): it ends 3.9e-4 from itself after
+# the first silhouette iteration and 4.9e-2 after 30.  The bands below are K = 3 x that drift (tests/ref_drift.py), never below 1e-4.
+import ref_drift as RD
+
+
+def _bands():
+    base, sens = load_golden("mask_fit_8view_30it.npz"), load_golden("sens_mask_fit_8view_30it.npz")
+    per_it = {k: RD.band(base, sens, [f"it{k}_{n}" for n in PARAMS]) for k in (12, 20, 30)}
+    return base, sens, per_it, RD.band(base, sens, ["joints"])
 
 
 def _batch(dev_model, prob):
@@ -95,11 +98,13 @@ def test_mask_fit_loop_against_the_reference(dev_model, smpl_model, gmm_bufs):
         got = N.split_params(b.get_params()[0])
         drift[k] = max(float(np.abs(got[n] - g[f"it{k}_{n}"]).max()) for n in PARAMS)
     print("mask loop, distances in the reference's fp32 form: max |param - reference| per snapshot =", drift)
+    _, sens, bands, joints_band = _bands()
+    print("bands = 3 x the reference's own drift:", bands, "joints", joints_band)
     assert drift[1] < 1e-6 and drift[11] < 1e-5                 # keypoint-only prefix
-    assert drift[12] < MASK_FIRST_STEP_TOL                      # the first silhouette iteration: at most a near-tie flip away
-    assert drift[30] < MASK_LOOP_TOL                            # afterwards the discontinuous objective amplifies single flips
+    assert drift[12] < bands[12]                                # the first silhouette iteration: at most a near-tie flip away
+    assert drift[20] < bands[20] and drift[30] < bands[30]      # afterwards the discontinuous objective amplifies single flips
     verts, joints, _, _ = b.get_result()
-    np.testing.assert_allclose(joints[0], g["joints"], atol=MASK_LOOP_TOL)
+    np.testing.assert_allclose(joints[0], g["joints"], atol=joints_band)
     assert b.mask_loss()[0][0] < 0.7 * l0                    # the silhouette term really went down
     b.close()
     b = _batch(dev_model, prob)                              # one call of 30 == the five calls above, bit for bit
@@ -112,11 +117,16 @@ def test_mask_fit_loop_against_the_reference(dev_model, smpl_model, gmm_bufs):
     mask_got, terms_got = _end_state(dev_model, prob, N.pack_params(got))
     print("silhouette loss: initial", float(l0), "reference end state", mask_ref, "HIP end state", mask_got,
           "| keypoint terms: reference", terms_ref.tolist(), "HIP", terms_got.tolist())
-    # 30 Adam steps do not converge this objective - the silhouette term still moves by tens of percent per step - so the
-    # end states are compared as what they are: both far below the initial loss, within 30 % of each other
+    # 30 Adam steps do not converge this objective, so the end states are compared as what they are: both far below the initial loss,
+    # and as far from each other as the reference's own perturbed runs end from the reference (K x that spread)
+    ends = [_end_state(dev_model, prob, N.pack_params({n: sens[f"{v}_it30_{n}"] for n in PARAMS})) for v in RD.VARIANTS]
+    mask_spread = max(abs(e[0] - mask_ref) for e in ends) / mask_ref
+    terms_spread = max(abs(float(e[1].sum()) - float(terms_ref.sum())) for e in ends) / float(terms_ref.sum())
+    print("the reference's own end states:", [(e[0], e[1].tolist()) for e in ends], "relative spread", mask_spread, terms_spread)
     assert mask_ref < 0.7 * float(l0) and mask_got < 0.7 * float(l0)
-    assert mask_got == pytest.approx(mask_ref, rel=0.3)
-    assert float(terms_got.sum()) == pytest.approx(float(terms_ref.sum()), rel=0.3)
+    assert mask_got == pytest.approx(mask_ref, rel=max(0.02, RD.K * mask_spread))
+    assert float(terms_got.sum()) == pytest.approx(float(terms_ref.sum()), rel=max(0.02, RD.K * terms_spread))
+    mask_band, terms_band = max(0.02, RD.K * mask_spread), max(0.02, RD.K * terms_spread)
     # exact distances: a chosen deviation that drifts from the reference (documented in DESIGN.md), same quality of fit
     b = _batch(dev_model, prob)
     b.fit(30, N.make_hyper(mask_cdist_form=0))
@@ -124,7 +134,7 @@ def test_mask_fit_loop_against_the_reference(dev_model, smpl_model, gmm_bufs):
     b.close()
     mask_x, terms_x = _end_state(dev_model, prob, N.pack_params(got_x))
     print("exact distances: end state", mask_x, terms_x.tolist())
-    assert mask_x == pytest.approx(mask_ref, rel=0.3) and float(terms_x.sum()) == pytest.approx(float(terms_ref.sum()), rel=0.3)
+    assert mask_x == pytest.approx(mask_ref, rel=mask_band) and float(terms_x.sum()) == pytest.approx(float(terms_ref.sum()), rel=terms_band)
     # keypoint-only prefix is exact: 11 steps == golden
     c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
     p = N.FrameBatch(dev_model, 1, 8)

@@ -102,7 +102,10 @@ def test_cfg2_fit_matches_reference(dev_model, smpl_model, frame):
     np.testing.assert_allclose(verts[0][::53], g["vertices_sample"], atol=FIT_TOL)
     np.testing.assert_allclose(full_pose[0], g["full_pose"], atol=FIT_TOL)
     p = N.split_params(b.get_params()[0])
-    np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=FIT_TOL)
+    # rtn_dict's global_transl = t * s (smplify.py:223): a derived quantity - an error dt of the fitted translation arrives as s dt
+    # (s ~ 3.3).  Frame 3's translation is the ill-conditioned one of the four: the float64 analytic oracle itself ends 1.7e-5 from
+    # the float32 reference there (6e-7 on frame 0)
+    np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=FIT_TOL * max(1.0, float(p["scale"][0])))
     b.close()
 
 
@@ -379,3 +382,102 @@ def test_untimed_submission_gives_the_same_fit(dev_model, smpl_model):
         np.testing.assert_array_equal(x, y)
     a.close()
     b.close()
+
+
+def _stream_case(dev_model, smpl_model, frames):
+    probs = [S.make_problem(smpl_model, frame=f, n_views=48) for f in frames]
+    packed = [N.pack_problem([p]) for p in probs]
+    return probs, packed
+
+
+def test_frames_streamed_back_to_back_hold_their_goldens(dev_model, smpl_model):
+    """The frame loop of apps/genebody_fitting.py:183-192 as the library runs it: frames 0..3 go through ONE batch back to back,
+    each frame's keypoints + initial estimate staged (bf_batch_stage_inputs) while the previous frame is still being fitted,
+    each result read (bf_batch_get_previous) while the next frame is being fitted.  Every frame lands on the reference's golden
+    (1e-4, the north-star tolerance) and on the bits of the same frame fitted alone."""
+    from bodyfitting_amd import _lib
+    flags = _lib.FIT_RESET | _lib.FIT_FETCH | _lib.FIT_NOTIME
+    frames = (0, 1, 2, 3)
+    probs, packed = _stream_case(dev_model, smpl_model, frames)
+    b = N.FrameBatch(dev_model, 1, 48)
+    b.set_cameras(packed[0][0], packed[0][1])               # the capture's cameras: shared by its frames
+    got = []
+    for i, (c2w, K, kp, ndiv, betas, pose) in enumerate(packed):
+        assert np.array_equal(c2w, packed[0][0])
+        b.stage_inputs(kp, ndiv, betas, pose)
+        b.fit(100, flags=flags)
+        if i > 0:
+            got.append(b.get_previous())
+    b.sync()
+    got.append((b.get_params(),) + b.get_result())
+    for f, (params, verts, joints, full_pose, terms) in zip(frames, got):
+        g = load_golden(f"cfg2_48view_100it_f{f}.npz")
+        p = N.split_params(params[0])
+        for k in PARAMS:
+            np.testing.assert_allclose(p[k], g[f"it100_{k}"], atol=FIT_TOL, err_msg=f"frame {f} {k}")
+        np.testing.assert_allclose(joints[0], g["joints"], atol=FIT_TOL)
+        np.testing.assert_allclose(verts[0][::53], g["vertices_sample"], atol=FIT_TOL)
+        np.testing.assert_allclose(full_pose[0], g["full_pose"], atol=FIT_TOL)
+        alone = _batch(dev_model, [probs[frames.index(f)]])
+        alone.fit(100)
+        assert np.array_equal(alone.get_params(), params), f"frame {f}: streamed fit differs from the frame fitted alone"
+        av, aj, _, _ = alone.get_result()
+        assert np.array_equal(av, verts) and np.array_equal(aj, joints)
+        alone.close()
+    b.close()
+
+
+@pytest.mark.parametrize("n_frames", [3, 32])
+def test_staging_while_a_fit_is_in_flight_never_touches_its_inputs(dev_model, smpl_model, n_frames):
+    """stage_inputs returns without draining the stream; the fit in flight must still see ITS frames (two input arenas), also for
+    a batch, and after eight alternations"""
+    from bodyfitting_amd import _lib
+    flags = _lib.FIT_RESET | _lib.FIT_FETCH | _lib.FIT_NOTIME
+    sets = [N.pack_problem([S.make_problem(smpl_model, frame=10 * s + f, n_views=48) for f in range(n_frames)]) for s in range(3)]
+    want = []
+    for c2w, K, kp, ndiv, betas, pose in sets:
+        ref = N.FrameBatch(dev_model, n_frames, 48)
+        ref.set_cameras(sets[0][0], sets[0][1]); ref.set_keypoints(kp, ndiv); ref.set_init(betas, pose)
+        ref.fit(100)
+        want.append(ref.get_params())
+        ref.close()
+    b = N.FrameBatch(dev_model, n_frames, 48)
+    b.set_cameras(sets[0][0], sets[0][1])
+    order = [0, 1, 2, 1, 0, 2, 2, 1]
+    seen = []
+    for i, s in enumerate(order):
+        _, _, kp, ndiv, betas, pose = sets[s]
+        b.stage_inputs(kp, ndiv, betas, pose)           # (issued while fit i-1 is running)
+        b.fit(100, flags=flags)
+        if i > 0:
+            seen.append(b.get_previous(vertices=False)[0])
+    seen.append(b.get_params())
+    for s, p in zip(order, seen):
+        assert np.array_equal(p, want[s])
+    # a staged frame needs a fresh start: continuing the previous frame's optimiser on new inputs is refused
+    b.stage_inputs(sets[0][2], sets[0][3], sets[0][4], sets[0][5])
+    with pytest.raises(_lib.BodyfitError, match="BF_FIT_RESET"):
+        b.fit(10, flags=_lib.FIT_FETCH)
+    b.fit(10, flags=flags)
+    # and the synchronous setters keep working on whichever arena is current
+    b.set_keypoints(sets[1][2], sets[1][3]); b.set_init(sets[1][4], sets[1][5])
+    b.fit(100)
+    assert np.array_equal(b.get_params(), want[1])
+    b.close()
+
+
+def test_smplify_stream_yields_the_frames_of_the_call_path(smpl_model, gmm):
+    """SMPLify.stream: the capture's frame loop as a generator (two-deep pipeline) == __call__ frame by frame, bit for bit"""
+    from bodyfitting_amd import assets
+    from bodyfitting_amd.smplify import SMPLify
+    assets.register_model(smpl_model, "smpl", "neutral")
+    assets.register_gmm(gmm)
+    fitter = SMPLify(smpl_type="smpl", num_iters=100, gender="neutral", device=0, debug=False)
+    probs = [S.make_problem(smpl_model, frame=f, n_views=48) for f in (2, 0, 3)]
+    streamed = list(fitter.stream((((p["init_betas"], p["init_pose"]), p["keypoints"]) for p in probs), probs[0]["c2ws"], probs[0]["Ks"]))
+    assert len(streamed) == 3
+    for p, res in zip(probs, streamed):
+        one = fitter((p["init_betas"], p["init_pose"]), p["c2ws"], p["Ks"], p["keypoints"], use_frames=p["use_frames"], imsize=512)
+        for key in ("vertices", "joints", "pose", "betas", "global_orient", "global_transl", "scale", "full_pose"):
+            assert np.array_equal(res[key], one[key]), key
+    fitter.close()

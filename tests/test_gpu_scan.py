@@ -284,8 +284,17 @@ def test_config5_iteration_counts_end_state_against_the_reference(small):
     its 300 steps are held to the reference by their END STATE: the distribution of point-to-scan distances and the icp /
     normal / laplacian terms of the displaced mesh within a stated fraction of the reference's, and clearly better than the
     undisplaced mesh."""
+    import ref_drift as RD
     model, dev = small
     g = load_golden("scan_nv690_300it.npz")
+    # the reference's own drift over the same 300 + 300 iterations (8 threads instead of 1; initial pose moved by one ulp)
+    sens = load_golden("sens_scan_nv690_300it.npz")
+    band = {k: RD.band(g, sens, [f"it{k}_{n}" for n in PARAMS]) for k in (100, 101, 300)}
+    print("bands = 3 x the reference's own drift:", band)
+
+    def rel_band(metric_of, ref_value, floor=0.05):
+        """K x how far the reference's perturbed runs end from the reference in this metric (relative), at least `floor`"""
+        return max(floor, RD.K * max(abs(metric_of(v) - ref_value) for v in RD.VARIANTS) / abs(ref_value))
     prob, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
     scan = N.Scan(sv, sf)
     c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
@@ -301,22 +310,28 @@ def test_config5_iteration_counts_end_state_against_the_reference(small):
         # the keypoint-only third and the first scan iteration hold the north-star tolerance (observed 7e-7); 199 more
         # iterations of the closest-point loss (the closest face of a vertex changes discretely, the reference's rule is not
         # even continuous on obtuse triangles) accumulate to 5e-3
-        assert drift < (1e-4 if k <= 101 else 2e-2), k
+        assert drift < band[k], (k, drift, band[k])
+    assert band[100] < 2e-4 and band[101] < 1e-3                   # (the keypoint-only third is well conditioned in the reference too)
     verts, joints, _, _ = b.get_result()
-    np.testing.assert_allclose(verts[0], g["vertices"], atol=2e-2)
-    np.testing.assert_allclose(joints[0], g["joints"], atol=2e-2)
+    np.testing.assert_allclose(verts[0], g["vertices"], atol=RD.band(g, sens, ["vertices"]))
+    np.testing.assert_allclose(joints[0], g["joints"], atol=RD.band(g, sens, ["joints"]))
     fit_ref = _disp_metrics(model, sv, sf, g["vertices"], 0 * g["vertices"])
     fit_got = _disp_metrics(model, sv, sf, verts[0], 0 * verts[0])
     print("scan loop end state  reference:", fit_ref, "\n                     HIP:      ", fit_got)
     # the closest-point term is ~10 % of the objective (keypoint terms ~2,400, 5 * imsize / height * icp ~270), so the distance
     # distribution is a soft quantity of the end state (held within a factor of two: rebuilds of the kernels that only changed an
     # fma contraction moved the mean between +16 % and +30 % of the reference's); the objective itself is held within 5 %
+    fit_var = {v: _disp_metrics(model, sv, sf, sens[f"{v}_vertices"], 0 * sens[f"{v}_vertices"]) for v in RD.VARIANTS}
+    print("                     reference, perturbed:", fit_var)
     for key in ("mean", "median", "p95", "icp"):
-        assert 0.5 < fit_got[key] / fit_ref[key] < 2.0, key
+        tol = rel_band(lambda v: fit_var[v][key], fit_ref[key])
+        assert abs(fit_got[key] - fit_ref[key]) / fit_ref[key] < tol, (key, fit_got[key], fit_ref[key], tol)
     w_pc = 5.0 * 512.0 / float(sv[:, 1].max() - sv[:, 1].min())
     params_got = b.get_params()
     obj = {}
-    for name, pk, icp in (("reference", N.pack_params({n: g[f"it300_{n}"] for n in PARAMS})[None], fit_ref["icp"]), ("HIP", params_got, fit_got["icp"])):
+    cases = [("reference", N.pack_params({n: g[f"it300_{n}"] for n in PARAMS})[None], fit_ref["icp"]), ("HIP", params_got, fit_got["icp"])]
+    cases += [(v, N.pack_params({n: sens[f"{v}_it300_{n}"] for n in PARAMS})[None], fit_var[v]["icp"]) for v in RD.VARIANTS]
+    for name, pk, icp in cases:
         probe = N.FrameBatch(dev, 1, 8)
         probe.set_cameras(c2w, K); probe.set_keypoints(kp, ndiv); probe.set_init(betas, pose); probe.set_scans([scan])   # (constant scale = height / 1.7)
         probe.set_params(pk)
@@ -325,16 +340,18 @@ def test_config5_iteration_counts_end_state_against_the_reference(small):
     print("objective after 300 iterations:", obj)
     # (Adam at lr 1e-2 does not settle: the reference's own objective moves between 2668 and 2768 over its last 12 iterations -
     #  oracle trace of the same loop - so two end states are "the same" within that band)
-    assert obj["HIP"] == pytest.approx(obj["reference"], rel=0.05)
+    assert obj["HIP"] == pytest.approx(obj["reference"], rel=rel_band(lambda v: obj[v], obj["reference"], floor=0.02))
     b.fit_displacement(300)
     disp = b.get_displacement()[0]
     want = _disp_metrics(model, sv, sf, g["vertices"], g["displacement"])
     before = _disp_metrics(model, sv, sf, g["vertices"], 0 * g["displacement"])
     got = _disp_metrics(model, sv, sf, verts[0], disp)
     print("SMPL+D end state  reference:", want, "\n                  HIP:      ", got, "\n                  before:   ", before)
-    for key in ("mean", "median", "p95", "icp", "laplacian"):
-        assert 0.5 < got[key] / want[key] < 2.0, key
-    assert got["normal"] == pytest.approx(want["normal"], abs=1e-3)
+    disp_var = {v: _disp_metrics(model, sv, sf, sens[f"{v}_vertices"], sens[f"{v}_displacement"]) for v in RD.VARIANTS}
+    print("                  reference, perturbed:", disp_var)
+    for key in ("mean", "median", "p95", "icp", "laplacian", "normal"):
+        tol = rel_band(lambda v: disp_var[v][key], want[key], floor=0.1)
+        assert abs(got[key] - want[key]) / abs(want[key]) < tol, (key, got[key], want[key], tol)
     assert got["mean"] < 0.6 * before["mean"] and got["median"] < 0.4 * before["median"]
     assert np.abs(disp).max() < 2 * np.abs(g["displacement"]).max()
     b.close()

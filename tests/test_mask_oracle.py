@@ -44,8 +44,15 @@ def test_mask_loss_and_gradient_match_reference(smpl_model):
     verts = golden_vertices(smpl_model, prob, g, torch.float64).requires_grad_(True)
     loss = O.multview_mask_loss(contours, masks, verts, w2cs, Ks, imsize=512)
     loss.backward()
-    # the reference evaluates torch.cdist's |a|^2+|b|^2-2ab form in fp32: ~1e-2 px noise per distance
-    assert float(loss) == np.float64(g["loss"]) * (1 + 0) or abs(float(loss) - float(g["loss"])) < 2e-5 * float(g["loss"])
+    # the reference evaluates torch.cdist's |a|^2+|b|^2-2ab form in fp32: ~1e-2 px noise per distance, which decides near-ties of
+    # the nearest-vertex choice; a flipped choice whose vertex lies across the silhouette border changes a 1 <-> 10 weight, i.e.
+    # ~10 px x the distance ~ 1e-5..1e-4 of the loss.  Exact float64 distances agree with it to that level ...
+    assert abs(float(loss) - float(g["loss"])) < 3e-4 * float(g["loss"])
+    # ... and the restatement evaluating torch.cdist literally, in float32 like the reference, reproduces its value
+    _, c32, m32, w32, K32 = mask_inputs(smpl_model, torch.float32)
+    v32 = golden_vertices(smpl_model, prob, g, torch.float32)
+    loss32 = O.multview_mask_loss(c32, m32, v32, w32, K32, imsize=512, pairwise="torch")
+    assert abs(float(loss32) - float(g["loss"])) < 2e-6 * float(g["loss"])
     got = verts.grad.numpy()[::4]
     err = np.abs(got - g["grad_sampled"])
     assert np.mean(err < 2e-3 * np.abs(g["grad_sampled"]).max()) > 0.995

@@ -184,8 +184,15 @@ def test_oracle_scan_fit_matches_reference_golden(small_model, gmm_bufs):
     # surface overshoot by ~lr = 5 cm, so round-off is amplified chaotically (fp32 vs fp64 of this very
     # code differ by 4e-2 after 11 steps, 0.35 after 30).  Only the first steps are a meaningful parity target.
     np.testing.assert_allclose(res["disp_snapshots"][1], g["disp1"], atol=1e-6)
+    # (how far the reference drifts from ITSELF over this stage is measured in tests/golden/sens_scan_nv690_300it.npz)
+    # after 11 steps the restatement is as far from the reference as the reference's own perturbed runs (8 threads, 1 ulp) are:
+    sens = load_golden("sens_scan_nv690_30it.npz")
     d11 = np.abs(res["disp_snapshots"][11] - g["disp11"])
-    assert np.mean(d11 < 1e-4) > 0.6
+    own = [np.abs(sens[f"{v}_disp11"] - g["disp11"]) for v in ("threads8", "ulp")]
+    print("SMPL+D step 11: |restatement - reference| median", np.median(d11), "p90", np.quantile(d11, 0.9),
+          "| reference vs itself: medians", [float(np.median(o)) for o in own], "p90", [float(np.quantile(o, 0.9)) for o in own])
+    assert np.median(d11) < max(1e-4, 3 * max(np.median(o) for o in own))
+    assert np.quantile(d11, 0.9) < max(1e-4, 3 * max(np.quantile(o, 0.9) for o in own))
 
 
 def test_intersect_tri2_degenerate_branches_known_answers():

@@ -72,3 +72,44 @@ def test_gather_world2_gloo(tmp_path, n_frames):
     want = _params(range(n_frames))
     for r in range(2):
         np.testing.assert_array_equal(np.load(tmp_path / f"r{r}.npy"), want)
+
+
+def test_contour_blocks_of_the_dense_setters_world2():
+    """bf_group_set_masks hands device s the masks of its frames and the contour points from xy_first[s] on
+    (bf_shard_contour_offsets - host arithmetic, the same call the group makes)."""
+    import ctypes as C
+    from bodyfitting_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    for n_frames, world, n_masks in ((7, 2, 4), (8, 2, 8), (64, 8, 8), (3, 2, 1)):
+        counts = rng.integers(0, 50, size=n_frames * n_masks).astype(np.int32)
+        out = (C.c_int64 * (world + 1))()
+        _lib.check(lib.bf_shard_contour_offsets(n_frames, world, n_masks, _lib.iptr(counts), out), "bf_shard_contour_offsets")
+        for s in range(world):
+            lo, hi = shard.shard_range(n_frames, s, world)
+            assert out[s] == counts[: lo * n_masks].sum()
+            assert out[s + 1] - out[s] == counts[lo * n_masks: hi * n_masks].sum()
+        assert out[world] == counts.sum()
+    bad = np.array([3, -1], np.int32)
+    assert lib.bf_shard_contour_offsets(2, 2, 1, _lib.iptr(bad), (C.c_int64 * 3)()) != 0
+
+
+def test_rendezvous_keys_separate_restarts_and_reused_names(tmp_path, monkeypatch):
+    """a restarted worker group (TORCHELASTIC_RESTART_COUNT) must not read the previous group's RCCL id; a barrier name used twice
+    does not pass on the first use's files; the directory is private and goes away with cleanup"""
+    monkeypatch.setenv("MASTER_PORT", "29999")
+    monkeypatch.setenv("TORCHELASTIC_RUN_ID", "job")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "0")
+    a = shard.FileRendezvous(0, 1, root=str(tmp_path))
+    a.broadcast("rccl-unique-id", b"old")
+    monkeypatch.setenv("TORCHELASTIC_RESTART_COUNT", "1")
+    b = shard.FileRendezvous(0, 1, root=str(tmp_path))
+    assert b.dir != a.dir and not os.path.exists(os.path.join(b.dir, "rccl-unique-id.0"))
+    assert (os.stat(b.dir).st_mode & 0o777) == 0o700
+    b.barrier("x"); b.barrier("x")
+    assert sorted(f for f in os.listdir(b.dir) if f.startswith("barrier-x")) == ["barrier-x-1.0", "barrier-x-2.0"]
+    b.cleanup()
+    assert not os.path.exists(b.dir)
+    os.chmod(a.dir, 0o755)
+    with pytest.raises(PermissionError):
+        shard.FileRendezvous(0, 1, key=os.path.basename(a.dir).split("-", 3)[3], root=str(tmp_path))
