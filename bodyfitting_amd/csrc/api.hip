@@ -374,6 +374,10 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
             for (int i = 0; i < d->n_lmk_static; ++i) face(d->lmk_faces_idx[i]);
             for (size_t i = 0; i < (size_t)d->n_dyn_rows * d->n_lmk_dynamic; ++i) face(d->dynamic_lmk_faces_idx[i]);
         }
+        // (the extra-joint regressor rows are gathered for the sub-model's vertices: every vertex that carries regressor weight
+        //  must be one of them, or the extra joints of the dense loop would be partial sums)
+        for (int e = 0; e < d->n_extra; ++e)
+            for (int v = 0; v < nv; ++v) if (d->j_regressor_extra[(size_t)e * nv + v] != 0.f) extra[v] = 1;
         for (int v = 0; v < nv; ++v) if (extra[v] && pos[v] < 0) { pos[v] = (int)S.size(); S.push_back(v); }
         const int sv = (int)S.size();
         if (sv * 10 <= nv * 6) {

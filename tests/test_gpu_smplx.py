@@ -228,3 +228,41 @@ def test_dense_fit_is_the_same_bits_run_to_run(sx):
     for p, v in runs[1:]:
         np.testing.assert_array_equal(p, runs[0][0])
         np.testing.assert_array_equal(v, runs[0][1])
+
+
+def test_sub_model_keeps_every_vertex_of_the_extra_regressor():
+    """An SMPL-X-kind model WITH a J_regressor_extra (the ABI allows it, models/smpl.py:62-64 is where SMPL gets its own): the dense
+    loop's sampled-first sub-model must contain every vertex that carries regressor weight, or the extra joints - here three of the
+    loss joints - would be formed from partial sums.  Sub-model on == off (float32 summation order apart)."""
+    import os
+    model = dict(S.make_model("smplx", seed=0))
+    nv = model["v_template"].shape[0]
+    rng = np.random.default_rng(11)
+    reg = np.zeros((3, nv), np.float32)
+    for r in range(3):
+        ids = rng.choice(np.arange(nv)[np.arange(nv) % 4 != 0], size=12, replace=False)      # vertices the silhouette sample does NOT contain
+        w = rng.uniform(0.2, 1.0, size=12)
+        reg[r, ids] = w / w.sum()
+    model["J_regressor_extra"] = reg
+    jm = np.asarray(model["joint_map"]).copy()
+    jm[jm >= 76] += 3                                  # all-joints layout: chain 55 | selector 21 | extra 3 | landmarks
+    jm[[1, 8, 15]] = [76, 77, 78]                      # three body loss joints now come from the extra regressor
+    model["joint_map"] = jm
+    dev = N.DeviceModel(model, S.make_gmm(seed=0), device=0)
+    prob = S.make_problem_smplx(S.make_model("smplx", seed=0), frame=0, n_views=8)
+    out = {}
+    for flag in ("1", "0"):
+        os.environ["BF_DENSE_SUBMODEL"] = flag
+        try:
+            b = _batch(dev, prob)
+            terms, grads = b.loss_grad()
+            b.fit(8)
+            out[flag] = (terms.copy(), grads.copy(), b.get_params().copy())
+            b.close()
+        finally:
+            del os.environ["BF_DENSE_SUBMODEL"]
+    assert np.abs(out["1"][1]).max() > 1.0
+    np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=2e-6)
+    np.testing.assert_allclose(out["1"][1], out["0"][1], atol=2e-5 * np.abs(out["0"][1]).max())
+    np.testing.assert_allclose(out["1"][2], out["0"][2], atol=2e-5)
+    dev.close()
