@@ -146,11 +146,17 @@ __device__ inline void sincos_small(float a, float *sn, float *cs) {
     *cs = ((q + 1) & 2) ? -c1 : c1;
 }
 
-// smplx batch_rodrigues for one joint
+// smplx batch_rodrigues for one joint: angle a = |theta + 1e-8|, axis n = theta / a,
+// R = I + sin(a) K(n) + (1 - cos(a)) K(n)^2.
+// rc = (sinc, cosc, d sinc / du, d cosc / du) at u = a^2, with sinc = sin a / a and cosc = (1 - cos a) / a^2: what the reverse pass
+// needs, in the form in which it needs no division (rodrigues_bwd).  [Measured: forming R itself from Taylor series of the four
+// functions - no sqrt, rcp or range reduction on the way - shortens the dependent chain but costs 46 fused multiply-adds per lane, and
+// the phase got 350 cycles LONGER; only the reverse pass keeps the division-free form.]
 __device__ inline void rodrigues_fwd(float tx, float ty, float tz, float *R, float *rc) {
     float ux = tx + 1e-8f, uy = ty + 1e-8f, uz = tz + 1e-8f;
     // (v_sqrt_f32 / v_rcp_f32, 1 ulp each: the correctly rounded forms cost ~25 more instructions on the critical path)
-    float a = __builtin_amdgcn_sqrtf(ux * ux + uy * uy + uz * uz);
+    const float u = ux * ux + uy * uy + uz * uz;
+    float a = __builtin_amdgcn_sqrtf(u);
     float ia = __builtin_amdgcn_rcpf(a);
     float nx = tx * ia, ny = ty * ia, nz = tz * ia;
     float s, c;
@@ -165,39 +171,35 @@ __device__ inline void rodrigues_fwd(float tx, float ty, float tz, float *R, flo
     R[6] = s * (-ny) + oc * (nx * nz);
     R[7] = s * nx + oc * (ny * nz);
     R[8] = 1.0f + oc * (-ny * ny - nx * nx);
-    rc[0] = a; rc[1] = s; rc[2] = c;
+    // (off the chain's critical path: stored by one wave, read in the reverse sweep)
+    const float iu = ia * ia, A = s * ia, B = oc * iu;
+    const bool tiny = u < 1.0e-3f;          // (c - A) and (A - 2 B) cancel there: two Taylor terms are exact to float32
+    rc[0] = A; rc[1] = B;
+    rc[2] = tiny ? fmaf(u, 1.6666667e-02f, -1.6666667e-01f) : (c - A) * (0.5f * iu);
+    rc[3] = tiny ? fmaf(u, 2.7777778e-03f, -4.1666667e-02f) : (A - 2.0f * B) * (0.5f * iu);
 }
 
-// reverse of rodrigues_fwd: G = dL/dR (row-major 3x3) -> dL/dtheta
+// reverse of rodrigues_fwd: G = dL/dR (row-major 3x3) -> dL/dtheta.
+//   dL/dtheta_k = sinc <G, dX/dtheta_k> + cosc <G, dY/dtheta_k> + (sinc' <G, X> + cosc' <G, Y>) du/dtheta_k
+// where R = I + sinc X + cosc Y, X = [theta]x, Y = theta theta^T - |theta|^2 I, u = |theta + 1e-8|^2 (the same matrix as the forward's),
+// with <G, dX/dtheta> = (G21 - G12, G02 - G20, G10 - G01), <G, dY/dtheta> = (G + G^T) theta - 2 tr(G) theta,
+// <G, X> = theta . <G, dX/dtheta>, <G, Y> = theta^T G theta - |theta|^2 tr(G), du/dtheta = 2 (theta + 1e-8).  No division anywhere:
+// theta = 0 (where the reference's own formula has angle = |1e-8|) is an ordinary point.
 __device__ inline void rodrigues_bwd(float tx, float ty, float tz, const float *rc, const float *G, float *gth) {
-    float a = rc[0], s = rc[1], c = rc[2], oc = 1.0f - c;
-    const float ia = __builtin_amdgcn_rcpf(a);
-    float n[3] = {tx * ia, ty * ia, tz * ia};
-    float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
-    float KK[9] = {-n[2] * n[2] - n[1] * n[1], n[0] * n[1], n[0] * n[2],
-                   n[0] * n[1], -n[2] * n[2] - n[0] * n[0], n[1] * n[2],
-                   n[0] * n[2], n[1] * n[2], -n[1] * n[1] - n[0] * n[0]};
-    float gk = 0.f, gkk = 0.f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { gk += G[i] * K[i]; gkk += G[i] * KK[i]; }
-    float da = c * gk + s * gkk;
-    // H = s G + (1-c) (G K^T + K^T G)
-    float H[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            float m = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) m += G[r * 3 + k] * K[q * 3 + k] + K[k * 3 + r] * G[k * 3 + q];
-            H[r * 3 + q] = s * G[r * 3 + q] + oc * m;
-        }
-    float dn0 = H[7] - H[5], dn1 = H[2] - H[6], dn2 = H[3] - H[1];
-    da -= (dn0 * tx + dn1 * ty + dn2 * tz) * (ia * ia);
-    float k = da * ia;
-    gth[0] = dn0 * ia + k * (tx + 1e-8f);
-    gth[1] = dn1 * ia + k * (ty + 1e-8f);
-    gth[2] = dn2 * ia + k * (tz + 1e-8f);
+    const float A = rc[0], B = rc[1], dA = rc[2], dB = rc[3];
+    const float x0 = G[7] - G[5], x1 = G[2] - G[6], x2 = G[3] - G[1];
+    const float tr = G[0] + G[4] + G[8];
+    const float s0 = (G[0] + G[0]) * tx + (G[1] + G[3]) * ty + (G[2] + G[6]) * tz;
+    const float s1 = (G[3] + G[1]) * tx + (G[4] + G[4]) * ty + (G[5] + G[7]) * tz;
+    const float s2 = (G[6] + G[2]) * tx + (G[7] + G[5]) * ty + (G[8] + G[8]) * tz;
+    const float tt = tx * tx + ty * ty + tz * tz;
+    const float gX = tx * x0 + ty * x1 + tz * x2;
+    const float gY = 0.5f * (tx * s0 + ty * s1 + tz * s2) - tt * tr;
+    const float k = 2.0f * (dA * gX + dB * gY);
+    const float tr2 = tr + tr;
+    gth[0] = A * x0 + B * (s0 - tr2 * tx) + k * (tx + 1e-8f);
+    gth[1] = A * x1 + B * (s1 - tr2 * ty) + k * (ty + 1e-8f);
+    gth[2] = A * x2 + B * (s2 - tr2 * tz) + k * (tz + 1e-8f);
 }
 
 
@@ -874,7 +876,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #endif
         // ================= phase A: forward chain (waves 0-2) | shaped selector verts (wave 3) | GMM (waves 4-7)
         if (wave < 3) {
-            float Ri[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rc[3], rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
+            float Ri[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, rc[4], rel0 = 0.f, rel1 = 0.f, rel2 = 0.f;
             float4 row = {0.f, 0.f, 0.f, 0.f};
             float jj0 = 0.f, jj1 = 0.f, jj2 = 0.f;
             const int wjq = bf_launder(wj);               // (this phase's LDS addresses are formed here, not kept across the loop)
@@ -898,7 +900,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #pragma unroll
                     for (int e = 0; e < 9; ++e) S.R[wjq * 9 + e] = Ri[e];
                 }
-                if (wave == 2) { S.rc[wjq * 4] = rc[0]; S.rc[wjq * 4 + 1] = rc[1]; S.rc[wjq * 4 + 2] = rc[2]; }
+                if (wave == 2) *(float4 *)(S.rc + wjq * 4) = make_float4(rc[0], rc[1], rc[2], rc[3]);
                 if (wave == 1 && wj > 0) {
                     float *f = S.feat + (wjq > 0 ? wjq - 1 : 0) * 9;
                     f[0] = Ri[0] - 1.f; f[1] = Ri[1]; f[2] = Ri[2]; f[3] = Ri[3]; f[4] = Ri[4] - 1.f;
@@ -1300,7 +1302,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #pragma unroll
             for (int e = 0; e < 9; ++e) df[e] = dfp[e];
             const float th0 = S.theta[tq * 3], th1 = S.theta[tq * 3 + 1], th2 = S.theta[tq * 3 + 2];
-            float rcl[3] = {S.rc[tq * 4], S.rc[tq * 4 + 1], S.rc[tq * 4 + 2]};
+            const float4 rc4 = *(const float4 *)(S.rc + tq * 4);
+            float rcl[4] = {rc4.x, rc4.y, rc4.z, rc4.w};
             const int pb0 = tq > 0 ? 3 * (tq - 1) : 0;                       // body-pose dof of the joint's first component
             const int pi0 = tq > 0 ? T.off_pose + pb0 : T.off_orient;        // its parameter index
             float pv[3], pm[3], pw[3], gq[BF_GMM_M];
@@ -1476,7 +1479,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #pragma unroll
             for (int e = 0; e < 9; ++e) df[e] = dfp[e];
             const float th0 = S.theta[tq * 3], th1 = S.theta[tq * 3 + 1], th2 = S.theta[tq * 3 + 2];
-            float rcl[3] = {S.rc[tq * 4], S.rc[tq * 4 + 1], S.rc[tq * 4 + 2]};
+            const float4 rc4 = *(const float4 *)(S.rc + tq * 4);
+            float rcl[4] = {rc4.x, rc4.y, rc4.z, rc4.w};
             __builtin_amdgcn_sched_barrier(0);
             float dRl[9], drl[3];
             if (tq == 0) {
