@@ -43,6 +43,64 @@ bf_tex_project_kernel(int nv, const float *__restrict__ verts, TexView V, float 
     pv[i * 3] = u; pv[i * 3 + 1] = w; pv[i * 3 + 2] = z;
 }
 
+// ---- the per-face / per-pixel arithmetic of the rasteriser, in this file's own terms ---------------------------------------------
+// (The VALUES follow neural_renderer's float32 operation order - rasterize_cuda_kernel.cu:38-63,110-137,209-240 - because a render has
+// to agree with it pixel for pixel: an edge test that rounds the other way hands a pixel to the neighbouring face.  This file is
+// compiled without fused multiply-adds for the same reason.)
+struct TexTri { float x[3], y[3], z[3]; };       // a face's corners: normalised device coordinates + depth
+
+__device__ __forceinline__ TexTri tex_tri(const float *f9) {
+    TexTri t;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { t.x[c] = f9[3 * c]; t.y[c] = f9[3 * c + 1]; t.z[c] = f9[3 * c + 2]; }
+    return t;
+}
+
+// the face shows its back when its signed area is negative: (c2 - c0) x (c1 - c0) compared as two products
+__device__ __forceinline__ bool tex_back_facing(const TexTri &t) {
+    return (t.y[2] - t.y[0]) * (t.x[1] - t.x[0]) < (t.y[1] - t.y[0]) * (t.x[2] - t.x[0]);
+}
+
+// A pixel centre (xp, yp) lies outside the face when it is on the wrong side of one of the three directed edges a -> b.
+__device__ __forceinline__ bool tex_outside(const TexTri &t, float xp, float yp) {
+    bool out = false;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int b = (a + 1) % 3;
+        out = out || (yp - t.y[a]) * (t.x[b] - t.x[a]) < (xp - t.x[a]) * (t.y[b] - t.y[a]);
+    }
+    return out;
+}
+
+// Rows of the inverse of [[x0 x1 x2], [y0 y1 y2], [1 1 1]] over pixel-space corners: row k gives corner k's barycentric weight as
+// a x + b y + c.  Row k is the cofactor row of the two OTHER corners taken cyclically, a = k + 1, b = k + 2.
+__device__ __forceinline__ void tex_barycentric_rows(const float px[3], const float py[3], float rows[9]) {
+    float cof[9];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int a = (k + 1) % 3, b = (k + 2) % 3;
+        cof[3 * k] = py[a] - py[b];
+        cof[3 * k + 1] = px[b] - px[a];
+        cof[3 * k + 2] = px[a] * py[b] - px[b] * py[a];
+    }
+    const float det = px[2] * cof[6] + px[0] * cof[0] + px[1] * cof[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) rows[k] = cof[k] / det;
+}
+
+// weights of pixel (xi, yi) clamped to [0, 1] and renormalised; returns the interpolated depth 1 / sum(w_k / z_k)
+__device__ __forceinline__ float tex_weights(const float rows[9], const TexTri &t, int xi, int yi, float w[3]) {
+    float total = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        w[k] = fminf(fmaxf(rows[3 * k] * xi + rows[3 * k + 1] * yi + rows[3 * k + 2], 0.f), 1.f);
+        total += w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[k] /= total;
+    return 1.f / (w[0] / t.z[0] + w[1] / t.z[1] + w[2] / t.z[2]);
+}
+
 // face record (BF_TEX_REC floats): nine projected coordinates (x0 y0 z0 x1 y1 z1 x2 y2 z2) | nine entries of the inverted
 // triangle | the pixel box that holds every pixel the face can own: x0 | x1 << 16, y0 | y1 << 16 (empty: x1 < x0)
 // pass 0: the record + count the tiles of the box; pass 1: write the face into their lists (cursor = running start)
@@ -59,25 +117,22 @@ bf_tex_face_kernel(int nf, const int *__restrict__ faces, const float *__restric
         f[c * 3] = v[0]; f[c * 3 + 1] = v[1]; f[c * 3 + 2] = v[2];
     }
     if (pass == 0) { rec[18] = __int_as_float(1); rec[19] = __int_as_float(1); }          // (empty box until shown otherwise)
-    if ((f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0])) return;            // back side: never drawn
-    float p[3][2];
+    const TexTri tri = tex_tri(f);
+    if (tex_back_facing(tri)) return;                                                      // never drawn
+    float px[3], py[3];                                                                    // corners in pixel units of the super-sampled image
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
-#pragma unroll
-        for (int d = 0; d < 2; ++d) p[n][d] = 0.5f * (f[3 * n + d] * is + is - 1);
+    for (int n = 0; n < 3; ++n) { px[n] = 0.5f * (tri.x[n] * is + is - 1); py[n] = 0.5f * (tri.y[n] * is + is - 1); }
     // pixels whose centre can pass the three edge tests lie inside the triangle's pixel-space bounding box (one pixel of slack)
-    const float xmin = fminf(p[0][0], fminf(p[1][0], p[2][0])), xmax = fmaxf(p[0][0], fmaxf(p[1][0], p[2][0]));
-    const float ymin = fminf(p[0][1], fminf(p[1][1], p[2][1])), ymax = fmaxf(p[0][1], fmaxf(p[1][1], p[2][1]));
+    const float xmin = fminf(px[0], fminf(px[1], px[2])), xmax = fmaxf(px[0], fmaxf(px[1], px[2]));
+    const float ymin = fminf(py[0], fminf(py[1], py[2])), ymax = fmaxf(py[0], fmaxf(py[1], py[2]));
     if (!(xmax >= -1.f && ymax >= -1.f && xmin <= (float)is && ymin <= (float)is)) return;       // (also drops NaN boxes)
     const int x0 = max((int)floorf(fmaxf(xmin, 0.f)) - 1, 0), x1 = min((int)ceilf(fminf(xmax, (float)is)) + 1, is - 1);
     const int y0 = max((int)floorf(fmaxf(ymin, 0.f)) - 1, 0), y1 = min((int)ceilf(fminf(ymax, (float)is)) + 1, is - 1);
     if (pass == 0) {
-        float inv[9] = {p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
-                        p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
-                        p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
-        const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]);
+        float rows[9];
+        tex_barycentric_rows(px, py, rows);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { rec[k] = f[k]; rec[9 + k] = inv[k] / den; }
+        for (int k = 0; k < 9; ++k) { rec[k] = f[k]; rec[9 + k] = rows[k]; }
         rec[18] = __int_as_float(x0 | (x1 << 16)); rec[19] = __int_as_float(y0 | (y1 << 16));
     }
     for (int ty = y0 / BF_TEX_TILE; ty <= y1 / BF_TEX_TILE; ++ty)
@@ -88,28 +143,24 @@ bf_tex_face_kernel(int nf, const int *__restrict__ faces, const float *__restric
         }
 }
 
-// texture sampling of one pixel (forward_texture_sampling, kernel.cu:205-250): the 8 corner indices and weights
+// Texture sampling of one pixel: position inside the face's ts^3 texture cube = barycentric weight x (ts - 1), perspective-corrected by
+// depth / corner depth and kept inside the cube; the colour is the trilinear blend of the 8 texels around it.  idx / wt: their
+// indices and weights, corner bit k set = the upper texel along axis k.
 __device__ __forceinline__ void tex_corners(const float w[3], float depth, const float *__restrict__ frec, int ts, int idx[8], float wt[8]) {
-    float tif[3];
+    int cell[3];
+    float hi[3], lo[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        float v = w[k] * (ts - 1) * (depth / frec[3 * k + 2]);
-        v = fmaxf(v, 0.f);
-        v = fminf(v, ts - 1 - 1e-4f);
-        tif[k] = v;
+        const float pos = fminf(fmaxf(w[k] * (ts - 1) * (depth / frec[3 * k + 2]), 0.f), ts - 1 - 1e-4f);
+        cell[k] = (int)pos;
+        hi[k] = pos - cell[k];
+        lo[k] = 1.f - hi[k];
     }
 #pragma unroll
-    for (int pn = 0; pn < 8; ++pn) {
-        float ww = 1.f;
-        int ti[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int fl = (int)tif[k];
-            if (((pn >> k) & 1) == 0) { ww *= 1.f - (tif[k] - fl); ti[k] = fl; }
-            else { ww *= tif[k] - fl; ti[k] = fl + 1; }
-        }
-        idx[pn] = ti[0] * ts * ts + ti[1] * ts + ti[2];
-        wt[pn] = ww;
+    for (int corner = 0; corner < 8; ++corner) {
+        const int u0 = corner & 1, u1 = (corner >> 1) & 1, u2 = corner >> 2;
+        idx[corner] = (cell[0] + u0) * ts * ts + (cell[1] + u1) * ts + (cell[2] + u2);
+        wt[corner] = (u0 ? hi[0] : lo[0]) * (u1 ? hi[1] : lo[1]) * (u2 ? hi[2] : lo[2]);
     }
 }
 
@@ -140,23 +191,12 @@ bf_tex_raster_kernel(int is, int tiles, const float *__restrict__ frec, const in
         }
         __builtin_amdgcn_wave_barrier();
         for (int j = 0; j < n; ++j) {
-            const float *face = s_f[wv][j], *inv = face + 9;
+            const float *face = s_f[wv][j];
             const int fn = __float_as_int(face[18]);
-            /* check [py, px] is inside the face */
-            if (((yp - face[1]) * (face[3] - face[0]) < (xp - face[0]) * (face[4] - face[1])) ||
-                ((yp - face[4]) * (face[6] - face[3]) < (xp - face[3]) * (face[7] - face[4])) ||
-                ((yp - face[7]) * (face[0] - face[6]) < (xp - face[6]) * (face[1] - face[7])))
-                continue;
+            const TexTri tri = tex_tri(face);
+            if (tex_outside(tri, xp, yp)) continue;
             float w[3];
-            w[0] = inv[0] * xi + inv[1] * yi + inv[2];
-            w[1] = inv[3] * xi + inv[4] * yi + inv[5];
-            w[2] = inv[6] * xi + inv[7] * yi + inv[8];
-            float wsum = 0.f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { w[k] = fminf(fmaxf(w[k], 0.f), 1.f); wsum += w[k]; }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) w[k] /= wsum;
-            const float zp = 1.f / (w[0] / face[2] + w[1] / face[5] + w[2] / face[8]);
+            const float zp = tex_weights(face + 9, tri, xi, yi, w);
             if (zp <= near || far <= zp) continue;
             if (zp < depth_min || (zp == depth_min && fmin >= 0 && fn < fmin)) {      // first strictly nearer face in face order
                 depth_min = zp; fmin = fn; wmin[0] = w[0]; wmin[1] = w[1]; wmin[2] = w[2];
@@ -173,9 +213,9 @@ bf_tex_raster_kernel(int is, int tiles, const float *__restrict__ frec, const in
         const float *tex = textures + (size_t)fmin * ts * ts * ts * 3;
         float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int pn = 0; pn < 8; ++pn)
+        for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) acc[k] += wt[pn] * (tex[idx[pn] * 3 + k] * 1.0f);      // (x 1: ambient light, lighting.py:33-37)
+            for (int k = 0; k < 3; ++k) acc[k] += wt[corner] * (tex[idx[corner] * 3 + k] * 1.0f);      // (x 1: ambient light, lighting.py:33-37)
         // forward_background: rgb * mask + (1 - mask) * background with mask = 1
         px[0] = acc[0] * 1.f + 0.f * bg0; px[1] = acc[1] * 1.f + 0.f * bg1; px[2] = acc[2] * 1.f + 0.f * bg2;
     }
@@ -246,9 +286,9 @@ bf_tex_backward_kernel(int nf, int is, int out, int aa, const float *__restrict_
             float wt[8];
             tex_corners(w, pp[3], rec, ts, idx, wt);
 #pragma unroll
-            for (int pn = 0; pn < 8; ++pn)
+            for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) atomicAdd(cube + idx[pn] * 3 + c, wt[pn] * g[c]);
+                for (int c = 0; c < 3; ++c) atomicAdd(cube + idx[corner] * 3 + c, wt[corner] * g[c]);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -277,9 +317,9 @@ bf_tex_backward_large_kernel(int is, int out, int aa, const float *__restrict__ 
     tex_corners(w, pp[3], rec, ts, idx, wt);
     float *gt = grad_tex + (size_t)fn * ts * ts * ts * 3;
 #pragma unroll
-    for (int pn = 0; pn < 8; ++pn)
+    for (int corner = 0; corner < 8; ++corner)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) atomicAdd(gt + idx[pn] * 3 + c, wt[pn] * g[c]);
+        for (int c = 0; c < 3; ++c) atomicAdd(gt + idx[corner] * 3 + c, wt[corner] * g[c]);
 }
 
 // torch.optim.Adam, single-tensor form
