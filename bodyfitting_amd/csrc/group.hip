@@ -144,7 +144,7 @@ struct bf_group {
 // fn(peer) on every device of the group, each from that device's own host thread, all running side by side; returns when every
 // one has returned, with the first failure (in device order) as this thread's error
 static int run_all(bf_group *g, const std::function<int(bf_group_peer &)> &fn) {
-    if (g->n == 1 || !g->peers[0].worker) {
+    if (!g->peers[0].worker) {
         for (auto &p : g->peers) { int rc = fn(p); if (rc) return rc; }
         return BF_OK;
     }
@@ -265,7 +265,9 @@ int bf_group_create(const bf_model_desc *desc, int n_devices, const int32_t *dev
         if (rc) { std::string keep = bf_err_slot(); bf_group_destroy(g); return fail(rc, keep); }
     }
     g->np = g->peers[0].model->np; g->nl = g->peers[0].model->nl_loss; g->nb = g->peers[0].model->nb;
-    if (n_devices > 1)
+    // (BF_GROUP_THREADS=1: a worker also for a one-device group - lets a 1-GPU box exercise the threaded issue path of N devices)
+    const char *force = std::getenv("BF_GROUP_THREADS");
+    if (n_devices > 1 || (force && force[0] == '1'))
         for (auto &p : g->peers) {
             p.worker = new bf_worker();
             bf_worker *w = p.worker;

@@ -68,14 +68,22 @@ def test_comm_world1_barrier_max_and_gather(dev_model, job, tmp_path):
     comm.close()
 
 
-def test_group_with_scans_and_masks_equals_a_plain_batch():
-    """bf_group_set_scans / set_masks / stage_inputs / fit_displacement hand every device its block and run the dense loops: with
+@pytest.mark.parametrize("threads", ["0", "1"])
+def test_group_with_scans_and_masks_equals_a_plain_batch(threads, monkeypatch):
+    """(threads = 1: the device's calls are issued from its worker thread, as in an N-device group - errors included)
+    bf_group_set_scans / set_masks / stage_inputs / fit_displacement hand every device its block and run the dense loops: with
     one device the results are a plain FrameBatch's, bit for bit (the same code path as N devices, each from its own host thread)"""
+    monkeypatch.setenv("BF_GROUP_THREADS", threads)
     model = S.make_model("smpl", seed=0, nv=690)
     gmm = S.make_gmm(seed=0)
     items = [S.make_scan_problem(model, frame=f, n_views=8) for f in range(3)]
     c2w, K, kp, ndiv, betas, pose = N.pack_problem([p for p, _, _ in items])
     g = shard.Group(model, gmm, n_frames=3, n_views=8, n_devices=1)
+    # an error raised on the worker thread reaches the caller with its message (staged inputs need a fresh start)
+    g.set_cameras(c2w, K); g.stage_inputs(kp, ndiv, betas, pose)
+    with pytest.raises(_lib.BodyfitError, match="BF_FIT_RESET"):
+        g.fit(5, flags=_lib.FIT_FETCH)
+    g.fit(5, flags=_lib.FIT_FETCH | _lib.FIT_RESET)
     assert [g.device_of_frame(f) for f in range(3)] == [0, 0, 0]
     g.set_cameras(c2w, K); g.set_keypoints(kp, ndiv); g.set_init(betas, pose)
     scans = [N.Scan(sv, sf, device=g.device_of_frame(f)) for f, (_, sv, sf) in enumerate(items)]
