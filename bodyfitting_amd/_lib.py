@@ -125,6 +125,7 @@ SIGNATURES = {
     "bf_texfit_destroy": (None, [_VP]),
     "bf_texfit_set_mesh": (C.c_int, [_VP, C.c_int, C.c_int, _FP, C.c_int, _IP, _FP]),
     "bf_texfit_render": (C.c_int, [_VP, C.c_int, _FP, _FP, _FP, C.c_float, _FP]),
+    "bf_texfit_render_ndc": (C.c_int, [_VP, C.c_int, _FP, C.c_int, _IP, _FP, _FP, _FP]),
     "bf_texfit_step": (C.c_int, [_VP, _FP, _FP, _FP, C.c_float, C.c_float, C.POINTER(C.c_double)]),
     "bf_texfit_loss_grad": (C.c_int, [_VP, _FP, _FP, _FP, C.c_float, C.POINTER(C.c_double), _FP]),
     "bf_texfit_get_textures": (C.c_int, [_VP, _FP]),

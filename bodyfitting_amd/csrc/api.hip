@@ -663,6 +663,7 @@ void bf_batch_destroy(bf_batch *b) {
         if (b->ev_copied[k]) (void)hipEventDestroy(b->ev_copied[k]);
     }
     if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
+    if (b->in_stream) { (void)hipStreamSynchronize(b->in_stream); (void)hipStreamDestroy(b->in_stream); }
     if (b->fit_stream) { (void)hipStreamSynchronize(b->fit_stream); (void)hipStreamDestroy(b->fit_stream); }
     for (auto &e : b->ev_door) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev_aux) if (e) (void)hipEventDestroy(e);
@@ -794,10 +795,15 @@ int bf_batch_stage_inputs(bf_batch *b, const float *keypoints, const int32_t *n_
         if (b->stage_mode == 3) {
             // the transfer on the batch's SECOND stream, under the fit in flight (the other arena is nobody's); the batch stream
             // only waits for its event - long complete when the next fit's turn comes
-            hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->copy_stream,
+            if (!b->in_stream) {            // (a stream of its own, highest priority: neither behind the fit nor behind the previous call's mesh tail)
+                int least = 0, greatest = 0;
+                HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIP_TRY(hipStreamCreateWithPriority(&b->in_stream, hipStreamNonBlocking, greatest));
+            }
+            hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->in_stream,
                                (const float4 *)h, (float4 *)b->in_dev[k].p, n4);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(b->ev_in[k], b->copy_stream));
+            HIP_TRY(hipEventRecord(b->ev_in[k], b->in_stream));
             HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_in[k], 0));
             b->in_pending[k] = true;
             bf_use_inputs(b, k, false);

@@ -132,6 +132,7 @@ struct bf_batch {
     size_t res_off[5] = {0, 0, 0, 0, 0}, res_cnt[5] = {0, 0, 0, 0, 0};   // params, terms, state, joints, vout
     int cur = 0;                    // arena the DevBuf views / h_* pointers are on
     hipStream_t copy_stream = nullptr;
+    hipStream_t in_stream = nullptr;      // BF_STAGE_MODE=aside: the input transfer's own stream
     // dense schedule with the fit kernel resident for the whole call (BfDoor, bf_internal.h)
     hipStream_t fit_stream = nullptr;
     hipEvent_t ev_aux[2] = {nullptr, nullptr};   // fork / join of the dense keypoint loss on the second stream

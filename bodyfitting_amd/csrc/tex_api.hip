@@ -7,6 +7,7 @@ extern "C" __global__ void bf_tex_face_kernel(int, const int *, const float *, i
 extern "C" __global__ void bf_tex_raster_kernel(int, int, const float *, const int *, const int *, const float *, int, float, float, float, float,
                                                 float, float *, float *, int);
 extern "C" __global__ void bf_tex_compose_kernel(int, int, const float *, float *);
+extern "C" __global__ void bf_tex_depth_kernel(int, int, const float *, float *);
 extern "C" __global__ void bf_tex_loss_kernel(int, const float *, const float *, float *, double *);
 extern "C" __global__ void bf_tex_backward_kernel(int, int, int, int, const float *, const float *, int, const float *, float *);
 extern "C" __global__ void bf_tex_backward_large_kernel(int, int, int, const float *, const float *, int, const float *, float *);
@@ -34,8 +35,8 @@ struct bf_texfit {
     int device = 0, out = 0, is = 0, tiles = 0, ts = 0, aa = 1, steps = 0;
     float near = 0.f, far = 100.f, bg[3] = {1.f, 1.f, 1.f};
     hipStream_t stream = nullptr;
-    bf_texmesh mesh[2];
-    DevBuf<float> image[2], grad_image;
+    bf_texmesh mesh[3];               // 0 = target, 1 = fitted, 2 = scratch of bf_texfit_render_ndc
+    DevBuf<float> image[3], grad_image, depth_image;
     DevBuf<double> partial;
     double *h_partial = nullptr;      // pinned copy of the loss partials
 };
@@ -130,7 +131,7 @@ void bf_texfit_destroy(bf_texfit *x) {
     if (!x) return;
     (void)hipSetDevice(x->device);
     if (x->stream) { (void)hipStreamSynchronize(x->stream); (void)hipStreamDestroy(x->stream); }
-    x->mesh[0].release(); x->mesh[1].release();
+    x->mesh[0].release(); x->mesh[1].release(); x->mesh[2].release();
     if (x->h_partial) (void)hipHostFree(x->h_partial);
     delete x;
 }
@@ -148,7 +149,8 @@ int bf_texfit_create(int device, int image_size, int texture_size, float near, f
     if (background) std::memcpy(x->bg, background, sizeof x->bg);
     const size_t n = (size_t)3 * image_size * image_size;
     bool ok = hipStreamCreateWithFlags(&x->stream, hipStreamNonBlocking) == hipSuccess && x->image[0].alloc(n) == hipSuccess &&
-              x->image[1].alloc(n) == hipSuccess && x->grad_image.alloc(n) == hipSuccess && x->partial.alloc((n + 255) / 256) == hipSuccess &&
+              x->image[1].alloc(n) == hipSuccess && x->image[2].alloc(n) == hipSuccess && x->depth_image.alloc(n / 3) == hipSuccess &&
+              x->grad_image.alloc(n) == hipSuccess && x->partial.alloc((n + 255) / 256) == hipSuccess &&
               hipHostMalloc((void **)&x->h_partial, ((n + 255) / 256) * sizeof(double)) == hipSuccess;
     if (!ok) { bf_texfit_destroy(x); return fail(BF_ERR_HIP, "bf_texfit_create: device allocation failed"); }
     *out = x;
@@ -157,8 +159,15 @@ int bf_texfit_create(int device, int image_size, int texture_size, float near, f
 
 // which: 0 = the target (the textured scan), 1 = the mesh whose textures are fitted (SMPL+D).  textures[nf][ts][ts][ts][3]
 // (neural_renderer's per-face texture cubes, load_obj.py / load_textures).  Setting mesh 1 resets the Adam state.
+static int tex_set_mesh(bf_texfit *x, int which, int n_verts, const float *verts, int n_faces, const int32_t *faces, const float *textures);
+
 int bf_texfit_set_mesh(bf_texfit *x, int which, int n_verts, const float *verts, int n_faces, const int32_t *faces, const float *textures) {
-    if (!x || which < 0 || which > 1 || n_verts <= 0 || n_faces <= 0 || !verts || !faces || !textures)
+    if (!x || which < 0 || which > 1) return fail(BF_ERR_INVALID, "bf_texfit_set_mesh: bad argument");
+    return tex_set_mesh(x, which, n_verts, verts, n_faces, faces, textures);
+}
+
+static int tex_set_mesh(bf_texfit *x, int which, int n_verts, const float *verts, int n_faces, const int32_t *faces, const float *textures) {
+    if (!x || n_verts <= 0 || n_faces <= 0 || !verts || !faces || !textures)
         return fail(BF_ERR_INVALID, "bf_texfit_set_mesh: bad argument");
     for (int i = 0; i < n_faces * 3; ++i)
         if (faces[i] < 0 || faces[i] >= n_verts) return fail(BF_ERR_INVALID, "bf_texfit_set_mesh: face index out of range");
@@ -184,6 +193,34 @@ int bf_texfit_set_mesh(bf_texfit *x, int which, int n_verts, const float *verts,
         x->steps = 0;
     }
     return BF_OK;
+}
+
+// Renderer.render_texture (neural_renderer/renderer.py:294-346: nr.rasterize_rgbad on faces that are already in normalised device
+// coordinates - the OBJ's `vt` lines mapped to [-1, 1], z = 1) = what render_texture_map (smplify/texture_fitting.py:149-151,298)
+// turns into the UV-space texture image smpl.png.  ndc[n_verts][3], faces[n_faces][3], textures[n_faces][ts][ts][ts][3] ->
+// rgb[3][image_size][image_size], depth[image_size][image_size] (far where nothing was drawn); either output may be NULL.
+// No projection: the vertices go to the rasteriser as they are.
+int bf_texfit_render_ndc(bf_texfit *x, int n_verts, const float *ndc, int n_faces, const int32_t *faces, const float *textures, float *rgb, float *depth) {
+    if (!x) return fail(BF_ERR_INVALID, "bf_texfit_render_ndc: null handle");
+    int rc = tex_set_mesh(x, 2, n_verts, ndc, n_faces, faces, textures);
+    if (rc) return rc;
+    TexView V{};
+    V.orig = -1.f;                                    // (bf_tex_project_kernel: pass the vertices through)
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        rc = tex_render(x, 2, V);
+        if (rc) return rc;
+        hipLaunchKernelGGL(bf_tex_depth_kernel, dim3((x->out * x->out + 255) / 256), dim3(256), 0, x->stream, x->out, x->aa,
+                           (const float *)x->mesh[2].pix.p, x->depth_image.p);
+        HIP_TRY(hipGetLastError());
+        if (rgb) HIP_TRY(hipMemcpyAsync(rgb, x->image[2].p, x->image[2].n * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+        if (depth) HIP_TRY(hipMemcpyAsync(depth, x->depth_image.p, x->depth_image.n * sizeof(float), hipMemcpyDeviceToHost, x->stream));
+        HIP_TRY(hipStreamSynchronize(x->stream));
+        bool fit = true;
+        rc = tex_lists_fit(x, 2, &fit);
+        if (rc) return rc;
+        if (fit) { x->mesh[2].release(); return BF_OK; }
+    }
+    return fail(BF_ERR_HIP, "bf_texfit_render_ndc: the tile lists keep overflowing");
 }
 
 // Renderer.render_rgb (neural_renderer/renderer.py:174-232, camera_mode='projection', ambient light 1, fill_back=False):

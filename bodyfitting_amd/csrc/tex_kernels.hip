@@ -30,6 +30,7 @@ bf_tex_project_kernel(int nv, const float *__restrict__ verts, TexView V, float 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nv) return;
     const float a = verts[i * 3], b = verts[i * 3 + 1], c = verts[i * 3 + 2];
+    if (V.orig < 0.f) { pv[i * 3] = a; pv[i * 3 + 1] = b; pv[i * 3 + 2] = c; return; }      // already normalised device coordinates (UV-space render)
     // vertices @ R^T + t : (a R00 + b R01) + c R02, then + t  (row-vector times matrix, k ascending)
     const float x = ((a * V.R[0] + b * V.R[1]) + c * V.R[2]) + V.t[0];
     const float y = ((a * V.R[3] + b * V.R[4]) + c * V.R[5]) + V.t[1];
@@ -233,6 +234,16 @@ bf_tex_compose_kernel(int out, int aa, const float *__restrict__ rgb, float *__r
     const int is = aa ? out * 2 : out;
     auto at = [&](int yy, int xx) { return rgb[((size_t)(is - 1 - yy) * is + xx) * 3 + c]; };      // flipped row yy
     image[i] = aa ? (at(2 * y, 2 * x) + at(2 * y, 2 * x + 1) + at(2 * y + 1, 2 * x) + at(2 * y + 1, 2 * x + 1)) * 0.25f : at(y, x);
+}
+
+// depth[y][x] (out x out) from pix[is][is][5]'s depth (far where no face was drawn): the same flip and 2 x 2 mean as the colours
+extern "C" __global__ void __launch_bounds__(256)
+bf_tex_depth_kernel(int out, int aa, const float *__restrict__ pix, float *__restrict__ depth) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= out * out) return;
+    const int y = i / out, x = i - y * out, is = aa ? out * 2 : out;
+    auto at = [&](int yy, int xx) { return pix[((size_t)(is - 1 - yy) * is + xx) * 5 + 3]; };
+    depth[i] = aa ? (at(2 * y, 2 * x) + at(2 * y, 2 * x + 1) + at(2 * y + 1, 2 * x) + at(2 * y + 1, 2 * x + 1)) * 0.25f : at(y, x);
 }
 
 // partial[block] = sum |a - b| over the block's elements (fixed order inside a block; the host adds the blocks in order);

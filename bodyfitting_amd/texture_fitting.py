@@ -124,6 +124,25 @@ class Renderer:
                                               self.orig_size, _lib.fptr(out)), "bf_texfit_render")
         return out
 
+    def render_texture(self, uv, uv_faces, textures=None):
+        """`Renderer.render_texture(filename_obj, textures)` of neural_renderer (renderer.py:294-346) with the OBJ's contents as
+        arrays: uv[n,2] = its `vt` lines, uv_faces[NF,3] = the 0-based vt indices of its faces (same face order as the fitted
+        mesh), textures (default: the fitted mesh's current ones) -> (rgb[3, image_size, image_size], depth[image_size, image_size]).
+        The UV-space image of the fitted textures: every face is drawn at its UV triangle, front and back."""
+        t = self.textures() if textures is None else np.ascontiguousarray(textures, dtype=np.float32)
+        uv = np.asarray(uv, np.float64).reshape(-1, 2)
+        verts = np.ascontiguousarray(np.concatenate([uv * 2.0 - 1.0, np.ones((len(uv), 1))], 1), dtype=np.float32)      # :303-304
+        f = np.ascontiguousarray(np.asarray(uv_faces).reshape(-1, 3), dtype=np.int32)
+        if len(f) != len(t):
+            raise ValueError("one UV triangle per textured face")
+        faces = np.ascontiguousarray(np.concatenate([f, f[:, ::-1]], 0))                      # fill back (:338-339)
+        tex = np.ascontiguousarray(np.concatenate([t, t.transpose(0, 3, 2, 1, 4)], 0))       # textures.permute((0, 1, 4, 3, 2, 5)) (:340)
+        rgb = np.empty((3, self.image_size, self.image_size), np.float32)
+        depth = np.empty((self.image_size, self.image_size), np.float32)
+        _lib.check(self._lib.bf_texfit_render_ndc(self._h, len(verts), _lib.fptr(verts), len(faces), _lib.iptr(faces), _lib.fptr(tex),
+                                                  _lib.fptr(rgb), _lib.fptr(depth)), "bf_texfit_render_ndc")
+        return rgb, depth
+
     def step(self, pose, lr):
         """one iteration (:262-270) from this view -> the L1 loss before the step"""
         R, t = self._view(pose)
@@ -147,6 +166,18 @@ class Renderer:
         out = np.empty((n, ts, ts, ts, 3), np.float32)
         _lib.check(self._lib.bf_texfit_get_textures(self._h, _lib.fptr(out)), "bf_texfit_get_textures")
         return out
+
+
+def to8b(x):
+    """texture_fitting.py:41"""
+    return (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+def render_texture_map(renderer, uv, uv_faces, textures=None):
+    """`render_texture_map(renderer, objdir, textures)` (smplify/texture_fitting.py:149-171, morph=False as the loop calls it, :298):
+    the UV-space texture image as uint8 [H, W, 3] in the channel order the reference writes to smpl.png (BGR: its [:, :, ::-1])."""
+    rgb, _ = renderer.render_texture(uv, uv_faces, textures)
+    return to8b(rgb.transpose(1, 2, 0)[:, :, ::-1])
 
 
 class TextureFitting:

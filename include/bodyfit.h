@@ -325,8 +325,9 @@ int bf_comm_gather_params(bf_comm *c, bf_batch *b, int n_frames, float *params);
  * (Renderer.render_rgb, camera_mode='projection', ambient light only, anti-aliasing by 2 x 2 super-sampling), the loss is
  * sum |scan_img - smpl_img| and Adam steps the per-face texture cubes of the SMPL+D mesh; only the textures are differentiated.
  * The rasteriser, texture sampling and backward_textures of thirdparty/neural_renderer (cuda/rasterize_cuda_kernel.cu:24-252,
- * 498-540) are restated as HIP kernels; file formats (OBJ / MTL / texture images), the inpainting CNN and the UV-space texture
- * image of :281-289 are out of scope. */
+ * 498-540) are restated as HIP kernels; the UV-space texture image of :298 is bf_texfit_render_ndc;
+ * file formats (OBJ / MTL / texture images), the inpainting CNN and the cv2 morphology of render_texture_map's `morph` branch are
+ * out of scope. */
 typedef struct bf_texfit bf_texfit;
 int bf_texfit_create(int device, int image_size, int texture_size, float near, float far, const float *background /*[3] or NULL = white*/,
                      int anti_aliasing, bf_texfit **out);
@@ -335,6 +336,12 @@ void bf_texfit_destroy(bf_texfit *x);
 int bf_texfit_set_mesh(bf_texfit *x, int which, int n_verts, const float *verts, int n_faces, const int32_t *faces, const float *textures);
 /* Renderer.render_rgb: R[9], t[3] (world to camera), K[9], orig_size -> rgb[3][image_size][image_size] */
 int bf_texfit_render(bf_texfit *x, int which, const float *R, const float *t, const float *K, float orig_size, float *rgb);
+/* Renderer.render_texture (thirdparty/neural_renderer/neural_renderer/renderer.py:294-346), the rasteriser behind render_texture_map
+ * (smplify/texture_fitting.py:149-151) and the UV-space texture image smpl.png (:298): a mesh whose vertices ndc[n_verts][3] are
+ * ALREADY normalised device coordinates (the OBJ's vt lines mapped to [-1, 1], z = 1; the caller appends the reversed faces with
+ * their cube axes swapped, renderer.py:338-340) is rasterised without projection -> rgb[3][image_size][image_size],
+ * depth[image_size][image_size] (far where nothing was drawn); either may be NULL. */
+int bf_texfit_render_ndc(bf_texfit *x, int n_verts, const float *ndc, int n_faces, const int32_t *faces, const float *textures, float *rgb, float *depth);
 /* one iteration (:262-270) from this view; *loss (may be NULL) = the loss before the step */
 int bf_texfit_step(bf_texfit *x, const float *R, const float *t, const float *K, float orig_size, float lr, double *loss);
 /* loss and d loss / d textures [n_faces][ts][ts][ts][3] of the fitted mesh from this view, without a step */

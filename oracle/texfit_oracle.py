@@ -176,6 +176,37 @@ def render(verts, faces, textures, K, R, t, orig_size, image_size, near, far, ba
     return np.ascontiguousarray(img, F32)
 
 
+def uv_mesh(uv, uv_faces, textures):
+    """What Renderer.render_texture (renderer.py:294-340) builds from an OBJ's `vt` lines and `f v/vt` indices: vertices
+    (2u - 1, 2v - 1, 1), the faces followed by the same faces with their corners reversed ("fill back"), the textures followed by
+    the same cubes with axes 0 and 2 swapped (textures.permute((0, 1, 4, 3, 2, 5)))."""
+    uv = np.asarray(uv, np.float64).reshape(-1, 2)
+    verts = np.concatenate([uv * 2.0 - 1.0, np.ones((len(uv), 1))], 1).astype(F32)          # (python floats, then astype(float32): :303-304)
+    f = np.asarray(uv_faces, np.int32).reshape(-1, 3)
+    t = np.asarray(textures, F32)
+    return verts, np.concatenate([f, f[:, ::-1]], 0), np.concatenate([t, t.transpose(0, 3, 2, 1, 4)], 0)
+
+
+def render_texture(uv, uv_faces, textures, image_size, near, far, background=(1, 1, 1), anti_aliasing=True):
+    """Renderer.render_texture -> nr.rasterize_rgbad (rasterize.py:254-330) on vertices that are already normalised device
+    coordinates: -> (rgb[3, is, is], depth[is, is]); render_texture_map (texture_fitting.py:149-151) keeps the rgb part."""
+    verts, faces, tex = uv_mesh(uv, uv_faces, textures)
+    fv = verts[faces.astype(np.int64)]
+    is2 = image_size * 2 if anti_aliasing else image_size
+    fi, w, d = rasterize(fv, is2, near, far)
+    rgb, _, _ = sample_textures(fv, tex, fi, w, d)
+    mask = (fi >= 0).astype(F32)[:, :, None]
+    rgb = (rgb * mask + (F32(1) - mask) * np.asarray(background, F32)[None, None, :]).astype(F32)
+    img = rgb.transpose(2, 0, 1)[:, ::-1, :]
+    dep = d[::-1, :]
+    if anti_aliasing:
+        img = img.reshape(3, image_size, 2, image_size, 2).astype(F32)
+        img = ((img[:, :, 0, :, 0] + img[:, :, 0, :, 1] + img[:, :, 1, :, 0] + img[:, :, 1, :, 1]) * F32(0.25)).astype(F32)
+        dep = dep.reshape(image_size, 2, image_size, 2).astype(F32)
+        dep = ((dep[:, 0, :, 0] + dep[:, 0, :, 1] + dep[:, 1, :, 0] + dep[:, 1, :, 1]) * F32(0.25)).astype(F32)
+    return np.ascontiguousarray(img, F32), np.ascontiguousarray(dep, F32)
+
+
 def texture_grad(grad_img, keep, n_faces, ts, image_size, anti_aliasing=True):
     """dL/dtextures from dL/d(rendered image)[3,is,is]: pooling, flip, background mask, backward_textures (kernel.cu:498-540)"""
     is2 = keep["is2"]

@@ -143,3 +143,34 @@ def test_adam_update_is_torch_adam():
         fit.adam(g)
         np.testing.assert_allclose(fit.mesh[2], tp.detach().numpy(), atol=2e-7, rtol=0)
     assert np.abs(fit.mesh[2] - p0).max() > 0.03
+
+
+def test_uv_texture_image_known_answers():
+    """render_texture / render_texture_map (neural_renderer/renderer.py:294-346, texture_fitting.py:149-151): every face drawn at its
+    UV triangle, front and back.  Constant-colour cubes: a pixel inside a face's UV triangle shows that face's colour whichever way
+    the triangle is wound (fill back), the gaps show the background, depth is 1 on the faces and `far` elsewhere."""
+    from texfit_cases import uv_atlas
+    rng = np.random.default_rng(3)
+    nf, ts, size = 6, 3, 24
+    uv, uvf = uv_atlas(nf, cols=3)
+    colours = rng.uniform(0.1, 0.9, (nf, 3)).astype(np.float32)
+    tex = np.broadcast_to(colours[:, None, None, None, :], (nf, ts, ts, ts, 3)).copy()
+    rgb, depth = TO.render_texture(uv, uvf, tex, size, near=0.0, far=5.0, background=(1, 1, 1), anti_aliasing=False)
+    assert rgb.shape == (3, size, size) and depth.shape == (size, size)
+    for i in range(nf):
+        c = uv[3 * i:3 * i + 3].mean(0)                          # centroid of the UV triangle, in [0, 1]^2
+        x, y = int(c[0] * size), size - 1 - int(c[1] * size)     # image row 0 is the top (vertical flip, rasterize.py:304-315)
+        np.testing.assert_allclose(rgb[:, y, x], colours[i], atol=1e-6, err_msg=f"face {i}")
+        assert abs(depth[y, x] - 1.0) < 1e-6                     # (1 / (w0 + w1 + w2) in float32)
+    assert (depth == 5.0).any() and np.all(rgb[:, depth == 5.0] == 1.0)
+    # an asymmetric cube: the back side samples the cube with axes 0 and 2 swapped - for a wound-the-other-way triangle that is
+    # the same texel as the front side of the un-reversed one
+    tex2 = rng.uniform(0, 1, (nf, ts, ts, ts, 3)).astype(np.float32)
+    a, _ = TO.render_texture(uv, uvf, tex2, size, 0.0, 5.0, anti_aliasing=False)
+    b, _ = TO.render_texture(uv, uvf[:, ::-1], tex2.transpose(0, 3, 2, 1, 4), size, 0.0, 5.0, anti_aliasing=False)
+    np.testing.assert_array_equal(a, b)
+    # anti-aliasing = the mean of the 2 x 2 block of the double-size render
+    big, _ = TO.render_texture(uv, uvf, tex2, 2 * size, 0.0, 5.0, anti_aliasing=False)
+    aa, _ = TO.render_texture(uv, uvf, tex2, size, 0.0, 5.0, anti_aliasing=True)
+    want = big.reshape(3, size, 2, size, 2)
+    np.testing.assert_allclose(aa, (want[:, :, 0, :, 0] + want[:, :, 0, :, 1] + want[:, :, 1, :, 0] + want[:, :, 1, :, 1]) * 0.25, atol=1e-7)

@@ -39,3 +39,21 @@ def blob_pair(level=2, ts=4, seed=0, wind=1):
     fit_v = (scan_v + 0.01 * rng.standard_normal(scan_v.shape)).astype(np.float32)
     fit_t = np.full((len(f), ts, ts, ts, 3), 0.5, np.float32)
     return (scan_v, f, scan_t), (fit_v, f, fit_t)
+
+
+def uv_atlas(n_faces, cols=None, margin=0.08, seed=0):
+    """A UV layout for a mesh of n_faces triangles, the way an OBJ's `vt` / `f v/vt` lines give it: every face its own triangle in a
+    grid cell of the unit square (half of them wound the other way, so front and back sides both occur).
+    -> (uv[3 n_faces, 2] in [0, 1], uv_faces[n_faces, 3] 0-based)"""
+    rng = np.random.default_rng(seed)
+    cols = cols or int(np.ceil(np.sqrt(n_faces)))
+    rows = int(np.ceil(n_faces / cols))
+    uv = np.zeros((3 * n_faces, 2))
+    for i in range(n_faces):
+        cx, cy = i % cols, i // cols
+        x0, y0, w, h = cx / cols, cy / rows, 1.0 / cols, 1.0 / rows
+        tri = np.array([[margin, margin], [1 - margin, margin + 0.1 * rng.uniform()], [margin + 0.2 * rng.uniform(), 1 - margin]])
+        if i % 2:
+            tri = tri[::-1]
+        uv[3 * i:3 * i + 3] = [x0, y0] + tri * [w, h]
+    return np.round(uv, 6), np.arange(3 * n_faces, dtype=np.int32).reshape(-1, 3)
