@@ -736,6 +736,7 @@ static int reset_adam(bf_batch *b, const float *params_host) {
     b->steps_done = 0;
     b->have_result = false;
     b->fetched = false;
+    b->staged = false;             // (a fresh start from these parameters: what BF_FIT_RESET would do for staged inputs)
     return BF_OK;
 }
 

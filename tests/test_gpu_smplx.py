@@ -266,3 +266,31 @@ def test_sub_model_keeps_every_vertex_of_the_extra_regressor():
     np.testing.assert_allclose(out["1"][1], out["0"][1], atol=2e-5 * np.abs(out["0"][1]).max())
     np.testing.assert_allclose(out["1"][2], out["0"][2], atol=2e-5)
     dev.close()
+
+
+def test_staged_inputs_on_the_dense_path(sx):
+    """bf_batch_stage_inputs with an SMPL-X batch (135 loss joints: the keypoint loss is a dense kernel, the fit kernel is resident and
+    paced by doorbells): frames staged back to back == the same frames through the synchronous setters, bit for bit; views the
+    staged frame does not see (confidence 0) and a per-frame divisor travel with it"""
+    from bodyfitting_amd import _lib
+    model, dev = sx
+    probs = [S.make_problem_smplx(model, frame=f, n_views=8) for f in (0, 1, 2)]
+    packed = [N.pack_problem([p]) for p in probs]
+    packed[1][2][0, 3] = 0.0                                   # frame 1: view 3 without a detection ...
+    nd1 = np.array([7], np.int32)                              # ... and the divisor the reference would use (len(use_frames), loss.py:197)
+    want = []
+    for i, (c2w, K, kp, ndiv, betas, pose) in enumerate(packed):
+        b = N.FrameBatch(dev, 1, 8)
+        b.set_cameras(packed[0][0], packed[0][1]); b.set_keypoints(kp, nd1 if i == 1 else ndiv); b.set_init(betas, pose)
+        b.fit(12)
+        want.append((b.get_params().copy(), b.get_result()[0].copy()))
+        b.close()
+    b = N.FrameBatch(dev, 1, 8)
+    b.set_cameras(packed[0][0], packed[0][1])
+    for i in (0, 1, 2, 1):
+        _, _, kp, ndiv, betas, pose = packed[i]
+        b.stage_inputs(kp, nd1 if i == 1 else ndiv, betas, pose)
+        b.fit(12, flags=_lib.FIT_RESET | _lib.FIT_FETCH)
+        np.testing.assert_array_equal(b.get_params(), want[i][0])
+        np.testing.assert_array_equal(b.get_result()[0], want[i][1])
+    b.close()
