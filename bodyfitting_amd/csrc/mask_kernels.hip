@@ -212,23 +212,25 @@ __device__ int contour_follow(ContourPlanes &P, int x0, int y0, float *out, int 
 }
 }  // namespace
 
-// grid (n_masks), 64 threads.  masks[n][H][W] (non-zero = foreground) -> count[n] = length of the kept contour (also when it
+// grid (n_masks), 256 threads: four waves build the bit planes, wave 0 then follows the borders alone.
+// masks[n][H][W] (non-zero = foreground) -> count[n] = length of the kept contour (also when it
 // exceeds cap: the caller retries with more room), count[n + m] = which half of xy[m][2][cap][2] holds its points (x, y).  planes_global: 3 * H * wpr words per mask,
 // or null when the planes fit the dynamic LDS given to the launch.
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(256)
 bf_contour_kernel(const unsigned char *__restrict__ masks, int H, int W, int cap, int select, float *__restrict__ xy, int *__restrict__ count,
                   unsigned *planes_global) {
     extern __shared__ unsigned s_planes[];
-    const int m = blockIdx.x, lane = threadIdx.x;
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     ContourPlanes P;
     P.H = H; P.W = W; P.wpr = (W + 31) >> 5;
     const int plane = H * P.wpr;
     P.fg = planes_global ? planes_global + (size_t)m * 3 * plane : s_planes;
     P.mk = P.fg + plane; P.ng = P.mk + plane;
     const unsigned char *img = masks + (size_t)m * H * W;
-    // bit planes: 64 consecutive pixels per step, one coalesced byte load per lane, the ballot is two finished words
+    // bit planes: 64 consecutive pixels per step, one coalesced byte load per lane, the ballot is two finished words; the steps are
+    // dealt out over the four waves (the loop is a chain of load -> ballot -> store round trips: 1,024 of them for 512 x 512 on one wave)
     const int chunks = (W + 63) >> 6;
-    for (int it = 0; it < H * chunks; it += 4) {
+    for (int it = wave * 4; it < H * chunks; it += 16) {
         unsigned long long bits[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -244,7 +246,9 @@ bf_contour_kernel(const unsigned char *__restrict__ masks, int H, int W, int cap
             }
         }
     }
+    __threadfence_block();                 // (the planes of a large image live in global memory: the other waves' words, before wave 0 reads them)
     __syncthreads();
+    if (wave != 0) return;
     // from here on every lane runs the same scalar program (one wave: lock-step, LDS accesses in program order)
     // Outer-border starts are rare (one per component, plus the skipped ones next to holes), so the words are screened 64
     // at a time - lane l looks at word base + l - and only a word with a start is handled, serially.  A walk changes marks,

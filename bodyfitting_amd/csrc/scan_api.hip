@@ -609,7 +609,7 @@ static int contours_on_device(const unsigned char *d_bin, int n, int H, int W, i
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (d_xy.p) { (void)hipFree(d_xy.p); d_xy.p = nullptr; }
         HIP_TRY(d_xy.alloc((size_t)n * 2 * cap * 2));
-        hipLaunchKernelGGL(bf_contour_kernel, dim3(n), dim3(64), in_lds ? plane_bytes : 0, 0, d_bin, H, W, cap, select, d_xy.p, d_cnt.p,
+        hipLaunchKernelGGL(bf_contour_kernel, dim3(n), dim3(256), in_lds ? plane_bytes : 0, 0, d_bin, H, W, cap, select, d_xy.p, d_cnt.p,
                            in_lds ? (unsigned *)nullptr : planes.p);
         HIP_TRY(hipGetLastError());
         std::vector<int> both(2 * (size_t)n);
@@ -656,11 +656,19 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     const int F = b->F, nv = b->m->nv;
     for (int i = 0; i < n_masks; ++i)
         if (view_index[i] < 0 || view_index[i] >= b->V) return fail(BF_ERR_INVALID, "bf_batch_set_masks: view index out of range");
-    std::vector<unsigned char> bin((size_t)F * n_masks * H * W);
-    for (size_t i = 0; i < bin.size(); ++i) bin[i] = masks[i] > 128 ? 1 : 0;                 // smplify.py:139
-    auto refresh = [](auto &buf) { if (buf.p) { (void)hipFree((void *)buf.p); buf.p = nullptr; } };
-    refresh(b->mk_masks);
-    HIP_TRY(b->mk_masks.upload(bin));
+    // (a frame loop hands over new masks of the same shape every frame: device buffers are kept and only grown - a dozen hipFree /
+    //  hipMalloc pairs cost more than the contour extraction itself)
+    auto ensure = [](auto &buf, size_t count) -> hipError_t {
+        if (buf.p && buf.n >= count && !buf.view) return hipSuccess;
+        if (buf.p && !buf.view) (void)hipFree((void *)buf.p);
+        buf.p = nullptr;
+        return buf.alloc(count);
+    };
+    const size_t npix = (size_t)F * n_masks * H * W;
+    std::vector<unsigned char> bin(npix);
+    for (size_t i = 0; i < npix; ++i) bin[i] = masks[i] > 128;                                 // smplify.py:139
+    HIP_TRY(ensure(b->mk_masks, npix));
+    HIP_TRY(hipMemcpy(b->mk_masks.p, bin.data(), npix, hipMemcpyHostToDevice));
     std::vector<int> start((size_t)F * n_masks), count((size_t)F * n_masks, 0), half;
     DevBuf<float> slab;                       // contours found on the device (contour_count == NULL): [F*M][cap][2]
     int cap = 0;
@@ -671,24 +679,24 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
         if (count[i] < 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: negative contour count");
         start[i] = total; total += count[i]; cmax = std::max(cmax, count[i]);
     }
-    refresh(b->mk_view); refresh(b->mk_cstart); refresh(b->mk_ccount); refresh(b->mk_cxy);
-    refresh(b->mk_uvi); refresh(b->mk_duvb); refresh(b->mk_gpart); refresh(b->mk_cgrad); refresh(b->mk_part); refresh(b->mk_loss); refresh(b->mk_choice);
     const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256, stride = pblocks + (cmax * 16 + 255) / 256;     // (16 lanes per contour point)
-    HIP_TRY(b->mk_view.upload(std::vector<int>(view_index, view_index + n_masks)));
-    HIP_TRY(b->mk_cstart.upload(start));
-    HIP_TRY(b->mk_ccount.upload(count));
-    if (contour_count) HIP_TRY(b->mk_cxy.upload(std::vector<float>(contour_xy, contour_xy + (size_t)std::max(total, 1) * 2)));
+    const size_t fm = (size_t)F * n_masks;
+    HIP_TRY(ensure(b->mk_view, n_masks)); HIP_TRY(ensure(b->mk_cstart, fm)); HIP_TRY(ensure(b->mk_ccount, fm));
+    HIP_TRY(hipMemcpy(b->mk_view.p, view_index, (size_t)n_masks * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->mk_cstart.p, start.data(), fm * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(b->mk_ccount.p, count.data(), fm * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(ensure(b->mk_cxy, (size_t)std::max(total, 1) * 2));
+    if (contour_count) { if (total > 0) HIP_TRY(hipMemcpy(b->mk_cxy.p, contour_xy, (size_t)total * 2 * sizeof(float), hipMemcpyHostToDevice)); }
     else {
-        HIP_TRY(b->mk_cxy.alloc((size_t)std::max(total, 1) * 2));
         for (size_t i = 0; i < count.size(); ++i)
             if (count[i] > 0)
-                HIP_TRY(hipMemcpy(b->mk_cxy.p + (size_t)start[i] * 2, slab.p + (i * 2 + half[i]) * (size_t)cap * 2, (size_t)count[i] * 2 * sizeof(float),
-                                  hipMemcpyDeviceToDevice));
+                HIP_TRY(hipMemcpyAsync(b->mk_cxy.p + (size_t)start[i] * 2, slab.p + (i * 2 + half[i]) * (size_t)cap * 2, (size_t)count[i] * 2 * sizeof(float),
+                                       hipMemcpyDeviceToDevice, 0));
+        HIP_TRY(hipStreamSynchronize(0));          // (`slab` goes away with this call)
     }
-    const size_t fm = (size_t)F * n_masks;
-    HIP_TRY(b->mk_uvi.alloc(fm * ns * 4)); HIP_TRY(b->mk_duvb.alloc(fm * ns * 2)); HIP_TRY(b->mk_gpart.alloc(fm * ns * 3));
-    HIP_TRY(b->mk_choice.alloc(fm * cmax)); HIP_TRY(b->mk_cgrad.alloc(fm * cmax * 2));
-    HIP_TRY(b->mk_part.alloc(fm * stride)); HIP_TRY(b->mk_loss.alloc(F));
+    HIP_TRY(ensure(b->mk_uvi, fm * ns * 4)); HIP_TRY(ensure(b->mk_duvb, fm * ns * 2)); HIP_TRY(ensure(b->mk_gpart, fm * ns * 3));
+    HIP_TRY(ensure(b->mk_choice, fm * cmax)); HIP_TRY(ensure(b->mk_cgrad, fm * cmax * 2));
+    HIP_TRY(ensure(b->mk_part, fm * stride)); HIP_TRY(ensure(b->mk_loss, F));
     MaskIO &K = b->mask;
     K.nv = nv; K.ns = ns; K.n_views = b->V; K.n_masks = n_masks; K.H = H; K.W = W; K.cmax = cmax;
     K.part_stride = stride; K.proj_blocks = pblocks; K.cdist = 1; K.sstride = 4; K.imsize = 512.f; K.eps = 10.f; K.weight = 5.f;
