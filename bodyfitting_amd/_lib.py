@@ -145,6 +145,8 @@ def load():
         raise BodyfitError(
             f"{LIB_PATH} is missing - build it with `make -C bodyfitting_amd/csrc` (or "
             "`python -c 'import __graft_entry__ as g; g.build()'`).  There is no CPU fallback.")
+    # (see csrc/api.hip: bf_more_hw_queues - also here, for the case that something in this process touches HIP before the library loads)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

@@ -13,6 +13,15 @@ extern "C" __global__ void bf_joints_kernel(MeshTab, const float *, const float 
 extern "C" size_t bf_fit_smem_bytes(int, int, int, int, int, int, int);
 extern "C" size_t bf_mesh_smem_bytes(int, int, int);
 
+// The HIP runtime multiplexes all streams of a process over GPU_MAX_HW_QUEUES hardware queues (default 4), and streams that share a
+// queue run in order.  A batch uses up to three streams that must run side by side (batch stream; second stream for a call's mesh tail
+// / the side kernels of a dense iteration; the resident fit launch's stream), and an RCCL communicator in the same process brings
+// streams of its own: with four queues the resident launch then lands on the batch stream's queue, its self-test fails and every
+// dense iteration pays a fit launch (measured: config 3 48.6 ms per fit instead of 16.4 with a communicator created first).  Eight
+// queues restore it.  Set when the library is loaded - before the first HIP call of a host that has not initialised HIP itself -
+// and never over a value the user chose.
+__attribute__((constructor)) static void bf_more_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 std::string &bf_err_slot() { thread_local std::string e; return e; }
 int bf_fail(int code, const std::string &msg) { bf_err_slot() = msg; return code; }
 

@@ -44,3 +44,20 @@ def test_missing_library_raises(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libbodyfit.so"))
     with pytest.raises(_lib.BodyfitError):
         _lib.load()
+
+
+def test_loading_the_library_asks_for_eight_hardware_queues():
+    """csrc/api.hip: bf_more_hw_queues - with HIP's default of four hardware queues an RCCL communicator in the process pushes the
+    resident fit launch onto the batch stream's queue (dense fits 3x slower, measured); the library raises the limit when it is
+    loaded, unless the user set one"""
+    import ctypes
+    import subprocess
+    import sys
+    code = ("import os, ctypes; os.environ.pop('GPU_MAX_HW_QUEUES', None); "
+            "from bodyfitting_amd import _lib; _lib.load(); "
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; print(libc.getenv(b'GPU_MAX_HW_QUEUES').decode())")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=REPO, env={k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"})
+    assert out.returncode == 0 and out.stdout.strip() == "8", out.stderr[-500:]
+    out = subprocess.run([sys.executable, "-c", code.replace("os.environ.pop('GPU_MAX_HW_QUEUES', None)", "os.environ['GPU_MAX_HW_QUEUES'] = '6'")],
+                         capture_output=True, text=True, cwd=REPO)
+    assert out.stdout.strip() == "6"
