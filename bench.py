@@ -72,6 +72,7 @@ def parse():
                     help="2 (default; 4 = 2 with --frames-per-gpu 32): keypoint-only SMPL.  3: SMPL-X, 48 views + 8 silhouettes, 200 iterations.  "
                          "5: SMPL-X + a ~84k-triangle scan per frame, 300 iterations + 300 SMPL+D iterations (default 8 frames per GPU)")
     ap.add_argument("--resident", action="store_true", help="headline WITHOUT the per-step input upload (re-fit one resident frame set, rounds 1-2)")
+    ap.add_argument("--force-ranks", action="store_true", help="run the one-process-per-GPU code path (bf_comm: file rendezvous, ncclCommInitRank, barrier, gather) even with WORLD_SIZE 1")
     ap.add_argument("--force-group", action="store_true", help="drive even ONE GPU through bf_group (the N-GPU code path, incl. its RCCL all-gather with one rank): a 1-GPU box's check of what --gpus N runs")
     ap.add_argument("--frame-sets", type=int, default=16, help="distinct frame sets resident on the host that the steps cycle over")
     return ap.parse_args()
@@ -207,7 +208,7 @@ def main_dense(a):
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0")) if env_world > 1 else 0
     local = int(os.environ.get("LOCAL_RANK", "0")) if env_world > 1 else 0
-    mode = "ranks" if env_world > 1 else ("group" if (a.gpus > 1 or a.force_group) else "single")
+    mode = "ranks" if (env_world > 1 or a.force_ranks) else ("group" if (a.gpus > 1 or a.force_group) else "single")
     n_gpus = env_world if mode == "ranks" else a.gpus
     have = _lib.load().bf_device_count()
     if (mode == "group" and a.gpus > have) or (mode == "ranks" and local >= have):
@@ -348,7 +349,7 @@ def main():
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0")) if env_world > 1 else 0
     local = int(os.environ.get("LOCAL_RANK", "0")) if env_world > 1 else 0
-    mode = "ranks" if env_world > 1 else ("group" if (a.gpus > 1 or a.force_group) else "single")
+    mode = "ranks" if (env_world > 1 or a.force_ranks) else ("group" if (a.gpus > 1 or a.force_group) else "single")
     n_gpus = env_world if mode == "ranks" else a.gpus
     if mode == "ranks" and a.gpus != env_world and rank == 0:
         print(f"warning: --gpus {a.gpus} but WORLD_SIZE {env_world}: using {env_world}", file=sys.stderr)
