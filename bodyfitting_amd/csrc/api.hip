@@ -664,6 +664,9 @@ void bf_batch_destroy(bf_batch *b) {
     if (b->h_res) (void)hipHostFree(b->h_res);
     if (b->h_res_b) (void)hipHostFree(b->h_res_b);
     if (b->h_pc_weight) (void)hipHostFree(b->h_pc_weight);
+    if (b->h_masks) (void)hipHostFree(b->h_masks);
+    if (b->h_ccount) (void)hipHostFree(b->h_ccount);
+    if (b->ev_masks) (void)hipEventDestroy(b->ev_masks);
     for (int k = 0; k < 2; ++k) {
         if (b->h_in[k]) (void)hipHostFree(b->h_in[k]);
         if (b->ev_in[k]) (void)hipEventDestroy(b->ev_in[k]);

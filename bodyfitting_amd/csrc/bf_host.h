@@ -166,6 +166,19 @@ struct bf_batch {
     // silhouette loss (use_mask, smplify.py:138-144,197-199)
     bool has_masks = false;
     MaskIO mask{};
+    // Contours extracted on the device are DEFERRED: bf_batch_set_masks queues the upload of the binarised masks and the border
+    // following on the second stream and returns; the bookkeeping that needs their lengths (cmax-sized buffers, offsets) is finished
+    // by bf_masks_finalize right before the first kernel that reads them - in a fit that is the first iteration past dense_after, by
+    // which time the keypoint-only iterations queued in front have long covered the extraction.
+    bool masks_pending = false;
+    unsigned char *h_masks = nullptr;   // pinned staging of the binarised masks
+    size_t h_masks_n = 0, h_ccount_n = 0;
+    int *h_ccount = nullptr;            // pinned: [2 * F * M] contour lengths | which half of the slab holds them
+    hipEvent_t ev_masks = nullptr;
+    DevBuf<float> mk_slab;              // [F*M][2][cap][2] the contour kernel's two-slot slabs
+    DevBuf<int> mk_cnt2;
+    DevBuf<unsigned> mk_planes;         // bit planes of images too large for LDS
+    int mk_cap = 0, mk_select = 0;
     DevBuf<int> mk_view, mk_cstart, mk_ccount, mk_choice;
     DevBuf<unsigned char> mk_masks;
     DevBuf<float> mk_cxy, mk_uvi, mk_duvb, mk_cgrad, mk_part, mk_loss, mk_gpart;
@@ -199,6 +212,7 @@ int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev,
 int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDev &hd, FrameIO io);
 int bf_dense_loss_grad(bf_batch *b, const bf_hyper &h, const HyperDev &hd, FrameIO io);
 int bf_ensure_dense_buffers(bf_batch *b);
+int bf_masks_finalize(bf_batch *b);      // no-op unless a deferred bf_batch_set_masks is pending
 HyperDev bf_to_dev(const bf_hyper &h);
 int bf_sync_all(bf_batch *b);            // copy stream, then compute stream
 int bf_guard_arena(bf_batch *b);         // the compute stream waits for a fetch still reading the current arena

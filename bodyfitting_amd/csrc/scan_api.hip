@@ -345,6 +345,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     const MeshTab &Q = sub ? m->sub.mesh : m->mesh;
     const int F = b->F, nv = Q.nv, nblk = (nv + 255) / 256;
     const bool scans = late && !b->scans.empty(), masks = late && b->has_masks, kp = m->kp_dense;
+    if (masks) { int rf = bf_masks_finalize(b); if (rf) return rf; }
     if (!door) {                     // (with the resident fit launch every state comes from it)
         hipLaunchKernelGGL(bf_pose_state_kernel, dim3(F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
                            (const float *)nullptr, (const float *)nullptr, (const float *)nullptr, b->state.p,
@@ -664,46 +665,127 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
         buf.p = nullptr;
         return buf.alloc(count);
     };
-    const size_t npix = (size_t)F * n_masks * H * W;
-    std::vector<unsigned char> bin(npix);
-    for (size_t i = 0; i < npix; ++i) bin[i] = masks[i] > 128;                                 // smplify.py:139
+    const size_t npix = (size_t)F * n_masks * H * W, fm = (size_t)F * n_masks;
+    const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256;
+    // binarised (smplify.py:139) straight into pinned staging
+    if (b->h_masks_n < npix) {
+        if (b->h_masks) (void)hipHostFree(b->h_masks);
+        b->h_masks = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&b->h_masks, npix));
+        b->h_masks_n = npix;
+    }
+    for (size_t i = 0; i < npix; ++i) b->h_masks[i] = masks[i] > 128;
     HIP_TRY(ensure(b->mk_masks, npix));
-    HIP_TRY(hipMemcpy(b->mk_masks.p, bin.data(), npix, hipMemcpyHostToDevice));
-    std::vector<int> start((size_t)F * n_masks), count((size_t)F * n_masks, 0), half;
-    DevBuf<float> slab;                       // contours found on the device (contour_count == NULL): [F*M][cap][2]
-    int cap = 0;
-    if (contour_count) count.assign(contour_count, contour_count + (size_t)F * n_masks);
-    else { int rc = contours_on_device(b->mk_masks.p, F * n_masks, H, W, contour_select, count, half, slab, cap); if (rc) return rc; }
+    HIP_TRY(ensure(b->mk_view, n_masks)); HIP_TRY(ensure(b->mk_cstart, fm)); HIP_TRY(ensure(b->mk_ccount, fm));
+    HIP_TRY(hipMemcpy(b->mk_view.p, view_index, (size_t)n_masks * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(ensure(b->mk_uvi, fm * ns * 4)); HIP_TRY(ensure(b->mk_duvb, fm * ns * 2)); HIP_TRY(ensure(b->mk_gpart, fm * ns * 3));
+    HIP_TRY(ensure(b->mk_loss, F));
+    MaskIO &K0 = b->mask;
+    K0.nv = nv; K0.ns = ns; K0.n_views = b->V; K0.n_masks = n_masks; K0.H = H; K0.W = W; K0.proj_blocks = pblocks;
+    K0.cdist = 1; K0.sstride = 4; K0.imsize = 512.f; K0.eps = 10.f; K0.weight = 5.f;
+    K0.view_index = b->mk_view.p; K0.masks = b->mk_masks.p;
+    b->masks_pending = false;
+    if (!contour_count) {
+        // DEFERRED: upload + border following on the second stream; lengths into pinned memory; bf_masks_finalize does the rest
+        if (!b->ev_masks) HIP_TRY(hipEventCreateWithFlags(&b->ev_masks, hipEventDisableTiming));
+        if (b->h_ccount_n < 2 * fm) {
+            if (b->h_ccount) (void)hipHostFree(b->h_ccount);
+            b->h_ccount = nullptr;
+            HIP_TRY(hipHostMalloc((void **)&b->h_ccount, 2 * fm * sizeof(int)));
+            b->h_ccount_n = 2 * fm;
+        }
+        const int wpr = (W + 31) / 32;
+        const size_t plane_bytes = (size_t)3 * H * wpr * sizeof(unsigned);
+        const bool in_lds = plane_bytes <= 150 * 1024;
+        if (!in_lds) HIP_TRY(ensure(b->mk_planes, fm * 3 * H * wpr));
+        if (in_lds && plane_bytes > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)bf_contour_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plane_bytes));
+        b->mk_cap = std::max(b->mk_cap, std::max(64, 4 * (H + W)));
+        b->mk_select = contour_select;
+        HIP_TRY(ensure(b->mk_slab, fm * 2 * (size_t)b->mk_cap * 2));
+        HIP_TRY(ensure(b->mk_cnt2, 2 * fm));
+        hipStream_t cs = b->copy_stream;
+        HIP_TRY(hipMemcpyAsync(b->mk_masks.p, b->h_masks, npix, hipMemcpyHostToDevice, cs));
+        hipLaunchKernelGGL(bf_contour_kernel, dim3((unsigned)fm), dim3(256), in_lds ? plane_bytes : 0, cs, (const unsigned char *)b->mk_masks.p, H, W,
+                           b->mk_cap, contour_select, b->mk_slab.p, b->mk_cnt2.p, in_lds ? (unsigned *)nullptr : b->mk_planes.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->h_ccount, b->mk_cnt2.p, 2 * fm * sizeof(int), hipMemcpyDeviceToHost, cs));
+        HIP_TRY(hipEventRecord(b->ev_masks, cs));
+        b->masks_pending = true;
+        b->has_masks = true;
+        K0.cmax = 1; K0.part_stride = pblocks + 1;         // (placeholders until finalize; nothing reads them before)
+        return bf_ensure_dense_buffers(b);
+    }
+    HIP_TRY(hipMemcpy(b->mk_masks.p, b->h_masks, npix, hipMemcpyHostToDevice));
+    std::vector<int> start(fm), count(contour_count, contour_count + fm);
     int total = 0, cmax = 1;
-    for (size_t i = 0; i < count.size(); ++i) {
+    for (size_t i = 0; i < fm; ++i) {
         if (count[i] < 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: negative contour count");
         start[i] = total; total += count[i]; cmax = std::max(cmax, count[i]);
     }
-    const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256, stride = pblocks + (cmax * 16 + 255) / 256;     // (16 lanes per contour point)
-    const size_t fm = (size_t)F * n_masks;
-    HIP_TRY(ensure(b->mk_view, n_masks)); HIP_TRY(ensure(b->mk_cstart, fm)); HIP_TRY(ensure(b->mk_ccount, fm));
-    HIP_TRY(hipMemcpy(b->mk_view.p, view_index, (size_t)n_masks * sizeof(int), hipMemcpyHostToDevice));
+    const int stride = pblocks + (cmax * 16 + 255) / 256;     // (16 lanes per contour point)
     HIP_TRY(hipMemcpy(b->mk_cstart.p, start.data(), fm * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(b->mk_ccount.p, count.data(), fm * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(ensure(b->mk_cxy, (size_t)std::max(total, 1) * 2));
-    if (contour_count) { if (total > 0) HIP_TRY(hipMemcpy(b->mk_cxy.p, contour_xy, (size_t)total * 2 * sizeof(float), hipMemcpyHostToDevice)); }
-    else {
-        for (size_t i = 0; i < count.size(); ++i)
-            if (count[i] > 0)
-                HIP_TRY(hipMemcpyAsync(b->mk_cxy.p + (size_t)start[i] * 2, slab.p + (i * 2 + half[i]) * (size_t)cap * 2, (size_t)count[i] * 2 * sizeof(float),
-                                       hipMemcpyDeviceToDevice, 0));
-        HIP_TRY(hipStreamSynchronize(0));          // (`slab` goes away with this call)
-    }
-    HIP_TRY(ensure(b->mk_uvi, fm * ns * 4)); HIP_TRY(ensure(b->mk_duvb, fm * ns * 2)); HIP_TRY(ensure(b->mk_gpart, fm * ns * 3));
+    if (total > 0) HIP_TRY(hipMemcpy(b->mk_cxy.p, contour_xy, (size_t)total * 2 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(ensure(b->mk_choice, fm * cmax)); HIP_TRY(ensure(b->mk_cgrad, fm * cmax * 2));
-    HIP_TRY(ensure(b->mk_part, fm * stride)); HIP_TRY(ensure(b->mk_loss, F));
+    HIP_TRY(ensure(b->mk_part, fm * stride));
     MaskIO &K = b->mask;
-    K.nv = nv; K.ns = ns; K.n_views = b->V; K.n_masks = n_masks; K.H = H; K.W = W; K.cmax = cmax;
-    K.part_stride = stride; K.proj_blocks = pblocks; K.cdist = 1; K.sstride = 4; K.imsize = 512.f; K.eps = 10.f; K.weight = 5.f;
-    K.view_index = b->mk_view.p; K.masks = b->mk_masks.p; K.contour_start = b->mk_cstart.p;
-    K.contour_count = b->mk_ccount.p; K.contour_xy = b->mk_cxy.p;
+    K.cmax = cmax; K.part_stride = stride;
+    K.contour_start = b->mk_cstart.p; K.contour_count = b->mk_ccount.p; K.contour_xy = b->mk_cxy.p;
     b->has_masks = true;
     return bf_ensure_dense_buffers(b);
+}
+
+// The second half of a deferred bf_batch_set_masks: wait (host) for the border following on the second stream, then size and fill
+// what depends on the contour lengths.  Everything queued here goes onto the BATCH stream, in front of the kernels that read it.
+int bf_masks_finalize(bf_batch *b) {
+    if (!b->masks_pending) return BF_OK;
+    b->masks_pending = false;
+    HIP_TRY(hipEventSynchronize(b->ev_masks));
+    MaskIO &K = b->mask;
+    const size_t fm = (size_t)b->F * K.n_masks;
+    int longest = 0;
+    for (size_t i = 0; i < fm; ++i) longest = std::max(longest, b->h_ccount[i]);
+    if (longest > b->mk_cap) {
+        // a border longer than the slab (4 (H + W) points): follow again with room for it (rare: synchronously)
+        b->mk_cap = longest;
+        HIP_TRY(hipStreamSynchronize(b->copy_stream));
+        if (b->mk_slab.p) { (void)hipFree(b->mk_slab.p); b->mk_slab.p = nullptr; }
+        HIP_TRY(b->mk_slab.alloc(fm * 2 * (size_t)b->mk_cap * 2));
+        const int wpr = (K.W + 31) / 32;
+        const size_t plane_bytes = (size_t)3 * K.H * wpr * sizeof(unsigned);
+        const bool in_lds = plane_bytes <= 150 * 1024;
+        hipLaunchKernelGGL(bf_contour_kernel, dim3((unsigned)fm), dim3(256), in_lds ? plane_bytes : 0, b->copy_stream, (const unsigned char *)b->mk_masks.p,
+                           K.H, K.W, b->mk_cap, b->mk_select, b->mk_slab.p, b->mk_cnt2.p, in_lds ? (unsigned *)nullptr : b->mk_planes.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->h_ccount, b->mk_cnt2.p, 2 * fm * sizeof(int), hipMemcpyDeviceToHost, b->copy_stream));
+        HIP_TRY(hipStreamSynchronize(b->copy_stream));
+    }
+    auto ensure = [](auto &buf, size_t count) -> hipError_t {
+        if (buf.p && buf.n >= count && !buf.view) return hipSuccess;
+        if (buf.p && !buf.view) (void)hipFree((void *)buf.p);
+        buf.p = nullptr;
+        return buf.alloc(count);
+    };
+    std::vector<int> start(fm);
+    int total = 0, cmax = 1;
+    for (size_t i = 0; i < fm; ++i) { start[i] = total; total += b->h_ccount[i]; cmax = std::max(cmax, b->h_ccount[i]); }
+    const int stride = K.proj_blocks + (cmax * 16 + 255) / 256;
+    HIP_TRY(ensure(b->mk_cxy, (size_t)std::max(total, 1) * 2));
+    HIP_TRY(ensure(b->mk_choice, fm * cmax)); HIP_TRY(ensure(b->mk_cgrad, fm * cmax * 2)); HIP_TRY(ensure(b->mk_part, fm * stride));
+    int *h = b->h_ccount;                                     // [0, fm): lengths; [fm, 2 fm): halves -> reused below for the offsets
+    std::vector<int> half(h + fm, h + 2 * fm);
+    for (size_t i = 0; i < fm; ++i) h[fm + i] = start[i];
+    HIP_TRY(hipMemcpyAsync(b->mk_ccount.p, h, fm * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->mk_cstart.p, h + fm, fm * sizeof(int), hipMemcpyHostToDevice, b->stream));
+    for (size_t i = 0; i < fm; ++i)
+        if (h[i] > 0)
+            HIP_TRY(hipMemcpyAsync(b->mk_cxy.p + (size_t)start[i] * 2, b->mk_slab.p + (i * 2 + half[i]) * (size_t)b->mk_cap * 2,
+                                   (size_t)h[i] * 2 * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    K.cmax = cmax; K.part_stride = stride;
+    K.contour_start = b->mk_cstart.p; K.contour_count = b->mk_ccount.p; K.contour_xy = b->mk_cxy.p;
+    return BF_OK;
 }
 
 // multview_mask_loss (loss.py:85-130) at the current parameters: loss[F] (unweighted, as the function
@@ -711,6 +793,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
 int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *dverts) {
     if (!b || !b->has_masks) return fail(BF_ERR_INVALID, "bf_batch_mask_loss: no masks attached");
     HIP_TRY(hipSetDevice(b->m->device));
+    { int rf = bf_masks_finalize(b); if (rf) return rf; }
     bf_hyper h;
     if (hyper) h = *hyper; else bf_hyper_default(&h);
     HyperDev hd = bf_to_dev(h);
