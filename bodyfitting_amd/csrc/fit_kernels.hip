@@ -498,7 +498,33 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
         }
     };
+    // The rotations left phase A: the lane that steps a joint's three dofs (phase I, wave 0) forms the joint's rotation for the NEXT
+    // forward pass right away (rotations_ahead: S.R, S.theta, S.rc, S.feat), so phase A starts with the chain, and the GMM waves find
+    // the pose feature in LDS.  (Not after the last step: the epilogue publishes the state of the last forward pass.)
+    constexpr bool ROT_AHEAD = NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36;       // (= MERGE_IK)
+#ifdef BF_NO_GMM
+    constexpr bool GBLEND = false;
+#else
+    constexpr bool GBLEND = ROT_AHEAD && NS <= 12;
+#endif
+    auto rotations_ahead = [&](int j, float th0, float th1, float th2) {
+        float Ri[9], rc[4];
+        rodrigues_fwd(th0, th1, th2, Ri, rc);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) S.R[j * 9 + e] = Ri[e];
+        S.theta[j * 3] = th0; S.theta[j * 3 + 1] = th1; S.theta[j * 3 + 2] = th2;
+        *(float4 *)(S.rc + j * 4) = make_float4(rc[0], rc[1], rc[2], rc[3]);
+        if (j > 0) {
+            float *f = S.feat + (j - 1) * 9;
+            f[0] = Ri[0] - 1.f; f[1] = Ri[1]; f[2] = Ri[2]; f[3] = Ri[3]; f[4] = Ri[4] - 1.f;
+            f[5] = Ri[5]; f[6] = Ri[6]; f[7] = Ri[7]; f[8] = Ri[8] - 1.f;
+        }
+    };
     if (wave == 3) beta_dependent(S.pa);
+    if (ROT_AHEAD && wave == 0 && lane < nj) {
+        const int po = lane > 0 ? T.off_pose + 3 * (lane - 1) : T.off_orient;
+        rotations_ahead(lane, 0.f + S.pa[po], 0.f + S.pa[po + 1], 0.f + S.pa[po + 2]);
+    }
     __syncthreads();
     // phases shared by both wave roles
     auto pose_blend = [&](auto nbatch) {
@@ -626,6 +652,78 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             S.TR[sv2c * 9 + k * 3 + b] = t;
             if (k == 0) S.vp[sv2c * 3 + b] = vpb;
         }
+        float contrib = trl ? (b < 3 ? t * vpb : t) : 0.f;
+        contrib = quad_sum(contrib);
+        if (trl && b == 0) S.vsel[sv2c * 3 + k] = contrib;
+    };
+    // Round 3: the pose blend LEFT the geometry waves.  The GMM waves issue ~300 instructions per iteration against the geometry waves'
+    // ~1,900, and the pose blend needs nothing but the pose feature, which is in LDS when the iteration starts (rotations_ahead):
+    // every GMM wave blends its three selector vertices (the lane pattern of blend_and_skin: 9 coordinates x 7 row slices, partials
+    // through a wave-private strip) into S.vp under the chain waves' phase A.  Phase B on the geometry waves is then the skinning
+    // alone (skin_only).
+    const bool gblend = GBLEND && merge_bc;
+    auto gmm_blend = [&]() {
+        constexpr int NPF = NJ > 0 ? 9 * (NJ - 1) : 8, RS = (NPF + 6) / 7, NH = 4, RB = (RS + NH - 1) / NH;      // (four batches of 8 rows: registers)
+        const int lq = bf_launder(lane);          // (fresh per iteration: the 30 row addresses below must not become loop invariants)
+        const int ol7 = lq / 7, ol = min(ol7, 8), sl = lq - ol7 * 7;
+        const int sv = gwi * 3 + ol / 3, c = ol - (ol / 3) * 3;
+        const bool on = ol7 < 9 && sv < ns;
+        const int o = (on ? sv : 0) * 3 + c;
+        const int p0 = sl * RS;
+        float acc = 0.f;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            float f[RB], w[RB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int p = min(p0 + h * RB + i, NPF - 1);
+                f[i] = S.feat[p];
+                w[i] = S.sel_pd2[p * (ns3 + 1) + o];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < RB; ++i) acc += (h * RB + i < RS && p0 + h * RB + i < NPF ? f[i] : 0.f) * w[i];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        float *strip = S.vpp + (4 + gwi) * 64;         // this wave's 63 partials (the geometry waves' strips are 0-3)
+        strip[lq] = on ? acc : 0.f;
+        BF_WAVE_FENCE();
+        // lanes 0-8: coordinate lq of the wave's three vertices = shaped vertex + the seven slice partials in slot order
+        const int o9 = min(lq, 8), sv9 = gwi * 3 + o9 / 3;
+        const bool on9 = lq < 9 && sv9 < ns;
+        const int oo = (on9 ? sv9 : 0) * 3 + (o9 - (o9 / 3) * 3);
+        const float *pp = strip + o9 * 7;
+        float pr[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) pr[i] = pp[i];
+        float vpb = S.vs[oo];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) vpb += pr[i];
+        if (on9) S.vp[oo] = vpb;
+    };
+    // phase B when the GMM waves blend: T_s = sum_j w_sj A_j of the wave's three vertices (lanes 0-35: vertex, row k, column b),
+    // skinned vertex = T_s [vp | 1]
+    auto skin_only = [&]() {
+        constexpr int NZ = 4;
+        const int lq = bf_launder(lane);
+        const int vloc = lq / 12, e12 = lq - vloc * 12, k = e12 >> 2, b = e12 & 3;
+        const int sv2 = wave * 3 + vloc;
+        const bool trl = lq < 36 && sv2 < ns;
+        const int sv2c = trl ? sv2 : 0;
+        float wq[NZ], aq[NZ];
+        int jq[NZ];
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) { wq[q] = S.nzw[sv2c * BF_SEL_NNZ + q]; jq[q] = S.nzj[sv2c * BF_SEL_NNZ + q]; }
+        const float vpb = S.vp[sv2c * 3 + (b < 3 ? b : 0)];
+        const float *A = b < 3 ? S.G + k * 4 + b : S.At + k;
+        const int stride = b < 3 ? 12 : 3;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) aq[q] = A[jq[q] * stride];
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < NZ; ++q) t += wq[q] * aq[q];
+        if (trl && b < 3) S.TR[sv2c * 9 + k * 3 + b] = t;
         float contrib = trl ? (b < 3 ? t * vpb : t) : 0.f;
         contrib = quad_sum(contrib);
         if (trl && b == 0) S.vsel[sv2c * 3 + k] = contrib;
@@ -769,6 +867,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #ifdef BF_STAMP
             int sidx = 0;
             const long long t_iter = clock64();
+#else
+            const long long t_iter = 0;
 #endif
             // The GMM prior (d = theta - mu, y = Psym d, q = 0.5 d'y - log w~ for this wave's two components) feeds only
             // the Adam phase and costs one wave ~3000 cycles, so it is cut into eight-column chunks, one or two per phase:
@@ -783,6 +883,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             ((v2f *)gdw)[lane] = dA;                   // LDS copy, interleaved (d_a[j], d_b[j]) pairs: one b128 = two columns
             if (lane < BF_GMM_LD - 64) ((v2f *)gdw)[64 + lane] = dB;
             BF_WAVE_FENCE();
+            if (gblend) { gmm_blend(); BF_MARK(42, 256, it, t_iter); }
             v2f y0 = {0.f, 0.f}, y1 = {0.f, 0.f};
 #define BF_GMM_CHUNK(c)                                                                         \
             _Pragma("unroll") for (int j2 = 4 * (c); j2 < 4 * (c) + 4; ++j2) {                  \
@@ -891,17 +992,23 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 // iteration (or in the prologue); read it before the Rodrigues arithmetic so the latency hides under it
                 const float a0 = S.rel[wjq * 3], a1 = S.rel[wjq * 3 + 1], a2 = S.rel[wjq * 3 + 2];
                 jj0 = S.J[wjq * 3]; jj1 = S.J[wjq * 3 + 1]; jj2 = S.J[wjq * 3 + 2];
+                if (ROT_AHEAD) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) Ri[e] = S.R[wjq * 9 + e];
+                }
                 __builtin_amdgcn_sched_barrier(0);
+                if (!ROT_AHEAD) {
                 rodrigues_fwd(th0, th1, th2, Ri, rc);
                 if (wave == 2) { S.theta[wjq * 3] = th0; S.theta[wjq * 3 + 1] = th1; S.theta[wjq * 3 + 2] = th2; }
+                }
                 rel0 = a0; rel1 = a1; rel2 = a2;
                 // bookkeeping stores spread over the three (otherwise identical) chain waves
-                if (wave == 0 && mode == 1) {                 // (debug dump only)
+                if (!ROT_AHEAD && wave == 0 && mode == 1) {                 // (debug dump only)
 #pragma unroll
                     for (int e = 0; e < 9; ++e) S.R[wjq * 9 + e] = Ri[e];
                 }
-                if (wave == 2) *(float4 *)(S.rc + wjq * 4) = make_float4(rc[0], rc[1], rc[2], rc[3]);
-                if (wave == 1 && wj > 0) {
+                if (!ROT_AHEAD && wave == 2) *(float4 *)(S.rc + wjq * 4) = make_float4(rc[0], rc[1], rc[2], rc[3]);
+                if (!ROT_AHEAD && wave == 1 && wj > 0) {
                     float *f = S.feat + (wjq > 0 ? wjq - 1 : 0) * 9;
                     f[0] = Ri[0] - 1.f; f[1] = Ri[1]; f[2] = Ri[2]; f[3] = Ri[3]; f[4] = Ri[4] - 1.f;
                     f[5] = Ri[5]; f[6] = Ri[6]; f[7] = Ri[7]; f[8] = Ri[8] - 1.f;
@@ -967,7 +1074,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
         if (merge_bc) {
             // ================= phase B (+C): pose blend and skinning of the selector vertices in one phase
-            blend_and_skin();
+            if (gblend) skin_only(); else blend_and_skin();
         } else {
         {
         // ================= phase B: pose blend of the selector vertices, partial sums over row slices
@@ -1375,8 +1482,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     for (int c = 0; c < 3; ++c) sq[c] = __builtin_amdgcn_sqrtf(pw[c]);
 #pragma unroll
                     for (int c = 0; c < 3; ++c) rd[c] = __builtin_amdgcn_rcpf(sq[c] * ir2 + hp.eps);
+                    float pn[3];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) { Pnext[pi0 + c] = pv[c] - at1 * (pm[c] * rd[c]); S.am[pi0 + c] = pm[c]; S.av[pi0 + c] = pw[c]; }
+                    for (int c = 0; c < 3; ++c) { pn[c] = pv[c] - at1 * (pm[c] * rd[c]); Pnext[pi0 + c] = pn[c]; S.am[pi0 + c] = pm[c]; S.av[pi0 + c] = pw[c]; }
+                    if (ROT_AHEAD && it + 1 < n_iters) rotations_ahead(tq, 0.f + pn[0], 0.f + pn[1], 0.f + pn[2]);
                 }
             }
             BF_MARK(51, 0, it, t_iter);
