@@ -369,6 +369,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         K.nl = m->nl_loss; K.nj = nj; K.npf = npf; K.nb = nb; K.nv = nv; K.n_all = n_all; K.n_selector = d->n_selector;
         K.n_extra = d->n_extra; K.n_lmk = n_lmk;
         K.joint_map = m->kp_jm.p; K.selector_ids = m->selector_ids.p; K.cj_start = m->cj_start.p; K.cj_list = m->cj_list.p;
+        K.j_extra = m->j_extra.p;
     }
     m->mesh_smem = bf_mesh_smem_bytes(nj, npf, nb);
     {
@@ -425,7 +426,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
             U.mesh.lbs_weights = U.lbs_weights.p; U.mesh.j_extra = U.j_extra.p; U.mesh.selector_ids = U.selector_ids.p;
             U.mesh.v_nzj = U.v_nzj.p; U.mesh.v_nzw = U.v_nzw.p;
             if (smplx) U.mesh.faces = U.faces.p;
-            U.kp = m->kp; U.kp.nv = sv; U.kp.selector_ids = U.selector_ids.p;
+            U.kp = m->kp; U.kp.nv = sv; U.kp.selector_ids = U.selector_ids.p; U.kp.j_extra = U.j_extra.p;
             U.ns = n_samp;
             U.on = true;
         }
@@ -597,7 +598,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
         b->in_total = b->in_off[2] + up(F);
         if (const char *e = getenv("BF_STAGE_MODE")) b->stage_mode = !strcmp(e, "memcpy") ? 1 : (!strcmp(e, "zerocopy") ? 2 : (!strcmp(e, "aside") ? 3 : 0));
         for (int k = 0; k < 2; ++k) {
-            ok = ok && b->in_dev[k].alloc(b->in_total) == hipSuccess && hipMemset(b->in_dev[k].p, 0, b->in_total * sizeof(float)) == hipSuccess;
+            ok = ok && b->in_dev[k].alloc(b->in_total) == hipSuccess && bf_memset_sync(b->in_dev[k].p, 0, b->in_total * sizeof(float)) == hipSuccess;
             ok = ok && hipHostMalloc((void **)&b->h_in[k], b->in_total * sizeof(float)) == hipSuccess;
             ok = ok && hipEventCreateWithFlags(&b->ev_in[k], hipEventDisableTiming) == hipSuccess;
             if (ok) std::memset(b->h_in[k], 0, b->in_total * sizeof(float));
@@ -625,7 +626,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
             ok = ok && hipEventCreateWithFlags(&b->ev_done[k], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&b->ev_copied[k], hipEventDisableTiming) == hipSuccess;
         if (ok) {
-            ok = hipMemset(b->res.p, 0, total * sizeof(float)) == hipSuccess && hipMemset(b->res_b.p, 0, total * sizeof(float)) == hipSuccess;
+            ok = bf_memset_sync(b->res.p, 0, total * sizeof(float)) == hipSuccess && bf_memset_sync(b->res_b.p, 0, total * sizeof(float)) == hipSuccess;
             const size_t offs[5] = {0, o_terms, o_state, o_joints, o_v}, cnts[5] = {n_par, n_terms, n_state, n_joints, n_v};
             for (int i = 0; i < 5; ++i) { b->res_off[i] = offs[i]; b->res_cnt[i] = cnts[i]; }
             b->res_small = o_v;
@@ -644,10 +645,10 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
     ok = ok && b->xpart.alloc(F * m->mesh.n_tiles * std::max(m->n_extra, 1) * 3) == hipSuccess;
     ok = ok && b->debug.alloc(8192) == hipSuccess;
     if (ok) {
-        ok = hipMemset(b->adam_m.p, 0, F * np * sizeof(float)) == hipSuccess &&
-             hipMemset(b->adam_v.p, 0, F * np * sizeof(float)) == hipSuccess &&
-             hipMemset(b->params.p, 0, F * np * sizeof(float)) == hipSuccess &&
-             hipMemset(b->debug.p, 0, 8192 * sizeof(float)) == hipSuccess;
+        ok = bf_memset_sync(b->adam_m.p, 0, F * np * sizeof(float)) == hipSuccess &&
+             bf_memset_sync(b->adam_v.p, 0, F * np * sizeof(float)) == hipSuccess &&
+             bf_memset_sync(b->params.p, 0, F * np * sizeof(float)) == hipSuccess &&
+             bf_memset_sync(b->debug.p, 0, 8192 * sizeof(float)) == hipSuccess;
     }
     if (!ok) { bf_batch_destroy(b); return fail(BF_ERR_HIP, "bf_batch_create: device allocation failed"); }
     b->fit_smem = smem;
@@ -665,6 +666,7 @@ void bf_batch_destroy(bf_batch *b) {
     if (b->h_res_b) (void)hipHostFree(b->h_res_b);
     if (b->h_pc_weight) (void)hipHostFree(b->h_pc_weight);
     if (b->h_masks) (void)hipHostFree(b->h_masks);
+    for (float *q : b->mk_retired) (void)hipFree(q);
     if (b->h_ccount) (void)hipHostFree(b->h_ccount);
     if (b->ev_masks) (void)hipEventDestroy(b->ev_masks);
     for (int k = 0; k < 2; ++k) {
@@ -743,8 +745,8 @@ int bf_batch_set_keypoints(bf_batch *b, const float *keypoints, const int32_t *n
 
 static int reset_adam(bf_batch *b, const float *params_host) {
     HIP_TRY(write_input(b, b->params0.p, params_host, b->params.n * sizeof(float)));
-    HIP_TRY(hipMemset(b->adam_m.p, 0, b->adam_m.n * sizeof(float)));
-    HIP_TRY(hipMemset(b->adam_v.p, 0, b->adam_v.n * sizeof(float)));
+    HIP_TRY(bf_memset_sync(b->adam_m.p, 0, b->adam_m.n * sizeof(float)));
+    HIP_TRY(bf_memset_sync(b->adam_v.p, 0, b->adam_v.n * sizeof(float)));
     b->steps_done = 0;
     b->have_result = false;
     b->fetched = false;

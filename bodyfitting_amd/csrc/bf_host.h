@@ -3,6 +3,7 @@
 #include "../../include/bodyfit.h"
 #include "bf_internal.h"
 
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -22,6 +23,13 @@ int bf_fail(int code, const std::string &msg);
             return fail(BF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
     } while (0)
 
+// hipMemset of device memory returns before the fill has run, and the fill is on the NULL stream: work enqueued afterwards on a
+// non-blocking stream (every stream of this library) is not ordered behind it.  Fills that are not stream-ordered wait here.
+inline hipError_t bf_memset_sync(void *p, int value, size_t bytes) {
+    hipError_t e = hipMemset(p, value, bytes);
+    return e == hipSuccess ? hipStreamSynchronize(nullptr) : e;
+}
+inline int bf_alloc_index() { static int counter = 0; return counter++; }      // (of this translation unit's allocations, all types)
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -30,7 +38,19 @@ struct DevBuf {
     void slice(T *base, size_t count) { p = base; n = count; view = true; }
     hipError_t alloc(size_t count) {
         n = count;
-        return hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
+        // BF_POISON=<byte>: fill every fresh allocation with that byte (255: NaNs) - a read of memory nobody wrote shows up in the
+        // results instead of depending on what the allocator hands out (bring-up switch)
+        // (BF_POISON_ONLY=<k>: only the k-th allocation of the process; BF_POISON_LOG=1 lists them on stderr)
+        static const int poison = [] { const char *v = std::getenv("BF_POISON"); return v ? std::atoi(v) : -1; }();
+        static const int only = [] { const char *v = std::getenv("BF_POISON_ONLY"); return v ? std::atoi(v) : -1; }();
+        static const bool log = std::getenv("BF_POISON_LOG") != nullptr;
+        const int k = bf_alloc_index();
+        if (log) std::fprintf(stderr, "alloc %d: %zu x %zu bytes\n", k, count, sizeof(T));
+        if (e == hipSuccess && poison >= 0 && (only < 0 || only == k)) {
+            e = bf_memset_sync(p, poison, std::max<size_t>(count, 1) * sizeof(T));
+        }
+        return e;
     }
     hipError_t upload(const std::vector<T> &h) {
         hipError_t e = alloc(h.size());
@@ -179,6 +199,7 @@ struct bf_batch {
     DevBuf<int> mk_cnt2;
     DevBuf<unsigned> mk_planes;         // bit planes of images too large for LDS
     int mk_cap = 0, mk_select = 0;
+    std::vector<float *> mk_retired;    // outgrown buffers a finalize inside a fit could not free
     DevBuf<int> mk_view, mk_cstart, mk_ccount, mk_choice;
     DevBuf<unsigned char> mk_masks;
     DevBuf<float> mk_cxy, mk_uvi, mk_duvb, mk_cgrad, mk_part, mk_loss, mk_gpart;

@@ -217,6 +217,7 @@ struct KpIO {
     const int *selector_ids;     // [n_selector]
     const int *cj_start;         // [nj+1]  loss joints mapping to each chain joint (CSR)
     const int *cj_list;
+    const float *j_extra;        // [n_extra][nv]  J_regressor_extra rows over THIS mesh's vertices (models/smpl.py:62-64, 72)
 };
 
 struct FrameIO {

@@ -52,7 +52,7 @@
 namespace {
 
 struct FitSmem {
-    float *pa, *pb, *R, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
+    float *pa, *pb, *R, *L, *rc, *J, *G, *At, *vs, *vp, *TR, *vsel, *part, *dvsel, *dvp;
     float *dGR, *dGt, *tt, *N, *dAt, *dJ, *dR, *drel, *dfeat, *gth, *g, *gd, *gy, *gq, *gtail, *scal, *feat, *vpp;
     float *Jtrel, *Dg, *Jt, *Jd, *Jdrel, *rel, *sel_vt, *sel_sd, *sel_pd, *sel_w, *means, *proj, *nzw, *theta, *pmean, *hcomp, *kp, *stamp, *sel_pd2;
     int *nzj, *thk, *tho, *par, *pk, *pa_, *pb_;
@@ -62,6 +62,7 @@ struct FitSmem {
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+#define BF_PDT_LD 210      // row stride of the transposed selector posedirs: 7 slices of 30 rows
 
 // Carve the dynamic LDS segment; the same function sizes it on the host (base == nullptr).
 __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj, int nb, int npf, int ns,
@@ -71,6 +72,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     // arrays whose size follows from (nj, nb, npf, ns) first: in the compile-time-sized instance their offsets are
     // immediates of the ds instructions; the ones sized by np (a launch value) and by the number of views come last
     s.R = take(nj * 9);    s.rc = take(nj * 4);   s.J = take(nj * 3);
+    s.L = take(nj * 12);   // local transforms [R_j | rel_j], row-major 3 x 4: what a chain lane reads at the top of phase A (3 x b128)
     s.G = take(nj * 12);   s.At = take(nj * 3);
     s.vs = take(ns * 3);   s.vp = take(ns * 3);   s.TR = take(ns * 9);   s.vsel = take(ns * 3);
     s.part = take(BF_VSUB * 32 * 4);
@@ -84,13 +86,13 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.Jtrel = take(nj * 3); s.Dg = take(nj * 12);
     s.Jt = take(nj * 3);   s.Jd = take(nj * 3 * pad4(nb + 1));      s.Jdrel = take(nj * 3 * pad4(nb + 1));
     s.rel = take(nj * 3);
-    s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * pad4(nb + 1)); s.sel_pd = take(npf * ns * 3);
+    s.sel_vt = take(ns * 3); s.sel_sd = take(ns * 3 * pad4(nb + 1)); s.sel_pd = take(npf * pad4(ns * 3));       // rows padded to float4s (the reverse pass reads a row as b128s)
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
     s.nzw = take(ns * BF_SEL_NNZ);  s.nzj = (int *)take(ns * BF_SEL_NNZ);
     s.kp = take(BF_VSUB * BF_KP_ROUNDS * 16 * 8);      // 8-float keypoint record per (view, loss-joint pair), zero padded
     s.stamp = take(64);
-    s.sel_pd2 = take(npf * (ns * 3 + 1));     // sel_pd again with row stride 3 ns + 1: 2-way instead of 3-way bank conflicts for
-                                              // the merged pose blend's (slice, output) lane pattern
+    s.sel_pd2 = take(npf * (ns * 3 + 1));     // sel_pd TRANSPOSED for the GMM waves' pose blend: [3 ns][BF_PDT_LD] (a lane's 30-row slice
+                                              // of one output is contiguous: b64 reads), zero padded; fits: 3 ns * 210 <= npf * (3 ns + 1)
     s.theta = take(nj * 3);  s.pmean = take(nj * 3);  s.hcomp = take(2 * 6 * 45);
     s.thk = (int *)take(nj); s.tho = (int *)take(nj); s.par = (int *)take(nj);
     s.pa = take(np);       s.pb = take(np);   s.g = take(np);
@@ -310,8 +312,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         S.sel_sd[i] = l < nb ? T.sel_sd[r * nb + l] : (l == nb ? T.sel_vt[r] : 0.f);
     }
     copy_f(S.sel_vt, T.sel_vt, ns3, tid, nt);
-    copy_f(S.sel_pd, T.sel_pd, npf * ns3, tid, nt);
-    for (int i = tid; i < npf * (ns3 + 1); i += nt) { const int p = i / (ns3 + 1), o = i - p * (ns3 + 1); S.sel_pd2[i] = o < ns3 ? T.sel_pd[p * ns3 + o] : 0.f; }
+    for (int i = tid; i < npf * pad4(ns3); i += nt) { const int pp = i / pad4(ns3), o = i - pp * pad4(ns3); S.sel_pd[i] = o < ns3 ? T.sel_pd[pp * ns3 + o] : 0.f; }
+    if (ns3 * BF_PDT_LD <= npf * (ns3 + 1))
+        for (int i = tid; i < ns3 * BF_PDT_LD; i += nt) { const int o = i / BF_PDT_LD, p = i - o * BF_PDT_LD; S.sel_pd2[i] = p < npf ? T.sel_pd[p * ns3 + o] : 0.f; }
     copy_f(S.sel_w, T.sel_w, ns * nj, tid, nt);
     for (int i = tid; i < ns * BF_SEL_NNZ; i += nt) { S.nzw[i] = T.sel_nzw[i]; S.nzj[i] = T.sel_nzj[i]; }
     for (int i = tid; i < nj; i += nt) { S.thk[i] = T.th_kind[i]; S.tho[i] = T.th_off[i]; S.par[i] = i > 0 ? T.parents[i] : 0; }
@@ -427,6 +430,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     (void)EXT0;
 
     // pose-blend role: (row slice sl, output column o of the selector vertices)
+    const int pd_ld = pad4(ns3);                   // row stride of S.sel_pd
     const int NSL = (ns3 > 0 && ns3 <= nt) ? nt / ns3 : 1;
     const int rows_sl = (npf + NSL - 1) / NSL;
 
@@ -453,6 +457,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     long long bf_t0 = 0;
     float grad_last = 0.f;
     int pidx_last = -1;
+    constexpr bool ROT_AHEAD = NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36;       // (= MERGE_IK; see rotations_ahead)
     // Everything that depends on the betas alone, for the NEXT forward pass (wave 3; its lanes cover the outputs):
     // shaped selector vertices, rest joints J, joint offsets rel_j = J_j - J_parent from the pre-contracted difference
     // tables, and the zeroed targets of the projection phase's routing
@@ -480,8 +485,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 return acc;
             };
             if (lane < ns3) { S.vs[lane] = dot(sq); S.dvsel[lane] = 0.f; }
-            S.J[i0] = dot(ja); S.rel[i0] = dot(ra); S.dGt[i0] = 0.f;
-            if (lane + 64 < nj3) { S.J[i1] = dot(jb); S.rel[i1] = dot(rb); S.dGt[i1] = 0.f; }
+            // (rel_j[r], i = 3 j + r: L[12 j + 4 r + 3] = L[4 i + 3] when the rotations are formed ahead)
+            S.J[i0] = dot(ja); (ROT_AHEAD ? S.L[4 * i0 + 3] : S.rel[i0]) = dot(ra); S.dGt[i0] = 0.f;
+            if (lane + 64 < nj3) { S.J[i1] = dot(jb); (ROT_AHEAD ? S.L[4 * i1 + 3] : S.rel[i1]) = dot(rb); S.dGt[i1] = 0.f; }
         } else {
             for (int o = lane; o < ns3; o += 64) {
                 float acc = S.sel_sd[o * nbp + nb];
@@ -501,17 +507,16 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     // The rotations left phase A: the lane that steps a joint's three dofs (phase I, wave 0) forms the joint's rotation for the NEXT
     // forward pass right away (rotations_ahead: S.R, S.theta, S.rc, S.feat), so phase A starts with the chain, and the GMM waves find
     // the pose feature in LDS.  (Not after the last step: the epilogue publishes the state of the last forward pass.)
-    constexpr bool ROT_AHEAD = NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36;       // (= MERGE_IK)
-#ifdef BF_NO_GMM
-    constexpr bool GBLEND = false;
-#else
     constexpr bool GBLEND = ROT_AHEAD && NS <= 12;
-#endif
     auto rotations_ahead = [&](int j, float th0, float th1, float th2) {
         float Ri[9], rc[4];
         rodrigues_fwd(th0, th1, th2, Ri, rc);
 #pragma unroll
-        for (int e = 0; e < 9; ++e) S.R[j * 9 + e] = Ri[e];
+        for (int e = 0; e < 9; ++e) S.L[j * 12 + (e / 3) * 4 + (e % 3)] = Ri[e];
+        if (mode == 1) {                             // (debug dump only)
+#pragma unroll
+            for (int e = 0; e < 9; ++e) S.R[j * 9 + e] = Ri[e];
+        }
         S.theta[j * 3] = th0; S.theta[j * 3 + 1] = th1; S.theta[j * 3 + 2] = th2;
         *(float4 *)(S.rc + j * 4) = make_float4(rc[0], rc[1], rc[2], rc[3]);
         if (j > 0) {
@@ -535,7 +540,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             int sl = idx / ns3, o = idx - sl * ns3;
             int p0 = sl * rows_sl, p1 = min(npf, p0 + rows_sl);
             float acc = 0.f;
-            const float *pd = S.sel_pd + p0 * ns3 + o;
+            const float *pd = S.sel_pd + p0 * pd_ld + o;
             if (RS > 0) {
                 // compile-time slice length: the LDS reads of a batch are issued before its multiply-adds (one wait instead
                 // of one per pair), rows past the end are clamped and weighted 0
@@ -546,7 +551,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     for (int i = 0; i < RB; ++i) {
                         const int p = min(p0 + h * RB + i, npf - 1);
                         f[i] = S.feat[p];
-                        w[i] = S.sel_pd[p * ns3 + o];
+                        w[i] = S.sel_pd[p * pd_ld + o];
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -554,7 +559,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
-                for (int p = p0; p < p1; ++p, pd += ns3) acc += S.feat[p] * pd[0];
+                for (int p = p0; p < p1; ++p, pd += pd_ld) acc += S.feat[p] * pd[0];
             }
             S.vpp[idx] = acc;
         }
@@ -569,11 +574,12 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             for (int q = 0; q < (NO + 3) / 4; ++q) dq4[q] = ((const float4 *)__builtin_assume_aligned(dvp_src, 16))[q];
             const float *dv = (const float *)dq4;
             for (int p = first; p < last; p += step) {
-                const float *row = S.sel_pd + p * ns3;
-                float rv[NO];
+                const float4 *row = (const float4 *)__builtin_assume_aligned(S.sel_pd + p * pd_ld, 16);
+                float4 rq[(NO + 3) / 4];
 #pragma unroll
-                for (int o = 0; o < NO; ++o) rv[o] = row[o];
+                for (int q = 0; q < (NO + 3) / 4; ++q) rq[q] = row[q];
                 __builtin_amdgcn_sched_barrier(0);
+                const float *rv = (const float *)rq;
                 float acc = 0.f;
 #pragma unroll
                 for (int o = 0; o < NO; ++o) acc += rv[o] * dv[o];
@@ -582,110 +588,50 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         } else {
             for (int p = first; p < last; p += step) {
                 float acc = 0.f;
-                const float *row = S.sel_pd + p * ns3;
+                const float *row = S.sel_pd + p * pd_ld;
                 for (int o = 0; o < ns3; ++o) acc += row[o] * dvp_src[o];
                 S.dfeat[p] = ext ? acc + ext[p] : acc;
             }
         }
     };
-    // Merged pose blend + skinning of the selector vertices on the four geometry waves, three vertices per wave:
-    // lane = (output ol = lane / 7 of the wave's nine coordinates, row slice sl = lane % 7 of 30 rows).  The slice
-    // partials cross lanes through a wave-private LDS strip (write, wave fence, 7 reads in slot order), so the finished
-    // pose-blended coordinates are in the wave that skins them: no barrier between the two steps.  Lanes 0..35 then own
-    // T[k][b] of T_s = sum_j w_sj A_j for the wave's three vertices (the <= 4 non-zero weights only; quad = one row k).
-    const bool merge_bc = NS > 0 && NS <= 12 && NJ > 0 && sel_nnz > 0 && sel_nnz <= 4;
-    const int bl_ol = lane / 7, bl_sl = lane - bl_ol * 7;            // (63 = 9 x 7: lane 63 idles)
-    auto blend_and_skin = [&]() {
-        constexpr int NPF = NJ > 0 ? 9 * (NJ - 1) : 8, RS = (NPF + 6) / 7, RB = (RS + 1) / 2, NZ = 4;
-        const int lq = bf_launder(lane);
-        const int ol = min(bl_ol, 8), sl = bl_sl;
-        const int sv = wave * 3 + ol / 3, c = ol - (ol / 3) * 3;
-        const bool on = bl_ol < 9 && sv < ns;
-        const int o = (on ? sv : 0) * 3 + c;
-        const int p0 = sl * RS;
-        // skinning role: lane = (vertex vloc, row k, column b)
-        const int vloc = lq / 12, e12 = lq - vloc * 12, k = e12 >> 2, b = e12 & 3;
-        const int sv2 = wave * 3 + vloc;
-        const bool trl = lq < 36 && sv2 < ns;
-        const int sv2c = trl ? sv2 : 0;
-        float wq[NZ], aq[NZ];
-        int jq[NZ];
-#pragma unroll
-        for (int q = 0; q < NZ; ++q) { wq[q] = S.nzw[sv2c * BF_SEL_NNZ + q]; jq[q] = S.nzj[sv2c * BF_SEL_NNZ + q]; }
-        const float vs0 = S.vs[sv2c * 3 + (b < 3 ? b : 0)];
-        const float *A = b < 3 ? S.G + k * 4 + b : S.At + k;
-        const int stride = b < 3 ? 12 : 3;
-        float acc = 0.f;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float f[RB], w[RB];
-#pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const int p = min(p0 + h * RB + i, NPF - 1);
-                f[i] = S.feat[p];
-                w[i] = S.sel_pd2[p * (ns3 + 1) + o];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (h == 0) {
-#pragma unroll
-                for (int q = 0; q < NZ; ++q) aq[q] = A[jq[q] * stride];
-            }
-#pragma unroll
-            for (int i = 0; i < RB; ++i) acc += (h * RB + i < RS && p0 + h * RB + i < NPF ? f[i] : 0.f) * w[i];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        float *strip = S.vpp + wave * 64;              // this wave's 63 partials
-        strip[lq] = on ? acc : 0.f;
-        BF_WAVE_FENCE();
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < NZ; ++q) t += wq[q] * aq[q];
-        // pose-blended coordinate b of the lane's vertex: the seven slice partials in slot order
-        const float *pp = strip + (vloc * 3 + (b < 3 ? b : 0)) * 7;
-        float pr[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) pr[i] = pp[i];
-        float vpb = vs0;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) vpb += pr[i];
-        if (trl && b < 3) {
-            S.TR[sv2c * 9 + k * 3 + b] = t;
-            if (k == 0) S.vp[sv2c * 3 + b] = vpb;
-        }
-        float contrib = trl ? (b < 3 ? t * vpb : t) : 0.f;
-        contrib = quad_sum(contrib);
-        if (trl && b == 0) S.vsel[sv2c * 3 + k] = contrib;
-    };
+    // The pose blend and the skinning of the selector vertices (models with at most 12 selector vertices and at most 4 bones per
+    // selector vertex; the others take the two-phase path: 15 row slices over all 8 waves, then skinning).
+    const bool merge_bc = GBLEND && sel_nnz > 0 && sel_nnz <= 4 && ns3 * BF_PDT_LD <= npf * (ns3 + 1);
     // Round 3: the pose blend LEFT the geometry waves.  The GMM waves issue ~300 instructions per iteration against the geometry waves'
     // ~1,900, and the pose blend needs nothing but the pose feature, which is in LDS when the iteration starts (rotations_ahead):
     // every GMM wave blends its three selector vertices (the lane pattern of blend_and_skin: 9 coordinates x 7 row slices, partials
     // through a wave-private strip) into S.vp under the chain waves' phase A.  Phase B on the geometry waves is then the skinning
     // alone (skin_only).
-    const bool gblend = GBLEND && merge_bc;
     auto gmm_blend = [&]() {
-        constexpr int NPF = NJ > 0 ? 9 * (NJ - 1) : 8, RS = (NPF + 6) / 7, NH = 4, RB = (RS + NH - 1) / NH;      // (four batches of 8 rows: registers)
-        const int lq = bf_launder(lane);          // (fresh per iteration: the 30 row addresses below must not become loop invariants)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        constexpr int RS = BF_PDT_LD / 7, NP2 = RS / 2, NH = 3, PB = NP2 / NH;      // 30 rows = 15 row pairs in three batches of five
+        constexpr int NPF = NJ > 0 ? 9 * (NJ - 1) : 8;
+        static_assert(RS * 7 == BF_PDT_LD && NP2 * 2 == RS && PB * NH == NP2, "slice shape");
+        const int lq = bf_launder(lane);          // (fresh per iteration: the row addresses below must not become loop invariants)
         const int ol7 = lq / 7, ol = min(ol7, 8), sl = lq - ol7 * 7;
         const int sv = gwi * 3 + ol / 3, c = ol - (ol / 3) * 3;
         const bool on = ol7 < 9 && sv < ns;
         const int o = (on ? sv : 0) * 3 + c;
         const int p0 = sl * RS;
+        const f2 *fp = (const f2 *)__builtin_assume_aligned(S.feat + p0, 8);
+        const f2 *wp_ = (const f2 *)__builtin_assume_aligned(S.sel_pd2 + o * BF_PDT_LD + p0, 8);
         float acc = 0.f;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            float f[RB], w[RB];
+            f2 f[PB], w[PB];
 #pragma unroll
-            for (int i = 0; i < RB; ++i) {
-                const int p = min(p0 + h * RB + i, NPF - 1);
-                f[i] = S.feat[p];
-                w[i] = S.sel_pd2[p * (ns3 + 1) + o];
+            for (int i = 0; i < PB; ++i) { f[i] = fp[h * PB + i]; w[i] = wp_[h * PB + i]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                // (rows past the end of the pose feature: the table holds zeros there, the feature's slot whatever follows it in LDS)
+                const int p = p0 + 2 * (h * PB + i);
+                acc += (p < NPF ? f[i].x : 0.f) * w[i].x;
+                acc += (p + 1 < NPF ? f[i].y : 0.f) * w[i].y;
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < RB; ++i) acc += (h * RB + i < RS && p0 + h * RB + i < NPF ? f[i] : 0.f) * w[i];
-            __builtin_amdgcn_sched_barrier(0);
         }
-        float *strip = S.vpp + (4 + gwi) * 64;         // this wave's 63 partials (the geometry waves' strips are 0-3)
+        float *strip = S.vpp + (4 + gwi) * 64;         // this wave's 63 partials
         strip[lq] = on ? acc : 0.f;
         BF_WAVE_FENCE();
         // lanes 0-8: coordinate lq of the wave's three vertices = shaped vertex + the seven slice partials in slot order
@@ -850,7 +796,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_DMARK(58);
     };
 
-#ifndef BF_NO_GMM
     if (gw) {
         // ================= GMM specialists (waves 4-7): the precision rows never leave their registers
         v2f P2[BF_GMM_LD];                      // (row `lane` of component a, of component b), column j
@@ -883,7 +828,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             ((v2f *)gdw)[lane] = dA;                   // LDS copy, interleaved (d_a[j], d_b[j]) pairs: one b128 = two columns
             if (lane < BF_GMM_LD - 64) ((v2f *)gdw)[64 + lane] = dB;
             BF_WAVE_FENCE();
-            if (gblend) { gmm_blend(); BF_MARK(42, 256, it, t_iter); }
+            if (merge_bc) { gmm_blend(); BF_MARK(42, 256, it, t_iter); }
             v2f y0 = {0.f, 0.f}, y1 = {0.f, 0.f};
 #define BF_GMM_CHUNK(c)                                                                         \
             _Pragma("unroll") for (int j2 = 4 * (c); j2 < 4 * (c) + 4; ++j2) {                  \
@@ -894,15 +839,18 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             }
             constexpr bool GMM_FG = NJ > 0 && NJ <= 32 && NS > 0 && NS * 3 <= 36;     // (= MERGE_FG of the geometry loop)
             BF_GMM_CHUNK(0)
-            BF_GMM_CHUNK(1)
-            BF_GMM_CHUNK(2)
+            if (!merge_bc) {
+                BF_GMM_CHUNK(1)
+                BF_GMM_CHUNK(2)
+            }
             BF_SYNC();                 // A
             if (EXT && door) door_mid(it, Pcur);
             if (merge_bc) {
-                // (the geometry waves do the merged pose blend + skinning alone)
+                // (this wave blended its selector vertices in phase A; the geometry waves skin them now: a short phase)
+                BF_GMM_CHUNK(1)
+                BF_GMM_CHUNK(2)
                 BF_GMM_CHUNK(3)
-                BF_GMM_CHUNK(4)
-                BF_GMM_CHUNK(5)
+                BF_MARK(49, 256, it, t_iter);
             } else {
                 pose_blend(std::integral_constant<int, 2>());
                 BF_SYNC();             // B
@@ -911,11 +859,20 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 BF_GMM_CHUNK(5)
             }
             BF_SYNC();                 // C
-            BF_SYNC();                 // D (+E): projection, view reduction and routing: VALU-bound on the geometry waves, no GMM here
-            BF_GMM_CHUNK(6)
+            if (merge_bc) {            // D (+E): projection, view reduction and routing on the geometry waves: the rest of the mat-vec
+                BF_GMM_CHUNK(4)
+                BF_GMM_CHUNK(5)
+                BF_GMM_CHUNK(6)
+                BF_GMM_CHUNK(7)
+                BF_GMM_CHUNK(8)
+            }
+            BF_SYNC();
+            if (!merge_bc) { BF_GMM_CHUNK(6) }
             if (!GMM_FG) BF_SYNC();    // F (two-phase path only)
-            BF_GMM_CHUNK(7)
-            BF_GMM_CHUNK(8)
+            if (!merge_bc) {
+                BF_GMM_CHUNK(7)
+                BF_GMM_CHUNK(8)
+            }
 #undef BF_GMM_CHUNK
             const v2f y = y0 + y1;
             const float ya = y.x, yb = y.y;
@@ -949,6 +906,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 S.gq[ma] = 0.5f * ta + logw_a;       // prior.py:188-189
                 S.gq[mb] = 0.5f * tb + logw_b;
             }
+            BF_MARK(48, 256, it, t_iter);
             BF_SYNC();                 // G (+H)
             if (!(NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36)) {     // (two-phase I, K path only)
             if (tid == 256) {                        // arg-min GMM component (prior.py:195) for the Adam phase
@@ -963,9 +921,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             BF_SYNC();                 // K
             if (mode == 0) { float *sw = Pcur; Pcur = Pnext; Pnext = sw; }
         }
-    } else
-#endif
-    {
+    } else {
     // ================= geometry waves (0-3)
     for (int it = 0; it < n_iters; ++it) {
 #ifdef BF_STAMP
@@ -986,16 +942,18 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 // (SMPL: the joint's parameter offset is arithmetic; kept in a register across the loop it gets spilled and the
                 //  reload delays the first read of the chain)
                 const int woff = NJ == 24 ? (wjq > 0 ? T.off_pose + 3 * (wjq - 1) : T.off_orient) : w_off;
-                if (NJ == 24 || w_kind == 0) { th0 += Pcur[woff]; th1 += Pcur[woff + 1]; th2 += Pcur[woff + 2]; }
+                if (ROT_AHEAD) { }
+                else if (NJ == 24 || w_kind == 0) { th0 += Pcur[woff]; th1 += Pcur[woff + 1]; th2 += Pcur[woff + 2]; }
                 else if (NJ != 24 && w_kind >= 2) { th0 = theta_of(Pcur, wj, 0); th1 = theta_of(Pcur, wj, 1); th2 = theta_of(Pcur, wj, 2); }
                 // rel_j = J_j - J_parent (rel_0 = J_0) was formed from the betas by wave 3 at the end of the previous
                 // iteration (or in the prologue); read it before the Rodrigues arithmetic so the latency hides under it
-                const float a0 = S.rel[wjq * 3], a1 = S.rel[wjq * 3 + 1], a2 = S.rel[wjq * 3 + 2];
-                jj0 = S.J[wjq * 3]; jj1 = S.J[wjq * 3 + 1]; jj2 = S.J[wjq * 3 + 2];
+                float a0, a1, a2;
                 if (ROT_AHEAD) {
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) Ri[e] = S.R[wjq * 9 + e];
-                }
+                    const float4 l0 = *(const float4 *)(S.L + wjq * 12), l1 = *(const float4 *)(S.L + wjq * 12 + 4), l2 = *(const float4 *)(S.L + wjq * 12 + 8);
+                    Ri[0] = l0.x; Ri[1] = l0.y; Ri[2] = l0.z; Ri[3] = l1.x; Ri[4] = l1.y; Ri[5] = l1.z; Ri[6] = l2.x; Ri[7] = l2.y; Ri[8] = l2.z;
+                    a0 = l0.w; a1 = l1.w; a2 = l2.w;
+                } else { a0 = S.rel[wjq * 3]; a1 = S.rel[wjq * 3 + 1]; a2 = S.rel[wjq * 3 + 2]; }
+                jj0 = S.J[wjq * 3]; jj1 = S.J[wjq * 3 + 1]; jj2 = S.J[wjq * 3 + 2];
                 __builtin_amdgcn_sched_barrier(0);
                 if (!ROT_AHEAD) {
                 rodrigues_fwd(th0, th1, th2, Ri, rc);
@@ -1074,7 +1032,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
         if (merge_bc) {
             // ================= phase B (+C): pose blend and skinning of the selector vertices in one phase
-            if (gblend) skin_only(); else blend_and_skin();
+            skin_only();
         } else {
         {
         // ================= phase B: pose blend of the selector vertices, partial sums over row slices
@@ -1253,7 +1211,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         BF_WAVE_FENCE();
         // d(pose feature) = sel_pd . dvp: all of it on wave 3 (dvp stays in its registers across the passes), in the shadow of
         // the row waves
+        BF_MARK(46, 0, it, t_iter);
         if (wave == 3) dfeat_rows(strip, lq, npf, 64);
+        BF_MARK(47, 192, it, t_iter);
         BF_SYNC();
         } else {
         {

@@ -401,7 +401,7 @@ static int group_comm(bf_group *g) {
     for (int i = 0; i < g->n && ok; ++i) {
         bf_group_peer &p = g->peers[i];
         ok = hipSetDevice(p.device) == hipSuccess && p.send.alloc(blk) == hipSuccess && p.recv.alloc(blk * g->n) == hipSuccess &&
-             hipMemset(p.send.p, 0, blk * sizeof(float)) == hipSuccess;
+             bf_memset_sync(p.send.p, 0, blk * sizeof(float)) == hipSuccess;
     }
     if (!ok) {                                    // (a retry must not find half a communicator)
         for (int i = 0; i < g->n; ++i) {
@@ -547,7 +547,7 @@ int bf_comm_gather_params(bf_comm *c, bf_batch *b, int n_frames, float *params) 
         if (c->recv.p) { (void)hipFree(c->recv.p); c->recv.p = nullptr; }
         HIP_TRY(c->send.alloc(blk));
         HIP_TRY(c->recv.alloc(blk * c->world));
-        HIP_TRY(hipMemset(c->send.p, 0, blk * sizeof(float)));
+        HIP_TRY(bf_memset_sync(c->send.p, 0, blk * sizeof(float)));
         c->host.resize(blk * c->world);
     }
     int rc = bf_guard_arena(b);

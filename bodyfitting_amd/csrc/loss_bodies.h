@@ -144,6 +144,7 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
             float w = 1.f;
             if (src >= Q.nj) {
                 if (src < n_ori) { if (c == 0) vid = Q.selector_ids[src - Q.nj]; }
+                else if (src < n_ori + Q.n_extra) { }                  // a regressed joint: every vertex of its row, below
                 else {
                     const size_t l = ((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c;
                     vid = lmk_vid[l];
@@ -179,6 +180,22 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
         }
         float *o = dv + (size_t)vid * 3;
         o[0] += a0; o[1] += a1; o[2] += a2;
+    }
+    // loss joints that come from J_regressor_extra (models/smpl.py:72: joint = row . vertices): every vertex of the row gets its
+    // weight times the joint's gradient.  Joint after joint in loss-joint order, a vertex always by the same thread, after the
+    // runs above: a fixed order of additions.  (No reference model has such a joint among the SMPL-X loss joints; the ABI allows it.)
+    if (Q.n_extra > 0) {
+        __syncthreads();
+        for (int q = 0; q < nl; ++q) {
+            const int src = Q.joint_map[q];
+            if (src < n_ori || src >= n_ori + Q.n_extra) continue;
+            const float *row = Q.j_extra + (size_t)(src - n_ori) * Q.nv;
+            const float gq0 = s_g[q * 4], gq1 = s_g[q * 4 + 1], gq2 = s_g[q * 4 + 2];
+            for (int v = tid; v < Q.nv; v += 512) {
+                const float w = row[v];
+                if (w != 0.f) { float *o = dv + (size_t)v * 3; o[0] += w * gq0; o[1] += w * gq1; o[2] += w * gq2; }
+            }
+        }
     }
 }
 

@@ -216,7 +216,7 @@ int bf_ensure_dense_buffers(bf_batch *b) {
                   b->lmk_w.alloc(F * std::max(m->n_lmk, 1) * 3) == hipSuccess &&
                   b->pc_partial.alloc(F * ((m->nv + 255) / 256)) == hipSuccess && b->pc_loss.alloc(F) == hipSuccess;
         if (!ok) return fail(BF_ERR_HIP, "dense-loss buffers: device allocation failed");
-        HIP_TRY(hipMemset(b->ext.p, 0, b->ext.n * sizeof(float)));
+        HIP_TRY(bf_memset_sync(b->ext.p, 0, b->ext.n * sizeof(float)));
     }
     {
         // [3NV][npf] transpose for the reverse pass (thread = pose-feature row, contiguous reads), built on the device once per
@@ -457,7 +457,7 @@ static int ensure_fit_stream(bf_batch *b, const FrameIO &io, const HyperDev &hd)
     HIP_TRY(hipStreamSynchronize(b->fit_stream));
     // ... and checked: do the two streams really run side by side? (bf_door_probe_kernel)
     HIP_TRY(hipStreamSynchronize(b->stream));
-    HIP_TRY(hipMemset(b->door.p, 0, BF_DOOR_STATE * sizeof(int)));
+    HIP_TRY(bf_memset_sync(b->door.p, 0, BF_DOOR_STATE * sizeof(int)));
     hipLaunchKernelGGL(bf_door_probe_kernel, dim3(1), dim3(64), 0, b->fit_stream, b->door.p);
     hipLaunchKernelGGL(bf_door_ring_kernel, dim3(1), dim3(64), 0, b->stream, b->door.p);
     HIP_TRY(hipGetLastError());
@@ -704,6 +704,16 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
         b->mk_select = contour_select;
         HIP_TRY(ensure(b->mk_slab, fm * 2 * (size_t)b->mk_cap * 2));
         HIP_TRY(ensure(b->mk_cnt2, 2 * fm));
+        for (float *q : b->mk_retired) (void)hipFree(q);          // (buffers a finalize inside a fit could not free: see there)
+        b->mk_retired.clear();
+        // everything bf_masks_finalize fills is sized NOW, for borders as long as the slab holds: it runs in the middle of a fit, with
+        // the resident fit launch waiting for kernels that are not enqueued yet - a hipFree there (it waits for the device) would
+        // never return
+        {
+            const size_t cap = (size_t)b->mk_cap;
+            HIP_TRY(ensure(b->mk_cxy, fm * cap * 2)); HIP_TRY(ensure(b->mk_choice, fm * cap)); HIP_TRY(ensure(b->mk_cgrad, fm * cap * 2));
+            HIP_TRY(ensure(b->mk_part, fm * (pblocks + (cap * 16 + 255) / 256)));
+        }
         hipStream_t cs = b->copy_stream;
         HIP_TRY(hipMemcpyAsync(b->mk_masks.p, b->h_masks, npix, hipMemcpyHostToDevice, cs));
         hipLaunchKernelGGL(bf_contour_kernel, dim3((unsigned)fm), dim3(256), in_lds ? plane_bytes : 0, cs, (const unsigned char *)b->mk_masks.p, H, W,
@@ -748,11 +758,19 @@ int bf_masks_finalize(bf_batch *b) {
     int longest = 0;
     for (size_t i = 0; i < fm; ++i) longest = std::max(longest, b->h_ccount[i]);
     if (longest > b->mk_cap) {
-        // a border longer than the slab (4 (H + W) points): follow again with room for it (rare: synchronously)
+        // A border longer than the slab (more than 4 (H + W) points; the kernel counted it without storing): follow again with room
+        // for it.  This may be the middle of a fit whose resident launch waits for kernels that are not enqueued yet, so nothing is
+        // FREED here (hipFree waits for the device): the outgrown buffers are retired and freed by the next bf_batch_set_masks.
+        auto regrow = [&](auto &buf, size_t count) -> hipError_t {
+            if (buf.p && !buf.view) b->mk_retired.push_back((float *)(void *)buf.p);
+            buf.p = nullptr;
+            return buf.alloc(count);
+        };
         b->mk_cap = longest;
-        HIP_TRY(hipStreamSynchronize(b->copy_stream));
-        if (b->mk_slab.p) { (void)hipFree(b->mk_slab.p); b->mk_slab.p = nullptr; }
-        HIP_TRY(b->mk_slab.alloc(fm * 2 * (size_t)b->mk_cap * 2));
+        const size_t cap = (size_t)longest;
+        HIP_TRY(regrow(b->mk_slab, fm * 2 * cap * 2));
+        HIP_TRY(regrow(b->mk_cxy, fm * cap * 2)); HIP_TRY(regrow(b->mk_choice, fm * cap)); HIP_TRY(regrow(b->mk_cgrad, fm * cap * 2));
+        HIP_TRY(regrow(b->mk_part, fm * (K.proj_blocks + (cap * 16 + 255) / 256)));
         const int wpr = (K.W + 31) / 32;
         const size_t plane_bytes = (size_t)3 * K.H * wpr * sizeof(unsigned);
         const bool in_lds = plane_bytes <= 150 * 1024;
@@ -762,18 +780,10 @@ int bf_masks_finalize(bf_batch *b) {
         HIP_TRY(hipMemcpyAsync(b->h_ccount, b->mk_cnt2.p, 2 * fm * sizeof(int), hipMemcpyDeviceToHost, b->copy_stream));
         HIP_TRY(hipStreamSynchronize(b->copy_stream));
     }
-    auto ensure = [](auto &buf, size_t count) -> hipError_t {
-        if (buf.p && buf.n >= count && !buf.view) return hipSuccess;
-        if (buf.p && !buf.view) (void)hipFree((void *)buf.p);
-        buf.p = nullptr;
-        return buf.alloc(count);
-    };
     std::vector<int> start(fm);
     int total = 0, cmax = 1;
     for (size_t i = 0; i < fm; ++i) { start[i] = total; total += b->h_ccount[i]; cmax = std::max(cmax, b->h_ccount[i]); }
     const int stride = K.proj_blocks + (cmax * 16 + 255) / 256;
-    HIP_TRY(ensure(b->mk_cxy, (size_t)std::max(total, 1) * 2));
-    HIP_TRY(ensure(b->mk_choice, fm * cmax)); HIP_TRY(ensure(b->mk_cgrad, fm * cmax * 2)); HIP_TRY(ensure(b->mk_part, fm * stride));
     int *h = b->h_ccount;                                     // [0, fm): lengths; [fm, 2 fm): halves -> reused below for the offsets
     std::vector<int> half(h + fm, h + 2 * fm);
     for (size_t i = 0; i < fm; ++i) h[fm + i] = start[i];

@@ -188,7 +188,7 @@ static int tex_set_mesh(bf_texfit *x, int which, int n_verts, const float *verts
     *M.h_total = 0;
     if (which == 1) {
         HIP_TRY(M.m.alloc(ntex)); HIP_TRY(M.v.alloc(ntex)); HIP_TRY(M.grad.alloc(ntex));
-        HIP_TRY(hipMemset(M.m.p, 0, ntex * sizeof(float))); HIP_TRY(hipMemset(M.v.p, 0, ntex * sizeof(float)));
+        HIP_TRY(bf_memset_sync(M.m.p, 0, ntex * sizeof(float))); HIP_TRY(bf_memset_sync(M.v.p, 0, ntex * sizeof(float)));
         M.adam = true;
         x->steps = 0;
     }

@@ -140,7 +140,12 @@ def smplx_forward(m, betas, global_orient, body_pose, leye_pose, reye_pose, left
     tri = m["faces"][lmk_faces]                                                                               # [B,68,3]
     lv = torch.stack([verts[b][tri[b]] for b in range(B)])                                                    # [B,68,3,3]
     landmarks = torch.einsum("blfi,blf->bli", lv, lmk_bary)
-    joints = torch.cat([chain_j, verts[:, m["selector_ids"]], landmarks], dim=1)                              # 55 + 21 + 68
+    parts = [chain_j, verts[:, m["selector_ids"]]]                                                              # 55 + 21
+    if "J_regressor_extra" in m and m["J_regressor_extra"].shape[0] > 0:
+        # (not a reference configuration: smplx has no extra regressor; the ABI's all-joints layout puts such rows here, as
+        #  models/smpl.py:72-75 does for SMPL)
+        parts.append(torch.einsum("bik,ji->bjk", verts, m["J_regressor_extra"]))
+    joints = torch.cat(parts + [landmarks], dim=1)                                                              # ... + 68
     return {"vertices": verts, "joints": joints[:, m["joint_map"]] if mapped else joints, "full_pose": full_pose, "dyn_row": y}
 
 

@@ -227,6 +227,43 @@ def test_set_masks_extracts_the_contours_itself(dev_model, smpl_model):
     assert np.isfinite(out[0][0]).all() and out[0][0][0] > 0
 
 
+def test_border_longer_than_the_first_slab_inside_a_fit(dev_model, smpl_model):
+    """A comb: its outer border has far more than 4 (H + W) points, so the contour kernel's first slab is too short and the
+    deferred second half of bf_batch_set_masks (which runs in the MIDDLE of the fit, under the resident fit launch, where nothing
+    may be freed) has to follow the border again with room for it.  Same loss, gradient and fitted parameters, bit for bit, as
+    with the contours handed over by the caller."""
+    from bodyfitting_amd import _lib
+    from bodyfitting_amd.contours import extract_contours as device_contours
+    prob = S.make_problem(smpl_model, frame=0, n_views=8, mask_frames=MASK_FRAMES)
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
+    masks = np.array(prob["masks"])[None].copy()
+    H, W = masks.shape[-2:]
+    comb = np.zeros((H, W), np.uint8)
+    comb[H // 8: 7 * H // 8, W // 8: 7 * W // 8: 2] = 255          # teeth, one pixel wide, every other column
+    comb[7 * H // 8 - 2: 7 * H // 8, W // 8: 7 * W // 8] = 255      # the back of the comb joins them: one component
+    masks[0, 1] = comb
+    view_index = [prob["use_frames"].index(f) for f in prob["mask_frames"]]
+    given = [device_contours(masks[0] > 128)]
+    assert len(given[0][1]) > 4 * (H + W)
+    out = []
+    for contours in (None, given, None):
+        b = N.FrameBatch(dev_model, 1, c2w.shape[1])
+        b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+        b.set_masks(masks, view_index, contours)
+        if len(out) < 2:
+            loss, dv = b.mask_loss()
+        b.fit(9, N.make_hyper(dense_after=3))                         # (the border is read from iteration 5 on)
+        out.append((loss, dv, b.get_params().copy()))
+        # a second frame's masks on the same batch: the outgrown buffers are retired, not leaked or reused
+        b.set_masks(np.array(prob["masks"])[None], view_index, None)
+        b.fit(9, N.make_hyper(dense_after=3), flags=_lib.FIT_RESET | _lib.FIT_FETCH)
+        assert np.isfinite(b.get_params()).all()
+        b.close()
+    for k in range(3):
+        np.testing.assert_array_equal(out[0][k], out[1][k])
+    np.testing.assert_array_equal(out[0][2], out[2][2])
+
+
 def test_two_frames_device_contours_match_single_frames(dev_model, smpl_model):
     """F = 2 with different silhouettes, contours extracted on the device for all F x M masks in one launch:
     each frame's loss and gradient are bit for bit those of the frame alone"""

@@ -230,7 +230,7 @@ def test_dense_fit_is_the_same_bits_run_to_run(sx):
         np.testing.assert_array_equal(v, runs[0][1])
 
 
-def test_sub_model_keeps_every_vertex_of_the_extra_regressor():
+def test_sub_model_keeps_every_vertex_of_the_extra_regressor(gmm_bufs):
     """An SMPL-X-kind model WITH a J_regressor_extra (the ABI allows it, models/smpl.py:62-64 is where SMPL gets its own): the dense
     loop's sampled-first sub-model must contain every vertex that carries regressor weight, or the extra joints - here three of the
     loss joints - would be formed from partial sums.  Sub-model on == off (float32 summation order apart)."""
@@ -250,6 +250,17 @@ def test_sub_model_keeps_every_vertex_of_the_extra_regressor():
     model["joint_map"] = jm
     dev = N.DeviceModel(model, S.make_gmm(seed=0), device=0)
     prob = S.make_problem_smplx(S.make_model("smplx", seed=0), frame=0, n_views=8)
+    # the regressed loss joints' gradient reaches every vertex of their rows: against autograd of the fp64 restatement
+    P = _params(prob)
+    b = _batch(dev, prob)
+    b.set_params(N.pack_params(P)[None])
+    terms, grads = b.loss_grad()
+    b.close()
+    _, t64, g64, _, _, _ = O.smplx_loss_and_grad(model, gmm_bufs, prob, P)
+    assert terms[0, 0] == pytest.approx(t64["reprojection_loss"], rel=3e-6)
+    got = N.split_params(grads[0])
+    for k in O.SMPLX_PARAMS:
+        np.testing.assert_allclose(got[k], g64[k], atol=1e-5 * np.abs(g64[k]).max(), err_msg=k)
     out = {}
     for flag in ("1", "0"):
         os.environ["BF_DENSE_SUBMODEL"] = flag
