@@ -62,6 +62,9 @@ struct FitSmem {
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
+#ifndef BF_DFEAT_ON_GMM
+#define BF_DFEAT_ON_GMM 1
+#endif
 #define BF_PDT_LD 210      // row stride of the transposed selector posedirs: 7 slices of 30 rows
 
 // Carve the dynamic LDS segment; the same function sizes it on the host (base == nullptr).
@@ -375,20 +378,16 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const bool gw = wave >= 4;
     const int gwi = gw ? wave - 4 : 0;
     const int ma = 2 * gwi, mb = 2 * gwi + 1;
-    const int tpiece = lane < 60 ? lane : 59;
     // d = theta - mu of a wave's two components sits interleaved in LDS, (d_a[j], d_b[j]) pairs, so one b128 read
     // feeds two packed FMAs (v_pk_fma_f32) with no register shuffling
     float *gdw = S.gd + gwi * 2 * BF_GMM_LD;
-    const int tail_c = tpiece < 30 ? 0 : 1;
-    const float4 *tail_d = (const float4 *)(gdw + 2 * 12 * (tpiece % 6));
     const float logw_a = T.g_logw[ma], logw_b = T.g_logw[mb];
-    int gd_src[2];                            // parameter index of theta_j for j = lane and j = 64 + lane (-1: zero pad)
     float gd_mu[4];                           // mu_a[lane], mu_b[lane], mu_a[64 + lane], mu_b[64 + lane]
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int j = lane + 64 * q;
         const bool ok = gw && j < BF_GMM_D;
-        gd_src[q] = (ok && j < T.nbp) ? T.off_pose + j : -1;       // smplx pads 63 -> 69 with zeros (loss.py:207)
+        // (theta_j itself: parameter T.off_pose + j for j < T.nbp, else the zero pad - smplx pads 63 -> 69, loss.py:207)
         gd_mu[2 * q] = ok ? T.g_means[ma * BF_GMM_D + j] : 0.f;
         gd_mu[2 * q + 1] = ok ? T.g_means[mb * BF_GMM_D + j] : 0.f;
     }
@@ -596,7 +595,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     };
     // The pose blend and the skinning of the selector vertices (models with at most 12 selector vertices and at most 4 bones per
     // selector vertex; the others take the two-phase path: 15 row slices over all 8 waves, then skinning).
-    const bool merge_bc = GBLEND && sel_nnz > 0 && sel_nnz <= 4 && ns3 * BF_PDT_LD <= npf * (ns3 + 1);
+    // (bf_fit_launch picks a GBLEND instance only for models whose selector vertices have at most BF_SEL_NNZ = 4 bones; the others
+    //  take the table-driven instance, whose pose blend is the two-phase one)
+    constexpr bool merge_bc = GBLEND;
+    static_assert(!GBLEND || NS * 3 * BF_PDT_LD <= 9 * (NJ - 1) * (NS * 3 + 1), "the transposed selector posedirs fit the sel_pd2 slot");
     // Round 3: the pose blend LEFT the geometry waves.  The GMM waves issue ~300 instructions per iteration against the geometry waves'
     // ~1,900, and the pose blend needs nothing but the pose feature, which is in LDS when the iteration starts (rotations_ahead):
     // every GMM wave blends its three selector vertices (the lane pattern of blend_and_skin: 9 coordinates x 7 row slices, partials
@@ -646,6 +648,63 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #pragma unroll
         for (int i = 0; i < 7; ++i) vpb += pr[i];
         if (on9) S.vp[oo] = vpb;
+    };
+    // d(pose feature) = sel_pd . dvp in phase F, a quarter of the rows per GMM wave (their prior is complete by then: phase D).  dvp =
+    // T_s^T dvsel is formed by the wave itself (lanes 0..3 ns - 1, wave 3's arithmetic) and crosses lanes through the wave's strip;
+    // rows and dvp are consumed in 8-column pieces (registers), in column order: the bits of dfeat_rows.
+    auto gmm_dfeat = [&]() {
+        constexpr int NO = NS > 0 ? NS * 3 : 1, NQ = (NO + 3) / 4, RW = NJ > 0 ? (9 * (NJ - 1) + 3) / 4 : 1;     // rows per wave
+        const int lq = bf_launder(lane);
+        float *strip = S.vpp + (4 + gwi) * 64;
+        {
+            const int o = min(lq, NO - 1), sv = o / 3, bb = o - sv * 3;
+            const float dvp = S.TR[sv * 9 + bb] * S.dvsel[sv * 3] + S.TR[sv * 9 + 3 + bb] * S.dvsel[sv * 3 + 1] +
+                              S.TR[sv * 9 + 6 + bb] * S.dvsel[sv * 3 + 2];
+            if (lq < NQ * 4) strip[lq] = lq < NO ? dvp : 0.f;
+        }
+        BF_WAVE_FENCE();
+        const int p = gwi * RW + lq;
+        const bool on = lq < RW && p < npf;
+        const float4 *row = (const float4 *)__builtin_assume_aligned(S.sel_pd + (on ? p : 0) * pd_ld, 16);
+        const float4 *dq = (const float4 *)__builtin_assume_aligned(strip, 16);
+        float acc = 0.f;
+#pragma unroll
+        for (int h = 0; h < NQ; ++h) {
+            const float4 rq = row[h], dv4 = dq[h];
+            __builtin_amdgcn_sched_barrier(0);
+            if (h * 4 < NO) acc += rq.x * dv4.x;
+            if (h * 4 + 1 < NO) acc += rq.y * dv4.y;
+            if (h * 4 + 2 < NO) acc += rq.z * dv4.z;
+            if (h * 4 + 3 < NO) acc += rq.w * dv4.w;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (on) S.dfeat[p] = ext ? acc + ext[p] : acc;
+    };
+    // What the pose priors add to dL/dtheta, per body dof, for the Adam phase (wave 3, phase F - all eight q values are in LDS
+    // since the barrier behind phase D): the arg-min component (prior.py:195), w_pose * y of that component, and the angle prior's
+    // term (loss.py:54-61: dofs 52, 55, 9, 12; the sign is 0 everywhere else, which zeroes it exactly).  The lane that steps a joint
+    // then adds two LDS values per dof instead of taking the arg-min and three exponentials on the critical path of the iteration.
+    auto gmm_prior_grad = [&]() {
+        const int lq = bf_launder(lane);
+        float gq[BF_GMM_M];
+#pragma unroll
+        for (int m = 0; m < BF_GMM_M; ++m) gq[m] = S.gq[m];
+        int ms = 0;
+        float qm = gq[0];
+#pragma unroll
+        for (int m = 1; m < BF_GMM_M; ++m) if (gq[m] < qm) { qm = gq[m]; ms = m; }
+        if (lq == 0) { S.scal[1] = (float)ms; S.scal[2] = qm; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int pb = lq + 64 * q;
+            if (pb < T.nbp && pb < BF_GMM_D) {
+                const float gyv = S.gy[ms * BF_GMM_LD + pb], pv = Pcur[T.off_pose + pb];
+                const float sg = (pb == 52 ? 1.f : 0.f) - (pb == 55 ? 1.f : 0.f) - (pb == 9 ? 1.f : 0.f) - (pb == 12 ? 1.f : 0.f);
+                const float ex = __expf(pv * sg);
+                S.gtail[pb] = hp.w_pose * gyv;
+                S.gtail[BF_GMM_LD + pb] = hp.w_angle * 2.f * ex * ex * sg;
+            }
+        }
     };
     // phase B when the GMM waves blend: T_s = sum_j w_sj A_j of the wave's three vertices (lanes 0-35: vertex, row k, column b),
     // skinned vertex = T_s [vp | 1]
@@ -798,10 +857,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 
     if (gw) {
         // ================= GMM specialists (waves 4-7): the precision rows never leave their registers
-        v2f P2[BF_GMM_LD];                      // (row `lane` of component a, of component b), column j
+        v2f P2[GBLEND ? BF_GMM_D : BF_GMM_LD];                       // (row `lane` of component a, of component b), column j (the padding columns meet d = 0: not kept)
         float Pt[12];
 #pragma unroll
-        for (int j = 0; j < BF_GMM_LD; ++j) {
+        for (int j = 0; j < (GBLEND ? BF_GMM_D : BF_GMM_LD); ++j) {
             P2[j].x = T.g_plane[((size_t)ma * BF_GMM_LD + j) * 64 + lane];
             P2[j].y = T.g_plane[((size_t)mb * BF_GMM_LD + j) * 64 + lane];
         }
@@ -819,10 +878,14 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             // the Adam phase and costs one wave ~3000 cycles, so it is cut into eight-column chunks, one or two per phase:
             // it never holds a barrier up and runs in the issue slots the geometry waves leave free.
             v2f dA = {0.f, 0.f}, dB = {0.f, 0.f};       // (d_a[lane], d_b[lane]) and (d_a[64 + lane], d_b[64 + lane])
-            if (gd_src[0] >= 0) { const float th = Pcur[gd_src[0]]; dA.x = th - gd_mu[0]; dA.y = th - gd_mu[1]; }
+            // (the parameter index of theta_j, j = lane and 64 + lane, is re-derived from the lane here: -1 = zero pad; kept across the
+            //  loop it costs two of the registers the pinned rows need)
+            const int lq0 = bf_launder(lane);
+            const int src0 = lq0 < T.nbp ? T.off_pose + lq0 : -1, src1 = 64 + lq0 < T.nbp ? T.off_pose + 64 + lq0 : -1;
+            if (src0 >= 0) { const float th = Pcur[src0]; dA.x = th - gd_mu[0]; dA.y = th - gd_mu[1]; }
             else { dA.x = -gd_mu[0]; dA.y = -gd_mu[1]; }
             if (lane < BF_GMM_D - 64) {
-                const float th = gd_src[1] >= 0 ? Pcur[gd_src[1]] : 0.f;
+                const float th = src1 >= 0 ? Pcur[src1] : 0.f;
                 dB.x = th - gd_mu[2]; dB.y = th - gd_mu[3];
             }
             ((v2f *)gdw)[lane] = dA;                   // LDS copy, interleaved (d_a[j], d_b[j]) pairs: one b128 = two columns
@@ -834,78 +897,102 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             _Pragma("unroll") for (int j2 = 4 * (c); j2 < 4 * (c) + 4; ++j2) {                  \
                 const float4 t = d4[j2];                                                        \
                 const v2f t0 = {t.x, t.y}, t1 = {t.z, t.w};                                     \
-                y0 += P2[2 * j2] * t0;                                                          \
-                y1 += P2[2 * j2 + 1] * t1;                                                      \
+                if (2 * j2 < (GBLEND ? BF_GMM_D : BF_GMM_LD)) y0 += P2[2 * j2] * t0;            \
+                if (2 * j2 + 1 < (GBLEND ? BF_GMM_D : BF_GMM_LD)) y1 += P2[2 * j2 + 1] * t1;    \
             }
             constexpr bool GMM_FG = NJ > 0 && NJ <= 32 && NS > 0 && NS * 3 <= 36;     // (= MERGE_FG of the geometry loop)
+            // The chunk schedule.  Instances whose GMM waves also blend (GBLEND: SMPL): chunk 0 in A, 1-8 in the short phase B, the rest of
+            // the prior in D (the projection phase), so that phase F finds all eight q values in LDS.  The other instances: 0-2
+            // in A, 3-5 in B / C, 6-8 and the rest in F (the Adam phase K takes the arg-min itself).
             BF_GMM_CHUNK(0)
-            if (!merge_bc) {
+            if (!GBLEND) {
                 BF_GMM_CHUNK(1)
                 BF_GMM_CHUNK(2)
             }
             BF_SYNC();                 // A
             if (EXT && door) door_mid(it, Pcur);
-            if (merge_bc) {
-                // (this wave blended its selector vertices in phase A; the geometry waves skin them now: a short phase)
+            if (!merge_bc) {           // (two-phase pose blend: everybody takes row slices)
+                pose_blend(std::integral_constant<int, 2>());
+                BF_SYNC();             // B
+            }
+            if (GBLEND) {              // (the geometry waves wait on LDS in this phase: a chunk costs ~70 cycles here, ~300 under the projection)
                 BF_GMM_CHUNK(1)
                 BF_GMM_CHUNK(2)
                 BF_GMM_CHUNK(3)
-                BF_MARK(49, 256, it, t_iter);
-            } else {
-                pose_blend(std::integral_constant<int, 2>());
-                BF_SYNC();             // B
-                BF_GMM_CHUNK(3)
-                BF_GMM_CHUNK(4)
-                BF_GMM_CHUNK(5)
-            }
-            BF_SYNC();                 // C
-            if (merge_bc) {            // D (+E): projection, view reduction and routing on the geometry waves: the rest of the mat-vec
                 BF_GMM_CHUNK(4)
                 BF_GMM_CHUNK(5)
                 BF_GMM_CHUNK(6)
                 BF_GMM_CHUNK(7)
                 BF_GMM_CHUNK(8)
+                // the order of issue for the eight chunks above: the reads of two chunks in flight, not of all eight (32 b128 = 128 registers
+                // next to 150 pinned ones); 0x100 = LDS reads, 0x002 = VALU
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int c = 0; c < 7; ++c) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                BF_MARK(49, 256, it, t_iter);
+            } else {
+                BF_GMM_CHUNK(3)
+                BF_GMM_CHUNK(4)
+                BF_GMM_CHUNK(5)
+            }
+            BF_SYNC();                 // C
+            // the rest of the prior once the mat-vec is complete: y -> LDS, the twelve-column tail pieces, the two quadratic forms
+            auto gmm_finish = [&]() {
+                const int tpq = min(bf_launder(lane), 59), tail_cq = tpq < 30 ? 0 : 1;          // (re-derived per iteration: registers)
+                const float4 *tail_dq = (const float4 *)(gdw + 2 * 12 * (tpq % 6));
+
+                const v2f y = y0 + y1;
+                const float ya = y.x, yb = y.y;
+                S.gy[ma * BF_GMM_LD + lane] = ya;
+                S.gy[mb * BF_GMM_LD + lane] = yb;
+                float yt = 0.f;
+    #pragma unroll
+                for (int e2 = 0; e2 < 6; ++e2) {
+                    float4 t = tail_dq[e2];
+                    yt += Pt[2 * e2] * (tail_cq ? t.y : t.x);
+                    yt += Pt[2 * e2 + 1] * (tail_cq ? t.w : t.z);
+                }
+                S.gtail[gwi * 64 + lane] = yt;
+                BF_WAVE_FENCE();
+                float ta = dA.x * ya, tb = dA.y * yb;
+                if (lane < 5) {
+                    float ysa = 0.f, ysb = 0.f;
+    #pragma unroll
+                    for (int e = 0; e < 6; ++e) {
+                        ysa += S.gtail[gwi * 64 + 6 * lane + e];
+                        ysb += S.gtail[gwi * 64 + 30 + 6 * lane + e];
+                    }
+                    S.gy[ma * BF_GMM_LD + 64 + lane] = ysa;
+                    S.gy[mb * BF_GMM_LD + 64 + lane] = ysb;
+                    ta += dB.x * ysa;
+                    tb += dB.y * ysb;
+                }
+                ta = wave_sum(ta);
+                tb = wave_sum(tb);
+                if (lane == 0) {
+                    S.gq[ma] = 0.5f * ta + logw_a;       // prior.py:188-189
+                    S.gq[mb] = 0.5f * tb + logw_b;
+                }
+            };
+            if (GBLEND) {              // D (+E): projection, view reduction and routing on the geometry waves: the rest of the prior
+                gmm_finish();
+                BF_MARK(55, 256, it, t_iter);
             }
             BF_SYNC();
-            if (!merge_bc) { BF_GMM_CHUNK(6) }
+            if (!GBLEND) { BF_GMM_CHUNK(6) }
             if (!GMM_FG) BF_SYNC();    // F (two-phase path only)
-            if (!merge_bc) {
+            if (!GBLEND) {
                 BF_GMM_CHUNK(7)
                 BF_GMM_CHUNK(8)
+                gmm_finish();
+            } else {                   // F: this wave's quarter of d(pose feature) = sel_pd . dvp
+                if (merge_bc && BF_DFEAT_ON_GMM) gmm_dfeat();
             }
 #undef BF_GMM_CHUNK
-            const v2f y = y0 + y1;
-            const float ya = y.x, yb = y.y;
-            S.gy[ma * BF_GMM_LD + lane] = ya;
-            S.gy[mb * BF_GMM_LD + lane] = yb;
-            float yt = 0.f;
-#pragma unroll
-            for (int e2 = 0; e2 < 6; ++e2) {
-                float4 t = tail_d[e2];
-                yt += Pt[2 * e2] * (tail_c ? t.y : t.x);
-                yt += Pt[2 * e2 + 1] * (tail_c ? t.w : t.z);
-            }
-            S.gtail[gwi * 64 + lane] = yt;
-            BF_WAVE_FENCE();
-            float ta = dA.x * ya, tb = dA.y * yb;
-            if (lane < 5) {
-                float ysa = 0.f, ysb = 0.f;
-#pragma unroll
-                for (int e = 0; e < 6; ++e) {
-                    ysa += S.gtail[gwi * 64 + 6 * lane + e];
-                    ysb += S.gtail[gwi * 64 + 30 + 6 * lane + e];
-                }
-                S.gy[ma * BF_GMM_LD + 64 + lane] = ysa;
-                S.gy[mb * BF_GMM_LD + 64 + lane] = ysb;
-                ta += dB.x * ysa;
-                tb += dB.y * ysb;
-            }
-            ta = wave_sum(ta);
-            tb = wave_sum(tb);
-            if (lane == 0) {
-                S.gq[ma] = 0.5f * ta + logw_a;       // prior.py:188-189
-                S.gq[mb] = 0.5f * tb + logw_b;
-            }
             BF_MARK(48, 256, it, t_iter);
             BF_SYNC();                 // G (+H)
             if (!(NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36)) {     // (two-phase I, K path only)
@@ -1212,7 +1299,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // d(pose feature) = sel_pd . dvp: all of it on wave 3 (dvp stays in its registers across the passes), in the shadow of
         // the row waves
         BF_MARK(46, 0, it, t_iter);
-        if (wave == 3) dfeat_rows(strip, lq, npf, 64);
+        if (wave == 3 && !(merge_bc && BF_DFEAT_ON_GMM)) dfeat_rows(strip, lq, npf, 64);
+        if (wave == 3 && GBLEND) gmm_prior_grad();       // (all eight q values are in LDS since the barrier behind phase D)
         BF_MARK(47, 192, it, t_iter);
         BF_SYNC();
         } else {
@@ -1373,20 +1461,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             float rcl[4] = {rc4.x, rc4.y, rc4.z, rc4.w};
             const int pb0 = tq > 0 ? 3 * (tq - 1) : 0;                       // body-pose dof of the joint's first component
             const int pi0 = tq > 0 ? T.off_pose + pb0 : T.off_orient;        // its parameter index
-            float pv[3], pm[3], pw[3], gq[BF_GMM_M];
+            float pv[3], pm[3], pw[3], pgm[3], pan[3];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) { pv[c] = Pcur[pi0 + c]; pm[c] = S.am[pi0 + c]; pw[c] = S.av[pi0 + c]; }
-#pragma unroll
-            for (int m = 0; m < BF_GMM_M; ++m) gq[m] = S.gq[m];
+            for (int c = 0; c < 3; ++c) {
+                pv[c] = Pcur[pi0 + c]; pm[c] = S.am[pi0 + c]; pw[c] = S.av[pi0 + c];
+                pgm[c] = S.gtail[pb0 + c]; pan[c] = S.gtail[BF_GMM_LD + pb0 + c];          // the priors' terms (gmm_prior_grad, phase F)
+            }
             __builtin_amdgcn_sched_barrier(0);
-            int ms = 0;
-            float qm = gq[0];
-#pragma unroll
-            for (int m = 1; m < BF_GMM_M; ++m) if (gq[m] < qm) { qm = gq[m]; ms = m; }     // arg-min component (prior.py:195)
-            if (tq == 0) { S.scal[1] = (float)ms; S.scal[2] = qm; }
-            float gy[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) gy[c] = S.gy[ms * BF_GMM_LD + pb0 + c];
             float dRl[9], drl[3];
             if (tq == 0) {
                 dRl[0] = c0.x; dRl[1] = c0.y; dRl[2] = c0.z; dRl[3] = c1.x; dRl[4] = c1.y; dRl[5] = c1.z;
@@ -1419,17 +1500,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             // other dof (and for the root joint), which zeroes the exponential term exactly.  The joint's three Adam steps
             // are written stage by stage so that their dependent chains (sqrt, two rcp) interleave.
             {
-                const float body = tq > 0 ? 1.f : 0.f;
-                float grad[3], sg[3], ex[3];
+                const float body = tq > 0 ? 1.f : 0.f;          // (the root joint has no prior: its slots above are another joint's)
+                float grad[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int pb = pb0 + c;
-                    sg[c] = body * ((pb == 52 ? 1.f : 0.f) - (pb == 55 ? 1.f : 0.f) - (pb == 9 ? 1.f : 0.f) - (pb == 12 ? 1.f : 0.f));
-                }
-#pragma unroll
-                for (int c = 0; c < 3; ++c) ex[c] = __expf(pv[c] * sg[c]);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) grad[c] = gl[c] + body * (hp.w_pose * gy[c]) + hp.w_angle * 2.f * ex[c] * ex[c] * sg[c];
+                for (int c = 0; c < 3; ++c) grad[c] = gl[c] + body * pgm[c] + body * pan[c];
                 if (mode == 1) {
 #pragma unroll
                     for (int c = 0; c < 3; ++c) if (io.grads) io.grads[(size_t)frame * np + pi0 + c] = grad[c];
@@ -1802,7 +1876,8 @@ extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int
 // Host-side launcher: picks the compile-time-sized instantiation for SMPL, the table-driven one otherwise.
 extern "C" hipError_t bf_fit_launch(const FitTab *T, const FrameIO *io, const HyperDev *hp, int n_iters, int mode,
                                     const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
-    const bool smpl = T->nj == 24 && T->nb == 10 && T->ns == 11 && T->nl == 25;
+    // (the compile-time-sized SMPL instance also assumes at most 4 bones per selector vertex - true of SMPL's skinning weights)
+    const bool smpl = T->nj == 24 && T->nb == 10 && T->ns == 11 && T->nl == 25 && T->sel_nnz > 0 && T->sel_nnz <= 4;
     const bool ext = io->ext != nullptr;
     // SMPL-X in the dense schedule (keypoints through bf_kp_loss_kernel: no selector vertices, no loss joints here): sizes fixed
     // at compile time like SMPL's, the phases stay the table-driven ones

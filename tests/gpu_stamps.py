@@ -24,6 +24,6 @@ for rep in range(3):
     print("  per-phase:", [int(x) for x in np.diff(np.concatenate([[0], st]))])
     print("  phase A inner: local transforms loaded, after chain levels:", [int(x) for x in d[40:42]])
     print("  phase D inner: start, after view loop, after reduce+route:", [int(d[45]), int(d[43]), int(d[44])])
-    print("  GMM wave 4: done with its pose blend (phase A), with its chunks of phase B:", int(d[42]), int(d[49]))
+    print("  GMM wave 4: done with its pose blend (phase A), with its chunks of phase B, with the prior (phase D):", int(d[42]), int(d[49]), int(d[55]))
     print("  phase F inner: wave 0 done, wave 3 done (d pose feature), GMM wave 4 done:", [int(d[46]), int(d[47]), int(d[48])])
     print("  IK inner: wave0 after rodrigues_bwd, wave0 end | wave3 after g_beta partials, after beta Adam, end:", [int(d[50]), int(d[51]), int(d[52]), int(d[53]), int(d[54])])

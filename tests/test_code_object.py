@@ -1,0 +1,65 @@
+"""The gfx950 code object inside libbodyfit.so (no GPU needed): every kernel's private segment (scratch) must stay clear of the
+size at which the ROCm runtime stops keeping a queue's scratch allocated.  Measured in round 3: an instance of the fit kernel at
+224 B per lane x 64 lanes x 40 wave slots x 256 CUs = 146,800,640 B = the runtime's single-allocation limit, and every LAUNCH of
+it then allocated and released its scratch - the dense-schedule tests ran 100 x slower while the long resident launches of the
+benchmark hid it."""
+import os
+import struct
+
+import msgpack
+import pytest
+
+from bodyfitting_amd import _lib
+
+SCRATCH_LIMIT_BYTES_PER_LANE = 200          # (224 is where the runtime's 140 MiB limit is reached on 256 CUs)
+
+
+def _amdgpu_code_objects(blob):
+    at = 1
+    while True:
+        at = blob.find(b"\x7fELF", at)
+        if at < 0:
+            return
+        if blob[at + 4] == 2 and struct.unpack_from("<H", blob, at + 18)[0] == 224:      # ELF64, EM_AMDGPU
+            yield at
+        at += 4
+
+
+def _kernel_metadata(blob, base):
+    shoff, = struct.unpack_from("<Q", blob, base + 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", blob, base + 0x3A)
+    for i in range(shnum):
+        sh = base + shoff + i * shentsize
+        sh_type, = struct.unpack_from("<I", blob, sh + 4)
+        off, size = struct.unpack_from("<QQ", blob, sh + 0x18)
+        if sh_type != 7:                     # SHT_NOTE
+            continue
+        p, end = base + off, base + off + size
+        while p + 12 <= end:
+            namesz, descsz, ntype = struct.unpack_from("<III", blob, p)
+            name = blob[p + 12:p + 12 + namesz].rstrip(b"\0")
+            desc_at = p + 12 + ((namesz + 3) & ~3)
+            if name == b"AMDGPU" and ntype == 32:
+                return msgpack.unpackb(blob[desc_at:desc_at + descsz], raw=False, strict_map_key=False)
+            p = desc_at + ((descsz + 3) & ~3)
+    return None
+
+
+def test_every_kernel_keeps_its_scratch_small():
+    path = _lib.LIB_PATH
+    if not os.path.exists(path):
+        pytest.skip("libbodyfit.so is not built")
+    blob = open(path, "rb").read()
+    kernels = []
+    for base in _amdgpu_code_objects(blob):
+        md = _kernel_metadata(blob, base)
+        if md:
+            kernels += md.get("amdhsa.kernels", [])
+    assert len(kernels) > 40, "no gfx950 kernels found in the library"
+    fit = [k for k in kernels if "fit_kernel" in k[".name"]]
+    assert len(fit) == 5
+    worst = max(kernels, key=lambda k: k[".private_segment_fixed_size"])
+    assert worst[".private_segment_fixed_size"] < SCRATCH_LIMIT_BYTES_PER_LANE, (worst[".name"], worst[".private_segment_fixed_size"])
+    # the headline instance (SMPL, sparse schedule): no spill inside its loop - what is left is the prologue's batched image copy
+    head = [k for k in fit if "ILi24ELi10ELi11ELi25ELb0EE" in k[".name"]][0]
+    assert head[".private_segment_fixed_size"] <= 96 and head[".vgpr_count"] <= 256
