@@ -241,7 +241,10 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans);
  * `contour[np.argmax([a.shape[1] for a in contour])]` (loss.py:80); every OpenCV contour has shape [C,1,2], so the argmax
  * runs over ones and returns OpenCV's FIRST listed contour.  OpenCV lists external borders in the reverse of the order its
  * raster scan meets them (each new contour is inserted as the first child of the frame), so that is the border whose start
- * pixel comes LAST in raster order: BF_CONTOUR_OPENCV_FIRST, the default.  For a one-component silhouette all three coincide. */
+ * pixel comes LAST in raster order: BF_CONTOUR_OPENCV_FIRST, the default.  For a one-component silhouette all three coincide.
+ * In this form the call returns once the mask upload and the border following are QUEUED (on the batch's second stream); the
+ * next bf_fit / bf_batch_mask_loss collects the contours right before the first kernel that reads them - in a fit, under the
+ * iterations that need no silhouette yet.  The caller's `masks` buffer is copied before the call returns. */
 #define BF_CONTOUR_OPENCV_FIRST 0   /* the last external border the raster scan meets = contours[0] of OpenCV = what loss.py:80 keeps */
 #define BF_CONTOUR_RASTER_FIRST 1   /* the first external border the raster scan meets */
 #define BF_CONTOUR_LONGEST      2   /* the longest external border (first on ties): the evident intent of loss.py:80 */
