@@ -13,17 +13,22 @@
 // 48-view projection + GMoF, the merged 8x69x69 GMM prior, the angle / shape priors, the exact
 // reverse sweep of all of it, and the torch-semantics Adam update.  Derivation: oracle/analytic.py.
 //
-// The kernel is latency-bound (a dependent chain of short phases), so the design minimises the
-// number of workgroup barriers (11 per iteration) and keeps every index in registers:
-//   waves 0-2  chain specialists: wave r carries matrix row r of every joint (row r of G_i depends
-//              only on row r of G_parent), lane = joint, levels run back to back with no barrier
-//              (LDS is in-order within a wave);
-//   wave 3     shaped selector vertices, housekeeping;
-//   waves 4-7  GMM specialists: the symmetrised precision rows of components 2g, 2g+1 live in
-//              VGPRs for the whole launch; d, the mat-vec, the tail rows and the quadratic forms
-//              run inside one phase, wave-locally;
-//   all waves  pose blend partials, 48-view projection (thread = joint x view slot, keypoints in
-//              registers), reverse skinning, d(pose feature).
+// The kernel is bound by instruction issue on its critical waves and by the LDS round trips between its phases, so the
+// design keeps the number of workgroup barriers at 5 per iteration, every index in registers, and deals the work out by
+// instruction count:
+//   waves 0-2  chain specialists: wave r carries matrix row r of every joint (row r of G_i depends only on row r of G_parent),
+//              lane = joint; the local transforms [R_j | rel_j] are in LDS when the iteration starts (the rotation formed by the
+//              lane that stepped the joint's dofs, rel_j by wave 3 with the betas), two tree levels per round through ds_bpermute;
+//              then skinning of the selector vertices, the 48-view projection, the reverse skinning + subtree sums, and on wave 0
+//              the reverse Rodrigues + Adam for the pose;
+//   wave 3     skinning / projection like the others; the betas' gradient, step and everything the next forward pass derives
+//              from them; the priors' share of dL/dtheta (arg-min component, angle prior) for the Adam phase;
+//   waves 4-7  GMM specialists: the symmetrised precision rows of components 2g, 2g+1 live in VGPRs for the whole launch; they
+//              also carry what needs few registers and only LDS inputs: the pose blend of the selector vertices (phase A) and
+//              d(pose feature) (phase F).
+// (That is the compile-time-sized SMPL instance.  Other models - and SMPL-X in the dense schedule, which has its own sized
+// instance - take the table-driven phases: Rodrigues in phase A on the chain waves, a two-phase pose blend over all eight waves,
+// masked subtree sums, Adam one parameter per thread.)
 // The reverse chain is flattened: with t_i = sum over subtree(i) of dL/dGt and
 // N_i = D_i GR_i^T + t_i (Gt_i - Gt_parent)^T, dL/dGR_p = (D_p GR_p^T + sum_{i in strict subtree} N_i) GR_p,
 // i.e. two subtree sums instead of one barrier per tree level.  All reductions have a fixed order.
@@ -62,9 +67,6 @@ struct FitSmem {
 };
 
 __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
-#ifndef BF_DFEAT_ON_GMM
-#define BF_DFEAT_ON_GMM 1
-#endif
 #define BF_PDT_LD 210      // row stride of the transposed selector posedirs: 7 slices of 30 rows
 
 // Carve the dynamic LDS segment; the same function sizes it on the host (base == nullptr).
@@ -827,7 +829,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     // from the LDS copies of the model's tables; the view-sum slots (dead until phase D) are its scratch.
     auto door_state = [&](const float *P) {
         const PoseTabs PT{S.thk, S.tho, S.par, S.pmean, S.hcomp, S.Jd, S.Jt, pad4(nb + 1), S.lvl, S.lvl + nj, S.lvl + nj + 67};
-        bf_pose_state_body<true, true, false>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, lane, 64, S.part, PT, P);
+        // (the table-driven beta_dependent leaves exactly the rest joints the pose state wants in S.J - see pose_state_body.h; the
+        //  SMPL instance's float4-row form sums in another order, so that instance lets the body form them)
+        constexpr bool J_SHARED = !(NB > 0 && NS > 0 && NS * 3 <= 64 && NJ > 0 && NJ * 3 <= 128);
+        bf_pose_state_body<true, true, false>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, lane, 64, S.part, PT, P,
+                                              J_SHARED ? S.J : nullptr);
 #ifdef BF_STAMP
         if (lane == 0) { const long long *mk = (const long long *)(S.part + 1740); for (int k = 1; k < 5; ++k) S.stamp[48 + k] = (float)(mk[k] - mk[0]); }
 #endif
@@ -990,7 +996,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 BF_GMM_CHUNK(8)
                 gmm_finish();
             } else {                   // F: this wave's quarter of d(pose feature) = sel_pd . dvp
-                if (merge_bc && BF_DFEAT_ON_GMM) gmm_dfeat();
+                if (merge_bc) gmm_dfeat();
             }
 #undef BF_GMM_CHUNK
             BF_MARK(48, 256, it, t_iter);
@@ -1304,7 +1310,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // d(pose feature) = sel_pd . dvp: all of it on wave 3 (dvp stays in its registers across the passes), in the shadow of
         // the row waves
         BF_MARK(46, 0, it, t_iter);
-        if (wave == 3 && !(merge_bc && BF_DFEAT_ON_GMM)) dfeat_rows(strip, lq, npf, 64);
+        if (wave == 3 && !merge_bc) dfeat_rows(strip, lq, npf, 64);
         if (wave == 3 && GBLEND) gmm_prior_grad();       // (all eight q values are in LDS since the barrier behind phase D)
         BF_MARK(47, 192, it, t_iter);
         BF_SYNC();

@@ -83,7 +83,7 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
                                                    const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
                                                    const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all,
                                                    const int f, const int tid, const int nt, float *lds, const PoseTabs P,
-                                                   const float *packed_lds = nullptr) {
+                                                   const float *packed_lds = nullptr, const float *J_pre = nullptr) {
     // lds: BF_POSE_STATE_LDS floats of workgroup-shared scratch
 #ifdef BF_STAMP
     long long *bf_marks = (long long *)(lds + 1740);
@@ -116,7 +116,13 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
         BF_PMARK(2);
         st.theta[tid * 3] = th[0]; st.theta[tid * 3 + 1] = th[1]; st.theta[tid * 3 + 2] = th[2];
     }
-    if (nb <= 16) {
+    // Rest joints J = Jt + Jd . beta, as ONE chain that starts at Jt and adds the products l ascending: the arithmetic of the fit
+    // kernel's own table-driven beta_dependent (fit_kernels.hip), so a caller that already holds those values (J_pre: the resident
+    // dense-schedule launch, whose wave 3 formed them right behind the betas' Adam step) hands them over instead of repeating
+    // 165 ten-term sums on the critical wave of every iteration - same bits either way.
+    if (J_pre) {
+        for (int i = tid; i < nj * 3; i += nt) J[i] = J_pre[i];
+    } else if (nb <= 16) {
         // (all of a row's operands requested before the first multiply-add: the chain below is the same sum, l ascending)
         float bb[16];
 #pragma unroll
@@ -125,17 +131,16 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
             float jd[16];
 #pragma unroll
             for (int l = 0; l < 16; ++l) jd[l] = l < nb ? P.Jd[i * P.jd_stride + l] : 0.f;
-            const float jt = P.Jt[i];
-            float acc = 0.f;
+            float acc = P.Jt[i];
 #pragma unroll
             for (int l = 0; l < 16; ++l) if (l < nb) acc += jd[l] * bb[l];
-            J[i] = jt + acc;
+            J[i] = acc;
         }
     } else
     for (int i = tid; i < nj * 3; i += nt) {
-        float acc = 0.f;
+        float acc = P.Jt[i];
         for (int l = 0; l < nb; ++l) acc += P.Jd[i * P.jd_stride + l] * beta[l];
-        J[i] = P.Jt[i] + acc;
+        J[i] = acc;
     }
     if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     BF_PMARK(3);
