@@ -106,6 +106,31 @@ __device__ inline float bf_theta(const float *params, int j, int k, const int *t
     return th;
 }
 
+// The three components of theta_j at once, bit for bit bf_theta's values: the PCA hands' operands (n_pca coefficients and 3 n_pca
+// component entries) are requested in batches of six BEFORE the first multiply-add, and the three sums (independent chains, q
+// ascending as above) run side by side - bf_theta called three times is 3 x n_pca dependent pairs of LDS reads on one wave.
+__device__ inline void bf_theta3(const float *params, int j, float th[3], const int *th_kind, const int *th_off, const float *pose_mean,
+                                 const float *hand_comp, int n_pca, int off_lh, int off_rh) {
+    const int kind = th_kind[j], off = th_off[j];
+    th[0] = pose_mean ? pose_mean[j * 3] : 0.f; th[1] = pose_mean ? pose_mean[j * 3 + 1] : 0.f; th[2] = pose_mean ? pose_mean[j * 3 + 2] : 0.f;
+    if (kind == 0) { th[0] += params[off]; th[1] += params[off + 1]; th[2] += params[off + 2]; }
+    else if (kind >= 2) {
+        const float *comp = hand_comp + (kind - 2) * n_pca * 45 + off * 3;
+        const float *c = params + (kind == 2 ? off_lh : off_rh);
+        for (int q0 = 0; q0 < n_pca; q0 += 6) {
+            float cq[6], m0[6], m1[6], m2[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int q = q0 + i < n_pca ? q0 + i : n_pca - 1;
+                cq[i] = c[q]; m0[i] = comp[q * 45]; m1[i] = comp[q * 45 + 1]; m2[i] = comp[q * 45 + 2];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (q0 + i < n_pca) { th[0] += cq[i] * m0[i]; th[1] += cq[i] * m1[i]; th[2] += cq[i] * m2[i]; }
+        }
+    }
+}
+
 // Per-frame pose state handed from the fit / pose-prep kernel to the mesh kernel.
 // layout per frame (floats): GR[nj*9] At[nj*3] Gt[nj*3] feat[npf] theta[nj*3] beta[nb] t[3] s c
 __host__ __device__ inline int bf_state_stride(int nj, int npf, int nb) {

@@ -250,9 +250,6 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     // ---- one-off loads --------------------------------------------------------------------
     const int nbp = pad4(nb + 1);
     const int sel_nnz = T.sel_nnz;
-    auto theta_of = [&](const float *P, int j, int k) {
-        return bf_theta(P, j, k, S.thk, S.tho, S.pmean, S.hcomp, T.n_pca, T.off_lh, T.off_rh);
-    };           // 0 = some selector vertex has more than BF_SEL_NNZ bones: dense loop
     // Dense-schedule launches run ONE iteration, so their prologue is on the critical path of every iteration (and a sparse-schedule
     // launch of 100 iterations still spends 2 % of its time in it).  Once a first
     // launch has left an image of the model-constant LDS arrays (three contiguous runs of the carve, FitTab::img_seg), everything
@@ -1037,7 +1034,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 const int woff = NJ == 24 ? (wjq > 0 ? T.off_pose + 3 * (wjq - 1) : T.off_orient) : w_off;
                 if (ROT_AHEAD) { }
                 else if (NJ == 24 || w_kind == 0) { th0 += Pcur[woff]; th1 += Pcur[woff + 1]; th2 += Pcur[woff + 2]; }
-                else if (NJ != 24 && w_kind >= 2) { th0 = theta_of(Pcur, wj, 0); th1 = theta_of(Pcur, wj, 1); th2 = theta_of(Pcur, wj, 2); }
+                else if (NJ != 24 && w_kind >= 2) {
+                    float t3[3];
+                    bf_theta3(Pcur, wj, t3, S.thk, S.tho, S.pmean, S.hcomp, T.n_pca, T.off_lh, T.off_rh);
+                    th0 = t3[0]; th1 = t3[1]; th2 = t3[2];
+                }
                 // rel_j = J_j - J_parent (rel_0 = J_0) was formed from the betas by wave 3 at the end of the previous
                 // iteration (or in the prologue); read it before the Rodrigues arithmetic so the latency hides under it
                 float a0, a1, a2;

@@ -105,8 +105,7 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
     if (tid < nj) {
         float th[3];
         if constexpr (PACKED) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) th[k] = bf_theta(pk, tid, k, P.th_kind, P.th_off, P.pose_mean, P.hand_comp, T.n_pca, T.off_lh, T.off_rh);
+            bf_theta3(pk, tid, th, P.th_kind, P.th_off, P.pose_mean, P.hand_comp, T.n_pca, T.off_lh, T.off_rh);
         } else {
             const float *src = tid == 0 ? orient + (size_t)f * 3 : body_pose + (size_t)f * 3 * (nj - 1) + 3 * (tid - 1);
             th[0] = src[0]; th[1] = src[1]; th[2] = src[2];
