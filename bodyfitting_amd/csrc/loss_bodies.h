@@ -129,7 +129,10 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
     // are SORTED by (vertex, item index) - a bitonic network over keys in LDS - so the items of a vertex become one run in
     // joint order; the thread at the start of a run adds them up in that order and applies the total with a single
     // read-modify-write (dL/dvertices is zero when this kernel starts, so the bits are those of adding item by item).
-    // (The first version ranked every item against all earlier ones: O(n^2) LDS reads, 15 of this kernel's 26 us.)
+    // (The first version ranked every item against all earlier ones: O(n^2) LDS reads, 15 of this kernel's 26 us.  A uniform walk -
+    //  every item reads the whole id list once, four ids per broadcast b128, and the lowest item of a vertex sums the later ones -
+    //  was measured in round 3: no barriers, but some lane of a wave matches in nearly every step, so every step pays the
+    //  accumulate body: config 3 went from 0.081 to 0.091 ms per iteration.  The sort's 45 short barrier stages are cheaper.)
     float *dv = dvout + (size_t)f * Q.nv * 3;
     const int n_ori = Q.nj + Q.n_selector;
     int *s_key = (int *)(s_x + nl * 3 + 8);               // [N] (vertex << 10 | item), 0x7fffffff = no vertex
