@@ -494,9 +494,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 S.dvsel[o] = 0.f;
             }
             for (int i = lane; i < nj3; i += 64) {
-                float acc = S.Jd[i * nbp + nb], acr = S.Jdrel[i * nbp + nb];
+                // (J as Jt + (sum of the products, l ascending): bf_pose_state_body's arithmetic, which takes these values over - J_pre)
+                float acc = 0.f, acr = S.Jdrel[i * nbp + nb];
                 for (int l = 0; l < nb; ++l) { const float bl = beta[l]; acc += S.Jd[i * nbp + l] * bl; acr += S.Jdrel[i * nbp + l] * bl; }
-                S.J[i] = acc;
+                S.J[i] = S.Jd[i * nbp + nb] + acc;
                 S.rel[i] = acr;
                 S.dGt[i] = 0.f;
             }

@@ -115,8 +115,8 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
         BF_PMARK(2);
         st.theta[tid * 3] = th[0]; st.theta[tid * 3 + 1] = th[1]; st.theta[tid * 3 + 2] = th[2];
     }
-    // Rest joints J = Jt + Jd . beta, as ONE chain that starts at Jt and adds the products l ascending: the arithmetic of the fit
-    // kernel's own table-driven beta_dependent (fit_kernels.hip), so a caller that already holds those values (J_pre: the resident
+    // Rest joints J = Jt + (Jd . beta, the products added l ascending from 0): the fit kernel's table-driven beta_dependent
+    // (fit_kernels.hip) forms its own J with exactly this arithmetic, so a caller that already holds those values (J_pre: the resident
     // dense-schedule launch, whose wave 3 formed them right behind the betas' Adam step) hands them over instead of repeating
     // 165 ten-term sums on the critical wave of every iteration - same bits either way.
     if (J_pre) {
@@ -130,16 +130,17 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
             float jd[16];
 #pragma unroll
             for (int l = 0; l < 16; ++l) jd[l] = l < nb ? P.Jd[i * P.jd_stride + l] : 0.f;
-            float acc = P.Jt[i];
+            const float jt = P.Jt[i];
+            float acc = 0.f;
 #pragma unroll
             for (int l = 0; l < 16; ++l) if (l < nb) acc += jd[l] * bb[l];
-            J[i] = acc;
+            J[i] = jt + acc;
         }
     } else
     for (int i = tid; i < nj * 3; i += nt) {
-        float acc = P.Jt[i];
+        float acc = 0.f;
         for (int l = 0; l < nb; ++l) acc += P.Jd[i * P.jd_stride + l] * beta[l];
-        J[i] = acc;
+        J[i] = P.Jt[i] + acc;
     }
     if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     BF_PMARK(3);
