@@ -1775,10 +1775,19 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 }
             } else if (pk == 2) grad = g_v + 2.f * hp.w_shape * pval;
             else {                                                   // hand PCA coefficient pb of hand pa
+                // (45 products, e ascending; the operands of fifteen requested before the first multiply-add: rolled, the loop was 45
+                //  dependent pairs of LDS reads on the wave that holds the hand coefficients, in every iteration's Adam phase)
                 const float *comp = S.hcomp + (pa * T.n_pca + pb) * 45;
                 const float *gh = S.gth + (pa == 0 ? hand_j0_l : hand_j0_r) * 3;
                 float acc = 0.f;
-                for (int e = 0; e < 45; ++e) acc += comp[e] * gh[e];
+#pragma unroll
+                for (int h = 0; h < 3; ++h) {
+                    float cv[15], gv[15];
+#pragma unroll
+                    for (int e = 0; e < 15; ++e) { cv[e] = comp[h * 15 + e]; gv[e] = gh[h * 15 + e]; }
+#pragma unroll
+                    for (int e = 0; e < 15; ++e) acc += cv[e] * gv[e];
+                }
                 grad = acc;
             }
         }
