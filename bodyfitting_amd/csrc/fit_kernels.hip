@@ -1391,8 +1391,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // ================= phase G (+H): per (joint p, row r) the two masked subtree sums (M rows and dL/dGt, one b128
         // read each), t_p, dL/dGR_p (total) = (Dg_p + sum_k M_k - st (Gt_p - Gt_0)^T) GR_p, direct dJ | d(pose feature)
         const int tq = bf_launder(tid);          // (fresh per phase: keeps this phase's address arithmetic out of the loop-invariant set)
-        if (wave >= 2) dfeat_rows(S.dvp, tq - 128, npf, 128);
-        for (int q = tq; q < nj3 && wave < 2; q += 128) {
+        // (who takes what: with selector vertices d(pose feature) is real work and gets waves 2-3, the (joint, row) items waves 0-1 -
+        //  two passes for 55 joints; without them - SMPL-X in the dense schedule - it is a copy of the outside block, wave 3 takes it
+        //  alone and the 165 items fit waves 0-2 in ONE pass: this phase was 7.5 k of the resident launch's 18 k cycles per iteration)
+        constexpr bool G_WIDE = NS == 0 && NJ > 0 && NJ * 3 <= 192;
+        constexpr int G_ITEM_WAVES = G_WIDE ? 3 : 2, G_ITEM_THREADS = G_ITEM_WAVES * 64;
+        if (wave >= G_ITEM_WAVES) dfeat_rows(S.dvp, tq - G_ITEM_THREADS, npf, NG - G_ITEM_THREADS);
+        for (int q = tq; q < nj3 && wave < G_ITEM_WAVES; q += G_ITEM_THREADS) {
             const int p = q / 3, r = q - p * 3;
             const unsigned long long mk = T.desc[p];
             const float4 own = *(const float4 *)(S.N + q * 4), dgr = *(const float4 *)(S.Dg + q * 4);
