@@ -456,6 +456,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     float grad_last = 0.f;
     int pidx_last = -1;
     constexpr bool ROT_AHEAD = NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS * 3 <= 36;       // (= MERGE_IK; see rotations_ahead)
+    // A sized instance without selector vertices and without loss joints of its own (SMPL-X in the dense schedule: the keypoint loss
+    // is the dense kernels') has nothing to do between the forward chain and the reverse sweep: the pose-blend, skinning and
+    // projection phases are empty, and their three barriers - ~2,000 cycles of every iteration of the resident launch - are dropped
+    // (in BOTH role loops: the barrier counts must match).
+    constexpr bool NO_VERT = NJ > 0 && NS == 0 && NL == 0;
     // Everything that depends on the betas alone, for the NEXT forward pass (wave 3; its lanes cover the outputs):
     // shaped selector vertices, rest joints J, joint offsets rel_j = J_j - J_parent from the pre-contracted difference
     // tables, and the zeroed targets of the projection phase's routing
@@ -917,7 +922,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (EXT && door) door_mid(it, Pcur);
             if (!merge_bc) {           // (two-phase pose blend: everybody takes row slices)
                 pose_blend(std::integral_constant<int, 2>());
-                BF_SYNC();             // B
+                if (!NO_VERT) BF_SYNC();             // B
             }
             if (GBLEND) {              // (the geometry waves wait on LDS in this phase: a chunk costs ~70 cycles here, ~300 under the projection)
                 BF_GMM_CHUNK(1)
@@ -943,7 +948,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 BF_GMM_CHUNK(4)
                 BF_GMM_CHUNK(5)
             }
-            BF_SYNC();                 // C
+            if (!NO_VERT) BF_SYNC();   // C
             // the rest of the prior once the mat-vec is complete: y -> LDS, the twelve-column tail pieces, the two quadratic forms
             auto gmm_finish = [&]() {
                 const int tpq = min(bf_launder(lane), 59), tail_cq = tpq < 30 ? 0 : 1;          // (re-derived per iteration: registers)
@@ -986,7 +991,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 gmm_finish();
                 BF_MARK(55, 256, it, t_iter);
             }
-            BF_SYNC();
+            if (!NO_VERT) BF_SYNC();   // D
             if (!GBLEND) { BF_GMM_CHUNK(6) }
             if (!GMM_FG) BF_SYNC();    // F (two-phase path only)
             if (!GBLEND) {
@@ -1138,7 +1143,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // ================= phase B: pose blend of the selector vertices, partial sums over row slices
         pose_blend(std::integral_constant<int, 1>());
         }
-                BF_SYNC();
+                if (!NO_VERT) BF_SYNC();
         {
         // ================= phase C: finish the pose blend; skin the selector vertices.  Lane b of a quad owns
         // column b of row k of T_s = sum_j w_sj A_j
@@ -1196,11 +1201,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         }
                 }
-        BF_SYNC();
+        if (!NO_VERT) BF_SYNC();
 
         // ================= phase D: similarity, multi-view projection, GMoF and its gradient
         if (nl > 0) project(it == n_iters - 1 || mode == 1);      // (no loss joints in this launch - the dense keypoint path: nothing to project)
-        BF_SYNC();
+        if (!NO_VERT) BF_SYNC();
 
         // (this step's Adam constants: a global read, issued ahead of its use)
         const float *at = adam_tab + (size_t)(adam_t0 + it) * 3;
