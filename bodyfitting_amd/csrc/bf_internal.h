@@ -204,6 +204,10 @@ struct MaskProj {
 #define BF_DOOR_TICKET 1
 #define BF_DOOR_ERR 2
 #define BF_DOOR_STATE 64
+#define BF_DOOR_FEAT 96          // (+ c * BF_DOOR_COPY_STRIDE) like BF_DOOR_STATE, one cache line further: the pose FEATURES of that many (frame,
+                                 // iteration) states are published - rung early in the fit launch's phase A, as soon as the rotations exist, so a
+                                 // forward mesh pass runs its pose blend (most of its work) under the rest of that phase and only then waits for
+                                 // the chain matrices (BF_DOOR_STATE)
 #define BF_DOOR_COPIES 32
 #define BF_DOOR_COPY_STRIDE 1056
 #define BF_DOOR_INTS (BF_DOOR_COPIES * BF_DOOR_COPY_STRIDE)

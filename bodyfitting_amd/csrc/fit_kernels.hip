@@ -835,8 +835,20 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         // (the table-driven beta_dependent leaves exactly the rest joints the pose state wants in S.J - see pose_state_body.h; the
         //  SMPL instance's float4-row form sums in another order, so that instance lets the body form them)
         constexpr bool J_SHARED = !(NB > 0 && NS > 0 && NS * 3 <= 64 && NJ > 0 && NJ * 3 <= 128);
+        // The pose feature leaves EARLY (BF_DOOR_FEAT): as soon as the rotations exist wave 3 stores it with device-scope stores (they
+        // go past this XCD's L2, so no write-back is needed), waits for them and rings - the forward mesh pass that was waiting runs
+        // its pose blend under the chain below and the hand-over, and waits for the chain matrices (BF_DOOR_STATE) only after that.
+        auto publish_feat = [&](const float *R) {
+            StateView st = bf_state_view(io.state + (size_t)frame * bf_state_stride(nj, npf, nb), nj, npf, nb);
+            for (int p = lane; p < npf; p += 64) {
+                const int j = 1 + p / 9, e = p - (p / 9) * 9;
+                __hip_atomic_store(st.feat + p, R[j * 9 + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the stores have reached memory at device scope
+            if (lane < BF_DOOR_COPIES) __hip_atomic_fetch_add(door + BF_DOOR_FEAT + lane * BF_DOOR_COPY_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
         bf_pose_state_body<true, true, false>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, lane, 64, S.part, PT, P,
-                                              J_SHARED ? S.J : nullptr);
+                                              J_SHARED ? S.J : nullptr, publish_feat);
 #ifdef BF_STAMP
         if (lane == 0) { const long long *mk = (const long long *)(S.part + 1740); for (int k = 1; k < 5; ++k) S.stamp[48 + k] = (float)(mk[k] - mk[0]); }
 #endif
@@ -849,7 +861,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         bf_d0 = clock64();
 #endif
         // (wave 3 left the rotations, chain matrices and joints of the state in the scratch during phase A: everybody writes the record)
-        bf_pose_state_emit<true>(T, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nt, S.part, nullptr, P);
+        bf_pose_state_emit<true>(T, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nt, S.part, nullptr, P, true);
         __syncthreads();                                       // the record's stores have reached the XCD's L2
         if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // one device-scope release (L2 write-back) for the workgroup
         BF_DMARK(56);

@@ -231,8 +231,9 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
 #pragma unroll
     for (int i = 0; i < BF_MM_CH; ++i) pv[i] = p0 + i < p1 ? pd[(size_t)i * ncols] : 0.f;
     const bool coh = door && (door_target & BF_DOOR_COHERENT_BIT);
-    if (door) {        // the pose states come from the persistent fit launch (BfDoor): wait for all of them, under the first chunk's loads
-        if (tid == 0) bf_door_wait(door, BF_DOOR_STATE + (int)((blockIdx.x + 7 * blockIdx.y) % BF_DOOR_COPIES) * BF_DOOR_COPY_STRIDE, door_target & ~BF_DOOR_COHERENT_BIT);
+    const int door_copy = (int)((blockIdx.x + 7 * blockIdx.y) % BF_DOOR_COPIES) * BF_DOOR_COPY_STRIDE;
+    if (door) {        // the pose FEATURES come first from the persistent fit launch (BF_DOOR_FEAT): wait for all of them, under the first chunk's loads
+        if (tid == 0) bf_door_wait(door, BF_DOOR_FEAT + door_copy, door_target & ~BF_DOOR_COHERENT_BIT);
         __syncthreads();
         // (this kernel started with invalidated caches and reads the states for the first time below: nothing stale to drop)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -241,6 +242,9 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
         const int p = i / FPW, f = i - p * FPW;
         s_feat[i] = (p < npf && f < nf) ? bf_ld_state(bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).feat + p, coh) : 0.f;
     }
+    // (without doorbells the whole state is there: everything is loaded now, as before; with them the chain matrices and the
+    //  betas are fetched behind the pose blend, when BF_DOOR_STATE has been rung - the fit launch is still forming them)
+    if (!door)
     for (int i = tid; i < FPW * nj * 12; i += nt) {
         const int f = i % FPW, r = i / FPW, j = r / 12, e = r - j * 12, a = e >> 2, b = e & 3;       // (FPW, 12: compile-time divisors)
         float x = 0.f;
@@ -250,6 +254,7 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
         }
         s_A[f * nj * 12 + r] = x;
     }
+    if (!door)
     for (int i = tid; i < FPW * 32; i += nt) {
         const int f = i >> 5, l = i & 31;
         s_beta[i] = (f < nf && l < nb + 5) ? bf_ld_state(bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).beta + l, coh) : 0.f;
@@ -290,6 +295,24 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
     }
 #pragma unroll
     for (int f = 0; f < FPW; ++f) s_red[(f * BF_MESH_RG + rg) * COLS + col] = acc[f];
+    if (door) {        // the rest of the states: chain matrices A_j, betas, similarity
+        if (tid == 0) bf_door_wait(door, BF_DOOR_STATE + door_copy, door_target & ~BF_DOOR_COHERENT_BIT);
+        __syncthreads();
+        for (int i = tid; i < FPW * nj * 12; i += nt) {
+            const int f = i % FPW, r = i / FPW, j = r / 12, e = r - j * 12, a = e >> 2, b = e & 3;
+            float x = 0.f;
+            if (f < nf) {
+                StateView st = bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb);
+                x = bf_ld_state(b < 3 ? st.GR + j * 9 + a * 3 + b : st.At + j * 3 + a, coh);
+            }
+            s_A[f * nj * 12 + r] = x;
+        }
+        for (int i = tid; i < FPW * 32; i += nt) {
+            const int f = i >> 5, l = i & 31;
+            s_beta[i] = (f < nf && l < nb + 5) ? bf_ld_state(bf_state_view(const_cast<float *>(state) + (fbase + f) * sstride, nj, npf, nb).beta + l, coh) : 0.f;
+        }
+        __syncthreads();
+    }
     // ---- from here on row group rg works for FRAME rg -----------------------------------------------------------------
     const int f = rg;
     const bool mine = f < nf;

@@ -40,10 +40,11 @@ __device__ __forceinline__ PoseTabs bf_pose_tabs(const FitTab &T) {
 
 // The outputs of bf_pose_state_body from what it left in `lds` (R, J, GR, Gt): GR, A_j translations, Gt, the pose feature, betas
 // and the similarity.  Separate so that a caller whose body ran on one wave can write the record with all its threads.
+struct PoseNoHook { __device__ __forceinline__ void operator()(const float *) const {} };
 template <bool PACKED>
 __device__ __forceinline__ void bf_pose_state_emit(const FitTab &T, const float *__restrict__ sim, float *state, const float *__restrict__ packed,
                                                    const float *__restrict__ cscale, float cscale_all, const int f, const int tid, const int nt,
-                                                   const float *lds, const float *__restrict__ betas, const float *packed_lds) {
+                                                   const float *lds, const float *__restrict__ betas, const float *packed_lds, const bool skip_feat = false) {
     const float *R = lds, *J = R + 64 * 9, *GR = J + 64 * 3, *Gt = GR + 64 * 9;
     const int nj = T.nj, nb = T.nb, npf = T.npf;
     const float *pk = PACKED ? (packed_lds ? packed_lds : packed + (size_t)f * T.np) : nullptr;
@@ -57,6 +58,7 @@ __device__ __forceinline__ void bf_pose_state_emit(const FitTab &T, const float 
         st.At[i] = Gt[i] - (g[0] * J[j * 3] + g[1] * J[j * 3 + 1] + g[2] * J[j * 3 + 2]);
         st.Gt[i] = Gt[i];
     }
+    if (!skip_feat)                  // (the resident dense launch published the pose feature early: bf_pose_state_body's hook)
     for (int p = tid; p < npf; p += nt) {
         int j = 1 + p / 9, e = p % 9;
         st.feat[p] = R[j * 9 + e] - ((e == 0 || e == 4 || e == 8) ? 1.0f : 0.0f);
@@ -78,12 +80,13 @@ __device__ __forceinline__ void bf_pose_state_emit(const FitTab &T, const float 
 // Called by EVERY thread of the workgroup (it synchronises); `nt` = the workgroup's thread count.
 // WAVE: the caller is ONE wavefront (tid = lane, nt = 64) with `lds` to itself: barriers become wave fences (a wave's LDS
 // operations execute in order), everything else - the arithmetic included - is the same code.
-template <bool PACKED, bool WAVE = false, bool EMIT = true>
+// `after_rotations(R)`: called by every thread once the rotations R[nj][9] are complete in LDS (behind the first fence / barrier).
+template <bool PACKED, bool WAVE = false, bool EMIT = true, class HOOK = PoseNoHook>
 __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float *__restrict__ betas, const float *__restrict__ orient,
                                                    const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
                                                    const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all,
                                                    const int f, const int tid, const int nt, float *lds, const PoseTabs P,
-                                                   const float *packed_lds = nullptr, const float *J_pre = nullptr) {
+                                                   const float *packed_lds = nullptr, const float *J_pre = nullptr, HOOK after_rotations = HOOK()) {
     // lds: BF_POSE_STATE_LDS floats of workgroup-shared scratch
 #ifdef BF_STAMP
     long long *bf_marks = (long long *)(lds + 1740);
@@ -144,6 +147,7 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
     }
     if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     BF_PMARK(3);
+    after_rotations(R);
     if (tid < 9) GR[tid] = R[tid];
     if (tid >= 9 && tid < 12) Gt[tid - 9] = J[tid - 9];
     if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
