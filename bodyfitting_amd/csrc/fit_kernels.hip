@@ -529,6 +529,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             f[5] = Ri[5]; f[6] = Ri[6]; f[7] = Ri[7]; f[8] = Ri[8] - 1.f;
         }
     };
+    if (EXT && tid == 0) ((int *)S.part)[BF_POSE_STATE_FLAG] = 0;          // (the chain waves' cue: no iteration's token yet)
     if (wave == 3) beta_dependent(S.pa);
     if (ROT_AHEAD && wave == 0 && lane < nj) {
         const int po = lane > 0 ? T.off_pose + 3 * (lane - 1) : T.off_orient;
@@ -830,6 +831,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     // division, OCML sin / cos: the fit kernel's own phase A uses 1-ulp forms, and a silhouette loss turns a last-bit difference in
     // a vertex into a different nearest-vertex choice), run by wave 3 - idle in phase A - while waves 0-2 form the chain,
     // from the LDS copies of the model's tables; the view-sum slots (dead until phase D) are its scratch.
+    int door_token = 0;                      // (this iteration's cue value for the chain waves: it + 1, never the value a stale flag holds)
     auto door_state = [&](const float *P) {
         const PoseTabs PT{S.thk, S.tho, S.par, S.pmean, S.hcomp, S.Jd, S.Jt, pad4(nb + 1), S.lvl, S.lvl + nj, S.lvl + nj + 67};
         // (the table-driven beta_dependent leaves exactly the rest joints the pose state wants in S.J - see pose_state_body.h; the
@@ -847,8 +849,14 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the stores have reached memory at device scope
             if (lane < BF_DOOR_COPIES) __hip_atomic_fetch_add(door + BF_DOOR_FEAT + lane * BF_DOOR_COPY_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
-        bf_pose_state_body<true, true, false>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, lane, 64, S.part, PT, P,
-                                              J_SHARED ? S.J : nullptr, publish_feat);
+        // ... and the chain of that state is formed by the three chain waves, a row each (bf_pose_chain_row), once they are through
+        // with the kernel's own chain: wave 3 tells them when R and J are complete, BEFORE it publishes the feature.
+        auto cue_then_publish = [&](const float *R) {
+            if (lane == 0) *(volatile int *)((int *)S.part + BF_POSE_STATE_FLAG) = door_token;
+            publish_feat(R);
+        };
+        bf_pose_state_body<true, true, false, decltype(cue_then_publish), false>(T, nullptr, nullptr, nullptr, nullptr, io.state, io.params, io.cscale, hp.cscale,
+                                                                                  frame, lane, 64, S.part, PT, P, J_SHARED ? S.J : nullptr, cue_then_publish);
 #ifdef BF_STAMP
         if (lane == 0) { const long long *mk = (const long long *)(S.part + 1740); for (int k = 1; k < 5; ++k) S.stamp[48 + k] = (float)(mk[k] - mk[0]); }
 #endif
@@ -1141,8 +1149,16 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (cw_on) S.At[wjq * 3 + wave] = row.w - (row.x * jj0 + row.y * jj1 + row.z * jj2);
             BF_MARK(41, 0, it, t_iter);
         } else if (EXT && door) {         // wave 3 has nothing of its own in this phase
+            door_token = it + 1;
             door_state(Pcur);
             BF_MARK(59, 192, it, t_iter);
+        }
+        if (EXT && door && wave < 3) {
+            // row `wave` of the published state's chain (the pose state's own arithmetic, from wave 3's rotations)
+            volatile int *cue = (volatile int *)((int *)S.part + BF_POSE_STATE_FLAG);
+            while (*cue != it + 1) __builtin_amdgcn_s_sleep(1);
+            BF_WAVE_FENCE();
+            bf_pose_chain_row(nj, T.n_levels, wave, lane, S.part, S.par, S.lvl + nj + 67);
         }
         BF_SYNC();
         if (EXT && door) door_mid(it, Pcur);

@@ -4,7 +4,8 @@
 #pragma once
 #include "bf_internal.h"
 
-#define BF_POSE_STATE_LDS (64 * 9 + 64 * 3 + 64 * 9 + 64 * 3 + 66 + 64 + 64)
+#define BF_POSE_STATE_LDS (64 * 9 + 64 * 3 + 64 * 9 + 64 * 3 + 66 + 64 + 64 + 2)
+#define BF_POSE_STATE_FLAG (64 * 9 + 64 * 3 + 64 * 9 + 64 * 3 + 66 + 64 + 64)      // (int) "R and J of iteration <value> are complete": bf_pose_chain_row's cue
 
 namespace {
 __device__ inline void m_rodrigues(float tx, float ty, float tz, float *R) {
@@ -81,7 +82,7 @@ __device__ __forceinline__ void bf_pose_state_emit(const FitTab &T, const float 
 // WAVE: the caller is ONE wavefront (tid = lane, nt = 64) with `lds` to itself: barriers become wave fences (a wave's LDS
 // operations execute in order), everything else - the arithmetic included - is the same code.
 // `after_rotations(R)`: called by every thread once the rotations R[nj][9] are complete in LDS (behind the first fence / barrier).
-template <bool PACKED, bool WAVE = false, bool EMIT = true, class HOOK = PoseNoHook>
+template <bool PACKED, bool WAVE = false, bool EMIT = true, class HOOK = PoseNoHook, bool CHAIN = true>
 __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float *__restrict__ betas, const float *__restrict__ orient,
                                                    const float *__restrict__ body_pose, const float *__restrict__ sim, float *state,
                                                    const float *__restrict__ packed, const float *__restrict__ cscale, float cscale_all,
@@ -148,6 +149,7 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
     if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
     BF_PMARK(3);
     after_rotations(R);
+    if constexpr (!CHAIN) return;          // (the caller's other waves form the chain, row by row: bf_pose_chain_row)
     if (tid < 9) GR[tid] = R[tid];
     if (tid >= 9 && tid < 12) Gt[tid - 9] = J[tid - 9];
     if constexpr (WAVE) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); else __syncthreads();
@@ -199,3 +201,34 @@ __device__ __forceinline__ void bf_pose_state_body(const FitTab &T, const float 
     if constexpr (EMIT) bf_pose_state_emit<PACKED>(T, sim, state, packed, cscale, cscale_all, f, tid, nt, lds, betas, packed_lds);
 }
 
+// Row r of every joint's chain transform, by ONE wave (lane = joint), from the rotations R and rest joints J that another wave left
+// in `lds` (bf_pose_state_body<.., CHAIN = false>): row r of G_i depends on row r of G_parent only, so three waves form the three
+// rows side by side without ever reading each other's results.  Per element the expressions of bf_pose_state_body's own chain.
+__device__ __forceinline__ void bf_pose_chain_row(const int nj, const int n_levels, const int r, const int lane, float *lds,
+                                                  const int *parents, const int *depth) {
+    const float *R = lds, *J = R + 64 * 9;
+    float *GR = lds + 64 * 9 + 64 * 3, *Gt = GR + 64 * 9;
+    const int i = lane < nj ? lane : 0, p = i > 0 ? parents[i] : 0;
+    const int dep = lane < nj ? depth[i] : 0;
+    float Ri[9], rj[3];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) Ri[e] = R[i * 9 + e];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) rj[e] = J[i * 3 + e] - J[p * 3 + e];
+    if (lane == 0) {
+        GR[r * 3] = Ri[r * 3]; GR[r * 3 + 1] = Ri[r * 3 + 1]; GR[r * 3 + 2] = Ri[r * 3 + 2];
+        Gt[r] = J[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    for (int lev = 1; lev < n_levels; ++lev) {
+        if (lane < nj && dep == lev) {
+            const float g0 = GR[p * 9 + r * 3], g1 = GR[p * 9 + r * 3 + 1], g2 = GR[p * 9 + r * 3 + 2], gt = Gt[p * 3 + r];
+            GR[i * 9 + r * 3 + 0] = g0 * Ri[0] + g1 * Ri[3] + g2 * Ri[6];
+            GR[i * 9 + r * 3 + 1] = g0 * Ri[1] + g1 * Ri[4] + g2 * Ri[7];
+            GR[i * 9 + r * 3 + 2] = g0 * Ri[2] + g1 * Ri[5] + g2 * Ri[8];
+            const float r0 = rj[0], r1 = rj[1], r2 = rj[2];
+            Gt[i * 3 + r] = g0 * r0 + g1 * r1 + g2 * r2 + gt;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+}
