@@ -498,6 +498,26 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 S.vs[o] = acc;
                 S.dvsel[o] = 0.f;
             }
+            if (NB > 0 && NB <= 11) {
+                // (sized instance: a row of each table is three b128 - ten coefficients, the constant term, a zero - requested before the
+                //  first multiply-add; the sums themselves are the loops' below, term by term)
+                float bq[12];
+#pragma unroll
+                for (int c = 0; c < 12; ++c) bq[c] = c < nb ? beta[c] : 0.f;
+                for (int i = lane; i < nj3; i += 64) {
+                    const float4 *jd4 = (const float4 *)__builtin_assume_aligned(S.Jd + i * nbp, 16), *jr4 = (const float4 *)__builtin_assume_aligned(S.Jdrel + i * nbp, 16);
+                    const float4 a0 = jd4[0], a1 = jd4[1], a2 = jd4[2], r0 = jr4[0], r1 = jr4[1], r2 = jr4[2];
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float jd[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+                    const float jr[12] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w};
+                    float acc = 0.f, acr = jr[NB > 0 ? NB : 0];
+#pragma unroll
+                    for (int l = 0; l < (NB > 0 ? NB : 0); ++l) { acc += jd[l] * bq[l]; acr += jr[l] * bq[l]; }
+                    S.J[i] = jd[NB > 0 ? NB : 0] + acc;
+                    S.rel[i] = acr;
+                    S.dGt[i] = 0.f;
+                }
+            } else
             for (int i = lane; i < nj3; i += 64) {
                 // (J as Jt + (sum of the products, l ascending): bf_pose_state_body's arithmetic, which takes these values over - J_pre)
                 float acc = 0.f, acr = S.Jdrel[i * nbp + nb];
@@ -1432,7 +1452,10 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         if (wave >= G_ITEM_WAVES) dfeat_rows(S.dvp, tq - G_ITEM_THREADS, npf, NG - G_ITEM_THREADS);
         for (int q = tq; q < nj3 && wave < G_ITEM_WAVES; q += G_ITEM_THREADS) {
             const int p = q / 3, r = q - p * 3;
-            const unsigned long long mk = T.desc[p];
+            // (one pass: q is this thread's own (joint, row), whose descendant mask has been in registers since the prologue - T.desc is
+            //  in global memory, and a load of it at the top of this phase was ~2 k cycles of every iteration)
+            const unsigned long long mk = G_WIDE ? cmask : T.desc[p];
+            const unsigned mk_lo = (unsigned)mk, mk_hi = (unsigned)(mk >> 32);
             const float4 own = *(const float4 *)(S.N + q * 4), dgr = *(const float4 *)(S.Dg + q * 4);
             const float4 gp0 = *(const float4 *)(S.G + p * 12), gp1 = *(const float4 *)(S.G + p * 12 + 4),
                          gp2 = *(const float4 *)(S.G + p * 12 + 8);
@@ -1450,7 +1473,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #pragma unroll
                     for (int i = 0; i < HB; ++i) {
                         const int k = h * HB + i;
-                        const bool in = (k < nj) && ((mk >> k) & 1ull);
+                        const bool in = (k < nj) && (((k < 32 ? mk_lo >> (k & 31) : mk_hi >> (k & 31)) & 1u) != 0u);     // (k is a constant here: one bit test)
                         s0 += in ? nq[i].x : 0.f; s1 += in ? nq[i].y : 0.f; s2 += in ? nq[i].z : 0.f; st += in ? nq[i].w : 0.f;
                     }
                     __builtin_amdgcn_sched_barrier(0);
