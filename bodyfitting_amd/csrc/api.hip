@@ -369,6 +369,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         K.nl = m->nl_loss; K.nj = nj; K.npf = npf; K.nb = nb; K.nv = nv; K.n_all = n_all; K.n_selector = d->n_selector;
         K.n_extra = d->n_extra; K.n_lmk = n_lmk;
         K.joint_map = m->kp_jm.p; K.selector_ids = m->selector_ids.p; K.cj_start = m->cj_start.p; K.cj_list = m->cj_list.p;
+        K.n_cj_list = (int)cl.size();
         K.j_extra = m->j_extra.p;
     }
     m->mesh_smem = bf_mesh_smem_bytes(nj, npf, nb);

@@ -240,7 +240,7 @@ __device__ inline bool bf_door_wait(int *door, int which, int target) {
 
 // Dense keypoint loss inputs (device pointers / sizes).
 struct KpIO {
-    int nl, n_views, nj, npf, nb, nv, n_all, n_selector, n_extra, n_lmk;
+    int nl, n_views, nj, npf, nb, nv, n_all, n_selector, n_extra, n_lmk, n_cj_list;
     float sigma2, coeff;
     const int *joint_map;        // [nl] index into the all-joints array
     const int *selector_ids;     // [n_selector]

@@ -62,21 +62,37 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
     const float ndiv_f = (float)ndiv[f], icoeff = 1.0f / Q.coeff, kscale = -1.0f / (Q.coeff * ndiv_f), s2 = Q.sigma2;
     const int j = tid % NLP, vs = tid / NLP;
     float g0 = 0.f, g1 = 0.f, g2 = 0.f, ls = 0.f;
+    // The views' projection matrices are staged in LDS once (the routing keys' slot: free until the loss is summed) and a thread's
+    // keypoints are requested four views ahead: rolled, with everything read from global memory inside it, the loop paid one
+    // memory latency per view - 16 views per thread, 21 k of this workgroup's 49 k cycles (round 3 stamps).  The arithmetic and its
+    // order per (joint, view slot) are unchanged.
+    float *s_P = s_x + nl * 3 + 8;                        // [V][12] while V * 12 <= 1024 + 3 nl, else the matrices stay in global memory
+    const bool p_lds = V * 12 <= 1024 + nl * 3;
+    // ... and the model's small index tables (joint map, the chain joints' CSR lists, selector vertex ids) go to LDS with them: every
+    // one of them was the first half of a dependent pair of global loads somewhere down this workgroup's chain
+    int *s_jm = (int *)(s_x + nl * 3 + 8) + 1024 + nl * 3 + 16;      // [nl] joint_map | [nj + 1] cj_start | [nl] cj_list | [n_selector] (bf_kp_tab_ints)
+    int *s_cs = s_jm + nl, *s_cl = s_cs + Q.nj + 1, *s_sel = s_cl + nl;
+    for (int i = tid; i < nl; i += 512) { s_jm[i] = Q.joint_map[i]; if (i < Q.n_cj_list) s_cl[i] = Q.cj_list[i]; }
+    for (int i = tid; i <= Q.nj; i += 512) s_cs[i] = Q.cj_start[i];
+    for (int i = tid; i < Q.n_selector; i += 512) s_sel[i] = Q.selector_ids[i];
+    if (p_lds)
+        for (int i = tid; i < V * 12; i += 512) s_P[i] = proj_all[(size_t)f * V * 12 + i];
+    __syncthreads();
     if (vs < slots && j < nl) {
-        const float *x = jraw + ((size_t)f * Q.n_all + Q.joint_map[j]) * 3;
+        const float *x = jraw + ((size_t)f * Q.n_all + s_jm[j]) * 3;
         const float y0 = x[0] + t0, y1 = x[1] + t1, y2 = x[2] + t2;
         const float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
         if (vs == 0) { s_x[j * 3] = x[0]; s_x[j * 3 + 1] = x[1]; s_x[j * 3 + 2] = x[2]; }
-        for (int v = vs; v < V; v += slots) {
-            const float *P = proj_all + ((size_t)f * V + v) * 12;
-            const float *kp = keypoints + (((size_t)f * V + v) * nl + j) * 3;
-            float c2 = kp[2] * kp[2];
+        auto one_view = [&](const float *P, float kx, float ky, float kc) {
+            float c2 = kc * kc;
             float p0 = P[0] * x0 + P[1] * x1 + P[2] * x2 + P[3];
             float p1 = P[4] * x0 + P[5] * x1 + P[6] * x2 + P[7];
             float p2 = P[8] * x0 + P[9] * x1 + P[10] * x2 + P[11];
-            float ip2 = 1.0f / p2, u = p0 * ip2, w = p1 * ip2;
-            float rx = (kp[0] - u) * icoeff, ry = (kp[1] - w) * icoeff;
-            float ix = 1.0f / (s2 + rx * rx), iy = 1.0f / (s2 + ry * ry);
+            // (v_rcp_f32, 1 ulp, like the sparse fit kernel's projection: the three correctly rounded divisions were a quarter of this
+            //  loop's instructions, and the loop is issue-bound - eight waves of one workgroup share four SIMDs)
+            float ip2 = __builtin_amdgcn_rcpf(p2), u = p0 * ip2, w = p1 * ip2;
+            float rx = (kx - u) * icoeff, ry = (ky - w) * icoeff;
+            float ix = __builtin_amdgcn_rcpf(s2 + rx * rx), iy = __builtin_amdgcn_rcpf(s2 + ry * ry);
             ls += c2 * (s2 * rx * rx * ix + s2 * ry * ry * iy);
             float k = c2 * kscale;
             float du = k * (2.f * s2 * s2 * rx * ix * ix), dw = k * (2.f * s2 * s2 * ry * iy * iy);
@@ -84,6 +100,27 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
             g0 += P[0] * q0 + P[4] * q1 + P[8] * q2;
             g1 += P[1] * q0 + P[5] * q1 + P[9] * q2;
             g2 += P[2] * q0 + P[6] * q1 + P[10] * q2;
+        };
+        const float *kp0 = keypoints + ((size_t)f * V * nl + j) * 3;             // + v * nl * 3
+        auto fetch = [&](int v, float *k3) {
+            if (v < V) { const float *kp = kp0 + (size_t)v * nl * 3; k3[0] = kp[0]; k3[1] = kp[1]; k3[2] = kp[2]; }
+            else { k3[0] = 0.f; k3[1] = 0.f; k3[2] = 0.f; }
+        };
+        float kn[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fetch(vs + q * slots, kn[q]);
+        for (int v = vs; v < V; v += 4 * slots) {
+            float kc_[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { kc_[q][0] = kn[q][0]; kc_[q][1] = kn[q][1]; kc_[q][2] = kn[q][2]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fetch(v + (4 + q) * slots, kn[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int vv = v + q * slots;
+                // (two calls, not one pointer chosen between LDS and global memory: that pointer would be a flat one)
+                if (vv < V) { if (p_lds) one_view(s_P + vv * 12, kc_[q][0], kc_[q][1], kc_[q][2]); else one_view(proj_all + ((size_t)f * V + vv) * 12, kc_[q][0], kc_[q][1], kc_[q][2]); }
+            }
         }
     }
     if (vs < slots && j < NLP) { float4 pr = {g0, g1, g2, ls}; ((float4 *)s_part)[vs * NLP + j] = pr; }
@@ -100,7 +137,7 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
     for (int i = tid; i < Q.nj * 3; i += 512) {
         int cj = i / 3, k = i - cj * 3;
         float acc = 0.f;
-        for (int q = Q.cj_start[cj]; q < Q.cj_start[cj + 1]; ++q) acc += s_g[Q.cj_list[q] * 4 + k];
+        for (int q = s_cs[cj]; q < s_cs[cj + 1]; ++q) acc += s_g[s_cl[q] * 4 + k];
         e[EXT_G + i] = acc * sc;
     }
     {
@@ -111,7 +148,7 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
         if (which >= 0 && which < 5) {
             float acc = 0.f;
             for (int q = lane; q < nl; q += 64) {
-                const bool chain = Q.joint_map[q] < Q.nj;
+                const bool chain = s_jm[q] < Q.nj;
                 if (which < 3) acc += chain ? s_g[q * 4 + which] : 0.f;
                 else if (which == 3) acc += chain ? s_g[q * 4] * (s_x[q * 3] + t0) + s_g[q * 4 + 1] * (s_x[q * 3 + 1] + t1) + s_g[q * 4 + 2] * (s_x[q * 3 + 2] + t2) : 0.f;
                 else acc += s_g[q * 4 + 3];
@@ -142,11 +179,11 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
     for (int i = tid; i < N; i += 512) {
         int key = 0x7fffffff;
         if (i < n_items) {
-            const int q = i / 3, c = i - q * 3, src = Q.joint_map[q];
+            const int q = i / 3, c = i - q * 3, src = s_jm[q];
             int vid = -1;
             float w = 1.f;
             if (src >= Q.nj) {
-                if (src < n_ori) { if (c == 0) vid = Q.selector_ids[src - Q.nj]; }
+                if (src < n_ori) { if (c == 0) vid = s_sel[src - Q.nj]; }
                 else if (src < n_ori + Q.n_extra) { }                  // a regressed joint: every vertex of its row, below
                 else {
                     const size_t l = ((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c;
@@ -160,6 +197,28 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
         s_key[i] = key;
     }
     __syncthreads();
+    if (N == 512) {
+        // one key per thread: a compare-exchange with a partner less than 64 positions away is a wave shuffle (39 of the 45 stages);
+        // the six others cross waves through LDS.  (All in LDS with a barrier per stage this sort was 20 k of the workgroup's 49 k cycles.)
+        int key = s_key[tid];
+        for (int k = 2; k <= 512; k <<= 1)
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                int other;
+                if (jj < 64) other = __shfl_xor(key, jj);
+                else {
+                    __syncthreads();
+                    s_key[tid] = key;
+                    __syncthreads();
+                    other = s_key[tid ^ jj];
+                }
+                const bool up = (tid & k) == 0, low = (tid & jj) == 0;            // (ascending block; this thread holds the lower position)
+                const int lo = key < other ? key : other, hi = key < other ? other : key;
+                key = (up == low) ? lo : hi;
+            }
+        __syncthreads();
+        s_key[tid] = key;
+        __syncthreads();
+    } else
     for (int k = 2; k <= N; k <<= 1)
         for (int jj = k >> 1; jj > 0; jj >>= 1) {
             for (int t = tid; t < N / 2; t += 512) {
@@ -190,7 +249,7 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
     if (Q.n_extra > 0) {
         __syncthreads();
         for (int q = 0; q < nl; ++q) {
-            const int src = Q.joint_map[q];
+            const int src = s_jm[q];
             if (src < n_ori || src >= n_ori + Q.n_extra) continue;
             const float *row = Q.j_extra + (size_t)(src - n_ori) * Q.nv;
             const float gq0 = s_g[q * 4], gq1 = s_g[q * 4 + 1], gq2 = s_g[q * 4 + 2];

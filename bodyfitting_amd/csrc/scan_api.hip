@@ -274,7 +274,9 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
 static size_t kp_smem(const KpIO &K) {
     const int NLP = (K.nl + 31) & ~31, slots = std::max(1, 512 / NLP);
     // (the joints prologue's scratch, 32*3 + 256*3 + 4 floats, fits the head of this)
-    return sizeof(float) * std::max<size_t>(1024, (size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + 1024 + (size_t)K.nl * 3 + 16);   // (+ sort keys, item weights)
+    // (+ sort keys, item weights, + the index tables staged in LDS: joint map, chain-joint CSR, selector ids)
+    return sizeof(float) * std::max<size_t>(1024, (size_t)slots * NLP * 4 + (size_t)K.nl * 4 + (size_t)K.nl * 3 + 8 + 1024 + (size_t)K.nl * 3 + 16 +
+                                                   (size_t)K.nl * 2 + K.nj + 1 + K.n_selector + 16);
 
 }
 static KpIO kp_io(bf_batch *b, const bf_hyper &h, bool sub = false) {
