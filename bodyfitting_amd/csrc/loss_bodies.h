@@ -66,8 +66,8 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
     // keypoints are requested four views ahead: rolled, with everything read from global memory inside it, the loop paid one
     // memory latency per view - 16 views per thread, 21 k of this workgroup's 49 k cycles (round 3 stamps).  The arithmetic and its
     // order per (joint, view slot) are unchanged.
-    float *s_P = s_x + nl * 3 + 8;                        // [V][12] while V * 12 <= 1024 + 3 nl, else the matrices stay in global memory
-    const bool p_lds = V * 12 <= 1024 + nl * 3;
+    float *s_P = sm + ((slots * NLP * 4 + nl * 4 + nl * 3 + 8 + 3) & ~3);   // [V][12], 16-byte aligned (three b128 per view), while it fits the keys' + weights' slot
+    const bool p_lds = V * 12 + 3 <= 1024 + nl * 3;
     // ... and the model's small index tables (joint map, the chain joints' CSR lists, selector vertex ids) go to LDS with them: every
     // one of them was the first half of a dependent pair of global loads somewhere down this workgroup's chain
     int *s_jm = (int *)(s_x + nl * 3 + 8) + 1024 + nl * 3 + 16;      // [nl] joint_map | [nj + 1] cj_start | [nl] cj_list | [n_selector] (bf_kp_tab_ints)
@@ -83,7 +83,9 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
         const float y0 = x[0] + t0, y1 = x[1] + t1, y2 = x[2] + t2;
         const float x0 = y0 * sc, x1 = y1 * sc, x2 = y2 * sc;
         if (vs == 0) { s_x[j * 3] = x[0]; s_x[j * 3 + 1] = x[1]; s_x[j * 3 + 2] = x[2]; }
-        auto one_view = [&](const float *P, float kx, float ky, float kc) {
+        auto one_view = [&](const float *Pm, float kx, float ky, float kc) {
+            const float4 Pr0 = ((const float4 *)Pm)[0], Pr1 = ((const float4 *)Pm)[1], Pr2 = ((const float4 *)Pm)[2];       // (rows of K [R | t]; 16-byte aligned in both homes)
+            const float P[12] = {Pr0.x, Pr0.y, Pr0.z, Pr0.w, Pr1.x, Pr1.y, Pr1.z, Pr1.w, Pr2.x, Pr2.y, Pr2.z, Pr2.w};
             float c2 = kc * kc;
             float p0 = P[0] * x0 + P[1] * x1 + P[2] * x2 + P[3];
             float p1 = P[4] * x0 + P[5] * x1 + P[6] * x2 + P[7];
