@@ -352,7 +352,18 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         if (!up) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (landmarks)"); }
         for (int i = 0; i < d->n_lmk_static; ++i)
             if (d->lmk_faces_idx[i] < 0 || d->lmk_faces_idx[i] >= d->n_faces) { delete m; return fail(BF_ERR_INVALID, "bf_model_create: landmark face out of range"); }
+        for (size_t i = 0; i < (size_t)d->n_dyn_rows * d->n_lmk_dynamic; ++i)
+            if (d->dynamic_lmk_faces_idx[i] < 0 || d->dynamic_lmk_faces_idx[i] >= d->n_faces) { delete m; return fail(BF_ERR_INVALID, "bf_model_create: dynamic landmark face out of range"); }
         Q.faces = m->faces_lm.p; Q.lmk_faces = m->lmk_faces.p; Q.lmk_bary = m->lmk_bary.p; Q.dyn_faces = m->dyn_faces.p; Q.dyn_bary = m->dyn_bary.p;
+        // the landmarks' corner vertices, looked up once (MeshTab::lmk_fv / dyn_fv)
+        std::vector<int> sfv((size_t)d->n_lmk_static * 3), dfv((size_t)d->n_dyn_rows * d->n_lmk_dynamic * 3);
+        for (int i = 0; i < d->n_lmk_static; ++i)
+            for (int c = 0; c < 3; ++c) sfv[(size_t)i * 3 + c] = d->faces[(size_t)d->lmk_faces_idx[i] * 3 + c];
+        for (size_t i = 0; i < (size_t)d->n_dyn_rows * d->n_lmk_dynamic; ++i)
+            for (int c = 0; c < 3; ++c) dfv[i * 3 + c] = d->faces[(size_t)d->dynamic_lmk_faces_idx[i] * 3 + c];
+        if (dfv.empty()) dfv.push_back(0);
+        if (m->lmk_fv.upload(sfv) != hipSuccess || m->dyn_fv.upload(dfv) != hipSuccess) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (landmark corners)"); }
+        Q.lmk_fv = m->lmk_fv.p; Q.dyn_fv = m->dyn_fv.p;
     }
     if (m->kp_dense) {
         // dense keypoint loss tables: loss joints -> all-joints index; per chain joint the loss joints that use it
@@ -426,7 +437,17 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
             U.mesh.v_template = U.v_template.p; U.mesh.shapedirs = U.shapedirs.p; U.mesh.posedirs = U.posedirs.p;
             U.mesh.lbs_weights = U.lbs_weights.p; U.mesh.j_extra = U.j_extra.p; U.mesh.selector_ids = U.selector_ids.p;
             U.mesh.v_nzj = U.v_nzj.p; U.mesh.v_nzw = U.v_nzw.p;
-            if (smplx) U.mesh.faces = U.faces.p;
+            if (smplx) {
+                U.mesh.faces = U.faces.p;
+                std::vector<int> sfv((size_t)d->n_lmk_static * 3), dfv((size_t)d->n_dyn_rows * d->n_lmk_dynamic * 3);
+                for (int i = 0; i < d->n_lmk_static; ++i)
+                    for (int c = 0; c < 3; ++c) sfv[(size_t)i * 3 + c] = fc[(size_t)d->lmk_faces_idx[i] * 3 + c];
+                for (size_t i = 0; i < (size_t)d->n_dyn_rows * d->n_lmk_dynamic; ++i)
+                    for (int c = 0; c < 3; ++c) dfv[i * 3 + c] = fc[(size_t)d->dynamic_lmk_faces_idx[i] * 3 + c];
+                if (dfv.empty()) dfv.push_back(0);
+                if (U.lmk_fv.upload(sfv) != hipSuccess || U.dyn_fv.upload(dfv) != hipSuccess) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (sub-model landmark corners)"); }
+                U.mesh.lmk_fv = U.lmk_fv.p; U.mesh.dyn_fv = U.dyn_fv.p;
+            }
             U.kp = m->kp; U.kp.nv = sv; U.kp.selector_ids = U.selector_ids.p; U.kp.j_extra = U.j_extra.p;
             U.ns = n_samp;
             U.on = true;

@@ -87,7 +87,7 @@ struct bf_model {
     DevBuf<float> Jt, Jd, Jdrel, sel_vt, sel_sd, sel_pd, sel_w, g_means, g_psym, g_logw;
     // SMPL-X pose assembly / parameter routing / landmarks / dense keypoint loss
     int kind = 0, kp_dense = 0, n_lmk = 0, n_all = 0, nl_loss = 0;
-    DevBuf<int> th_kind, th_off, p_kind, p_a, p_b, faces_lm, lmk_faces, dyn_faces, kp_jm, cj_start, cj_list;
+    DevBuf<int> th_kind, th_off, p_kind, p_a, p_b, faces_lm, lmk_faces, dyn_faces, kp_jm, cj_start, cj_list, lmk_fv, dyn_fv;
     DevBuf<float> pose_mean, hand_comp, lmk_bary, dyn_bary;
     KpIO kp{};
     DevBuf<int> v_nzj;            // sparse skinning rows (MeshTab::v_nnz)
@@ -102,7 +102,7 @@ struct bf_model {
         MeshTab mesh{};
         KpIO kp{};
         DevBuf<float> v_template, shapedirs, posedirs, lbs_weights, j_extra, v_nzw, posedirsT;
-        DevBuf<int> v_nzj, selector_ids, faces;
+        DevBuf<int> v_nzj, selector_ids, faces, lmk_fv, dyn_fv;
     } sub;
     DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass (under `lazy`, device-synchronised)
     DevBuf<float> fit_image;      // FitTab::lds_image of the dense-schedule fit instance, built on first use (under `lazy`)

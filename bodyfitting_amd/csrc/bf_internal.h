@@ -90,6 +90,9 @@ struct MeshTab {
     const float *lmk_bary;           // [n_lmk_static][3]
     const int *dyn_faces;            // [rows][n_lmk_dyn]
     const float *dyn_bary;           // [rows][n_lmk_dyn][3]
+    const int *lmk_fv, *dyn_fv;      // [n_lmk_static][3] / [rows][n_lmk_dyn][3]: faces[lmk_faces[l]] / faces[dyn_faces[..]] looked up once, on the host
+                                     // (the joints prologue of the dense keypoint workgroup had three dependent global loads per landmark: face ->
+                                     //  its corners -> their coordinates; now two)
 };
 
 // theta_j[k] of the full pose: shared by the fit kernel (LDS copies of the tables) and the pose-state kernel

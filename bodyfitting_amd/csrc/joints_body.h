@@ -62,9 +62,9 @@ __device__ __forceinline__ void bf_joints_body(const MeshTab &M, const float *__
         else if (j < n_ori + ne) x = s_extra[(j - n_ori) * 3 + k];
         else {
             int l = j - n_ori - ne;
-            int face = l < M.n_lmk_static ? M.lmk_faces[l] : M.dyn_faces[s_row * M.n_lmk_dyn + (l - M.n_lmk_static)];
             const float *bw = l < M.n_lmk_static ? M.lmk_bary + l * 3 : M.dyn_bary + ((size_t)s_row * M.n_lmk_dyn + (l - M.n_lmk_static)) * 3;
-            const int *fv = M.faces + (size_t)face * 3;
+            // (the landmark's corner vertices: faces[lmk_faces[l]] / faces[dyn_faces[row][.]], looked up on the host)
+            const int *fv = l < M.n_lmk_static ? M.lmk_fv + l * 3 : M.dyn_fv + ((size_t)s_row * M.n_lmk_dyn + (l - M.n_lmk_static)) * 3;
             x = bw[0] * vr[(size_t)fv[0] * 3 + k] + bw[1] * vr[(size_t)fv[1] * 3 + k] + bw[2] * vr[(size_t)fv[2] * 3 + k];
             if (k == 0 && lmk_vid) {
                 int *vo = lmk_vid + ((size_t)frame * nlm + l) * 3;
