@@ -290,26 +290,42 @@ __device__ __forceinline__ void bf_mask_contour_body(int bx, int m, int f, float
         r.z = __fadd_rn(__fmul_rn(r.x, r.x), __fmul_rn(r.y, r.y));
         return r;
     };
+    // The tile sits in LDS as three arrays - X = -2 u, Y = -2 v (cdist form; u, v in the exact form), Z = |uv|^2 - and lane `sub` takes the
+    // records 2 sub, 2 sub + 1 (+ 32 t): a pair is three b64 reads and the distance of both is five packed instructions (the factor
+    // -2 is applied once per record when the tile is stored, not once per evaluation; a product by 2 is exact, so the bits are those of
+    // the one-record form).  Each lane still walks its records in ascending order with a strict <, and the lanes are merged on
+    // (distance, index): torch.min's first minimum, whatever the partition.
+    typedef float c2f __attribute__((ext_vector_type(2)));
+    float *tX = (float *)tile, *tY = tX + NT, *tZ = tY + NT;
     float4 nxt = fetch(threadIdx.x);
     for (int base = 0; base < K.ns; base += NT) {
-        tile[threadIdx.x] = nxt;
+        tX[threadIdx.x] = cdist ? -2.f * nxt.x : nxt.x;
+        tY[threadIdx.x] = cdist ? -2.f * nxt.y : nxt.y;
+        tZ[threadIdx.x] = nxt.z;
         nxt = fetch(base + NT + threadIdx.x);
         __syncthreads();
-        int lim = min(NT, K.ns - base);
-        for (int i = sub; i < lim; i += 16) {
-            const float4 r = tile[i];
-            float d2;
-            if (cdist) {
-                float acc = __fmul_rn(cx, -2.f * r.x);
-                acc = __fmaf_rn(cy, -2.f * r.y, acc);
-                acc = __fadd_rn(acc, r.z);
-                acc = __fadd_rn(acc, n2);
-                d2 = fmaxf(acc, 0.f);                                          // clamp_min(0); a parked vertex gives +inf
-            } else {
-                const float dx = r.x - cx, dy = r.y - cy;
-                d2 = dx * dx + dy * dy;
+        const int lim = min(NT, K.ns - base);
+        if (cdist) {
+            const c2f cx2 = {cx, cx}, cy2 = {cy, cy}, n22 = {n2, n2};
+            for (int i = 2 * sub; i < lim; i += 32) {
+                const c2f x2 = *(const c2f *)(tX + i), y2 = *(const c2f *)(tY + i), z2 = *(const c2f *)(tZ + i);
+                c2f acc = cx2 * x2;                                            // (separate statements: no contraction across them, as in the scalar form)
+                acc = __builtin_elementwise_fma(cy2, y2, acc);
+                acc = acc + z2;
+                acc = acc + n22;
+                const float d0 = fmaxf(acc.x, 0.f), d1 = fmaxf(acc.y, 0.f);  // clamp_min(0); a parked record gives +inf (so does one past the end)
+                if (d0 < best) { best = d0; bidx = base + i; }
+                if (d1 < best) { best = d1; bidx = base + i + 1; }
             }
-            if (d2 < best) { best = d2; bidx = base + i; }                     // first minimum of this lane's subset
+        } else {
+            for (int i = 2 * sub; i < lim; i += 32) {
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const float dx = tX[i + e] - cx, dy = tY[i + e] - cy;
+                    const float d2 = dx * dx + dy * dy;
+                    if (d2 < best) { best = d2; bidx = base + i + e; }
+                }
+            }
         }
         __syncthreads();
     }
