@@ -9,7 +9,7 @@ python3 - "$f" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 idx=[i for i,r in enumerate(rows) if r['Kernel_Name'].startswith('bf_kp_contour')]
-k=idx[len(idx)//2]
+k=idx[-20]
 t0=int(rows[k-6]['Start_Timestamp'])
 for r in rows[k-7:k+9]:
     s=(int(r['Start_Timestamp'])-t0)/1000; e=(int(r['End_Timestamp'])-t0)/1000
