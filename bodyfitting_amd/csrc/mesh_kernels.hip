@@ -369,13 +369,17 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
             s_red[f * COLS + col] = ok ? (r + sb[k]) * sb[3] * sb[4] : 0.f;
         }
         __syncthreads();
-        if (mine) {
+        {
+            // (every thread of the workgroup takes (frame, sample, view) items - with one frame per workgroup only the 96 threads of row
+            //  group 0 used to: three passes of projection + four dependent mask reads each instead of one)
             const int sst = mp.K.sstride, spt = BF_MESH_TILE / sst;        // samples of a tile: every 4th vertex, or (sub-model) all that are samples
-            for (int idx = col; idx < spt * mp.K.n_masks; idx += COLS) {
-                const int sv = idx % spt, m = idx / spt, vv = tile * BF_MESH_TILE + sv * sst, sidx = sst == 4 ? vv >> 2 : vv;
+            const int per = spt * mp.K.n_masks;
+            for (int idx = tid; idx < per * nf; idx += nt) {
+                const int ff = idx / per, q = idx - ff * per;
+                const int sv = q % spt, m = q / spt, vv = tile * BF_MESH_TILE + sv * sst, sidx = sst == 4 ? vv >> 2 : vv;
                 if (vv < nv && sidx < mp.K.ns) {
-                    const float *X = s_red + f * COLS + sv * sst * 3;
-                    (void)bf_mask_project_one(mp.K, X[0], X[1], X[2], mp.proj, fbase + f, m, sidx, mp.uvi, mp.duvb);
+                    const float *X = s_red + ff * COLS + sv * sst * 3;
+                    (void)bf_mask_project_one(mp.K, X[0], X[1], X[2], mp.proj, fbase + ff, m, sidx, mp.uvi, mp.duvb);
                 }
             }
         }
