@@ -231,6 +231,25 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
 #pragma unroll
     for (int i = 0; i < BF_MM_CH; ++i) pv[i] = p0 + i < p1 ? pd[(size_t)i * ncols] : 0.f;
     const bool coh = door && (door_target & BF_DOOR_COHERENT_BIT);
+    // ... and so are the model rows the epilogue needs for this thread's vertex coordinate (shape directions, template, the sparse
+    // skinning row): they depend on nothing that is waited for below, and requested here their two memory round trips are over
+    // before the pose blend is (they used to start behind it, on the 96 threads that do the epilogue of a frame)
+    // (one frame per workgroup only: with eight, the 28 registers of the rows take the kernel from 3 to 2 waves per SIMD - config 5's
+    //  iteration went from 0.202 to 0.214 ms)
+    const bool pre = FPW == 1 && rg < nf && ok && nb <= 10 && (M.v_nnz == 4 || M.v_nnz == 8);
+    float pre_sd[10], pre_vt = 0.f, pre_w[8];
+    int pre_j[8];
+    if (pre) {
+        const float *sd = M.shapedirs + (size_t)gcol * nb;
+#pragma unroll
+        for (int l = 0; l < 10; ++l) pre_sd[l] = l < nb ? sd[l] : 0.f;
+        pre_vt = M.v_template[gcol];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            pre_w[q] = q < M.v_nnz ? M.v_nzw[(size_t)v * M.v_nnz + q] : 0.f;
+            pre_j[q] = q < M.v_nnz ? M.v_nzj[(size_t)v * M.v_nnz + q] : 0;
+        }
+    }
     const int door_copy = (int)((blockIdx.x + 7 * blockIdx.y) % BF_DOOR_COPIES) * BF_DOOR_COPY_STRIDE;
     if (door) {        // the pose FEATURES come first from the persistent fit launch (BF_DOOR_FEAT): wait for all of them, under the first chunk's loads
         if (tid == 0) bf_door_wait(door, BF_DOOR_FEAT + door_copy, door_target & ~BF_DOOR_COHERENT_BIT);
@@ -318,9 +337,15 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
     const bool mine = f < nf;
     float a2 = 0.f, vt = 0.f;
     if (mine && ok) {
-        const float *sd = M.shapedirs + (size_t)gcol * nb;
-        vt = M.v_template[gcol];
-        for (int l = 0; l < nb; ++l) a2 += sd[l] * s_beta[f * 32 + l];
+        if (pre) {
+            vt = pre_vt;
+#pragma unroll
+            for (int l = 0; l < 10; ++l) if (l < nb) a2 += pre_sd[l] * s_beta[f * 32 + l];
+        } else {
+            const float *sd = M.shapedirs + (size_t)gcol * nb;
+            vt = M.v_template[gcol];
+            for (int l = 0; l < nb; ++l) a2 += sd[l] * s_beta[f * 32 + l];
+        }
     }
     __syncthreads();
     if (mine) {
@@ -337,7 +362,15 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
     if (mine && ok) {
         const float *A = s_A + f * nj * 12;
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, tt = 0.f;
-        if (M.v_nnz) {
+        if (pre) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (q < M.v_nnz) {
+                    const float w = pre_w[q];
+                    const float4 a = *(const float4 *)(A + pre_j[q] * 12 + k * 4);
+                    t0 += w * a.x; t1 += w * a.y; t2 += w * a.z; tt += w * a.w;
+                }
+        } else if (M.v_nnz) {
             const int nnz = M.v_nnz;
             for (int q = 0; q < nnz; ++q) {
                 const float w = M.v_nzw[(size_t)v * nnz + q];
