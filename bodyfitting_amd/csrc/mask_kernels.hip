@@ -57,20 +57,28 @@ bf_mask_contour_kernel(MaskIO K, const float *__restrict__ uvi, int *__restrict_
 
 // grid (ceil(Ns/64), M, F), 256 threads.  gpart[f][m][s][3] = dL/dvertex 4 s from mask view m (one workgroup per view and
 // block of 64 sampled vertices: the views run in parallel; bf_mask_gsum_kernel adds them in view order).  The workgroup
-// walks the contour 256 points at a time; a point that chose one of ITS vertices is appended - in contour order, by ballot
+// walks the contour 1,024 points at a time (four per thread); a point that chose one of ITS vertices is appended - in contour order, by ballot
 // ranks - to a short list in LDS (a block of 64 vertices is chosen by ~70 of the ~3000 points), and the 64 vertex lanes add
 // up their entries of the list in list order = contour order (deterministic; no atomics).  The first version compared every
 // point with every vertex of the block: 64 compares per point instead of one.
 extern "C" __global__ void __launch_bounds__(256)
 bf_mask_gather_kernel(MaskIO K, const float *__restrict__ proj_all, const float *__restrict__ uvi, const float *__restrict__ duvb,
                       const int *__restrict__ choice, const float *__restrict__ cgrad, float *__restrict__ gpart) {
-    constexpr int CAP = 1024;
+    constexpr int CAP = 2048, SUB = 4;                     // SUB x 256 contour points per step: two barriers per 1,024 points, not per 256
     __shared__ int s_v[CAP];                               // vertex (0..63 inside the block) of a listed point
     __shared__ float2 s_g[CAP];
-    __shared__ int s_wcnt[4];
+    __shared__ int s_wcnt[SUB * 4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, s0 = blockIdx.x * 64, m = blockIdx.y, f = blockIdx.z;
     const int vm = f * K.n_masks + m;
     const int cnt = K.contour_count[vm];
+    // (what the closing step needs is requested now: it depends on nothing the walk produces)
+    const int s_fin = s0 + tid;
+    float fin_tu = 0.f, fin_tv = 0.f;
+    float4 fin_r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 64 && s_fin < K.ns) {
+        fin_tu = duvb[((size_t)vm * K.ns + s_fin) * 2]; fin_tv = duvb[((size_t)vm * K.ns + s_fin) * 2 + 1];
+        fin_r = ((const float4 *)uvi)[(size_t)vm * K.ns + s_fin];
+    }
     float du = 0.f, dv = 0.f;                              // (vertex lanes: tid < 64)
     int n = 0;                                             // (uniform) entries in the list
     auto drain = [&]() {
@@ -80,33 +88,51 @@ bf_mask_gather_kernel(MaskIO K, const float *__restrict__ proj_all, const float 
         n = 0;
         __syncthreads();
     };
-    // (the next tile of the contour is requested before this one is handled)
-    int ch_n = tid < cnt ? choice[(size_t)vm * K.cmax + tid] : -1;
-    float2 g_n = tid < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + tid] : make_float2(0.f, 0.f);
-    for (int base = 0; base < cnt; base += 256) {
-        const int ch = ch_n;
-        const float2 g = g_n;
-        const int c2 = base + 256 + tid;
-        ch_n = c2 < cnt ? choice[(size_t)vm * K.cmax + c2] : -1;
-        g_n = c2 < cnt ? ((const float2 *)cgrad)[(size_t)vm * K.cmax + c2] : make_float2(0.f, 0.f);
-        const bool mine = ch >= s0 && ch < s0 + 64;
-        const unsigned long long mk = __ballot(mine);
-        if (lane == 0) s_wcnt[wv] = __popcll(mk);
+    // (the next step's points are requested before this step's are handled)
+    const int *chp = choice + (size_t)vm * K.cmax;
+    const float2 *cgp = (const float2 *)cgrad + (size_t)vm * K.cmax;
+    int ch_n[SUB];
+    float2 g_n[SUB];
+#pragma unroll
+    for (int j = 0; j < SUB; ++j) {
+        const int c = j * 256 + tid;
+        ch_n[j] = c < cnt ? chp[c] : -1;
+        g_n[j] = c < cnt ? cgp[c] : make_float2(0.f, 0.f);
+    }
+    for (int base = 0; base < cnt; base += SUB * 256) {
+        int ch[SUB];
+        float2 g[SUB];
+        bool mine[SUB];
+        unsigned long long mk[SUB];
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            ch[j] = ch_n[j]; g[j] = g_n[j];
+            const int c2 = base + SUB * 256 + j * 256 + tid;
+            ch_n[j] = c2 < cnt ? chp[c2] : -1;
+            g_n[j] = c2 < cnt ? cgp[c2] : make_float2(0.f, 0.f);
+            mine[j] = ch[j] >= s0 && ch[j] < s0 + 64;
+            mk[j] = __ballot(mine[j]);
+            if (lane == 0) s_wcnt[j * 4 + wv] = __popcll(mk[j]);
+        }
         __syncthreads();
-        int off = n;
-        for (int w = 0; w < wv; ++w) off += s_wcnt[w];
-        const int total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-        if (mine) { const int o = off + __popcll(mk & ((1ull << lane) - 1ull)); s_v[o] = ch - s0; s_g[o] = g; }
-        n += total;
+        int off = n;                                       // contour order: sub-tile after sub-tile, wave after wave, lane after lane
+#pragma unroll
+        for (int j = 0; j < SUB; ++j) {
+            int mine_off = off;
+            for (int w = 0; w < wv; ++w) mine_off += s_wcnt[j * 4 + w];
+            if (mine[j]) { const int o = mine_off + __popcll(mk[j] & ((1ull << lane) - 1ull)); s_v[o] = ch[j] - s0; s_g[o] = g[j]; }
+            off += s_wcnt[j * 4] + s_wcnt[j * 4 + 1] + s_wcnt[j * 4 + 2] + s_wcnt[j * 4 + 3];
+        }
+        n = off;
         __syncthreads();
-        if (n > CAP - 256) drain();
+        if (n > CAP - SUB * 256) drain();
     }
     drain();
-    const int s = s0 + tid;
+    const int s = s_fin;
     if (tid < 64 && s < K.ns) {
-        float tu = duvb[((size_t)vm * K.ns + s) * 2], tv = duvb[((size_t)vm * K.ns + s) * 2 + 1];
+        float tu = fin_tu, tv = fin_tv;
         tu += du; tv += dv;
-        float4 r = ((const float4 *)uvi)[(size_t)vm * K.ns + s];
+        float4 r = fin_r;
         const float *P = proj_all + ((size_t)f * K.n_views + K.view_index[m]) * 12;
         float q0 = tu * r.w, q1 = tv * r.w, q2 = -(tu * r.x + tv * r.y) * r.w;
         float *o = gpart + ((size_t)vm * K.ns + s) * 3;
