@@ -9,7 +9,7 @@ extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int
 extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
 extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const float *, int, const float *, const float *, const float *, float *, hipStream_t,
-                                        const float *, int, int, int);
+                                        const float *, int, int, int, int, int *);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int, int *, int);
 extern "C" int bf_mesh_use_multi(int npf, int n);
 extern "C" __global__ void bf_door_probe_kernel(int *);
@@ -400,13 +400,15 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
                            b->dvout.p, b->pc_loss.p, (kp || masks) ? 1 : 0);
     }
     const int EXT = m->npf + m->nj * 12 + m->nb + 4;
+    int part_rows = Q.n_tiles;             // (two per tile when the reverse pass splits its tiles: one frame, a small grid)
     {
         const int e = bf_mesh_bwd_multi_launch(&Q, sub ? m->sub.posedirsT.p : m->posedirsT.p, b->state.p, F, b->dvout.p, b->vposed.p, b->vraw.p, b->ext_part.p,
-                                               b->stream, fold_views ? (const float *)b->mk_gpart.p : nullptr, b->mask.n_masks, b->mask.ns, sub ? 1 : 4);
+                                               b->stream, fold_views ? (const float *)b->mk_gpart.p : nullptr, b->mask.n_masks, b->mask.ns, sub ? 1 : 4,
+                                               m->mesh.n_tiles, &part_rows);
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_bwd_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     }
     hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 31) / 32, F), dim3(256), 0, b->stream,
-                       (const float *)b->ext_part.p, Q.n_tiles, EXT, b->ext.p, EXT + m->nj * 3 + 4, door, door_k);
+                       (const float *)b->ext_part.p, part_rows, EXT, b->ext.p, EXT + m->nj * 3 + 4, door, door_k);
     HIP_TRY(hipGetLastError());
     return BF_OK;
 }

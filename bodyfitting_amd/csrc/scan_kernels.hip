@@ -327,7 +327,11 @@ template <int FPW>
 __global__ void __launch_bounds__(512)
 bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const float *__restrict__ state, int n_frames,
                          const float *__restrict__ dvout, const float *__restrict__ vposed, const float *__restrict__ vraw,
-                         float *__restrict__ part, const float *__restrict__ gpart, int n_masks, int n_sampled, int samp_stride) {
+                         float *__restrict__ part, const float *__restrict__ gpart, int n_masks, int n_sampled, int samp_stride, int split) {
+    // split = 2 (one frame per workgroup, the grid smaller than half the machine): TWO workgroups per tile, each streaming half of the
+    // tile's posedirsT columns in (a) - that stream is a chain of dependent batches at ~1.3 us each (a kernel starts with cold caches),
+    // and more loads in flight per CU made it slower, more CUs do not.  Each half leaves a partial row of its own (the reduction adds the
+    // rows in order); half 0 also does (b)-(d), half 1 writes zeros there.
     constexpr int TV = BF_MESH_TILE, COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
@@ -339,7 +343,7 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
     float *s_sim = s_vp + FPW * COLS;        // [FPW][8]: t[3], s, c
     float *s_sd = s_sim + FPW * 8;           // [COLS][nb]
     float *s_ts = s_sd + COLS * nb;          // [FPW][2][COLS]  dt, ds terms
-    const int tile = blockIdx.x, fbase = blockIdx.y * FPW, nf = min(FPW, n_frames - fbase);
+    const int tile = blockIdx.x / split, half = blockIdx.x - tile * split, fbase = blockIdx.y * FPW, nf = min(FPW, n_frames - fbase);
     const int tid = threadIdx.x, v0 = tile * TV;
     const size_t sstride = bf_state_stride(nj, npf, nb);
     const int nvt = min(TV, nv - v0);
@@ -411,7 +415,8 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
     }
     __syncthreads();
     const int EXT = npf + nj * 12 + nb + 4;
-    float *out0 = part + ((size_t)fbase * gridDim.x + tile) * EXT;
+    float *out0 = part + ((size_t)fbase * gridDim.x + blockIdx.x) * EXT;
+    const int ca = half * (COLS / split), cb = ca + COLS / split;         // this workgroup's columns of (a)
     const size_t fstride = (size_t)gridDim.x * EXT;
     // (a) dfeat partials: thread p streams posedirsT[col][p] once for all frames
     for (int p = tid; p < npf; p += 512) {
@@ -419,7 +424,7 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
         float acc[FPW];
 #pragma unroll
         for (int f = 0; f < FPW; ++f) acc[f] = 0.f;
-        for (int c0 = 0; c0 < COLS; c0 += 16) {
+        for (int c0 = ca; c0 < cb; c0 += 16) {
             float x[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) x[i] = c0 + i < nvt * 3 ? src[(size_t)(c0 + i) * npf] : 0.f;
@@ -442,6 +447,10 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
         }
 #pragma unroll
         for (int f = 0; f < FPW; ++f) if (f < nf) out0[f * fstride + p] = acc[f];
+    }
+    if (half != 0) {                       // (the second half of a split tile: zeros in the other sections of its row)
+        for (int i = tid; i < nf * (EXT - npf); i += 512) { const int f = i / (EXT - npf), e = i - f * (EXT - npf); out0[f * fstride + npf + e] = 0.f; }
+        return;
     }
     // (b) chain-matrix partials: item (f, j) = all twelve entries sum_v w_vj dv_a [vp_b | 1] of a joint: per vertex one weight,
     // three dv and three vp reads feed twelve products (the entry-per-thread version issued 36 LDS reads for them and was
@@ -483,18 +492,21 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
 
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT, const float *state, int n, const float *dvout,
                                         const float *vposed, const float *vraw, float *part, hipStream_t stream,
-                                        const float *gpart, int n_masks, int n_sampled, int samp_stride) {
+                                        const float *gpart, int n_masks, int n_sampled, int samp_stride, int part_rows, int *rows_out) {
+    // part_rows: rows per frame the partial buffer holds; *rows_out: rows per frame this launch wrote (n_tiles, or 2 n_tiles when split)
     constexpr int COLS = BF_MESH_TILE * 3;
     const int fpw = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
+    const int split = (fpw == 1 && M->n_tiles * 2 <= part_rows && M->n_tiles * 2 <= 256 && COLS % 32 == 0) ? 2 : 1;
+    if (rows_out) *rows_out = M->n_tiles * split;
     const size_t smem = sizeof(float) * ((size_t)COLS * fpw + (size_t)fpw * M->nj * 12 + (size_t)BF_MESH_TILE * M->nj + 2 * (size_t)fpw * COLS +
                                          (size_t)fpw * 8 + (size_t)COLS * M->nb + 2 * (size_t)fpw * COLS);
-    const dim3 grid(M->n_tiles, (n + fpw - 1) / fpw), block(512);
+    const dim3 grid(M->n_tiles * split, (n + fpw - 1) / fpw), block(512);
     if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
     switch (fpw) {
-    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride); break;
-    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride); break;
-    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride); break;
-    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride); break;
+    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split); break;
+    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split); break;
+    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split); break;
+    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split); break;
     }
     return (int)hipGetLastError();
 }
