@@ -11,6 +11,7 @@
 #define BF_KP_ROUNDS 3      // keypoint records staged in LDS for V <= 16*3 = 48 views
 #define BF_SEL_NNZ 8         // compacted skinning weights per selector vertex (real SMPL has <= 4)
 #define BF_MFMA_MIN_FRAMES 16
+#define BF_BATCH32_MAX_FRAMES 64   // up to here the final mesh of a batch is bf_mesh_batch32_kernel (32-frame blocks, fused epilogue)
 #define BF_EPI_FRAMES 8      // frames one workgroup of the batched mesh epilogue walks over (its tile's tables stay in registers)
 #define BF_GEMM_KB 26        // K pairs per register block of the pose-blend GEMM (A operand resident in VGPRs)  // from this batch size on the pose blend runs as one fp32-MFMA GEMM for all frames
 #define BF_MESH_TILE 32     // vertices per workgroup of the full-mesh forward

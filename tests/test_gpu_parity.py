@@ -225,15 +225,17 @@ def test_smplify_mirror_reuses_its_batch_between_frames(smpl_model, gmm):
     fitter.close()
 
 
-def test_batched_mfma_pose_blend_matches_per_frame_path(dev_model, smpl_model):
-    """>= 16 frames: the pose blend runs as one fp32-MFMA GEMM over the batch; same vertices as frame by frame"""
+@pytest.mark.parametrize("n", [17, 32, 37, 64, 70])
+def test_batched_mfma_pose_blend_matches_per_frame_path(dev_model, smpl_model, n):
+    """>= 16 frames: the pose blend runs on the matrix cores over the batch; same vertices as frame by frame.  Up to 64 frames it is
+    ONE launch with the epilogue behind the accumulators (bf_mesh_batch32_kernel: 17 = a ragged block, 32 = config 4's shard,
+    37 = a second, ragged block, 64 = two full blocks), beyond that pack_feat -> GEMM -> batched epilogue (70)"""
     rng = np.random.default_rng(11)
-    n = 37                                            # not a multiple of the 32-frame MFMA tile
     betas = rng.normal(0, 0.7, (n, 10)).astype(np.float32)
     orient = rng.normal(0, 0.8, (n, 3)).astype(np.float32)
     pose = rng.normal(0, 0.3, (n, 69)).astype(np.float32)
     verts, joints, _ = dev_model.forward(betas, orient, pose)
-    for i in (0, 5, 31, 32, 36):
+    for i in sorted({0, 5, 16, min(31, n - 1), n - 1}):
         v1, j1, _ = dev_model.forward(betas[i:i + 1], orient[i:i + 1], pose[i:i + 1])
         np.testing.assert_allclose(verts[i], v1[0], atol=2e-6)
         np.testing.assert_allclose(joints[i], j1[0], atol=2e-6)

@@ -76,7 +76,7 @@ for fr in (32, 256):
     print(f"## counters - batched mesh path, {fr} frames per launch (durations: the un-overlapped trace)\n")
     print("| kernel | avg us (trace) | MFMA MOPS_F32 / launch | => GFLOP | TFLOP/s | frac of 157 TF | MFMA busy / SQ busy | FETCH_SIZE KB (x2 corrected) | WRITE_SIZE KB | GB/s |\n|---|---|---|---|---|---|---|---|---|---|")
     for k in m:
-        if not any(s in k for s in ("poseblend", "epilogue_batch", "pack_feat", "fit_kernel", "joints")):
+        if not any(s in k for s in ("poseblend", "epilogue_batch", "pack_feat", "fit_kernel", "joints", "batch32")):
             continue
         c = m[k]
         mean = lambda x: sum(x) / len(x) if x else 0.0       # noqa: E731
