@@ -724,29 +724,29 @@ bf_mesh_epilogue_batch_kernel(MeshTab M, const float *__restrict__ state, const 
 
 // Final mesh of a 32-frame block in ONE launch (config 4's per-GPU shard is exactly one block): pose blend on the
 // matrix cores with the shape blend, skinning and similarity BEHIND THE ACCUMULATORS - no featT, no pose_off round trip.
-// grid (n_tiles, ceil(F / 32)), 256 threads; SMPL-sized models (bf_mesh_batch32_fits).
+// grid (n_tiles, ceil(F / 32)), 512 threads; SMPL-sized models (bf_mesh_batch32_fits).
 // A workgroup owns 32 vertices x 32 frames.  The MFMA column j of block cb is coordinate cb of vertex j, so a lane's B
 // operand for a row is its vertex's 12 contiguous bytes (one dwordx3, 384 contiguous bytes per half wave) and the
-// accumulators come out vertex-major.  K is dealt over the four waves (wave w takes the row pairs 4 s + w).  Every global
+// accumulators come out vertex-major.  K is dealt over the eight waves (wave w takes the row pairs 8 s + w).  Every global
 // read of the kernel - the block's pose features, bone transforms and records (coalesced float2 along each frame's state
-// record), the wave's 26 B operands, the vertex's tables, the tile's extra-joint rows - is requested before the first one
+// record), the wave's 13 B operands, the vertex's tables, the tile's extra-joint rows - is requested before the first one
 // is used, in the order of use: a wave has at most 64 loads in flight, so that is two memory latencies for the kernel.
-// Then 26 x 3 v_mfma_f32_32x32x2_f32 per wave (A operand: pose features frame-minor in LDS, conflict free), the four
-// partial tiles meet in LDS and are added in wave order; thread (vertex, frame quad) does what
+// Then 13 x 3 v_mfma_f32_32x32x2_f32 per wave (A operand: pose features frame-minor in LDS, conflict free), the eight
+// partial tiles meet in LDS (over the pose features) and are added in wave order; thread (vertex, frame pair) does what
 // bf_mesh_epilogue_batch_kernel does per vertex and frame.  Stores leave through LDS, 384 consecutive bytes per frame.
 typedef float bf_f3u __attribute__((ext_vector_type(3), aligned(4)));
 typedef float bf_f2u __attribute__((ext_vector_type(2), aligned(8)));
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(512)
 bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames, float *__restrict__ vraw, float *__restrict__ vout,
                        float *__restrict__ xpart) {
-    constexpr int FB = 32, COLS = BF_MESH_TILE * 3, KS = 26, KROWS = 8 * KS, FLD = FB + 1, ALD = COLS + 1, XLD = BF_MESH_TILE + 1;
-    constexpr int NF2 = FB / 2;                             // 16 float2 of pose features per thread (threads 0..207: two frames a step)
-    constexpr int NA2 = FB * 6 * 24 / 256;                  // 18 float2 of bone transforms per thread (nj <= 24)
-    constexpr int NX = (24 * BF_MESH_TILE + 255) / 256;     // 3 extra-joint regressor values per thread (n_extra <= 24)
+    constexpr int FB = 32, COLS = BF_MESH_TILE * 3, NW = 8, KS = 13, KROWS = 2 * NW * KS, FLD = FB + 1, ALD = COLS + 1, XLD = BF_MESH_TILE + 1;
+    constexpr int NF2 = FB / 4;                             // 8 float2 of pose features per thread (threads 0..415: four frames a step)
+    constexpr int NA2 = (FB + 2) / 3;                       // 11 float2 of bone transforms per thread (threads 0..3 nj6 - 1: three frames a step)
+    constexpr int NX = (24 * BF_MESH_TILE + 511) / 512;     // 2 extra-joint regressor values per thread (n_extra <= 24)
     extern __shared__ __align__(16) float s_dyn[];
-    float *s_feat = s_dyn;                                  // [KROWS][FLD]   pose features, frame-minor
-    float *s_acc = s_feat + KROWS * FLD;                    // [4][FB][ALD]   the waves' partial tiles; [0] becomes the raw vertices
-    float *s_beta = s_acc + 4 * FB * ALD;                   // [FB][16]       beta (12, zero padded) | t (3) | s * cscale
+    float *s_feat = s_dyn;                                  // [KROWS][FLD]   pose features, frame-minor (dead after the K loop, under s_acc)
+    float *s_acc = s_dyn;                                   // [NW][FB][ALD]  the waves' partial tiles; [0] becomes the raw vertices
+    float *s_beta = s_acc + NW * FB * ALD;                  // [FB][16]       beta (12, zero padded) | t (3) | s * cscale
     float *s_A = s_beta + FB * 16;                          // [FB][nj * 12]  bone transforms
     float *s_x = s_A + FB * 24 * 12;                        // [n_extra][XLD] extra-joint regressor rows over this tile
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv, ncols = 3 * nv, nj12 = nj * 12, nj6 = nj * 6;
@@ -756,35 +756,28 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
     const int feat_off = nj * 15;
     // ---- the loads, in the order of use
     bf_f2u tfe[NF2], tA[NA2];
-    float tbe[2], tbs[2], tx[NX];
+    float tbe, tbs, tx[NX];
     const float *sblk = state + (size_t)fbase * stride;      // (the block's records: 32-bit offsets from here on)
     const int istride = (int)stride;
-    const int fe_hi = tid >= KROWS / 2 ? 1 : 0, fe_p = 2 * (tid - fe_hi * (KROWS / 2));     // frame parity, row pair of this thread
-    if (tid < KROWS) {
+    constexpr int HP = KROWS / 2;                            // row pairs of a frame
+    const int fe_hi = (tid >= HP ? 1 : 0) + (tid >= 2 * HP ? 1 : 0) + (tid >= 3 * HP ? 1 : 0), fe_p = 2 * (tid - fe_hi * HP);   // frame mod 4, row pair
+    if (tid < 4 * HP) {
         // (unconditional: frames past the block repeat its last one, rows past npf read on into the record - zeroed when stored)
 #pragma unroll
-        for (int r = 0; r < NF2; ++r) tfe[r] = *(const bf_f2u *)(sblk + min(2 * r + fe_hi, nf - 1) * istride + feat_off + fe_p);
+        for (int r = 0; r < NF2; ++r) tfe[r] = *(const bf_f2u *)(sblk + min(4 * r + fe_hi, nf - 1) * istride + feat_off + fe_p);
     }
-    {
-        int f = 0, e = tid;                                   // pair tid + 256 r of [FB][nj6], without a division by nj6
-        { const int wr = (e >= nj6 ? 1 : 0) + (e >= 2 * nj6 ? 1 : 0); e -= wr * nj6; f += wr; }      // (3 nj6 > 256 + nj6: bf_mesh_batch32_fits)
+    const int fa = (tid >= nj6 ? 1 : 0) + (tid >= 2 * nj6 ? 1 : 0) + (tid >= 3 * nj6 ? 1 : 0), ea = tid - fa * nj6;      // frame mod 3, pair
+    if (fa < 3) {
 #pragma unroll
-        for (int r = 0; r < NA2; ++r) {
-            tA[r] = *(const bf_f2u *)(sblk + min(f, nf - 1) * istride + 2 * e);
-            e += 256;
-            { const int wr = (e >= nj6 ? 1 : 0) + (e >= 2 * nj6 ? 1 : 0); e -= wr * nj6; f += wr; }      // (3 nj6 > 256 + nj6: bf_mesh_batch32_fits)
-        }
+        for (int r = 0; r < NA2; ++r) tA[r] = *(const bf_f2u *)(sblk + min(3 * r + fa, nf - 1) * istride + 2 * ea);
     }
     {
         // (beta | t | s cscale) records: plain loads, no branches - a wait inside this stream would serialise everything behind it
         const size_t boff = (size_t)nj * 15 + npf + (size_t)nj * 3;           // beta, t, sc are contiguous in the state record
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int i = tid + 256 * r, f = min(i >> 4, nf - 1), e = i & 15;
-            const float *rec = sblk + f * istride + (int)boff;
-            tbe[r] = rec[e < 12 ? min(e, nb - 1) : nb + (e - 12)];           // e == 15: body scale
-            tbs[r] = rec[nb + 4];                                             //          x constant scale
-        }
+        const int f = min(tid >> 4, nf - 1), e = tid & 15;
+        const float *rec = sblk + f * istride + (int)boff;
+        tbe = rec[e < 12 ? min(e, nb - 1) : nb + (e - 12)];                  // e == 15: body scale
+        tbs = rec[nb + 4];                                                    //          x constant scale
     }
     // B operands of this wave: rows 2 (4 s + wave) + kh, the three coordinates of vertex v0 + mi
     // (unconditional, addresses clamped: a row past npf meets a zero A operand, a vertex past nv is never stored)
@@ -793,11 +786,11 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
         const int wv = __builtin_amdgcn_readfirstlane(wave);
         const float *bcol = M.posedirs + (size_t)(2 * wv) * ncols + min(v0 + mi, nv - 1) * 3 + kh * ncols;
 #pragma unroll
-        for (int s2 = 0; s2 < KS - 1; ++s2) bq[s2] = *(const bf_f3u *)(bcol + (size_t)(8 * s2) * ncols);
-        bq[KS - 1] = *(const bf_f3u *)(bcol + (size_t)(min(8 * (KS - 1) + 2 * wv + kh, npf - 1) - 2 * wv - kh) * ncols);
+        for (int s2 = 0; s2 < KS - 1; ++s2) bq[s2] = *(const bf_f3u *)(bcol + (size_t)(2 * NW * s2) * ncols);
+        bq[KS - 1] = *(const bf_f3u *)(bcol + (size_t)(min(2 * NW * (KS - 1) + 2 * wv + kh, npf - 1) - 2 * wv - kh) * ncols);
     }
     // the vertex's tables (thread = vertex tid & 31, frames 4 (tid >> 5) ..)
-    const int vl = tid & 31, fq = tid >> 5, v = v0 + vl;
+    const int vl = tid & 31, fo = tid >> 5, v = v0 + vl;
     const bool ok = v < nv;
     const int vc = ok ? v : nv - 1;
     float sd[30], w4[4];
@@ -820,45 +813,41 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
     if (nxr) {
 #pragma unroll
         for (int r = 0; r < NX; ++r) {
-            const int i = tid + 256 * r, e = min(i >> 5, M.n_extra - 1), t = i & 31;
+            const int i = tid + 512 * r, e = min(i >> 5, M.n_extra - 1), t = i & 31;
             tx[r] = M.j_extra[(size_t)e * nv + min(v0 + t, nv - 1)];
         }
     }
     // ---- LDS: pose features frame-minor, bone transforms as [joint][3][4], records, regressor rows
-    if (tid < KROWS) {
+    if (tid < 4 * HP) {
         const bool px = fe_p < npf, py = fe_p + 1 < npf;
 #pragma unroll
         for (int r = 0; r < NF2; ++r) {
-            s_feat[fe_p * FLD + 2 * r + fe_hi] = px ? tfe[r].x : 0.f; s_feat[(fe_p + 1) * FLD + 2 * r + fe_hi] = py ? tfe[r].y : 0.f;
+            s_feat[fe_p * FLD + 4 * r + fe_hi] = px ? tfe[r].x : 0.f; s_feat[(fe_p + 1) * FLD + 4 * r + fe_hi] = py ? tfe[r].y : 0.f;
         }
     }
-    {
-        int f = 0, e = tid;
-        { const int wr = (e >= nj6 ? 1 : 0) + (e >= 2 * nj6 ? 1 : 0); e -= wr * nj6; f += wr; }      // (3 nj6 > 256 + nj6: bf_mesh_batch32_fits)
+    if (fa < 3) {
 #pragma unroll
         for (int r = 0; r < NA2; ++r) {
+            const int f = 3 * r + fa;
             if (f < FB) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     // GR[nj][3][3] | At[nj][3] -> [nj][3][4]: 9 j + 3 a + b -> 12 j + 4 a + b = src + src / 3;  9 nj + 3 j + a -> 12 j + 4 a + 3
-                    const int src = 2 * e + h;
+                    const int src = 2 * ea + h;
                     const int dst = src < nj * 9 ? src + src / 3 : 4 * (src - nj * 9) + 3;
                     s_A[f * nj12 + dst] = h ? tA[r].y : tA[r].x;
                 }
             }
-            e += 256;
-            { const int wr = (e >= nj6 ? 1 : 0) + (e >= 2 * nj6 ? 1 : 0); e -= wr * nj6; f += wr; }      // (3 nj6 > 256 + nj6: bf_mesh_batch32_fits)
         }
     }
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i = tid + 256 * r, f = i >> 4, e = i & 15;
-        s_beta[i] = f >= nf || (e < 12 && e >= nb) ? 0.f : (e == 15 ? tbe[r] * tbs[r] : tbe[r]);
+    {
+        const int f = tid >> 4, e = tid & 15;
+        s_beta[tid] = f >= nf || (e < 12 && e >= nb) ? 0.f : (e == 15 ? tbe * tbs : tbe);
     }
 #pragma unroll
-    for (int r = 0; r < NX; ++r) { const int i = tid + 256 * r; if (i < nxr) s_x[(i >> 5) * XLD + (i & 31)] = v0 + (i & 31) < nv ? tx[r] : 0.f; }
+    for (int r = 0; r < NX; ++r) { const int i = tid + 512 * r; if (i < nxr) s_x[(i >> 5) * XLD + (i & 31)] = v0 + (i & 31) < nv ? tx[r] : 0.f; }
     __syncthreads();
-    // ---- this wave's quarter of K
+    // ---- this wave's eighth of K
     f32x16 acc[3];
 #pragma unroll
     for (int cb = 0; cb < 3; ++cb)
@@ -866,11 +855,12 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
         for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
 #pragma unroll
     for (int s2 = 0; s2 < KS; ++s2) {
-        const float a = s_feat[(2 * (4 * s2 + wave) + kh) * FLD + mi];
+        const float a = s_feat[(2 * (NW * s2 + wave) + kh) * FLD + mi];
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[s2].x, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[s2].y, acc[1], 0, 0, 0);
         acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[s2].z, acc[2], 0, 0, 0);
     }
+    __syncthreads();                                         // (the partial tiles go where the pose features were)
 #pragma unroll
     for (int cb = 0; cb < 3; ++cb)
 #pragma unroll
@@ -879,10 +869,10 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
             s_acc[(wave * FB + f) * ALD + mi * 3 + cb] = acc[cb][r];
         }
     __syncthreads();
-    // ---- behind the accumulators: shape blend + pose offset -> skinning, 4 frames per thread
+    // ---- behind the accumulators: shape blend + pose offset -> skinning, 2 frames per thread
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int f = fq * 4 + i;
+    for (int i = 0; i < 2; ++i) {
+        const int f = fo * 2 + i;
         const float *bp = s_beta + f * 16;
         const float4 bq0 = *(const float4 *)bp, bq1 = *(const float4 *)(bp + 4), bq2 = *(const float4 *)(bp + 8);
         const float be[10] = {bq0.x, bq0.y, bq0.z, bq0.w, bq1.x, bq1.y, bq1.z, bq1.w, bq2.x, bq2.y};
@@ -890,7 +880,9 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int o = f * ALD + vl * 3 + c;
-            const float po = ((s_acc[o] + s_acc[FB * ALD + o]) + s_acc[2 * FB * ALD + o]) + s_acc[3 * FB * ALD + o];
+            float po = s_acc[o];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; ++w2) po += s_acc[w2 * FB * ALD + o];       // (wave order)
             float a2 = 0.f;
 #pragma unroll
             for (int l = 0; l < 10; ++l) a2 += sd[c * 10 + l] * be[l];
@@ -915,14 +907,14 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
         raw[0] = ok ? x0 : 0.f; raw[1] = ok ? x1 : 0.f; raw[2] = ok ? x2 : 0.f;
     }
     __syncthreads();
-    if (tid < 2 * COLS) {
-        // threads 0..191: column tid % 96 of frames 2 r + (tid >= 96)
-        const int hi = tid >= COLS ? 1 : 0, c = tid - hi * COLS, kk = c % 3;
+    if (tid < 4 * COLS) {
+        // threads 0..383: column tid % 96 of frames 4 r + tid / 96
+        const int hi = (tid >= COLS ? 1 : 0) + (tid >= 2 * COLS ? 1 : 0) + (tid >= 3 * COLS ? 1 : 0), c = tid - hi * COLS, kk = c % 3;
         if (cbase + c < ncols) {
             size_t o = (size_t)(fbase + hi) * ncols + cbase + c;
 #pragma unroll
-            for (int r = 0; r < FB / 2; ++r, o += 2 * (size_t)ncols) {
-                const int f = 2 * r + hi;
+            for (int r = 0; r < FB / 4; ++r, o += 4 * (size_t)ncols) {
+                const int f = 4 * r + hi;
                 if (f < nf) {
                     const float x = s_acc[f * ALD + c], tk = s_beta[f * 16 + 12 + kk], sc = s_beta[f * 16 + 15];
                     if (vraw) vraw[o] = x;
@@ -956,20 +948,19 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
 }
 
 extern "C" bool bf_mesh_batch32_fits(const MeshTab *M) {
-    return M->npf <= 208 && M->nj <= 24 && M->nj >= 22 && M->v_nnz == 4 && M->nb == 10 && M->n_extra <= 24;
+    return M->npf <= 208 && M->nj <= 24 && M->nj >= 22 /* three frames' bone transforms per 512-thread step */ && M->v_nnz == 4 && M->nb == 10 && M->n_extra <= 24;
 }
 extern "C" hipError_t bf_mesh_batch32_launch(const MeshTab *M, const float *state, int n, float *vraw, float *vout, float *xpart,
                                              hipStream_t stream) {
-    constexpr int FB = 32, COLS = BF_MESH_TILE * 3, KROWS = 8 * 26;
-    const size_t smem = sizeof(float) * ((size_t)KROWS * (FB + 1) + 4 * (size_t)FB * (COLS + 1) + (size_t)FB * 16 + (size_t)FB * 24 * 12 +
-                                         24 * (size_t)(BF_MESH_TILE + 1));
+    constexpr int FB = 32, COLS = BF_MESH_TILE * 3;
+    const size_t smem = sizeof(float) * (8 * (size_t)FB * (COLS + 1) + (size_t)FB * 16 + (size_t)FB * 24 * 12 + 24 * (size_t)(BF_MESH_TILE + 1));
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void *)bf_mesh_batch32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(bf_mesh_batch32_kernel, dim3(M->n_tiles, (n + FB - 1) / FB), dim3(256), smem, stream, *M, state, n, vraw, vout, xpart);
+    hipLaunchKernelGGL(bf_mesh_batch32_kernel, dim3(M->n_tiles, (n + FB - 1) / FB), dim3(512), smem, stream, *M, state, n, vraw, vout, xpart);
     return hipGetLastError();
 }
 
