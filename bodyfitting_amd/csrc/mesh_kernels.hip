@@ -954,11 +954,9 @@ extern "C" hipError_t bf_mesh_batch32_launch(const MeshTab *M, const float *stat
                                              hipStream_t stream) {
     constexpr int FB = 32, COLS = BF_MESH_TILE * 3;
     const size_t smem = sizeof(float) * (8 * (size_t)FB * (COLS + 1) + (size_t)FB * 16 + (size_t)FB * 24 * 12 + 24 * (size_t)(BF_MESH_TILE + 1));
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void *)bf_mesh_batch32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    {   // (every launch: the attribute belongs to the current device, and a group drives several from one process)
+        hipError_t e = hipFuncSetAttribute((const void *)bf_mesh_batch32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
-        attr = true;
     }
     hipLaunchKernelGGL(bf_mesh_batch32_kernel, dim3(M->n_tiles, (n + FB - 1) / FB), dim3(512), smem, stream, *M, state, n, vraw, vout, xpart);
     return hipGetLastError();
