@@ -948,6 +948,8 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
 }
 
 extern "C" bool bf_mesh_batch32_fits(const MeshTab *M) {
+    // (float2 reads along a frame's record: the record and its pose-feature block have to start on 8-byte boundaries)
+    if (bf_state_stride(M->nj, M->npf, M->nb) % 2 != 0 || (M->nj * 15) % 2 != 0) return false;
     return M->npf <= 208 && M->nj <= 24 && M->nj >= 22 /* three frames' bone transforms per 512-thread step */ && M->v_nnz == 4 && M->nb == 10 && M->n_extra <= 24;
 }
 extern "C" hipError_t bf_mesh_batch32_launch(const MeshTab *M, const float *state, int n, float *vraw, float *vout, float *xpart,
