@@ -103,6 +103,7 @@ class SMPLify:
                 batch.clear_masks()
                 batch._had_masks = False
             batch.set_cameras(c2ws, Ks)
+            batch._cams = None
             batch.set_keypoints(keypoints, n_use_frames)
             batch.set_init(init_betas, init_poses)
             if scans is not None:
@@ -171,6 +172,7 @@ class SMPLify:
         if batch._had_masks:
             batch.clear_masks(); batch._had_masks = False
         batch.set_cameras(c2w, K)
+        batch._cams = None
         hyper = make_hyper(imsize=imsize, constant_scale=0.3)
         flags = _lib.FIT_RESET | _lib.FIT_FETCH | _lib.FIT_NOTIME
         nl = self._dev.n_loss_joints
@@ -212,8 +214,39 @@ class SMPLify:
         for i in range(V):
             if keypoints[i] is not None:                                               # loss.py:157
                 kp[i] = pack_keypoints_smplx(keypoints[i]) if self.use_hand_face else np.asarray(keypoints[i]["pose"], np.float32)[:nl]
+        if mk is None and scans is None and not self.use_hand_face:
+            return self._call_staged(init_betas[:1], init_poses[:1], c2w, K, kp, imsize)
         res = self.fit_frames(init_betas[:1], init_poses[:1], c2w[None], K[None], kp[None], n_use_frames=[V],
                               imsize=imsize, scans=scans, displacement=displacement, masks=mk,
                               mask_view_index=mk_idx)[0]                               # divisor loss.py:197
         res.pop("loss_terms")
         return res
+
+    def _call_staged(self, betas, poses, c2w, K, kp, imsize):
+        """The keypoint-only SMPL call as a `stream` of one frame: the inputs go up through bf_batch_stage_inputs (one copy kernel on
+        the batch's stream instead of three synchronous setters), the fit re-arms itself (BF_FIT_RESET) and the cameras of the
+        previous call stay on the device when these are the same arrays' values - a capture's frames share them
+        (apps/genebody_fitting.py:134-140).  Same bits as `fit_frames` (tests/test_gpu_parity.py)."""
+        from . import _lib
+        V = c2w.shape[0]
+        batch = self._batch(1, V)
+        if batch._had_scans:
+            batch.set_scans(None); batch._had_scans = False
+        if batch._had_masks:
+            batch.clear_masks(); batch._had_masks = False
+        cams = getattr(batch, "_cams", None)
+        if cams is None or not (np.array_equal(cams[0], c2w) and np.array_equal(cams[1], K)):
+            batch.set_cameras(c2w[None], K[None])
+            batch._cams = (c2w.copy(), K.copy())
+        ok = False
+        try:
+            batch.stage_inputs(kp[None], [V], betas, poses)
+            batch.fit(self.num_iters, make_hyper(imsize=imsize, constant_scale=0.3), _lib.FIT_RESET | _lib.FIT_FETCH | _lib.FIT_NOTIME)
+            params = batch.get_params()
+            verts, joints, full_pose, _ = batch.get_result()
+            ok = True
+        finally:
+            if not ok:                         # do not keep a batch in an unknown state
+                self._batches.pop((1, V), None)
+                batch.close()
+        return self._result_dict(params[0], verts[0], joints[0], full_pose[0])

@@ -484,4 +484,22 @@ def test_smplify_stream_yields_the_frames_of_the_call_path(smpl_model, gmm):
         one = fitter((p["init_betas"], p["init_pose"]), p["c2ws"], p["Ks"], p["keypoints"], use_frames=p["use_frames"], imsize=512)
         for key in ("vertices", "joints", "pose", "betas", "global_orient", "global_transl", "scale", "full_pose"):
             assert np.array_equal(res[key], one[key]), key
+        # ... and both equal the synchronous setters' path (the call stages its frame like the stream does)
+        V = len(p["use_frames"])
+        kp = np.stack([np.zeros((25, 3), np.float32) if k is None else np.asarray(k["pose"], np.float32)[:25] for k in p["keypoints"][:V]])
+        c2w = np.stack([np.asarray(c, np.float32) for c in p["c2ws"][:V]])
+        K = np.stack([np.asarray(k, np.float32) for k in p["Ks"][:V]])
+        sync = fitter.fit_frames(np.asarray(p["init_betas"], np.float32)[:1], np.asarray(p["init_pose"], np.float32)[:1], c2w[None], K[None],
+                                 kp[None], n_use_frames=[V], imsize=512)[0]
+        for key in ("vertices", "joints", "pose", "betas", "global_orient", "global_transl", "scale", "full_pose"):
+            assert np.array_equal(sync[key], one[key]), key
+    # a call after the cameras changed must not reuse the cached ones
+    p = probs[0]
+    moved = [np.asarray(c, np.float32).copy() for c in p["c2ws"]]
+    for c in moved:
+        c[:3, 3] += 0.05
+    a = fitter((p["init_betas"], p["init_pose"]), moved, p["Ks"], p["keypoints"], use_frames=p["use_frames"], imsize=512)
+    b = fitter((p["init_betas"], p["init_pose"]), p["c2ws"], p["Ks"], p["keypoints"], use_frames=p["use_frames"], imsize=512)
+    assert not np.array_equal(a["pose"], b["pose"])
+    assert np.array_equal(b["pose"], streamed[0]["pose"])
     fitter.close()
