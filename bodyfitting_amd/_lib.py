@@ -43,6 +43,7 @@ class Hyper(C.Structure):
 
 
 CONTOUR_OPENCV_FIRST, CONTOUR_RASTER_FIRST, CONTOUR_LONGEST = 0, 1, 2
+NEAREST_REFERENCE, NEAREST_FAST = 0, 1
 FIT_DEFAULT, FIT_DENSE, FIT_NO_VERTICES, FIT_FETCH, FIT_RESET, FIT_GRAPH, FIT_NOTIME = 0, 1, 2, 4, 8, 16, 32
 
 # every entry point include/bodyfit.h declares: name -> (restype, argtypes)
@@ -83,6 +84,8 @@ SIGNATURES = {
     "bf_scan_intersects": (C.c_int, [_VP, C.c_int, _FP, _FP, C.POINTER(C.c_uint8)]),
     "bf_scan_nearest": (C.c_int, [_VP, C.c_int, _FP, _IP, _FP, _FP]),
     "bf_scan_nearest_backward": (C.c_int, [_VP, C.c_int, _IP, _FP, _FP, _FP]),
+    "bf_nearest_rule_set": (C.c_int, [C.c_int]),
+    "bf_nearest_rule_get": (C.c_int, []),
     "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
     "bf_batch_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),
     "bf_extract_contours": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),

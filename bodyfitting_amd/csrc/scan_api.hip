@@ -5,7 +5,8 @@
 #include <chrono>
 
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
-extern "C" __global__ void bf_nearest_kernel(const ScanDev *, const float *, int, int *, float *, float *, int);
+extern "C" void bf_nearest_launch(dim3 grid, hipStream_t stream, const ScanDev *scans, const float *points, int n, int *face, float *pts,
+                                  float *bary, int warm);        // scan_kernels.hip: the rule selected by bf_nearest_rule_set / BF_NEAREST_RULE
 extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
 extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const float *, int, const float *, const float *, const float *, float *, hipStream_t,
@@ -176,8 +177,7 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
     HIP_TRY(d_p.upload(std::vector<float>(points, points + (size_t)n * 3)));
     HIP_TRY(d_c.alloc((size_t)n * 3)); HIP_TRY(d_b.alloc((size_t)n * 3)); HIP_TRY(d_f.alloc(n));
     HIP_TRY(d_s.upload(std::vector<ScanDev>(1, s->dev)));
-    hipLaunchKernelGGL(bf_nearest_kernel, dim3((n + 3) / 4, 1), dim3(256), 0, 0, (const ScanDev *)d_s.p, (const float *)d_p.p, n,
-                       d_f.p, d_c.p, d_b.p, 0);
+    bf_nearest_launch(dim3((n + 3) / 4, 1), 0, (const ScanDev *)d_s.p, (const float *)d_p.p, n, d_f.p, d_c.p, d_b.p, 0);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     if (face_ids) HIP_TRY(hipMemcpy(face_ids, d_f.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
@@ -389,8 +389,8 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     const bool fold_views = masks && !scans;
     if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr, projected, sub); if (rc) return rc; }
     if (scans) {
-        hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv + 3) / 4, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p,
-                           (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);   // (one wave per query; warm start from the previous call's faces)
+        bf_nearest_launch(dim3((nv + 3) / 4, F), b->stream, (const ScanDev *)b->scan_dev.p,
+                          (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);   // (one wave per query; warm start from the previous call's faces)
         b->cface_valid = true;
         hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, b->pc_partial.p);
@@ -878,8 +878,8 @@ int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
                            (const float *)b->disp_base.p, (const float *)b->disp.p, b->disp_fn.p);
         hipLaunchKernelGGL(bf_disp_vertex_kernel, gv, dim3(256), 0, b->stream, (const int *)m->adj_start.p, (const int *)m->adj.p, nf, nv,
                            (const float *)b->disp_base.p, (const float *)b->disp.p, (const float *)b->disp_fn.p, b->disp_P.p, b->disp_vn.p);
-        hipLaunchKernelGGL(bf_nearest_kernel, dim3((nv + 3) / 4, F), dim3(256), 0, b->stream, (const ScanDev *)b->scan_dev.p, (const float *)b->disp_P.p, nv,
-                           b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);
+        bf_nearest_launch(dim3((nv + 3) / 4, F), b->stream, (const ScanDev *)b->scan_dev.p, (const float *)b->disp_P.p, nv,
+                          b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);
         b->cface_valid = true;
         hipLaunchKernelGGL(bf_disp_vgrad_kernel, gv, dim3(256), 0, b->stream, (const int *)m->faces_d.p, (const int *)m->adj_start.p,
                            (const int *)m->adj.p, nf, nv, (const float *)b->disp_vn.p, (const float *const *)b->scan_fn.p,

@@ -16,6 +16,9 @@
 #include "bf_internal.h"
 #include "loss_bodies.h"
 #include "joints_body.h"
+#include "../../include/bodyfit.h"
+#include <cstdlib>
+#include "nearest_rule_ref.h"
 
 namespace {
 
@@ -112,8 +115,14 @@ __device__ inline int nn_wave_min_i(int v) {
 // neighbours pruned - with the distance the home cell gave.  `warm`: face[] still holds this query's answer of the
 // previous call - a real candidate; it rides on the last lane of the home-cell pass (its vertices arrive while the
 // cell bounds do), so the warm start costs no pass of its own.
-extern "C" __global__ void __launch_bounds__(256)
-bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
+//
+// RULE selects the per-triangle arithmetic: BF_NEAREST_REFERENCE = the reference's own (nearest_rule_ref.h: Gram matrix, bordered
+// KKT system, pivoted elimination with its absolute rank tests, IEEE divisions, nothing fused) - the default, face ids / coefficients /
+// points equal to oracle/nearest_ref.c wherever no two faces tie bit for bit; BF_NEAREST_FAST = the 2 x 2 normal equations with
+// v_rcp_f32 (same mathematics, ~half the instructions, other last bits: 4.7 % of config 5's queries then pick the other face of a
+// shared edge - DESIGN 2.3).
+template <int RULE>
+__device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                   int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
     const int lane = threadIdx.x & 63, id = blockIdx.x * 4 + (threadIdx.x >> 6), f = blockIdx.y;
     if (id >= n) return;                                   // (wave-uniform)
@@ -130,7 +139,7 @@ bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ p
     float gbest = 3.0e38f;                                  // (wave-uniform) best distance so far, for the pruning
     auto test = [&](const float *p, int t) {
         float co[3];
-        const float dist = closest_rule(p, p + 3, p + 6, co);
+        const float dist = RULE == BF_NEAREST_REFERENCE ? nrule::nearest_proj(p, co) : closest_rule(p, p + 3, p + 6, co);
         if (dist < best || (dist == best && t < bface)) { best = dist; bface = t; bc0 = co[0]; bc1 = co[1]; bc2 = co[2]; }
     };
     auto test_record = [&](int rec) {
@@ -268,12 +277,51 @@ bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ p
         const int *tv = S.faces + (size_t)fmin_ * 3;
         const float *v0 = S.verts + (size_t)tv[0] * 3, *v1 = S.verts + (size_t)tv[1] * 3, *v2 = S.verts + (size_t)tv[2] * 3;
         // proj = q + sum c_i (v_i - q), as the reference forms it (:318-329)
-        r0 = qx + w0 * (v0[0] - qx) + w1 * (v1[0] - qx) + w2 * (v2[0] - qx);
-        r1 = qy + w0 * (v0[1] - qy) + w1 * (v1[1] - qy) + w2 * (v2[1] - qy);
-        r2 = qz + w0 * (v0[2] - qz) + w1 * (v1[2] - qz) + w2 * (v2[2] - qz);
+        if (RULE == BF_NEAREST_REFERENCE) {                // ... every product and sum rounded, left to right
+            r0 = nrule::project(qx, w0, v0[0] - qx, w1, v1[0] - qx, w2, v2[0] - qx);
+            r1 = nrule::project(qy, w0, v0[1] - qy, w1, v1[1] - qy, w2, v2[1] - qy);
+            r2 = nrule::project(qz, w0, v0[2] - qz, w1, v1[2] - qz, w2, v2[2] - qz);
+        } else {
+            r0 = qx + w0 * (v0[0] - qx) + w1 * (v1[0] - qx) + w2 * (v2[0] - qx);
+            r1 = qy + w0 * (v0[1] - qy) + w1 * (v1[1] - qy) + w2 * (v2[1] - qy);
+            r2 = qz + w0 * (v0[2] - qz) + w1 * (v1[2] - qz) + w2 * (v2[2] - qz);
+        }
     }
     pts[o * 3] = r0; pts[o * 3 + 1] = r1; pts[o * 3 + 2] = r2;
     if (bary) { bary[o * 3] = found ? w0 : 0.f; bary[o * 3 + 1] = found ? w1 : 0.f; bary[o * 3 + 2] = found ? w2 : 0.f; }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
+                  int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
+    nearest_body<BF_NEAREST_REFERENCE>(scans, points, n, face, pts, bary, warm);
+}
+extern "C" __global__ void __launch_bounds__(256)
+bf_nearest_fast_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
+                       int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
+    nearest_body<BF_NEAREST_FAST>(scans, points, n, face, pts, bary, warm);
+}
+
+// which arithmetic bf_nearest_launch uses: BF_NEAREST_RULE=fast|reference in the environment at first use, or bf_nearest_rule_set()
+static int g_nearest_rule = -1;
+extern "C" int bf_nearest_rule_get(void) {
+    if (g_nearest_rule < 0) {
+        const char *e = getenv("BF_NEAREST_RULE");
+        g_nearest_rule = (e && (e[0] == 'f' || e[0] == '1')) ? BF_NEAREST_FAST : BF_NEAREST_REFERENCE;
+    }
+    return g_nearest_rule;
+}
+extern "C" int bf_nearest_rule_set(int rule) {
+    if (rule != BF_NEAREST_REFERENCE && rule != BF_NEAREST_FAST) return -1;
+    g_nearest_rule = rule;
+    return 0;
+}
+extern "C" void bf_nearest_launch(dim3 grid, hipStream_t stream, const ScanDev *scans, const float *points, int n, int *face, float *pts,
+                                  float *bary, int warm) {
+    if (bf_nearest_rule_get() == BF_NEAREST_FAST)
+        hipLaunchKernelGGL(bf_nearest_fast_kernel, grid, dim3(256), 0, stream, scans, points, n, face, pts, bary, warm);
+    else
+        hipLaunchKernelGGL(bf_nearest_kernel, grid, dim3(256), 0, stream, scans, points, n, face, pts, bary, warm);
 }
 
 // grid (nblk, F): partial[f][blk] = sum over this block's vertices of |P - C|^2

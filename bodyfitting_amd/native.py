@@ -206,6 +206,18 @@ class Scan:
         return out
 
 
+def set_nearest_rule(rule):
+    """The arithmetic of every closest-point search of the process: "reference" (default: search_nearest_proj as the reference's
+    source evaluates it in float32, mesh_grid_kernel.cu:12-109 + matrix.h) or "fast" (2 x 2 normal equations, v_rcp_f32).
+    -> the rule that was active before."""
+    names = {"reference": _lib.NEAREST_REFERENCE, "fast": _lib.NEAREST_FAST}
+    lib = _lib.load()
+    before = lib.bf_nearest_rule_get()
+    if lib.bf_nearest_rule_set(names[rule] if isinstance(rule, str) else int(rule)) != 0:
+        raise ValueError("unknown closest-point rule %r" % (rule,))
+    return "fast" if before == _lib.NEAREST_FAST else "reference"
+
+
 def make_hyper(**kw):
     h = _lib.Hyper()
     _lib.load().bf_hyper_default(C.byref(h))

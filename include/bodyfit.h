@@ -213,6 +213,18 @@ int bf_scan_grid_lists(const bf_scan *s, int32_t *tri_num, int32_t *tri_idx, int
 /* MeshGridSearcher.nearest_points / search_nearest_point (mesh_grid.cpp:54-72): points[n,3] ->
  * face_ids[n] int32, nearest[n,3], bary[n,3] (any output may be NULL) */
 int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, float *nearest, float *bary);
+/* The per-triangle arithmetic of every closest-point search of the process (bf_scan_nearest, the scan loss of bf_fit, SMPL+D).
+ * BF_NEAREST_REFERENCE (default): search_nearest_proj as the reference's source evaluates it in float32 - Gram matrix of the corner
+ * vectors, the bordered 4 x 4 system through solve4 / solve3 with their pivot order and absolute 1e-9 rank tests, IEEE divisions,
+ * no fused multiply-adds (mesh_grid_kernel.cu:12-109, matrix.h:13-316): face ids, coefficients and points are those of the
+ * reference's arithmetic wherever no two faces return the same distance bit for bit (such ties go to the lowest face id; the
+ * reference's own order inside a cell is an atomicCAS race).  BF_NEAREST_FAST: the same rule through the 2 x 2 normal equations
+ * and v_rcp_f32 - about half the instructions, other last bits (DESIGN.md 2.3 has the measured difference).
+ * Also read once from the environment: BF_NEAREST_RULE=reference|fast. */
+#define BF_NEAREST_REFERENCE 0
+#define BF_NEAREST_FAST      1
+int bf_nearest_rule_set(int rule);                     /* 0 on success, -1 for an unknown rule */
+int bf_nearest_rule_get(void);
 /* SurfaceNearest.backward with respect to the query points (utils/mesh_grid_searcher.py:17-49; search_nearest_point_backward,
  * mesh_grid.cpp:120-128, mesh_grid_kernel.cu:354-382 - left unfinished in the reference: its kernel never inverts the KKT matrix).
  * face_ids[n], bary[n,3] as bf_scan_nearest returned them, dnearest[n,3] = dL/d(nearest point) -> dpoints[n,3] = dL/d(query):
