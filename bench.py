@@ -142,6 +142,47 @@ def event_leg(batch, steps, iters, flags):
     return batch.timing_sum()
 
 
+def scaling_legs(mode, model, gmm, dev, n_gpus, rank, views, iters, comm, per_gpu=(32, 256), steps=10):
+    """Config 2's job at CU-filling sizes, for the N-GPU modes: `per_gpu` frames on every GPU (32 = BASELINE config 4's shard: 32 of a GPU's
+    256 CUs busy; 256 = one frame per CU), one RCCL all-gather per job - and THE SAME TOTAL JOB ON ONE GPU next to it, so that the line
+    carries weak scaling (per-GPU work fixed) and strong scaling (total work fixed) of the same code.  Every rank runs this (the gather
+    is a collective); rank 0 alone runs the one-GPU job while the others wait at the barrier."""
+    legs = []
+    flags = _lib.FIT_FETCH | _lib.FIT_NOTIME
+    for fb in per_gpu:
+        total = fb * n_gpus
+        try:
+            if mode == "group":
+                g = shard.Group(model, gmm, n_frames=total, n_views=views, n_devices=n_gpus)
+                c2w, K, kp, ndiv, betas, pose = pack(model, range(total), views)
+                g.set_cameras(c2w, K); g.set_keypoints(kp, ndiv); g.set_init(betas, pose)
+                w, full = timed_brackets(g, steps, 2, iters, flags, 3, g.sync, g.gather_params)
+                g.close()
+            else:
+                lo, hi = shard.shard_range(total, rank, n_gpus)
+                bb = build_batch(dev, model, list(range(lo, hi)), views)
+                w, full = timed_brackets(bb, steps, 2, iters, flags, 3, comm.barrier, (lambda: comm.gather_params(bb, total)), comm.max)
+                bb.close()
+            assert full.shape[0] == total and np.isfinite(full).all()
+            wm = statistics.median(w)
+            leg = {"frames_per_gpu": fb, "total_frames": total, "n_gpus": n_gpus, "value": total * steps / wm, "unit": "frames/s",
+                   "ms_per_step": wm / steps * 1e3, "ms_per_step_spread": spread([x / steps * 1e3 for x in w])}
+            if rank == 0:
+                one = build_batch(dev, model, list(range(total)), views)
+                w1, _ = timed_brackets(one, steps, 2, iters, flags, 3, one.sync)
+                one.close()
+                w1m = statistics.median(w1)
+                leg["same_job_on_one_gpu"] = {"value": total * steps / w1m, "unit": "frames/s", "ms_per_step": w1m / steps * 1e3}
+                leg["strong_scaling_speedup"] = w1m / wm
+            if mode == "ranks":
+                comm.barrier()
+            legs.append(leg)
+        except Exception as exc:                               # (never let a side leg take the headline line down)
+            legs.append({"frames_per_gpu": fb, "error": repr(exc)})
+            break
+    return legs
+
+
 def batch_result_bytes(F):
     """params + terms + state + joints + vertices of F SMPL frames (the result arena's slices, 256-byte aligned)"""
     up = lambda n: (n + 63) // 64 * 64
@@ -484,8 +525,18 @@ def main():
         "device_ms_per_step": {k: ev[k] / max(ev["calls"], 1) for k in ("fit_ms", "mesh_ms", "tail_ms", "total_ms")},
     }
 
+    legs = None
+    if not a.no_extra and mode in ("group", "ranks") and F == 1:
+        legs = scaling_legs(mode, model, gmm, dev, n_gpus, rank, a.views, a.iters, comm)
     if rank == 0 and not a.no_extra:
         extra = {}
+        if legs is not None:
+            extra["scaling_legs"] = legs
+            extra["scaling_legs_note"] = ("weak scaling = `value` of a leg against n_gpus x the one-GPU value of ITS per-GPU size; strong scaling = "
+                                          "strong_scaling_speedup (the same total job on one GPU / on n_gpus).  Expectation (DESIGN 6): a frame is one "
+                                          "workgroup on one CU for ~0.44 ms whatever else runs, so 32 per GPU fills 1/8 of a GPU and the total job on one "
+                                          "GPU (256 frames at 8 GPUs) takes ~0.6 ms against ~0.46 ms + the gather sharded: ~1.25x from 8 GPUs; 256 per GPU "
+                                          "fills every CU and 2,048 frames on one GPU are eight rounds: ~6-7x from 8 GPUs")
         if mode == "single" and stream:
             w, _ = timed_brackets(batch, a.steps, 3, a.iters, flags, 3, batch.sync)
             wm = statistics.median(w)
@@ -508,8 +559,11 @@ def main():
                 e = event_leg(bb, n, a.iters, _lib.FIT_FETCH)                                  # (with events: device times)
                 w, _ = timed_brackets(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_NOTIME, 3, bb.sync)
                 wg, _ = timed_brackets(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_GRAPH, 3, bb.sync)   # (pipelined fetch from 8 frames on)
-                w = min(statistics.median(w), statistics.median(wg))
+                wh, wgm = statistics.median(w), statistics.median(wg)
+                w = min(wh, wgm)
                 extra[f"batch_{fb}_frames"] = {"value": fb * n / w, "unit": "frames/s", "ms_per_step": w / n * 1e3,
+                                               "submission": "host-issued kernels" if wh <= wgm else "one hipGraph per step",
+                                               "ms_per_step_host_issued": wh / n * 1e3, "ms_per_step_graph": wgm / n * 1e3,
                                                "device_fit_ms": e["fit_ms"] / e["calls"], "device_mesh_ms": e["mesh_ms"] / e["calls"]}
                 bb.close()
             # the dense-loss configurations of BASELINE.json (3 and 5 as stated) on this GPU: tools/bench_configs.py
@@ -521,7 +575,7 @@ def main():
                     extra["config_5"] = BC.cfg5x(2)
                 except Exception as exc:                       # (never let a side leg take the headline line down)
                     extra["configs_error"] = repr(exc)
-        elif mode == "group" and F != 32:
+        elif mode == "group" and F != 32 and legs is None:
             # BASELINE config 4 as stated: 32 frames per GPU, sharded by the same group API
             try:
                 g4 = shard.Group(model, gmm, n_frames=32 * n_gpus, n_views=a.views, n_devices=n_gpus)

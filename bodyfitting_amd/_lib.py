@@ -86,6 +86,8 @@ SIGNATURES = {
     "bf_scan_nearest_backward": (C.c_int, [_VP, C.c_int, _IP, _FP, _FP, _FP]),
     "bf_nearest_rule_set": (C.c_int, [C.c_int]),
     "bf_nearest_rule_get": (C.c_int, []),
+    "bf_nearest_selftest_quot": (C.c_int, [C.c_int, C.c_int, _FP, _FP, _FP]),
+    "bf_nearest_selftest_rule": (C.c_int, [C.c_int, C.c_int, _FP, C.c_int, _FP, _FP]),
     "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
     "bf_batch_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),
     "bf_extract_contours": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),

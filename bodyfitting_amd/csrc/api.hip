@@ -624,7 +624,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
         const size_t n_kp = F * n_views * m->nl_loss * 3;
         b->in_off[0] = 0; b->in_off[1] = up(n_kp); b->in_off[2] = b->in_off[1] + up(F * np);
         b->in_total = b->in_off[2] + up(F);
-        if (const char *e = getenv("BF_STAGE_MODE")) b->stage_mode = !strcmp(e, "memcpy") ? 1 : (!strcmp(e, "zerocopy") ? 2 : (!strcmp(e, "aside") ? 3 : 0));
+        if (const char *e = getenv("BF_STAGE_MODE")) b->stage_mode = !strcmp(e, "memcpy") ? 1 : (!strcmp(e, "zerocopy") ? 2 : 0);
         for (int k = 0; k < 2; ++k) {
             ok = ok && b->in_dev[k].alloc(b->in_total) == hipSuccess && bf_memset_sync(b->in_dev[k].p, 0, b->in_total * sizeof(float)) == hipSuccess;
             ok = ok && hipHostMalloc((void **)&b->h_in[k], b->in_total * sizeof(float)) == hipSuccess;
@@ -705,7 +705,6 @@ void bf_batch_destroy(bf_batch *b) {
         if (b->ev_copied[k]) (void)hipEventDestroy(b->ev_copied[k]);
     }
     if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
-    if (b->in_stream) { (void)hipStreamSynchronize(b->in_stream); (void)hipStreamDestroy(b->in_stream); }
     if (b->fit_stream) { (void)hipStreamSynchronize(b->fit_stream); (void)hipStreamDestroy(b->fit_stream); }
     for (auto &e : b->ev_door) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev_aux) if (e) (void)hipEventDestroy(e);
@@ -786,12 +785,14 @@ int bf_batch_reset(bf_batch *b) {
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_reset: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
     { int rg_ = bf_guard_arena(b); if (rg_) return rg_; }
-    HIP_TRY(hipMemcpyAsync(b->params.p, b->params0.p, b->params.n * sizeof(float), hipMemcpyDeviceToDevice, b->stream));
+    // (hipMemcpyDefault: with BF_STAGE_MODE=zerocopy params0 is a view into the pinned staging buffer, not device memory)
+    HIP_TRY(hipMemcpyAsync(b->params.p, b->params0.p, b->params.n * sizeof(float), hipMemcpyDefault, b->stream));
     HIP_TRY(hipMemsetAsync(b->adam_m.p, 0, b->adam_m.n * sizeof(float), b->stream));
     HIP_TRY(hipMemsetAsync(b->adam_v.p, 0, b->adam_v.n * sizeof(float), b->stream));
     b->steps_done = 0;
     b->have_result = false;
     b->fetched = false;
+    b->staged = false;             // (re-armed from the staged parameters: a following bf_fit needs no BF_FIT_RESET)
     return BF_OK;
 }
 
@@ -835,24 +836,6 @@ int bf_batch_stage_inputs(bf_batch *b, const float *keypoints, const int32_t *n_
         bf_use_inputs(b, k, true);
     } else {
         const size_t n4 = b->in_total / 4;
-        if (b->stage_mode == 3) {
-            // the transfer on the batch's SECOND stream, under the fit in flight (the other arena is nobody's); the batch stream
-            // only waits for its event - long complete when the next fit's turn comes
-            if (!b->in_stream) {            // (a stream of its own, highest priority: neither behind the fit nor behind the previous call's mesh tail)
-                int least = 0, greatest = 0;
-                HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
-                HIP_TRY(hipStreamCreateWithPriority(&b->in_stream, hipStreamNonBlocking, greatest));
-            }
-            hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->in_stream,
-                               (const float4 *)h, (float4 *)b->in_dev[k].p, n4);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(b->ev_in[k], b->in_stream));
-            HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_in[k], 0));
-            b->in_pending[k] = true;
-            bf_use_inputs(b, k, false);
-            b->staged = true;
-            return BF_OK;
-        }
         if (b->stage_mode == 1) {
             HIP_TRY(hipMemcpyAsync(b->in_dev[k].p, h, b->in_total * sizeof(float), hipMemcpyHostToDevice, b->stream));
         } else {
@@ -1134,7 +1117,7 @@ static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t fl
         if (rc) return rc;
     } else {
         if (reset) {
-            HIP_TRY(hipMemcpyAsync(b->params.p, b->params0.p, b->params.n * fb, hipMemcpyDeviceToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->params.p, b->params0.p, b->params.n * fb, hipMemcpyDefault, b->stream));   // (params0 may be pinned host memory: zero-copy staging)
             HIP_TRY(hipMemsetAsync(b->adam_m.p, 0, b->adam_m.n * fb, b->stream));
             HIP_TRY(hipMemsetAsync(b->adam_v.p, 0, b->adam_v.n * fb, b->stream));
         }

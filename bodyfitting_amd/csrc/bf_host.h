@@ -3,6 +3,7 @@
 #include "../../include/bodyfit.h"
 #include "bf_internal.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <algorithm>
 #include <cmath>
@@ -29,7 +30,7 @@ inline hipError_t bf_memset_sync(void *p, int value, size_t bytes) {
     hipError_t e = hipMemset(p, value, bytes);
     return e == hipSuccess ? hipStreamSynchronize(nullptr) : e;
 }
-inline int bf_alloc_index() { static int counter = 0; return counter++; }      // (of this translation unit's allocations, all types)
+inline int bf_alloc_index() { static std::atomic<int> counter{0}; return counter++; }      // (of this translation unit's allocations, all types; bf_group's workers allocate side by side)
 template <class T>
 struct DevBuf {
     T *p = nullptr;
@@ -152,7 +153,6 @@ struct bf_batch {
     size_t res_off[5] = {0, 0, 0, 0, 0}, res_cnt[5] = {0, 0, 0, 0, 0};   // params, terms, state, joints, vout
     int cur = 0;                    // arena the DevBuf views / h_* pointers are on
     hipStream_t copy_stream = nullptr;
-    hipStream_t in_stream = nullptr;      // BF_STAGE_MODE=aside: the input transfer's own stream
     // dense schedule with the fit kernel resident for the whole call (BfDoor, bf_internal.h)
     hipStream_t fit_stream = nullptr;
     hipEvent_t ev_aux[2] = {nullptr, nullptr};   // fork / join of the dense keypoint loss on the second stream

@@ -229,90 +229,105 @@ extern "C" __global__ void __launch_bounds__(256) bf_inside_mesh_kernel(ScanDev 
 // (A zero direction is rejected by the caller, kernel.cu:1062-1065, so the norm <= 1e-9 branches :793-848 are never reached.)
 // The answer is an OR over triangles, so the order of the reference's cell walk does not matter: one thread per ray walks the cells
 // its ray crosses (3-D DDA from the ray's entry into the grid) and stops at the first hit.
+// (float32 throughout, no fused multiply-adds: `#pragma clang fp contract(off)` in every helper; sums run left to right)
+struct Vec3 { float x, y, z; };
+__device__ inline Vec3 v3_sub(const float *a, const float *b) { return Vec3{a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+__device__ inline Vec3 v3_cross(const Vec3 &u, const Vec3 &v) {
+#pragma clang fp contract(off)
+    return Vec3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+}
+__device__ inline float v3_dot(const Vec3 &u, const Vec3 &v) {
+#pragma clang fp contract(off)
+    return u.x * v.x + u.y * v.y + u.z * v.z;
+}
+__device__ inline float v3_minus_dot(const Vec3 &u, const Vec3 &v) {      // -u.v, the negation inside the first product
+#pragma clang fp contract(off)
+    return -u.x * v.x - u.y * v.y - u.z * v.z;
+}
+__device__ inline Vec3 v3_pick(int i, const Vec3 &a, const Vec3 &b, const Vec3 &c) { return i == 0 ? a : (i == 1 ? b : c); }
+
+// One ray against one triangle: the corners relative to the ray's origin, minus the direction, and the three products
+// face[c] = rel[c + 1] x rel[c + 2] (the rows of the adjugate of [rel_a | rel_b | rel_c]).
+struct RayTriangle {
+    Vec3 rel[3], minus_dir, face[3];
+    float prec;
+    __device__ RayTriangle(const float o[3], const float d[3], const float *va, const float *vb, const float *vc) : prec(1e-9f) {
+        rel[0] = v3_sub(va, o); rel[1] = v3_sub(vb, o); rel[2] = v3_sub(vc, o);
+        minus_dir = Vec3{-d[0], -d[1], -d[2]};
+        face[0] = v3_cross(rel[1], rel[2]); face[1] = v3_cross(rel[2], rel[0]); face[2] = v3_cross(rel[0], rel[1]);
+    }
+    __device__ Vec3 rel_of(int c) const { return v3_pick(c, rel[0], rel[1], rel[2]); }
+    __device__ Vec3 face_of(int c) const { return v3_pick(c, face[0], face[1], face[2]); }
+    // does the ray, seen in the plane whose normal is face_of(i), pass between corners j and k - and on which side of each?
+    // (the two numerators of kernel.cu:868-871 / 960-963: n . (rel_k x -d) and -n . (rel_j x -d))
+    __device__ void between(int i, int j, int k, float &nj, float &nk) const {
+        const Vec3 n = face_of(i);
+        nj = v3_dot(n, v3_cross(rel_of(k), minus_dir));
+        nk = v3_minus_dot(n, v3_cross(rel_of(j), minus_dir));
+    }
+    __device__ bool within(float x) const { return x >= -prec && x <= prec; }
+
+    // |det| > 1e-9: Cramer's rule, numerators signed by the determinant (kernel.cu:742-780)
+    __device__ bool regular(float num[4], float det) const {
+        const bool flip = det < 0.f;
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ok = ok && (flip ? -num[c] : num[c]) >= -prec;
+        return ok;
+    }
+    // area^2 <= 1e-9: the triangle is a segment or a point (kernel.cu:849-911)
+    __device__ bool degenerate(const float num[4], const float *va, const float *vb, const float *vc) const {
+#pragma clang fp contract(off)
+        const Vec3 edge[3] = {v3_sub(vc, vb), v3_sub(va, vc), v3_sub(vb, va)};          // edge c is opposite corner c
+        const float len[3] = {v3_dot(edge[0], edge[0]), v3_dot(edge[1], edge[1]), v3_dot(edge[2], edge[2])};
+        int i = len[0] < len[1] ? 1 : 0;                                                // the longest edge
+        i = len[i] < len[2] ? 2 : i;
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        if (len[i] <= prec) {                                                           // a point: origin-to-point parallel to the ray, not behind it
+            const Vec3 c = v3_cross(rel_of(i), minus_dir);
+            return v3_dot(c, c) <= prec && v3_minus_dot(rel_of(i), minus_dir) >= -prec;
+        }
+        const Vec3 n = face_of(i), e = v3_pick(i, edge[0], edge[1], edge[2]);
+        float nj, nk, ahead;
+        if (v3_dot(n, n) > prec) { between(i, j, k, nj, nk); ahead = nj + nk; }
+        else { nj = v3_dot(rel_of(k), e); nk = v3_minus_dot(rel_of(j), e); ahead = len[i]; }     // the origin is on the segment's line
+        return within(num[i]) && nj >= -prec && nk >= -prec && ahead > prec;
+    }
+    // |det| <= 1e-9, area^2 > 1e-9: the ray is parallel to the triangle's plane (kernel.cu:912-1023)
+    __device__ bool coplanar(const float num[4], const Vec3 &normal) const {
+        const float inside[3] = {v3_dot(face[0], normal), v3_dot(face[1], normal), v3_dot(face[2], normal)};   // the origin's barycentric numerators
+        int i = inside[0] < inside[1] ? 0 : 1;                                          // the smallest
+        i = inside[i] < inside[2] ? i : 2;
+        int j = (i + 1) % 3, k = (i + 2) % 3;
+        if (inside[k] < -prec) { k = j; j = i; i = 3 - j - k; }
+        const bool in_plane = within(num[3]);
+        if (inside[j] < -prec) {                                                        // outside two edges: in through either
+            float a0, a1, b0, b1;
+            between(i, j, k, a0, a1);
+            between(j, k, i, b0, b1);
+            const Vec3 ni = face_of(i), nj = face_of(j);
+            const bool through_i = a0 >= -prec && a1 >= -prec && v3_dot(ni, ni) > prec;
+            const bool through_j = b0 >= -prec && b1 >= -prec && v3_dot(nj, nj) > prec;
+            return (through_i || through_j) && in_plane;
+        }
+        if (inside[i] < -prec) {                                                        // outside one edge: in through that one
+            float nj, nk;
+            between(i, j, k, nj, nk);
+            return nj >= -prec && nk >= -prec && in_plane && nj + nk > prec;
+        }
+        return inside[i] >= -prec && in_plane;                                          // the origin is inside the triangle
+    }
+};
+
 __device__ inline bool ray_hits_triangle(const float o[3], const float d[3], const float *va, const float *vb, const float *vc) {
 #pragma clang fp contract(off)
-    const float prec = 1e-9f;
-    // A = [va - o | vb - o | vc - o | -d] by rows x, y, z: A[r * 4 + c]
-    const float A[12] = {va[0] - o[0], vb[0] - o[0], vc[0] - o[0], -d[0],
-                         va[1] - o[1], vb[1] - o[1], vc[1] - o[1], -d[1],
-                         va[2] - o[2], vb[2] - o[2], vc[2] - o[2], -d[2]};
-    const float I[9] = {A[5] * A[10] - A[6] * A[9], A[2] * A[9] - A[1] * A[10], A[1] * A[6] - A[2] * A[5],
-                        A[6] * A[8] - A[4] * A[10], A[0] * A[10] - A[2] * A[8], A[2] * A[4] - A[0] * A[6],
-                        A[4] * A[9] - A[5] * A[8], A[1] * A[8] - A[0] * A[9], A[0] * A[5] - A[1] * A[4]};
-    float N[4] = {-A[3] * I[0] - A[7] * I[1] - A[11] * I[2], -A[3] * I[3] - A[7] * I[4] - A[11] * I[5],
-                  -A[3] * I[6] - A[7] * I[7] - A[11] * I[8], A[0] * I[0] + A[4] * I[1] + A[8] * I[2]};
-    float det = N[0] + N[1] + N[2];
-    if (det > prec || det < -prec) {
-        if (det < 0.f) { N[0] = -N[0]; N[1] = -N[1]; N[2] = -N[2]; N[3] = -N[3]; }
-        return N[0] >= -prec && N[1] >= -prec && N[2] >= -prec && N[3] >= -prec;
-    }
-    // ---- |det| <= 1e-9 (the direction is not degenerate here)
-    const float Sx = I[0] + I[3] + I[6], Sy = I[1] + I[4] + I[7], Sz = I[2] + I[5] + I[8];
-    const float area = Sx * Sx + Sy * Sy + Sz * Sz;
-    auto col = [&](int c, int r) { return A[r * 4 + c]; };                       // component r of column c
-    auto cross_d = [&](int c, float out[3]) {                                    // (column c) x (-d)
-        out[0] = col(c, 1) * A[11] - col(c, 2) * A[7];
-        out[1] = col(c, 2) * A[3] - col(c, 0) * A[11];
-        out[2] = col(c, 0) * A[7] - col(c, 1) * A[3];
-    };
-    if (area <= prec) {
-        const float e[9] = {vc[0] - vb[0], vc[1] - vb[1], vc[2] - vb[2], va[0] - vc[0], va[1] - vc[1], va[2] - vc[2],
-                            vb[0] - va[0], vb[1] - va[1], vb[2] - va[2]};
-        const float l[3] = {e[0] * e[0] + e[1] * e[1] + e[2] * e[2], e[3] * e[3] + e[4] * e[4] + e[5] * e[5], e[6] * e[6] + e[7] * e[7] + e[8] * e[8]};
-        int i = l[0] < l[1] ? 1 : 0;
-        i = l[i] < l[2] ? 2 : i;
-        const int j = (i + 1) % 3, k = (i + 2) % 3;
-        if (l[i] <= prec) {                                  // the triangle is a point
-            float cr[3];
-            cross_d(i, cr);
-            const float n_i = cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2];
-            const float n3 = -col(i, 0) * A[3] - col(i, 1) * A[7] - col(i, 2) * A[11];
-            return n_i <= prec && n3 >= -prec;
-        }
-        // the triangle is a segment (its longest edge e_i, from corner j to corner k)
-        const float norm_ = I[3 * i] * I[3 * i] + I[3 * i + 1] * I[3 * i + 1] + I[3 * i + 2] * I[3 * i + 2];
-        float nj, nk, n3;
-        if (norm_ > prec) {
-            float cj[3], ck[3];
-            cross_d(j, cj); cross_d(k, ck);
-            nj = I[3 * i] * ck[0] + I[3 * i + 1] * ck[1] + I[3 * i + 2] * ck[2];
-            nk = -I[3 * i] * cj[0] - I[3 * i + 1] * cj[1] - I[3 * i + 2] * cj[2];
-            n3 = nj + nk;
-        } else {                                             // the origin is on the segment's line
-            nj = col(k, 0) * e[3 * i] + col(k, 1) * e[3 * i + 1] + col(k, 2) * e[3 * i + 2];
-            nk = -col(j, 0) * e[3 * i] - col(j, 1) * e[3 * i + 1] - col(j, 2) * e[3 * i + 2];
-            n3 = l[i];
-        }
-        return N[i] >= -prec && N[i] <= prec && nj >= -prec && nk >= -prec && n3 > prec;
-    }
-    // ---- the ray is parallel to the triangle's plane
-    float B[3] = {I[0] * Sx + I[1] * Sy + I[2] * Sz, I[3] * Sx + I[4] * Sy + I[5] * Sz, I[6] * Sx + I[7] * Sy + I[8] * Sz};
-    int i = B[0] < B[1] ? 0 : 1;
-    i = B[i] < B[2] ? i : 2;
-    int j = (i + 1) % 3, k = (i + 2) % 3;
-    if (B[k] < -prec) { k = j; j = i; i = 3 - j - k; }
-    const bool in_plane = N[3] >= -prec && N[3] <= prec;
-    if (B[j] < -prec) {                                      // outside two edges: the ray has to come in through one of them
-        float ci[3], cj[3], ck[3];
-        cross_d(i, ci); cross_d(j, cj); cross_d(k, ck);
-        const float d0 = I[3 * i] * ck[0] + I[3 * i + 1] * ck[1] + I[3 * i + 2] * ck[2];
-        const float d1 = -I[3 * i] * cj[0] - I[3 * i + 1] * cj[1] - I[3 * i + 2] * cj[2];
-        const float d2 = I[3 * j] * ci[0] + I[3 * j + 1] * ci[1] + I[3 * j + 2] * ci[2];
-        const float d3 = -I[3 * j] * ck[0] - I[3 * j + 1] * ck[1] - I[3 * j + 2] * ck[2];
-        const float ni = I[3 * i] * I[3 * i] + I[3 * i + 1] * I[3 * i + 1] + I[3 * i + 2] * I[3 * i + 2];
-        const float nj = I[3 * j] * I[3 * j] + I[3 * j + 1] * I[3 * j + 1] + I[3 * j + 2] * I[3 * j + 2];
-        const bool v0 = d0 >= -prec && d1 >= -prec && ni > prec, v1 = d2 >= -prec && d3 >= -prec && nj > prec;
-        return (v0 || v1) && in_plane;
-    }
-    if (B[i] < -prec) {                                      // outside one edge
-        float cj[3], ck[3];
-        cross_d(j, cj); cross_d(k, ck);
-        const float nj = I[3 * i] * ck[0] + I[3 * i + 1] * ck[1] + I[3 * i + 2] * ck[2];
-        const float nk = -I[3 * i] * cj[0] - I[3 * i + 1] * cj[1] - I[3 * i + 2] * cj[2];
-        const float ni = nj + nk;
-        return nj >= -prec && nk >= -prec && in_plane && ni > prec;
-    }
-    return B[i] >= -prec && in_plane;                        // the origin is inside the triangle
+    const RayTriangle T(o, d, va, vb, vc);
+    float num[4] = {v3_minus_dot(T.minus_dir, T.face[0]), v3_minus_dot(T.minus_dir, T.face[1]), v3_minus_dot(T.minus_dir, T.face[2]),
+                    v3_dot(T.rel[0], T.face[0])};
+    const float det = num[0] + num[1] + num[2];
+    if (det > T.prec || det < -T.prec) return T.regular(num, det);
+    const Vec3 normal{T.face[0].x + T.face[1].x + T.face[2].x, T.face[0].y + T.face[1].y + T.face[2].y, T.face[0].z + T.face[1].z + T.face[2].z};
+    return v3_dot(normal, normal) <= T.prec ? T.degenerate(num, va, vb, vc) : T.coplanar(num, normal);
 }
 
 extern "C" __global__ void __launch_bounds__(256) bf_intersect_kernel(ScanDev S, const float *__restrict__ origins,

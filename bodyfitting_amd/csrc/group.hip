@@ -41,11 +41,22 @@ Rccl *rccl() {
     static Rccl R;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+        // BF_RCCL_PATH first (a full path), then the loader's search path (a process that imported torch finds torch's copy there),
+        // then ROCm's own install
+        std::string tried;
+        const char *env = std::getenv("BF_RCCL_PATH");
+        for (const char *name : {env ? env : "", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
+            if (!name[0]) continue;
             R.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (R.handle) break;
+            const char *why = dlerror();
+            tried += std::string(tried.empty() ? "" : "; ") + name + " (" + (why ? why : "?") + ")";
         }
-        if (!R.handle) { R.error = std::string("dlopen(librccl.so.1): ") + dlerror(); return; }
+        if (!R.handle) {
+            R.error = "RCCL could not be loaded - tried: " + tried + ".  Multi-GPU jobs (bf_group_* with more than one device, bf_comm_*) need "
+                      "librccl.so.1 on the loader's path or BF_RCCL_PATH=/full/path/librccl.so.1; single-GPU fitting does not use it";
+            return;
+        }
         auto sym = [&](const char *n) {
             void *p = dlsym(R.handle, n);
             if (!p && R.error.empty()) R.error = std::string("librccl has no symbol ") + n;

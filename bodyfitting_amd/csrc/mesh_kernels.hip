@@ -950,7 +950,10 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
 extern "C" bool bf_mesh_batch32_fits(const MeshTab *M) {
     // (float2 reads along a frame's record: the record and its pose-feature block have to start on 8-byte boundaries)
     if (bf_state_stride(M->nj, M->npf, M->nb) % 2 != 0 || (M->nj * 15) % 2 != 0) return false;
-    return M->npf <= 208 && M->nj <= 24 && M->nj >= 22 /* three frames' bone transforms per 512-thread step */ && M->v_nnz == 4 && M->nb == 10 && M->n_extra <= 24;
+    // npf >= 2 NW (KS - 1) + 1 = 193: only the LAST of a wave's 13 row pairs is clamped to the table's end (bq[KS - 1]); with fewer
+    // rows an earlier pair would read past posedirs (nj = 22: npf = 189 - the operand it meets is zero, but 0 x garbage may be NaN)
+    return M->npf <= 208 && M->npf >= 193 && M->nj <= 24 && M->nj >= 22 /* three frames' bone transforms per 512-thread step */ && M->v_nnz == 4 &&
+           M->nb == 10 && M->n_extra <= 24;
 }
 extern "C" hipError_t bf_mesh_batch32_launch(const MeshTab *M, const float *state, int n, float *vraw, float *vout, float *xpart,
                                              hipStream_t stream) {

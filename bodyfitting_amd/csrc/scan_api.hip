@@ -186,6 +186,32 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
     return BF_OK;
 }
 
+// self-tests of the reference-arithmetic rule (nearest_rule_ref.h): its division helper against the caller's IEEE quotients, and the
+// per-triangle rule on explicit patches
+extern "C" __global__ void bf_nearest_quot_kernel(int, const float *, const float *, float *);
+extern "C" __global__ void bf_nearest_rule_kernel(int, const float *, float *, float *, int);
+int bf_nearest_selftest_quot(int device, int n, const float *num, const float *den, float *out) {
+    if (n <= 0 || !num || !den || !out) return fail(BF_ERR_INVALID, "bf_nearest_selftest_quot: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<float> d_n, d_d, d_o;
+    HIP_TRY(d_n.upload(std::vector<float>(num, num + n))); HIP_TRY(d_d.upload(std::vector<float>(den, den + n))); HIP_TRY(d_o.alloc(n));
+    hipLaunchKernelGGL(bf_nearest_quot_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, n, (const float *)d_n.p, (const float *)d_d.p, d_o.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d_o.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+int bf_nearest_selftest_rule(int device, int n, const float *patches, int general, float *dist, float *coeff) {
+    if (n <= 0 || !patches || !dist || !coeff) return fail(BF_ERR_INVALID, "bf_nearest_selftest_rule: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    DevBuf<float> d_p, d_d, d_c;
+    HIP_TRY(d_p.upload(std::vector<float>(patches, patches + (size_t)n * 9))); HIP_TRY(d_d.alloc(n)); HIP_TRY(d_c.alloc((size_t)n * 3));
+    hipLaunchKernelGGL(bf_nearest_rule_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, n, (const float *)d_p.p, d_d.p, d_c.p, general);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(dist, d_d.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(coeff, d_c.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
 // SurfaceNearest.backward with respect to the query points (utils/mesh_grid_searcher.py:17-49, unfinished in the reference):
 // dpoints = (d nearest / d points)^T dnearest for the faces / coefficients bf_scan_nearest returned
 int bf_scan_nearest_backward(bf_scan *s, int n, const int32_t *face_ids, const float *bary, const float *dnearest, float *dpoints) {
@@ -470,6 +496,16 @@ static int ensure_fit_stream(bf_batch *b, const FrameIO &io, const HyperDev &hd)
     int verdict = 0;
     HIP_TRY(hipMemcpy(&verdict, b->door.p + BF_DOOR_TICKET, sizeof(int), hipMemcpyDeviceToHost));
     b->door_usable = verdict == 1;
+    if (!b->door_usable) {
+        // said once per process: the dense loops still give the same results, about three times slower (one fit launch per iteration)
+        static std::atomic<bool> told{false};
+        if (!told.exchange(true))
+            std::fprintf(stderr, "libbodyfit: the resident fit launch is off - its stream shares a hardware queue with the batch stream (self-test "
+                                 "verdict %d).  The dense loops (use_mask / use_mesh / SMPL-X) fall back to one fit launch per iteration: same "
+                                 "results, ~3x slower.  HIP multiplexes a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4; the "
+                                 "library asks for 8 when it is loaded BEFORE HIP initialises): export GPU_MAX_HW_QUEUES=8 before the first HIP "
+                                 "call of the process, or load libbodyfit first.\n", verdict);
+    }
     return BF_OK;
 }
 
@@ -656,7 +692,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     if (!b || contour_select < 0 || contour_select > 2) return fail(BF_ERR_INVALID, "bf_batch_set_masks: null batch / bad contour_select");
     HIP_TRY(hipSetDevice(b->m->device));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
-    if (n_masks <= 0 || !masks) { b->has_masks = false; return BF_OK; }
+    if (n_masks <= 0 || !masks) { b->has_masks = false; b->masks_pending = false; return BF_OK; }   // (bf_sync_all above drained a deferred extraction)
     if (!view_index || (contour_count && !contour_xy) || H <= 0 || W <= 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: bad argument");
     const int F = b->F, nv = b->m->nv;
     for (int i = 0; i < n_masks; ++i)

@@ -121,25 +121,37 @@ __device__ inline int nn_wave_min_i(int v) {
 // points equal to oracle/nearest_ref.c wherever no two faces tie bit for bit; BF_NEAREST_FAST = the 2 x 2 normal equations with
 // v_rcp_f32 (same mathematics, ~half the instructions, other last bits: 4.7 % of config 5's queries then pick the other face of a
 // shared edge - DESIGN 2.3).
+// The reference rule's regular paths are straight-line code (nearest_rule_ref.h); a triangle on which the reference would take a rank
+// decision - a scan has a handful of degenerate / collinear triangles (coincident vertices after the OBJ's four decimals), and every
+// query that walks a cell holding one meets it: hundreds of evaluations per launch at config 5's size - goes through the general
+// routines right there: a call on the lanes concerned, its systems in the wave's slot of an LDS array (a version with private arrays
+// needed 104 registers and scratch memory; a second kernel doing such queries again cost 55 - 85 us per launch for a few hundred of
+// them, one wave-latency each).
 template <int RULE>
 __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
-                  int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
-    const int lane = threadIdx.x & 63, id = blockIdx.x * 4 + (threadIdx.x >> 6), f = blockIdx.y;
-    if (id >= n) return;                                   // (wave-uniform)
+                  int *face, float *__restrict__ pts, float *__restrict__ bary, int warm, int id, int f) {
+    const int lane = threadIdx.x & 63;
     const ScanDev S = scans[f];
     const size_t o = (size_t)f * n + id;
     const float *q = points + o * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
     int cx = (int)floorf((qx - S.ox) / S.step), cy = (int)floorf((qy - S.oy) / S.step), cz = (int)floorf((qz - S.oz) / S.step);
     cx = min(max(cx, 0), S.nx - 1); cy = min(max(cy, 0), S.ny - 1); cz = min(max(cz, 0), S.nz - 1);
-    const int maxL = max(max(max(cx, S.nx - 1 - cx), max(cy, S.ny - 1 - cy)), max(cz, S.nz - 1 - cz));
+    // the reference's shell limit (mesh_grid_kernel.cu:254-257, 262): per axis x > size - x ? x : size - x, shells L < that - on the
+    // side where the home cell is past the middle this is one short of the far wall, and a query metres outside the grid (the only
+    // kind that walks that far) never sees the last layer of cells.  Kept.
+    const int maxL = max(max(cx > S.nx - cx ? cx : S.nx - cx, cy > S.ny - cy ? cy : S.ny - cy), cz > S.nz - cz ? cz : S.nz - cz) - 1;
     // this lane's best so far (distance, face, coefficients); merged after every shell
     float best = 3.0e38f, bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
     int bface = 0x7fffffff;
     float gbest = 3.0e38f;                                  // (wave-uniform) best distance so far, for the pruning
+    __shared__ float s_general[RULE == BF_NEAREST_REFERENCE ? 4 * 20 * nrule::LANES : 1];     // the systems of the general routines, a slot per lane
+    float *scr = s_general + (RULE == BF_NEAREST_REFERENCE ? (threadIdx.x >> 6) * 20 * nrule::LANES + lane : 0);
     auto test = [&](const float *p, int t) {
         float co[3];
-        const float dist = RULE == BF_NEAREST_REFERENCE ? nrule::nearest_proj(p, co) : closest_rule(p, p + 3, p + 6, co);
+        float dist;
+        if (RULE == BF_NEAREST_FAST) dist = closest_rule(p, p + 3, p + 6, co);
+        else dist = nrule::nearest_proj_general(p, co, scr);
         if (dist < best || (dist == best && t < bface)) { best = dist; bface = t; bc0 = co[0]; bc1 = co[1]; bc2 = co[2]; }
     };
     auto test_record = [&](int rec) {
@@ -185,7 +197,7 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
     {   // ---- shells 0 and 1: the 27-cell cube, lane c = (dz+1)*9 + (dy+1)*3 + (dx+1); the home cell is lane 13
         const int dz = lane / 9 - 1, rem = lane % 9, dy = rem / 3 - 1, dx = rem % 3 - 1;
         const int x = cx + dx, y = cy + dy, z = cz + dz;
-        const bool cell_ok = lane < 27 && x >= 0 && x < S.nx && y >= 0 && y < S.ny && z >= 0 && z < S.nz;
+        const bool cell_ok = lane < 27 && x >= 0 && x < S.nx && y >= 0 && y < S.ny && z >= 0 && z < S.nz && (maxL >= 1 || lane == 13);
         int st = 0, cnt = 0;
         float d2 = 0.f;
         if (cell_ok) {
@@ -277,7 +289,7 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
         const int *tv = S.faces + (size_t)fmin_ * 3;
         const float *v0 = S.verts + (size_t)tv[0] * 3, *v1 = S.verts + (size_t)tv[1] * 3, *v2 = S.verts + (size_t)tv[2] * 3;
         // proj = q + sum c_i (v_i - q), as the reference forms it (:318-329)
-        if (RULE == BF_NEAREST_REFERENCE) {                // ... every product and sum rounded, left to right
+        if (RULE != BF_NEAREST_FAST) {                     // ... every product and sum rounded, left to right
             r0 = nrule::project(qx, w0, v0[0] - qx, w1, v1[0] - qx, w2, v2[0] - qx);
             r1 = nrule::project(qy, w0, v0[1] - qy, w1, v1[1] - qy, w2, v2[1] - qy);
             r2 = nrule::project(qz, w0, v0[2] - qz, w1, v1[2] - qz, w2, v2[2] - qz);
@@ -294,12 +306,34 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
 extern "C" __global__ void __launch_bounds__(256)
 bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                   int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
-    nearest_body<BF_NEAREST_REFERENCE>(scans, points, n, face, pts, bary, warm);
+    const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (id >= n) return;                                   // (wave-uniform)
+    nearest_body<BF_NEAREST_REFERENCE>(scans, points, n, face, pts, bary, warm, id, blockIdx.y);
 }
 extern "C" __global__ void __launch_bounds__(256)
 bf_nearest_fast_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                        int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
-    nearest_body<BF_NEAREST_FAST>(scans, points, n, face, pts, bary, warm);
+    const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (id >= n) return;
+    nearest_body<BF_NEAREST_FAST>(scans, points, n, face, pts, bary, warm, id, blockIdx.y);
+}
+
+// nearest_rule_ref.h's division helper and per-triangle rule, exposed for the tests (bf_nearest_selftest_*)
+extern "C" __global__ void bf_nearest_quot_kernel(int n, const float *__restrict__ num, const float *__restrict__ den, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = nrule::quot(num[i], nrule::recip(den[i]));
+}
+// patches[n][9] (corners relative to the query) -> dist[n], coeff[n][3]; general != 0: with the general routines behind the regular
+// paths (what the pair of kernels computes), 0: the regular paths alone (-1 where they decline)
+extern "C" __global__ void bf_nearest_rule_kernel(int n, const float *__restrict__ patches, float *__restrict__ dist, float *__restrict__ coeff, int general) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    __shared__ float s_general[20 * nrule::LANES];
+    float p[9], c[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p[k] = patches[(size_t)i * 9 + k];
+    dist[i] = general ? nrule::nearest_proj_general(p, c, s_general + threadIdx.x) : nrule::nearest_proj_regular(p, c);
+    coeff[i * 3] = c[0]; coeff[i * 3 + 1] = c[1]; coeff[i * 3 + 2] = c[2];
 }
 
 // which arithmetic bf_nearest_launch uses: BF_NEAREST_RULE=fast|reference in the environment at first use, or bf_nearest_rule_set()

@@ -225,6 +225,12 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
 #define BF_NEAREST_FAST      1
 int bf_nearest_rule_set(int rule);                     /* 0 on success, -1 for an unknown rule */
 int bf_nearest_rule_get(void);
+/* Self-tests of the reference-arithmetic rule: out[i] = num[i] / den[i] through the kernel's division helper (exact IEEE division
+ * for 1e-8 < |den| < 4, |num / den| < 2^90); the per-triangle rule itself on patches[n][9] = the corners relative to the query
+ * (mesh_grid_kernel.cu:305-311) -> dist[n], coeff[n][3]; general = 0 evaluates the straight-line paths alone and returns -1 where
+ * they decline. */
+int bf_nearest_selftest_quot(int device, int n, const float *num, const float *den, float *out);
+int bf_nearest_selftest_rule(int device, int n, const float *patches, int general, float *dist, float *coeff);
 /* SurfaceNearest.backward with respect to the query points (utils/mesh_grid_searcher.py:17-49; search_nearest_point_backward,
  * mesh_grid.cpp:120-128, mesh_grid_kernel.cu:354-382 - left unfinished in the reference: its kernel never inverts the KKT matrix).
  * face_ids[n], bary[n,3] as bf_scan_nearest returned them, dnearest[n,3] = dL/d(nearest point) -> dpoints[n,3] = dL/d(query):

@@ -139,17 +139,26 @@ def reference_loss_terms(model, gmm, problem, params):
 
 
 class StandInMeshGridSearcher:
-    """Replaces utils.mesh_grid_searcher.MeshGridSearcher (whose CUDA extension cannot be built here)
-    inside the imported reference: same interface, brute-force search with the reference's per-triangle
-    rule (oracle/mesh_oracle.py)."""
+    """Replaces utils.mesh_grid_searcher.MeshGridSearcher (whose CUDA extension cannot be built here) inside the imported reference:
+    same interface; `set_mesh`'s grid (utils/mesh_grid_searcher.py:56-79, insert_grid_surface) and the search of
+    search_nearest_point_kenerel IN THE REFERENCE'S OWN float32 ARITHMETIC (oracle/nearest_ref.c: mesh_grid_kernel.cu:12-109, 239-353 +
+    matrix.h, the latter held bit for bit to the reference's header).  FUSED = True selects the build of that restatement in which the
+    compiler may fuse multiply-adds, as nvcc's default does for the reference: one of the perturbations of sensitivity_goldens.
+    (Rounds 1-3 used a float64 brute-force search by the same rule here.)"""
+    FUSED = False
 
     def __init__(self, verts=None, faces=None, device="cpu"):
-        self.verts, self.faces = np.asarray(verts), np.asarray(faces)
+        from oracle import mesh_oracle as MO
+        self.verts = np.ascontiguousarray(np.asarray(verts), np.float32)
+        self.faces = np.ascontiguousarray(np.asarray(faces), np.int32)
+        step, num, origin = MO.grid_params(self.verts)
+        tri_num, tri_idx = MO.insert_grid_surface(self.verts, self.faces, step, origin, num)
+        self.grid = (step, num, origin, tri_num, tri_idx)
 
     def nearest_points(self, points):
         import torch
-        from oracle import mesh_oracle as MO
-        ids, pts, _ = MO.nearest_bruteforce(self.verts, self.faces, points.detach().cpu().numpy())
+        from oracle import nearest_ref as NR
+        ids, pts, _, _ = NR.search_nearest(self.verts, self.faces, points.detach().cpu().numpy().reshape(-1, 3), self.grid, fused=self.FUSED)
         return torch.from_numpy(pts), torch.from_numpy(ids)
 
 
@@ -372,6 +381,52 @@ def _nudge(problem):
     return q
 
 
+def sensitivity_scan_goldens():
+    """The scan loops' share of sensitivity_goldens: 8 threads, one ulp, and - for the closest-point search, whose answers are face
+    ids decided by last bits - the restated search built with fused multiply-adds ('fused': what nvcc is free to do to the
+    reference's own build)."""
+    import torch
+    import smplx
+    from bodyfitting_amd import synthetic as S
+    from bodyfitting_amd.io import save_obj_mesh
+
+    variants = (("threads8", 8, False, False), ("ulp", 1, True, False), ("fused", 1, False, True))
+    gmm = S.make_gmm(seed=0)
+    # ---- scan loop 300 + SMPL+D 300 on the reduced model (scan_goldens_long) -----------------------------------------
+    model = S.make_model("smpl", seed=0, nv=690)
+    smplx.MODEL_REGISTRY["smpl"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_sens_scan_")
+    write_data_dir(tmp, model, gmm)
+    os.chdir(tmp)
+    base, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
+    meshfile = os.path.join(tmp, "scan.obj")
+    save_obj_mesh(meshfile, sv, sf)
+    out = {}
+    for tag, threads, nudge, fused in variants:
+        torch.set_num_threads(threads)
+        StandInMeshGridSearcher.FUSED = fused
+        prob = _nudge(base) if nudge else base
+        res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 300, snapshots=(100, 101, 300), displacement=True)
+        out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
+        out[f"{tag}_vertices"], out[f"{tag}_joints"], out[f"{tag}_displacement"] = res["vertices"], res["joints"], res["displacement"]
+    torch.set_num_threads(1)
+    np.savez_compressed(os.path.join(GOLDEN, "sens_scan_nv690_300it.npz"), model_digest=S.model_digest(model), **out)
+    print("sensitivity: scan loop done")
+    out = {}
+    for tag, threads, nudge, fused in variants:       # the 30 + 30-iteration run of scan_goldens, with its displacement snapshots
+        torch.set_num_threads(threads)
+        StandInMeshGridSearcher.FUSED = fused
+        prob = _nudge(base) if nudge else base
+        res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 30, snapshots=(1, 11, 12, 20, 30), displacement=True)
+        out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
+        out.update({f"{tag}_disp{k}": v for k, v in dsn.items()})
+        out[f"{tag}_vertices"], out[f"{tag}_displacement"] = res["vertices"], res["displacement"]
+    torch.set_num_threads(1)
+    StandInMeshGridSearcher.FUSED = False
+    np.savez_compressed(os.path.join(GOLDEN, "sens_scan_nv690_30it.npz"), model_digest=S.model_digest(model), **out)
+    print("sensitivity: short scan loop done")
+
+
 def sensitivity_goldens():
     """How far does the REFERENCE move from itself?  The dense-loss loops (silhouette: nearest-vertex choices and 1 <-> 10 weights;
     scan: closest faces; SMPL+D: Adam's normalised steps) amplify round-off, so the parity bands of those loops in tests/ are
@@ -433,36 +488,7 @@ def sensitivity_goldens():
     np.savez_compressed(os.path.join(GOLDEN, "sens_mask_fit_8view_30it.npz"), model_digest=S.model_digest(model), **out)
     print("sensitivity: mask loop done")
 
-    # ---- scan loop 300 + SMPL+D 300 on the reduced model (scan_goldens_long) -----------------------------------------
-    model = S.make_model("smpl", seed=0, nv=690)
-    smplx.MODEL_REGISTRY["smpl"] = model
-    tmp = tempfile.mkdtemp(prefix="bf_sens_scan_")
-    write_data_dir(tmp, model, gmm)
-    os.chdir(tmp)
-    base, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
-    meshfile = os.path.join(tmp, "scan.obj")
-    save_obj_mesh(meshfile, sv, sf)
-    out = {}
-    for tag, threads, nudge in variants:
-        torch.set_num_threads(threads)
-        prob = _nudge(base) if nudge else base
-        res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 300, snapshots=(100, 101, 300), displacement=True)
-        out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
-        out[f"{tag}_vertices"], out[f"{tag}_joints"], out[f"{tag}_displacement"] = res["vertices"], res["joints"], res["displacement"]
-    torch.set_num_threads(1)
-    np.savez_compressed(os.path.join(GOLDEN, "sens_scan_nv690_300it.npz"), model_digest=S.model_digest(model), **out)
-    print("sensitivity: scan loop done")
-    out = {}
-    for tag, threads, nudge in variants:              # the 30 + 30-iteration run of scan_goldens, with its displacement snapshots
-        torch.set_num_threads(threads)
-        prob = _nudge(base) if nudge else base
-        res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 30, snapshots=(1, 11, 12, 20, 30), displacement=True)
-        out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
-        out.update({f"{tag}_disp{k}": v for k, v in dsn.items()})
-        out[f"{tag}_vertices"], out[f"{tag}_displacement"] = res["vertices"], res["displacement"]
-    torch.set_num_threads(1)
-    np.savez_compressed(os.path.join(GOLDEN, "sens_scan_nv690_30it.npz"), model_digest=S.model_digest(model), **out)
-    print("sensitivity: short scan loop done")
+    sensitivity_scan_goldens()
 
     # ---- silhouette loop, SMPL-X, 15 iterations (smplx_goldens) ------------------------------------------------------
     model = S.make_model("smplx", seed=0)
@@ -741,6 +767,9 @@ if __name__ == "__main__":
     elif "--openpose-only" in sys.argv:
         install_reference_imports()
         openpose_goldens()
+    elif "--sens-scan-only" in sys.argv:
+        install_reference_imports()
+        sensitivity_scan_goldens()
     elif "--sensitivity-only" in sys.argv:
         install_reference_imports()
         sensitivity_goldens()

@@ -377,6 +377,26 @@ def nearest_bruteforce(verts, faces, queries, chunk=256):
     return ids, pts, bary
 
 
+class ReferenceSearcher:
+    """MeshGridSearcher (utils/mesh_grid_searcher.py:51-84) in the reference's OWN float32 arithmetic: set_mesh's grid + the search of
+    oracle/nearest_ref.c (mesh_grid_kernel.cu:12-109, 239-353, matrix.h).  What the loops of oracle/smplify_oracle.py and the goldens'
+    stand-in searcher (oracle/gen_golden.py) use since round 4; nearest_bruteforce above is the float64 form of the same rule."""
+
+    def __init__(self, verts, faces, fused=False):
+        self.verts = np.ascontiguousarray(verts, np.float32)
+        self.faces = np.ascontiguousarray(faces, np.int32)
+        step, num, origin = grid_params(self.verts)
+        tri_num, tri_idx = insert_grid_surface(self.verts, self.faces, step, origin, num)
+        self.grid = (step, num, origin, tri_num, tri_idx)
+        self.fused = fused
+
+    def nearest(self, queries):
+        """-> (face ids int32[Q], nearest points f32[Q,3], coefficients f32[Q,3])"""
+        from . import nearest_ref as NR
+        ids, pts, coeff, _ = NR.search_nearest(self.verts, self.faces, np.asarray(queries, np.float32).reshape(-1, 3), self.grid, fused=self.fused)
+        return ids, pts, coeff
+
+
 # ----------------------------------------------------------------------------------------------
 # the losses built on the search (torch, differentiable): restated from loss.py / io_utils.py
 # ----------------------------------------------------------------------------------------------

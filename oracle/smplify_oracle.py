@@ -316,6 +316,7 @@ def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=
     if scan is not None:                                                         # smplify.py:146-156
         from oracle import mesh_oracle as MO
         scan_v, scan_f = np.asarray(scan[0], np.float64), np.asarray(scan[1])
+        searcher = MO.ReferenceSearcher(scan[0], scan[1])      # MeshGridSearcher in the reference's own float32 arithmetic (smplify.py:146-148)
         scan_height = float((scan_v.max(0) - scan_v.min(0))[1])
         c = scan_height / 1.7
     mask_in = None
@@ -356,7 +357,7 @@ def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=
             loss = loss + 5 * multview_mask_loss(mask_in[0], mask_in[1], body_vertices[0], mask_in[2], mask_in[3],
                                                  imsize=problem["imsize"], pairwise=mask_pairwise)
         if scan is not None and i > (num_iters // 3):                             # smplify.py:205-210
-            _, cpts, _ = MO.nearest_bruteforce(scan_v, scan_f, body_vertices.detach().numpy()[0])
+            _, cpts, _ = searcher.nearest(body_vertices.detach().numpy()[0])
             pc = MO.point_cloud_loss(body_vertices, torch.as_tensor(cpts, dtype=dtype)) / scan_height * problem["imsize"]
             loss = loss + 5 * pc
         if trace is not None:
@@ -394,7 +395,7 @@ def fit(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snapshots=
         for i in range(num_iters):
             deformed = bv + disp
             norms = MO.compute_normal_torch(deformed[0], faces_t)
-            ids, cpts, _ = MO.nearest_bruteforce(scan_v, scan_f, deformed.detach().numpy()[0])
+            ids, cpts, _ = searcher.nearest(deformed.detach().numpy()[0])
             icp = MO.point_cloud_loss(deformed, torch.as_tensor(cpts, dtype=dtype))
             nl = MO.normal_loss(face_norms[torch.as_tensor(ids, dtype=torch.long)], norms)
             sm = MO.normal_laplacian_smoothness(norms, faces_t)
@@ -452,6 +453,7 @@ def fit_smplx(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snap
     if scan is not None:                                                         # smplify.py:146-156
         from oracle import mesh_oracle as MO
         scan_v, scan_f = np.asarray(scan[0], np.float64), np.asarray(scan[1])
+        searcher = MO.ReferenceSearcher(scan[0], scan[1])      # MeshGridSearcher in the reference's own float32 arithmetic (smplify.py:146-148)
         scan_height = float((scan_v.max(0) - scan_v.min(0))[1])
         c = scan_height / 1.7
     init_pose = torch.as_tensor(problem["init_pose"], dtype=torch.float32).to(dtype)
@@ -481,7 +483,7 @@ def fit_smplx(model, gmm_bufs, problem, num_iters=100, dtype=torch.float32, snap
             loss = loss + 5 * multview_mask_loss(mask_in[0], mask_in[1], bv[0], mask_in[2], mask_in[3], imsize=problem["imsize"],
                                                  pairwise=mask_pairwise)
         if scan is not None and i > (num_iters // 3):                             # smplify.py:205-210
-            _, cpts, _ = MO.nearest_bruteforce(scan_v, scan_f, bv.detach().numpy()[0])
+            _, cpts, _ = searcher.nearest(bv.detach().numpy()[0])
             loss = loss + 5 * (MO.point_cloud_loss(bv, torch.as_tensor(cpts, dtype=dtype)) / scan_height * problem["imsize"])
         opt.zero_grad()
         loss.backward()

@@ -10,8 +10,22 @@ if REPO not in sys.path:
 GOLDEN = os.path.join(REPO, "tests", "golden")
 
 
+FRESH = None      # multiprocessing context whose children are forked from a server started BEFORE this process touched a GPU
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A process that has initialised HIP must not exec another program on the GPU boxes, and a fork of it inherits that state.  The
+    # multi-process GPU test (one rank per process, tests/test_gpu_group.py) therefore gets its children from a fork server that is
+    # started here, at configuration time - before any test has made a HIP call.
+    global FRESH
+    try:
+        import multiprocessing
+        from multiprocessing import forkserver
+        FRESH = multiprocessing.get_context("forkserver")
+        forkserver.ensure_running()
+    except Exception:                                      # (no fork server: the test that needs it skips)
+        FRESH = None
 
 
 @pytest.fixture(scope="session")

@@ -8,6 +8,9 @@ import numpy as np
 from conftest import load_golden
 
 VARIANTS = ("threads8", "ulp")
+# the scan loops have a third perturbation (tests/golden/sens_scan_*.npz, round 4): the closest-point search - whose face ids are decided by
+# last bits - built with the compiler free to fuse multiply-adds, as nvcc's default is for the reference's own build
+SCAN_VARIANTS = VARIANTS + ("fused",)
 K = 3.0                 # band = K x the reference's own drift (the larger of the two perturbations)
 FLOOR = 1e-4            # north star: 1e-4 abs
 

@@ -136,3 +136,43 @@ def test_two_devices_when_the_box_has_them(smpl_model, gmm, job):
         for n in PARAMS:
             np.testing.assert_allclose(got[n], gold[f"it100_{n}"], rtol=0, atol=1e-4, err_msg=f"frame {f} {n}")
     g.close()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_ranks_in_fresh_processes(world, tmp_path, job):
+    """ranks mode end to end, as the benchmark contract launches it: `world` FRESH processes (forked from a server that was started
+    before this process made a HIP call, conftest.FRESH), one GPU each: file rendezvous of the RCCL id, ncclCommInitRank, barrier,
+    max over the ranks, fit of the rank's block of frames, the one all-gather.  Every rank must hold the same gathered parameters,
+    and they must be the bits of one process fitting all frames.  world = 2 runs wherever two devices are visible."""
+    import conftest
+    import ranks_child
+    if conftest.FRESH is None:
+        pytest.skip("no fork server")
+    if _lib.load().bf_device_count() < world:
+        pytest.skip("%d visible device(s)" % _lib.load().bf_device_count())
+    n_frames, n_views, iters = 5, 8, 20
+    pattern = str(tmp_path / "rank%d.npz")
+    procs = [conftest.FRESH.Process(target=ranks_child.rank_main, args=(r, world, str(tmp_path), "pytest-fresh-%d" % world, pattern, n_frames, n_views, iters))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+    for r, p in enumerate(procs):
+        if p.is_alive():
+            p.terminate()
+        err = tmp_path / ("rank%d.npz.err" % r)
+        assert p.exitcode == 0, "rank %d: exit code %s\n%s" % (r, p.exitcode, err.read_text() if err.exists() else "")
+    outs = [np.load(pattern % r) for r in range(world)]
+    model, gmm = S.make_model("smpl", seed=0), S.make_gmm(seed=0)
+    dev = N.DeviceModel(model, gmm, device=0)
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([S.make_problem(model, frame=f, n_views=n_views) for f in range(n_frames)])
+    b = N.FrameBatch(dev, n_frames, n_views)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+    b.fit(iters)
+    want = b.get_params()
+    b.close(); dev.close()
+    for r, o in enumerate(outs):
+        assert int(o["size"]) == world and float(o["top"]) == world - 0.5
+        np.testing.assert_array_equal(o["full"], want, err_msg="rank %d" % r)
+        np.testing.assert_array_equal(o["mine"], want[int(o["lo"]):int(o["hi"])])

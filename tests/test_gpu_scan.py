@@ -131,17 +131,162 @@ def test_nearest_points_match_bruteforce_rule(small, spread):
     ids_o, pts_o, bary_o = MO.nearest_bruteforce(sv, sf, q)
     d = np.linalg.norm(pts - q, axis=1)
     d_o = np.linalg.norm(pts_o - q, axis=1)
-    np.testing.assert_allclose(d, d_o, rtol=2e-5, atol=2e-6)          # same distance (ties may pick another face)
+    if spread < 1.0:
+        np.testing.assert_allclose(d, d_o, rtol=2e-5, atol=2e-6)      # same distance (ties may pick another face)
+    else:
+        # metres outside the grid the walk keeps the reference's shell limit (mesh_grid_kernel.cu:254-257: one layer of cells short on
+        # the far side, tests/test_nearest_ref_oracle.py): a per cent of such queries answer with a face ~1 % farther than the argmin
+        short = ~np.isclose(d, d_o, rtol=2e-5, atol=2e-6)
+        assert short.mean() < 0.02 and np.all(d[short] > d_o[short]) and np.all(d[short] < 1.03 * d_o[short])
+        ids, pts, bary, ids_o, pts_o, bary_o, d, d_o, q = (x[~short] for x in (ids, pts, bary, ids_o, pts_o, bary_o, d, d_o, q))
     # (on a closed surface the closest point of a far query is often a mesh vertex or an edge, shared by several faces: they
     #  tie in exact arithmetic and the float32 distances through different triangles decide in the last bit)
     same = ids == ids_o
     assert same.mean() > 0.8
-    tol = 5e-6 * max(1.0, float(d_o.max()))                          # fp32 offsets relative to the query
+    # fp32 offsets relative to the query; metres away the reference's own arithmetic (Gram entries ~d^2 in float32 against edges of
+    # centimetres) moves a coefficient more than the float64 rule's rounding does: the point to 1e-5 of the distance there
+    tol = (5e-6 if spread < 1.0 else 1e-5) * max(1.0, float(d_o.max()))
     np.testing.assert_allclose(pts[same], pts_o[same], atol=tol)
-    np.testing.assert_allclose(bary[same], bary_o[same], atol=2e-4 * max(1.0, float(d_o.max())))
+    np.testing.assert_allclose(bary[same], bary_o[same], atol=(2e-4 if spread < 1.0 else 5e-4) * max(1.0, float(d_o.max())))
     np.testing.assert_allclose(bary.sum(1), 1.0, atol=1e-5)
     # the returned point really is that barycentric combination of that face
     np.testing.assert_allclose(np.einsum("qi,qik->qk", bary, sv[sf[ids]]), pts, atol=tol)
+    scan.close()
+
+
+def _against_reference_arithmetic(verts, faces, queries, allow_far_quirk=False):
+    """bf_scan_nearest (default rule) against oracle/nearest_ref.c - the reference's search in its own float32 arithmetic.
+    -> (n queries, n exact ties, n decisions that differ); asserts points / coefficients bit for bit wherever the faces agree"""
+    from oracle import nearest_ref as NR
+    verts = np.ascontiguousarray(verts, np.float32); faces = np.ascontiguousarray(faces, np.int32); queries = np.ascontiguousarray(queries, np.float32)
+    scan = N.Scan(verts, faces)
+    pts, ids, bary = scan.nearest_points(queries)
+    dims, origin, step = scan.grid_info()
+    tri_num, tri_idx = scan.grid_lists()
+    scan.close()
+    f_o, p_o, c_o, d_o = NR.search_nearest(verts, faces, queries, (step, dims, origin, tri_num, tri_idx))
+    differ = np.nonzero(ids != f_o)[0]
+    ties = 0
+    if len(differ):
+        _, d_mine, _ = NR.rule(verts, faces, ids[differ], queries[differ])          # the reference's rule on the face the kernel chose
+        tie = d_mine.view(np.uint32) == d_o[differ].view(np.uint32)
+        ties = int(tie.sum())
+        assert tie.all(), "the kernel picked a face the reference's arithmetic ranks strictly behind its own, %d times (gap %.3g)" % (
+            (~tie).sum(), float(((d_mine - d_o[differ]) / d_o[differ])[~tie].max()))
+    same = ids == f_o
+    assert (pts[same].view(np.uint32) == p_o[same].view(np.uint32)).all()
+    assert (bary[same].view(np.uint32) == c_o[same].view(np.uint32)).all()
+    return len(queries), ties, len(differ) - ties
+
+
+@pytest.mark.parametrize("spread", [0.002, 0.02, 0.3, 3.0])
+def test_nearest_equals_the_references_own_arithmetic(small, spread):
+    """face ids equal to the reference's float32 arithmetic (oracle/nearest_ref.c = mesh_grid_kernel.cu:12-109, 239-353 + matrix.h,
+    the latter pinned bit for bit to the reference's header) except where several faces return the SAME distance bit for bit - the
+    reference's own answer then hangs on the order an atomicCAS race left in its lists; points and coefficients bit for bit.
+    Near, far, and metres outside the grid (where the reference's shell limit stops one layer short, kept)."""
+    model, _ = small
+    _, sv, sf = S.make_scan_problem(model, 1)
+    rng = np.random.default_rng(21)
+    q = (sv[rng.integers(0, len(sv), 3000)] + rng.normal(0, spread, (3000, 3))).astype(np.float32)
+    n, ties, wrong = _against_reference_arithmetic(sv, sf, q)
+    print("spread %g: %d queries, %d exact ties resolved the other way, %d decisions that differ" % (spread, n, ties, wrong))
+    assert wrong == 0 and ties < 0.2 * n
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.1, 0.01, 0.001])
+def test_nearest_equals_the_references_own_arithmetic_on_slivers(scale):
+    """needles, slivers and obtuse triangles with edges from a metre down to a millimetre, queries in every Voronoi region and none
+    dropped for being close to a branch decision: at the small scales the reference's absolute 1e-9 rank tests fire (solve4 drops a
+    pivot and answers with a point on the long edge, tests/test_nearest_ref_oracle.py) - the kernel's general routines take those
+    triangles and give the reference's answer, bit for bit"""
+    from oracle import adversarial as ADV
+    d = ADV.soup(seed=0, min_margin=0.0)
+    v = (d["verts"].astype(np.float64) * scale).astype(np.float32)
+    q = (d["queries"].astype(np.float64) * scale).astype(np.float32)
+    n, ties, wrong = _against_reference_arithmetic(v, d["faces"], q)
+    assert wrong == 0 and ties == 0                                      # (isolated triangles: nothing ties)
+    # how many of these patches the straight-line paths decline (the second kernel's share)
+    lib = N._lib.load()
+    tri = v[d["faces"][d["owner"]]] - q[:, None, :]
+    patches = np.ascontiguousarray(tri.reshape(-1, 9), np.float32)
+    dist = np.empty(len(patches), np.float32); coeff = np.empty((len(patches), 3), np.float32)
+    N._lib.check(lib.bf_nearest_selftest_rule(0, len(patches), N._lib.fptr(patches), 0, N._lib.fptr(dist), N._lib.fptr(coeff)), "selftest_rule")
+    declined = float((dist < 0).mean())
+    print("scale %g: the regular paths decline %.1f %% of the soup's patches" % (scale, 100 * declined))
+    # (at scale 1 the queries are up to three units away: Gram entries above 1 put the border row's 1 out of the first pivot's place)
+    assert declined > 0.2 if scale <= 0.01 else declined < 0.3
+
+
+def test_rule_on_the_device_equals_the_oracle_patch_by_patch():
+    """search_nearest_proj on explicit patches: regular, degenerate (repeated corners, collinear), far (Gram entries above 1) and
+    tiny ones; distance and coefficients bit for bit against oracle/nearest_ref.c"""
+    from oracle import nearest_ref as NR
+    rng = np.random.default_rng(8)
+    tri = rng.normal(size=(60000, 3, 3))
+    tri[:10000] *= 0.01; tri[10000:20000] *= 1e-3; tri[20000:30000] *= 3.0; tri[30000:40000] *= 1e-4
+    tri[40000:45000, 2] = tri[40000:45000, 1]                                          # a repeated corner
+    t = rng.random((5000, 1)); tri[45000:50000, 2] = tri[45000:50000, 0] * t + tri[45000:50000, 1] * (1 - t)   # collinear
+    tri[50000:55000] = tri[50000:55000] * 1e-2 + rng.normal(size=(5000, 1, 3)) * 2.0    # small triangle, far query
+    tri[55000:] = np.round(tri[55000:] * 4) / 4                                       # dyadic: exact ties inside the rule
+    q = np.zeros((len(tri), 3), np.float32)
+    verts = tri.reshape(-1, 3).astype(np.float32)
+    faces = np.arange(len(verts), dtype=np.int32).reshape(-1, 3)
+    c_o, d_o, path = NR.rule(verts, faces, np.arange(len(tri)), q)
+    lib = N._lib.load()
+    patches = np.ascontiguousarray(verts.reshape(-1, 9))
+    dist = np.empty(len(patches), np.float32); coeff = np.empty((len(patches), 3), np.float32)
+    N._lib.check(lib.bf_nearest_selftest_rule(0, len(patches), N._lib.fptr(patches), 1, N._lib.fptr(dist), N._lib.fptr(coeff)), "selftest_rule")
+    ok = ((dist.view(np.uint32) == d_o.view(np.uint32)) | (np.isnan(dist) & np.isnan(d_o))) & \
+         ((coeff.view(np.uint32) == c_o.view(np.uint32)) | (np.isnan(coeff) & np.isnan(c_o))).all(1)
+    assert ok.all(), "device rule differs from the oracle on %d patches (branches %s)" % ((~ok).sum(), np.unique(path[~ok]))
+    assert len(np.unique(path)) >= 5                                                    # face, both edge kinds, clamped, the (.5, .5) fallback
+    N._lib.check(lib.bf_nearest_selftest_rule(0, len(patches), N._lib.fptr(patches), 0, N._lib.fptr(dist), N._lib.fptr(coeff)), "selftest_rule")
+    reg = dist >= 0
+    assert 0.3 < reg.mean() < 0.9 and (dist[reg].view(np.uint32) == d_o[reg].view(np.uint32)).all()
+
+
+def test_division_helper_is_ieee_division():
+    """nearest_rule_ref.h's quot / recip (reciprocal refined once, quotient twice, no range scaling) against numpy's correctly rounded
+    float32 division over the range the regular paths use it in: 1e-8 < |d| < 4, quotients up to 2^90, plus zeros and exact cases"""
+    rng = np.random.default_rng(4)
+    n = 1 << 24
+    lib = N._lib.load()
+    bad = 0
+    for rep in range(4):
+        den = (10.0 ** rng.uniform(-8, 0.6, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+        num = (10.0 ** rng.uniform(-20, 19, n) * rng.choice([-1.0, 1.0], n)).astype(np.float32)
+        num[::97] = 0.0
+        num[1::101] = (den[1::101].astype(np.float64) * rng.integers(1, 1 << 12, len(den[1::101]))).astype(np.float32)      # near-exact quotients
+        num[2::103] = np.nextafter(num[2::103], np.float32(0))
+        keep = np.abs(num.astype(np.float64) / den) < 2.0 ** 90
+        num, den = np.ascontiguousarray(num[keep]), np.ascontiguousarray(den[keep])
+        out = np.empty(len(num), np.float32)
+        N._lib.check(lib.bf_nearest_selftest_quot(0, len(num), N._lib.fptr(num), N._lib.fptr(den), N._lib.fptr(out)), "selftest_quot")
+        bad += int((out.view(np.uint32) != (num / den).view(np.uint32)).sum())
+    assert bad == 0
+
+
+def test_fast_rule_is_still_there_and_close(small):
+    """BF_NEAREST_FAST: the 2 x 2 normal equations with v_rcp_f32 - same distances to float32 noise, another face on a few per cent of
+    shared edges (DESIGN 2.3 has the rates at config 5's size)"""
+    model, _ = small
+    _, sv, sf = S.make_scan_problem(model, 1)
+    rng = np.random.default_rng(22)
+    q = (sv[rng.integers(0, len(sv), 3000)] + rng.normal(0, 0.02, (3000, 3))).astype(np.float32)
+    scan = N.Scan(sv, sf)
+    ref = scan.nearest_points(q)
+    before = N.set_nearest_rule("fast")
+    try:
+        fast = scan.nearest_points(q)
+    finally:
+        N.set_nearest_rule(before)
+    assert before == "reference"
+    d_r, d_f = np.linalg.norm(ref[0] - q, axis=1), np.linalg.norm(fast[0] - q, axis=1)
+    np.testing.assert_allclose(d_f, d_r, rtol=2e-5, atol=2e-6)
+    assert 0.8 < np.mean(ref[1] == fast[1]) < 1.0
+    again = scan.nearest_points(q)
+    np.testing.assert_array_equal(again[1], ref[1])
     scan.close()
 
 
@@ -210,6 +355,11 @@ def test_nearest_at_config5_size_against_bruteforce():
     again = scan.nearest_points(q)
     np.testing.assert_array_equal(again[1], ids)                    # deterministic
     scan.close()
+    # and EVERY query against the reference's own float32 arithmetic (the grid walk of oracle/nearest_ref.c): faces equal outside
+    # exact ties, points and coefficients bit for bit
+    n, ties, wrong = _against_reference_arithmetic(sv, sf, q)
+    print("config 5 size: %d queries, %d exact ties resolved the other way, %d decisions that differ" % (n, ties, wrong))
+    assert wrong == 0 and ties < 0.1 * n
 
 
 def test_nearest_points_backward_matches_autograd(small):
@@ -268,7 +418,7 @@ def _disp_metrics(model, sv, sf, base, disp):
     pieces: distribution of point-to-scan distances, the icp term, normal and laplacian energies"""
     import torch
     P = (base + disp).astype(np.float32)
-    ids, cp, _ = MO.nearest_bruteforce(sv, sf, P)
+    ids, cp, _ = MO.ReferenceSearcher(sv, sf).nearest(P)
     d = np.linalg.norm(P - cp, axis=1)
     faces_t = torch.as_tensor(np.asarray(model["faces"]), dtype=torch.long)
     norms = MO.compute_normal_torch(torch.tensor(P, dtype=torch.float64), faces_t)
@@ -289,14 +439,15 @@ def test_config5_iteration_counts_end_state_against_the_reference(small):
     import ref_drift as RD
     model, dev = small
     g = load_golden("scan_nv690_300it.npz")
-    # the reference's own drift over the same 300 + 300 iterations (8 threads instead of 1; initial pose moved by one ulp)
+    # the reference's own drift over the same 300 + 300 iterations (8 threads instead of 1; initial pose moved by one ulp; the
+    # closest-point search built with fused multiply-adds)
     sens = load_golden("sens_scan_nv690_300it.npz")
-    band = {k: RD.band(g, sens, [f"it{k}_{n}" for n in PARAMS]) for k in (100, 101, 300)}
+    band = {k: RD.band(g, sens, [f"it{k}_{n}" for n in PARAMS], variants=RD.SCAN_VARIANTS) for k in (100, 101, 300)}
     print("bands = 3 x the reference's own drift:", band)
 
     def rel_band(metric_of, ref_value, floor=0.05):
         """K x how far the reference's perturbed runs end from the reference in this metric (relative), at least `floor`"""
-        return max(floor, RD.K * max(abs(metric_of(v) - ref_value) for v in RD.VARIANTS) / abs(ref_value))
+        return max(floor, RD.K * max(abs(metric_of(v) - ref_value) for v in RD.SCAN_VARIANTS) / abs(ref_value))
     prob, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
     scan = N.Scan(sv, sf)
     c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
@@ -315,15 +466,15 @@ def test_config5_iteration_counts_end_state_against_the_reference(small):
         assert drift < band[k], (k, drift, band[k])
     assert band[100] < 2e-4 and band[101] < 1e-3                   # (the keypoint-only third is well conditioned in the reference too)
     verts, joints, _, _ = b.get_result()
-    np.testing.assert_allclose(verts[0], g["vertices"], atol=RD.band(g, sens, ["vertices"]))
-    np.testing.assert_allclose(joints[0], g["joints"], atol=RD.band(g, sens, ["joints"]))
+    np.testing.assert_allclose(verts[0], g["vertices"], atol=RD.band(g, sens, ["vertices"], variants=RD.SCAN_VARIANTS))
+    np.testing.assert_allclose(joints[0], g["joints"], atol=RD.band(g, sens, ["joints"], variants=RD.SCAN_VARIANTS))
     fit_ref = _disp_metrics(model, sv, sf, g["vertices"], 0 * g["vertices"])
     fit_got = _disp_metrics(model, sv, sf, verts[0], 0 * verts[0])
     print("scan loop end state  reference:", fit_ref, "\n                     HIP:      ", fit_got)
     # the closest-point term is ~10 % of the objective (keypoint terms ~2,400, 5 * imsize / height * icp ~270), so the distance
     # distribution is a soft quantity of the end state (held within a factor of two: rebuilds of the kernels that only changed an
     # fma contraction moved the mean between +16 % and +30 % of the reference's); the objective itself is held within 5 %
-    fit_var = {v: _disp_metrics(model, sv, sf, sens[f"{v}_vertices"], 0 * sens[f"{v}_vertices"]) for v in RD.VARIANTS}
+    fit_var = {v: _disp_metrics(model, sv, sf, sens[f"{v}_vertices"], 0 * sens[f"{v}_vertices"]) for v in RD.SCAN_VARIANTS}
     print("                     reference, perturbed:", fit_var)
     for key in ("mean", "median", "p95", "icp"):
         tol = rel_band(lambda v: fit_var[v][key], fit_ref[key])
@@ -332,7 +483,7 @@ def test_config5_iteration_counts_end_state_against_the_reference(small):
     params_got = b.get_params()
     obj = {}
     cases = [("reference", N.pack_params({n: g[f"it300_{n}"] for n in PARAMS})[None], fit_ref["icp"]), ("HIP", params_got, fit_got["icp"])]
-    cases += [(v, N.pack_params({n: sens[f"{v}_it300_{n}"] for n in PARAMS})[None], fit_var[v]["icp"]) for v in RD.VARIANTS]
+    cases += [(v, N.pack_params({n: sens[f"{v}_it300_{n}"] for n in PARAMS})[None], fit_var[v]["icp"]) for v in RD.SCAN_VARIANTS]
     for name, pk, icp in cases:
         probe = N.FrameBatch(dev, 1, 8)
         probe.set_cameras(c2w, K); probe.set_keypoints(kp, ndiv); probe.set_init(betas, pose); probe.set_scans([scan])   # (constant scale = height / 1.7)
@@ -349,12 +500,14 @@ def test_config5_iteration_counts_end_state_against_the_reference(small):
     before = _disp_metrics(model, sv, sf, g["vertices"], 0 * g["displacement"])
     got = _disp_metrics(model, sv, sf, verts[0], disp)
     print("SMPL+D end state  reference:", want, "\n                  HIP:      ", got, "\n                  before:   ", before)
-    disp_var = {v: _disp_metrics(model, sv, sf, sens[f"{v}_vertices"], sens[f"{v}_displacement"]) for v in RD.VARIANTS}
+    disp_var = {v: _disp_metrics(model, sv, sf, sens[f"{v}_vertices"], sens[f"{v}_displacement"]) for v in RD.SCAN_VARIANTS}
     print("                  reference, perturbed:", disp_var)
     for key in ("mean", "median", "p95", "icp", "laplacian", "normal"):
         tol = rel_band(lambda v: disp_var[v][key], want[key], floor=0.1)
         assert abs(got[key] - want[key]) / abs(want[key]) < tol, (key, got[key], want[key], tol)
-    assert got["mean"] < 0.6 * before["mean"] and got["median"] < 0.4 * before["median"]
+    # (the stage is chaotic: eight HIP runs of it - both closest-point rules, the initial pose nudged by 0..3 ulp, tools/diag_disp.py -
+    #  end with means of 2.08 .. 3.06 mm, icp 0.10 .. 0.21 and one to three vertices 31 .. 146 mm off; the median is the robust figure)
+    assert got["mean"] < 0.75 * before["mean"] and got["median"] < 0.4 * before["median"]
     assert np.abs(disp).max() < 2 * np.abs(g["displacement"]).max()
     b.close()
     scan.close()
@@ -409,7 +562,7 @@ def test_displacement_stage_first_steps(small, gmm_bufs):
     bv = torch.tensor(base, dtype=torch.float64)
     disp = torch.zeros_like(bv, requires_grad=True)
     faces_t = torch.as_tensor(np.asarray(model["faces"]), dtype=torch.long)
-    ids, cpts, _ = MO.nearest_bruteforce(sv, sf, base)
+    ids, cpts, _ = MO.ReferenceSearcher(sv, sf).nearest(base)              # (face ids feed the normal term: the reference's arithmetic)
     tris = sv.astype(np.float64)[sf]
     fnorm = torch.tensor(np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0]).astype(np.float32), dtype=torch.float64)
     P = bv + disp

@@ -182,6 +182,6 @@ def test_adversarial_soup_rule_never_closer_than_exact():
     d_exact = MO.closest_exact(tri[:, 0] - q, tri[:, 1] - q, tri[:, 2] - q)
     x = np.einsum("ni,nik->nk", c.astype(np.float64), tri) - q        # the point the coefficients name
     d_point = (x * x).sum(1)
-    assert (d_point >= d_exact * (1 - 1e-4) - 1e-9).all()
+    assert (d_point >= d_exact * (1 - 1e-3) - 1e-9).all()          # (float32 coefficients: a sliver's point sits 3e-4 off the triangle)
     regular = np.array([d["kind"][o] in ("regular", "right") for o in d["owner"]])
     np.testing.assert_allclose(dist[regular], d_exact[regular], rtol=2e-4, atol=1e-6)
