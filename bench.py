@@ -25,6 +25,7 @@ The K-step bracket (barrier + device sync on both sides, max over ranks) is repe
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -122,15 +123,26 @@ def run_steps(job, steps, iters, flags, finish=None, feed=None):
 
 
 def timed_brackets(job, steps, warmup, iters, flags, repeats, barrier, finish=None, reduce_max=lambda x: x, feed=None):
-    """W untimed steps, then `repeats` brackets of exactly K steps: barrier + device sync | K steps (+ the gather) | barrier."""
+    """W untimed steps, then `repeats` brackets of exactly K steps: barrier + device sync | K steps (+ the gather) | barrier.
+    The cyclic garbage collector is off inside the brackets (a generation-2 pass over the synthetic models' objects is 10 - 30 ms: one
+    of those inside a 9 ms bracket was the 3 - 8 x outlier of rounds 2 - 3) and runs between them."""
     run_steps(job, warmup, iters, flags, finish, feed)
     walls, last = [], None
-    for _ in range(repeats):
-        barrier()
-        t0 = time.perf_counter()
-        last = run_steps(job, steps, iters, flags, finish, feed)
-        barrier()
-        walls.append(reduce_max(time.perf_counter() - t0))
+    was_on = gc.isenabled()
+    try:
+        for _ in range(repeats):
+            gc.collect()
+            gc.disable()
+            barrier()
+            t0 = time.perf_counter()
+            last = run_steps(job, steps, iters, flags, finish, feed)
+            barrier()
+            walls.append(reduce_max(time.perf_counter() - t0))
+            if was_on:
+                gc.enable()
+    finally:
+        if was_on:
+            gc.enable()
     return walls, last
 
 
@@ -442,7 +454,20 @@ def main():
 
     stream = not a.resident and not a.dense
     feed = FrameFeed(model, feed_lo, feed_hi, a.views, max(2, a.frame_sets)) if stream else None
-    walls, gathered = timed_brackets(job, a.steps, a.warmup, a.iters, flags, a.repeats, barrier, finish, reduce_max, feed)
+    # every frame set of the feed goes through the staging path once before the W warm-up steps (first touch of its pages by the
+    # copy into pinned memory), untimed like the pre-warm above; and a bracket shorter than ~50 ms is repeated more often - with the
+    # driver's --steps 20 a bracket is 9 ms, and one scheduler hiccup is then the whole bracket: the median of 11 does not flip on one
+    if feed is not None:
+        run_steps(job, len(feed.sets), a.iters, flags, None, feed)
+        job.sync()
+    est = None
+    repeats = a.repeats
+    if a.repeats < 11:
+        t0 = time.perf_counter(); run_steps(job, 3, a.iters, flags, None, feed); job.sync(); est = (time.perf_counter() - t0) / 3
+        est = reduce_max(est)                              # (ranks mode: every rank must take the same decision - the brackets hold barriers)
+        if est * a.steps < 0.05:
+            repeats = 11
+    walls, gathered = timed_brackets(job, a.steps, a.warmup, a.iters, flags, repeats, barrier, finish, reduce_max, feed)
     wall = statistics.median(walls)
 
     # sanity: the timed path really produced a fit (and the gather really carried every GPU's frames)
@@ -472,6 +497,14 @@ def main():
     mesh_ms = ev["mesh_ms"] / max(ev["calls"], 1)
     traffic = pmc_traffic() or {}
     fit_traffic = traffic.get("bf_fit_kernel_bytes_per_launch")
+    span = None
+    if F == 1 and mode == "single":
+        try:
+            span = batch.mesh_span(100)                    # the kernel's own duration, measured inside it (no event record, no launch gap)
+        except _lib.BodyfitError:
+            span = None
+    if span:
+        mesh_ms = span["mean_us"] * 1e-3
     how = {"single": "1 GPU", "group": f"frames sharded over {n_gpus} GPUs driven by one process (bf_group: ncclCommInitAll), one RCCL all-gather "
                                        f"of the fitted parameters per job",
            "ranks": f"frames sharded over {n_gpus} GPUs, one process per GPU (bf_comm: ncclCommInitRank, id exchanged through the file system), "
@@ -519,8 +552,11 @@ def main():
             "frac": BYTES_MESH_LAUNCH * F / (mesh_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if mesh_ms > 0 else None,
             "traffic": traffic.get("bf_mesh_kernel_bytes_per_launch"), "avg_launch_ms": mesh_ms,
             "algorithmic_bytes_per_launch": BYTES_MESH_LAUNCH * F,
-            "note": "avg_launch_ms is the HIP-event bracket around a ~6 us kernel and includes the record overhead; rocprofv3 "
-                    "--kernel-trace gives the kernel alone (profiles/)",
+            "launch_us_min_max": [span["min_us"], span["max_us"]] if span else None,
+            "note": ("avg_launch_ms = first workgroup's start to last workgroup's end on the device's 100 MHz clock, 100 launches "
+                     "(bf_batch_mesh_span): the kernel alone, comparable with rocprofv3 --kernel-trace (profiles/)") if span else
+                    ("avg_launch_ms is the HIP-event bracket around a ~6 us kernel and includes the record overhead; rocprofv3 "
+                     "--kernel-trace gives the kernel alone (profiles/)"),
         },
         "device_ms_per_step": {k: ev[k] / max(ev["calls"], 1) for k in ("fit_ms", "mesh_ms", "tail_ms", "total_ms")},
     }

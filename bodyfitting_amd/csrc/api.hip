@@ -4,6 +4,7 @@
 extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
 extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *, const float *, int *, int);
+extern "C" __global__ void bf_mesh_span_kernel(MeshTab, const float *, float *, float *, float *, unsigned long long *);
 extern "C" int bf_mesh_use_multi(int npf, int n);
 extern "C" int bf_mesh_multi_launch(const MeshTab *, const float *, int, float *, float *, float *, float *, float *, hipStream_t, const MaskProj *, int *, int);
 extern "C" __global__ void bf_mesh_epilogue_kernel(MeshTab, const float *, const float *, float *, float *, float *, float *);
@@ -1084,10 +1085,21 @@ static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t fl
         FrameIO io2 = bf_frame_io(b, false);
         io2.params0 = b->params0.p;                  // re-arm inside the fit kernel
         HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream));
+        // A batch that fills the machine (a frame's workgroup per CU, one workgroup fits per CU): under the NEXT fit the mesh kernels
+        // would only get the CUs that fit's workgroups leave as they finish - measured 379 us for a 33 us GEMM at 256 frames.  The mesh
+        // then goes on the fit's own stream, ahead of the next fit (0.462 + 0.074 ms instead of 0.601); only the copy stays aside.
+        static const int n_cus = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+        const bool crowded = b->F >= n_cus;
+        if (crowded) {
+            rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
+            if (rc) return rc;
+        }
         HIP_TRY(hipEventRecord(b->ev_done[k], b->stream));
         HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_done[k], 0));
-        rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->copy_stream, nullptr, nullptr);
-        if (rc) return rc;
+        if (!crowded) {
+            rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->copy_stream, nullptr, nullptr);
+            if (rc) return rc;
+        }
         if (big_fetch) {
             HIP_TRY(hipMemcpyAsync(k ? b->h_res_b : b->h_res, k ? b->res_b.p : b->res.p, b->res.n * fb, hipMemcpyDeviceToHost, b->copy_stream));
         } else {
@@ -1281,6 +1293,34 @@ int bf_batch_timing_sum(bf_batch *b, float ms[4], int32_t *n_calls) {
     }
     for (int k = 0; k < 4; ++k) ms[k] = (float)acc[k];
     *n_calls = n;
+    return BF_OK;
+}
+
+/* The full-mesh forward's OWN duration (bench.py's roofline_mesh): `reps` launches of the single-frame kernel on frame 0's pose state, each
+ * leaving first-workgroup-start .. last-workgroup-end on the device's 100 MHz wall clock - no event record, no launch gap in the figure.
+ * us[0..2] = mean / min / max in microseconds.  Single-frame SMPL-sized models only (the kernel bf_fit uses there). */
+int bf_batch_mesh_span(bf_batch *b, int reps, float us[3]) {
+    if (!b || reps <= 0 || !us) return fail(BF_ERR_INVALID, "bf_batch_mesh_span: bad argument");
+    bf_model *m = b->m;
+    if (bf_mesh_use_multi(m->npf, 1)) return fail(BF_ERR_UNSUPPORTED, "bf_batch_mesh_span: this model's single-frame forward is bf_mesh_multi_kernel");
+    HIP_TRY(hipSetDevice(m->device));
+    { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
+    DevBuf<unsigned long long> d_span;
+    HIP_TRY(d_span.alloc(2));
+    double sum = 0.0, lo = 1e30, hi = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        const unsigned long long init[2] = {~0ull, 0ull};
+        HIP_TRY(hipMemcpy(d_span.p, init, sizeof init, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(bf_mesh_span_kernel, dim3(m->mesh.n_tiles, 1), dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, b->stream, m->mesh,
+                           (const float *)b->state.p, b->vraw.p, b->vout.p, b->xpart.p, d_span.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        unsigned long long got[2];
+        HIP_TRY(hipMemcpy(got, d_span.p, sizeof got, hipMemcpyDeviceToHost));
+        const double t = (double)(got[1] - got[0]) * 0.01;          // 100 MHz ticks -> us
+        sum += t; lo = std::min(lo, t); hi = std::max(hi, t);
+    }
+    us[0] = (float)(sum / reps); us[1] = (float)lo; us[2] = (float)hi;
     return BF_OK;
 }
 

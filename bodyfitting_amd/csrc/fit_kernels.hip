@@ -884,22 +884,30 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     static_assert(BF_VSUB * 32 * 4 >= BF_POSE_STATE_LDS, "the view-sum slots are the pose-state scratch");
     // Between phase A and the rest of an iteration (called by EVERY thread: it synchronises): publish that state, then wait for the
     // outside gradient blocks the dense kernels make of it and stage them in LDS.
-    auto door_mid = [&](int it, const float *P) {
+    // `works` = false: the GMM waves - 150 pinned precision registers and nothing to spare: taking row slices of the record and of the
+    // staging made their loop spill 24 - 31 registers in every iteration of the dense instances (128 - 176 B of scratch per lane on the
+    // resident launch's critical path) - only keep the barriers; the four geometry waves copy (plain copies: the same bits).
+    auto door_mid = [&](int it, const float *P, auto works) {
 #ifdef BF_STAMP
         bf_d0 = clock64();
 #endif
-        // (wave 3 left the rotations, chain matrices and joints of the state in the scratch during phase A: everybody writes the record)
-        bf_pose_state_emit<true>(T, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nt, S.part, nullptr, P, true);
+        constexpr int nw = BF_FIT_THREADS / 2;
+        // (wave 3 left the rotations, chain matrices and joints of the state in the scratch during phase A: the geometry waves write the record)
+        if constexpr (decltype(works)::value) bf_pose_state_emit<true>(T, nullptr, io.state, io.params, io.cscale, hp.cscale, frame, tid, nw, S.part, nullptr, P, true);
         __syncthreads();                                       // the record's stores have reached the XCD's L2
-        if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // one device-scope release (L2 write-back) for the workgroup
-        BF_DMARK(56);
-        if (tid < BF_DOOR_COPIES) __hip_atomic_fetch_add(door + BF_DOOR_STATE + tid * BF_DOOR_COPY_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) bf_door_wait(door, BF_DOOR_EXT, it + 1);
-        BF_DMARK(57);
+        if constexpr (decltype(works)::value) {
+            if (wave == 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");        // one device-scope release (L2 write-back) for the workgroup
+            BF_DMARK(56);
+            if (tid < BF_DOOR_COPIES) __hip_atomic_fetch_add(door + BF_DOOR_STATE + tid * BF_DOOR_COPY_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) bf_door_wait(door, BF_DOOR_EXT, it + 1);
+            BF_DMARK(57);
+        }
         __syncthreads();
         // (the blocks were read through this CU's caches an iteration ago: device-scope loads go past them, no invalidate)
-        float *eg = const_cast<float *>(io.ext) + (size_t)frame * n_ext;
-        for (int i = tid; i < n_ext; i += nt) S.ext[i] = __hip_atomic_load(eg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (decltype(works)::value) {
+            float *eg = const_cast<float *>(io.ext) + (size_t)frame * n_ext;
+            for (int i = tid; i < n_ext; i += nw) S.ext[i] = __hip_atomic_load(eg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         BF_DMARK(58);
     };
@@ -959,7 +967,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 BF_GMM_CHUNK(2)
             }
             BF_SYNC();                 // A
-            if (EXT && door) door_mid(it, Pcur);
+            if (EXT && door) door_mid(it, Pcur, std::false_type());
             if (!merge_bc) {           // (two-phase pose blend: everybody takes row slices)
                 pose_blend(std::integral_constant<int, 2>());
                 if (!NO_VERT) BF_SYNC();             // B
@@ -1181,7 +1189,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             bf_pose_chain_row(nj, T.n_levels, wave, lane, S.part, S.par, S.lvl + nj + 67);
         }
         BF_SYNC();
-        if (EXT && door) door_mid(it, Pcur);
+        if (EXT && door) door_mid(it, Pcur, std::true_type());
 
         if (merge_bc) {
             // ================= phase B (+C): pose blend and skinning of the selector vertices in one phase

@@ -52,9 +52,13 @@ bf_pose_state_kernel(FitTab T, const float *__restrict__ betas, const float *__r
 // slice by row-group 2), so the kernel pays one memory round trip instead of one per phase.
 #define BF_MESH_PF 26      // posedirs rows prefetched per thread (= ceil(207 / 8) for SMPL); more are streamed
 #define BF_MESH_WPF 24     // lbs weights prefetched per vertex thread
-extern "C" __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
-bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ vraw, float *__restrict__ vout,
-               float *__restrict__ xpart, float *__restrict__ vposed, const float *__restrict__ pose_off, int *door, int door_target) {
+// (SPAN: the instance bf_batch_mesh_span launches - every workgroup leaves its start and end on the 100 MHz wall clock in span[0]
+//  (minimum) / span[1] (maximum): the kernel's own duration, with no event record or launch gap in it)
+template <bool SPAN>
+__device__ __forceinline__ void bf_mesh_body(const MeshTab &M, const float *__restrict__ state, float *__restrict__ vraw, float *__restrict__ vout,
+               float *__restrict__ xpart, float *__restrict__ vposed, const float *__restrict__ pose_off, int *door, int door_target,
+               unsigned long long *span) {
+    const unsigned long long t_begin = SPAN ? (unsigned long long)wall_clock64() : 0ull;
     constexpr int COLS = BF_MESH_TILE * 3;
     extern __shared__ __align__(16) float sm[];
     const int nj = M.nj, nb = M.nb, npf = M.npf, nv = M.nv;
@@ -190,6 +194,20 @@ bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ v
             xpart[((size_t)frame * gridDim.x + tile) * ne3 + col] = a3;
         }
     }
+    if (SPAN) {
+        __syncthreads();                                   // (the workgroup's stores are issued; the clock is read after them)
+        if (tid == 0) { atomicMin(span, t_begin); atomicMax(span + 1, (unsigned long long)wall_clock64()); }
+    }
+}
+extern "C" __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
+bf_mesh_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ vraw, float *__restrict__ vout,
+               float *__restrict__ xpart, float *__restrict__ vposed, const float *__restrict__ pose_off, int *door, int door_target) {
+    bf_mesh_body<false>(M, state, vraw, vout, xpart, vposed, pose_off, door, door_target, nullptr);
+}
+extern "C" __global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
+bf_mesh_span_kernel(MeshTab M, const float *__restrict__ state, float *__restrict__ vraw, float *__restrict__ vout,
+                    float *__restrict__ xpart, unsigned long long *span) {
+    bf_mesh_body<true>(M, state, vraw, vout, xpart, nullptr, nullptr, nullptr, 0, span);
 }
 
 // Small batches (2..15 frames) and models whose pose feature is longer than the 8 x BF_MESH_PF rows the kernel above

@@ -393,6 +393,12 @@ class FrameBatch:
         return {"fit_ms": float(ms[0]), "mesh_ms": float(ms[1]), "tail_ms": float(ms[2]), "total_ms": float(ms[3]),
                 "calls": int(n.value)}
 
+    def mesh_span(self, reps=50):
+        """the single-frame full-mesh forward's own duration, measured inside the kernel -> {"mean_us", "min_us", "max_us"}"""
+        us = np.zeros(3, np.float32)
+        _lib.check(self._lib.bf_batch_mesh_span(self._h, int(reps), _lib.fptr(us)), "bf_batch_mesh_span")
+        return {"mean_us": float(us[0]), "min_us": float(us[1]), "max_us": float(us[2])}
+
     def debug_dump(self, n):
         out = np.zeros(n, np.float32)
         _lib.check(self._lib.bf_batch_debug_dump(self._h, _lib.fptr(out), int(n)), "bf_batch_debug_dump")

@@ -377,6 +377,11 @@ int bf_batch_last_timing(bf_batch *b, float ms[4]);
  * *n_calls receives how many were summed. */
 int bf_batch_timing_reset(bf_batch *b);
 int bf_batch_timing_sum(bf_batch *b, float ms[4], int32_t *n_calls);
+/* Duration of the single-frame full-mesh forward (bf_mesh_kernel, the HBM-bound kernel of the keypoint-only path) measured INSIDE the
+ * kernel: first workgroup's start to last workgroup's end on the device's 100 MHz clock, `reps` launches on frame 0's current pose state;
+ * us[3] = mean, min, max in microseconds.  What bench.py's roofline_mesh divides the kernel's algorithmic bytes by (an event bracket
+ * around a 6 us kernel is half record overhead).  SMPL-sized models. */
+int bf_batch_mesh_span(bf_batch *b, int reps, float us[3]);
 
 /* ---- test hooks (bring-up / parity tests only; not part of the drop-in surface) ----------------------------------
  * first-iteration intermediates of frame 0 written by the last bf_loss_grad launch (layout: tests/gpu_debug.py) */
