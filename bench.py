@@ -301,15 +301,24 @@ def main_dense(a):
         else:
             barrier, finish, reduce_max = batch.sync, None, (lambda x: x)
     job.set_cameras(c2w, K); job.set_keypoints(kp, ndiv); job.set_init(betas, pose)
-    live = {"scans": None}
+    live = {"scans": None, "next": None}
     parts = {"upload_s": 0.0, "fit_s": 0.0, "disp_s": 0.0, "n": 0}
+
+    def make_scans():
+        return [N.Scan(sv, sf, device=device_of(i)) for i, (sv, sf) in enumerate(scans_host)]     # upload + grid build on the device
 
     def step(timed_parts=False):
         t0 = time.perf_counter()
         if cfg == 3:
             job.set_masks(masks, mask_frames, None)                      # upload + contour extraction on the device(s)
         else:
-            new = [N.Scan(sv, sf, device=device_of(i)) for i, (sv, sf) in enumerate(scans_host)]     # upload + grid build on the device
+            # this step's scans: built at the end of the previous step, under its fit and SMPL+D stage (the frame loop of a capture knows
+            # its next frame; a scan's device buffers come from the library's block cache, so building one does not wait for the device)
+            new = live["next"] if live["next"] is not None and not timed_parts else make_scans()
+            if new is not live["next"] and live["next"] is not None:
+                for sc in live["next"]:
+                    sc.close()
+            live["next"] = None
             job.set_scans(new)
             if live["scans"]:
                 for sc in live["scans"]:
@@ -322,6 +331,8 @@ def main_dense(a):
             job.sync(); t2 = time.perf_counter()
         if cfg == 5:
             job.fit_displacement(iters)
+            if not timed_parts:
+                live["next"] = make_scans()                              # the NEXT step's scans, while this step runs on the device
         if timed_parts:
             job.sync(); t3 = time.perf_counter()
             parts["upload_s"] += t1 - t0; parts["fit_s"] += t2 - t1; parts["disp_s"] += t3 - t2; parts["n"] += 1
@@ -380,7 +391,7 @@ def main_dense(a):
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if live["scans"]:
         job.set_scans(None)
-        for sc in live["scans"]:
+        for sc in live["scans"] + (live["next"] or []):
             sc.close()
     if comm is not None:
         comm.barrier(); comm.rendezvous.cleanup(); comm.close()
@@ -602,6 +613,28 @@ def main():
                                                "ms_per_step_host_issued": wh / n * 1e3, "ms_per_step_graph": wgm / n * 1e3,
                                                "device_fit_ms": e["fit_ms"] / e["calls"], "device_mesh_ms": e["mesh_ms"] / e["calls"]}
                 bb.close()
+            # the table-driven instance of the fit kernel (fit_kernel<0,0,0,0,false>): what a model gets whose selector vertices have more
+            # than 4 bones - here the same model with a fifth, small weight on its 11 selector vertices
+            try:
+                m5 = dict(model)
+                w = np.array(model["lbs_weights"], np.float32).copy()
+                for v in np.asarray(model["selector_ids"])[:11]:
+                    j = int(np.argmax(w[v])); k = int(np.argmin(w[v]))
+                    w[v, j] -= 0.05; w[v, k] += 0.05
+                    assert (w[v] > 0).sum() >= 5
+                m5["lbs_weights"] = w
+                dev5 = N.DeviceModel(m5, gmm, device=local)
+                b5 = build_batch(dev5, m5, [0], a.views)
+                w5, _ = timed_brackets(b5, a.steps, 3, a.iters, _lib.FIT_FETCH | _lib.FIT_NOTIME, 3, b5.sync)
+                e5 = event_leg(b5, max(10, a.steps // 4), a.iters, _lib.FIT_FETCH)
+                wm5 = statistics.median(w5)
+                extra["table_driven_instance"] = {"value": a.steps / wm5, "unit": "frames/s", "ms_per_step": wm5 / a.steps * 1e3,
+                                                  "device_fit_ms": e5["fit_ms"] / e5["calls"],
+                                                  "cycles_per_iteration": e5["fit_ms"] / e5["calls"] * 1e-3 * ENGINE_CLOCK_GHZ * 1e9 / a.iters,
+                                                  "note": "inputs resident; 5 bones on the selector vertices -> the instance without compile-time sizes"}
+                b5.close(); dev5.close()
+            except Exception as exc:
+                extra["table_driven_instance_error"] = repr(exc)
             # the dense-loss configurations of BASELINE.json (3 and 5 as stated) on this GPU: tools/bench_configs.py
             if not a.no_configs:
                 try:

@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -30,13 +31,66 @@ inline hipError_t bf_memset_sync(void *p, int value, size_t bytes) {
     hipError_t e = hipMemset(p, value, bytes);
     return e == hipSuccess ? hipStreamSynchronize(nullptr) : e;
 }
+// A cache of freed device blocks per device (bf_pool_alloc / bf_pool_free), for objects that come and go with every frame of a
+// capture: a scan is created, attached, fitted against and destroyed once per frame (apps/genebody_fitting.py:183-192), and every
+// hipFree waits for the whole device - i.e. for the fit of the PREVIOUS frame that is still running - while a hipMalloc of a fresh
+// block costs tens of microseconds.  A block is handed out again for a request of its size up to 25 % smaller; the cache holds at
+// most 2 GB per device (beyond that a block is really freed).  The caller guarantees what hipFree used to: nothing on the device
+// still uses a block it gives back (bf_scan_destroy waits for the device itself when the scan is still attached to a batch).
+struct BfPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> blocks[16];
+    size_t held[16] = {0};
+};
+inline BfPool &bf_pool() { static BfPool P; return P; }
+inline hipError_t bf_pool_alloc(void **p, size_t bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (dev >= 0 && dev < 16) {
+        BfPool &P = bf_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.blocks[dev].lower_bound(bytes);
+        if (it != P.blocks[dev].end() && it->first <= bytes + bytes / 4 + 4096) {
+            *p = it->second;
+            P.held[dev] -= it->first;
+            P.blocks[dev].erase(it);
+            return hipSuccess;
+        }
+    }
+    return hipMalloc(p, bytes);
+}
+// `bytes`: what the block was asked for (the same rounding happens here)
+inline void bf_pool_free(void *p, size_t bytes, int dev) {
+    if (!p) return;
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (dev >= 0 && dev < 16) {
+        BfPool &P = bf_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (P.held[dev] + bytes <= ((size_t)2 << 30)) { P.blocks[dev].emplace(bytes, p); P.held[dev] += bytes; return; }
+    }
+    (void)hipFree(p);
+}
 inline int bf_alloc_index() { static std::atomic<int> counter{0}; return counter++; }      // (of this translation unit's allocations, all types; bf_group's workers allocate side by side)
 template <class T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
     bool view = false;          // a slice of another allocation: not freed here
+    int pool_dev = -1;          // >= 0: the block came from (and goes back to) bf_pool of that device
+    size_t pool_bytes = 0;
     void slice(T *base, size_t count) { p = base; n = count; view = true; }
+    hipError_t alloc_pooled(size_t count) {       // for buffers of per-frame objects (see BfPool); contents undefined
+        n = count;
+        pool_bytes = std::max<size_t>(count, 1) * sizeof(T);
+        (void)hipGetDevice(&pool_dev);
+        return bf_pool_alloc((void **)&p, pool_bytes);
+    }
+    hipError_t upload_pooled(const T *h, size_t count) {
+        hipError_t e = alloc_pooled(count);
+        if (e != hipSuccess) return e;
+        return count == 0 ? hipSuccess : hipMemcpy(p, h, count * sizeof(T), hipMemcpyHostToDevice);
+    }
     hipError_t alloc(size_t count) {
         n = count;
         hipError_t e = hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T));
@@ -58,8 +112,9 @@ struct DevBuf {
         if (e != hipSuccess) return e;
         return h.empty() ? hipSuccess : hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     }
-    void release() { if (p && !view) (void)hipFree(p); p = nullptr; n = 0; view = false; }
-    ~DevBuf() { if (p && !view) (void)hipFree(p); }
+    void drop() { if (p && !view) { if (pool_dev >= 0) bf_pool_free(p, pool_bytes, pool_dev); else (void)hipFree(p); } }
+    void release() { drop(); p = nullptr; n = 0; view = false; pool_dev = -1; }
+    ~DevBuf() { drop(); }
 };
 
 // Scratch of the MFMA batch path of the full-mesh forward (>= BF_MFMA_MIN_FRAMES frames).  Owned by whoever owns the stream
@@ -212,6 +267,7 @@ struct bf_batch {
 
 struct bf_scan {
     int device = 0, nv = 0, nf = 0, n_entries = 0;
+    int attached = 0;               // batches that hold this scan (bf_batch_set_scans): destroying it then waits for the device first
     ScanDev dev{};
     DevBuf<float> verts, face_norms;
     DevBuf<int> faces, cell_start, cell_tris;

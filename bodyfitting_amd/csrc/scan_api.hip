@@ -75,10 +75,11 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
     auto *s = new bf_scan();
     s->device = device; s->nv = n_verts; s->nf = n_faces;
     DevBuf<int> cursor, tris_raw;
-    bool ok = s->verts.upload(std::vector<float>(verts, verts + (size_t)n_verts * 3)) == hipSuccess &&
-              s->faces.upload(std::vector<int>(faces, faces + (size_t)n_faces * 3)) == hipSuccess &&
-              s->cell_start.alloc(ncell + 1) == hipSuccess && cursor.alloc(ncell + 1) == hipSuccess &&
-              s->face_norms.alloc((size_t)n_faces * 3) == hipSuccess;
+    // (every device buffer of a scan and of its construction comes from the block cache: a capture makes one scan per frame)
+    bool ok = s->verts.upload_pooled(verts, (size_t)n_verts * 3) == hipSuccess &&
+              s->faces.upload_pooled(faces, (size_t)n_faces * 3) == hipSuccess &&
+              s->cell_start.alloc_pooled(ncell + 1) == hipSuccess && cursor.alloc_pooled(ncell + 1) == hipSuccess &&
+              s->face_norms.alloc_pooled((size_t)n_faces * 3) == hipSuccess;
     if (!ok) { delete s; return fail(BF_ERR_HIP, "bf_scan_create: device allocation failed"); }
     ScanDev &d = s->dev;
     d.nv = n_verts; d.nf = n_faces; d.nx = num[0]; d.ny = num[1]; d.nz = num[2];
@@ -97,8 +98,8 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
     }
     if (e == hipSuccess) e = hipMemcpy(&total, s->cell_start.p + ncell, sizeof(int), hipMemcpyDeviceToHost);   // (syncs)
     if (e == hipSuccess && total > 0) {
-        ok = tris_raw.alloc(total) == hipSuccess && s->cell_tris.alloc(total) == hipSuccess &&
-             s->cell_pack.alloc((size_t)total * 12) == hipSuccess;
+        ok = tris_raw.alloc_pooled(total) == hipSuccess && s->cell_tris.alloc_pooled(total) == hipSuccess &&
+             s->cell_pack.alloc_pooled((size_t)total * 12) == hipSuccess;
         if (!ok) { delete s; return fail(BF_ERR_HIP, "bf_scan_create: device allocation failed (cell lists)"); }
         d.cell_tris = s->cell_tris.p;
         d.cell_pack = (const float4 *)s->cell_pack.p;
@@ -114,7 +115,13 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
     return BF_OK;
 }
 
-void bf_scan_destroy(bf_scan *s) { delete s; }
+void bf_scan_destroy(bf_scan *s) {
+    if (!s) return;
+    // the scan's blocks go back to the cache without the device-wide wait a hipFree implies; a scan that a batch still holds may
+    // be in use by queued work: wait for the device then, as hipFree would have
+    if (s->attached > 0) { (void)hipSetDevice(s->device); (void)hipDeviceSynchronize(); }
+    delete s;
+}
 float bf_scan_height(const bf_scan *s) { return s ? s->dev.height : 0.f; }
 
 int bf_scan_grid_info(const bf_scan *s, int32_t dims[3], float origin_step[4]) {
@@ -277,6 +284,7 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
     HIP_TRY(hipSetDevice(b->m->device));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (!scans) {                                  // detach
+        for (bf_scan *old : b->scans) if (old) --old->attached;
         b->scans.clear();
         if (b->cscale.p) { (void)hipFree(b->cscale.p); b->cscale.p = nullptr; }
         return BF_OK;
@@ -288,12 +296,15 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
         dev[f] = scans[f]->dev;
         cs[f] = scans[f]->dev.height / 1.7f;
     }
+    for (bf_scan *old : b->scans) if (old) --old->attached;
     b->scans.assign(scans, scans + b->F);
+    for (bf_scan *sc : b->scans) ++sc->attached;
     b->cface_valid = false;
-    if (b->scan_dev.p) { (void)hipFree(b->scan_dev.p); b->scan_dev.p = nullptr; }
-    if (b->cscale.p) { (void)hipFree(b->cscale.p); b->cscale.p = nullptr; }
-    HIP_TRY(b->scan_dev.upload(dev));
-    HIP_TRY(b->cscale.upload(cs));
+    // (a capture attaches new scans every frame: the two small tables are written in place - a hipFree waits for the whole device)
+    if (b->scan_dev.p && b->scan_dev.n == dev.size()) HIP_TRY(hipMemcpy(b->scan_dev.p, dev.data(), dev.size() * sizeof(ScanDev), hipMemcpyHostToDevice));
+    else { b->scan_dev.release(); HIP_TRY(b->scan_dev.upload(dev)); }
+    if (b->cscale.p && b->cscale.n == cs.size()) HIP_TRY(hipMemcpy(b->cscale.p, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
+    else { b->cscale.release(); HIP_TRY(b->cscale.upload(cs)); }
     return bf_ensure_dense_buffers(b);
 }
 
@@ -691,12 +702,26 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
                        const int32_t *contour_count, const float *contour_xy, int contour_select) {
     if (!b || contour_select < 0 || contour_select > 2) return fail(BF_ERR_INVALID, "bf_batch_set_masks: null batch / bad contour_select");
     HIP_TRY(hipSetDevice(b->m->device));
+    if (n_masks > 0 && masks) {
+        if (!view_index || (contour_count && !contour_xy) || H <= 0 || W <= 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: bad argument");
+        for (int i = 0; i < n_masks; ++i)
+            if (view_index[i] < 0 || view_index[i] >= b->V) return fail(BF_ERR_INVALID, "bf_batch_set_masks: view index out of range");
+        // The host's share - binarising 2 MB per frame (smplify.py:139) into the pinned staging buffer - happens BEFORE the wait for the
+        // work in flight: in a frame loop that is the previous frame's fit, and the buffer is free (its last upload, ev_masks, went out
+        // early in that fit).
+        const size_t npix0 = (size_t)b->F * n_masks * H * W;
+        if (b->ev_masks) HIP_TRY(hipEventSynchronize(b->ev_masks));
+        if (b->h_masks_n < npix0) {
+            if (b->h_masks) (void)hipHostFree(b->h_masks);
+            b->h_masks = nullptr;
+            HIP_TRY(hipHostMalloc((void **)&b->h_masks, npix0));
+            b->h_masks_n = npix0;
+        }
+        for (size_t i = 0; i < npix0; ++i) b->h_masks[i] = masks[i] > 128;
+    }
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (n_masks <= 0 || !masks) { b->has_masks = false; b->masks_pending = false; return BF_OK; }   // (bf_sync_all above drained a deferred extraction)
-    if (!view_index || (contour_count && !contour_xy) || H <= 0 || W <= 0) return fail(BF_ERR_INVALID, "bf_batch_set_masks: bad argument");
     const int F = b->F, nv = b->m->nv;
-    for (int i = 0; i < n_masks; ++i)
-        if (view_index[i] < 0 || view_index[i] >= b->V) return fail(BF_ERR_INVALID, "bf_batch_set_masks: view index out of range");
     // (a frame loop hands over new masks of the same shape every frame: device buffers are kept and only grown - a dozen hipFree /
     //  hipMalloc pairs cost more than the contour extraction itself)
     auto ensure = [](auto &buf, size_t count) -> hipError_t {
@@ -707,14 +732,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     };
     const size_t npix = (size_t)F * n_masks * H * W, fm = (size_t)F * n_masks;
     const int ns = (nv + 3) / 4, pblocks = (ns + 255) / 256;
-    // binarised (smplify.py:139) straight into pinned staging
-    if (b->h_masks_n < npix) {
-        if (b->h_masks) (void)hipHostFree(b->h_masks);
-        b->h_masks = nullptr;
-        HIP_TRY(hipHostMalloc((void **)&b->h_masks, npix));
-        b->h_masks_n = npix;
-    }
-    for (size_t i = 0; i < npix; ++i) b->h_masks[i] = masks[i] > 128;
+    // (binarised into pinned staging above, before the wait)
     HIP_TRY(ensure(b->mk_masks, npix));
     HIP_TRY(ensure(b->mk_view, n_masks)); HIP_TRY(ensure(b->mk_cstart, fm)); HIP_TRY(ensure(b->mk_ccount, fm));
     HIP_TRY(hipMemcpy(b->mk_view.p, view_index, (size_t)n_masks * sizeof(int), hipMemcpyHostToDevice));

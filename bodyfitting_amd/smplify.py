@@ -154,15 +154,19 @@ class SMPLify:
                 "global_orient": p["global_orient"].copy(), "faces": self.smpl_faces[0], "global_transl": p["global_transl"] * p["scale"],
                 "scale": p["scale"].copy(), "full_pose": full_pose_f}
 
-    def stream(self, frames, c2ws, Ks, use_frames=None, imsize=512):
-        """The frame loop of apps/genebody_fitting.py:183-192 for ONE capture (fixed cameras, keypoint-only, SMPL): `frames`
-        yields (net_output, keypoints) per frame - what BodyFitting hands `SMPLify.__call__` - and the results come back in
-        order, as a generator, one frame behind: frame i+1's inputs are uploaded and its fit is issued before frame i's result is
-        read, so uploads, fits and downloads of consecutive frames overlap (bf_batch_stage_inputs / bf_batch_get_previous).
-        Each result equals `__call__`'s for that frame bit for bit."""
+    def stream(self, frames, c2ws, Ks, use_frames=None, imsize=512, mask_frames=None, displacement=False):
+        """The frame loop of apps/genebody_fitting.py:183-192 for ONE capture (fixed cameras): `frames` yields per frame what
+        BodyFitting hands `SMPLify.__call__` - `(net_output, keypoints)`, or `(net_output, keypoints, masks)` /
+        `(net_output, keypoints, masks, meshfile)` with `masks` the silhouettes of the views `mask_frames` (None: no silhouette loss
+        for that frame) and `meshfile` a scan OBJ (None: no scan) - and the results come back in order, as a generator, one frame
+        behind: what `__call__` returns for that frame, bit for bit.
+
+        Keypoint-only SMPL: frame i+1's inputs are uploaded and its fit is issued before frame i's result is read, so uploads, fits
+        and downloads of consecutive frames overlap (bf_batch_stage_inputs / bf_batch_get_previous).  SMPL-X and the dense losses:
+        frame i+1's host work (keypoint packing, OBJ parsing) and its scan's upload and grids happen while frame i is being fitted
+        (a scan's device buffers come from the library's block cache, so building one does not wait for the device); the
+        silhouettes go up with the frame's own keypoint-only iterations (bf_batch_set_masks defers the contour extraction)."""
         from . import _lib
-        if self.use_hand_face:
-            raise NotImplementedError("stream(): the two-deep frame pipeline covers the keypoint-only SMPL path")
         V = len(c2ws) if use_frames is None else len(use_frames)
         c2w = np.stack([_np(c) for c in c2ws[:V]]).astype(np.float32)[None]
         K = np.stack([_np(k) for k in Ks[:V]]).astype(np.float32)[None]
@@ -173,26 +177,93 @@ class SMPLify:
             batch.clear_masks(); batch._had_masks = False
         batch.set_cameras(c2w, K)
         batch._cams = None
-        hyper = make_hyper(imsize=imsize, constant_scale=0.3)
-        flags = _lib.FIT_RESET | _lib.FIT_FETCH | _lib.FIT_NOTIME
         nl = self._dev.n_loss_joints
-        issued = 0
-        for net_output, keypoints in frames:
-            betas, poses = (_np(x) for x in net_output)
+        mk_idx = None if mask_frames is None else [list(use_frames if use_frames is not None else range(V)).index(f) for f in mask_frames]
+
+        def pack(keypoints):
             kp = np.zeros((1, V, nl, 3), np.float32)
             for i in range(V):
                 if keypoints[i] is not None:
-                    kp[0, i] = np.asarray(keypoints[i]["pose"], np.float32)[:nl]
-            batch.stage_inputs(kp, [V], betas[:1], poses[:1])
-            batch.fit(self.num_iters, hyper, flags)
-            issued += 1
-            if issued > 1:
-                params, verts, joints, full_pose, _ = batch.get_previous()
+                    kp[0, i] = pack_keypoints_smplx(keypoints[i]) if self.use_hand_face else np.asarray(keypoints[i]["pose"], np.float32)[:nl]
+            return kp
+
+        frames = iter(frames)
+        first = next(frames, None)
+        if first is None:
+            return
+        dense = self.use_hand_face or len(first) > 2 or displacement
+        import itertools
+        frames = itertools.chain([first], frames)
+        if not dense:
+            hyper = make_hyper(imsize=imsize, constant_scale=0.3)
+            flags = _lib.FIT_RESET | _lib.FIT_FETCH | _lib.FIT_NOTIME
+            issued = 0
+            for net_output, keypoints in frames:
+                betas, poses = (_np(x) for x in net_output)
+                batch.stage_inputs(pack(keypoints), [V], betas[:1], poses[:1])
+                batch.fit(self.num_iters, hyper, flags)
+                issued += 1
+                if issued > 1:
+                    params, verts, joints, full_pose, _ = batch.get_previous()
+                    yield self._result_dict(params[0], verts[0], joints[0], full_pose[0])
+            if issued:
+                params = batch.get_params()
+                verts, joints, full_pose, _ = batch.get_result()
                 yield self._result_dict(params[0], verts[0], joints[0], full_pose[0])
-        if issued:
+            return
+
+        # ---- SMPL-X / silhouettes / scans: one fit in flight, the next frame prepared under it
+        in_flight = None                      # (device scan or None, wants displacement)
+
+        def collect(state):
+            scan, with_disp = state
             params = batch.get_params()
             verts, joints, full_pose, _ = batch.get_result()
-            yield self._result_dict(params[0], verts[0], joints[0], full_pose[0])
+            res = self._result_dict(params[0], verts[0], joints[0], full_pose[0])
+            p = split_params(params[0], self._dev.n_joints, self._dev.n_betas)
+            res.update({k: p[k].copy() for k in ("leye_pose", "reye_pose", "left_hand_pose", "right_hand_pose") if k in p})
+            if with_disp:
+                batch.fit_displacement(self.num_iters, state_hyper[0])
+                res["displacement"] = batch.get_displacement()[0]
+            if scan is not None:
+                batch.set_scans(None); batch._had_scans = False
+                scan.close()
+            return res
+
+        state_hyper = [None]
+        try:
+            for item in frames:
+                net_output, keypoints = item[0], item[1]
+                masks = item[2] if len(item) > 2 else None
+                meshfile = item[3] if len(item) > 3 else None
+                betas, poses = (_np(x) for x in net_output)
+                kp = pack(keypoints)
+                scan = cscale = None
+                if meshfile is not None:      # (parsed, uploaded and indexed while the previous frame's fit runs)
+                    sv, sf = load_obj_mesh(meshfile)
+                    scan = Scan(sv.astype(np.float32), sf.astype(np.int32), device=self.device)
+                mk = None if masks is None else np.stack([np.asarray(m) for m in masks]).astype(np.uint8)[None]
+                if in_flight is not None:
+                    yield collect(in_flight)
+                    in_flight = None
+                if scan is not None:
+                    batch.set_scans([scan]); batch._had_scans = True
+                if mk is not None:
+                    batch.set_masks(mk, mk_idx, None); batch._had_masks = True
+                elif batch._had_masks:
+                    batch.clear_masks(); batch._had_masks = False
+                hyper = make_hyper(imsize=imsize, constant_scale=0.3)
+                state_hyper[0] = hyper
+                batch.stage_inputs(kp, [V], betas[:1], poses[:1])
+                batch.fit(self.num_iters, hyper, _lib.FIT_RESET | _lib.FIT_FETCH)
+                in_flight = (scan, bool(displacement and scan is not None))
+            if in_flight is not None:
+                yield collect(in_flight)
+                in_flight = None
+        finally:
+            if in_flight is not None and in_flight[0] is not None:      # (the consumer stopped early)
+                batch.set_scans(None); batch._had_scans = False
+                in_flight[0].close()
 
     def __call__(self, net_output, c2ws, Ks, keypoints, output_folder=None, use_mask=False, masks=None,
                  use_frames=[0], mask_frames=[0], keyframe=6, imsize=512, use_mesh=False, meshfile=None,

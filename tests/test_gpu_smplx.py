@@ -305,3 +305,34 @@ def test_staged_inputs_on_the_dense_path(sx):
         np.testing.assert_array_equal(b.get_params(), want[i][0])
         np.testing.assert_array_equal(b.get_result()[0], want[i][1])
     b.close()
+
+
+def test_stream_of_smplx_frames_with_silhouettes_equals_the_call_path(sx, tmp_path):
+    """SMPLify.stream for smpl_type='smplx' with use_mask (and, for one frame, a scan): the capture's frame loop with the next frame
+    prepared under the running fit == SMPLify.__call__ frame by frame, bit for bit (staged inputs + re-arm inside the fit against the
+    synchronous setters; a scan built while another frame's fit is in flight)"""
+    from bodyfitting_amd import assets
+    from bodyfitting_amd.io import save_obj_mesh
+    from bodyfitting_amd.smplify import SMPLify
+    model, _ = sx
+    assets.register_model(model, "smplx", "neutral")
+    assets.register_gmm(S.make_gmm(seed=0))
+    mask_frames = [1, 3, 5, 7]
+    probs = [S.make_problem_smplx(model, frame=f, n_views=8, mask_frames=mask_frames) for f in (0, 2, 1)]
+    _, sv, sf = S.make_scan_problem_smplx(model, 3, n_views=8, subdivide=0)
+    meshfile = str(tmp_path / "scan.obj")
+    save_obj_mesh(meshfile, sv, sf)
+    fitter = SMPLify(smpl_type="smplx", num_iters=24, gender="neutral", device=0, debug=False)
+    p0 = probs[0]
+
+    def items():
+        for i, p in enumerate(probs):
+            yield ((p["init_betas"], p["init_pose"]), p["keypoints"], p["masks"], meshfile if i == 1 else None)
+    streamed = list(fitter.stream(items(), p0["c2ws"], p0["Ks"], use_frames=p0["use_frames"], imsize=512, mask_frames=mask_frames))
+    assert len(streamed) == 3
+    for i, (p, res) in enumerate(zip(probs, streamed)):
+        one = fitter((p["init_betas"], p["init_pose"]), p0["c2ws"], p0["Ks"], p["keypoints"], use_mask=True, masks=p["masks"],
+                     use_frames=p0["use_frames"], mask_frames=mask_frames, imsize=512, use_mesh=(i == 1), meshfile=meshfile if i == 1 else None)
+        for key in ("vertices", "joints", "pose", "betas", "global_orient", "global_transl", "scale", "full_pose", "left_hand_pose", "leye_pose"):
+            assert np.array_equal(res[key], one[key]), (i, key)
+    fitter.close()
