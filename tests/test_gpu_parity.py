@@ -102,10 +102,17 @@ def test_cfg2_fit_matches_reference(dev_model, smpl_model, frame):
     np.testing.assert_allclose(verts[0][::53], g["vertices_sample"], atol=FIT_TOL)
     np.testing.assert_allclose(full_pose[0], g["full_pose"], atol=FIT_TOL)
     p = N.split_params(b.get_params()[0])
-    # rtn_dict's global_transl = t * s (smplify.py:223): a derived quantity - an error dt of the fitted translation arrives as s dt
-    # (s ~ 3.3).  Frame 3's translation is the ill-conditioned one of the four: the float64 analytic oracle itself ends 1.7e-5 from
-    # the float32 reference there (6e-7 on frame 0)
-    np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=FIT_TOL * max(1.0, float(p["scale"][0])))
+    # rtn_dict's global_transl = t * s (smplify.py:223), a field of the result: 1e-4 like everything else on the well-conditioned
+    # frames.  Frame 3's translation is the ill-conditioned one of the four: the float64 analytic oracle itself ends 5.6e-5 from the
+    # float32 reference in this field there (2e-6 on frame 0) - MEASURED here, and the band for that frame is 3 x it
+    if frame != 3:
+        np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=FIT_TOL)
+    else:
+        from oracle import analytic as A
+        want, _, _ = A.fit(smpl_model, S.gmm_buffers(S.make_gmm(seed=0)), prob, 100, dtype=np.float64)
+        oracle_drift = float(np.abs(want["global_transl"] * want["scale"] - g["final_global_transl"]).max())
+        assert 2e-5 < oracle_drift < 2e-4, oracle_drift
+        np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=max(FIT_TOL, 3 * oracle_drift))
     b.close()
 
 
