@@ -79,12 +79,24 @@ def parse():
     return ap.parse_args()
 
 
-def pack(model, frames, n_views):
-    return N.pack_problem([S.make_problem(model, frame=f, n_views=n_views) for f in frames])
+_PROBLEMS = {}
 
 
-def build_batch(dev, model, frames, n_views):
-    c2w, K, kp, ndiv, betas, pose = pack(model, frames, n_views)
+def problem(model, frame, n_views, distinct=None):
+    """synthetic frame `frame` (cached; `distinct`: frames repeat modulo that many - generating one takes 76 ms on the host, and the
+    scaling legs fit up to 2,048 of them)"""
+    key = (id(model), frame if distinct is None else frame % distinct, n_views)
+    if key not in _PROBLEMS:
+        _PROBLEMS[key] = S.make_problem(model, frame=key[1], n_views=n_views)
+    return _PROBLEMS[key]
+
+
+def pack(model, frames, n_views, distinct=None):
+    return N.pack_problem([problem(model, f, n_views, distinct) for f in frames])
+
+
+def build_batch(dev, model, frames, n_views, distinct=None):
+    c2w, K, kp, ndiv, betas, pose = pack(model, frames, n_views, distinct)
     b = N.FrameBatch(dev, len(frames), n_views)
     b.set_cameras(c2w, K)
     b.set_keypoints(kp, ndiv)
@@ -166,13 +178,13 @@ def scaling_legs(mode, model, gmm, dev, n_gpus, rank, views, iters, comm, per_gp
         try:
             if mode == "group":
                 g = shard.Group(model, gmm, n_frames=total, n_views=views, n_devices=n_gpus)
-                c2w, K, kp, ndiv, betas, pose = pack(model, range(total), views)
+                c2w, K, kp, ndiv, betas, pose = pack(model, range(total), views, distinct=64)
                 g.set_cameras(c2w, K); g.set_keypoints(kp, ndiv); g.set_init(betas, pose)
                 w, full = timed_brackets(g, steps, 2, iters, flags, 3, g.sync, g.gather_params)
                 g.close()
             else:
                 lo, hi = shard.shard_range(total, rank, n_gpus)
-                bb = build_batch(dev, model, list(range(lo, hi)), views)
+                bb = build_batch(dev, model, list(range(lo, hi)), views, distinct=64)
                 w, full = timed_brackets(bb, steps, 2, iters, flags, 3, comm.barrier, (lambda: comm.gather_params(bb, total)), comm.max)
                 bb.close()
             assert full.shape[0] == total and np.isfinite(full).all()
@@ -180,7 +192,7 @@ def scaling_legs(mode, model, gmm, dev, n_gpus, rank, views, iters, comm, per_gp
             leg = {"frames_per_gpu": fb, "total_frames": total, "n_gpus": n_gpus, "value": total * steps / wm, "unit": "frames/s",
                    "ms_per_step": wm / steps * 1e3, "ms_per_step_spread": spread([x / steps * 1e3 for x in w])}
             if rank == 0:
-                one = build_batch(dev, model, list(range(total)), views)
+                one = build_batch(dev, model, list(range(total)), views, distinct=64)
                 w1, _ = timed_brackets(one, steps, 2, iters, flags, 3, one.sync)
                 one.close()
                 w1m = statistics.median(w1)
@@ -607,7 +619,7 @@ def main():
             for fb in (32, 256, 1024):
                 if fb == F:
                     continue
-                bb = build_batch(dev, model, list(range(fb)), a.views)
+                bb = build_batch(dev, model, list(range(fb)), a.views, distinct=64)      # (64 distinct frames, repeated: 76 ms of host time per synthetic frame)
                 n = 10
                 e = event_leg(bb, n, a.iters, _lib.FIT_FETCH)                                  # (with events: device times)
                 w, _ = timed_brackets(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_NOTIME, 3, bb.sync)
