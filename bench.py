@@ -313,7 +313,7 @@ def main_dense(a):
         else:
             barrier, finish, reduce_max = batch.sync, None, (lambda x: x)
     job.set_cameras(c2w, K); job.set_keypoints(kp, ndiv); job.set_init(betas, pose)
-    live = {"scans": None, "next": None}
+    live = {"scans": None, "next": None, "masks": False}
     parts = {"upload_s": 0.0, "fit_s": 0.0, "disp_s": 0.0, "n": 0}
 
     def make_scans():
@@ -327,7 +327,13 @@ def main_dense(a):
     def step(timed_parts=False):
         t0 = time.perf_counter()
         if cfg == 3:
-            job.set_masks(masks, mask_frames, None)                      # upload + contour extraction on the device(s)
+            # upload + contour extraction on the device(s): the first step's with the step, the later ones' staged under the fit in
+            # flight (the capture's frame loop knows its next frame's silhouettes: bf_batch_stage_masks)
+            if live["masks"] and not timed_parts:
+                job.stage_masks(masks, mask_frames)
+            else:
+                job.set_masks(masks, mask_frames, None)
+            live["masks"] = True
         else:
             # this step's scans: built at the end of the previous step, under its fit and SMPL+D stage (the frame loop of a capture knows
             # its next frame; a scan's device buffers come from the library's block cache, so building one does not wait for the device)

@@ -91,6 +91,7 @@ SIGNATURES = {
     "bf_nearest_selftest_rule": (C.c_int, [C.c_int, C.c_int, _FP, C.c_int, _FP, _FP]),
     "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
     "bf_batch_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),
+    "bf_batch_stage_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int]),
     "bf_extract_contours": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),
     "bf_batch_mask_loss": (C.c_int, [_VP, C.POINTER(Hyper), _FP, _FP]),
     "bf_fit_displacement": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper)]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "bf_group_set_init": (C.c_int, [_VP, _FP, _FP]),
     "bf_group_stage_inputs": (C.c_int, [_VP, _FP, _IP, _FP, _FP]),
     "bf_group_set_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), _IP, _FP, C.c_int]),
+    "bf_group_stage_masks": (C.c_int, [_VP, C.c_int, _IP, C.c_int, C.c_int, C.POINTER(C.c_uint8), C.c_int]),
     "bf_group_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),
     "bf_group_fit": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper), C.c_uint32]),
     "bf_group_fit_displacement": (C.c_int, [_VP, C.c_int, C.POINTER(Hyper)]),

@@ -698,6 +698,11 @@ void bf_batch_destroy(bf_batch *b) {
     for (float *q : b->mk_retired) (void)hipFree(q);
     if (b->h_ccount) (void)hipHostFree(b->h_ccount);
     if (b->ev_masks) (void)hipEventDestroy(b->ev_masks);
+    if (b->ev_masks_used) (void)hipEventDestroy(b->ev_masks_used);
+    if (b->mk_stage.ev) (void)hipEventDestroy(b->mk_stage.ev);
+    if (b->mk_stage.ev_used) (void)hipEventDestroy(b->mk_stage.ev_used);
+    if (b->mk_stage.h_masks) (void)hipHostFree(b->mk_stage.h_masks);
+    if (b->mk_stage.h_ccount) (void)hipHostFree(b->mk_stage.h_ccount);
     for (int k = 0; k < 2; ++k) {
         if (b->h_in[k]) (void)hipHostFree(b->h_in[k]);
         if (b->ev_in[k]) (void)hipEventDestroy(b->ev_in[k]);
@@ -967,8 +972,13 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (!b || n_iters <= 0) return fail(BF_ERR_INVALID, "bf_fit: bad argument");
     if (b->staged && !(flags & BF_FIT_RESET))
         return fail(BF_ERR_INVALID, "bf_fit: inputs were staged with bf_batch_stage_inputs - the fit of a new frame starts from its initial estimate (BF_FIT_RESET)");
+    bf_masks_commit(b);                       // (silhouettes staged with bf_batch_stage_masks become this fit's)
     int rc = fit_impl(b, n_iters, hyper, flags);
     if (rc) return rc;
+    if (b->has_masks) {                       // (the arena these masks live in may be overwritten once this fit is done)
+        if (!b->ev_masks_used) HIP_TRY(hipEventCreateWithFlags(&b->ev_masks_used, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(b->ev_masks_used, b->stream));
+    }
     b->staged = false;
     if (b->in_host) { HIP_TRY(hipEventRecord(b->ev_in[b->in_cur], b->stream)); b->in_pending[b->in_cur] = true; }   // (zero-copy: this fit read the pinned buffer)
     b->arena_seq[b->cur] = b->fit_seq++;

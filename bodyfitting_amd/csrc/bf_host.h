@@ -254,7 +254,25 @@ struct bf_batch {
     DevBuf<int> mk_cnt2;
     DevBuf<unsigned> mk_planes;         // bit planes of images too large for LDS
     int mk_cap = 0, mk_select = 0;
+    bool mk_on_device = false;          // the attached masks' contours were followed on the device (contour_count = NULL)
     std::vector<float *> mk_retired;    // outgrown buffers a finalize inside a fit could not free
+    // bf_batch_stage_masks: the NEXT frame's silhouettes in an arena of their own (pinned staging, device masks, the contour kernel's
+    // slab and counts), filled on the second stream under the fit in flight; the next bf_fit swaps the two arenas' pointers.
+    struct MaskStage {
+        unsigned char *h_masks = nullptr;
+        size_t h_masks_n = 0, h_ccount_n = 0;
+        int *h_ccount = nullptr;
+        hipEvent_t ev = nullptr;        // the arena's upload + border following have finished
+        hipEvent_t ev_used = nullptr;   // the last fit that read the arena has finished
+        DevBuf<unsigned char> masks;
+        DevBuf<float> slab;
+        DevBuf<int> cnt2;
+        DevBuf<unsigned> planes;
+        int select = 0;
+        bool staged = false;
+    } mk_stage;
+    hipEvent_t ev_masks_used = nullptr; // (the active arena's ev_used)
+    std::vector<int> mk_view_host;      // the view indices the active masks were set with
     DevBuf<int> mk_view, mk_cstart, mk_ccount, mk_choice;
     DevBuf<unsigned char> mk_masks;
     DevBuf<float> mk_cxy, mk_uvi, mk_duvb, mk_cgrad, mk_part, mk_loss, mk_gpart;
@@ -290,6 +308,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
 int bf_dense_loss_grad(bf_batch *b, const bf_hyper &h, const HyperDev &hd, FrameIO io);
 int bf_ensure_dense_buffers(bf_batch *b);
 int bf_masks_finalize(bf_batch *b);      // no-op unless a deferred bf_batch_set_masks is pending
+void bf_masks_commit(bf_batch *b);       // no-op unless bf_batch_stage_masks has staged the next frame's silhouettes
 HyperDev bf_to_dev(const bf_hyper &h);
 int bf_sync_all(bf_batch *b);            // copy stream, then compute stream
 int bf_guard_arena(bf_batch *b);         // the compute stream waits for a fetch still reading the current arena

@@ -360,6 +360,14 @@ int bf_group_set_masks(bf_group *g, int n_masks, const int32_t *view_index, int 
     });
 }
 
+/* bf_batch_stage_masks for the whole job: the next step's masks[F,M,H,W], every device its own block, under the fits in flight */
+int bf_group_stage_masks(bf_group *g, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks, int contour_select) {
+    if (!g || !masks || n_masks <= 0) return fail(BF_ERR_INVALID, "bf_group_stage_masks: bad argument");
+    return run_all(g, [&](bf_group_peer &p) {
+        return bf_batch_stage_masks(p.batch, n_masks, view_index, H, W, masks + (size_t)p.first * n_masks * H * W, contour_select);
+    });
+}
+
 /* bf_batch_set_scans for the whole job: scans[F], scan f created (bf_scan_create) on the device bf_group_shard reports for f's
  * block; NULL detaches */
 int bf_group_set_scans(bf_group *g, bf_scan *const *scans) {

@@ -736,6 +736,8 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     HIP_TRY(ensure(b->mk_masks, npix));
     HIP_TRY(ensure(b->mk_view, n_masks)); HIP_TRY(ensure(b->mk_cstart, fm)); HIP_TRY(ensure(b->mk_ccount, fm));
     HIP_TRY(hipMemcpy(b->mk_view.p, view_index, (size_t)n_masks * sizeof(int), hipMemcpyHostToDevice));
+    b->mk_view_host.assign(view_index, view_index + n_masks);
+    b->mk_stage.staged = false;                              // (masks set synchronously supersede staged ones)
     HIP_TRY(ensure(b->mk_uvi, fm * ns * 4)); HIP_TRY(ensure(b->mk_duvb, fm * ns * 2)); HIP_TRY(ensure(b->mk_gpart, fm * ns * 3));
     HIP_TRY(ensure(b->mk_loss, F));
     MaskIO &K0 = b->mask;
@@ -743,6 +745,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     K0.cdist = 1; K0.sstride = 4; K0.imsize = 512.f; K0.eps = 10.f; K0.weight = 5.f;
     K0.view_index = b->mk_view.p; K0.masks = b->mk_masks.p;
     b->masks_pending = false;
+    b->mk_on_device = !contour_count;
     if (!contour_count) {
         // DEFERRED: upload + border following on the second stream; lengths into pinned memory; bf_masks_finalize does the rest
         if (!b->ev_masks) HIP_TRY(hipEventCreateWithFlags(&b->ev_masks, hipEventDisableTiming));
@@ -803,6 +806,80 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     K.contour_start = b->mk_cstart.p; K.contour_count = b->mk_ccount.p; K.contour_xy = b->mk_cxy.p;
     b->has_masks = true;
     return bf_ensure_dense_buffers(b);
+}
+
+/* The NEXT frame's silhouettes, WITHOUT draining the work in flight (the frame loop of apps/genebody_fitting.py:183-192 hands SMPLify
+ * new masks with every frame): same views and shape as the masks attached with bf_batch_set_masks (contours extracted on the device).
+ * They are binarised into a second pinned buffer, uploaded and border-followed into a second arena on the batch's second stream - under
+ * the fit in flight - and the next bf_fit switches to that arena (bf_masks_commit).  Two-deep like bf_batch_stage_inputs: staging waits
+ * for the fit that last read the arena it overwrites. */
+int bf_batch_stage_masks(bf_batch *b, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks, int contour_select) {
+    if (!b || !view_index || !masks || contour_select < 0 || contour_select > 2) return fail(BF_ERR_INVALID, "bf_batch_stage_masks: bad argument");
+    const MaskIO &K = b->mask;
+    if (!b->has_masks || !b->mk_on_device || K.n_masks != n_masks || K.H != H || K.W != W || (int)b->mk_view_host.size() != n_masks ||
+        !std::equal(view_index, view_index + n_masks, b->mk_view_host.begin()))
+        return fail(BF_ERR_INVALID, "bf_batch_stage_masks: the first frame's masks go through bf_batch_set_masks (device contours); later frames must "
+                                    "keep its views and shape");
+    HIP_TRY(hipSetDevice(b->m->device));
+    bf_batch::MaskStage &S = b->mk_stage;
+    const size_t fm = (size_t)b->F * n_masks, npix = fm * H * W;
+    if (S.ev_used) HIP_TRY(hipEventSynchronize(S.ev_used));          // the fit that read this arena two frames ago
+    if (S.ev) HIP_TRY(hipEventSynchronize(S.ev));
+    if (S.h_masks_n < npix) {
+        if (S.h_masks) (void)hipHostFree(S.h_masks);
+        S.h_masks = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&S.h_masks, npix));
+        S.h_masks_n = npix;
+    }
+    for (size_t i = 0; i < npix; ++i) S.h_masks[i] = masks[i] > 128;
+    if (S.h_ccount_n < 2 * fm) {
+        if (S.h_ccount) (void)hipHostFree(S.h_ccount);
+        S.h_ccount = nullptr;
+        HIP_TRY(hipHostMalloc((void **)&S.h_ccount, 2 * fm * sizeof(int)));
+        S.h_ccount_n = 2 * fm;
+    }
+    const int wpr = (W + 31) / 32;
+    const size_t plane_bytes = (size_t)3 * H * wpr * sizeof(unsigned);
+    const bool in_lds = plane_bytes <= 150 * 1024;
+    // (first use, or the active arena's slab has grown since: fresh blocks - nothing is freed while a fit may be running)
+    auto fresh = [&](auto &buf, size_t count) -> hipError_t {
+        if (buf.p && buf.n >= count) return hipSuccess;
+        if (buf.p) b->mk_retired.push_back((float *)(void *)buf.p);
+        buf.p = nullptr;
+        return buf.alloc(count);
+    };
+    HIP_TRY(fresh(S.masks, npix));
+    HIP_TRY(fresh(S.slab, fm * 2 * (size_t)b->mk_cap * 2));
+    HIP_TRY(fresh(S.cnt2, 2 * fm));
+    if (!in_lds) HIP_TRY(fresh(S.planes, fm * 3 * H * wpr));
+    if (!S.ev) HIP_TRY(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+    S.select = contour_select;
+    hipStream_t cs = b->copy_stream;
+    HIP_TRY(hipMemcpyAsync(S.masks.p, S.h_masks, npix, hipMemcpyHostToDevice, cs));
+    hipLaunchKernelGGL(bf_contour_kernel, dim3((unsigned)fm), dim3(256), in_lds ? plane_bytes : 0, cs, (const unsigned char *)S.masks.p, H, W,
+                       b->mk_cap, contour_select, S.slab.p, S.cnt2.p, in_lds ? (unsigned *)nullptr : S.planes.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(S.h_ccount, S.cnt2.p, 2 * fm * sizeof(int), hipMemcpyDeviceToHost, cs));
+    HIP_TRY(hipEventRecord(S.ev, cs));
+    S.staged = true;
+    return BF_OK;
+}
+
+// bf_fit's first act when masks were staged: the two arenas change places (pointers only; the kernels of the fit still in flight
+// hold the old ones by value) and the contours are pending again (bf_masks_finalize).
+void bf_masks_commit(bf_batch *b) {
+    bf_batch::MaskStage &S = b->mk_stage;
+    if (!S.staged) return;
+    S.staged = false;
+    auto swap_buf = [](auto &x, auto &y) { std::swap(x.p, y.p); std::swap(x.n, y.n); };
+    std::swap(b->h_masks, S.h_masks); std::swap(b->h_masks_n, S.h_masks_n);
+    std::swap(b->h_ccount, S.h_ccount); std::swap(b->h_ccount_n, S.h_ccount_n);
+    std::swap(b->ev_masks, S.ev); std::swap(b->ev_masks_used, S.ev_used);
+    swap_buf(b->mk_masks, S.masks); swap_buf(b->mk_slab, S.slab); swap_buf(b->mk_cnt2, S.cnt2); swap_buf(b->mk_planes, S.planes);
+    std::swap(b->mk_select, S.select);
+    b->mask.masks = b->mk_masks.p;
+    b->mask.cmax = 1; b->mask.part_stride = b->mask.proj_blocks + 1;      // (placeholders until finalize, as after bf_batch_set_masks)
+    b->masks_pending = true;
 }
 
 // The second half of a deferred bf_batch_set_masks: wait (host) for the border following on the second stream, then size and fill

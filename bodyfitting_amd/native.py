@@ -302,6 +302,16 @@ class FrameBatch:
         xy = _f32(np.concatenate(flat, 0)) if sum(len(c) for c in flat) else np.zeros((1, 2), np.float32)
         _lib.check(self._lib.bf_batch_set_masks(self._h, M, _lib.iptr(vi), H, W, mp, _lib.iptr(counts), _lib.fptr(xy), 0), "bf_batch_set_masks")
 
+    def stage_masks(self, masks, view_index, contour_select=_lib.CONTOUR_OPENCV_FIRST):
+        """the NEXT frame's masks (same views and shape as the ones attached with set_masks(contours=None)): uploaded and
+        border-followed under the fit in flight, used by the next fit()"""
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        F, M, H, W = masks.shape
+        assert F == self.F
+        vi = _i32(view_index)
+        _lib.check(self._lib.bf_batch_stage_masks(self._h, M, _lib.iptr(vi), H, W, masks.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                  int(contour_select)), "bf_batch_stage_masks")
+
     def clear_masks(self):
         """detach the silhouettes (use_mask=False for the next fit)"""
         _lib.check(self._lib.bf_batch_set_masks(self._h, 0, None, 0, 0, None, None, None, 0), "bf_batch_set_masks")

@@ -162,6 +162,15 @@ class Group:
         p = _f32(np.asarray(init_pose).reshape(self.F, -1)[:, :72], (self.F, 72))
         _lib.check(self._lib.bf_group_stage_inputs(self._h, _lib.fptr(kp), _lib.iptr(nd), _lib.fptr(b), _lib.fptr(p)), "bf_group_stage_inputs")
 
+    def stage_masks(self, masks, view_index, contour_select=_lib.CONTOUR_OPENCV_FIRST):
+        """the next step's masks[F,M,H,W] (views and shape of the attached ones), every device its block, under the fits in flight"""
+        masks = np.ascontiguousarray(masks, dtype=np.uint8)
+        F, M, H, W = masks.shape
+        assert F == self.F
+        vi = _i32(view_index)
+        _lib.check(self._lib.bf_group_stage_masks(self._h, int(M), _lib.iptr(vi), int(H), int(W), masks.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                  int(contour_select)), "bf_group_stage_masks")
+
     def set_masks(self, masks, view_index, contours=None, contour_select=_lib.CONTOUR_OPENCV_FIRST):
         """masks[F,M,H,W] uint8 of the whole job; contours = per (frame, mask view) arrays of (x, y) points, or None = extracted
         on the devices (bf_group_set_masks hands every device its block; the devices work side by side)"""

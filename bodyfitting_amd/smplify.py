@@ -165,7 +165,8 @@ class SMPLify:
         and downloads of consecutive frames overlap (bf_batch_stage_inputs / bf_batch_get_previous).  SMPL-X and the dense losses:
         frame i+1's host work (keypoint packing, OBJ parsing) and its scan's upload and grids happen while frame i is being fitted
         (a scan's device buffers come from the library's block cache, so building one does not wait for the device); the
-        silhouettes go up with the frame's own keypoint-only iterations (bf_batch_set_masks defers the contour extraction)."""
+        first frame's silhouettes go up with its own keypoint-only iterations (bf_batch_set_masks defers the contour extraction), the
+        later frames' under the fit before (bf_batch_stage_masks)."""
         from . import _lib
         V = len(c2ws) if use_frames is None else len(use_frames)
         c2w = np.stack([_np(c) for c in c2ws[:V]]).astype(np.float32)[None]
@@ -231,6 +232,7 @@ class SMPLify:
             return res
 
         state_hyper = [None]
+        mask_shape = None
         try:
             for item in frames:
                 net_output, keypoints = item[0], item[1]
@@ -243,13 +245,20 @@ class SMPLify:
                     sv, sf = load_obj_mesh(meshfile)
                     scan = Scan(sv.astype(np.float32), sf.astype(np.int32), device=self.device)
                 mk = None if masks is None else np.stack([np.asarray(m) for m in masks]).astype(np.uint8)[None]
+                staged = False
+                if mk is not None and in_flight is not None and batch._had_masks and mask_shape == mk.shape:
+                    batch.stage_masks(mk, mk_idx)      # (binarised, uploaded and border-followed under the previous frame's fit)
+                    staged = True
                 if in_flight is not None:
                     yield collect(in_flight)
                     in_flight = None
                 if scan is not None:
                     batch.set_scans([scan]); batch._had_scans = True
-                if mk is not None:
+                if staged:
+                    pass
+                elif mk is not None:
                     batch.set_masks(mk, mk_idx, None); batch._had_masks = True
+                    mask_shape = mk.shape
                 elif batch._had_masks:
                     batch.clear_masks(); batch._had_masks = False
                 hyper = make_hyper(imsize=imsize, constant_scale=0.3)

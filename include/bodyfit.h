@@ -268,6 +268,12 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans);
 #define BF_CONTOUR_LONGEST      2   /* the longest external border (first on ties): the evident intent of loss.py:80 */
 int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
                        const int32_t *contour_count, const float *contour_xy, int contour_select);
+/* The NEXT frame's silhouettes without draining the work in flight (a capture hands SMPLify new masks with every frame,
+ * apps/genebody_fitting.py:183-192; smplify.py:138-144): same views and image shape as the masks attached with bf_batch_set_masks
+ * (contour_count = NULL there: contours on the device).  Binarisation, upload and border following (loss.py:73-83) go into a second
+ * arena, on the batch's second stream, under the fit in flight; the next bf_fit uses them.  Two-deep: the call waits for the fit that
+ * last read the arena it overwrites. */
+int bf_batch_stage_masks(bf_batch *b, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks, int contour_select);
 /* extract_countours (smplify/loss.py:73-83) on its own: masks[n,H,W] uint8 (non-zero = foreground) -> counts[n] and,
  * when xy != NULL, the (x, y) points of the n contours concatenated (sum(counts) pairs; call with xy == NULL first). */
 int bf_extract_contours(int device, int n, int H, int W, const uint8_t *masks, int32_t *counts, float *xy, int select);
@@ -315,6 +321,7 @@ int bf_group_stage_inputs(bf_group *g, const float *keypoints, const int32_t *n_
 /* masks[F,M,H,W] + optional contours of the whole job (bf_batch_set_masks per device; the devices extract their contours side by side) */
 int bf_group_set_masks(bf_group *g, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks,
                        const int32_t *contour_count, const float *contour_xy, int contour_select);
+int bf_group_stage_masks(bf_group *g, int n_masks, const int32_t *view_index, int H, int W, const uint8_t *masks, int contour_select);   /* bf_batch_stage_masks, every device its block */
 /* scans[F]: frame f's scan must have been created on the device of f's block (bf_group_shard); NULL detaches */
 int bf_group_set_scans(bf_group *g, bf_scan *const *scans);
 /* Every device's bf_fit is issued from a host thread of its own (created with the group), so the devices run side by side also

@@ -307,3 +307,70 @@ def test_sixteen_frames_with_masks_take_the_batched_mesh_path(dev_model, smpl_mo
         np.testing.assert_allclose(together[i], b1.get_params()[0], atol=2e-3)      # (one iteration of a discontinuous loss on 2e-6-different meshes)
         b1.close()
     np.testing.assert_array_equal(together[0], together[16])                        # same frame, same batch: same bits
+
+
+def test_staged_masks_equal_masks_set_between_the_fits(dev_model, smpl_model):
+    """bf_batch_stage_masks: the next frame's silhouettes go up and are border-followed while the previous frame's fit is still in
+    flight (no wait for the device in between), two arenas changing places - every frame's fit equals, bit for bit, the one with
+    bf_batch_set_masks called after the previous result was read.  One of the frames is the comb whose border outgrows the slab
+    (the arena is regrown inside that fit and the other arena catches up when it is next staged into)."""
+    from bodyfitting_amd import _lib
+    probs = [S.make_problem(smpl_model, frame=f, n_views=8, mask_frames=MASK_FRAMES) for f in (0, 1, 2, 0, 1)]
+    view_index = [probs[0]["use_frames"].index(f) for f in MASK_FRAMES]
+    frames = []
+    for i, p in enumerate(probs):
+        c2w, K, kp, ndiv, betas, pose = N.pack_problem([p])
+        masks = np.array(p["masks"])[None].copy()
+        if i == 2:
+            H, W = masks.shape[-2:]
+            comb = np.zeros((H, W), np.uint8)
+            comb[H // 8: 7 * H // 8, W // 8: 7 * W // 8: 2] = 255
+            comb[7 * H // 8 - 2: 7 * H // 8, W // 8: 7 * W // 8] = 255
+            masks[0, 1] = comb
+        frames.append((kp, ndiv, betas, pose, masks))
+    hyper = N.make_hyper(dense_after=3)
+    flags = _lib.FIT_RESET | _lib.FIT_FETCH
+
+    def run(staged):
+        b = N.FrameBatch(dev_model, 1, 8)
+        b.set_cameras(c2w, K)
+        out = []
+        for i, (kp, ndiv, betas, pose, masks) in enumerate(frames):
+            if i == 0 or not staged:
+                if i:
+                    out.append(b.get_params().copy())
+                b.set_masks(masks, view_index, None)
+            else:
+                b.stage_masks(masks, view_index)                 # (frame i - 1's fit is in flight)
+                out.append(b.get_params().copy())
+            b.stage_inputs(kp, ndiv, betas, pose)
+            b.fit(9, hyper, flags)
+        out.append(b.get_params().copy())
+        b.close()
+        return out
+    plain, staged = run(False), run(True)
+    for a, c in zip(plain, staged):
+        np.testing.assert_array_equal(a, c)
+    assert not np.array_equal(plain[0], plain[1])
+
+
+def test_stage_masks_refuses_what_it_cannot_take(dev_model, smpl_model):
+    from bodyfitting_amd._lib import BodyfitError
+    prob = S.make_problem(smpl_model, frame=0, n_views=8, mask_frames=MASK_FRAMES)
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([prob])
+    masks = np.array(prob["masks"])[None]
+    view_index = [prob["use_frames"].index(f) for f in MASK_FRAMES]
+    b = N.FrameBatch(dev_model, 1, 8)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+    with pytest.raises(BodyfitError, match="first frame"):
+        b.stage_masks(masks, view_index)                          # nothing attached yet
+    b.set_masks(masks, view_index, None)
+    with pytest.raises(BodyfitError, match="keep its views and shape"):
+        b.stage_masks(masks[:, :, :-2], view_index)
+    with pytest.raises(BodyfitError, match="keep its views and shape"):
+        b.stage_masks(masks, view_index[::-1])
+    b.stage_masks(masks, view_index)
+    b.set_masks(masks, view_index, None)                          # (supersedes the staged set)
+    b.fit(6, N.make_hyper(dense_after=3))
+    assert np.isfinite(b.get_params()).all()
+    b.close()
