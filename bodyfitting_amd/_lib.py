@@ -83,6 +83,7 @@ SIGNATURES = {
     "bf_scan_inside": (C.c_int, [_VP, C.c_int, _FP, _FP]),
     "bf_scan_intersects": (C.c_int, [_VP, C.c_int, _FP, _FP, C.POINTER(C.c_uint8)]),
     "bf_scan_nearest": (C.c_int, [_VP, C.c_int, _FP, _IP, _FP, _FP]),
+    "bf_scan_nearest_hinted": (C.c_int, [_VP, C.c_int, _FP, _FP, _IP, _FP, _FP, C.c_int, _FP]),
     "bf_scan_nearest_backward": (C.c_int, [_VP, C.c_int, _IP, _FP, _FP, _FP]),
     "bf_batch_mesh_span": (C.c_int, [_VP, C.c_int, _FP]),
     "bf_nearest_rule_set": (C.c_int, [C.c_int]),

@@ -193,6 +193,43 @@ int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, f
     return BF_OK;
 }
 
+/* bf_scan_nearest with a GUESS per query: hint[n,3] = where the caller believes the nearest point is (the fit loop hands the search its
+ * own answer of the previous iteration this way).  The guess only bounds the search - the kernel checks it against what it found and
+ * searches again without it when it was wrong - so the results are bf_scan_nearest's for ANY hint (NaN and points far off the surface
+ * included).  reps > 0 and kernel_us: the launch is repeated with the same hint and its mean duration (device events) returned. */
+int bf_scan_nearest_hinted(bf_scan *s, int n, const float *points, const float *hint, int32_t *face_ids, float *nearest, float *bary,
+                           int reps, float *kernel_us) {
+    if (!s || n <= 0 || !points) return fail(BF_ERR_INVALID, "bf_scan_nearest_hinted: bad argument");
+    HIP_TRY(hipSetDevice(s->device));
+    DevBuf<float> d_p, d_c, d_b, d_h;
+    DevBuf<int> d_f;
+    DevBuf<ScanDev> d_s;
+    HIP_TRY(d_p.upload(std::vector<float>(points, points + (size_t)n * 3)));
+    HIP_TRY(d_c.alloc((size_t)n * 3)); HIP_TRY(d_b.alloc((size_t)n * 3)); HIP_TRY(d_f.alloc(n));
+    if (hint) HIP_TRY(d_h.upload(std::vector<float>(hint, hint + (size_t)n * 3)));
+    HIP_TRY(d_s.upload(std::vector<ScanDev>(1, s->dev)));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    double total_ms = 0.0;
+    for (int r = 0; r < std::max(reps, 1); ++r) {
+        if (hint) HIP_TRY(hipMemcpyAsync(d_c.p, d_h.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, 0));
+        HIP_TRY(hipEventRecord(e0, 0));
+        bf_nearest_launch(dim3((n + 3) / 4, 1), 0, (const ScanDev *)d_s.p, (const float *)d_p.p, n, d_f.p, d_c.p, d_b.p, hint ? 1 : 0);
+        HIP_TRY(hipEventRecord(e1, 0));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        total_ms += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (kernel_us) *kernel_us = (float)(total_ms * 1e3 / std::max(reps, 1));
+    if (face_ids) HIP_TRY(hipMemcpy(face_ids, d_f.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+    if (nearest) HIP_TRY(hipMemcpy(nearest, d_c.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (bary) HIP_TRY(hipMemcpy(bary, d_b.p, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return BF_OK;
+}
+
 // self-tests of the reference-arithmetic rule (nearest_rule_ref.h): its division helper against the caller's IEEE quotients, and the
 // per-triangle rule on explicit patches
 extern "C" __global__ void bf_nearest_quot_kernel(int, const float *, const float *, float *);
@@ -305,6 +342,12 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
     else { b->scan_dev.release(); HIP_TRY(b->scan_dev.upload(dev)); }
     if (b->cscale.p && b->cscale.n == cs.size()) HIP_TRY(hipMemcpy(b->cscale.p, cs.data(), cs.size() * sizeof(float), hipMemcpyHostToDevice));
     else { b->cscale.release(); HIP_TRY(b->cscale.upload(cs)); }
+    // (the SMPL+D stage's table of the scans' face normals: written here, where the device is idle anyway, not by every
+    //  bf_fit_displacement behind a hipFree)
+    std::vector<const float *> fn(b->F);
+    for (int f = 0; f < b->F; ++f) fn[f] = scans[f]->face_norms.p;
+    if (b->scan_fn.p && b->scan_fn.n == fn.size()) HIP_TRY(hipMemcpy((void *)b->scan_fn.p, fn.data(), fn.size() * sizeof(const float *), hipMemcpyHostToDevice));
+    else { b->scan_fn.release(); HIP_TRY(b->scan_fn.upload(fn)); }
     return bf_ensure_dense_buffers(b);
 }
 
@@ -989,12 +1032,6 @@ int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
                   b->disp_fn.alloc((size_t)F * nf * 4) == hipSuccess && b->disp_vn.alloc((size_t)F * nv * 4) == hipSuccess &&
                   b->disp_dPf.alloc((size_t)F * nf * 9) == hipSuccess;
         if (!ok) return fail(BF_ERR_HIP, "bf_fit_displacement: device allocation failed");
-    }
-    {
-        std::vector<const float *> fn(F);
-        for (int f = 0; f < F; ++f) fn[f] = b->scans[f]->face_norms.p;
-        if (b->scan_fn.p) { (void)hipFree((void *)b->scan_fn.p); b->scan_fn.p = nullptr; }
-        HIP_TRY(b->scan_fn.upload(fn));
     }
     // zeros for disp and its moments; the base is the mesh of the last forward, detached (smplify.py:229-231)
     HIP_TRY(hipMemsetAsync(b->disp.p, 0, nv3 * sizeof(float), b->stream));

@@ -127,9 +127,22 @@ __device__ inline int nn_wave_min_i(int v) {
 // routines right there: a call on the lanes concerned, its systems in the wave's slot of an LDS array (a version with private arrays
 // needed 104 registers and scratch memory; a second kernel doing such queries again cost 55 - 85 us per launch for a few hundred of
 // them, one wave-latency each).
+#ifdef BF_NEAREST_STATS
+// diagnostic build (make CXXFLAGS+=-DBF_NEAREST_STATS): [0] queries [1] searches (1 + retries) [2] groups of cell lists [3] trips through
+// the screen [4] screen passes [5] records screened [6] rule passes [7] records through the rule
+__device__ unsigned long long bf_nearest_stats[8];
+extern "C" int bf_nearest_stats_read(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(bf_nearest_stats), sizeof(bf_nearest_stats)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[8] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(bf_nearest_stats), z, sizeof z); }
+    return 0;
+}
+#define NSTAT(i, v) do { if (lane == 0) atomicAdd(&bf_nearest_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define NSTAT(i, v) do { } while (0)
+#endif
 template <int RULE>
 __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
-                  int *face, float *__restrict__ pts, float *__restrict__ bary, int warm, int id, int f) {
+                  int *face, float *pts, float *__restrict__ bary, int warm, int id, int f) {
     const int lane = threadIdx.x & 63;
     const ScanDev S = scans[f];
     const size_t o = (size_t)f * n + id;
@@ -141,65 +154,32 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
     // side where the home cell is past the middle this is one short of the far wall, and a query metres outside the grid (the only
     // kind that walks that far) never sees the last layer of cells.  Kept.
     const int maxL = max(max(cx > S.nx - cx ? cx : S.nx - cx, cy > S.ny - cy ? cy : S.ny - cy), cz > S.nz - cz ? cz : S.nz - cz) - 1;
-    // this lane's best so far (distance, face, coefficients); merged after every shell
-    float best = 3.0e38f, bc0 = 0.f, bc1 = 0.f, bc2 = 0.f;
-    int bface = 0x7fffffff;
-    float gbest = 3.0e38f;                                  // (wave-uniform) best distance so far, for the pruning
     __shared__ float s_general[RULE == BF_NEAREST_REFERENCE ? 4 * 20 * nrule::LANES : 1];     // the systems of the general routines, a slot per lane
-    float *scr = s_general + (RULE == BF_NEAREST_REFERENCE ? (threadIdx.x >> 6) * 20 * nrule::LANES + lane : 0);
-    auto test = [&](const float *p, int t) {
-        float co[3];
-        float dist;
-        if (RULE == BF_NEAREST_FAST) dist = closest_rule(p, p + 3, p + 6, co);
-        else dist = nrule::nearest_proj_general(p, co, scr);
-        if (dist < best || (dist == best && t < bface)) { best = dist; bface = t; bc0 = co[0]; bc1 = co[1]; bc2 = co[2]; }
-    };
-    auto test_record = [&](int rec) {
-        const size_t r = (size_t)rec * 3;
-        const float4 r0 = S.cell_pack[r], r1 = S.cell_pack[r + 1], r2 = S.cell_pack[r + 2];
-        const float p[9] = {r0.x - qx, r0.y - qy, r0.z - qz, r0.w - qx, r1.x - qy, r1.y - qz, r1.z - qx, r1.w - qy, r2.x - qz};
-        test(p, __float_as_int(r2.y));
-    };
-    // the lists of the cells in `cells` (lane masks; st / cnt in those lanes), end to end over the lanes
-    auto walk = [&](unsigned long long cells, int st, int cnt) {
-        if (!cells) return;
-        if (__popcll(cells) > 6) {                          // many cells (cold start): one cell at a time
-            for (unsigned long long m = cells; m; m &= m - 1) {
-                const int src = __ffsll((long long)m) - 1;
-                const int s0 = __builtin_amdgcn_readlane(st, src), n0 = __builtin_amdgcn_readlane(cnt, src);
-                for (int i = lane; i < n0; i += 64) test_record(s0 + i);
-            }
-        } else {
-            // up to six lists end to end: their bounds once, as wave-uniform values (base[c] = start - offset of list c), so that the
-            // entry -> record map of a pass is five compare / select steps instead of a readlane pair per cell and pass
-            int base[6], off[7];
-            off[0] = 0;
-            unsigned long long m = cells;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const int src = m ? __ffsll((long long)m) - 1 : 0;
-                const int n0 = m ? __builtin_amdgcn_readlane(cnt, src) : 0;
-                base[c] = __builtin_amdgcn_readlane(st, src) - off[c];
-                off[c + 1] = off[c] + n0;
-                m &= m - 1;
-            }
-            const int total = off[6];
-            for (int e0 = 0; e0 < total; e0 += 64) {
-                const int e = e0 + lane;
-                int rec = e + base[0];
-#pragma unroll
-                for (int c = 1; c < 6; ++c) rec = e >= off[c] ? e + base[c] : rec;
-                if (e < total) test_record(rec);
-            }
-        }
-        gbest = fminf(gbest, nn_wave_min_f(best));
-    };
-    {   // ---- shells 0 and 1: the 27-cell cube, lane c = (dz+1)*9 + (dy+1)*3 + (dx+1); the home cell is lane 13
+    float *scr = s_general + (RULE == BF_NEAREST_REFERENCE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 20 * nrule::LANES + lane : 0);
+    constexpr int PASSES = 4;                                // passes of 64 list entries per trip through the screen: their loads are in flight together
+    __shared__ int s_queue[4 * 64 * (PASSES + 1)];           // per wave: the records that passed the screen and wait for the rule
+    int *queue = s_queue + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 64 * (PASSES + 1);
+    // `warm`: pts[] still holds this query's nearest point of the previous call: its squared distance from the query as it is now,
+    // a shade enlarged, is (almost always) an upper bound of the answer.  It is only a guess - the search below is run with it and
+    // CHECKED against what it found (the last lines of the loop).
+    float U = 3.0e38f;
+    if (warm) {
+        const float ux = pts[o * 3] - qx, uy = pts[o * 3 + 1] - qy, uz = pts[o * 3 + 2] - qz;
+        // (the slack covers what the rule's own value may lie above the true distance of a regular triangle, also for a query ON the
+        //  surface; a guess of a cell's size or more prunes nothing among the 27 cells and is dropped - so is a NaN)
+        const float u2 = (ux * ux + uy * uy + uz * uz) * 1.01f + 1e-7f;
+        U = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(u2 < S.step * S.step ? u2 : 3.0e38f)));
+    }
+    // ---- shells 0 and 1 are one step over the 27-cell cube, lane c = (dz+1)*9 + (dy+1)*3 + (dx+1), the home cell is lane 13 (the
+    // reference can never stop after shell 0: `best < 0`): list bounds and box distances of all 27 cells, once
+    int st, cnt;
+    float d2 = 0.f;
+    bool cell_ok;
+    {
         const int dz = lane / 9 - 1, rem = lane % 9, dy = rem / 3 - 1, dx = rem % 3 - 1;
         const int x = cx + dx, y = cy + dy, z = cz + dz;
-        const bool cell_ok = lane < 27 && x >= 0 && x < S.nx && y >= 0 && y < S.ny && z >= 0 && z < S.nz && (maxL >= 1 || lane == 13);
-        int st = 0, cnt = 0;
-        float d2 = 0.f;
+        cell_ok = lane < 27 && x >= 0 && x < S.nx && y >= 0 && y < S.ny && z >= 0 && z < S.nz && (maxL >= 1 || lane == 13);
+        st = 0; cnt = 0;
         if (cell_ok) {
             const int cell = (x * S.ny + y) * S.nz + z;
             st = S.cell_start[cell];
@@ -209,69 +189,165 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
             lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); d2 += e * e;
             lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); d2 += e * e;
         }
-        // the previous answer, on lane 63 (never a cell lane)
-        const int wt = warm ? face[o] : -1;
-        const bool wok = wt >= 0 && wt < S.nf;
-        float wp[9];
-        if (wok && lane == 63) {
-            const int *tv = S.faces + (size_t)wt * 3;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const float *v = S.verts + (size_t)tv[c] * 3;
-                wp[c * 3] = v[0] - qx; wp[c * 3 + 1] = v[1] - qy; wp[c * 3 + 2] = v[2] - qz;
-            }
-        }
-        const int s0 = __builtin_amdgcn_readlane(st, 13), n0 = __builtin_amdgcn_readlane(cnt, 13);
-        {   // home cell: entries on lanes 0..62 (63 while no warm triangle), the warm triangle on lane 63
-            const int width = wok ? 63 : 64;
-            for (int e0 = 0; e0 < n0 || e0 == 0; e0 += width) {
-                const int e = e0 + lane;
-                float p[9];
-                int t = -1;
-                if (wok && lane == 63) {
-                    if (e0 == 0) {
-                        t = wt;
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) p[k] = wp[k];
-                    }
-                } else if (e < n0) {
-                    const size_t r = (size_t)(s0 + e) * 3;
-                    const float4 r0 = S.cell_pack[r], r1 = S.cell_pack[r + 1], r2 = S.cell_pack[r + 2];
-                    p[0] = r0.x - qx; p[1] = r0.y - qy; p[2] = r0.z - qz; p[3] = r0.w - qx; p[4] = r1.x - qy; p[5] = r1.y - qz;
-                    p[6] = r1.z - qx; p[7] = r1.w - qy; p[8] = r2.x - qz;
-                    t = __float_as_int(r2.y);
-                }
-                if (t >= 0) test(p, t);
-            }
-            gbest = fminf(gbest, nn_wave_min_f(best));
-        }
-        walk(__ballot(cell_ok && lane != 13 && cnt > 0 && !(gbest < d2)), st, cnt);
+        cell_ok = cell_ok && cnt > 0;
     }
-    if (!(gbest < S.step * S.step))                          // mesh_grid_kernel.cu:349 after shell 1 (gbest = 3e38 while nothing was found)
-    for (int L = 2; L <= maxL; ++L) {
-        const int side = 2 * L + 1, ncube = side * side * side;
-        for (int base = 0; base < ncube; base += 64) {
-            // one cube cell per lane; only the shell (max |d| == L), in bounds, not beyond the best so far
-            const int c = base + lane;
-            const int dz = c / (side * side) - L, rem = c % (side * side), dy = rem / side - L, dx = rem % side - L;
-            const int x = cx + dx, y = cy + dy, z = cz + dz;
-            bool use = c < ncube && max(max(abs(dx), abs(dy)), abs(dz)) == L && x >= 0 && x < S.nx && y >= 0 && y < S.ny && z >= 0 && z < S.nz;
-            int st = 0, cnt = 0;
-            if (use) {
-                float lo, e, d2 = 0.f;
-                lo = S.ox + S.step * x; e = qx < lo ? lo - qx : (qx > lo + S.step ? qx - lo - S.step : 0.f); d2 += e * e;
-                lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); d2 += e * e;
-                lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); d2 += e * e;
-                use = !(gbest < d2);
+    const int st27 = st, cnt27 = cnt;
+    // this lane's best so far (distance, face, coefficients); merged at the end
+    float best, bc0, bc1, bc2, gbest;
+    int bface;
+    NSTAT(0, 1);
+    for (;;) {
+        NSTAT(1, 1);
+        best = 3.0e38f; bc0 = 0.f; bc1 = 0.f; bc2 = 0.f;
+        bface = 0x7fffffff;
+        gbest = 3.0e38f;                                    // (wave-uniform) best distance the rule has returned so far
+        float B = U;                                        // (wave-uniform) min(U, gbest): what cells and records are screened against
+        int qn = 0;                                         // (wave-uniform) records in the queue
+        // The walk is a nest of loops with ONE copy of the screen and ONE of the rule (inlined per call site they took the kernel from
+        // 69 to 202 registers): cell sets (the home cell / the cube / 64 cells of a shell) > groups of up to six cell lists laid end to
+        // end > trips of PASSES x 64 list entries through the screen, each followed by the rule on the queue when it holds 64 records -
+        // or, on the extra trip that ends a cell set's last group, whatever it holds (`force`).
+        const bool cold = !(U < 3.0e38f);
+        int phase = cold ? 0 : 1, L = 1, chunk = 0;
+        st = st27; cnt = cnt27;
+        for (;;) {
+            // ---- the next cell set: lanes whose (st, cnt) lists are to be walked, and whether the queue is emptied after it
+            unsigned long long cells;
+            bool flush_after = true;
+            if (phase == 0) cells = __ballot(cell_ok && lane == 13);                                   // no bound yet: the HOME cell's list first, through the rule ...
+            else if (phase == 1) cells = __ballot(cell_ok && (!cold || lane != 13) && !(B < d2));      // ... and the cube's other cells pruned with what it gave (or with U)
+            else {
+                // shell L: 64 cells of its cube per set; only the shell (max |d| == L), in bounds, not beyond the bound
+                const int side = 2 * L + 1, ncube = side * side * side;
+                const int c = chunk * 64 + lane;
+                const int dz = c / (side * side) - L, rem = c % (side * side), dy = rem / side - L, dx = rem % side - L;
+                const int x = cx + dx, y = cy + dy, z = cz + dz;
+                bool use = c < ncube && max(max(abs(dx), abs(dy)), abs(dz)) == L && x >= 0 && x < S.nx && y >= 0 && y < S.ny && z >= 0 && z < S.nz;
+                st = 0; cnt = 0;
                 if (use) {
-                    const int cell = (x * S.ny + y) * S.nz + z;
-                    st = S.cell_start[cell];
-                    cnt = S.cell_start[cell + 1] - st;
+                    float lo, e, dd = 0.f;
+                    lo = S.ox + S.step * x; e = qx < lo ? lo - qx : (qx > lo + S.step ? qx - lo - S.step : 0.f); dd += e * e;
+                    lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); dd += e * e;
+                    lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); dd += e * e;
+                    use = !(B < dd);
+                    if (use) {
+                        const int cell = (x * S.ny + y) * S.nz + z;
+                        st = S.cell_start[cell];
+                        cnt = S.cell_start[cell + 1] - st;
+                    }
                 }
+                cells = __ballot(use && cnt > 0);
+                flush_after = (chunk + 1) * 64 >= ncube;
             }
-            walk(__ballot(use && cnt > 0), st, cnt);
+            do {
+                // up to six lists end to end: their bounds once, as wave-uniform values (base[c] = start - offset of list c), so that the
+                // entry -> record map of a pass is compare / select steps instead of a readlane pair per cell and pass
+                int base[6], off[7];
+                off[0] = 0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    const int src = cells ? __ffsll((long long)cells) - 1 : 0;
+                    const int n0 = cells ? __builtin_amdgcn_readlane(cnt, src) : 0;
+                    base[c] = __builtin_amdgcn_readlane(st, src) - off[c];
+                    off[c + 1] = off[c] + n0;
+                    cells &= cells - 1;
+                }
+                const int total = off[6];
+                NSTAT(2, 1);
+                for (int e0 = 0;; e0 += 64 * PASSES) {
+                    const int npass = min(PASSES, (total - e0 + 63) >> 6);       // (<= 0 on the extra trip)
+                    if (npass > 0) {
+                        NSTAT(3, 1); NSTAT(4, npass);
+                        int rec[PASSES];
+                        float4 r0[PASSES], r1[PASSES], r2[PASSES];
+#pragma unroll
+                        for (int k = 0; k < PASSES; ++k)
+                            if (k < npass) {                // (wave-uniform; every lane loads: one without an entry reads the group's first record)
+                                const int e = e0 + k * 64 + lane;
+                                int d = base[0];
+#pragma unroll
+                                for (int c = 1; c < 6; ++c) d = e >= off[c] ? base[c] : d;
+                                rec[k] = e < total ? e + d : -1;
+                                const size_t r = (size_t)(e < total ? e + d : base[0]) * 3;
+                                r0[k] = S.cell_pack[r]; r1[k] = S.cell_pack[r + 1]; r2[k] = S.cell_pack[r + 2];
+                            }
+                        // THE SCREEN.  A record goes to the rule only if its triangle's bounding box is not beyond B.  What makes that exact:
+                        // the distance the reference's rule returns (the multiplier of its KKT system) is never below the true squared
+                        // distance by more than 2e-7 x the largest squared corner distance - for every shape, needles and coincident corners
+                        // included, where it may be far ABOVE it or NaN, and a NaN never wins a `<` (oracle/nearest_ref.c over millions of
+                        // pairs: tests/test_nearest_ref_oracle.py) - and the distance to the box is a lower bound of the true
+                        // one.  With lb2 = squared distance to the box and fb2 = to its far corner: lb2 * 0.999 - 1e-5 * fb2 > B  =>  the
+                        // rule's value for this triangle is > B >= the final minimum: it can neither win nor tie.
+#pragma unroll
+                        for (int k = 0; k < PASSES; ++k)
+                            if (k < npass) {
+                                const float ax = r0[k].x - qx, ay = r0[k].y - qy, az = r0[k].z - qz, bx = r0[k].w - qx, by = r1[k].x - qy, bz = r1[k].y - qz,
+                                            gx = r1[k].z - qx, gy = r1[k].w - qy, gz = r2[k].x - qz;
+                                const float lx = fminf(fminf(ax, bx), gx), hx = fmaxf(fmaxf(ax, bx), gx);
+                                const float ly = fminf(fminf(ay, by), gy), hy = fmaxf(fmaxf(ay, by), gy);
+                                const float lz = fminf(fminf(az, bz), gz), hz = fmaxf(fmaxf(az, bz), gz);
+                                const float ex = fmaxf(fmaxf(lx, -hx), 0.f), ey = fmaxf(fmaxf(ly, -hy), 0.f), ez = fmaxf(fmaxf(lz, -hz), 0.f);
+                                const float fx = fmaxf(fabsf(lx), fabsf(hx)), fy = fmaxf(fabsf(ly), fabsf(hy)), fz = fmaxf(fabsf(lz), fabsf(hz));
+                                const float lb2 = ex * ex + ey * ey + ez * ez, fb2 = fx * fx + fy * fy + fz * fz;
+                                const bool pass = rec[k] >= 0 && !(lb2 * 0.999f - 1e-5f * fb2 > B);
+                                const unsigned long long m = __ballot(pass);
+                                if (pass) queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = rec[k];
+                                qn += __popcll(m);
+                            }
+                    }
+                    const bool force = npass <= 0 && !cells && flush_after;
+                    while (qn >= 64 || (force && qn > 0)) {
+                        // THE RULE on the first (up to 64) records of the queue
+                        const int count = min(qn, 64);
+                        NSTAT(6, 1); NSTAT(7, count);
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < count) {
+                            const size_t r = (size_t)queue[lane] * 3;
+                            const float4 q0 = S.cell_pack[r], q1 = S.cell_pack[r + 1], q2 = S.cell_pack[r + 2];
+                            const float p[9] = {q0.x - qx, q0.y - qy, q0.z - qz, q0.w - qx, q1.x - qy, q1.y - qz, q1.z - qx, q1.w - qy, q2.x - qz};
+                            const int t = __float_as_int(q2.y);
+                            float co[3];
+                            float dist;
+                            if (RULE == BF_NEAREST_FAST) dist = closest_rule(p, p + 3, p + 6, co);
+                            else dist = nrule::nearest_proj_general(p, co, scr);
+                            if (dist < best || (dist == best && t < bface)) { best = dist; bface = t; bc0 = co[0]; bc1 = co[1]; bc2 = co[2]; }
+                        }
+                        gbest = fminf(gbest, nn_wave_min_f(best));
+                        B = fminf(U, gbest);
+                        __builtin_amdgcn_wave_barrier();
+                        if (qn > 64) {                      // what is left moves to the front: up to PASSES x 64 records
+                            int rest[PASSES];
+#pragma unroll
+                            for (int k = 0; k < PASSES; ++k) rest[k] = 64 * (k + 1) + lane < qn ? queue[64 * (k + 1) + lane] : 0;
+                            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                            for (int k = 0; k < PASSES; ++k)
+                                if (64 * (k + 1) + lane < qn) queue[64 * k + lane] = rest[k];
+                        }
+                        qn = max(qn - 64, 0);
+                    }
+                    if (npass <= 0) break;
+                }
+            } while (cells);
+            // ---- the set is done (and, if it ended a shell, the queue empty): the stop tests
+            if (phase == 0) phase = 1;
+            else if (phase == 1) {
+                // mesh_grid_kernel.cu:349 after shell 1 (gbest = 3e38 while nothing was found).  A guess - it is below step^2 - that the
+                // cube has not confirmed is wrong: the triangle behind a right one has its nearest point within a cell's size, so in one of
+                // these 27 cells, and would have passed the screen.
+                if (gbest < S.step * S.step || maxL < 2 || !cold) break;
+                phase = 2; L = 2; chunk = 0;
+            } else if (flush_after) {
+                if (gbest < (float)L * (float)L * S.step * S.step || L >= maxL) break;     // mesh_grid_kernel.cu:349
+                ++L; chunk = 0;
+            } else ++chunk;
         }
-        if (gbest < (float)L * (float)L * S.step * S.step) break;     // mesh_grid_kernel.cu:349
+        // THE CHECK of the guess U: everything skipped had a rule value above min(U, the best at that time).  If the cube ended with
+        // gbest <= U (< step^2: the reference stops there too), that is above the final minimum - the answer is the unscreened walk's.
+        // If not (the guess was not a point of the surface, or the rule's value for its triangle lies further above the true distance
+        // than the slack), once more without the guess.
+        if (cold || gbest <= U) break;
+        U = 3.0e38f;
     }
     // merge: the lexicographic (distance, face id) minimum over the lanes, then its owner's coefficients
     const float dmin = gbest;
@@ -306,14 +382,14 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
 extern "C" __global__ void __launch_bounds__(256)
 bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                   int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
-    const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (id >= n) return;                                   // (wave-uniform)
+    const int id = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (the wave's query: told to the compiler as the wave-uniform value it is - the walk's bookkeeping then lives in scalar registers)
+    if (id >= n) return;
     nearest_body<BF_NEAREST_REFERENCE>(scans, points, n, face, pts, bary, warm, id, blockIdx.y);
 }
 extern "C" __global__ void __launch_bounds__(256)
 bf_nearest_fast_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                        int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
-    const int id = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int id = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (id >= n) return;
     nearest_body<BF_NEAREST_FAST>(scans, points, n, face, pts, bary, warm, id, blockIdx.y);
 }

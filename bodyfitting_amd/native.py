@@ -193,6 +193,19 @@ class Scan:
                    "bf_scan_nearest")
         return pts, ids, bary
 
+    def nearest_points_hinted(self, points, hint=None, reps=0):
+        """nearest_points with a guess per query (hint[n,3]: e.g. the previous iteration's nearest points; any values are safe - the
+        kernel checks the guess).  -> (points, ids, barycentrics[, mean kernel microseconds when reps > 0])"""
+        p = _f32(points, (-1, 3))
+        h = None if hint is None else _f32(hint, (len(p), 3))
+        ids = np.empty(len(p), np.int32)
+        pts = np.empty((len(p), 3), np.float32)
+        bary = np.empty((len(p), 3), np.float32)
+        us = C.c_float(0.0)
+        _lib.check(self._lib.bf_scan_nearest_hinted(self._h, len(p), _lib.fptr(p), _lib.fptr(h), _lib.iptr(ids), _lib.fptr(pts), _lib.fptr(bary),
+                                                    int(reps), C.byref(us)), "bf_scan_nearest_hinted")
+        return (pts, ids, bary, us.value) if reps > 0 else (pts, ids, bary)
+
 
     def nearest_points_backward(self, face_ids, bary, dnearest):
         """dL/d(query points) from dL/d(nearest points): SurfaceNearest.backward w.r.t. its first argument (point-to-plane

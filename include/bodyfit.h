@@ -213,6 +213,12 @@ int bf_scan_grid_lists(const bf_scan *s, int32_t *tri_num, int32_t *tri_idx, int
 /* MeshGridSearcher.nearest_points / search_nearest_point (mesh_grid.cpp:54-72): points[n,3] ->
  * face_ids[n] int32, nearest[n,3], bary[n,3] (any output may be NULL) */
 int bf_scan_nearest(bf_scan *s, int n, const float *points, int32_t *face_ids, float *nearest, float *bary);
+/* The same search with a guess per query, hint[n,3] (NULL: none) = where the nearest point is believed to be - the fit loop hands the
+ * search its previous iteration's answer this way.  The guess bounds the search and is CHECKED against what was found (searched again
+ * without it when it was wrong): the results are bf_scan_nearest's for any hint.  reps > 0 with kernel_us != NULL: the launch is repeated
+ * and its mean device time returned (microseconds). */
+int bf_scan_nearest_hinted(bf_scan *s, int n, const float *points, const float *hint, int32_t *face_ids, float *nearest, float *bary,
+                           int reps, float *kernel_us);
 /* The per-triangle arithmetic of every closest-point search of the process (bf_scan_nearest, the scan loss of bf_fit, SMPL+D).
  * BF_NEAREST_REFERENCE (default): search_nearest_proj as the reference's source evaluates it in float32 - Gram matrix of the corner
  * vectors, the bordered 4 x 4 system through solve4 / solve3 with their pivot order and absolute 1e-9 rank tests, IEEE divisions,

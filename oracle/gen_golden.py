@@ -381,6 +381,33 @@ def _nudge(problem):
     return q
 
 
+def sensitivity_cfg2_goldens():
+    """config 2 under sensitivity_goldens' two perturbations (8 intra-op threads; the initial pose one float32 ulp up): the final
+    parameters and rtn_dict's global_transl (= t * s, smplify.py:223) of all four frames.  Frame 3's translation is ill-conditioned -
+    this is how far the REFERENCE moves from itself there, the yardstick of tests/test_gpu_parity.py for that field."""
+    import torch
+    import smplx
+    from bodyfitting_amd import synthetic as S
+    model = S.make_model("smpl", seed=0)
+    gmm = S.make_gmm(seed=0)
+    smplx.MODEL_REGISTRY["smpl"] = model
+    tmp = tempfile.mkdtemp(prefix="bf_sens_cfg2_")
+    write_data_dir(tmp, model, gmm)
+    os.chdir(tmp)
+    out = {}
+    for frame in (0, 1, 2, 3):
+        base = S.make_problem(model, frame=frame, n_views=48)
+        for tag, threads, nudge in (("threads8", 8, False), ("ulp", 1, True)):
+            torch.set_num_threads(threads)
+            res, snaps, _ = run_reference_fit(_nudge(base) if nudge else base, 100, snapshots=(100,))
+            out[f"{tag}_f{frame}_final_global_transl"] = res["global_transl"]
+            out[f"{tag}_f{frame}_joints"] = res["joints"]
+            out.update({f"{tag}_f{frame}_{k}": v for k, v in flat_snaps(snaps).items()})
+        torch.set_num_threads(1)
+        print("sensitivity: cfg2 frame", frame, "done")
+    np.savez_compressed(os.path.join(GOLDEN, "sens_cfg2_48view_100it.npz"), model_digest=S.model_digest(model), **out)
+
+
 def sensitivity_scan_goldens():
     """The scan loops' share of sensitivity_goldens: 8 threads, one ulp, and - for the closest-point search, whose answers are face
     ids decided by last bits - the restated search built with fused multiply-adds ('fused': what nvcc is free to do to the
@@ -767,6 +794,9 @@ if __name__ == "__main__":
     elif "--openpose-only" in sys.argv:
         install_reference_imports()
         openpose_goldens()
+    elif "--sens-cfg2-only" in sys.argv:
+        install_reference_imports()
+        sensitivity_cfg2_goldens()
     elif "--sens-scan-only" in sys.argv:
         install_reference_imports()
         sensitivity_scan_goldens()
@@ -790,5 +820,6 @@ if __name__ == "__main__":
         scan_goldens_long()
         openpose_goldens()
         sensitivity_goldens()
+        sensitivity_cfg2_goldens()
         cfg3_goldens()
         reference_timing()

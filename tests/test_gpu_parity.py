@@ -103,16 +103,18 @@ def test_cfg2_fit_matches_reference(dev_model, smpl_model, frame):
     np.testing.assert_allclose(full_pose[0], g["full_pose"], atol=FIT_TOL)
     p = N.split_params(b.get_params()[0])
     # rtn_dict's global_transl = t * s (smplify.py:223), a field of the result: 1e-4 like everything else on the well-conditioned
-    # frames.  Frame 3's translation is the ill-conditioned one of the four: the float64 analytic oracle itself ends 5.6e-5 from the
-    # float32 reference in this field there (2e-6 on frame 0) - MEASURED here, and the band for that frame is 3 x it
-    if frame != 3:
-        np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=FIT_TOL)
-    else:
-        from oracle import analytic as A
-        want, _, _ = A.fit(smpl_model, S.gmm_buffers(S.make_gmm(seed=0)), prob, 100, dtype=np.float64)
-        oracle_drift = float(np.abs(want["global_transl"] * want["scale"] - g["final_global_transl"]).max())
-        assert 2e-5 < oracle_drift < 2e-4, oracle_drift
-        np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=max(FIT_TOL, 3 * oracle_drift))
+    # frames.  Frame 3's translation is the ill-conditioned one of the four: the imported reference itself ends 1.6e-4 from its own
+    # answer in this field when the initial pose moves by one float32 ulp (6e-5 with 8 threads; 3e-6 on frame 0) -
+    # tests/golden/sens_cfg2_48view_100it.npz, oracle/gen_golden.py: sensitivity_cfg2_goldens - and the band for that frame is the
+    # one of the other round-off-amplifying loops: 3 x the reference's own drift (tests/ref_drift.py)
+    band = FIT_TOL
+    if frame == 3:
+        import ref_drift as RD
+        sens = load_golden("sens_cfg2_48view_100it.npz")
+        own = max(float(np.abs(sens[f"{v}_f3_final_global_transl"] - g["final_global_transl"]).max()) for v in RD.VARIANTS)
+        assert 1e-4 < own < 3e-4, own
+        band = max(FIT_TOL, RD.K * own)
+    np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=band)
     b.close()
 
 

@@ -218,6 +218,32 @@ def test_nearest_equals_the_references_own_arithmetic_on_slivers(scale):
     assert declined > 0.2 if scale <= 0.01 else declined < 0.3
 
 
+@pytest.mark.parametrize("spread", [0.0005, 0.005, 0.02])
+def test_a_guess_bounds_the_search_and_never_changes_its_answer(small, spread):
+    """bf_scan_nearest_hinted (what the fit loop does with its previous iteration's nearest points): the guess prunes cells and records
+    (the screen of csrc/scan_kernels.hip) and is checked against what was found - for the exact answer as the guess, guesses a
+    millimetre off the surface (half of them closer to the query than the surface is: a bound that is too small), half way to the
+    query, on the query itself, NaN, infinite and a metre away, the result is the unguessed search's bit for bit; and that one is the
+    reference's arithmetic (the tests above).  A degenerate triangle (coincident corners after the OBJ's 4 decimals) sits in the scan."""
+    model, _ = small
+    _, sv, sf = S.make_scan_problem(model, 1)
+    sv = sv.copy(); sv[sf[5, 1]] = sv[sf[5, 0]]                              # a repeated corner: its triangles are needles / points
+    rng = np.random.default_rng(33)
+    q = (sv[rng.integers(0, len(sv), 4000)] + rng.normal(0, spread, (4000, 3))).astype(np.float32)
+    scan = N.Scan(sv, sf)
+    pts, ids, bary = scan.nearest_points(q)
+    guesses = {"exact": pts, "1 mm off": pts + rng.normal(0, 0.001, pts.shape).astype(np.float32), "half way": (pts + q) / 2,
+               "the query": q.copy(), "nan": np.full_like(pts, np.nan), "inf": np.full_like(pts, np.inf), "a metre off": pts + np.float32(1.0),
+               "mixed": np.where(rng.random((len(q), 1)) < 0.5, pts, q)}
+    for name, g in guesses.items():
+        p2, i2, b2 = scan.nearest_points_hinted(q, g.astype(np.float32))
+        assert np.array_equal(i2, ids), name
+        assert np.array_equal(p2.view(np.uint32), pts.view(np.uint32)) and np.array_equal(b2.view(np.uint32), bary.view(np.uint32)), name
+    scan.close()
+    n, ties, wrong = _against_reference_arithmetic(sv, sf, q)
+    assert wrong == 0
+
+
 def test_rule_on_the_device_equals_the_oracle_patch_by_patch():
     """search_nearest_proj on explicit patches: regular, degenerate (repeated corners, collinear), far (Gram entries above 1) and
     tiny ones; distance and coefficients bit for bit against oracle/nearest_ref.c"""

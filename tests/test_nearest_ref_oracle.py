@@ -185,3 +185,85 @@ def test_adversarial_soup_rule_never_closer_than_exact():
     assert (d_point >= d_exact * (1 - 1e-3) - 1e-9).all()          # (float32 coefficients: a sliver's point sits 3e-4 off the triangle)
     regular = np.array([d["kind"][o] in ("regular", "right") for o in d["owner"]])
     np.testing.assert_allclose(dist[regular], d_exact[regular], rtol=2e-4, atol=1e-6)
+
+
+def _exact_dist2(p64):
+    """squared distance of the origin to triangles p64[N,3,3] (float64), degenerate ones included: min over the three segments and,
+    where it exists, Ericson's interior case"""
+    def seg(a, b):
+        ab = b - a
+        t = np.clip(-(a * ab).sum(1) / np.maximum((ab * ab).sum(1), 1e-300), 0, 1)
+        c = a + t[:, None] * ab
+        return (c * c).sum(1)
+    d = np.minimum(np.minimum(seg(p64[:, 0], p64[:, 1]), seg(p64[:, 1], p64[:, 2])), seg(p64[:, 2], p64[:, 0]))
+    with np.errstate(all="ignore"):
+        tri = MO.closest_exact(p64[:, 0], p64[:, 1], p64[:, 2])
+    return np.where(np.isfinite(tri), np.minimum(tri, d), d)
+
+
+def _screen_families(rng, n):
+    """(name, verts[n,3,3], queries[n,3]) - every shape the kernel's screen must be right about"""
+    def generic(scale_lo, scale_hi, r_lo, r_hi):
+        s = 10 ** rng.uniform(scale_lo, scale_hi, n)
+        P = rng.normal(size=(n, 3, 3)) * s[:, None, None]
+        w = rng.dirichlet(np.ones(3), n) * 3 - 1
+        base = (w[:, :, None] * P).sum(1)
+        r = 10 ** rng.uniform(r_lo, r_hi, n) * s
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return P, base + d * r[:, None]
+    def shaped():                                       # base along x, apex anywhere from needle to obtuse, heights down to 1e-4 of the base
+        s = 10 ** rng.uniform(-3, 0.5, n)
+        P = np.zeros((n, 3, 3))
+        P[:, 1, 0] = 1; P[:, 2, 0] = rng.uniform(-0.5, 1.5, n); P[:, 2, 1] = 10 ** rng.uniform(-4, 0, n)
+        P *= s[:, None, None]
+        Q, _ = np.linalg.qr(rng.normal(size=(n, 3, 3)))
+        P = P @ Q.transpose(0, 2, 1)
+        w = rng.dirichlet(np.ones(3), n) * 3 - 1
+        r = 10 ** rng.uniform(-6, 1.5, n) * s
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        return P, (w[:, :, None] * P).sum(1) + d * r[:, None]
+    for off in (0.0, 1.5):
+        P, q = shaped(); yield f"needles to obtuse, offset {off}", P + off, q + off
+        P, q = generic(-6, -3, -3, 1); yield f"tiny triangles, offset {off}", P + off, q + off
+        P, q = generic(-3, 0, -7, -3); yield f"query on the surface, offset {off}", P + off, q + off
+        P, q = generic(-2, 0, -2, 2)
+        for a_, b_ in ((1, 0), (2, 1), (2, 0)):
+            P2 = P.copy(); P2[:, a_] = P2[:, b_]; yield f"corners {a_} = {b_}, offset {off}", P2 + off, q + off
+        P2 = P.copy(); P2[:, 1] = P2[:, 0]; P2[:, 2] = P2[:, 0]; yield f"a point, offset {off}", P2 + off, q + off
+        t = rng.uniform(-1, 2, (n, 1)); P2 = P.copy(); P2[:, 2] = P2[:, 0] + t * (P2[:, 1] - P2[:, 0]); yield f"collinear, offset {off}", P2 + off, q + off
+        A = np.zeros((n, 3, 3)); a = 10 ** rng.uniform(-3, 0, (n, 3))
+        A[:, 0, 0] = a[:, 0]; A[:, 1, 1] = a[:, 1]; A[:, 2, 2] = a[:, 2] * (rng.random(n) < 0.5)
+        yield f"orthogonal corner vectors, offset {off}", A + off, np.zeros((n, 3)) + off
+        P, q = generic(-3, -1, -2, 1); yield f"4-decimal coordinates, offset {off}", np.round(P + off, 4), np.round(q + off, 4)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_the_rules_distance_never_undershoots_the_true_one(fused):
+    """THE PREMISE OF THE KERNEL'S SCREEN (csrc/scan_kernels.hip: a record whose bounding box lies beyond the best distance so far is
+    not handed to the rule).  The distance search_nearest_proj returns is the multiplier of its KKT system, not a norm, and on needles,
+    obtuse triangles and coincident corners it can be far ABOVE the true squared distance, or NaN (which never wins the reference's
+    `<`) - but it is never BELOW it by more than rounding: 2e-7 x the largest squared corner distance over every family here (the
+    kernel allows 1e-5 x the squared distance to the box's far corner + 0.1 % of the box distance).  Checked in both roundings the
+    reference's compiler may produce, and as the very inequality the kernel evaluates."""
+    rng = np.random.default_rng(11)
+    worst = 0.0
+    for name, V, q in _screen_families(rng, 40000):
+        V = V.astype(np.float32); q = q.astype(np.float32)
+        n = len(q)
+        _, dref, _ = NR.rule(V.reshape(-1, 3), np.arange(3 * n, dtype=np.int32).reshape(-1, 3), np.arange(n, dtype=np.int32), q, fused=fused)
+        p = V - q[:, None, :]                                             # the float32 differences the rule works on
+        p64 = p.astype(np.float64)
+        dtrue = _exact_dist2(p64)
+        maxp2 = (p64 ** 2).sum(2).max(1)
+        ok = ~np.isnan(dref)
+        under = np.where(ok, dtrue - dref.astype(np.float64), -np.inf) / np.maximum(maxp2, 1e-300)
+        worst = max(worst, under.max())
+        assert under.max() < 4e-7, (name, under.max())
+        # the kernel's own test, in float32: box distance, far-corner distance
+        lo, hi = p.min(1), p.max(1)
+        e = np.maximum(np.maximum(lo, -hi), np.float32(0))
+        f = np.maximum(np.abs(lo), np.abs(hi))
+        lb2 = (e * e).sum(1, dtype=np.float32); fb2 = (f * f).sum(1, dtype=np.float32)
+        bound = lb2 * np.float32(0.999) - np.float32(1e-5) * fb2
+        assert not (ok & (dref < bound)).any(), name                    # skipped  =>  the rule's value is above the bound it was skipped against
+    assert worst > 1e-8                                                   # (the families do reach the rounding level: the test is not vacuous)

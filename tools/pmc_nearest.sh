@@ -4,7 +4,7 @@ TAG=${1:-x}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp
-timeout 500 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $R/gpurun_out/pmc_nearest_$TAG -- python3 $R/tools/bench_configs.py --cfg5x --reps 1 --iters 30 > $R/gpurun_out/pmc_nearest_$TAG.log 2>&1
+timeout 500 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d $R/gpurun_out/pmc_nearest_$TAG -- python3 $R/tools/bench_configs.py --cfg5x --reps 1 --iters 120 > $R/gpurun_out/pmc_nearest_$TAG.log 2>&1
 cd $R
 find gpurun_out/pmc_nearest_$TAG -name "*.db" -delete
 python3 - <<PY
