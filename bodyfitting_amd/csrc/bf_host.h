@@ -289,7 +289,7 @@ struct bf_scan {
     ScanDev dev{};
     DevBuf<float> verts, face_norms;
     DevBuf<int> faces, cell_start, cell_tris;
-    DevBuf<float> cell_pack;
+    DevBuf<float> cell_pack, cell_box;
 };
 
 

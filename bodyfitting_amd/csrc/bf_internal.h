@@ -168,6 +168,8 @@ struct ScanDev {
     const int *cell_tris;     // triangles per cell, ascending face id
     const float4 *cell_pack;  // per cell-list entry: the triangle's corners and id, 3 x float4 = (p0.xyz p1.x)(p1.yz p2.xy)(p2.z id 0 0):
                               // one contiguous 48-byte record instead of the list -> faces -> vertices pointer chase
+    const float4 *cell_box;   // per cell-list entry, for the search's screen: 2 x float4 = (box lo.xyz, m)(box hi.xyz, 0) of the triangle, m =
+                              // 2.1e-5 x the box's squared diagonal (what the rule's value may lie below the true distance, scan_kernels.hip)
 };
 
 // Silhouette-loss inputs of one batch (device pointers).

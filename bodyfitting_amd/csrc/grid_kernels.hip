@@ -95,7 +95,7 @@ extern "C" __global__ void __launch_bounds__(256) bf_grid_fill_kernel(ScanDev S,
 // One thread per list entry e: its cell by bisection of cell_start, its rank = number of smaller face ids in the cell
 // (a triangle enters a cell once, so the ids of a cell are distinct), then the sorted list entry and the packed record.
 extern "C" __global__ void __launch_bounds__(256) bf_grid_pack_kernel(ScanDev S, const int *tris_raw, int *tris_sorted, float4 *pack,
-                                                                     int n_entries) {
+                                                                     float4 *box, int n_entries) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= n_entries) return;
     int lo = 0, hi = S.nx * S.ny * S.nz;            // largest c with cell_start[c] <= e
@@ -114,6 +114,12 @@ extern "C" __global__ void __launch_bounds__(256) bf_grid_pack_kernel(ScanDev S,
     pack[(size_t)o * 3] = make_float4(a[0], a[1], a[2], b[0]);
     pack[(size_t)o * 3 + 1] = make_float4(b[1], b[2], c[0], c[1]);
     pack[(size_t)o * 3 + 2] = make_float4(c[2], __int_as_float(f), 0.f, 0.f);
+    // the screen's record: the triangle's box (exact minima / maxima of its float32 coordinates) and its margin
+    const float lx = fminf(a[0], fminf(b[0], c[0])), ly = fminf(a[1], fminf(b[1], c[1])), lz = fminf(a[2], fminf(b[2], c[2]));
+    const float hx = fmaxf(a[0], fmaxf(b[0], c[0])), hy = fmaxf(a[1], fmaxf(b[1], c[1])), hz = fmaxf(a[2], fmaxf(b[2], c[2]));
+    const float dx = hx - lx, dy = hy - ly, dz = hz - lz;
+    box[(size_t)o * 2] = make_float4(lx, ly, lz, 2.1e-5f * (dx * dx + dy * dy + dz * dz));
+    box[(size_t)o * 2 + 1] = make_float4(hx, hy, hz, 0.f);
 }
 
 extern "C" __global__ void __launch_bounds__(256) bf_face_normal_kernel(const float *verts, const int *faces, int nf, float *fn) {

@@ -20,7 +20,7 @@ extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *,
 extern "C" __global__ void bf_grid_count_kernel(ScanDev, int *);
 extern "C" __global__ void bf_grid_scan_kernel(int *, int *, int);
 extern "C" __global__ void bf_grid_fill_kernel(ScanDev, int *, int *);
-extern "C" __global__ void bf_grid_pack_kernel(ScanDev, const int *, int *, float4 *, int);
+extern "C" __global__ void bf_grid_pack_kernel(ScanDev, const int *, int *, float4 *, float4 *, int);
 extern "C" __global__ void bf_face_normal_kernel(const float *, const int *, int, float *);
 extern "C" __global__ void bf_inside_mesh_kernel(ScanDev, const float *, int, float *);
 extern "C" __global__ void bf_intersect_kernel(ScanDev, const float *, const float *, int, unsigned char *);
@@ -85,7 +85,7 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
     d.nv = n_verts; d.nf = n_faces; d.nx = num[0]; d.ny = num[1]; d.nz = num[2];
     d.ox = org[0]; d.oy = org[1]; d.oz = org[2]; d.step = step; d.height = ext[1];
     d.verts = s->verts.p; d.faces = s->faces.p; d.cell_start = s->cell_start.p;
-    d.cell_tris = nullptr; d.cell_pack = nullptr;
+    d.cell_tris = nullptr; d.cell_pack = nullptr; d.cell_box = nullptr;
     const dim3 fgrid((n_faces + 255) / 256);
     int total = 0;
     hipError_t e = hipMemsetAsync(s->cell_start.p, 0, (ncell + 1) * sizeof(int), 0);
@@ -97,15 +97,17 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(&total, s->cell_start.p + ncell, sizeof(int), hipMemcpyDeviceToHost);   // (syncs)
+    if (e == hipSuccess && total >= (1 << 28)) { delete s; return fail(BF_ERR_UNSUPPORTED, "bf_scan_create: more than 2^28 cell-list entries"); }   // (the search's queue entries: 28 bits of record index)
     if (e == hipSuccess && total > 0) {
         ok = tris_raw.alloc_pooled(total) == hipSuccess && s->cell_tris.alloc_pooled(total) == hipSuccess &&
-             s->cell_pack.alloc_pooled((size_t)total * 12) == hipSuccess;
+             s->cell_pack.alloc_pooled((size_t)total * 12) == hipSuccess && s->cell_box.alloc_pooled((size_t)total * 8) == hipSuccess;
         if (!ok) { delete s; return fail(BF_ERR_HIP, "bf_scan_create: device allocation failed (cell lists)"); }
         d.cell_tris = s->cell_tris.p;
         d.cell_pack = (const float4 *)s->cell_pack.p;
+        d.cell_box = (const float4 *)s->cell_box.p;
         hipLaunchKernelGGL(bf_grid_fill_kernel, fgrid, dim3(256), 0, 0, d, cursor.p, tris_raw.p);
         hipLaunchKernelGGL(bf_grid_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, 0, d, (const int *)tris_raw.p, s->cell_tris.p,
-                           (float4 *)s->cell_pack.p, total);
+                           (float4 *)s->cell_pack.p, (float4 *)s->cell_box.p, total);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();       // tris_raw / cursor are released on return
     }

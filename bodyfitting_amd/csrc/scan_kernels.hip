@@ -127,6 +127,8 @@ __device__ inline int nn_wave_min_i(int v) {
 // routines right there: a call on the lanes concerned, its systems in the wave's slot of an LDS array (a version with private arrays
 // needed 104 registers and scratch memory; a second kernel doing such queries again cost 55 - 85 us per launch for a few hundred of
 // them, one wave-latency each).
+constexpr int NN_PASSES = 4;                    // passes of 64 list entries per trip through the screen: their loads are in flight together
+constexpr int NN_QCAP = 64 * (NN_PASSES + 1);   // a wave's queue of screened records
 #ifdef BF_NEAREST_STATS
 // diagnostic build (make CXXFLAGS+=-DBF_NEAREST_STATS): [0] queries [1] searches (1 + retries) [2] groups of cell lists [3] trips through
 // the screen [4] screen passes [5] records screened [6] rule passes [7] records through the rule
@@ -142,7 +144,7 @@ extern "C" int bf_nearest_stats_read(unsigned long long *out, int reset) {
 #endif
 template <int RULE>
 __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
-                  int *face, float *pts, float *__restrict__ bary, int warm, int id, int f) {
+                  int *face, float *pts, float *__restrict__ bary, int warm, int id, int f, float *scr, int *queue) {
     const int lane = threadIdx.x & 63;
     const ScanDev S = scans[f];
     const size_t o = (size_t)f * n + id;
@@ -154,11 +156,9 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
     // side where the home cell is past the middle this is one short of the far wall, and a query metres outside the grid (the only
     // kind that walks that far) never sees the last layer of cells.  Kept.
     const int maxL = max(max(cx > S.nx - cx ? cx : S.nx - cx, cy > S.ny - cy ? cy : S.ny - cy), cz > S.nz - cz ? cz : S.nz - cz) - 1;
-    __shared__ float s_general[RULE == BF_NEAREST_REFERENCE ? 4 * 20 * nrule::LANES : 1];     // the systems of the general routines, a slot per lane
-    float *scr = s_general + (RULE == BF_NEAREST_REFERENCE ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 20 * nrule::LANES + lane : 0);
-    constexpr int PASSES = 4;                                // passes of 64 list entries per trip through the screen: their loads are in flight together
-    __shared__ int s_queue[4 * 64 * (PASSES + 1)];           // per wave: the records that passed the screen and wait for the rule
-    int *queue = s_queue + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 64 * (PASSES + 1);
+    // scr: this lane's slot of the wave's [20][LANES] systems of the general routines; queue: the wave's NN_QCAP records that passed the
+    // screen and wait for the rule (both in LDS, the kernel's)
+    constexpr int PASSES = NN_PASSES;
     // `warm`: pts[] still holds this query's nearest point of the previous call: its squared distance from the query as it is now,
     // a shade enlarged, is (almost always) an upper bound of the answer.  It is only a guess - the search below is run with it and
     // CHECKED against what it found (the last lines of the loop).
@@ -166,9 +166,9 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
     if (warm) {
         const float ux = pts[o * 3] - qx, uy = pts[o * 3 + 1] - qy, uz = pts[o * 3 + 2] - qz;
         // (the slack covers what the rule's own value may lie above the true distance of a regular triangle, also for a query ON the
-        //  surface; a guess of a cell's size or more prunes nothing among the 27 cells and is dropped - so is a NaN)
+        //  surface; a NaN is no guess)
         const float u2 = (ux * ux + uy * uy + uz * uz) * 1.01f + 1e-7f;
-        U = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(u2 < S.step * S.step ? u2 : 3.0e38f)));
+        U = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(u2 < 3.0e38f ? u2 : 3.0e38f)));
     }
     // ---- shells 0 and 1 are one step over the 27-cell cube, lane c = (dz+1)*9 + (dy+1)*3 + (dx+1), the home cell is lane 13 (the
     // reference can never stop after shell 0: `best < 0`): list bounds and box distances of all 27 cells, once
@@ -194,12 +194,12 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
     const int st27 = st, cnt27 = cnt;
     // this lane's best so far (distance, face, coefficients); merged at the end
     float best, bc0, bc1, bc2, gbest;
-    int bface;
+    int bface, brec;                                          // (brec: the best triangle's record, for the result's corners)
     NSTAT(0, 1);
     for (;;) {
         NSTAT(1, 1);
         best = 3.0e38f; bc0 = 0.f; bc1 = 0.f; bc2 = 0.f;
-        bface = 0x7fffffff;
+        bface = 0x7fffffff; brec = 0;
         gbest = 3.0e38f;                                    // (wave-uniform) best distance the rule has returned so far
         float B = U;                                        // (wave-uniform) min(U, gbest): what cells and records are screened against
         int qn = 0;                                         // (wave-uniform) records in the queue
@@ -207,15 +207,17 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
         // 69 to 202 registers): cell sets (the home cell / the cube / 64 cells of a shell) > groups of up to six cell lists laid end to
         // end > trips of PASSES x 64 list entries through the screen, each followed by the rule on the queue when it holds 64 records -
         // or, on the extra trip that ends a cell set's last group, whatever it holds (`force`).
+        // (a guess of a cell's size or more prunes none of the 27 cells: the home cell goes first then too - its records screened
+        //  against the guess - and what it gives prunes the others)
         const bool cold = !(U < 3.0e38f);
-        int phase = cold ? 0 : 1, L = 1, chunk = 0;
+        int phase = U < S.step * S.step ? 1 : 0, L = 1, chunk = 0;
         st = st27; cnt = cnt27;
         for (;;) {
             // ---- the next cell set: lanes whose (st, cnt) lists are to be walked, and whether the queue is emptied after it
             unsigned long long cells;
             bool flush_after = true;
             if (phase == 0) cells = __ballot(cell_ok && lane == 13);                                   // no bound yet: the HOME cell's list first, through the rule ...
-            else if (phase == 1) cells = __ballot(cell_ok && (!cold || lane != 13) && !(B < d2));      // ... and the cube's other cells pruned with what it gave (or with U)
+            else if (phase == 1) cells = __ballot(cell_ok && (U < S.step * S.step || lane != 13) && !(B < d2));      // ... and the cube's other cells pruned with what it gave (or with U)
             else {
                 // shell L: 64 cells of its cube per set; only the shell (max |d| == L), in bounds, not beyond the bound
                 const int side = 2 * L + 1, ncube = side * side * side;
@@ -253,43 +255,44 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
                     cells &= cells - 1;
                 }
                 const int total = off[6];
+                int nlists = 1;
+#pragma unroll
+                for (int c = 1; c < 6; ++c) nlists += off[c + 1] > off[c] ? 1 : 0;
                 NSTAT(2, 1);
                 for (int e0 = 0;; e0 += 64 * PASSES) {
                     const int npass = min(PASSES, (total - e0 + 63) >> 6);       // (<= 0 on the extra trip)
                     if (npass > 0) {
                         NSTAT(3, 1); NSTAT(4, npass);
                         int rec[PASSES];
-                        float4 r0[PASSES], r1[PASSES], r2[PASSES];
+                        float4 lo[PASSES], hi[PASSES];
 #pragma unroll
                         for (int k = 0; k < PASSES; ++k)
                             if (k < npass) {                // (wave-uniform; every lane loads: one without an entry reads the group's first record)
                                 const int e = e0 + k * 64 + lane;
                                 int d = base[0];
 #pragma unroll
-                                for (int c = 1; c < 6; ++c) d = e >= off[c] ? base[c] : d;
+                                for (int c = 1; c < 6; ++c)
+                                    if (c < nlists) d = e >= off[c] ? base[c] : d;       // (wave-uniform: most groups are two or three lists)
                                 rec[k] = e < total ? e + d : -1;
-                                const size_t r = (size_t)(e < total ? e + d : base[0]) * 3;
-                                r0[k] = S.cell_pack[r]; r1[k] = S.cell_pack[r + 1]; r2[k] = S.cell_pack[r + 2];
+                                const size_t r = (size_t)(e < total ? e + d : base[0]) * 2;
+                                lo[k] = S.cell_box[r]; hi[k] = S.cell_box[r + 1];
                             }
                         // THE SCREEN.  A record goes to the rule only if its triangle's bounding box is not beyond B.  What makes that exact:
                         // the distance the reference's rule returns (the multiplier of its KKT system) is never below the true squared
                         // distance by more than 2e-7 x the largest squared corner distance - for every shape, needles and coincident corners
                         // included, where it may be far ABOVE it or NaN, and a NaN never wins a `<` (oracle/nearest_ref.c over millions of
                         // pairs: tests/test_nearest_ref_oracle.py) - and the distance to the box is a lower bound of the true
-                        // one.  With lb2 = squared distance to the box and fb2 = to its far corner: lb2 * 0.999 - 1e-5 * fb2 > B  =>  the
-                        // rule's value for this triangle is > B >= the final minimum: it can neither win nor tie.
+                        // one.  With lb2 = squared distance to the box and fb2 = to its far corner, lb2 * 0.999 - 1e-5 * fb2 > B  =>  the
+                        // rule's value for this triangle is > B >= the final minimum: it can neither win nor tie.  The far corner is within
+                        // a box diagonal of the near point, fb2 <= 2 lb2 + 2 diag^2, so the test is made with the record's own margin
+                        // m = 2.1e-5 diag^2 (grid_kernels.hip): lb2 * 0.998 - m > B.
 #pragma unroll
                         for (int k = 0; k < PASSES; ++k)
                             if (k < npass) {
-                                const float ax = r0[k].x - qx, ay = r0[k].y - qy, az = r0[k].z - qz, bx = r0[k].w - qx, by = r1[k].x - qy, bz = r1[k].y - qz,
-                                            gx = r1[k].z - qx, gy = r1[k].w - qy, gz = r2[k].x - qz;
-                                const float lx = fminf(fminf(ax, bx), gx), hx = fmaxf(fmaxf(ax, bx), gx);
-                                const float ly = fminf(fminf(ay, by), gy), hy = fmaxf(fmaxf(ay, by), gy);
-                                const float lz = fminf(fminf(az, bz), gz), hz = fmaxf(fmaxf(az, bz), gz);
+                                const float lx = lo[k].x - qx, ly = lo[k].y - qy, lz = lo[k].z - qz, hx = hi[k].x - qx, hy = hi[k].y - qy, hz = hi[k].z - qz;
                                 const float ex = fmaxf(fmaxf(lx, -hx), 0.f), ey = fmaxf(fmaxf(ly, -hy), 0.f), ez = fmaxf(fmaxf(lz, -hz), 0.f);
-                                const float fx = fmaxf(fabsf(lx), fabsf(hx)), fy = fmaxf(fabsf(ly), fabsf(hy)), fz = fmaxf(fabsf(lz), fabsf(hz));
-                                const float lb2 = ex * ex + ey * ey + ez * ez, fb2 = fx * fx + fy * fy + fz * fz;
-                                const bool pass = rec[k] >= 0 && !(lb2 * 0.999f - 1e-5f * fb2 > B);
+                                const float lb2 = ex * ex + ey * ey + ez * ez;
+                                const bool pass = rec[k] >= 0 && !(lb2 * 0.998f - lo[k].w > B);
                                 const unsigned long long m = __ballot(pass);
                                 if (pass) queue[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = rec[k];
                                 qn += __popcll(m);
@@ -302,7 +305,8 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
                         NSTAT(6, 1); NSTAT(7, count);
                         __builtin_amdgcn_wave_barrier();
                         if (lane < count) {
-                            const size_t r = (size_t)queue[lane] * 3;
+                            const int rq = queue[lane];
+                            const size_t r = (size_t)rq * 3;
                             const float4 q0 = S.cell_pack[r], q1 = S.cell_pack[r + 1], q2 = S.cell_pack[r + 2];
                             const float p[9] = {q0.x - qx, q0.y - qy, q0.z - qz, q0.w - qx, q1.x - qy, q1.y - qz, q1.z - qx, q1.w - qy, q2.x - qz};
                             const int t = __float_as_int(q2.y);
@@ -310,7 +314,7 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
                             float dist;
                             if (RULE == BF_NEAREST_FAST) dist = closest_rule(p, p + 3, p + 6, co);
                             else dist = nrule::nearest_proj_general(p, co, scr);
-                            if (dist < best || (dist == best && t < bface)) { best = dist; bface = t; bc0 = co[0]; bc1 = co[1]; bc2 = co[2]; }
+                            if (dist < best || (dist == best && t < bface)) { best = dist; bface = t; brec = rq; bc0 = co[0]; bc1 = co[1]; bc2 = co[2]; }
                         }
                         gbest = fminf(gbest, nn_wave_min_f(best));
                         B = fminf(U, gbest);
@@ -332,18 +336,18 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
             // ---- the set is done (and, if it ended a shell, the queue empty): the stop tests
             if (phase == 0) phase = 1;
             else if (phase == 1) {
-                // mesh_grid_kernel.cu:349 after shell 1 (gbest = 3e38 while nothing was found).  A guess - it is below step^2 - that the
-                // cube has not confirmed is wrong: the triangle behind a right one has its nearest point within a cell's size, so in one of
-                // these 27 cells, and would have passed the screen.
-                if (gbest < S.step * S.step || maxL < 2 || !cold) break;
+                // mesh_grid_kernel.cu:349 after shell 1 (gbest = 3e38 while nothing was found).  A guess below (L step)^2 that the shells up
+                // to L have not confirmed is wrong: the triangle behind a right one has its nearest point within L cells, so in one of the
+                // cells walked so far, and would have passed the screen.
+                if (gbest < S.step * S.step || maxL < 2 || U < S.step * S.step) break;
                 phase = 2; L = 2; chunk = 0;
             } else if (flush_after) {
-                if (gbest < (float)L * (float)L * S.step * S.step || L >= maxL) break;     // mesh_grid_kernel.cu:349
+                if (gbest < (float)L * (float)L * S.step * S.step || L >= maxL || U < (float)L * (float)L * S.step * S.step) break;     // mesh_grid_kernel.cu:349
                 ++L; chunk = 0;
             } else ++chunk;
         }
-        // THE CHECK of the guess U: everything skipped had a rule value above min(U, the best at that time).  If the cube ended with
-        // gbest <= U (< step^2: the reference stops there too), that is above the final minimum - the answer is the unscreened walk's.
+        // THE CHECK of the guess U: everything skipped had a rule value above min(U, the best at that time).  If the walk ended with
+        // gbest <= U, that is above the final minimum, and so was the value of every stop test - the answer is the unscreened walk's.
         // If not (the guess was not a point of the surface, or the rule's value for its triangle lies further above the true distance
         // than the slack), once more without the guess.
         if (cold || gbest <= U) break;
@@ -358,40 +362,60 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
     const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc0), wl < 0 ? 0 : wl));
     const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc1), wl < 0 ? 0 : wl));
     const float w2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bc2), wl < 0 ? 0 : wl));
-    if (lane != 0) return;
-    face[o] = found ? fmin_ : -1;
-    float r0 = qx, r1 = qy, r2 = qz;
-    if (found) {
-        const int *tv = S.faces + (size_t)fmin_ * 3;
-        const float *v0 = S.verts + (size_t)tv[0] * 3, *v1 = S.verts + (size_t)tv[1] * 3, *v2 = S.verts + (size_t)tv[2] * 3;
-        // proj = q + sum c_i (v_i - q), as the reference forms it (:318-329)
-        if (RULE != BF_NEAREST_FAST) {                     // ... every product and sum rounded, left to right
-            r0 = nrule::project(qx, w0, v0[0] - qx, w1, v1[0] - qx, w2, v2[0] - qx);
-            r1 = nrule::project(qy, w0, v0[1] - qy, w1, v1[1] - qy, w2, v2[1] - qy);
-            r2 = nrule::project(qz, w0, v0[2] - qz, w1, v1[2] - qz, w2, v2[2] - qz);
-        } else {
-            r0 = qx + w0 * (v0[0] - qx) + w1 * (v1[0] - qx) + w2 * (v2[0] - qx);
-            r1 = qy + w0 * (v0[1] - qy) + w1 * (v1[1] - qy) + w2 * (v2[1] - qy);
-            r2 = qz + w0 * (v0[2] - qz) + w1 * (v1[2] - qz) + w2 * (v2[2] - qz);
+    // the winner's corners: its record (a copy of the three vertices), found by its index - one round trip of wave-uniform loads
+    // instead of the face -> vertex indices -> vertices chase
+    const size_t wr = (size_t)__builtin_amdgcn_readlane(brec, wl < 0 ? 0 : wl) * 3;
+    // (no early return for the other lanes: inlined into a loop it becomes a `continue`, and the lanes then run ahead of lane 0)
+    if (lane == 0) {
+        face[o] = found ? fmin_ : -1;
+        float r0 = qx, r1 = qy, r2 = qz;
+        if (found) {
+            const float4 q0 = S.cell_pack[wr], q1 = S.cell_pack[wr + 1], q2 = S.cell_pack[wr + 2];
+            const float v0[3] = {q0.x, q0.y, q0.z}, v1[3] = {q0.w, q1.x, q1.y}, v2[3] = {q1.z, q1.w, q2.x};
+            // proj = q + sum c_i (v_i - q), as the reference forms it (:318-329)
+            if (RULE != BF_NEAREST_FAST) {                     // ... every product and sum rounded, left to right
+                r0 = nrule::project(qx, w0, v0[0] - qx, w1, v1[0] - qx, w2, v2[0] - qx);
+                r1 = nrule::project(qy, w0, v0[1] - qy, w1, v1[1] - qy, w2, v2[1] - qy);
+                r2 = nrule::project(qz, w0, v0[2] - qz, w1, v1[2] - qz, w2, v2[2] - qz);
+            } else {
+                r0 = qx + w0 * (v0[0] - qx) + w1 * (v1[0] - qx) + w2 * (v2[0] - qx);
+                r1 = qy + w0 * (v0[1] - qy) + w1 * (v1[1] - qy) + w2 * (v2[1] - qy);
+                r2 = qz + w0 * (v0[2] - qz) + w1 * (v1[2] - qz) + w2 * (v2[2] - qz);
+            }
         }
+        pts[o * 3] = r0; pts[o * 3 + 1] = r1; pts[o * 3 + 2] = r2;
+        if (bary) { bary[o * 3] = found ? w0 : 0.f; bary[o * 3 + 1] = found ? w1 : 0.f; bary[o * 3 + 2] = found ? w2 : 0.f; }
     }
-    pts[o * 3] = r0; pts[o * 3 + 1] = r1; pts[o * 3 + 2] = r2;
-    if (bary) { bary[o * 3] = found ? w0 : 0.f; bary[o * 3 + 1] = found ? w1 : 0.f; bary[o * 3 + 2] = found ? w2 : 0.f; }
 }
+
+// A launch covers F frames, each with its own scan: the grid is ONE-dimensional and frame-MINOR - workgroup l works on frame l % F, block
+// l / F of it.  Workgroups go to the eight XCDs round-robin by their linear id, so with F = 8 (config 5's shard; any F that divides 8 or
+// is a multiple of it) a frame's workgroups all land on one XCD and its scan's records (4 + 6 MB) are that XCD's L2 contents instead of
+// one eighth of every scan's.
+#define NN_FRAME(F) ((int)(blockIdx.x % (unsigned)(F)))
+#define NN_BLOCK(F) ((int)(blockIdx.x / (unsigned)(F)))
+#define NN_WAVE_LDS(RULE)                                                                                                               \
+    __shared__ float s_general[RULE == BF_NEAREST_REFERENCE ? 4 * 20 * nrule::LANES : 1];                                                \
+    __shared__ int s_queue[4 * NN_QCAP];                                                                                                 \
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* (told to the compiler as the wave-uniform value it is: the walk's bookkeeping then lives in scalar registers) */ \
+    float *scr = s_general + (RULE == BF_NEAREST_REFERENCE ? wave * 20 * nrule::LANES + (threadIdx.x & 63) : 0);                          \
+    int *queue = s_queue + wave * NN_QCAP;
 
 extern "C" __global__ void __launch_bounds__(256)
 bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
-                  int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
-    const int id = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (the wave's query: told to the compiler as the wave-uniform value it is - the walk's bookkeeping then lives in scalar registers)
+                  int *face, float *pts, float *__restrict__ bary, int warm, int n_frames) {
+    NN_WAVE_LDS(BF_NEAREST_REFERENCE)
+    const int id = NN_BLOCK(n_frames) * 4 + wave;
     if (id >= n) return;
-    nearest_body<BF_NEAREST_REFERENCE>(scans, points, n, face, pts, bary, warm, id, blockIdx.y);
+    nearest_body<BF_NEAREST_REFERENCE>(scans, points, n, face, pts, bary, warm, id, NN_FRAME(n_frames), scr, queue);
 }
 extern "C" __global__ void __launch_bounds__(256)
 bf_nearest_fast_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
-                       int *face, float *__restrict__ pts, float *__restrict__ bary, int warm) {
-    const int id = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+                       int *face, float *pts, float *__restrict__ bary, int warm, int n_frames) {
+    NN_WAVE_LDS(BF_NEAREST_FAST)
+    const int id = NN_BLOCK(n_frames) * 4 + wave;
     if (id >= n) return;
-    nearest_body<BF_NEAREST_FAST>(scans, points, n, face, pts, bary, warm, id, blockIdx.y);
+    nearest_body<BF_NEAREST_FAST>(scans, points, n, face, pts, bary, warm, id, NN_FRAME(n_frames), scr, queue);
 }
 
 // nearest_rule_ref.h's division helper and per-triangle rule, exposed for the tests (bf_nearest_selftest_*)
@@ -428,10 +452,13 @@ extern "C" int bf_nearest_rule_set(int rule) {
 }
 extern "C" void bf_nearest_launch(dim3 grid, hipStream_t stream, const ScanDev *scans, const float *points, int n, int *face, float *pts,
                                   float *bary, int warm) {
+    // (grid = (ceil(n / 4), frames) as the callers think of it: one query per wave; launched one-dimensional and frame-minor, NN_FRAME)
+    const int F = (int)grid.y;
+    const dim3 sgrid(grid.x * F);
     if (bf_nearest_rule_get() == BF_NEAREST_FAST)
-        hipLaunchKernelGGL(bf_nearest_fast_kernel, grid, dim3(256), 0, stream, scans, points, n, face, pts, bary, warm);
+        hipLaunchKernelGGL(bf_nearest_fast_kernel, sgrid, dim3(256), 0, stream, scans, points, n, face, pts, bary, warm, F);
     else
-        hipLaunchKernelGGL(bf_nearest_kernel, grid, dim3(256), 0, stream, scans, points, n, face, pts, bary, warm);
+        hipLaunchKernelGGL(bf_nearest_kernel, sgrid, dim3(256), 0, stream, scans, points, n, face, pts, bary, warm, F);
 }
 
 // grid (nblk, F): partial[f][blk] = sum over this block's vertices of |P - C|^2

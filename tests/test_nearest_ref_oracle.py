@@ -243,7 +243,7 @@ def test_the_rules_distance_never_undershoots_the_true_one(fused):
     not handed to the rule).  The distance search_nearest_proj returns is the multiplier of its KKT system, not a norm, and on needles,
     obtuse triangles and coincident corners it can be far ABOVE the true squared distance, or NaN (which never wins the reference's
     `<`) - but it is never BELOW it by more than rounding: 2e-7 x the largest squared corner distance over every family here (the
-    kernel allows 1e-5 x the squared distance to the box's far corner + 0.1 % of the box distance).  Checked in both roundings the
+    kernel allows 1e-5 x the squared distance to the box's far corner + 0.1 % of the box distance, in the form of a margin per record).  Checked in both roundings the
     reference's compiler may produce, and as the very inequality the kernel evaluates."""
     rng = np.random.default_rng(11)
     worst = 0.0
@@ -266,4 +266,11 @@ def test_the_rules_distance_never_undershoots_the_true_one(fused):
         lb2 = (e * e).sum(1, dtype=np.float32); fb2 = (f * f).sum(1, dtype=np.float32)
         bound = lb2 * np.float32(0.999) - np.float32(1e-5) * fb2
         assert not (ok & (dref < bound)).any(), name                    # skipped  =>  the rule's value is above the bound it was skipped against
+        # ... which the kernel evaluates with a margin per record instead of the far corner (grid_kernels.hip: 2.1e-5 x the squared
+        # diagonal of the triangle's box in world coordinates; fb2 <= 2 lb2 + 2 diag^2): never a sharper test than the one above
+        ext = V.max(1) - V.min(1)
+        margin = np.float32(2.1e-5) * (ext * ext).sum(1, dtype=np.float32)
+        kernel_bound = lb2 * np.float32(0.998) - margin
+        assert (kernel_bound <= bound + np.float32(1e-6) * np.abs(bound)).all(), name
+        assert not (ok & (dref < kernel_bound)).any(), name
     assert worst > 1e-8                                                   # (the families do reach the rounding level: the test is not vacuous)
