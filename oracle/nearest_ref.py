@@ -36,6 +36,8 @@ def lib(fused=False):
     name = "libnearest_oracle_fma.so" if fused else "libnearest_oracle.so"
     if name not in _libs:
         path = os.path.join(HERE, name)
+        if not fused and os.environ.get("BF_NEAREST_ORACLE_LIB"):          # (`make -C oracle sanitize`: the strict build under ASan / UBSan)
+            path = os.path.abspath(os.environ["BF_NEAREST_ORACLE_LIB"])
         if not os.path.exists(path):
             build()
         L = C.CDLL(path)
