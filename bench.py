@@ -626,8 +626,10 @@ def main():
                 if fb == F:
                     continue
                 bb = build_batch(dev, model, list(range(fb)), a.views, distinct=64)      # (64 distinct frames, repeated: 76 ms of host time per synthetic frame)
-                n = 10
-                e = event_leg(bb, n, a.iters, _lib.FIT_FETCH)                                  # (with events: device times)
+                # (steps per bracket: a bracket ends with the last step's result download - 21 MB at 256 frames, 0.39 ms - which no next fit hides:
+                #  with 10 steps it is 7 % of the bracket, the steady state is what a capture sees)
+                n = 50 if fb <= 256 else 20
+                e = event_leg(bb, 10, a.iters, _lib.FIT_FETCH)                                  # (with events: device times)
                 w, _ = timed_brackets(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_NOTIME, 3, bb.sync)
                 wg, _ = timed_brackets(bb, n, 2, a.iters, _lib.FIT_FETCH | _lib.FIT_GRAPH, 3, bb.sync)   # (pipelined fetch from 8 frames on)
                 wh, wgm = statistics.median(w), statistics.median(wg)
