@@ -166,7 +166,7 @@ def event_leg(batch, steps, iters, flags):
     return batch.timing_sum()
 
 
-def scaling_legs(mode, model, gmm, dev, n_gpus, rank, views, iters, comm, per_gpu=(32, 256), steps=10):
+def scaling_legs(mode, model, gmm, dev, n_gpus, rank, views, iters, comm, per_gpu=(32, 256), steps=40):
     """Config 2's job at CU-filling sizes, for the N-GPU modes: `per_gpu` frames on every GPU (32 = BASELINE config 4's shard: 32 of a GPU's
     256 CUs busy; 256 = one frame per CU), one RCCL all-gather per job - and THE SAME TOTAL JOB ON ONE GPU next to it, so that the line
     carries weak scaling (per-GPU work fixed) and strong scaling (total work fixed) of the same code.  Every rank runs this (the gather
