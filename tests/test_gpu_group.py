@@ -114,6 +114,17 @@ def test_group_with_scans_and_masks_equals_a_plain_batch(threads, monkeypatch):
         b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose); b.set_masks(masks, mask_frames, contours)
         b.fit(15, flags=_lib.FIT_FETCH)
         np.testing.assert_array_equal(g.gather_params(), b.get_params())
+    # the NEXT step's silhouettes staged under the fit in flight (bf_group_stage_masks: every device its block) == set between the fits
+    probs2 = [S.make_problem(model, frame=f + 3, n_views=8, mask_frames=mask_frames) for f in range(3)]
+    _, _, kp2, ndiv2, betas2, pose2 = N.pack_problem(probs2)
+    masks2 = np.stack([np.array(p["masks"]) for p in probs2])
+    g.set_masks(masks, mask_frames, None)                    # (device contours: what staging continues from)
+    g.stage_inputs(kp, ndiv, betas, pose); g.fit(15, flags=_lib.FIT_FETCH | _lib.FIT_RESET)
+    g.stage_masks(masks2, mask_frames)
+    g.stage_inputs(kp2, ndiv2, betas2, pose2); g.fit(15, flags=_lib.FIT_FETCH | _lib.FIT_RESET)
+    b.set_keypoints(kp2, ndiv2); b.set_init(betas2, pose2); b.set_masks(masks2, mask_frames, None)
+    b.fit(15, flags=_lib.FIT_FETCH)
+    np.testing.assert_array_equal(g.gather_params(), b.get_params())
     for s in scans:
         s.close()
     b.close(); dev.close(); g.close()
