@@ -244,6 +244,26 @@ def test_a_guess_bounds_the_search_and_never_changes_its_answer(small, spread):
     assert wrong == 0
 
 
+@pytest.mark.parametrize("scale", [1.0, 0.01])
+def test_guesses_on_the_adversarial_soup(scale):
+    """the guessed search where the reference takes rank decisions (needles, slivers, obtuse triangles; at centimetre scale the absolute
+    1e-9 tests fire): exact, half-way, NaN and mixed guesses give the unguessed search's bits - which are the reference arithmetic's
+    (test_nearest_equals_the_references_own_arithmetic_on_slivers)"""
+    from oracle import adversarial as ADV
+    d = ADV.soup(seed=0, min_margin=0.0)
+    v = (d["verts"].astype(np.float64) * scale).astype(np.float32)
+    q = (d["queries"].astype(np.float64) * scale).astype(np.float32)
+    scan = N.Scan(v, d["faces"])
+    pts, ids, bary = scan.nearest_points(q)
+    rng = np.random.default_rng(2)
+    for name, g in (("exact", pts), ("half way", (pts + q) / 2), ("nan", np.full_like(pts, np.nan)),
+                    ("mixed", np.where(rng.random((len(q), 1)) < 0.5, pts, pts + np.float32(0.3 * scale)))):
+        p2, i2, b2 = scan.nearest_points_hinted(q, g.astype(np.float32))
+        assert np.array_equal(i2, ids), name
+        assert np.array_equal(p2.view(np.uint32), pts.view(np.uint32)) and np.array_equal(b2.view(np.uint32), bary.view(np.uint32)), name
+    scan.close()
+
+
 def test_rule_on_the_device_equals_the_oracle_patch_by_patch():
     """search_nearest_proj on explicit patches: regular, degenerate (repeated corners, collinear), far (Gram entries above 1) and
     tiny ones; distance and coefficients bit for bit against oracle/nearest_ref.c"""
