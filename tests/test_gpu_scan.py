@@ -400,6 +400,13 @@ def test_nearest_at_config5_size_against_bruteforce():
     assert np.mean(ids[sample] == ids_o) > 0.8                      # (a closest point on a shared edge / vertex ties between the faces around it)
     again = scan.nearest_points(q)
     np.testing.assert_array_equal(again[1], ids)                    # deterministic
+    # the same queries the way an iteration of the fit loop searches them: with the answers of the iteration before as guesses (here:
+    # the answers for queries 0.5 mm / 5 mm away) - the guess only bounds the search, the result is the unguessed one, bit for bit
+    for moved in (0.0005, 0.005):
+        before = scan.nearest_points((q + rng.normal(0, moved, q.shape)).astype(np.float32))[0]
+        p2, i2, b2 = scan.nearest_points_hinted(q, before)
+        np.testing.assert_array_equal(i2, ids)
+        assert np.array_equal(p2.view(np.uint32), pts.view(np.uint32)) and np.array_equal(b2.view(np.uint32), bary.view(np.uint32))
     scan.close()
     # and EVERY query against the reference's own float32 arithmetic (the grid walk of oracle/nearest_ref.c): faces equal outside
     # exact ties, points and coefficients bit for bit
