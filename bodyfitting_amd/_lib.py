@@ -58,6 +58,7 @@ SIGNATURES = {
     "bf_model_create": (C.c_int, [C.POINTER(ModelDesc), C.c_int, C.POINTER(_VP)]),
     "bf_model_destroy": (None, [_VP]),
     "bf_model_n_params": (C.c_int, [_VP]),
+    "bf_model_fit_instance": (C.c_int, [_VP]),
     "bf_smpl_forward": (C.c_int, [_VP, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP]),
     "bf_model_forward": (C.c_int, [_VP, C.c_int, _FP, _FP, _FP]),
     "bf_batch_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(_VP)]),

@@ -5,8 +5,11 @@ The reference reads `data/smpl/*.pkl` through smplx, `data/J_regressor_extra.npy
 per *frame*.  Here a model is resolved once per process and cached per (type, gender, device):
 
   1. a dict registered with `register_model(...)` (tests, synthetic benchmarks),
-  2. an `.npz` with the smplx tensor names under `data/` (`{type}_{gender}.npz`),
-  3. otherwise a clear error - nothing is downloaded and nothing is silently replaced.
+  2. the files the reference itself opens - `data/smpl/SMPL_{GENDER}.pkl` + `data/J_regressor_extra.npy` (config.py:1-4,
+     models/smpl.py:56-66) or `data/smplx/SMPLX_{GENDER}.npz` (smplify.py:63-80) - converted as smplx converts them
+     (`model_files`),
+  3. an `.npz` already in this package's tensor layout under `data/` (`{type}_{gender}.npz`),
+  4. otherwise a clear error - nothing is downloaded and nothing is silently replaced.
 """
 from __future__ import annotations
 
@@ -14,6 +17,8 @@ import os
 import pickle
 
 import numpy as np
+
+from . import model_files
 
 _MODELS = {}
 _GMM = {}
@@ -50,11 +55,14 @@ def get_model(model_type="smpl", gender="neutral"):
     for key in ((model_type, gender), (model_type, "neutral")):
         if key in _MODELS:
             return _MODELS[key]
-    model = _load_npz_model(model_type, gender)
+    model = model_files.load(model_type, gender)
     if model is None:
+        model = _load_npz_model(model_type, gender)
+    if model is None:
+        official = "data/smpl/SMPL_%s.pkl + data/J_regressor_extra.npy" % gender.upper() if model_type == "smpl" else "data/smplx/SMPLX_%s.npz" % gender.upper()
         raise FileNotFoundError(
-            f"no {model_type}/{gender} body model: register one with bodyfitting_amd.assets.register_model() "
-            f"or place data/{model_type}_{gender}.npz (smplx tensor names) next to the working directory")
+            f"no {model_type}/{gender} body model: place {official} (the files the reference reads) next to the working "
+            f"directory, or register a model dict with bodyfitting_amd.assets.register_model()")
     _MODELS[(model_type, gender)] = model
     return model
 

@@ -462,6 +462,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
 
 void bf_model_destroy(bf_model *m) { delete m; }
 int bf_model_n_params(const bf_model *m) { return m ? m->np : 0; }
+int bf_model_fit_instance(const bf_model *m) { return (m && bf_fit_is_sized_smpl(&m->fit)) ? 1 : 0; }
 
 int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw, int *lmk_vid,

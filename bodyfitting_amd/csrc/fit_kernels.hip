@@ -1964,11 +1964,15 @@ extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int
     return fit_smem_carve(s, nullptr, nj, nb, npf, ns, nl, np, nviews);
 }
 
+// (the compile-time-sized SMPL instance also assumes at most 4 bones per selector vertex - true of SMPL's skinning weights)
+extern "C" bool bf_fit_is_sized_smpl(const FitTab *T) {
+    return T->nj == 24 && T->nb == 10 && T->ns == 11 && T->nl == 25 && T->sel_nnz > 0 && T->sel_nnz <= 4;
+}
+
 // Host-side launcher: picks the compile-time-sized instantiation for SMPL, the table-driven one otherwise.
 extern "C" hipError_t bf_fit_launch(const FitTab *T, const FrameIO *io, const HyperDev *hp, int n_iters, int mode,
                                     const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
-    // (the compile-time-sized SMPL instance also assumes at most 4 bones per selector vertex - true of SMPL's skinning weights)
-    const bool smpl = T->nj == 24 && T->nb == 10 && T->ns == 11 && T->nl == 25 && T->sel_nnz > 0 && T->sel_nnz <= 4;
+    const bool smpl = bf_fit_is_sized_smpl(T);
     const bool ext = io->ext != nullptr;
     // SMPL-X in the dense schedule (keypoints through bf_kp_loss_kernel: no selector vertices, no loss joints here): sizes fixed
     // at compile time like SMPL's, the phases stay the table-driven ones

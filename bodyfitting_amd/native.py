@@ -93,6 +93,7 @@ class DeviceModel:
         del keep
         self.device = int(device)
         self.n_params = lib.bf_model_n_params(self._h)
+        self.fit_instance = "sized" if lib.bf_model_fit_instance(self._h) else "table-driven"
 
     def close(self):
         if getattr(self, "_h", None):

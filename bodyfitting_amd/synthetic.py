@@ -30,6 +30,7 @@ import numpy as np
 
 from .assets import gmm_buffers                                   # noqa: F401  (product code; re-exported for the tests)
 from .keypoints import FACE_MAPPING, pack_keypoints_smplx          # noqa: F401
+from .layout import SELECTOR_ORDER, SMPL_JOINT_MAP, smpl_to_openpose   # noqa: F401  (the product's tables: constants.py:71-89, models/utils.py:32-141)
 
 # kinematic trees (smplx 0.1.13 semantics)
 SMPL_PARENTS = np.array(
@@ -74,13 +75,6 @@ _SMPL_REST = np.array([
 _SMPL_RADIUS = np.array([
     0.0, 0.085, 0.085, 0.120, 0.070, 0.070, 0.125, 0.050, 0.050, 0.125, 0.040, 0.040,
     0.055, 0.070, 0.070, 0.095, 0.055, 0.055, 0.045, 0.045, 0.035, 0.035, 0.030, 0.030])
-
-# JOINT_MAP of the reference, evaluated over JOINT_NAMES (constants.py:13-89)
-SMPL_JOINT_MAP = np.array(
-    [24, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
-     8, 5, 45, 46, 4, 7, 21, 19, 17, 16, 18, 20, 47, 48, 49, 50, 51, 52, 53, 24, 26, 25, 28, 27],
-    dtype=np.int32)
-
 
 def _smplx_rest():
     """55-joint rest skeleton: the SMPL body (22 joints) + jaw/eyes + 2x15 finger joints."""
@@ -331,10 +325,68 @@ def _add_smplx_extras(out, rng, verts, faces, rest, taken):
     out["dynamic_lmk_bary_coords"] = bary(79 * 17).reshape(79, 17, 3)
     out["neck_kin_chain"] = np.array([12, 9, 6, 3, 0], dtype=np.int32)
     # reference models/utils.py:75-94 with use_hands, use_face, use_face_contour -> 135 joints
-    body = [55, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 56, 57, 58, 59, 60, 61, 62, 63, 64, 65]
-    lhand = [20, 37, 38, 39, 66, 25, 26, 27, 67, 28, 29, 30, 68, 34, 35, 36, 69, 31, 32, 33, 70]
-    rhand = [21, 52, 53, 54, 71, 40, 41, 42, 72, 43, 44, 45, 73, 49, 50, 51, 74, 46, 47, 48, 75]
-    out["joint_map"] = np.array(body + lhand + rhand + list(range(76, 127 + 17)), dtype=np.int32)
+    out["joint_map"] = smpl_to_openpose("smplx", use_hands=True, use_face=True, use_face_contour=True)
+
+
+def write_official_files(model, folder, gender="neutral", shape_columns=None):
+    """Write `model` (a dict of this module) the way the licensed files are laid out, so that the product's loaders
+    (`model_files`, the path apps/genebody_fitting.py takes through smplx) can be tested without them:
+
+      SMPL   -> {folder}/smpl/SMPL_{GENDER}.pkl: a pickled dict with `v_template[NV,3]`, `shapedirs[NV,3,10]`, `posedirs[NV,3,207]`,
+                `J_regressor` (scipy.sparse csc), `weights[NV,24]`, `kintree_table[2,24]` (uint32, root parent 2^32 - 1), `f` (uint32),
+                + {folder}/J_regressor_extra.npy, J_regressor_h36m.npy (config.py:1-2);
+      SMPL-X -> {folder}/smplx/SMPLX_{GENDER}.npz with the same keys + `hands_components{l,r}[45,45]`, `hands_mean{l,r}[45]`,
+                `lmk_faces_idx`, `lmk_bary_coords`, `dynamic_lmk_*`; `shape_columns` = 20 (v1.0 layout) or 400 (v1.1: expression at 300).
+    Returns (path, vertex_ids): the selector vertices of a synthetic template are not the licensed topology's, so they come back as
+    the dict smplx's `vertex_ids` argument takes."""
+    import pickle
+    import scipy.sparse as sp
+    mt = model.get("model_type", "smpl")
+    nv, nj = model["lbs_weights"].shape
+    P = model["posedirs"].shape[0]
+    kin = np.stack([np.asarray(model["parents"]).astype(np.int64) % (1 << 32), np.arange(nj)]).astype(np.uint32)
+    d = {
+        "v_template": np.asarray(model["v_template"], np.float64),
+        "posedirs": np.ascontiguousarray(np.asarray(model["posedirs"], np.float64).T.reshape(nv, 3, P)),
+        "J_regressor": sp.csc_matrix(np.asarray(model["J_regressor"], np.float64)),
+        "weights": np.asarray(model["lbs_weights"], np.float64),
+        "kintree_table": kin,
+        "f": np.asarray(model["faces"]).astype(np.uint32),
+    }
+    vertex_ids = {k: int(v) for k, v in zip(SELECTOR_ORDER, model["selector_ids"])}
+    if mt == "smpl":
+        d["shapedirs"] = np.asarray(model["shapedirs"], np.float64)
+        os.makedirs(os.path.join(folder, "smpl"), exist_ok=True)
+        path = os.path.join(folder, "smpl", "SMPL_%s.pkl" % gender.upper())
+        with open(path, "wb") as f:
+            pickle.dump(d, f, protocol=2)
+        np.save(os.path.join(folder, "J_regressor_extra.npy"), np.asarray(model["J_regressor_extra"], np.float64))
+        np.save(os.path.join(folder, "J_regressor_h36m.npy"), np.asarray(model["J_regressor_h36m"], np.float64))
+        return path, vertex_ids
+    sd = np.asarray(model["shapedirs"], np.float64)
+    ncol = int(shape_columns or 20)
+    full = np.zeros((nv, 3, ncol))
+    full[:, :, :10] = sd[:, :, :10]
+    e0 = 300 if ncol >= 310 else 10
+    full[:, :, e0:e0 + 10] = sd[:, :, 10:20]
+    if ncol >= 310:
+        full[:, :, 10:300] = 0.125                      # directions the loader must NOT pick up
+    d["shapedirs"] = full
+    rng = np.random.default_rng(7)
+    for side, key in (("l", "left_hand_components"), ("r", "right_hand_components")):
+        comp = rng.normal(0.0, 0.3, size=(45, 45))      # the file holds all 45 components; the first six are the model's
+        comp[:6] = model[key]
+        d["hands_components" + side] = comp
+    pm = np.asarray(model["pose_mean"], np.float64)
+    d["hands_meanl"], d["hands_meanr"] = pm[3 * (nj - 30):3 * (nj - 15)].copy(), pm[3 * (nj - 15):].copy()
+    d["lmk_faces_idx"] = np.asarray(model["lmk_faces_idx"]).astype(np.int64)
+    d["lmk_bary_coords"] = np.asarray(model["lmk_bary_coords"], np.float64)
+    d["dynamic_lmk_faces_idx"] = np.asarray(model["dynamic_lmk_faces_idx"]).astype(np.int64)
+    d["dynamic_lmk_bary_coords"] = np.asarray(model["dynamic_lmk_bary_coords"], np.float64)
+    os.makedirs(os.path.join(folder, "smplx"), exist_ok=True)
+    path = os.path.join(folder, "smplx", "SMPLX_%s.npz" % gender.upper())
+    np.savez(path, **{k: (v.toarray() if hasattr(v, "toarray") else v) for k, v in d.items()})
+    return path, vertex_ids
 
 
 def model_digest(model):

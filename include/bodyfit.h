@@ -135,6 +135,10 @@ void bf_model_destroy(bf_model *m);
 /* number of optimised scalars per frame: 86 for SMPL, laid out in the reference's optimiser order
  * (smplify.py:167-171): global_transl[3] body_scale[1] body_pose[69] betas[10] global_orient[3] */
 int bf_model_n_params(const bf_model *m);
+/* which instance of the persistent keypoint fit this model takes (no reference counterpart: the reference has one code path):
+ * 1 = sizes fixed at compile time (24 joints, 10 betas, 11 loss selector vertices with at most 4 bones each, 25 loss joints: SMPL
+ * as models/smpl.py:56-66 builds it), 0 = table-driven (any other model; ~2.5x more cycles per iteration) */
+int bf_model_fit_instance(const bf_model *m);
 
 /* models.smpl.SMPL.forward (models/smpl.py:69-83) for `n` parameter sets:
  * betas[n,NB], global_orient[n,3], body_pose[n,3(NJ-1)] ->

@@ -40,9 +40,35 @@ def test_dropin_import_lines():
         from smplify.smplify import SMPLify as S2
         from models.smpl import SMPL as M
         assert B is BodyFitting and S2 is SMPLify and M is SMPL
+        from utils.mesh_grid_searcher import MeshGridSearcher as G1     # smplify/smplify.py:15
+        from mesh_grid_searcher import MeshGridSearcher as G2           # thirdparty/mesh_grid/test_mesh_grid.py:2
+        from bodyfitting_amd.mesh_grid_searcher import MeshGridSearcher as G0
+        assert G1 is G0 and G2 is G0
+        import utils
+        assert os.path.abspath(utils.__path__[0]) == os.path.join(REPO, "bodyfitting_amd", "dropin", "utils")
     finally:
         sys.path.pop(0)
-        for mod in [m for m in sys.modules if m.split(".")[0] in ("smplify", "models")]:
+        for mod in [m for m in sys.modules if m.split(".")[0] in ("smplify", "models", "utils", "mesh_grid_searcher")]:
+            sys.modules.pop(mod)
+
+
+def test_dropin_utils_package_still_reaches_the_callers_own_utils(tmp_path):
+    """apps/genebody_fitting.py:14 imports utils.io_utils next to the drop-in: a `utils` package further down sys.path keeps resolving"""
+    (tmp_path / "utils").mkdir()
+    (tmp_path / "utils" / "__init__.py").write_text("")
+    (tmp_path / "utils" / "io_utils.py").write_text("MARK = 41\n")
+    sys.path.insert(0, str(tmp_path))
+    sys.path.insert(0, os.path.join(REPO, "bodyfitting_amd", "dropin"))
+    try:
+        for mod in [m for m in sys.modules if m.split(".")[0] == "utils"]:
+            sys.modules.pop(mod)
+        from utils.io_utils import MARK
+        from utils.mesh_grid_searcher import MeshGridSearcher
+        assert MARK == 41 and MeshGridSearcher.__module__ == "bodyfitting_amd.mesh_grid_searcher"
+    finally:
+        sys.path.pop(0)
+        sys.path.pop(0)
+        for mod in [m for m in sys.modules if m.split(".")[0] == "utils"]:
             sys.modules.pop(mod)
 
 

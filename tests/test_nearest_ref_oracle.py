@@ -38,9 +38,16 @@ def test_elimination_equals_the_references_matrix_h_on_the_committed_vectors(n, 
         assert (g["valid%d" % n] == 0).sum() > 40       # the rank-deficient paths are in the vectors
 
 
-@pytest.mark.skipif(NR.matrix_ref_lib() is None, reason="oracle/_ref/libmatrix_ref.so needs /root/reference to be built")
+@pytest.fixture(scope="module")
+def matrix_ref_library():
+    """loaded when the live test runs, not when the file is collected: the GPU box neither has nor needs oracle/_ref (the committed
+    vectors above serve there), and no `-m gpu` process should map a compiled form of reference code"""
+    if NR.matrix_ref_lib() is None:
+        pytest.skip("oracle/_ref/libmatrix_ref.so needs /root/reference to be built")
+
+
 @pytest.mark.parametrize("n", [3, 4])
-def test_elimination_equals_the_references_matrix_h_live(n):
+def test_elimination_equals_the_references_matrix_h_live(n, matrix_ref_library):
     import importlib.util
     import os
     spec = importlib.util.spec_from_file_location("gen_matrix_vectors", os.path.join(os.path.dirname(NR.HERE), "oracle", "gen_matrix_vectors.py"))
