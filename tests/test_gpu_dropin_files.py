@@ -33,7 +33,13 @@ def test_mesh_grid_searcher_with_the_references_test_sequence():
     sdf = np.linalg.norm(near - pts, axis=1) * inside                 # :27
     ids_ref, near_ref, _ = MO.nearest_bruteforce(sv, sf, pts)       # the reference rule over ALL faces, float64
     np.testing.assert_allclose(np.abs(sdf), np.linalg.norm(near_ref - pts, axis=1), atol=2e-5)
-    assert np.mean(face_ids == ids_ref) > 0.97                        # (equidistant faces along a shared edge may swap)
+    # ... and the reference's own float32 arithmetic (oracle/nearest_ref.c) on the grid the device built: where the faces agree
+    # (everywhere but on exact ties along shared edges / corners) the points are the same bits
+    from oracle import nearest_ref as NR
+    f_o, p_o, _, _ = NR.search_nearest(grid.verts, grid.faces, pts, (float(grid.step), grid.num[:3], grid.minmax[:3], grid.tri_num, grid.tri_idx))
+    same = face_ids == f_o
+    assert same.mean() > 0.8 and (near[same].view(np.uint32) == p_o[same].view(np.uint32)).all()
+    assert np.abs(near[~same] - p_o[~same]).max(initial=0.0) < 1e-6
     want_inside = MO.inside_mesh(sv, sf, pts, grid.step, grid.minmax[:3], grid.num[:3], grid.tri_num, grid.tri_idx)
     np.testing.assert_array_equal(inside, want_inside)
     assert set(np.unique(inside)) == {-1.0, 1.0}
