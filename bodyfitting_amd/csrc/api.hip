@@ -690,6 +690,7 @@ void bf_batch_destroy(bf_batch *b) {
     if (!b) return;
     if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    { std::lock_guard<std::mutex> lk(bf_scan_links()); bf_batch_unlink_scans(b); }      // (its scans outlive it: they forget this batch)
     if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
     for (auto &e : b->ring) if (e) (void)hipEventDestroy(e);
     if (b->h_res) (void)hipHostFree(b->h_res);

@@ -34,33 +34,57 @@ inline hipError_t bf_memset_sync(void *p, int value, size_t bytes) {
 // A cache of freed device blocks per device (bf_pool_alloc / bf_pool_free), for objects that come and go with every frame of a
 // capture: a scan is created, attached, fitted against and destroyed once per frame (apps/genebody_fitting.py:183-192), and every
 // hipFree waits for the whole device - i.e. for the fit of the PREVIOUS frame that is still running - while a hipMalloc of a fresh
-// block costs tens of microseconds.  A block is handed out again for a request of its size up to 25 % smaller; the cache holds at
-// most 2 GB per device (beyond that a block is really freed).  The caller guarantees what hipFree used to: nothing on the device
-// still uses a block it gives back (bf_scan_destroy waits for the device itself when the scan is still attached to a batch).
+// block costs tens of microseconds.  A block is handed out again for a request of its size up to 25 % smaller (and comes back under its true size); the
+// cache holds at most 2 GB per device (beyond that a block is really freed), gives everything back when a hipMalloc fails, and
+// bf_pool_trim() empties it.  The caller guarantees what hipFree used to: nothing on the device
+// still uses a block it gives back (bf_scan_destroy waits for the device itself when the scan is still attached to a batch, and detaches it).
 struct BfPool {
     std::mutex mu;
     std::multimap<size_t, void *> blocks[16];
     size_t held[16] = {0};
 };
 inline BfPool &bf_pool() { static BfPool P; return P; }
-inline hipError_t bf_pool_alloc(void **p, size_t bytes) {
+// every cached block of a device goes back to the runtime (device idle or not: hipFree waits); -> bytes released
+inline size_t bf_pool_trim(int dev) {
+    std::vector<void *> drop;
+    size_t bytes = 0;
+    if (dev >= 0 && dev < 16) {
+        BfPool &P = bf_pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        for (auto &kv : P.blocks[dev]) drop.push_back(kv.second);
+        bytes = P.held[dev];
+        P.blocks[dev].clear();
+        P.held[dev] = 0;
+    }
+    for (void *q : drop) (void)hipFree(q);
+    return bytes;
+}
+// `*got` = the size of the block handed out (>= bytes): what bf_pool_free must be told, so that the cache's accounting holds
+inline hipError_t bf_pool_alloc(void **p, size_t bytes, size_t *got) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     bytes = (bytes + 255) & ~(size_t)255;
+    *got = bytes;
     if (dev >= 0 && dev < 16) {
         BfPool &P = bf_pool();
         std::lock_guard<std::mutex> lk(P.mu);
         auto it = P.blocks[dev].lower_bound(bytes);
         if (it != P.blocks[dev].end() && it->first <= bytes + bytes / 4 + 4096) {
             *p = it->second;
+            *got = it->first;
             P.held[dev] -= it->first;
             P.blocks[dev].erase(it);
             return hipSuccess;
         }
     }
-    return hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess && bf_pool_trim(dev) > 0) {          // the cache itself may be what exhausted the device: give it back, once
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
 }
-// `bytes`: what the block was asked for (the same rounding happens here)
+// `bytes`: the block's size as bf_pool_alloc reported it
 inline void bf_pool_free(void *p, size_t bytes, int dev) {
     if (!p) return;
     bytes = (bytes + 255) & ~(size_t)255;
@@ -82,9 +106,8 @@ struct DevBuf {
     void slice(T *base, size_t count) { p = base; n = count; view = true; }
     hipError_t alloc_pooled(size_t count) {       // for buffers of per-frame objects (see BfPool); contents undefined
         n = count;
-        pool_bytes = std::max<size_t>(count, 1) * sizeof(T);
         (void)hipGetDevice(&pool_dev);
-        return bf_pool_alloc((void **)&p, pool_bytes);
+        return bf_pool_alloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T), &pool_bytes);
     }
     hipError_t upload_pooled(const T *h, size_t count) {
         hipError_t e = alloc_pooled(count);
@@ -285,13 +308,17 @@ struct bf_batch {
 
 struct bf_scan {
     int device = 0, nv = 0, nf = 0, n_entries = 0;
-    int attached = 0;               // batches that hold this scan (bf_batch_set_scans): destroying it then waits for the device first
+    std::vector<struct bf_batch *> holders;   // batches that hold this scan (bf_batch_set_scans), one entry per frame slot, under bf_scan_links():
+                                              // destroying the scan waits for the device and detaches those batches' scans first
     ScanDev dev{};
     DevBuf<float> verts, face_norms;
     DevBuf<int> faces, cell_start, cell_tris;
     DevBuf<float> cell_pack, cell_box;
 };
 
+
+inline std::mutex &bf_scan_links() { static std::mutex mu; return mu; }      // guards bf_scan::holders and bf_batch::scans of every object
+extern "C" void bf_batch_unlink_scans(struct bf_batch *b);                                // (caller holds bf_scan_links(); device idle) batch forgets its scans, scans forget the batch
 
 // shared between api.hip and scan_api.hip
 extern "C" {

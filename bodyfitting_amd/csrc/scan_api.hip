@@ -1,6 +1,7 @@
 // Host side of the scan (use_mesh) path: grid construction, closest-point queries, and the per-iteration
 // schedule of smplify.py:205-213 with the point-cloud loss switched on after num_iters // 3.
 #include "bf_host.h"
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 
@@ -71,13 +72,22 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
     }
     const size_t ncell = (size_t)num[0] * num[1] * num[2];
     if (ncell > (size_t)1 << 28) return fail(BF_ERR_UNSUPPORTED, "bf_scan_create: grid too large");
-    // everything below runs on the device: only the vertices and faces cross PCIe (the packed cell records would be ~50x that)
+    // everything below runs on the device: only the vertices and faces cross PCIe (the packed cell records would be ~50x that).
+    // It runs on a stream of its own (one per host thread and device, non-blocking) and this call waits for THAT stream only: a fit
+    // in flight on a batch's stream - the previous frame's, in a capture - keeps running under the build (a hipDeviceSynchronize or
+    // a NULL-stream launch here would wait for it).
+    static thread_local hipStream_t build_streams[16] = {};
+    hipStream_t st = nullptr;
+    if (device >= 0 && device < 16) {
+        if (!build_streams[device]) HIP_TRY(hipStreamCreateWithFlags(&build_streams[device], hipStreamNonBlocking));
+        st = build_streams[device];
+    }
     auto *s = new bf_scan();
     s->device = device; s->nv = n_verts; s->nf = n_faces;
     DevBuf<int> cursor, tris_raw;
     // (every device buffer of a scan and of its construction comes from the block cache: a capture makes one scan per frame)
-    bool ok = s->verts.upload_pooled(verts, (size_t)n_verts * 3) == hipSuccess &&
-              s->faces.upload_pooled(faces, (size_t)n_faces * 3) == hipSuccess &&
+    bool ok = s->verts.alloc_pooled((size_t)n_verts * 3) == hipSuccess &&
+              s->faces.alloc_pooled((size_t)n_faces * 3) == hipSuccess &&
               s->cell_start.alloc_pooled(ncell + 1) == hipSuccess && cursor.alloc_pooled(ncell + 1) == hipSuccess &&
               s->face_norms.alloc_pooled((size_t)n_faces * 3) == hipSuccess;
     if (!ok) { delete s; return fail(BF_ERR_HIP, "bf_scan_create: device allocation failed"); }
@@ -88,15 +98,19 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
     d.cell_tris = nullptr; d.cell_pack = nullptr; d.cell_box = nullptr;
     const dim3 fgrid((n_faces + 255) / 256);
     int total = 0;
-    hipError_t e = hipMemsetAsync(s->cell_start.p, 0, (ncell + 1) * sizeof(int), 0);
+    // (pageable sources: the runtime stages them before the call returns; the copies themselves are ordered on `st`)
+    hipError_t e = hipMemcpyAsync(s->verts.p, verts, (size_t)n_verts * 3 * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->faces.p, faces, (size_t)n_faces * 3 * sizeof(int), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(s->cell_start.p, 0, (ncell + 1) * sizeof(int), st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(bf_grid_count_kernel, fgrid, dim3(256), 0, 0, d, s->cell_start.p);
-        hipLaunchKernelGGL(bf_grid_scan_kernel, dim3(1), dim3(1024), 0, 0, s->cell_start.p, cursor.p, (int)(ncell + 1));
-        hipLaunchKernelGGL(bf_face_normal_kernel, fgrid, dim3(256), 0, 0, (const float *)s->verts.p, (const int *)s->faces.p, n_faces,
+        hipLaunchKernelGGL(bf_grid_count_kernel, fgrid, dim3(256), 0, st, d, s->cell_start.p);
+        hipLaunchKernelGGL(bf_grid_scan_kernel, dim3(1), dim3(1024), 0, st, s->cell_start.p, cursor.p, (int)(ncell + 1));
+        hipLaunchKernelGGL(bf_face_normal_kernel, fgrid, dim3(256), 0, st, (const float *)s->verts.p, (const int *)s->faces.p, n_faces,
                            s->face_norms.p);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpy(&total, s->cell_start.p + ncell, sizeof(int), hipMemcpyDeviceToHost);   // (syncs)
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, s->cell_start.p + ncell, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e == hipSuccess && total >= (1 << 28)) { delete s; return fail(BF_ERR_UNSUPPORTED, "bf_scan_create: more than 2^28 cell-list entries"); }   // (the search's queue entries: 28 bits of record index)
     if (e == hipSuccess && total > 0) {
         ok = tris_raw.alloc_pooled(total) == hipSuccess && s->cell_tris.alloc_pooled(total) == hipSuccess &&
@@ -105,11 +119,11 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
         d.cell_tris = s->cell_tris.p;
         d.cell_pack = (const float4 *)s->cell_pack.p;
         d.cell_box = (const float4 *)s->cell_box.p;
-        hipLaunchKernelGGL(bf_grid_fill_kernel, fgrid, dim3(256), 0, 0, d, cursor.p, tris_raw.p);
-        hipLaunchKernelGGL(bf_grid_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, 0, d, (const int *)tris_raw.p, s->cell_tris.p,
+        hipLaunchKernelGGL(bf_grid_fill_kernel, fgrid, dim3(256), 0, st, d, cursor.p, tris_raw.p);
+        hipLaunchKernelGGL(bf_grid_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, d, (const int *)tris_raw.p, s->cell_tris.p,
                            (float4 *)s->cell_pack.p, (float4 *)s->cell_box.p, total);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();       // tris_raw / cursor are released on return
+        if (e == hipSuccess) e = hipStreamSynchronize(st);       // tris_raw / cursor are released on return
     }
     if (e != hipSuccess) { delete s; return fail(BF_ERR_HIP, std::string("bf_scan_create: grid build: ") + hipGetErrorString(e)); }
     s->n_entries = total;
@@ -121,8 +135,32 @@ void bf_scan_destroy(bf_scan *s) {
     if (!s) return;
     // the scan's blocks go back to the cache without the device-wide wait a hipFree implies; a scan that a batch still holds may
     // be in use by queued work: wait for the device then, as hipFree would have
-    if (s->attached > 0) { (void)hipSetDevice(s->device); (void)hipDeviceSynchronize(); }
+    // ... and those batches forget ALL their scans (the same state as bf_batch_set_scans(b, NULL)): a later fit runs without the
+    // closest-point loss instead of reading freed grids, and bf_batch_set_scans / bf_batch_destroy never touch this pointer again
+    {
+        std::lock_guard<std::mutex> lk(bf_scan_links());
+        if (!s->holders.empty()) {
+            (void)hipSetDevice(s->device);
+            (void)hipDeviceSynchronize();
+            while (!s->holders.empty()) bf_batch_unlink_scans(s->holders.back());
+        }
+    }
     delete s;
+}
+
+void bf_batch_unlink_scans(bf_batch *b) {
+    for (bf_scan *sc : b->scans) {
+        if (!sc) continue;
+        auto it = std::find(sc->holders.begin(), sc->holders.end(), b);
+        if (it != sc->holders.end()) sc->holders.erase(it);
+    }
+    b->scans.clear();
+    b->cface_valid = false;
+    if (b->cscale.p) { (void)hipFree(b->cscale.p); b->cscale.p = nullptr; }
+}
+int64_t bf_device_cache_trim(int device) {
+    if (device < 0 || device >= 16 || hipSetDevice(device) != hipSuccess) return -1;
+    return (int64_t)bf_pool_trim(device);
 }
 float bf_scan_height(const bf_scan *s) { return s ? s->dev.height : 0.f; }
 
@@ -323,9 +361,8 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
     HIP_TRY(hipSetDevice(b->m->device));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (!scans) {                                  // detach
-        for (bf_scan *old : b->scans) if (old) --old->attached;
-        b->scans.clear();
-        if (b->cscale.p) { (void)hipFree(b->cscale.p); b->cscale.p = nullptr; }
+        std::lock_guard<std::mutex> lk(bf_scan_links());
+        bf_batch_unlink_scans(b);
         return BF_OK;
     }
     std::vector<ScanDev> dev(b->F);
@@ -335,9 +372,15 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
         dev[f] = scans[f]->dev;
         cs[f] = scans[f]->dev.height / 1.7f;
     }
-    for (bf_scan *old : b->scans) if (old) --old->attached;
-    b->scans.assign(scans, scans + b->F);
-    for (bf_scan *sc : b->scans) ++sc->attached;
+    {
+        std::lock_guard<std::mutex> lk(bf_scan_links());
+        for (bf_scan *old : b->scans) {            // (the tables below are rewritten in place: no detach of cscale)
+            auto it = std::find(old->holders.begin(), old->holders.end(), b);
+            if (it != old->holders.end()) old->holders.erase(it);
+        }
+        b->scans.assign(scans, scans + b->F);
+        for (bf_scan *sc : b->scans) sc->holders.push_back(b);
+    }
     b->cface_valid = false;
     // (a capture attaches new scans every frame: the two small tables are written in place - a hipFree waits for the whole device)
     if (b->scan_dev.p && b->scan_dev.n == dev.size()) HIP_TRY(hipMemcpy(b->scan_dev.p, dev.data(), dev.size() * sizeof(ScanDev), hipMemcpyHostToDevice));

@@ -13,6 +13,7 @@
 // The grid itself (cell lists in CSR form, cells from MeshGridSearcher.set_mesh,
 // utils/mesh_grid_searcher.py:56-79) is built once per scan by grid_kernels.hip, with triangles in face
 // order inside every cell (the reference fills its lists with atomicCAS in arbitrary order).
+#include <atomic>
 #include "bf_internal.h"
 #include "loss_bodies.h"
 #include "joints_body.h"
@@ -437,17 +438,18 @@ extern "C" __global__ void bf_nearest_rule_kernel(int n, const float *__restrict
 }
 
 // which arithmetic bf_nearest_launch uses: BF_NEAREST_RULE=fast|reference in the environment at first use, or bf_nearest_rule_set()
-static int g_nearest_rule = -1;
-extern "C" int bf_nearest_rule_get(void) {
-    if (g_nearest_rule < 0) {
+// (read by bf_group's worker threads side by side: an atomic, initialised from the environment exactly once)
+static std::atomic<int> &nearest_rule_cell() {
+    static std::atomic<int> cell([] {
         const char *e = getenv("BF_NEAREST_RULE");
-        g_nearest_rule = (e && (e[0] == 'f' || e[0] == '1')) ? BF_NEAREST_FAST : BF_NEAREST_REFERENCE;
-    }
-    return g_nearest_rule;
+        return (e && (e[0] == 'f' || e[0] == '1')) ? BF_NEAREST_FAST : BF_NEAREST_REFERENCE;
+    }());
+    return cell;
 }
+extern "C" int bf_nearest_rule_get(void) { return nearest_rule_cell().load(std::memory_order_relaxed); }
 extern "C" int bf_nearest_rule_set(int rule) {
     if (rule != BF_NEAREST_REFERENCE && rule != BF_NEAREST_FAST) return -1;
-    g_nearest_rule = rule;
+    nearest_rule_cell().store(rule, std::memory_order_relaxed);
     return 0;
 }
 extern "C" void bf_nearest_launch(dim3 grid, hipStream_t stream, const ScanDev *scans, const float *points, int n, int *face, float *pts,

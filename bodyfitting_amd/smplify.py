@@ -154,11 +154,11 @@ class SMPLify:
                 "global_orient": p["global_orient"].copy(), "faces": self.smpl_faces[0], "global_transl": p["global_transl"] * p["scale"],
                 "scale": p["scale"].copy(), "full_pose": full_pose_f}
 
-    def stream(self, frames, c2ws, Ks, use_frames=None, imsize=512, mask_frames=None, displacement=False):
+    def stream(self, frames, c2ws, Ks, use_frames=None, imsize=512, mask_frames=(0,), displacement=False):
         """The frame loop of apps/genebody_fitting.py:183-192 for ONE capture (fixed cameras): `frames` yields per frame what
         BodyFitting hands `SMPLify.__call__` - `(net_output, keypoints)`, or `(net_output, keypoints, masks)` /
-        `(net_output, keypoints, masks, meshfile)` with `masks` the silhouettes of the views `mask_frames` (None: no silhouette loss
-        for that frame) and `meshfile` a scan OBJ (None: no scan) - and the results come back in order, as a generator, one frame
+        `(net_output, keypoints, masks, meshfile)` with `masks` the silhouettes of the views `mask_frames` (default [0], as
+        `__call__`'s, smplify.py:85; a frame's `masks` = None: no silhouette loss for that frame) and `meshfile` a scan OBJ (None: no scan) - and the results come back in order, as a generator, one frame
         behind: what `__call__` returns for that frame, bit for bit.
 
         Keypoint-only SMPL: frame i+1's inputs are uploaded and its fit is issued before frame i's result is read, so uploads, fits
@@ -179,7 +179,9 @@ class SMPLify:
         batch.set_cameras(c2w, K)
         batch._cams = None
         nl = self._dev.n_loss_joints
-        mk_idx = None if mask_frames is None else [list(use_frames if use_frames is not None else range(V)).index(f) for f in mask_frames]
+        if mask_frames is None:
+            raise ValueError("stream(): mask_frames=None - name the views the frames' masks belong to (default [0], like __call__)")
+        mk_idx = [list(use_frames if use_frames is not None else range(V)).index(f) for f in mask_frames]
 
         def pack(keypoints):
             kp = np.zeros((1, V, nl, 3), np.float32)

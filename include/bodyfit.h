@@ -205,9 +205,17 @@ int bf_batch_export_params_dev(bf_batch *b, void *dst_dev);
 /* ---- scan closest-point path (use_mesh, BASELINE config 5) ------------------------------------------
  * MeshGridSearcher(verts, faces) (utils/mesh_grid_searcher.py:51-79 -> insert_grid_surface,
  * thirdparty/mesh_grid/mesh_grid.cpp:31-52): verts[n_verts,3], faces[n_faces,3] int32. */
+/* ORDER OF DESTRUCTION: a scan may be destroyed while batches still hold it (bf_batch_set_scans): bf_scan_destroy then waits for
+ * the device and DETACHES every scan from those batches - the state bf_batch_set_scans(b, NULL) leaves: a later bf_fit runs
+ * without the closest-point loss, bf_fit_displacement reports "no scans attached" - and a batch may be destroyed before its scans.
+ * Not thread-safe against a bf_fit / bf_batch_set_scans of a holding batch running at the same moment on another thread.
+ * bf_scan_create builds the grid on a stream of its own and waits for that stream only: a fit in flight keeps running. */
 int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, const int32_t *faces, bf_scan **out);
 void bf_scan_destroy(bf_scan *s);
 float bf_scan_height(const bf_scan *s);                 /* (max - min)[1], smplify.py:150-151 */
+/* The library caches the device blocks of destroyed scans per device (at most 2 GB; a failed hipMalloc empties it and retries):
+ * give them back to the runtime now.  -> bytes released, < 0 on a bad device index.  (Waits for the device, as hipFree does.) */
+int64_t bf_device_cache_trim(int device);
 int bf_scan_grid_info(const bf_scan *s, int32_t dims[3], float origin_step[4]);
 /* The tensors insert_grid_surface leaves with its caller (mesh_grid.cpp:129-136, mesh_grid_kernel.cu:178-236; built on
  * the device by bf_scan_create): tri_num[nx*ny*nz] = inclusive cumulative triangle count per cell (cell = (x*ny+y)*nz+z),

@@ -633,3 +633,61 @@ def test_displacement_stage_first_steps(small, gmm_bufs):
     assert np.mean(np.abs(d3 - res["disp_snapshots"][3]) < 2e-4) > 0.97
     b.close()
     scan.close()
+
+
+def test_scan_and_batch_may_be_destroyed_in_any_order(small):
+    """bodyfit.h "ORDER OF DESTRUCTION": a scan destroyed while a batch still holds it detaches that batch's scans (the later
+    fit then equals a fit that never had scans, bit for bit; the SMPL+D stage reports that nothing is attached), re-attaching and
+    detaching afterwards never touch the freed scan, and a batch may go before its scans."""
+    from bodyfitting_amd import _lib
+    model, dev = small
+    items = [S.make_scan_problem(model, frame=f, n_views=8) for f in (0, 1)]
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([p for p, _, _ in items])
+
+    def batch():
+        b = N.FrameBatch(dev, 2, 8)
+        b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+        return b
+    plain = batch()
+    plain.fit(12)
+    want = plain.get_params()
+    plain.close()
+    scans = [N.Scan(sv, sf) for _, sv, sf in items]
+    b = batch()
+    b.set_scans(scans)
+    b.fit(3)                                   # queued work that reads the scans
+    scans[0].close()                           # destroy-then-detach: waits for the device, detaches BOTH frames' scans
+    b.reset()
+    b.fit(12)
+    np.testing.assert_array_equal(b.get_params(), want)
+    with pytest.raises(_lib.BodyfitError, match="no scans attached"):
+        b.fit_displacement(2)
+    b.set_scans(None)                          # detach after the destroy: nothing to touch
+    fresh = N.Scan(items[0][1], items[0][2])
+    b.set_scans([fresh, scans[1]])             # replace after the destroy
+    b.fit(2)
+    b.close()                                  # the batch goes first ...
+    fresh.close(); scans[1].close()            # ... its scans afterwards (no device-wide wait: nothing holds them)
+    assert _lib.load().bf_device_cache_trim(dev.device) > 0      # the destroyed scans' blocks sat in the cache
+    assert _lib.load().bf_device_cache_trim(dev.device) == 0
+
+
+def test_building_a_scan_does_not_wait_for_a_fit_in_flight(small):
+    """bf_scan_create runs on its own stream and waits for that stream only: with a long fit queued on a batch's stream, building a
+    scan returns while the fit is still running (the fit alone takes several times as long as the build)"""
+    import time
+    model, dev = small
+    p, sv, sf = S.make_scan_problem(model, frame=0, n_views=8)
+    c2w, K, kp, ndiv, betas, pose = N.pack_problem([p])
+    b = N.FrameBatch(dev, 1, 8)
+    b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+    N.Scan(sv, sf).close()                     # warm: streams, block cache, code objects
+    b.fit(50); b.sync()
+    t0 = time.perf_counter(); N.Scan(sv, sf).close(); t_build = time.perf_counter() - t0
+    t0 = time.perf_counter(); b.fit(60000); t_issue = time.perf_counter() - t0       # asynchronous: ~0.25 s of device time
+    t0 = time.perf_counter(); s = N.Scan(sv, sf); t_under = time.perf_counter() - t0
+    t0 = time.perf_counter(); b.sync(); t_rest = time.perf_counter() - t0
+    print("scan build alone %.2f ms, under a fit in flight %.2f ms; the fit still ran %.1f ms after it (issue %.2f ms)" % (
+        t_build * 1e3, t_under * 1e3, t_rest * 1e3, t_issue * 1e3))
+    assert t_rest > 5 * t_under and t_under < 10 * t_build + 2e-3
+    s.close(); b.close()
