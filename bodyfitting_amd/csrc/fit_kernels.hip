@@ -36,15 +36,23 @@
 #include "pose_state_body.h"
 #include <type_traits>
 
-// Diagnostic build only (-DBF_STAMP, libbodyfit_stamp.so): thread 0 stamps the shader clock after every
-// barrier of iteration 2 into io.debug[4096..]; the product library has no stamps.
+// Diagnostic build only (-DBF_STAMP, libbodyfit_stamp.so; the product library has no stamps).  Round 5: the stamps are LIGHT - EVERY
+// wave stores the low word of the shader clock as it arrives at a barrier and as it leaves it, every iteration (the last one
+// stays), raw, into S.stamp[64 + (2 b + {0: arrive, 1: leave}) * 8 + wave] (BF_T(k): slot k, k < 24; 22 / 23 = the tops of the last
+// two iterations; 12 .. 21 free for marks inside a phase); the differences are taken on the host (tests/gpu_stamps.py).  The earlier
+// form (64-bit differences converted to float under `it == 2`, extra marks inside the phases) cost the stamp build 352 B of scratch
+// per lane and 60 % more cycles per iteration than the product build: it measured itself.  (Branch-free - every lane stores the same
+// word to the same slot, the wave index in a scalar register: an `if (lane == 0)` around the store split the scheduling regions
+// of the GMM loop and brought 250 B of the spills back.  The stamp array stays at 64 + 192 floats: at 64 + 256 the compiler
+// emitted "Illegal instruction detected: Operand has incorrect register class".)
 #ifdef BF_STAMP
-#define BF_SYNC() do { __syncthreads(); if (tid == 0 && (it == 2 || EXT) && sidx < 32) { S.stamp[sidx] = (float)(long long)(clock64() - t_iter); } ++sidx; } while (0)
-#define BF_MARK(k, who, itv, t0v) do { if (tid == (who) && ((itv) == 2 || EXT)) S.stamp[k] = (float)(long long)(clock64() - (t0v)); } while (0)
+#define BF_T(k) do { S.stamp[64 + (k) * 8 + bf_wave_s] = __int_as_float((int)clock64()); } while (0)
+#define BF_SYNC() do { BF_T(2 * sidx); __syncthreads(); BF_T(2 * sidx + 1); ++sidx; } while (0)
 #else
+#define BF_T(k) do { } while (0)
 #define BF_SYNC() __syncthreads()
-#define BF_MARK(k, who, itv, t0v) do { (void)(itv); (void)(t0v); } while (0)
 #endif
+#define BF_MARK(k, who, itv, t0v) do { (void)(itv); (void)(t0v); } while (0)
 // (stamp build) cycles since kernel entry at a few points of a dense-schedule launch: thread `who` of frame 0 -> io.debug[4160 + k]
 #ifdef BF_STAMP
 #define BF_KMARK(k, who) do { if (EXT && tid == (who) && frame == 0 && io.debug) io.debug[4160 + (k)] = (float)(long long)(clock64() - bf_k0); } while (0)
@@ -95,7 +103,7 @@ __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj
     s.sel_w = take(ns * nj); s.means = take(BF_GMM_M * BF_GMM_LD);
     s.nzw = take(ns * BF_SEL_NNZ);  s.nzj = (int *)take(ns * BF_SEL_NNZ);
     s.kp = take(BF_VSUB * BF_KP_ROUNDS * 16 * 8);      // 8-float keypoint record per (view, loss-joint pair), zero padded
-    s.stamp = take(64);
+    s.stamp = take(64 + 192);
     s.sel_pd2 = take(npf * (ns * 3 + 1));     // sel_pd TRANSPOSED for the GMM waves' pose blend: [3 ns][BF_PDT_LD] (a lane's 30-row slice
                                               // of one output is contiguous: b64 reads), zero padded; fits: 3 ns * 210 <= npf * (3 ns + 1)
     s.theta = take(nj * 3);  s.pmean = take(nj * 3);  s.hcomp = take(2 * 6 * 45);
@@ -236,6 +244,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const long long bf_k0 = clock64();
 #endif
     const int tid = threadIdx.x, nt = BF_FIT_THREADS;
+#ifdef BF_STAMP
+    const int bf_wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x) >> 6;        // (the wave index in a scalar register, for the stamps)
+#endif
     constexpr int NG = 256;                    // threads of the geometry waves (0-3)
     const int lane = tid & 63, wave = tid >> 6;
     const int frame = blockIdx.x;
@@ -927,7 +938,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         for (int it = 0; it < n_iters; ++it) {
 #ifdef BF_STAMP
             int sidx = 0;
-            const long long t_iter = clock64();
+            const long long t_iter = 0;
 #else
             const long long t_iter = 0;
 #endif
@@ -1070,8 +1081,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     for (int it = 0; it < n_iters; ++it) {
 #ifdef BF_STAMP
         int sidx = 0;
-        const long long t_iter = clock64();
-        bf_it = it; bf_t0 = t_iter;
+        const long long t_iter = 0;
+        BF_T(it == n_iters - 1 ? 23 : 22);        // top of the last two iterations: their difference is one iteration
 #else
         const long long t_iter = 0;
 #endif
@@ -1938,6 +1949,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #ifdef BF_STAMP
     __syncthreads();
     if (tid < 64 && io.debug && frame == 0) io.debug[4096 + tid] = S.stamp[tid];
+    if (tid < 192 && io.debug && frame == 0) io.debug[4352 + tid] = S.stamp[64 + tid];
 #endif
     BF_KMARK(4, 0); BF_KMARK(5, 256);
     if (mode == 0 && tid < np) {
