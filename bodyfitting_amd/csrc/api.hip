@@ -333,6 +333,40 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     T.parents = m->parents.p; T.level_start = m->level_start.p; T.level_joints = m->level_joints.p;
     T.child_start = m->child_start.p; T.child_list = m->child_list.p;
     T.lj_kind = m->lj_kind.p; T.lj_index = m->lj_index.p;
+    {   // deal pairs and selector vertices to the four geometry waves (FitTab::pair_slot): pairs with the most selector vertices
+        // first, each to the wave that already owns its vertices, else to the wave with the fewest vertices, then the fewest pairs
+        const int npairs = (m->nl + 1) / 2;
+        for (int &x : T.pair_slot) x = -1;
+        for (int &x : T.skin_vert) x = -1;
+        T.bd_ok = (npairs >= 1 && npairs <= 16 && ns <= 4 * BF_SKIN_PER_WAVE) ? 1 : 0;
+        std::vector<int> owner(ns, -1), order(std::max(npairs, 0)), nverts(4, 0), npw(4, 0);
+        auto verts_of = [&](int p) {
+            std::vector<int> v;
+            for (int l = 2 * p; l < std::min(2 * p + 2, m->nl); ++l)
+                if (lj_kind[l] == 1 && std::find(v.begin(), v.end(), lj_index[l]) == v.end()) v.push_back(lj_index[l]);
+            return v;
+        };
+        for (int p = 0; p < npairs; ++p) order[p] = p;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return verts_of(a).size() > verts_of(b).size(); });
+        for (int p : order) {
+            if (!T.bd_ok) break;
+            const std::vector<int> v = verts_of(p);
+            int w = -1;
+            for (int x : v) if (owner[x] >= 0) { if (w >= 0 && w != owner[x]) T.bd_ok = 0; w = owner[x]; }
+            int fresh = 0;
+            for (int x : v) if (owner[x] < 0) ++fresh;
+            if (w < 0) {
+                for (int c = 0; c < 4; ++c) {
+                    if (npw[c] >= 4 || nverts[c] + fresh > BF_SKIN_PER_WAVE) continue;
+                    if (w < 0 || nverts[c] < nverts[w] || (nverts[c] == nverts[w] && npw[c] < npw[w])) w = c;
+                }
+            }
+            if (w < 0 || npw[w] >= 4 || nverts[w] + fresh > BF_SKIN_PER_WAVE) { T.bd_ok = 0; break; }
+            T.pair_slot[4 * w + npw[w]++] = p;
+            for (int x : v) if (owner[x] < 0) { owner[x] = w; T.skin_vert[BF_SKIN_PER_WAVE * w + nverts[w]++] = x; }
+        }
+        for (int x = 0; x < ns && T.bd_ok; ++x) if (owner[x] < 0) T.bd_ok = 0;       // (a selector vertex no pair reads: cannot happen, sel is built from the loss joints)
+    }
     T.Jt = m->Jt.p; T.Jd = m->Jd.p; T.Jdrel = m->Jdrel.p; T.Jtrel = m->Jtrel.p;
     T.sel_vt = m->sel_vt.p; T.sel_sd = m->sel_sd.p; T.sel_pd = m->sel_pd.p; T.sel_w = m->sel_w.p;
     T.g_means = m->g_means.p; T.g_psym = m->g_psym.p; T.g_logw = m->g_logw.p;

@@ -10,6 +10,7 @@
 #define BF_VSUB 16          // view lanes per loss-joint pair in the projection phase (one DPP row)
 #define BF_KP_ROUNDS 3      // keypoint records staged in LDS for V <= 16*3 = 48 views
 #define BF_SEL_NNZ 8         // compacted skinning weights per selector vertex (real SMPL has <= 4)
+#define BF_SKIN_PER_WAVE 5   // selector vertices a geometry wave can skin in one pass (12 lanes each) in the merged skin + projection phase
 #define BF_MFMA_MIN_FRAMES 16
 #define BF_BATCH32_MAX_FRAMES 64   // up to here the final mesh of a batch is bf_mesh_batch32_kernel (32-frame blocks, fused epilogue)
 #define BF_EPI_FRAMES 8      // frames one workgroup of the batched mesh epilogue walks over (its tile's tables stay in registers)
@@ -44,6 +45,13 @@ struct FitTab {
     const int *child_list;           // [nj-1]
     const int *lj_kind;              // [nl] 0 = chain joint, 1 = selector vertex slot
     const int *lj_index;             // [nl]
+    // The deal of the merged skinning + projection phase (sized SMPL instance): loss-joint PAIR (2 p, 2 p + 1) pair_slot[4 w + q] is
+    // projected by the q-th sixteen lanes of geometry wave w (-1: nobody), and wave w skins selector vertices skin_vert[5 w ..]
+    // (-1: none) - every selector vertex a wave's pairs read is skinned by that wave, so no workgroup barrier separates the two.
+    // bd_ok = 0: no such deal exists for this model (it takes the table-driven instance).
+    int bd_ok;
+    int pair_slot[16];
+    int skin_vert[4 * BF_SKIN_PER_WAVE];
     const float *Jt;                 // [nj*3]        J_regressor v_template
     const float *Jd;                 // [nj*3][nb]    J_regressor shapedirs
     const float *Jdrel;              // [nj*3][nb]    Jd[j] - Jd[parent(j)]   (Jd[0] for the root)

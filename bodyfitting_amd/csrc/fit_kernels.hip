@@ -373,9 +373,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     // owns a PAIR of loss joints (2 ps, 2 ps + 1) on one view lane, ps = 4 * wave + lane / 16, view lane = lane % 16.
     // Both joints see the same projection matrix, so every multiply-add of the projection, the GMoF and the
     // reverse pass is one packed v_pk_*_f32 over the pair; the 16 view lanes of a pair are one DPP row.
-    const int pslot = (wave & 3) * 4 + (lane >> 4), vsub = lane & 15;
+    // (MERGE_BD instances: WHICH pair is the deal of FitTab::pair_slot - the selector vertices a wave projects are the ones it skins)
+    constexpr bool MERGE_BD = NJ == 24 && NB > 0 && NB <= 10 && NS > 0 && NS <= 12;          // (= GBLEND)
+    const int pphys = (wave & 3) * 4 + (lane >> 4), vsub = lane & 15;      // the physical slot: wave, quarter
+    const int pdealt = MERGE_BD ? T.pair_slot[pphys] : pphys;
+    const int pslot = pdealt >= 0 ? pdealt : 0;
     const int ja = 2 * pslot, jb = 2 * pslot + 1;
-    const bool ja_on = wave < 4 && ja < nl, jb_on = wave < 4 && jb < nl;
+    const bool ja_on = wave < 4 && pdealt >= 0 && ja < nl, jb_on = wave < 4 && pdealt >= 0 && jb < nl;
     const int lkind_a = ja_on ? T.lj_kind[ja] : 0, lidx_a = ja_on ? T.lj_index[ja] : 0;
     const int lkind_b = jb_on ? T.lj_kind[jb] : 0, lidx_b = jb_on ? T.lj_index[jb] : 0;
     const float *lsrc_a = lkind_a == 0 ? S.G + lidx_a * 12 + 3 : S.vsel + lidx_a * 3;
@@ -430,7 +434,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         ((float4 *)S.kp)[2 * i + 1] = e1;
     }
     BF_KMARK(11, 0);
-    const float4 *kp_lane = (const float4 *)__builtin_assume_aligned(S.kp, 16) + (vsub * 16 + pslot) * 2;
+    // the selector vertex this lane skins in the merged phase (lane / 12-th of the wave's deal; one register kept across the loop -
+    // indexing the kernel argument per lane inside the loop would be a global load per iteration)
+    const int skin_dealt = MERGE_BD ? T.skin_vert[BF_SKIN_PER_WAVE * (wave & 3) + min(lane / 12, BF_SKIN_PER_WAVE - 1)] : -1;
+    // (a slot nobody was dealt reads pair 15's records: zeros - there are at most 15 pairs when a slot is empty)
+    const float4 *kp_lane = (const float4 *)__builtin_assume_aligned(S.kp, 16) + (vsub * 16 + (pdealt >= 0 ? pdealt : 15)) * 2;
     const int EXT0 = npf, EXT_A = npf, EXT_B = npf + nj * 12, EXT_T = npf + nj * 12 + nb;
     const int EXT_G = npf + nj * 12 + nb + 4;
     const int EXT_K = EXT_G + nj * 3;          // dt, ds of the dense keypoint loss
@@ -475,33 +483,41 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     // Everything that depends on the betas alone, for the NEXT forward pass (wave 3; its lanes cover the outputs):
     // shaped selector vertices, rest joints J, joint offsets rel_j = J_j - J_parent from the pre-contracted difference
     // tables, and the zeroed targets of the projection phase's routing
+    // (sized instances) one selector output and two joint coordinates per lane; every LDS read issued before the arithmetic.
+    // bq = (beta_0 .. beta_{nb-1}, 1, 0 ...): column nb of a table row is its constant term.  `parts`: 1 = the rest joints J (+ the zeroed
+    // routing targets dGt), 2 = the joint offsets rel, 4 = the shaped selector vertices (+ zeroed dvsel) - the Adam phase deals the
+    // three parts to three waves.
+    auto beta_rows = [&](const float *bq, auto parts_c) {
+        constexpr int NQ = NB ? (NB + 4) / 4 : 1;
+        constexpr int parts = decltype(parts_c)::value;
+        const int o = lane < ns3 ? lane : 0, i0 = lane, i1 = lane + 64 < nj3 ? lane + 64 : 0;
+        float4 sq[NQ], ja[NQ], ra[NQ], jb[NQ], rb[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            if (parts & 4) sq[q] = ((const float4 *)(S.sel_sd + o * nbp))[q];
+            if (parts & 1) { ja[q] = ((const float4 *)(S.Jd + i0 * nbp))[q]; jb[q] = ((const float4 *)(S.Jd + i1 * nbp))[q]; }
+            if (parts & 2) { ra[q] = ((const float4 *)(S.Jdrel + i0 * nbp))[q]; rb[q] = ((const float4 *)(S.Jdrel + i1 * nbp))[q]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto dot = [&](const float4 *t) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) acc += t[q].x * bq[4 * q] + t[q].y * bq[4 * q + 1] + t[q].z * bq[4 * q + 2] + t[q].w * bq[4 * q + 3];
+            return acc;
+        };
+        if ((parts & 4) && lane < ns3) { S.vs[lane] = dot(sq); S.dvsel[lane] = 0.f; }
+        // (rel_j[r], i = 3 j + r: L[12 j + 4 r + 3] = L[4 i + 3] when the rotations are formed ahead)
+        if (parts & 1) { S.J[i0] = dot(ja); S.dGt[i0] = 0.f; if (lane + 64 < nj3) { S.J[i1] = dot(jb); S.dGt[i1] = 0.f; } }
+        if (parts & 2) { (ROT_AHEAD ? S.L[4 * i0 + 3] : S.rel[i0]) = dot(ra); if (lane + 64 < nj3) (ROT_AHEAD ? S.L[4 * i1 + 3] : S.rel[i1]) = dot(rb); }
+    };
     auto beta_dependent = [&](const float *P) {
         const float *beta = P + T.off_beta;
         constexpr int NQ = NB ? (NB + 4) / 4 : 0;          // float4s per table row (compile-time for the SMPL instance)
         if (NQ > 0 && NS > 0 && NS * 3 <= 64 && NJ > 0 && NJ * 3 <= 128) {
-            // one selector output and two joint coordinates per lane; every LDS read issued before the arithmetic
-            const int o = lane < ns3 ? lane : 0, i0 = lane, i1 = lane + 64 < nj3 ? lane + 64 : 0;
             float bq[NQ > 0 ? NQ * 4 : 4];
 #pragma unroll
             for (int c = 0; c < NQ * 4; ++c) bq[c] = c < nb ? beta[c] : (c == nb ? 1.0f : 0.f);
-            float4 sq[NQ > 0 ? NQ : 1], ja[NQ > 0 ? NQ : 1], ra[NQ > 0 ? NQ : 1], jb[NQ > 0 ? NQ : 1], rb[NQ > 0 ? NQ : 1];
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                sq[q] = ((const float4 *)(S.sel_sd + o * nbp))[q];
-                ja[q] = ((const float4 *)(S.Jd + i0 * nbp))[q]; ra[q] = ((const float4 *)(S.Jdrel + i0 * nbp))[q];
-                jb[q] = ((const float4 *)(S.Jd + i1 * nbp))[q]; rb[q] = ((const float4 *)(S.Jdrel + i1 * nbp))[q];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            auto dot = [&](const float4 *t) {
-                float acc = 0.f;
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) acc += t[q].x * bq[4 * q] + t[q].y * bq[4 * q + 1] + t[q].z * bq[4 * q + 2] + t[q].w * bq[4 * q + 3];
-                return acc;
-            };
-            if (lane < ns3) { S.vs[lane] = dot(sq); S.dvsel[lane] = 0.f; }
-            // (rel_j[r], i = 3 j + r: L[12 j + 4 r + 3] = L[4 i + 3] when the rotations are formed ahead)
-            S.J[i0] = dot(ja); (ROT_AHEAD ? S.L[4 * i0 + 3] : S.rel[i0]) = dot(ra); S.dGt[i0] = 0.f;
-            if (lane + 64 < nj3) { S.J[i1] = dot(jb); (ROT_AHEAD ? S.L[4 * i1 + 3] : S.rel[i1]) = dot(rb); S.dGt[i1] = 0.f; }
+            beta_rows(bq, std::integral_constant<int, 7>());
         } else {
             for (int o = lane; o < ns3; o += 64) {
                 float acc = S.sel_sd[o * nbp + nb];
@@ -749,8 +765,9 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         constexpr int NZ = 4;
         const int lq = bf_launder(lane);
         const int vloc = lq / 12, e12 = lq - vloc * 12, k = e12 >> 2, b = e12 & 3;
-        const int sv2 = wave * 3 + vloc;
-        const bool trl = lq < 36 && sv2 < ns;
+        // (MERGE_BD: the wave's vertices are the deal's - up to five, lanes 0-59 - so that it projects what it skins)
+        const int sv2 = MERGE_BD ? skin_dealt : wave * 3 + vloc;
+        const bool trl = MERGE_BD ? (lq < 12 * BF_SKIN_PER_WAVE && sv2 >= 0) : (lq < 36 && sv2 < ns);
         const int sv2c = trl ? sv2 : 0;
         float wq[NZ], aq[NZ];
         int jq[NZ];
@@ -844,8 +861,8 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             // slot order); joints off the end have zero records, their sums are exactly 0
             const float gsa = ga0 * y0.x + ga1 * y1.x + ga2 * y2.x, gsb = gb0 * y0.y + gb1 * y1.y + gb2 * y2.y;
             float4 q0 = {ga0 + gb0, ga1 + gb1, ga2 + gb2, jb_on ? gsa + gsb : (ja_on ? gsa : 0.f)};
-            *(float4 *)(S.part + pslot * 8) = q0;
-            S.part[pslot * 8 + 4] = la + lb;
+            *(float4 *)(S.part + pphys * 8) = q0;               // (by physical slot: the Adam phase adds the 16 slots in that order)
+            S.part[pphys * 8 + 4] = la + lb;
         }
         BF_MARK(44, 0, bf_it, bf_t0);
     };
@@ -1007,7 +1024,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 BF_GMM_CHUNK(4)
                 BF_GMM_CHUNK(5)
             }
-            if (!NO_VERT) BF_SYNC();   // C
+            if (!NO_VERT && !MERGE_BD) BF_SYNC();   // C (the merged skin + projection phase of the geometry waves has no barrier here)
             // the rest of the prior once the mat-vec is complete: y -> LDS, the twelve-column tail pieces, the two quadratic forms
             auto gmm_finish = [&]() {
                 const int tpq = min(bf_launder(lane), 59), tail_cq = tpq < 30 ? 0 : 1;          // (re-derived per iteration: registers)
@@ -1268,14 +1285,17 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         }
         }
                 }
-        if (!NO_VERT) BF_SYNC();
+        if (MERGE_BD) BF_WAVE_FENCE();       // (the wave projects the selector vertices it has just skinned: no workgroup barrier)
+        else if (!NO_VERT) BF_SYNC();
 
         // ================= phase D: similarity, multi-view projection, GMoF and its gradient
         if (nl > 0) project(it == n_iters - 1 || mode == 1);      // (no loss joints in this launch - the dense keypoint path: nothing to project)
         if (!NO_VERT) BF_SYNC();
 
-        // (this step's Adam constants: a global read, issued ahead of its use)
-        const float *at = adam_tab + (size_t)(adam_t0 + it) * 3;
+        // (this step's Adam constants: a global read, issued ahead of its use - as a VECTOR load, the address made lane-dependent on
+        //  purpose: a scalar load returns through the counter the LDS reads use, so every wave's first LDS wait of this phase also
+        //  waited for the scalar cache - a miss to L2 every fifth iteration, the table being 12 bytes per iteration)
+        const float *at = adam_tab + (size_t)(adam_t0 + it) * 3 + bf_launder(0);
         const float at0 = at[0], at1 = at[1], at2 = at[2];
         constexpr bool MERGE_FG = NJ > 0 && NJ <= 32 && NS > 0 && NS * 3 <= 36;
         if (MERGE_FG) {
@@ -1978,7 +1998,7 @@ extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int
 
 // (the compile-time-sized SMPL instance also assumes at most 4 bones per selector vertex - true of SMPL's skinning weights)
 extern "C" bool bf_fit_is_sized_smpl(const FitTab *T) {
-    return T->nj == 24 && T->nb == 10 && T->ns == 11 && T->nl == 25 && T->sel_nnz > 0 && T->sel_nnz <= 4;
+    return T->nj == 24 && T->nb == 10 && T->ns == 11 && T->nl == 25 && T->sel_nnz > 0 && T->sel_nnz <= 4 && T->bd_ok;
 }
 
 // Host-side launcher: picks the compile-time-sized instantiation for SMPL, the table-driven one otherwise.

@@ -15,7 +15,7 @@ dev = N.DeviceModel(model, gmm)
 c2w, K, kp, ndiv, betas, pose = N.pack_problem([S.make_problem(model, 0, 48)])
 b = N.FrameBatch(dev, 1, 48)
 b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
-NAMES = os.environ.get("BF_PHASES", "A B D F I").split()
+NAMES = os.environ.get("BF_PHASES", "A BD F I").split()
 for rep in range(3):
     b.reset(); b.fit(100); b.sync()
     raw = b.debug_dump(4352 + 192)[4352:].view(np.int32).astype(np.int64).reshape(-1, 8)      # [2 b + {arrive, leave}][wave]
