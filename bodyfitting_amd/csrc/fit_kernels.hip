@@ -443,9 +443,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     const int EXT_G = npf + nj * 12 + nb + 4;
     const int EXT_K = EXT_G + nj * 3;          // dt, ds of the dense keypoint loss
     // (EXT = the dense schedule's per-iteration launch with outside gradient blocks; compiled out of the persistent loop)
-    // (this frame's blocks, staged in LDS by the prologue.  Never a null pointer, tested through EXT: a nullable generic pointer here made
-    //  the compiler emit "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base" whenever the code around its uses moved)
-    const float *const ext = S.ext;
+    const float *ext = EXT ? S.ext : nullptr;          // (this frame's blocks, staged in LDS by the prologue)
     (void)EXT0;
 
     // pose-blend role: (row slice sl, output column o of the selector vertices)
@@ -637,14 +635,14 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 float acc = 0.f;
 #pragma unroll
                 for (int o = 0; o < NO; ++o) acc += rv[o] * dv[o];
-                S.dfeat[p] = EXT ? acc + ext[p] : acc;
+                S.dfeat[p] = ext ? acc + ext[p] : acc;
             }
         } else {
             for (int p = first; p < last; p += step) {
                 float acc = 0.f;
                 const float *row = S.sel_pd + p * pd_ld;
                 for (int o = 0; o < ns3; ++o) acc += row[o] * dvp_src[o];
-                S.dfeat[p] = EXT ? acc + ext[p] : acc;
+                S.dfeat[p] = ext ? acc + ext[p] : acc;
             }
         }
     };
@@ -733,7 +731,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             if (h * 4 + 3 < NO) acc += rq.w * dv4.w;
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (on) S.dfeat[p] = EXT ? acc + ext[p] : acc;
+        if (on) S.dfeat[p] = ext ? acc + ext[p] : acc;
     };
     // What the pose priors add to dL/dtheta, per body dof, for the Adam phase (wave 3, phase F - all eight q values are in LDS
     // since the barrier behind phase D): the arg-min component (prior.py:195), w_pose * y of that component, and the angle prior's
@@ -1357,13 +1355,13 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 r0 += wd_ * v0s; r1 += wd_ * v1s; r2 += wd_ * v2s;
             }
             float dat = r == 0 ? da0 : (r == 1 ? da1 : da2);
-            if (EXT) {                      // dense vertex losses: sum_v w_vj dv (x) [vp | 1] from bf_mesh_bwd_kernel (all rows of dAt)
+            if (ext) {                      // dense vertex losses: sum_v w_vj dv (x) [vp | 1] from bf_mesh_bwd_kernel (all rows of dAt)
                 const float *ea = ext + EXT_A + k * 12;
                 r0 += ea[r * 4]; r1 += ea[r * 4 + 1]; r2 += ea[r * 4 + 2];
                 da0 += ea[3]; da1 += ea[7]; da2 += ea[11];
                 dat = r == 0 ? da0 : (r == 1 ? da1 : da2);
             }
-            const float gt_fin = routed + (EXT ? dat + ext[EXT_G + k * 3 + r] : dat);
+            const float gt_fin = routed + (ext ? dat + ext[EXT_G + k * 3 + r] : dat);
             const float d0 = r0 - dat * j0, d1 = r1 - dat * j1, d2 = r2 - dat * j2;       // row r of D_k
             const float dg0 = d0 * gi0.x + d1 * gi0.y + d2 * gi0.z;                      // row r of Dg_k = D_k GR_k^T
             const float dg1 = d0 * gi1.x + d1 * gi1.y + d2 * gi1.z;
@@ -1441,12 +1439,12 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                     r0 += wd_ * S.vp[sv * 3]; r1 += wd_ * S.vp[sv * 3 + 1]; r2 += wd_ * S.vp[sv * 3 + 2];
                 }
             }
-            if (EXT) {                      // dense vertex losses: sum_v w_vj dv (x) [vp | 1] from bf_mesh_bwd_kernel
+            if (ext) {                      // dense vertex losses: sum_v w_vj dv (x) [vp | 1] from bf_mesh_bwd_kernel
                 const float *ea = ext + EXT_A + ci * 12 + cr * 4;
                 r0 += ea[0]; r1 += ea[1]; r2 += ea[2]; dat += ea[3];
             }
             S.dAt[tq] = dat;
-            const float gt_fin = S.dGt[tq] + (EXT ? dat + ext[EXT_G + tq] : dat);     // + dL/d(chain joint) of the dense keypoint loss
+            const float gt_fin = S.dGt[tq] + (ext ? dat + ext[EXT_G + tq] : dat);     // + dL/d(chain joint) of the dense keypoint loss
             const float d0 = r0 - dat * S.J[ci * 3], d1 = r1 - dat * S.J[ci * 3 + 1], d2 = r2 - dat * S.J[ci * 3 + 2];   // row cr of D_i
             // Row cr of Dg_i = D_i GR_i^T and of M_i = Dg_i + dGt_i (Gt_i - Gt_0)^T.  With these, the sum over the strict
             // subtree of p of N_i = Dg_i + t_i (Gt_i - Gt_parent(i))^T (t_i itself a subtree sum) telescopes to
@@ -1642,7 +1640,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         if (tq >= 64 && tq < 68) {                                   // transl / scale
             const int pidx = tq - 64;
             const float pval = Pcur[pidx], am = S.am[pidx], av = S.av[pidx], psum = S.scal[3 + pidx], sc3 = Pcur[3];
-            const float grad = psum * (pidx < 3 ? sc3 * cscale : cscale) + (EXT ? ext[EXT_T + pidx] + ext[EXT_K + pidx] : 0.f);
+            const float grad = psum * (pidx < 3 ? sc3 * cscale : cscale) + (ext ? ext[EXT_T + pidx] + ext[EXT_K + pidx] : 0.f);
             S.g[pidx] = grad;                                        // (kept for the debug dump)
             adam(pidx, pval, am, av, grad);
         }
@@ -1710,7 +1708,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 float g = 0.f;
 #pragma unroll
                 for (int i = 0; i < 6; ++i) g += pr[i];
-                if (EXT) g += ext[EXT_B + lane];
+                if (ext) g += ext[EXT_B + lane];
                 S.g[pidx] = g;                                       // (kept for the debug dump)
                 adam(pidx, pval, am, av, g + 2.f * hp.w_shape * pval);
             }
@@ -1834,7 +1832,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
                 }
             }
             acc = row16_sum(acc);
-            if (l < nb && sl == 0) S.g[T.off_beta + l] = EXT ? acc + ext[EXT_B + l] : acc;
+            if (l < nb && sl == 0) S.g[T.off_beta + l] = ext ? acc + ext[EXT_B + l] : acc;
         }
         }
         BF_SYNC();
@@ -1866,7 +1864,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             const float ang_sg = (pk == 1 && pb >= 0) ? (pb == 52 ? 1.f : ((pb == 55 || pb == 9 || pb == 12) ? -1.f : 0.f)) : 0.f;
             if (pk == 0) {                                           // transl / scale: the geometry waves' shares in wave order
                 const float acc = psum;
-                grad = acc * (pidx < 3 ? sc3 * cscale : cscale) + (EXT ? ext[EXT_T + pidx] + ext[EXT_K + pidx] : 0.f);
+                grad = acc * (pidx < 3 ? sc3 * cscale : cscale) + (ext ? ext[EXT_T + pidx] + ext[EXT_K + pidx] : 0.f);
                 S.g[pidx] = grad;                                    // (kept for the debug dump)
             }
             else if (pk == 1) {
