@@ -422,10 +422,11 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     }
     m->mesh_smem = bf_mesh_smem_bytes(nj, npf, nb);
     {
-        // ---- sampled-first sub-model (bf_model::Sub) ------------------------------------------------------------------
-        std::vector<int> pos(nv, -1), S;
-        for (int v = 0; v < nv; v += 4) { pos[v] = (int)S.size(); S.push_back(v); }
-        const int n_samp = (int)S.size();
+        // ---- sub-models (bf_model::Sub): the model's tables gathered for a subset of its vertices --------------------------
+        //   sub     "sampled first": every 4th vertex (the silhouette loss, loss.py:99) first, then what the dense keypoint loss reads;
+        //   sub_kp  (round 5) only what the dense keypoint loss reads - selector vertices, the landmark faces' corners, the support of
+        //           the extra regressor: the iterations BEFORE the silhouette / scan losses switch on (i <= num_iters // 3,
+        //           smplify.py:197,205) touch nothing else, with or without a scan attached.
         std::vector<char> extra(nv, 0);
         for (int i = 0; i < d->n_selector; ++i) extra[d->selector_ids[i]] = 1;
         if (smplx) {
@@ -437,10 +438,13 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
         //  must be one of them, or the extra joints of the dense loop would be partial sums)
         for (int e = 0; e < d->n_extra; ++e)
             for (int v = 0; v < nv; ++v) if (d->j_regressor_extra[(size_t)e * nv + v] != 0.f) extra[v] = 1;
-        for (int v = 0; v < nv; ++v) if (extra[v] && pos[v] < 0) { pos[v] = (int)S.size(); S.push_back(v); }
-        const int sv = (int)S.size();
-        if (sv * 10 <= nv * 6) {
-            bf_model::Sub &U = m->sub;
+        auto build_sub = [&](bf_model::Sub &U, bool sampled_first, int max_tenths) -> int {
+            std::vector<int> pos(nv, -1), S;
+            if (sampled_first) for (int v = 0; v < nv; v += 4) { pos[v] = (int)S.size(); S.push_back(v); }
+            const int n_samp = (int)S.size();
+            for (int v = 0; v < nv; ++v) if (extra[v] && pos[v] < 0) { pos[v] = (int)S.size(); S.push_back(v); }
+            const int sv = (int)S.size();
+            if (sv == 0 || sv * 10 > nv * max_tenths) return BF_OK;          // (not worth it: the full model serves)
             std::vector<float> vt((size_t)sv * 3), sd((size_t)sv * 3 * nb), pd((size_t)npf * 3 * sv), lw((size_t)sv * nj), jx((size_t)std::max(d->n_extra, 0) * sv);
             const int nnz = m->mesh.v_nnz;
             std::vector<int> zj((size_t)sv * std::max(nnz, 1), 0), sel(d->n_selector), fc;
@@ -468,7 +472,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
             bool up = U.v_template.upload(vt) == hipSuccess && U.shapedirs.upload(sd) == hipSuccess && U.posedirs.upload(pd) == hipSuccess &&
                       U.lbs_weights.upload(lw) == hipSuccess && U.j_extra.upload(jx) == hipSuccess && U.v_nzj.upload(zj) == hipSuccess &&
                       U.v_nzw.upload(zw) == hipSuccess && U.selector_ids.upload(sel) == hipSuccess && U.faces.upload(fc) == hipSuccess;
-            if (!up) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (sub-model)"); }
+            if (!up) return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (sub-model)");
             U.mesh = m->mesh;
             U.mesh.nv = sv; U.mesh.n_tiles = (sv + BF_MESH_TILE - 1) / BF_MESH_TILE;
             U.mesh.v_template = U.v_template.p; U.mesh.shapedirs = U.shapedirs.p; U.mesh.posedirs = U.posedirs.p;
@@ -482,13 +486,17 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
                 for (size_t i = 0; i < (size_t)d->n_dyn_rows * d->n_lmk_dynamic; ++i)
                     for (int c = 0; c < 3; ++c) dfv[i * 3 + c] = fc[(size_t)d->dynamic_lmk_faces_idx[i] * 3 + c];
                 if (dfv.empty()) dfv.push_back(0);
-                if (U.lmk_fv.upload(sfv) != hipSuccess || U.dyn_fv.upload(dfv) != hipSuccess) { delete m; return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (sub-model landmark corners)"); }
+                if (U.lmk_fv.upload(sfv) != hipSuccess || U.dyn_fv.upload(dfv) != hipSuccess) return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (sub-model landmark corners)");
                 U.mesh.lmk_fv = U.lmk_fv.p; U.mesh.dyn_fv = U.dyn_fv.p;
             }
             U.kp = m->kp; U.kp.nv = sv; U.kp.selector_ids = U.selector_ids.p; U.kp.j_extra = U.j_extra.p;
             U.ns = n_samp;
             U.on = true;
-        }
+            return BF_OK;
+        };
+        int rs = build_sub(m->sub, true, 6);
+        if (rs == BF_OK && m->kp_dense) rs = build_sub(m->sub_kp, false, 5);      // (only models whose keypoint loss is dense have keypoint-only dense iterations)
+        if (rs != BF_OK) { delete m; return rs; }
     }
     *out = m;
     return BF_OK;

@@ -182,7 +182,7 @@ struct bf_model {
         KpIO kp{};
         DevBuf<float> v_template, shapedirs, posedirs, lbs_weights, j_extra, v_nzw, posedirsT;
         DevBuf<int> v_nzj, selector_ids, faces, lmk_fv, dyn_fv;
-    } sub;
+    } sub, sub_kp;                // (sub_kp: the keypoint-only sub-model of the iterations before the dense losses switch on - no sampled vertices)
     DevBuf<float> posedirsT;      // [3NV][npf], built on first use of the dense reverse pass (under `lazy`, device-synchronised)
     DevBuf<float> fit_image;      // FitTab::lds_image of the dense-schedule fit instance, built on first use (under `lazy`)
     std::mutex lazy;              // guards the build-on-first-use tables (posedirsT, faces_d / adj)

@@ -73,12 +73,16 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
     const size_t ncell = (size_t)num[0] * num[1] * num[2];
     if (ncell > (size_t)1 << 28) return fail(BF_ERR_UNSUPPORTED, "bf_scan_create: grid too large");
     // everything below runs on the device: only the vertices and faces cross PCIe (the packed cell records would be ~50x that).
-    // It runs on a stream of its own (one per host thread and device, non-blocking) and this call waits for THAT stream only: a fit
-    // in flight on a batch's stream - the previous frame's, in a capture - keeps running under the build (a hipDeviceSynchronize or
-    // a NULL-stream launch here would wait for it).
+    // It runs on the NULL stream and this call waits for THAT stream only (hipStreamSynchronize(0), not hipDeviceSynchronize): the
+    // library's own streams are all non-blocking, so neither the launches nor the wait are ordered behind a fit in flight on a
+    // batch's stream - the previous frame's, in a capture - which keeps running under the build.
+    // (A stream of its own per host thread was measured first and is what BF_SCAN_BUILD_STREAM=1 still selects: correct, but the
+    //  extra stream changed the runtime's mapping of streams onto hardware queues, and config 5's fit - whose keypoint workgroups run
+    //  on the batch's second stream beside the search - went from 62 to 139 ms.)
     static thread_local hipStream_t build_streams[16] = {};
     hipStream_t st = nullptr;
-    if (device >= 0 && device < 16) {
+    static const bool own_stream = [] { const char *e = std::getenv("BF_SCAN_BUILD_STREAM"); return e && e[0] == '1'; }();
+    if (own_stream && device >= 0 && device < 16) {
         if (!build_streams[device]) HIP_TRY(hipStreamCreateWithFlags(&build_streams[device], hipStreamNonBlocking));
         st = build_streams[device];
     }
@@ -341,15 +345,16 @@ int bf_ensure_dense_buffers(bf_batch *b) {
             HIP_TRY(hipStreamSynchronize(b->stream));
             m->posedirsT.p = t.p; m->posedirsT.n = t.n; t.p = nullptr;
         }
-        if (m->sub.on && !m->sub.posedirsT.p) {
-            const size_t sv3 = (size_t)m->sub.mesh.nv * 3;
+        for (bf_model::Sub *U : {&m->sub, &m->sub_kp}) {
+            if (!U->on || U->posedirsT.p) continue;
+            const size_t sv3 = (size_t)U->mesh.nv * 3;
             DevBuf<float> t;
             HIP_TRY(t.alloc(sv3 * m->npf));
             hipLaunchKernelGGL(bf_transpose_kernel, dim3((sv3 + 31) / 32, (m->npf + 31) / 32), dim3(256), 0, b->stream,
-                               (const float *)m->sub.posedirs.p, m->npf, (int)sv3, t.p);
+                               (const float *)U->posedirs.p, m->npf, (int)sv3, t.p);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(b->stream));
-            m->sub.posedirsT.p = t.p; m->sub.posedirsT.n = t.n; t.p = nullptr;
+            U->posedirsT.p = t.p; U->posedirsT.n = t.n; t.p = nullptr;
         }
     }
     return BF_OK;
@@ -404,17 +409,17 @@ static size_t kp_smem(const KpIO &K) {
                                                    (size_t)K.nl * 2 + K.nj + 1 + K.n_selector + 16);
 
 }
-static KpIO kp_io(bf_batch *b, const bf_hyper &h, bool sub = false) {
-    KpIO K = sub ? b->m->sub.kp : b->m->kp;
+static KpIO kp_io(bf_batch *b, const bf_hyper &h, const bf_model::Sub *sub = nullptr) {
+    KpIO K = sub ? sub->kp : b->m->kp;
     K.n_views = b->V; K.sigma2 = h.sigma * h.sigma; K.coeff = h.imsize / 1024.0f;
     return K;
 }
 // (the keypoint workgroup computes the joints itself from the mesh pass's vraw / xpart: no bf_joints_kernel launch)
-static int launch_kp(bf_batch *b, const bf_hyper &h, bool sub = false, hipStream_t on = nullptr) {
+static int launch_kp(bf_batch *b, const bf_hyper &h, const bf_model::Sub *sub = nullptr, hipStream_t on = nullptr) {
     const KpIO K = kp_io(b, h, sub);
     hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), kp_smem(K), on ? on : b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
                        (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
-                       (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p, sub ? b->m->sub.mesh : b->m->mesh, (const float *)b->vraw.p,
+                       (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p, sub ? sub->mesh : b->m->mesh, (const float *)b->vraw.p,
                        (const float *)b->xpart.p);
     HIP_TRY(hipGetLastError());
     return BF_OK;
@@ -422,10 +427,10 @@ static int launch_kp(bf_batch *b, const bf_hyper &h, bool sub = false, hipStream
 
 // `with_kp`: the dense keypoint loss rides in the contour launch (bf_kp_contour_kernel) instead of a launch of its own
 static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss, bool sum_views = true, const bf_hyper *with_kp = nullptr,
-                               bool projected = false, bool sub = false) {
+                               bool projected = false, const bf_model::Sub *sub = nullptr) {
     MaskIO K = b->mask;
     K.weight = weight;
-    if (sub) { K.nv = b->m->sub.mesh.nv; K.sstride = 1; }
+    if (sub) { K.nv = sub->mesh.nv; K.sstride = 1; }
     const int F = b->F;
     // (projected: the forward mesh pass already wrote uvi / duvb for its sampled vertices)
     if (!projected) hipLaunchKernelGGL(bf_mask_project_kernel, dim3(K.proj_blocks, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->vout.p,
@@ -435,7 +440,7 @@ static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss, bool s
         hipLaunchKernelGGL(bf_kp_contour_kernel, dim3((K.cmax * 16 + 511) / 512 + 1, K.n_masks, F), dim3(512), kp_smem(Q), b->stream, Q,
                            (const float *)b->jraw.p, (const float *)b->state.p, (const float *)b->proj.p, (const float *)b->keypoints.p,
                            (const int *)b->ndiv.p, (const int *)b->lmk_vid.p, (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p,
-                           K, (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p, sub ? b->m->sub.mesh : b->m->mesh, (const float *)b->vraw.p,
+                           K, (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p, sub ? sub->mesh : b->m->mesh, (const float *)b->vraw.p,
                            (const float *)b->xpart.p);
     } else
     hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax * 16 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
@@ -462,14 +467,15 @@ static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
 
 // one dense iteration's forward + loss + reverse passes up to `ext` (everything except the fit kernel itself)
 // door / door_k: the persistent fit launch's doorbells and this pass's 1-based dense iteration (null / 0: fit launches per iteration)
-// sub: run the mesh passes on the sampled-first sub-model (bf_model::Sub; fit loops without scans)
+// sub: run the mesh passes on a sub-model (bf_model::Sub): the sampled-first one for fit loops without scans, the keypoint-only one for
+// the iterations before the dense losses switch on; null = the full model
 // BF_DOOR_COHERENT=0: the kernels that wait for the resident fit launch read its pose states with plain loads (see bf_ld_state)
 static bool door_coherent() { const char *e = std::getenv("BF_DOOR_COHERENT"); return !(e && e[0] == '0'); }
 
 static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight, int *door = nullptr, int door_k = 0,
-                      bool sub = false) {
+                      const bf_model::Sub *sub = nullptr) {
     bf_model *m = b->m;
-    const MeshTab &Q = sub ? m->sub.mesh : m->mesh;
+    const MeshTab &Q = sub ? sub->mesh : m->mesh;
     const int F = b->F, nv = Q.nv, nblk = (nv + 255) / 256;
     const bool scans = late && !b->scans.empty(), masks = late && b->has_masks, kp = m->kp_dense;
     if (masks) { int rf = bf_masks_finalize(b); if (rf) return rf; }
@@ -527,9 +533,9 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     const int EXT = m->npf + m->nj * 12 + m->nb + 4;
     int part_rows = Q.n_tiles;             // (two per tile when the reverse pass splits its tiles: one frame, a small grid)
     {
-        const int e = bf_mesh_bwd_multi_launch(&Q, sub ? m->sub.posedirsT.p : m->posedirsT.p, b->state.p, F, b->dvout.p, b->vposed.p, b->vraw.p, b->ext_part.p,
+        const int e = bf_mesh_bwd_multi_launch(&Q, sub ? sub->posedirsT.p : m->posedirsT.p, b->state.p, F, b->dvout.p, b->vposed.p, b->vraw.p, b->ext_part.p,
                                                b->stream, fold_views ? (const float *)b->mk_gpart.p : nullptr, b->mask.n_masks, b->mask.ns, sub ? 1 : 4,
-                                               m->mesh.n_tiles, &part_rows);
+                                               (sub && sub == &m->sub_kp) ? Q.n_tiles : m->mesh.n_tiles, &part_rows);      // (keypoint-only sub-model: no tile split - a batch of 8 and its single frames keep the same partial sums)
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_bwd_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     }
     hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 31) / 32, F), dim3(256), 0, b->stream,
@@ -639,7 +645,15 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     // per iteration, with the pose state from bf_pose_state_kernel every time.
     // (read on every call: a test switches them between two calls of one process)
     const bool sub_ok = [] { const char *e = std::getenv("BF_DENSE_SUBMODEL"); return !(e && e[0] == '0'); }();
-    const bool sub = sub_ok && m->sub.on && b->scans.empty();
+    // (the sub-model of iteration `it`: before the dense losses switch on only the keypoint loss's vertices matter - with or without scans)
+    const bf_model::Sub *const sub_late = (sub_ok && m->sub.on && b->scans.empty()) ? &m->sub : nullptr;
+    const bool sub_kp_ok = [] { const char *e = std::getenv("BF_DENSE_SUBMODEL_KP"); return !(e && e[0] == '0'); }();      // (bring-up switch, like BF_DENSE_SUBMODEL)
+    // (not with silhouettes attached: the silhouette loop amplifies round-off - the reference's own end state moves by 0.75 % of its
+    //  silhouette loss under a one-ulp nudge - and the other summation order of the first third's mesh passes moved config 3's end state
+    //  from 1.9 % to 3.9 % of the reference's, outside the band tests/test_gpu_configs_full.py derives from the reference's own drift,
+    //  for 3 % of the fit's time; with scans the early iterations run on a tenth of the vertices instead of all of them: -6 %)
+    const bf_model::Sub *const sub_early = (sub_ok && sub_kp_ok && m->sub_kp.on && !b->has_masks) ? &m->sub_kp : sub_late;
+    auto sub_of = [&](int it) { return it > thr ? sub_late : sub_early; };
     const bool door_ok = [] { const char *e = std::getenv("BF_DENSE_PERSISTENT"); return !(e && e[0] == '0'); }();
     const int n_dense = n_iters - n_plain;
     if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES) { rc = ensure_fit_stream(b, io, hd); if (rc) return rc; }
@@ -666,7 +680,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
                     }
                 }
             }
-            rc = dense_pass(b, h, hd, it > thr, 5.0f, b->door.p, it - n_plain + 1, sub);
+            rc = dense_pass(b, h, hd, it > thr, 5.0f, b->door.p, it - n_plain + 1, sub_of(it));
             if (rc) {               // do not leave the resident launch waiting for bells that will not ring
                 const int one = 1;
                 (void)hipMemcpy(b->door.p + BF_DOOR_ERR, &one, sizeof one, hipMemcpyHostToDevice);
@@ -679,7 +693,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
         return BF_OK;
     }
     for (int it = n_plain; it < n_iters; ++it) {
-        rc = dense_pass(b, h, hd, it > thr, 5.0f, nullptr, 0, sub);                    // smplify.py:210
+        rc = dense_pass(b, h, hd, it > thr, 5.0f, nullptr, 0, sub_of(it));                    // smplify.py:210
         if (rc) return rc;
         FrameIO io2 = io;
         io2.ext = b->ext.p;

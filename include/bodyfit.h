@@ -209,7 +209,8 @@ int bf_batch_export_params_dev(bf_batch *b, void *dst_dev);
  * the device and DETACHES every scan from those batches - the state bf_batch_set_scans(b, NULL) leaves: a later bf_fit runs
  * without the closest-point loss, bf_fit_displacement reports "no scans attached" - and a batch may be destroyed before its scans.
  * Not thread-safe against a bf_fit / bf_batch_set_scans of a holding batch running at the same moment on another thread.
- * bf_scan_create builds the grid on a stream of its own and waits for that stream only: a fit in flight keeps running. */
+ * bf_scan_create builds the grid on the NULL stream and waits for that stream only (the library's streams are non-blocking):
+ * a fit in flight on a batch's stream keeps running. */
 int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, const int32_t *faces, bf_scan **out);
 void bf_scan_destroy(bf_scan *s);
 float bf_scan_height(const bf_scan *s);                 /* (max - min)[1], smplify.py:150-151 */

@@ -673,7 +673,7 @@ def test_scan_and_batch_may_be_destroyed_in_any_order(small):
 
 
 def test_building_a_scan_does_not_wait_for_a_fit_in_flight(small):
-    """bf_scan_create runs on its own stream and waits for that stream only: with a long fit queued on a batch's stream, building a
+    """bf_scan_create runs on the NULL stream and waits for that stream only (the library's streams are non-blocking): with a long fit queued on a batch's stream, building a
     scan returns while the fit is still running (the fit alone takes several times as long as the build)"""
     import time
     model, dev = small

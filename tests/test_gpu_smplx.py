@@ -204,6 +204,11 @@ def test_sub_model_loop_matches_the_full_model_loop():
     a = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "1"})
     b = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "0"})
     np.testing.assert_allclose(a, b, rtol=0, atol=2e-5)
+    # round 5: the iterations before the dense losses switch on (i <= num_iters // 3: here 0..4 of 12) run on the keypoint-only
+    # sub-model - selector vertices, landmark corners, the extra regressor's support - the later ones on the sampled-first one
+    c = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "1", "BF_DENSE_SUBMODEL_KP": "0"})
+    np.testing.assert_allclose(a, c, rtol=0, atol=2e-5)
+    assert np.abs(a - c).max() > 0                     # (another summation order: the switch really selects another sub-model)
     a = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "1"}, n_iters=6, masks=True)          # 2 keypoint-only + 4 silhouette iterations
     b = _fit_in_subprocess({"BF_DENSE_SUBMODEL": "0"}, n_iters=6, masks=True)
     # (four silhouette iterations: as far apart as the reference's own perturbed runs are after their first ten)
@@ -262,8 +267,10 @@ def test_sub_model_keeps_every_vertex_of_the_extra_regressor(gmm_bufs):
     for k in O.SMPLX_PARAMS:
         np.testing.assert_allclose(got[k], g64[k], atol=1e-5 * np.abs(g64[k]).max(), err_msg=k)
     out = {}
-    for flag in ("1", "0"):
-        os.environ["BF_DENSE_SUBMODEL"] = flag
+    # "1": both sub-models (iterations 0..2 of 8 on the keypoint-only one, 3..7 on the sampled-first one), "kp0": sampled-first only,
+    # "0": the full model throughout
+    for flag, env in (("1", {"BF_DENSE_SUBMODEL": "1"}), ("kp0", {"BF_DENSE_SUBMODEL": "1", "BF_DENSE_SUBMODEL_KP": "0"}), ("0", {"BF_DENSE_SUBMODEL": "0"})):
+        os.environ.update(env)
         try:
             b = _batch(dev, prob)
             terms, grads = b.loss_grad()
@@ -271,11 +278,14 @@ def test_sub_model_keeps_every_vertex_of_the_extra_regressor(gmm_bufs):
             out[flag] = (terms.copy(), grads.copy(), b.get_params().copy())
             b.close()
         finally:
-            del os.environ["BF_DENSE_SUBMODEL"]
+            for k in env:
+                del os.environ[k]
     assert np.abs(out["1"][1]).max() > 1.0
-    np.testing.assert_allclose(out["1"][0], out["0"][0], rtol=2e-6)
-    np.testing.assert_allclose(out["1"][1], out["0"][1], atol=2e-5 * np.abs(out["0"][1]).max())
-    np.testing.assert_allclose(out["1"][2], out["0"][2], atol=2e-5)
+    for flag in ("1", "kp0"):
+        np.testing.assert_allclose(out[flag][0], out["0"][0], rtol=2e-6)
+        np.testing.assert_allclose(out[flag][1], out["0"][1], atol=2e-5 * np.abs(out["0"][1]).max())
+        np.testing.assert_allclose(out[flag][2], out["0"][2], atol=2e-5)
+    assert np.abs(out["1"][2] - out["kp0"][2]).max() > 0
     dev.close()
 
 
