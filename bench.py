@@ -387,6 +387,14 @@ def main_dense(a):
     for _ in range(2):
         step(timed_parts=True)
     per = {k: parts[k] / parts["n"] * 1e3 for k in ("upload_s", "fit_s", "disp_s")}
+    # device time of the kernel classes of the last dense iteration of one more fit (HIP events on the batch's stream: bf_batch_dense_timing)
+    per_class = None
+    try:
+        batch.dense_timing(True)
+        job.fit(iters, flags=_lib.FIT_FETCH | _lib.FIT_RESET); job.sync()
+        per_class = batch.dense_timing(False, read=True)
+    except Exception as exc:                                   # (a diagnostic: never take the line down)
+        per_class = {"error": repr(exc)}
     bytes_iter = (BYTES_SMPLX_FWD * iters + BYTES_CFG3_MASK * (iters - iters // 3 - 1)) if cfg == 3 else BYTES_CFG5_ITER * iters
     fit_s = per["fit_s"] * 1e-3
     what = {3: f"{F} frame(s) per GPU per step x {a.views} views (+ 8 silhouettes at 512 x 512), SMPL-X-shaped synthetic model (10,475 v, 55 joints, "
@@ -411,6 +419,16 @@ def main_dense(a):
                         "traffic": None, "algorithmic_bytes_per_fit": bytes_iter * F,
                         "note": "nominal SURVEY 8(d) bytes per frame-iteration x iterations x frames over the fit's wall time on rank 0 "
                                 "(the resident fit launch and 5 kernels per iteration; frames of a shard share one model stream)"}}
+    out["device_ms_last_iteration"] = per_class
+    if cfg == 5 and per_class and per_class.get("closest_point_search"):
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import bench_configs as BC
+        nvx, s_search = dev.n_verts, per_class["closest_point_search"] * 1e-3
+        out["dominant_kernel"] = {"name": "bf_nearest_kernel", "bound": "valu_issue", "queries_per_launch": F * nvx,
+                                  "valu_per_query_wave": BC.NEAREST_VALU_PER_QUERY, "ms_per_launch": s_search * 1e3,
+                                  "issue_bound_ms": F * nvx * BC.NEAREST_VALU_PER_QUERY / BC.SIMD_VALU_PER_S * 1e3,
+                                  "frac": F * nvx * BC.NEAREST_VALU_PER_QUERY / BC.SIMD_VALU_PER_S / s_search,
+                                  "note": "queries x VALU instructions per query-wave (PMC, profiles/) / (1,024 SIMDs x 2.4 GHz / 4) / the search's device time"}
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if live["scans"]:

@@ -747,6 +747,7 @@ void bf_batch_destroy(bf_batch *b) {
     if (b->mk_stage.ev_used) (void)hipEventDestroy(b->mk_stage.ev_used);
     if (b->mk_stage.h_masks) (void)hipHostFree(b->mk_stage.h_masks);
     if (b->mk_stage.h_ccount) (void)hipHostFree(b->mk_stage.h_ccount);
+    for (auto &e : b->ev_dense) if (e) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
         if (b->h_in[k]) (void)hipHostFree(b->h_in[k]);
         if (b->ev_in[k]) (void)hipEventDestroy(b->ev_in[k]);

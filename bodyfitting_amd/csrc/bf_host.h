@@ -234,6 +234,9 @@ struct bf_batch {
     // dense schedule with the fit kernel resident for the whole call (BfDoor, bf_internal.h)
     hipStream_t fit_stream = nullptr;
     hipEvent_t ev_aux[2] = {nullptr, nullptr};   // fork / join of the dense keypoint loss on the second stream
+    // bf_batch_dense_timing: events between the kernel classes of the LAST dense iteration of a fit (recorded only when asked for)
+    bool dense_timing = false, dense_timed = false;
+    hipEvent_t ev_dense[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool door_usable = false;           // the self-test at first use found the fit stream running beside the batch stream
     hipEvent_t ev_door[2] = {nullptr, nullptr};
     DevBuf<int> door;

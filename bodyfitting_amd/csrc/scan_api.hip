@@ -473,8 +473,15 @@ static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
 static bool door_coherent() { const char *e = std::getenv("BF_DOOR_COHERENT"); return !(e && e[0] == '0'); }
 
 static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight, int *door = nullptr, int door_k = 0,
-                      const bf_model::Sub *sub = nullptr) {
+                      const bf_model::Sub *sub = nullptr, bool timed = false) {
     bf_model *m = b->m;
+    // (timed: events between the kernel classes of this pass, for bf_batch_dense_timing)
+    auto mark = [&](int k) -> hipError_t {
+        if (!timed) return hipSuccess;
+        if (!b->ev_dense[k]) { hipError_t e = hipEventCreate(&b->ev_dense[k]); if (e != hipSuccess) return e; }
+        return hipEventRecord(b->ev_dense[k], b->stream);
+    };
+    HIP_TRY(mark(0));
     const MeshTab &Q = sub ? sub->mesh : m->mesh;
     const int F = b->F, nv = Q.nv, nblk = (nv + 255) / 256;
     const bool scans = late && !b->scans.empty(), masks = late && b->has_masks, kp = m->kp_dense;
@@ -498,6 +505,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
                             &projected, door, (F * door_k) | (door_coherent() ? 0x40000000 : 0), sub ? &Q : nullptr);
     if (rc) return rc;
     if ((kp || masks) && !zeroed) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
+    HIP_TRY(mark(1));                         // [0,1] pose state (when not resident) + forward mesh pass
     // The dense keypoint loss and the closest-point search both only read the mesh: with scans attached the keypoint workgroups (one
     // per frame, a ~25 us latency chain) run on the batch's second stream UNDER the search - that stream is idle during a dense loop
     // and, being on another priority, has a hardware queue of its own - and are joined before bf_pc_grad_kernel adds onto their
@@ -519,10 +527,12 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     // with a scan as well, bf_pc_grad_kernel adds onto (keypoints + silhouette): keep that order of additions
     const bool fold_views = masks && !scans;
     if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr, projected, sub); if (rc) return rc; }
+    HIP_TRY(mark(2));                         // [1,2] keypoint loss (on this stream) and / or the silhouette kernels
     if (scans) {
         bf_nearest_launch(dim3((nv + 3) / 4, F), b->stream, (const ScanDev *)b->scan_dev.p,
                           (const float *)b->vout.p, nv, b->cface.p, b->cpts.p, (float *)nullptr, b->cface_valid ? 1 : 0);   // (one wave per query; warm start from the previous call's faces)
         b->cface_valid = true;
+        HIP_TRY(mark(3));                     // [2,3] closest-point search
         hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, b->pc_partial.p);
         if (kp_aside) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_aux[1], 0));
@@ -530,6 +540,8 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
                            (const float *)b->cpts.p, nv, (const float *)b->pc_partial.p, (const float *)b->pc_weight.p,
                            b->dvout.p, b->pc_loss.p, (kp || masks) ? 1 : 0);
     }
+    if (!scans) HIP_TRY(mark(3));
+    HIP_TRY(mark(4));                         // [3,4] point-cloud loss + gradient (+ the join with the keypoint workgroups of the second stream)
     const int EXT = m->npf + m->nj * 12 + m->nb + 4;
     int part_rows = Q.n_tiles;             // (two per tile when the reverse pass splits its tiles: one frame, a small grid)
     {
@@ -538,9 +550,12 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
                                                (sub && sub == &m->sub_kp) ? Q.n_tiles : m->mesh.n_tiles, &part_rows);      // (keypoint-only sub-model: no tile split - a batch of 8 and its single frames keep the same partial sums)
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_bwd_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     }
+    HIP_TRY(mark(5));                         // [4,5] reverse mesh pass
     hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 31) / 32, F), dim3(256), 0, b->stream,
                        (const float *)b->ext_part.p, part_rows, EXT, b->ext.p, EXT + m->nj * 3 + 4, door, door_k);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(mark(6));                         // [5,6] reduction of the partial blocks (rings the resident fit launch)
+    if (timed) b->dense_timed = true;
     return BF_OK;
 }
 
@@ -680,7 +695,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
                     }
                 }
             }
-            rc = dense_pass(b, h, hd, it > thr, 5.0f, b->door.p, it - n_plain + 1, sub_of(it));
+            rc = dense_pass(b, h, hd, it > thr, 5.0f, b->door.p, it - n_plain + 1, sub_of(it), b->dense_timing && it == n_iters - 1);
             if (rc) {               // do not leave the resident launch waiting for bells that will not ring
                 const int one = 1;
                 (void)hipMemcpy(b->door.p + BF_DOOR_ERR, &one, sizeof one, hipMemcpyHostToDevice);
@@ -693,12 +708,24 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
         return BF_OK;
     }
     for (int it = n_plain; it < n_iters; ++it) {
-        rc = dense_pass(b, h, hd, it > thr, 5.0f, nullptr, 0, sub_of(it));                    // smplify.py:210
+        rc = dense_pass(b, h, hd, it > thr, 5.0f, nullptr, 0, sub_of(it), b->dense_timing && it == n_iters - 1);                    // smplify.py:210
         if (rc) return rc;
         FrameIO io2 = io;
         io2.ext = b->ext.p;
         HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, b->fit_smem, b->stream));
     }
+    return BF_OK;
+}
+
+int bf_batch_dense_timing(bf_batch *b, int enable, float ms[6]) {
+    if (!b) return fail(BF_ERR_INVALID, "bf_batch_dense_timing: null batch");
+    HIP_TRY(hipSetDevice(b->m->device));
+    if (ms) {
+        if (!b->dense_timed) return fail(BF_ERR_INVALID, "bf_batch_dense_timing: no dense iteration has been timed (enable, then bf_fit with a dense loss)");
+        { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
+        for (int k = 0; k < 6; ++k) HIP_TRY(hipEventElapsedTime(&ms[k], b->ev_dense[k], b->ev_dense[k + 1]));
+    }
+    b->dense_timing = enable != 0;
     return BF_OK;
 }
 

@@ -423,6 +423,15 @@ class FrameBatch:
         _lib.check(self._lib.bf_batch_mesh_span(self._h, int(reps), _lib.fptr(us)), "bf_batch_mesh_span")
         return {"mean_us": float(us[0]), "min_us": float(us[1]), "max_us": float(us[2])}
 
+    DENSE_CLASSES = ("state_and_forward_mesh", "keypoint_and_silhouette_losses", "closest_point_search", "point_cloud_loss_and_gradient",
+                     "reverse_mesh", "partial_block_reduction")
+
+    def dense_timing(self, enable=True, read=False):
+        """device milliseconds of the kernel classes of the last dense iteration of the last fit (bf_batch_dense_timing)"""
+        ms = np.zeros(6, np.float32) if read else None
+        _lib.check(self._lib.bf_batch_dense_timing(self._h, int(bool(enable)), _lib.fptr(ms)), "bf_batch_dense_timing")
+        return None if ms is None else dict(zip(self.DENSE_CLASSES, (float(x) for x in ms)))
+
     def debug_dump(self, n):
         out = np.zeros(n, np.float32)
         _lib.check(self._lib.bf_batch_debug_dump(self._h, _lib.fptr(out), int(n)), "bf_batch_debug_dump")

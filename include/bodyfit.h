@@ -408,6 +408,11 @@ int bf_batch_timing_sum(bf_batch *b, float ms[4], int32_t *n_calls);
  * us[3] = mean, min, max in microseconds.  What bench.py's roofline_mesh divides the kernel's algorithmic bytes by (an event bracket
  * around a 6 us kernel is half record overhead).  SMPL-sized models. */
 int bf_batch_mesh_span(bf_batch *b, int reps, float us[3]);
+/* Device time of the kernel classes of the LAST dense iteration (smplify.py:177-213 with use_mask / use_mesh / SMPL-X keypoints) of the
+ * last bf_fit, from HIP events on the batch's stream: ms[0] pose state + forward mesh pass, ms[1] keypoint loss and / or silhouette kernels,
+ * ms[2] closest-point search, ms[3] point-cloud loss + gradient, ms[4] reverse mesh pass, ms[5] reduction of the partial blocks.  `enable`
+ * switches the recording for the following fits (the events cost a few microseconds of that one iteration); ms may be NULL. */
+int bf_batch_dense_timing(bf_batch *b, int enable, float ms[6]);
 
 /* ---- test hooks (bring-up / parity tests only; not part of the drop-in surface) ----------------------------------
  * first-iteration intermediates of frame 0 written by the last bf_loss_grad launch (layout: tests/gpu_debug.py) */

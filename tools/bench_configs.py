@@ -16,6 +16,25 @@ sys.path.insert(0, REPO)
 from bodyfitting_amd import native as N, synthetic as S   # noqa: E402
 
 
+# algorithmic bytes per frame-iteration (the same constants bench.py --config 3 | 5 prices its roofline with)
+BYTES_SMPLX_FWD = 61_090_200 + 2_514_000 + 2_304_500 + 2_304_500 + 125_700          # 68,338,900: the SMPL-X forward's tensors, each once
+BYTES_CFG3_MASK = 15_270_000                                                       # + the sampled vertices' posedirs columns when the silhouette loss is on
+BYTES_CFG5_ITER = 136_600_000                                                      # forward + full reverse pass
+HBM_PEAK_GBS = 8000.0
+# bf_nearest_kernel (reference rule): VALU instructions per query-wave from the PMC pass of profiles/r04_rocprof_summary.md
+# (SQ_INSTS_VALU / queries; the kernel is unchanged since).  1,024 SIMDs issue one wave64 VALU instruction per 4 cycles at 2.4 GHz.
+NEAREST_VALU_PER_QUERY = 868
+SIMD_VALU_PER_S = 1024 * 2.4e9 / 4
+
+
+def nominal_roofline(bytes_per_fit, fit_s, what):
+    gbs = bytes_per_fit / fit_s / 1e9
+    return {"bound": "hbm", "kernel": what, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_fit": bytes_per_fit,
+            "note": "nominal SURVEY 8(d) bytes per frame-iteration x iterations x frames over the fit's wall time (the resident fit launch and "
+                    "4-5 kernels per iteration: no single dominant kernel for the byte figure; device_ms_last_iteration has the split)"}
+
+
 def timed(fn, reps):
     fn()                                   # warm (allocations, first-use tables)
     t0 = time.perf_counter()
@@ -40,10 +59,13 @@ def cfg3(reps, n_views=48, iters=200, mask_views=8):
     def run():
         b.reset(); b.fit(iters); b.sync()
     dt = timed(run, reps)
+    b.dense_timing(True); run(); per_class = b.dense_timing(False, read=True)
     out = {"config": "cfg3: 1 frame x %d views, SMPL-X (10475 v, 55 joints, 135 loss joints), keypoint + silhouette loss "
                      "(%d mask views), %d iterations" % (n_views, len(mask_frames), iters),
            "frames_per_s": 1.0 / dt, "ms_per_fit": dt * 1e3, "ms_per_iteration": dt * 1e3 / iters,
-           "ms_mask_upload_and_contours": t_masks * 1e3}
+           "ms_mask_upload_and_contours": t_masks * 1e3,
+           "roofline": nominal_roofline(BYTES_SMPLX_FWD * iters + BYTES_CFG3_MASK * (iters - iters // 3 - 1), dt, "config 3's dense iteration (forward mesh, keypoints + contours, gather, reverse mesh, reduce)"),
+           "device_ms_last_iteration": per_class}
     b.close(); dev.close()
     return out
 
@@ -98,15 +120,28 @@ def cfg5x(reps, frames=8, n_views=48, iters=300, disp_iters=300):
         b.reset(); b.fit(iters); b.sync()
     dt = timed(run_fit, reps)
 
+    b.dense_timing(True); run_fit(); per_class = b.dense_timing(False, read=True)
+
     def run_disp():
         b.fit_displacement(disp_iters); b.sync()
     dd = timed(run_disp, reps)
     total = t_scan + dt + dd
+    nv = model["v_template"].shape[0]
+    search_s = per_class["closest_point_search"] * 1e-3
     out = {"config": "cfg5: %d frames x %d views, SMPL-X (%d v) with a %d-triangle scan each, closest-point loss, %d iterations, "
-                     "then %d SMPL+D iterations" % (frames, n_views, model["v_template"].shape[0], len(items[0][2]), iters, disp_iters),
+                     "then %d SMPL+D iterations" % (frames, n_views, nv, len(items[0][2]), iters, disp_iters),
            "frames_per_s_end_to_end": frames / total, "ms_scan_upload_and_grid": t_scan * 1e3, "ms_per_fit": dt * 1e3,
            "ms_per_iteration": dt * 1e3 / iters, "ms_displacement_stage": dd * 1e3,
-           "ms_per_displacement_iteration": dd * 1e3 / disp_iters}
+           "ms_per_displacement_iteration": dd * 1e3 / disp_iters,
+           "roofline": nominal_roofline(BYTES_CFG5_ITER * iters * frames, dt, "config 5's dense iteration (forward mesh, closest-point search, point-cloud loss, reverse mesh, reduce)"),
+           "device_ms_last_iteration": per_class,
+           # the iteration's dominant kernel is not bound by bytes: one query per wave, ~868 VALU instructions per query
+           "dominant_kernel": {"name": "bf_nearest_kernel", "bound": "valu_issue", "queries_per_launch": frames * nv,
+                               "valu_per_query_wave": NEAREST_VALU_PER_QUERY, "ms_per_launch": search_s * 1e3,
+                               "issue_bound_ms": frames * nv * NEAREST_VALU_PER_QUERY / SIMD_VALU_PER_S * 1e3,
+                               "frac": frames * nv * NEAREST_VALU_PER_QUERY / SIMD_VALU_PER_S / search_s if search_s > 0 else None,
+                               "note": "frac = queries x VALU instructions per query-wave / (1,024 SIMDs x 2.4 GHz / 4) / the search's device time in "
+                                       "the last dense iteration (HIP events); instructions per query from the PMC pass in profiles/"}}
     b.close()
     for s in scans:
         s.close()
