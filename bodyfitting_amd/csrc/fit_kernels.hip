@@ -801,9 +801,11 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
         auto one_view = [&](int v, float4 gxy, float4 kc) {
             const float4 *P = (const float4 *)__builtin_assume_aligned(S.proj + v * 12, 16);
             const float4 Pa4 = P[0], Pb4 = P[1], Pc4 = P[2];
-            const v2f p0 = Pa4.x * x0 + Pa4.y * x1 + Pa4.z * x2 + Pa4.w;
-            const v2f p1 = Pb4.x * x0 + Pb4.y * x1 + Pb4.z * x2 + Pb4.w;
-            const v2f p2 = Pc4.x * x0 + Pc4.y * x1 + Pc4.z * x2 + Pc4.w;
+            // (the row's fourth entry seeds the multiply-add chain: three packed fma per row instead of mul, fma, fma, splat, add)
+            const v2f w0 = {Pa4.w, Pa4.w}, w1 = {Pb4.w, Pb4.w}, w2 = {Pc4.w, Pc4.w};
+            v2f p0 = Pa4.x * x0 + w0; p0 = Pa4.y * x1 + p0; p0 = Pa4.z * x2 + p0;
+            v2f p1 = Pb4.x * x0 + w1; p1 = Pb4.y * x1 + p1; p1 = Pb4.z * x2 + p1;
+            v2f p2 = Pc4.x * x0 + w2; p2 = Pc4.y * x1 + p2; p2 = Pc4.z * x2 + p2;
             const v2f ip2 = {__builtin_amdgcn_rcpf(p2.x), __builtin_amdgcn_rcpf(p2.y)};     // v_rcp_f32: 1 ulp
             const v2f u = p0 * ip2, w = p1 * ip2;
             const v2f gx = {gxy.x, gxy.y}, gy = {gxy.z, gxy.w}, kk = {kc.x, kc.y}, cc = {kc.z, kc.w};
