@@ -78,10 +78,14 @@ __host__ __device__ inline int pad4(int n) { return (n + 3) & ~3; }
 #define BF_PDT_LD 210      // row stride of the transposed selector posedirs: 7 slices of 30 rows
 
 // Carve the dynamic LDS segment; the same function sizes it on the host (base == nullptr).
+// (`placed`: false = sizes only.  Said by the caller, NOT read off `base`: in the kernel `base` is the LDS segment, a generic pointer whose
+//  test against null the compiler sometimes failed to fold - "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base", a
+//  compare of the segment's aperture with zero in a form the instruction set does not have - and sometimes not, with unrelated edits
+//  deciding which: the defect that cost round 5 six builds before `llc` on the whole module, not on one kernel, reproduced it.)
 __host__ __device__ inline size_t fit_smem_carve(FitSmem &s, float *base, int nj, int nb, int npf, int ns,
-                                                  int nl, int np, int nviews) {
+                                                  int nl, int np, int nviews, bool placed = true) {
     size_t o = 0;
-    auto take = [&](int n) { float *p = base ? base + o : nullptr; o += pad4(n); return p; };
+    auto take = [&](int n) { float *p = placed ? base + o : nullptr; o += pad4(n); return p; };
     // arrays whose size follows from (nj, nb, npf, ns) first: in the compile-time-sized instance their offsets are
     // immediates of the ds instructions; the ones sized by np (a launch value) and by the number of views come last
     s.R = take(nj * 9);    s.rc = take(nj * 4);   s.J = take(nj * 3);
@@ -1995,7 +1999,7 @@ extern "C" void bf_fit_image_segments(int nj, int nb, int npf, int ns, int nl, i
 
 extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int np, int nviews) {
     FitSmem s;
-    return fit_smem_carve(s, nullptr, nj, nb, npf, ns, nl, np, nviews);
+    return fit_smem_carve(s, nullptr, nj, nb, npf, ns, nl, np, nviews, false);
 }
 
 // (the compile-time-sized SMPL instance also assumes at most 4 bones per selector vertex - true of SMPL's skinning weights)

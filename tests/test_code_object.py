@@ -62,4 +62,37 @@ def test_every_kernel_keeps_its_scratch_small():
     assert worst[".private_segment_fixed_size"] < SCRATCH_LIMIT_BYTES_PER_LANE, (worst[".name"], worst[".private_segment_fixed_size"])
     # the headline instance (SMPL, sparse schedule): no spill inside its loop - what is left is the prologue's batched image copy
     head = [k for k in fit if "ILi24ELi10ELi11ELi25ELb0EE" in k[".name"]][0]
-    assert head[".private_segment_fixed_size"] <= 96 and head[".vgpr_count"] <= 256
+    # (round 5: 112 B with the scheduler's max-ILP strategy, which batches more of the prologue's LDS-image loads; the scratch traffic is
+    #  still the prologue's eight scratch_store / scratch_load_dwordx4, none between the loop's barriers - the disassembly check below)
+    assert head[".private_segment_fixed_size"] <= 128 and head[".vgpr_count"] <= 256
+
+
+def test_headline_fit_kernel_has_no_scratch_traffic_inside_its_loops(tmp_path):
+    """the persistent loops of fit_kernel<24,10,11,25,false> (everything from its third s_barrier on: the two before it belong to the
+    prologue) must not touch scratch memory - a spill there is a global-memory round trip in every iteration"""
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    path = _lib.LIB_PATH
+    if not (os.path.exists(objdump) and os.path.exists(path)):
+        pytest.skip("llvm-objdump or libbodyfit.so not available")
+    blob = open(path, "rb").read()
+    dis = ""
+    for k, base in enumerate(_amdgpu_code_objects(blob)):
+        shoff, = struct.unpack_from("<Q", blob, base + 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", blob, base + 0x3A)
+        co = tmp_path / f"co{k}.elf"
+        co.write_bytes(blob[base:base + shoff + shentsize * shnum])
+        out = subprocess.run([objdump, "-d", "--mcpu=gfx950", str(co)], capture_output=True, text=True).stdout
+        if "fit_kernelILi24ELi10ELi11ELi25ELb0E" in out:
+            dis = out
+            break
+    start = dis.find("fit_kernelILi24ELi10ELi11ELi25ELb0E")
+    assert start >= 0, "the headline instance was not found in any embedded code object"
+    body = dis[start:]
+    body = body[:body.find("s_endpgm")]
+    lines = body.splitlines()
+    bars = [i for i, l in enumerate(lines) if "s_barrier" in l]
+    assert len(bars) >= 8
+    in_loops = [l for l in lines[bars[2]:] if "scratch_" in l]
+    assert not in_loops, in_loops[:4]
+    assert any("scratch_" in l for l in lines[:bars[0]])            # (the prologue's batched image copy: where the segment is used)
