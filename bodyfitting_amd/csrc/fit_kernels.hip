@@ -816,14 +816,17 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             const v2f rx = (gx - u) * icoeff, ry = (gy - w) * icoeff;
             const v2f ax = rx * rx, ay = ry * ry;
             const v2f dx = ax + s2, dy = ay + s2;
-            const v2f ix = {__builtin_amdgcn_rcpf(dx.x), __builtin_amdgcn_rcpf(dx.y)};
-            const v2f iy = {__builtin_amdgcn_rcpf(dy.x), __builtin_amdgcn_rcpf(dy.y)};
+            // (one v_rcp_f32 per joint for both GMoF denominators, 1 / dx = dy / (dx dy): a transcendental is a quarter-rate instruction;
+            //  with the two regroupings below - (kk ix)(rx ix), and q2's term last in the gradient's sum - 9,93x -> 9,85x cycles, same box)
+            const v2f dxy = dx * dy;
+            const v2f ixy = {__builtin_amdgcn_rcpf(dxy.x), __builtin_amdgcn_rcpf(dxy.y)};
+            const v2f ix = ixy * dy, iy = ixy * dx;
             if (want_loss) lsum += cc * (ax * ix + ay * iy);          // (the value only leaves with the last forward pass)
-            const v2f du = kk * rx * ix * ix, dw = kk * ry * iy * iy;
+            const v2f du = (kk * ix) * (rx * ix), dw = (kk * iy) * (ry * iy);
             const v2f q0 = du * ip2, q1 = dw * ip2, q2 = -(du * u + dw * w) * ip2;
-            g0 += Pa4.x * q0 + Pb4.x * q1 + Pc4.x * q2;
-            g1 += Pa4.y * q0 + Pb4.y * q1 + Pc4.y * q2;
-            g2 += Pa4.z * q0 + Pb4.z * q1 + Pc4.z * q2;
+            g0 = Pc4.x * q2 + (g0 + (Pa4.x * q0 + Pb4.x * q1));
+            g1 = Pc4.y * q2 + (g1 + (Pa4.y * q0 + Pb4.y * q1));
+            g2 = Pc4.z * q2 + (g2 + (Pa4.z * q0 + Pb4.z * q1));
         };
         // no per-round branch: records past V carry zero factors and the view index is clamped, so the rounds are
         // independent straight-line code the scheduler interleaves
