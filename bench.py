@@ -420,6 +420,7 @@ def main_dense(a):
                         "note": "nominal SURVEY 8(d) bytes per frame-iteration x iterations x frames over the fit's wall time on rank 0 "
                                 "(the resident fit launch and 5 kernels per iteration; frames of a shard share one model stream)"}}
     out["device_ms_last_iteration"] = per_class
+    out["resident_fit_launch"] = batch.dense_resident()
     if cfg == 5 and per_class and per_class.get("closest_point_search"):
         sys.path.insert(0, os.path.join(REPO, "tools"))
         import bench_configs as BC

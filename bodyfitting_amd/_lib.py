@@ -61,6 +61,7 @@ SIGNATURES = {
     "bf_model_fit_instance": (C.c_int, [_VP]),
     "bf_device_cache_trim": (C.c_int64, [C.c_int]),
     "bf_batch_dense_timing": (C.c_int, [_VP, C.c_int, _FP]),
+    "bf_batch_dense_resident": (C.c_int, [_VP]),
     "bf_smpl_forward": (C.c_int, [_VP, C.c_int, _FP, _FP, _FP, _FP, _FP, _FP]),
     "bf_model_forward": (C.c_int, [_VP, C.c_int, _FP, _FP, _FP]),
     "bf_batch_create": (C.c_int, [_VP, C.c_int, C.c_int, C.POINTER(_VP)]),

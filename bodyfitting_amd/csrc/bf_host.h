@@ -238,6 +238,7 @@ struct bf_batch {
     bool dense_timing = false, dense_timed = false;
     hipEvent_t ev_dense[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool door_usable = false;           // the self-test at first use found the fit stream running beside the batch stream
+    int dense_resident = -1;            // bf_batch_dense_resident: how the last dense fit ran
     hipEvent_t ev_door[2] = {nullptr, nullptr};
     DevBuf<int> door;
     int *h_resident = nullptr;          // pinned, device-visible: workgroups of the persistent launch that have started (this call)

@@ -672,6 +672,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     const bool door_ok = [] { const char *e = std::getenv("BF_DENSE_PERSISTENT"); return !(e && e[0] == '0'); }();
     const int n_dense = n_iters - n_plain;
     if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES) { rc = ensure_fit_stream(b, io, hd); if (rc) return rc; }
+    if (n_dense >= 1) b->dense_resident = (door_ok && F < BF_MFMA_MIN_FRAMES && b->door_usable) ? 1 : 0;
     if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES && b->door_usable) {
         *(volatile int *)b->h_resident = 0;
         HIP_TRY(hipMemsetAsync(b->door.p, 0, BF_DOOR_INTS * sizeof(int), b->stream));
@@ -716,6 +717,8 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     }
     return BF_OK;
 }
+
+int bf_batch_dense_resident(const bf_batch *b) { return b ? b->dense_resident : -1; }
 
 int bf_batch_dense_timing(bf_batch *b, int enable, float ms[6]) {
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_dense_timing: null batch");

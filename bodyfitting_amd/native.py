@@ -432,6 +432,11 @@ class FrameBatch:
         _lib.check(self._lib.bf_batch_dense_timing(self._h, int(bool(enable)), _lib.fptr(ms)), "bf_batch_dense_timing")
         return None if ms is None else dict(zip(self.DENSE_CLASSES, (float(x) for x in ms)))
 
+    def dense_resident(self):
+        """True / False: the last dense fit ran with the fit kernel resident / one launch per iteration; None: no dense fit yet"""
+        r = self._lib.bf_batch_dense_resident(self._h)
+        return None if r < 0 else bool(r)
+
     def debug_dump(self, n):
         out = np.zeros(n, np.float32)
         _lib.check(self._lib.bf_batch_debug_dump(self._h, _lib.fptr(out), int(n)), "bf_batch_debug_dump")

@@ -413,6 +413,10 @@ int bf_batch_mesh_span(bf_batch *b, int reps, float us[3]);
  * ms[2] closest-point search, ms[3] point-cloud loss + gradient, ms[4] reverse mesh pass, ms[5] reduction of the partial blocks.  `enable`
  * switches the recording for the following fits (the events cost a few microseconds of that one iteration); ms may be NULL. */
 int bf_batch_dense_timing(bf_batch *b, int enable, float ms[6]);
+/* How the dense iterations of this batch's fits have run: 1 = with the fit kernel resident (one launch per fit on its own stream, paced by
+ * doorbells), 0 = one fit launch per iteration (the self-test found the two streams on one hardware queue - libbodyfit says so once on
+ * stderr - or BF_DENSE_PERSISTENT=0, or 16+ frames), -1 = no dense fit has run yet.  Same results either way; ~3x the time without. */
+int bf_batch_dense_resident(const bf_batch *b);
 
 /* ---- test hooks (bring-up / parity tests only; not part of the drop-in surface) ----------------------------------
  * first-iteration intermediates of frame 0 written by the last bf_loss_grad launch (layout: tests/gpu_debug.py) */

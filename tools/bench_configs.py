@@ -65,7 +65,7 @@ def cfg3(reps, n_views=48, iters=200, mask_views=8):
            "frames_per_s": 1.0 / dt, "ms_per_fit": dt * 1e3, "ms_per_iteration": dt * 1e3 / iters,
            "ms_mask_upload_and_contours": t_masks * 1e3,
            "roofline": nominal_roofline(BYTES_SMPLX_FWD * iters + BYTES_CFG3_MASK * (iters - iters // 3 - 1), dt, "config 3's dense iteration (forward mesh, keypoints + contours, gather, reverse mesh, reduce)"),
-           "device_ms_last_iteration": per_class}
+           "device_ms_last_iteration": per_class, "resident_fit_launch": b.dense_resident()}
     b.close(); dev.close()
     return out
 
@@ -134,7 +134,7 @@ def cfg5x(reps, frames=8, n_views=48, iters=300, disp_iters=300):
            "ms_per_iteration": dt * 1e3 / iters, "ms_displacement_stage": dd * 1e3,
            "ms_per_displacement_iteration": dd * 1e3 / disp_iters,
            "roofline": nominal_roofline(BYTES_CFG5_ITER * iters * frames, dt, "config 5's dense iteration (forward mesh, closest-point search, point-cloud loss, reverse mesh, reduce)"),
-           "device_ms_last_iteration": per_class,
+           "device_ms_last_iteration": per_class, "resident_fit_launch": b.dense_resident(),
            # the iteration's dominant kernel is not bound by bytes: one query per wave, ~868 VALU instructions per query
            "dominant_kernel": {"name": "bf_nearest_kernel", "bound": "valu_issue", "queries_per_launch": frames * nv,
                                "valu_per_query_wave": NEAREST_VALU_PER_QUERY, "ms_per_launch": search_s * 1e3,
