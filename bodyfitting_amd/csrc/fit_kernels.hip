@@ -1988,6 +1988,44 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
     }
 }
 
+// This file is compiled TWICE (Makefile): BF_FIT_PART 0 - the instances with compile-time sizes and everything on the host side, with
+// the scheduler's max-ILP strategy - and BF_FIT_PART 1 (fit_kernels_table.o) - the two table-driven instances behind
+// bf_fit_launch_table, with the default scheduler: same box, max-ILP is 2 % faster on the sized SMPL instance and 8 % SLOWER on the
+// table-driven one (837 against 909 frames/s).
+#ifndef BF_FIT_PART
+#define BF_FIT_PART 0
+#endif
+
+// launches one of two instantiations; `slot`: the per-device cache entry of the dynamic-LDS attribute already set for it
+template <class K>
+static hipError_t fit_launch_one(K kern, size_t *have, const FitTab *T, const FrameIO *io, const HyperDev *hp, int n_iters, int mode,
+                                 const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
+    if (smem > 64 * 1024 && smem > *have) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return e;
+        *have = smem;
+    }
+    hipLaunchKernelGGL(kern, dim3(io->n_frames), dim3(BF_FIT_THREADS), smem, stream, *T, *io, *hp, n_iters, mode, adam_tab, adam_t0);
+    return hipGetLastError();
+}
+
+#if BF_FIT_PART == 1
+// the table-driven instances (any model the sized ones do not cover)
+extern "C" hipError_t bf_fit_launch_table(const FitTab *T, const FrameIO *io, const HyperDev *hp, int n_iters, int mode,
+                                          const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
+    // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: the cache of what was set is keyed by device
+    static size_t attr[16][2] = {};
+    size_t none = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    const bool ext = io->ext != nullptr;
+    size_t *have = (dev >= 0 && dev < 16) ? &attr[dev][ext ? 1 : 0] : &none;
+    if (ext) return fit_launch_one(fit_kernel<0, 0, 0, 0, true>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
+    return fit_launch_one(fit_kernel<0, 0, 0, 0, false>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
+}
+#else
+extern "C" hipError_t bf_fit_launch_table(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
+
 // The three contiguous runs of model-constant arrays in the carve, as (first float4, float4 count): Jtrel .. nzj | sel_pd2 .. par |
 // pk .. pb_ (each run may contain a scratch array or two; copying them is cheaper than splitting the run)
 extern "C" void bf_fit_image_segments(int nj, int nb, int npf, int ns, int nl, int np, int seg[6]) {
@@ -2018,19 +2056,15 @@ extern "C" hipError_t bf_fit_launch(const FitTab *T, const FrameIO *io, const Hy
     // SMPL-X in the dense schedule (keypoints through bf_kp_loss_kernel: no selector vertices, no loss joints here): sizes fixed
     // at compile time like SMPL's, the phases stay the table-driven ones
     const bool smplx_dense = ext && T->nj == 55 && T->nb == 10 && T->ns == 0 && T->nl == 0;
-    auto kern = smpl ? (ext ? fit_kernel<24, 10, 11, 25, true> : fit_kernel<24, 10, 11, 25, false>)
-                     : (smplx_dense ? fit_kernel<55, 10, 0, 0, true> : (ext ? fit_kernel<0, 0, 0, 0, true> : fit_kernel<0, 0, 0, 0, false>));
+    if (!smpl && !smplx_dense) return bf_fit_launch_table(T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
     // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: the cache of what was set is keyed by device
-    static size_t attr[16][5] = {};
-    static size_t none = 0;
+    static size_t attr[16][3] = {};
+    size_t none = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
-    size_t &have = (dev >= 0 && dev < 16) ? attr[dev][smplx_dense ? 4 : (smpl ? 2 : 0) + (ext ? 1 : 0)] : (none = 0);
-    if (smem > 64 * 1024 && smem > have) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return e;
-        have = smem;
-    }
-    hipLaunchKernelGGL(kern, dim3(io->n_frames), dim3(BF_FIT_THREADS), smem, stream, *T, *io, *hp, n_iters, mode, adam_tab, adam_t0);
-    return hipGetLastError();
+    size_t *have = (dev >= 0 && dev < 16) ? &attr[dev][smplx_dense ? 2 : (ext ? 1 : 0)] : &none;
+    if (smplx_dense) return fit_launch_one(fit_kernel<55, 10, 0, 0, true>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
+    if (ext) return fit_launch_one(fit_kernel<24, 10, 11, 25, true>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
+    return fit_launch_one(fit_kernel<24, 10, 11, 25, false>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
 }
+#endif
