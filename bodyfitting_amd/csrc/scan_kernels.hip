@@ -128,7 +128,11 @@ __device__ inline int nn_wave_min_i(int v) {
 // routines right there: a call on the lanes concerned, its systems in the wave's slot of an LDS array (a version with private arrays
 // needed 104 registers and scratch memory; a second kernel doing such queries again cost 55 - 85 us per launch for a few hundred of
 // them, one wave-latency each).
-constexpr int NN_PASSES = 4;                    // passes of 64 list entries per trip through the screen: their loads are in flight together
+#ifndef BF_NN_PASSES
+#define BF_NN_PASSES 3
+#endif
+constexpr int NN_PASSES = BF_NN_PASSES;   // passes of 64 list entries per trip through the screen, their loads in flight together (same box,
+                                           // config 5 size, warm / moved 5 mm / cold us: 2 -> 117 / 165 / 208, 3 -> 114 / 156 / 216, 4 -> 121 / 166 / 234, 5 -> 122 / 169 / 240)
 constexpr int NN_QCAP = 64 * (NN_PASSES + 1);   // a wave's queue of screened records
 #ifdef BF_NEAREST_STATS
 // diagnostic build (make CXXFLAGS+=-DBF_NEAREST_STATS): [0] queries [1] searches (1 + retries) [2] groups of cell lists [3] trips through
