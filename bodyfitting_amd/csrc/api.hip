@@ -232,7 +232,16 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     auto up_vi = [&](DevBuf<int> &b, const std::vector<int> &h) { okay = okay && b.upload(h) == hipSuccess; };
     up_f(m->v_template, d->v_template, (size_t)nv * 3);
     up_f(m->shapedirs, d->shapedirs, (size_t)nv * 3 * nb);
-    up_f(m->posedirs, d->posedirs, (size_t)npf * 3 * nv);
+    // posedirs rows are padded to a multiple of 128 bytes: a tile's 96 columns are 384 bytes, and with the natural pitch (SMPL: 82,680 B)
+    // every slice straddled a fourth line that the neighbouring tile's workgroup - usually on another XCD - fetched again (counter
+    // traffic 1.30 x the algorithmic bytes in rounds 2-4)
+    auto pd_pitch_of = [](int cols) { return (cols + 31) & ~31; };
+    auto up_rows = [&](DevBuf<float> &b, const float *src, int rows, int cols, int pitch) {
+        std::vector<float> h((size_t)rows * pitch, 0.f);
+        for (int r = 0; r < rows; ++r) memcpy(h.data() + (size_t)r * pitch, src + (size_t)r * cols, (size_t)cols * sizeof(float));
+        okay = okay && b.upload(h) == hipSuccess;
+    };
+    up_rows(m->posedirs, d->posedirs, npf, 3 * nv, pd_pitch_of(3 * nv));
     if (d->n_faces > 0 && d->faces) {
         for (int i = 0; i < d->n_faces * 3; ++i)
             if (d->faces[i] < 0 || d->faces[i] >= nv) { delete m; return fail(BF_ERR_INVALID, "bf_model_create: face index out of range"); }
@@ -373,7 +382,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
     MeshTab &Q = m->mesh;
     Q.nv = nv; Q.nj = nj; Q.nb = nb; Q.npf = npf;
     Q.n_selector = d->n_selector; Q.n_extra = d->n_extra; Q.n_joint_map = d->n_joint_map;
-    Q.v_template = m->v_template.p; Q.shapedirs = m->shapedirs.p; Q.posedirs = m->posedirs.p;
+    Q.v_template = m->v_template.p; Q.shapedirs = m->shapedirs.p; Q.posedirs = m->posedirs.p; Q.pd_pitch = pd_pitch_of(3 * nv);
     Q.lbs_weights = m->lbs_weights.p; Q.j_extra = m->j_extra.p;
     Q.selector_ids = m->selector_ids.p; Q.joint_map = m->joint_map.p;
     Q.n_tiles = (nv + BF_MESH_TILE - 1) / BF_MESH_TILE;
@@ -445,7 +454,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
             for (int v = 0; v < nv; ++v) if (extra[v] && pos[v] < 0) { pos[v] = (int)S.size(); S.push_back(v); }
             const int sv = (int)S.size();
             if (sv == 0 || sv * 10 > nv * max_tenths) return BF_OK;          // (not worth it: the full model serves)
-            std::vector<float> vt((size_t)sv * 3), sd((size_t)sv * 3 * nb), pd((size_t)npf * 3 * sv), lw((size_t)sv * nj), jx((size_t)std::max(d->n_extra, 0) * sv);
+            std::vector<float> vt((size_t)sv * 3), sd((size_t)sv * 3 * nb), pd((size_t)npf * pd_pitch_of(3 * sv), 0.f), lw((size_t)sv * nj), jx((size_t)std::max(d->n_extra, 0) * sv);
             const int nnz = m->mesh.v_nnz;
             std::vector<int> zj((size_t)sv * std::max(nnz, 1), 0), sel(d->n_selector), fc;
             std::vector<float> zw((size_t)sv * std::max(nnz, 1), 0.f);
@@ -454,7 +463,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
                 for (int k = 0; k < 3; ++k) {
                     vt[(size_t)i * 3 + k] = d->v_template[(size_t)v * 3 + k];
                     for (int l = 0; l < nb; ++l) sd[((size_t)i * 3 + k) * nb + l] = d->shapedirs[((size_t)v * 3 + k) * nb + l];
-                    for (int p = 0; p < npf; ++p) pd[(size_t)p * 3 * sv + (size_t)i * 3 + k] = d->posedirs[(size_t)p * 3 * nv + (size_t)v * 3 + k];
+                    for (int p = 0; p < npf; ++p) pd[(size_t)p * pd_pitch_of(3 * sv) + (size_t)i * 3 + k] = d->posedirs[(size_t)p * 3 * nv + (size_t)v * 3 + k];
                 }
                 int c = 0;
                 for (int j = 0; j < nj; ++j) {
@@ -475,7 +484,7 @@ int bf_model_create(const bf_model_desc *d, int device, bf_model **out) {
             if (!up) return fail(BF_ERR_HIP, "bf_model_create: device allocation failed (sub-model)");
             U.mesh = m->mesh;
             U.mesh.nv = sv; U.mesh.n_tiles = (sv + BF_MESH_TILE - 1) / BF_MESH_TILE;
-            U.mesh.v_template = U.v_template.p; U.mesh.shapedirs = U.shapedirs.p; U.mesh.posedirs = U.posedirs.p;
+            U.mesh.v_template = U.v_template.p; U.mesh.shapedirs = U.shapedirs.p; U.mesh.posedirs = U.posedirs.p; U.mesh.pd_pitch = pd_pitch_of(3 * sv);
             U.mesh.lbs_weights = U.lbs_weights.p; U.mesh.j_extra = U.j_extra.p; U.mesh.selector_ids = U.selector_ids.p;
             U.mesh.v_nzj = U.v_nzj.p; U.mesh.v_nzw = U.v_nzw.p;
             if (smplx) {

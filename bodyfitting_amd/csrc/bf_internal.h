@@ -81,7 +81,8 @@ struct MeshTab {
     int n_selector, n_extra, n_joint_map;
     const float *v_template;         // [nv*3]
     const float *shapedirs;          // [nv*3][nb]
-    const float *posedirs;           // [npf][3nv]
+    const float *posedirs;           // [npf][pd_pitch]: rows of 3 nv floats, padded to a multiple of 128 bytes
+    int pd_pitch;
     const float *lbs_weights;        // [nv][nj]
     const float *j_extra;            // [n_extra][nv]
     const int *selector_ids;         // [n_selector]

@@ -79,10 +79,11 @@ __device__ __forceinline__ void bf_mesh_body(const MeshTab &M, const float *__re
     // ---- request everything ------------------------------------------------------------------
     const int rows = (npf + BF_MESH_RG - 1) / BF_MESH_RG;
     const int p0 = rg * rows, p1 = min(npf, p0 + rows);
-    const float *pd = M.posedirs + (size_t)p0 * ncols + (ok ? gcol : 0);
+    const int pdp = M.pd_pitch;                 // (floats between posedirs rows: 3 nv rounded up to 128 bytes, so that a tile's 384-byte slice of a row is three whole lines)
+    const float *pd = M.posedirs + (size_t)p0 * pdp + (ok ? gcol : 0);
     float pv[BF_MESH_PF];
 #pragma unroll
-    for (int i = 0; i < BF_MESH_PF; ++i) pv[i] = (!pose_off && p0 + i < p1) ? pd[(size_t)i * ncols] : 0.f;
+    for (int i = 0; i < BF_MESH_PF; ++i) pv[i] = (!pose_off && p0 + i < p1) ? pd[(size_t)i * pdp] : 0.f;
     // (pose_off: the pose blend of this frame was already formed by bf_poseblend_mfma_kernel for the whole batch)
     const float poff = (pose_off && rg == 0 && ok) ? pose_off[(size_t)frame * ncols + gcol] : 0.f;
     float wreg[BF_MESH_WPF], sdreg[12], vt = 0.f, jx[BF_MESH_TILE];
@@ -133,7 +134,7 @@ __device__ __forceinline__ void bf_mesh_body(const MeshTab &M, const float *__re
     float acc = 0.f;
 #pragma unroll
     for (int i = 0; i < BF_MESH_PF; ++i) acc += (p0 + i < p1 ? s_feat[p0 + i] : 0.f) * pv[i];
-    if (!pose_off) for (int p = p0 + BF_MESH_PF; p < p1; ++p) acc += s_feat[p] * pd[(size_t)(p - p0) * ncols];
+    if (!pose_off) for (int p = p0 + BF_MESH_PF; p < p1; ++p) acc += s_feat[p] * pd[(size_t)(p - p0) * pdp];
     s_red[rg * COLS + col] = pose_off ? (rg == 0 ? poff : 0.f) : acc;
     if (rg == 1) {
         float a2 = 0.f;
@@ -244,10 +245,11 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
 
     // ---- first chunk of the stream, then the per-frame state into LDS ----------------------------------------------
     const int p0 = rg * rows, p1 = min(npf, p0 + rows);
-    const float *pd = M.posedirs + (size_t)p0 * ncols + (ok ? gcol : 0);
+    const int pdp = M.pd_pitch;
+    const float *pd = M.posedirs + (size_t)p0 * pdp + (ok ? gcol : 0);
     float pv[BF_MM_CH];
 #pragma unroll
-    for (int i = 0; i < BF_MM_CH; ++i) pv[i] = p0 + i < p1 ? pd[(size_t)i * ncols] : 0.f;
+    for (int i = 0; i < BF_MM_CH; ++i) pv[i] = p0 + i < p1 ? pd[(size_t)i * pdp] : 0.f;
     const bool coh = door && (door_target & BF_DOOR_COHERENT_BIT);
     // ... and so are the model rows the epilogue needs for this thread's vertex coordinate (shape directions, template, the sparse
     // skinning row): they depend on nothing that is waited for below, and requested here their two memory round trips are over
@@ -307,7 +309,7 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
         const bool more = c0 + BF_MM_CH < rows;
         if (more) {
 #pragma unroll
-            for (int i = 0; i < BF_MM_CH; ++i) nx[i] = p0 + c0 + BF_MM_CH + i < p1 ? pd[(size_t)(c0 + BF_MM_CH + i) * ncols] : 0.f;
+            for (int i = 0; i < BF_MM_CH; ++i) nx[i] = p0 + c0 + BF_MM_CH + i < p1 ? pd[(size_t)(c0 + BF_MM_CH + i) * pdp] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < BF_MM_CH; ++i) {
@@ -549,7 +551,7 @@ bf_poseblend_gemm_kernel(MeshTab M, const float *__restrict__ featT, int kpad, i
             const int r = r0 + 8 * q, p = 2 * kb + r;
             float2 v = {0.f, 0.f};
             if (r < ROWS && p < npf) {
-                const float *src = M.posedirs + (size_t)p * ncols + cbase + c2;
+                const float *src = M.posedirs + (size_t)p * M.pd_pitch + cbase + c2;
                 if (cpair) v = *(const float2 *)src; else if (csingle) v.x = src[0];
             }
             st[q] = v;
@@ -802,10 +804,11 @@ bf_mesh_batch32_kernel(MeshTab M, const float *__restrict__ state, int n_frames,
     bf_f3u bq[KS];
     {
         const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const float *bcol = M.posedirs + (size_t)(2 * wv) * ncols + min(v0 + mi, nv - 1) * 3 + kh * ncols;
+        const int pdp = M.pd_pitch;
+        const float *bcol = M.posedirs + (size_t)(2 * wv) * pdp + min(v0 + mi, nv - 1) * 3 + kh * pdp;
 #pragma unroll
-        for (int s2 = 0; s2 < KS - 1; ++s2) bq[s2] = *(const bf_f3u *)(bcol + (size_t)(2 * NW * s2) * ncols);
-        bq[KS - 1] = *(const bf_f3u *)(bcol + (size_t)(min(2 * NW * (KS - 1) + 2 * wv + kh, npf - 1) - 2 * wv - kh) * ncols);
+        for (int s2 = 0; s2 < KS - 1; ++s2) bq[s2] = *(const bf_f3u *)(bcol + (size_t)(2 * NW * s2) * pdp);
+        bq[KS - 1] = *(const bf_f3u *)(bcol + (size_t)(min(2 * NW * (KS - 1) + 2 * wv + kh, npf - 1) - 2 * wv - kh) * pdp);
     }
     // the vertex's tables (thread = vertex tid & 31, frames 4 (tid >> 5) ..)
     const int vl = tid & 31, fo = tid >> 5, v = v0 + vl;
@@ -1068,13 +1071,13 @@ bf_mesh_epilogue_kernel(MeshTab M, const float *__restrict__ state, const float 
 
 // out[c][r] = in[r][c]: posedirs [npf][3NV] -> posedirsT [3NV][npf] for the reverse pass, once per model.  32 x 32 tiles through
 // LDS (padded row: no bank conflicts), both sides coalesced.  grid (ceil(cols / 32), ceil(rows / 32)), 256 threads.
-extern "C" __global__ void __launch_bounds__(256) bf_transpose_kernel(const float *__restrict__ in, int rows, int cols, float *__restrict__ out) {
+extern "C" __global__ void __launch_bounds__(256) bf_transpose_kernel(const float *__restrict__ in, int rows, int cols, float *__restrict__ out, int in_pitch) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = r0 + ty + k * 8, c = c0 + tx;
-        tile[ty + k * 8][tx] = (r < rows && c < cols) ? in[(size_t)r * cols + c] : 0.f;
+        tile[ty + k * 8][tx] = (r < rows && c < cols) ? in[(size_t)r * in_pitch + c] : 0.f;
     }
     __syncthreads();
 #pragma unroll

@@ -26,7 +26,7 @@ extern "C" __global__ void bf_face_normal_kernel(const float *, const int *, int
 extern "C" __global__ void bf_inside_mesh_kernel(ScanDev, const float *, int, float *);
 extern "C" __global__ void bf_intersect_kernel(ScanDev, const float *, const float *, int, unsigned char *);
 extern "C" __global__ void bf_nearest_backward_kernel(ScanDev, int, const int *, const float *, const float *, float *);
-extern "C" __global__ void bf_transpose_kernel(const float *, int, int, float *);
+extern "C" __global__ void bf_transpose_kernel(const float *, int, int, float *, int);
 extern "C" __global__ void bf_contour_kernel(const unsigned char *, int, int, int, int, float *, int *, unsigned *);
 extern "C" __global__ void bf_kp_contour_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
                                                 const float *, float *, float *, float *, MaskIO, const float *, int *, float *, float *,
@@ -340,7 +340,7 @@ int bf_ensure_dense_buffers(bf_batch *b) {
             DevBuf<float> t;
             HIP_TRY(t.alloc((size_t)nv3 * m->npf));
             hipLaunchKernelGGL(bf_transpose_kernel, dim3((nv3 + 31) / 32, (m->npf + 31) / 32), dim3(256), 0, b->stream,
-                               (const float *)m->posedirs.p, m->npf, (int)nv3, t.p);
+                               (const float *)m->posedirs.p, m->npf, (int)nv3, t.p, m->mesh.pd_pitch);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(b->stream));
             m->posedirsT.p = t.p; m->posedirsT.n = t.n; t.p = nullptr;
@@ -351,7 +351,7 @@ int bf_ensure_dense_buffers(bf_batch *b) {
             DevBuf<float> t;
             HIP_TRY(t.alloc(sv3 * m->npf));
             hipLaunchKernelGGL(bf_transpose_kernel, dim3((sv3 + 31) / 32, (m->npf + 31) / 32), dim3(256), 0, b->stream,
-                               (const float *)U->posedirs.p, m->npf, (int)sv3, t.p);
+                               (const float *)U->posedirs.p, m->npf, (int)sv3, t.p, U->mesh.pd_pitch);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipStreamSynchronize(b->stream));
             U->posedirsT.p = t.p; U->posedirsT.n = t.n; t.p = nullptr;
