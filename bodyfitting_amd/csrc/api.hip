@@ -1,5 +1,6 @@
 // Host side of libbodyfit: the C ABI of include/bodyfit.h over the gfx950 kernels.
 #include "bf_host.h"
+#include <chrono>
 
 extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
@@ -636,7 +637,34 @@ static hipError_t write_input(bf_batch *b, void *dst, const void *src, size_t by
     return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice);
 }
 
+// the deferred part of a frame-after-frame call (fit_impl, `tail_aside`): mesh + joints + hand-over of result arena tail_k on the
+// second stream, behind the fit that filled it.  Every entry point that looks at results, events of the second stream or starts
+// another fit comes through here first (bf_sync_all, bf_fit, bf_batch_get_previous, bf_batch_stage_inputs, bf_batch_destroy).
+int bf_flush_tail(bf_batch *b) {
+    const int k = b->tail_k;
+    if (k < 0) return BF_OK;
+    b->tail_k = -1;
+    bf_model *m = b->m;
+    HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_done[k], 0));
+    float *d = k ? b->res_b.p : b->res.p;            // (arena k's slices by address: the views may already have moved on)
+    int rc = bf_launch_mesh(m, &b->scratch, b->F, d + b->res_off[2], b->vraw.p, d + b->res_off[4], b->xpart.p, d + b->res_off[3], nullptr,
+                            b->copy_stream, nullptr, nullptr);
+    if (rc) return rc;
+    if (b->tail_big) {
+        HIP_TRY(hipMemcpyAsync(k ? b->h_res_b : b->h_res, d, b->res.n * sizeof(float), hipMemcpyDeviceToHost, b->copy_stream));
+    } else {
+        const size_t n4 = b->res.n / 4;
+        hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->copy_stream,
+                           (const float4 *)d, (float4 *)(k ? b->h_res_b : b->h_res), n4);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(b->ev_copied[k], b->copy_stream));
+    b->tail_seq = b->arena_seq[k];
+    return BF_OK;
+}
+
 int bf_sync_all(bf_batch *b) {
+    { int rt_ = bf_flush_tail(b); if (rt_) return rt_; }
     if (b->copy_stream) HIP_TRY(hipStreamSynchronize(b->copy_stream));
     HIP_TRY(hipStreamSynchronize(b->stream));
     b->copy_pending[0] = b->copy_pending[1] = false;
@@ -653,6 +681,7 @@ int bf_sync_all(bf_batch *b) {
 }
 
 int bf_guard_arena(bf_batch *b) {
+    { int rt_ = bf_flush_tail(b); if (rt_) return rt_; }
     if (b->copy_pending[b->cur]) {
         HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_copied[b->cur], 0));
         b->copy_pending[b->cur] = false;
@@ -739,6 +768,7 @@ int bf_batch_create(bf_model *m, int n_frames, int n_views, bf_batch **out) {
 
 void bf_batch_destroy(bf_batch *b) {
     if (!b) return;
+    b->tail_k = -1;                       // (a tail never enqueued: nobody will read that result)
     if (b->copy_stream) (void)hipStreamSynchronize(b->copy_stream);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
     { std::lock_guard<std::mutex> lk(bf_scan_links()); bf_batch_unlink_scans(b); }      // (its scans outlive it: they forget this batch)
@@ -896,6 +926,24 @@ int bf_batch_stage_inputs(bf_batch *b, const float *keypoints, const int32_t *n_
         bf_use_inputs(b, k, true);
     } else {
         const size_t n4 = b->in_total / 4;
+        b->in_aside[k] = false;
+        if (b->stage_mode == 0 && b->tail_k >= 0 && b->copy_stream && b->in_reader[k] <= b->tail_seq) {
+            // Frame after frame (the fit in flight has its tail still to be enqueued): the transfer goes on the second stream, AHEAD of
+            // that tail, and runs under the fit in flight; the batch stream then holds that fit and the next one back to back (the
+            // transfer in between cost its 4.6 us and a second dispatch gap: ~13 us of a 430 us step).  Arena k was last read by fit
+            // in_reader[k], whose tail - it starts by waiting for that fit - is already on the second stream: the transfer is ordered
+            // behind it.  The fit that reads arena k waits for ev_in[k] (bf_fit: on the host while the fit in flight runs).
+            hipLaunchKernelGGL(bf_publish_kernel, dim3((unsigned)std::min<size_t>((n4 + 255) / 256, 64)), dim3(256), 0, b->copy_stream,
+                               (const float4 *)h, (float4 *)b->in_dev[k].p, n4);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(b->ev_in[k], b->copy_stream));
+            b->in_pending[k] = true;
+            b->in_aside[k] = true;
+            bf_use_inputs(b, k, false);
+            b->staged = true;
+            return bf_flush_tail(b);
+        }
+        { int rt_ = bf_flush_tail(b); if (rt_) return rt_; }
         if (b->stage_mode == 1) {
             HIP_TRY(hipMemcpyAsync(b->in_dev[k].p, h, b->in_total * sizeof(float), hipMemcpyHostToDevice, b->stream));
         } else {
@@ -1027,8 +1075,22 @@ int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (b->staged && !(flags & BF_FIT_RESET))
         return fail(BF_ERR_INVALID, "bf_fit: inputs were staged with bf_batch_stage_inputs - the fit of a new frame starts from its initial estimate (BF_FIT_RESET)");
     bf_masks_commit(b);                       // (silhouettes staged with bf_batch_stage_masks become this fit's)
-    int rc = fit_impl(b, n_iters, hyper, flags);
+    int rc = bf_flush_tail(b);
     if (rc) return rc;
+    if (b->in_aside[b->in_cur]) {
+        // inputs staged aside: their transfer was queued on the second stream a few microseconds ago and runs under the fit in flight.
+        // Waiting for it HERE, on the host, keeps a wait packet out of the batch stream (the fit in flight has hundreds of
+        // microseconds to go); only if it does not show up in time does the stream wait for it.
+        hipError_t q = hipErrorNotReady;
+        const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(500);
+        while ((q = hipEventQuery(b->ev_in[b->in_cur])) == hipErrorNotReady && std::chrono::steady_clock::now() < t_end) { }
+        if (q == hipErrorNotReady) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_in[b->in_cur], 0));
+        else HIP_TRY(q);
+        b->in_aside[b->in_cur] = false;
+    }
+    rc = fit_impl(b, n_iters, hyper, flags);
+    if (rc) return rc;
+    b->in_reader[b->in_cur] = b->fit_seq;       // (this fit's number, given to its arena below)
     if (b->has_masks) {                       // (the arena these masks live in may be overwritten once this fit is done)
         if (!b->ev_masks_used) HIP_TRY(hipEventCreateWithFlags(&b->ev_masks_used, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(b->ev_masks_used, b->stream));
@@ -1159,11 +1221,17 @@ static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t fl
             if (rc) return rc;
         }
         HIP_TRY(hipEventRecord(b->ev_done[k], b->stream));
-        HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_done[k], 0));
         if (!crowded) {
-            rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->copy_stream, nullptr, nullptr);
-            if (rc) return rc;
+            // the rest - wait for this fit, mesh, joints, hand-over, on the second stream - is enqueued at the next entry point
+            // (bf_flush_tail): a bf_batch_stage_inputs that follows puts the next frame's inputs ahead of it
+            b->tail_k = k; b->tail_big = big_fetch;
+            b->copy_pending[k] = true;
+            b->fetched = true;
+            b->steps_done += n_iters;
+            b->have_result = true;
+            return BF_OK;
         }
+        HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_done[k], 0));
         if (big_fetch) {
             HIP_TRY(hipMemcpyAsync(k ? b->h_res_b : b->h_res, k ? b->res_b.p : b->res.p, b->res.n * fb, hipMemcpyDeviceToHost, b->copy_stream));
         } else {
@@ -1269,6 +1337,7 @@ int bf_batch_get_previous(bf_batch *b, float *params, float *vertices, float *jo
         return fail(BF_ERR_INVALID, "bf_batch_get_previous: the previous fit's result is not held in the other arena (both fits need "
                                     "BF_FIT_RESET | BF_FIT_FETCH | BF_FIT_NOTIME on the keypoint-only path)");
     if ((vertices || joints) && !b->arena_has_v[k]) return fail(BF_ERR_INVALID, "bf_batch_get_previous: no mesh was evaluated");
+    { int rt_ = bf_flush_tail(b); if (rt_) return rt_; }
     HIP_TRY(hipEventSynchronize(b->ev_copied[k]));
     const float *h = k ? b->h_res_b : b->h_res;
     if (params) std::memcpy(params, h + b->res_off[0], b->res_cnt[0] * sizeof(float));

@@ -214,6 +214,16 @@ struct bf_batch {
     hipEvent_t ev_in[2] = {nullptr, nullptr};            // the transfer out of staging buffer k has finished
     bool in_pending[2] = {false, false};
     int in_cur = 0;
+    // Staging ASIDE (round 5): the transfer of the next frame's inputs rides on the second stream, AHEAD of the mesh / hand-over tail of
+    // the fit in flight - which is why that tail is enqueued late (`tail_k`: at the next entry point, bf_flush_tail) - so that the batch
+    // stream holds fit kernel after fit kernel with nothing in between.  in_aside[k]: arena k's transfer is on the second stream and
+    // the fit that reads it must see ev_in[k] first; in_reader[k]: sequence number of the last fit that read arena k (-1: none);
+    // tail_seq: the last fit whose tail - it starts by waiting for that fit - is already on the second stream.
+    bool in_aside[2] = {false, false};
+    long long in_reader[2] = {-1, -1};
+    long long tail_seq = -1;
+    int tail_k = -1;                // result arena whose tail is still to be enqueued (-1: none)
+    bool tail_big = false;
     bool in_host = false;           // the views point at the pinned staging buffer itself (BF_STAGE_MODE=zerocopy)
     int stage_mode = 0;             // 0 = copy kernel reading pinned memory, 1 = hipMemcpyAsync, 2 = zero-copy
     bool staged = false;            // inputs were staged since the last fit: the next bf_fit must carry BF_FIT_RESET
@@ -341,6 +351,7 @@ int bf_ensure_dense_buffers(bf_batch *b);
 int bf_masks_finalize(bf_batch *b);      // no-op unless a deferred bf_batch_set_masks is pending
 void bf_masks_commit(bf_batch *b);       // no-op unless bf_batch_stage_masks has staged the next frame's silhouettes
 HyperDev bf_to_dev(const bf_hyper &h);
+int bf_flush_tail(bf_batch *b);          // enqueue the deferred mesh / hand-over tail of the last frame-after-frame fit (api.hip)
 int bf_sync_all(bf_batch *b);            // copy stream, then compute stream
 int bf_guard_arena(bf_batch *b);         // the compute stream waits for a fetch still reading the current arena
 void bf_use_arena(bf_batch *b, int k);
