@@ -2,7 +2,7 @@
 #include "bf_host.h"
 #include <chrono>
 
-extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
+extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t, hipEvent_t);
 extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const float *, const float *, const float *, float *, const float *, const float *, float);
 extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *, const float *, int *, int);
 extern "C" __global__ void bf_mesh_span_kernel(MeshTab, const float *, float *, float *, float *, unsigned long long *);
@@ -1047,7 +1047,7 @@ static int enqueue_plain(bf_batch *b, int n_iters, const HyperDev &hd, const Fra
     const size_t fb = sizeof(float);
     FrameIO io2 = io;
     if (reset) io2.params0 = b->params0.p;      // re-arm inside the fit kernel: no copy / memset commands
-    HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, adam_t0, b->fit_smem, b->stream));
+    HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, adam_t0, b->fit_smem, b->stream, nullptr));
     if (ev) HIP_TRY(hipEventRecord(ev[1], b->stream));
     if (want_v) {
         int rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream,
@@ -1210,7 +1210,10 @@ static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t fl
         bf_use_arena(b, k);
         FrameIO io2 = bf_frame_io(b, false);
         io2.params0 = b->params0.p;                  // re-arm inside the fit kernel
-        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream));
+        static const bool own_signal = [] { const char *e = getenv("BF_FIT_DONE_EVENT"); return !(e && e[0] == '0'); }();
+        const bool crowded_ = b->F >= [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+        const bool signal_here = own_signal && !crowded_;       // (ev_done[k] completes with the fit's own dispatch: no marker packet between this fit and the next)
+        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream, signal_here ? b->ev_done[k] : nullptr));
         // A batch that fills the machine (a frame's workgroup per CU, one workgroup fits per CU): under the NEXT fit the mesh kernels
         // would only get the CUs that fit's workgroups leave as they finish - measured 379 us for a 33 us GEMM at 256 frames.  The mesh
         // then goes on the fit's own stream, ahead of the next fit (0.462 + 0.074 ms instead of 0.601); only the copy stays aside.
@@ -1220,7 +1223,7 @@ static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t fl
             rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
             if (rc) return rc;
         }
-        HIP_TRY(hipEventRecord(b->ev_done[k], b->stream));
+        if (!signal_here) HIP_TRY(hipEventRecord(b->ev_done[k], b->stream));
         if (!crowded) {
             // the rest - wait for this fit, mesh, joints, hand-over, on the second stream - is enqueued at the next entry point
             // (bf_flush_tail): a bf_batch_stage_inputs that follows puts the next frame's inputs ahead of it
@@ -1276,7 +1279,7 @@ static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t fl
         } else {
             // reference-literal schedule: every iteration evaluates the whole mesh (smplify.py:179-190)
             for (int it = 0; it < n_iters; ++it) {
-                HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, b->fit_smem, b->stream));
+                HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, b->fit_smem, b->stream, nullptr));
                 rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
                 if (rc) return rc;
             }
@@ -1310,7 +1313,7 @@ int bf_loss_grad(bf_batch *b, const bf_hyper *hyper, float *terms, float *grads)
     if (rc) return rc;
     FrameIO io = bf_frame_io(b, true);
     if (m->kp_dense) { rc = bf_dense_loss_grad(b, h, hd, io); if (rc) return rc; }
-    else HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, b->fit_smem, b->stream));
+    else HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, b->fit_smem, b->stream, nullptr));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
     if (terms) HIP_TRY(hipMemcpy(terms, b->terms.p, b->terms.n * sizeof(float), hipMemcpyDeviceToHost));
     if (grads) HIP_TRY(hipMemcpy(grads, b->grads.p, b->grads.n * sizeof(float), hipMemcpyDeviceToHost));

@@ -360,5 +360,5 @@ FrameIO bf_frame_io(bf_batch *b, bool want_grads);
 }
 extern "C" void bf_fit_image_segments(int nj, int nb, int npf, int ns, int nl, int np, int seg[6]);
 extern "C" size_t bf_fit_smem_bytes(int nj, int nb, int npf, int ns, int nl, int np, int nviews);
-extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
+extern "C" hipError_t bf_fit_launch(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t, hipEvent_t);
 extern "C" bool bf_fit_is_sized_smpl(const FitTab *);

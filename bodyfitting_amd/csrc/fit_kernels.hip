@@ -33,6 +33,7 @@
 // N_i = D_i GR_i^T + t_i (Gt_i - Gt_parent)^T, dL/dGR_p = (D_p GR_p^T + sum_{i in strict subtree} N_i) GR_p,
 // i.e. two subtree sums instead of one barrier per tree level.  All reductions have a fixed order.
 #include "bf_internal.h"
+#include <hip/hip_ext.h>
 #include "pose_state_body.h"
 #include <type_traits>
 
@@ -1999,20 +2000,22 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 // launches one of two instantiations; `slot`: the per-device cache entry of the dynamic-LDS attribute already set for it
 template <class K>
 static hipError_t fit_launch_one(K kern, size_t *have, const FitTab *T, const FrameIO *io, const HyperDev *hp, int n_iters, int mode,
-                                 const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
+                                 const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream, hipEvent_t done) {
     if (smem > 64 * 1024 && smem > *have) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return e;
         *have = smem;
     }
-    hipLaunchKernelGGL(kern, dim3(io->n_frames), dim3(BF_FIT_THREADS), smem, stream, *T, *io, *hp, n_iters, mode, adam_tab, adam_t0);
+    // (`done`: an event that completes with THIS dispatch - its own completion signal, no marker packet behind it on the queue)
+    if (done) hipExtLaunchKernelGGL(kern, dim3(io->n_frames), dim3(BF_FIT_THREADS), smem, stream, nullptr, done, 0, *T, *io, *hp, n_iters, mode, adam_tab, adam_t0);
+    else hipLaunchKernelGGL(kern, dim3(io->n_frames), dim3(BF_FIT_THREADS), smem, stream, *T, *io, *hp, n_iters, mode, adam_tab, adam_t0);
     return hipGetLastError();
 }
 
 #if BF_FIT_PART == 1
 // the table-driven instances (any model the sized ones do not cover)
 extern "C" hipError_t bf_fit_launch_table(const FitTab *T, const FrameIO *io, const HyperDev *hp, int n_iters, int mode,
-                                          const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
+                                          const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream, hipEvent_t done) {
     // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: the cache of what was set is keyed by device
     static size_t attr[16][2] = {};
     size_t none = 0;
@@ -2020,11 +2023,11 @@ extern "C" hipError_t bf_fit_launch_table(const FitTab *T, const FrameIO *io, co
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
     const bool ext = io->ext != nullptr;
     size_t *have = (dev >= 0 && dev < 16) ? &attr[dev][ext ? 1 : 0] : &none;
-    if (ext) return fit_launch_one(fit_kernel<0, 0, 0, 0, true>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
-    return fit_launch_one(fit_kernel<0, 0, 0, 0, false>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
+    if (ext) return fit_launch_one(fit_kernel<0, 0, 0, 0, true>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream, done);
+    return fit_launch_one(fit_kernel<0, 0, 0, 0, false>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream, done);
 }
 #else
-extern "C" hipError_t bf_fit_launch_table(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t);
+extern "C" hipError_t bf_fit_launch_table(const FitTab *, const FrameIO *, const HyperDev *, int, int, const float *, int, size_t, hipStream_t, hipEvent_t);
 
 // The three contiguous runs of model-constant arrays in the carve, as (first float4, float4 count): Jtrel .. nzj | sel_pd2 .. par |
 // pk .. pb_ (each run may contain a scratch array or two; copying them is cheaper than splitting the run)
@@ -2050,21 +2053,21 @@ extern "C" bool bf_fit_is_sized_smpl(const FitTab *T) {
 
 // Host-side launcher: picks the compile-time-sized instantiation for SMPL, the table-driven one otherwise.
 extern "C" hipError_t bf_fit_launch(const FitTab *T, const FrameIO *io, const HyperDev *hp, int n_iters, int mode,
-                                    const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream) {
+                                    const float *adam_tab, int adam_t0, size_t smem, hipStream_t stream, hipEvent_t done) {
     const bool smpl = bf_fit_is_sized_smpl(T);
     const bool ext = io->ext != nullptr;
     // SMPL-X in the dense schedule (keypoints through bf_kp_loss_kernel: no selector vertices, no loss joints here): sizes fixed
     // at compile time like SMPL's, the phases stay the table-driven ones
     const bool smplx_dense = ext && T->nj == 55 && T->nb == 10 && T->ns == 0 && T->nl == 0;
-    if (!smpl && !smplx_dense) return bf_fit_launch_table(T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
+    if (!smpl && !smplx_dense) return bf_fit_launch_table(T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream, done);
     // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute: the cache of what was set is keyed by device
     static size_t attr[16][3] = {};
     size_t none = 0;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = -1;
     size_t *have = (dev >= 0 && dev < 16) ? &attr[dev][smplx_dense ? 2 : (ext ? 1 : 0)] : &none;
-    if (smplx_dense) return fit_launch_one(fit_kernel<55, 10, 0, 0, true>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
-    if (ext) return fit_launch_one(fit_kernel<24, 10, 11, 25, true>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
-    return fit_launch_one(fit_kernel<24, 10, 11, 25, false>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream);
+    if (smplx_dense) return fit_launch_one(fit_kernel<55, 10, 0, 0, true>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream, done);
+    if (ext) return fit_launch_one(fit_kernel<24, 10, 11, 25, true>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream, done);
+    return fit_launch_one(fit_kernel<24, 10, 11, 25, false>, have, T, io, hp, n_iters, mode, adam_tab, adam_t0, smem, stream, done);
 }
 #endif

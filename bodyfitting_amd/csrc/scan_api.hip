@@ -573,7 +573,7 @@ int bf_ensure_fit_image(bf_batch *b, FrameIO io, const HyperDev &hd) {
     T.lds_image_n4 = (int)(bytes / 16);
     HIP_TRY(m->fit_image.alloc(bytes / sizeof(float)));
     io.ext = nullptr; io.image_out = m->fit_image.p; io.n_frames = 1;      // (the carve, hence the image, is the same for every instance of the model's sizes)
-    HIP_TRY(bf_fit_launch(&T, &io, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->stream));
+    HIP_TRY(bf_fit_launch(&T, &io, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->stream, nullptr));
     HIP_TRY(hipStreamSynchronize(b->stream));
     m->fit.lds_image_n4 = T.lds_image_n4;
     bf_fit_image_segments(m->fit.nj, m->fit.nb, m->fit.npf, m->fit.ns, m->fit.nl, m->fit.np, &m->fit.img_seg[0][0]);
@@ -603,7 +603,7 @@ static int ensure_fit_stream(bf_batch *b, const FrameIO &io, const HyperDev &hd)
     // already waiting for this launch (mode 2 = prologue only)
     FrameIO iow = io;
     iow.ext = b->ext.p; iow.image_out = nullptr; iow.n_frames = 1;
-    HIP_TRY(bf_fit_launch(&m->fit, &iow, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->fit_stream));
+    HIP_TRY(bf_fit_launch(&m->fit, &iow, &hd, 1, 2, b->adam_tab.p, 0, b->fit_smem, b->fit_stream, nullptr));
     HIP_TRY(hipStreamSynchronize(b->fit_stream));
     // ... and checked: do the two streams really run side by side? (bf_door_probe_kernel)
     HIP_TRY(hipStreamSynchronize(b->stream));
@@ -653,7 +653,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     int rc = bf_ensure_dense_buffers(b);
     if (rc) return rc;
     if (n_plain > 0)
-        HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream));
+        HIP_TRY(bf_fit_launch(&m->fit, &io, &hd, n_plain, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream, nullptr));
     if (n_plain < n_iters) { rc = bf_ensure_fit_image(b, io, hd); if (rc) return rc; }
     // The dense iterations with the fit kernel RESIDENT (one launch on a second stream, paced by doorbells, BfDoor) when the
     // forward pass is a kernel that knows how to wait (1..15 frames); BF_DENSE_PERSISTENT=0, or a larger batch, keeps one fit launch
@@ -680,7 +680,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
         HIP_TRY(hipStreamWaitEvent(b->fit_stream, b->ev_door[0], 0));
         FrameIO io2 = io;
         io2.ext = b->ext.p; io2.door = b->door.p; io2.door_resident = b->h_resident;
-        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_dense, 0, b->adam_tab.p, b->steps_done + n_plain, b->fit_smem, b->fit_stream));
+        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_dense, 0, b->adam_tab.p, b->steps_done + n_plain, b->fit_smem, b->fit_stream, nullptr));
         HIP_TRY(hipEventRecord(b->ev_door[1], b->fit_stream));
         for (int it = n_plain; it < n_iters; ++it) {
             if (it == n_plain) {
@@ -713,7 +713,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
         if (rc) return rc;
         FrameIO io2 = io;
         io2.ext = b->ext.p;
-        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, b->fit_smem, b->stream));
+        HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, 1, 0, b->adam_tab.p, b->steps_done + it, b->fit_smem, b->stream, nullptr));
     }
     return BF_OK;
 }
@@ -739,7 +739,7 @@ int bf_dense_loss_grad(bf_batch *b, const bf_hyper &h, const HyperDev &hd, Frame
     rc = dense_pass(b, h, hd, false, 5.0f);
     if (rc) return rc;
     io.ext = b->ext.p;
-    HIP_TRY(bf_fit_launch(&b->m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, b->fit_smem, b->stream));
+    HIP_TRY(bf_fit_launch(&b->m->fit, &io, &hd, 1, 1, b->adam_tab.p, 0, b->fit_smem, b->stream, nullptr));
     return BF_OK;
 }
 
