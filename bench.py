@@ -126,7 +126,7 @@ class FrameFeed:
 def run_steps(job, steps, iters, flags, finish=None, feed=None):
     for _ in range(steps):
         if feed is not None:
-            job.stage_inputs(*feed.next())                   # this step's frames: host -> device, behind the fit in flight
+            job.stage_inputs(*feed.next())                   # this step's frames: host -> device, under the fit in flight
         job.fit(iters, flags=flags | _lib.FIT_RESET)         # re-arm + fit + mesh + joints + fetch, one call (per device)
     if finish is not None:
         return finish()                                      # the job's one collective: gather of the fitted parameters
@@ -582,7 +582,7 @@ def main():
                    "download_bytes_per_step_per_gpu": int(batch_result_bytes(F)),
                    "schedule": "dense (full mesh every iteration)" if a.dense else "sparse (gradient-carrying vertices only) + one final full mesh",
                    "submission": ("one hipGraph launch per step" if graph and not a.dense else
-                                  "host-issued: 4 kernels per step (fit, mesh, joints, publish)" + (", no event records in the timed steps" if no_events else "")),
+                                  "host-issued: fit kernel after fit kernel on the batch stream; the next frame's input transfer, then mesh + joints + result hand-over of the frame before, on the second stream under the fit in flight" + (", no timing records in the timed steps" if no_events else "")),
                    "parallelism": how, "launch_mode": mode, "rccl_ranks": rccl_ranks, "torch_on_measured_path": "torch" in sys.modules},
         "roofline": {
             "bound": "hbm", "kernel": "bf_fit_kernel" if not a.dense else "bf_fit_kernel+bf_mesh_kernel (per iteration)",

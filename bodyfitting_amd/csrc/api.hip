@@ -904,7 +904,8 @@ static void pack_init(const bf_batch *b, const float *init_betas, const float *i
 /* The next frame's keypoints and initial estimate, WITHOUT draining the work in flight (apps/genebody_fitting.py:183-192 hands
  * SMPLify a new frame's detections and HMR estimate every call; loss.py:160 re-uploads the keypoints every iteration).  The
  * inputs are packed into the pinned staging buffer the fit in flight does not use and their transfer into the other device
- * arena is queued on the batch stream, behind that fit; the next bf_fit - which must carry BF_FIT_RESET - reads them. */
+ * arena is queued on the batch stream, behind that fit - or, frame after frame, on the second stream under it (below); the next
+ * bf_fit - which must carry BF_FIT_RESET - reads them. */
 int bf_batch_stage_inputs(bf_batch *b, const float *keypoints, const int32_t *n_use_frames, const float *init_betas, const float *init_pose) {
     if (!b || !keypoints || !init_betas || !init_pose) return fail(BF_ERR_INVALID, "bf_batch_stage_inputs: null argument");
     if (n_use_frames)

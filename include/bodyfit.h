@@ -169,7 +169,9 @@ int bf_batch_set_init(bf_batch *b, const float *init_betas, const float *init_po
  * bf_batch_set_keypoints / bf_batch_set_init) without waiting for the work in flight: the frame loop of
  * apps/genebody_fitting.py:183-192 hands SMPLify.__call__ new detections and a new HMR estimate every frame (and loss.py:160
  * uploads the keypoints again every iteration).  The arrays are copied into pinned staging before the call returns; their
- * transfer into the device arena the running fit does not read is queued on the batch's stream.  The next bf_fit must carry
+ * transfer into the device arena the running fit does not read is queued behind that fit on the batch's stream - or, in the
+ * frame-after-frame loop (fits with BF_FIT_RESET | BF_FIT_FETCH | BF_FIT_NOTIME), on the batch's second stream, where it runs
+ * UNDER the fit in flight (round 5; the fit that reads it waits for it, on the host).  The next bf_fit must carry
  * BF_FIT_RESET (anything else fails with BF_ERR_INVALID).  Cameras, masks and scans are not staged: they stay as set. */
 int bf_batch_stage_inputs(bf_batch *b, const float *keypoints, const int32_t *n_use_frames, const float *init_betas, const float *init_pose);
 /* Re-arm the batch for another fit of the same inputs without touching the host: restores the
