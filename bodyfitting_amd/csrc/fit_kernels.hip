@@ -435,15 +435,21 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
             const float c2 = k[2] * k[2];
             e0.y = k[0]; e0.w = k[1]; e1.y = c2 * kscale * (2.f * s2 * s2); e1.w = c2 * s2;
         }
-        ((float4 *)S.kp)[2 * i] = e0;
-        ((float4 *)S.kp)[2 * i + 1] = e1;
+        // (pair-major inside a round - the 16 view lanes of a pair read CONSECUTIVE records - and the two halves of a record swapped
+        //  for view lanes 4-7 and 12-15: the eight lanes a b128 read serves per cycle then cover all 32 banks.  View-major, all 16
+        //  lanes of a DPP row sat 512 bytes apart, on the same four banks: 22 % of the launch's LDS cycles were bank conflicts, PMC)
+        const int rec = (v >> 4) * (BF_VSUB * 16) + ps * BF_VSUB + (v & 15), sw = (v >> 2) & 1;
+        ((float4 *)S.kp)[2 * rec + sw] = e0;
+        ((float4 *)S.kp)[2 * rec + 1 - sw] = e1;
     }
     BF_KMARK(11, 0);
     // the selector vertex this lane skins in the merged phase (lane / 12-th of the wave's deal; one register kept across the loop -
     // indexing the kernel argument per lane inside the loop would be a global load per iteration)
     const int skin_dealt = MERGE_BD ? T.skin_vert[BF_SKIN_PER_WAVE * (wave & 3) + min(lane / 12, BF_SKIN_PER_WAVE - 1)] : -1;
     // (a slot nobody was dealt reads pair 15's records: zeros - there are at most 15 pairs when a slot is empty)
-    const float4 *kp_lane = (const float4 *)__builtin_assume_aligned(S.kp, 16) + (vsub * 16 + (pdealt >= 0 ? pdealt : 15)) * 2;
+    const int kp_sw = (vsub >> 2) & 1;
+    const float4 *kp_lane = (const float4 *)__builtin_assume_aligned(S.kp, 16) + ((pdealt >= 0 ? pdealt : 15) * BF_VSUB + vsub) * 2 + kp_sw;
+    const int kp_other = 1 - 2 * kp_sw;        // (float4s from a record's first half, as this lane finds it, to its second)
     const int EXT0 = npf, EXT_A = npf, EXT_B = npf + nj * 12, EXT_T = npf + nj * 12 + nb;
     const int EXT_G = npf + nj * 12 + nb + 4;
     const int EXT_K = EXT_G + nj * 3;          // dt, ds of the dense keypoint loss
@@ -834,7 +840,7 @@ fit_kernel(FitTab T, FrameIO io, HyperDev hp, int n_iters, int mode, const float
 #pragma unroll
         for (int r = 0; r < BF_KP_ROUNDS; ++r) {
             const float4 *kq = kp_lane + r * BF_VSUB * 32;
-            one_view(min(vsub + BF_VSUB * r, V - 1), kq[0], kq[1]);
+            one_view(min(vsub + BF_VSUB * r, V - 1), kq[0], kq[kp_other]);
         }
         for (int v = vsub + BF_VSUB * BF_KP_ROUNDS; v < V; v += BF_VSUB) {   // V > 48: stream the rest from global memory
             float4 gxy = {0.f, 0.f, 0.f, 0.f}, kc = {0.f, 0.f, 0.f, 0.f};
