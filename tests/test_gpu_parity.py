@@ -479,6 +479,49 @@ def test_staging_while_a_fit_is_in_flight_never_touches_its_inputs(dev_model, sm
     b.close()
 
 
+def test_staging_aside_in_irregular_call_orders(dev_model, smpl_model):
+    """Round 5: in the frame loop the input transfer rides on the second stream ahead of the deferred mesh / hand-over tail of the fit
+    in flight (api.hip: bf_batch_stage_inputs, bf_flush_tail).  Call orders a frame loop does not produce must give the same bits:
+    two stagings before one fit (the second goes into the arena the fit in flight reads from: it has to be ordered behind that fit),
+    a result read straight after a fit whose tail is still deferred, a plain fit in between, and a batch destroyed with a tail
+    pending."""
+    from bodyfitting_amd import _lib
+    flags = _lib.FIT_RESET | _lib.FIT_FETCH | _lib.FIT_NOTIME
+    sets = [N.pack_problem([S.make_problem(smpl_model, frame=20 * s + 3, n_views=48)]) for s in range(3)]
+    want = []
+    for c2w, K, kp, ndiv, betas, pose in sets:
+        ref = N.FrameBatch(dev_model, 1, 48)
+        ref.set_cameras(sets[0][0], sets[0][1]); ref.set_keypoints(kp, ndiv); ref.set_init(betas, pose)
+        ref.fit(100)
+        want.append((ref.get_params(), ref.get_result()[0]))
+        ref.close()
+    b = N.FrameBatch(dev_model, 1, 48)
+    b.set_cameras(sets[0][0], sets[0][1])
+    stage = lambda s: b.stage_inputs(sets[s][2], sets[s][3], sets[s][4], sets[s][5])
+    stage(0); b.fit(100, flags=flags)
+    stage(1); b.fit(100, flags=flags)                   # (fit of set 1 in flight, its tail deferred)
+    stage(2); stage(0)                                  # the second staging overwrites the arena fit 1 reads from ... behind it
+    b.fit(100, flags=flags)
+    p1 = b.get_previous()                               # fit of set 1
+    assert np.array_equal(p1[0], want[1][0]) and np.array_equal(p1[1], want[1][1])
+    verts = b.get_result()[0]                           # fit of set 0 (staged last), read with its tail still deferred
+    assert np.array_equal(b.get_params(), want[0][0]) and np.array_equal(verts, want[0][1])
+    stage(2); b.fit(100, flags=flags)
+    b.set_keypoints(sets[1][2], sets[1][3]); b.set_init(sets[1][4], sets[1][5])       # synchronous setters drain everything
+    b.fit(100)                                          # a plain fit
+    assert np.array_equal(b.get_params(), want[1][0])
+    stage(2); b.fit(100, flags=flags)
+    stage(0); b.fit(100, flags=flags)
+    p2 = b.get_previous()
+    assert np.array_equal(p2[0], want[2][0]) and np.array_equal(p2[1], want[2][1])
+    b.close()                                           # (a tail pending: nobody reads it)
+    c = N.FrameBatch(dev_model, 1, 48)                  # the device is fine afterwards
+    c.set_cameras(sets[0][0], sets[0][1]); c.set_keypoints(sets[2][2], sets[2][3]); c.set_init(sets[2][4], sets[2][5])
+    c.fit(100)
+    assert np.array_equal(c.get_params(), want[2][0])
+    c.close()
+
+
 def test_smplify_stream_yields_the_frames_of_the_call_path(smpl_model, gmm):
     """SMPLify.stream: the capture's frame loop as a generator (two-deep pipeline) == __call__ frame by frame, bit for bit"""
     from bodyfitting_amd import assets
