@@ -77,6 +77,25 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
     for (int i = tid; i < Q.n_selector; i += 512) s_sel[i] = Q.selector_ids[i];
     if (p_lds)
         for (int i = tid; i < V * 12; i += 512) s_P[i] = proj_all[(size_t)f * V * 12 + i];
+    // The routing stage far below needs, per (loss joint, corner) item, the vertex a barycentric landmark's corner sits on and its weight
+    // (per frame: the contour landmarks move with the neck).  They depend on nothing this workgroup computes, so they are requested
+    // NOW - joint map entry, then the pair - and wait in registers: down there the pair was a global round trip (~1.5 us with the
+    // caches as cold as a kernel start leaves them) in the middle of the chain.
+    const int n_ori = Q.nj + Q.n_selector;
+    int pre_vid[2] = {-1, -1};
+    float pre_w[2] = {1.f, 1.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = tid + h * 512;
+        if (i < nl * 3) {
+            const int q = i / 3, c = i - q * 3, src = Q.joint_map[q];
+            if (src >= n_ori + Q.n_extra) {
+                const size_t l = ((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c;
+                pre_vid[h] = lmk_vid[l];
+                pre_w[h] = lmk_w[l];
+            }
+        }
+    }
     __syncthreads();
     if (vs < slots && j < nl) {
         const float *x = jraw + ((size_t)f * Q.n_all + s_jm[j]) * 3;
@@ -173,7 +192,6 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
     //  was measured in round 3: no barriers, but some lane of a wave matches in nearly every step, so every step pays the
     //  accumulate body: config 3 went from 0.081 to 0.091 ms per iteration.  The sort's 45 short barrier stages are cheaper.)
     float *dv = dvout + (size_t)f * Q.nv * 3;
-    const int n_ori = Q.nj + Q.n_selector;
     int *s_key = (int *)(s_x + nl * 3 + 8);               // [N] (vertex << 10 | item), 0x7fffffff = no vertex
     float *s_w = (float *)(s_key + 1024);                 // [n_items] weight of the item
     const int n_items = nl * 3, N = n_items <= 512 ? 512 : 1024;
@@ -187,11 +205,7 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
             if (src >= Q.nj) {
                 if (src < n_ori) { if (c == 0) vid = s_sel[src - Q.nj]; }
                 else if (src < n_ori + Q.n_extra) { }                  // a regressed joint: every vertex of its row, below
-                else {
-                    const size_t l = ((size_t)f * Q.n_lmk + (src - n_ori - Q.n_extra)) * 3 + c;
-                    vid = lmk_vid[l];
-                    w = lmk_w[l];
-                }
+                else { vid = pre_vid[i >= 512 ? 1 : 0]; w = pre_w[i >= 512 ? 1 : 0]; }       // (requested at the top of the kernel)
             }
             s_w[i] = w;
             if (vid >= 0) key = (vid << 10) | i;
@@ -242,8 +256,11 @@ __device__ __forceinline__ void bf_kp_loss_body(int f, float *sm, KpIO Q, const 
             const float w = s_w[item];
             a0 += w * s_g[q * 4]; a1 += w * s_g[q * 4 + 1]; a2 += w * s_g[q * 4 + 2];
         }
+        // (dL/dvertices is zero when this workgroup starts - the forward mesh pass or a memset left it so, and nothing else writes it
+        //  before the keypoint loss - and a vertex's run has exactly one owner: a plain store, not a load + add + store whose load
+        //  was the last global round trip of the chain)
         float *o = dv + (size_t)vid * 3;
-        o[0] += a0; o[1] += a1; o[2] += a2;
+        o[0] = a0; o[1] = a1; o[2] = a2;
     }
     // loss joints that come from J_regressor_extra (models/smpl.py:72: joint = row . vertices): every vertex of the row gets its
     // weight times the joint's gradient.  Joint after joint in loss-joint order, a vertex always by the same thread, after the
