@@ -92,6 +92,8 @@ SIGNATURES = {
     "bf_batch_mesh_span": (C.c_int, [_VP, C.c_int, _FP]),
     "bf_nearest_rule_set": (C.c_int, [C.c_int]),
     "bf_nearest_rule_get": (C.c_int, []),
+    "bf_mask_fold_set": (C.c_int, [C.c_int]),
+    "bf_mask_fold_get": (C.c_int, []),
     "bf_nearest_selftest_quot": (C.c_int, [C.c_int, C.c_int, _FP, _FP, _FP]),
     "bf_nearest_selftest_rule": (C.c_int, [C.c_int, C.c_int, _FP, C.c_int, _FP, _FP]),
     "bf_batch_set_scans": (C.c_int, [_VP, C.POINTER(_VP)]),

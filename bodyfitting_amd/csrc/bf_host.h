@@ -313,6 +313,7 @@ struct bf_batch {
     DevBuf<int> mk_view, mk_cstart, mk_ccount, mk_choice;
     DevBuf<unsigned char> mk_masks;
     DevBuf<float> mk_cxy, mk_uvi, mk_duvb, mk_cgrad, mk_part, mk_loss, mk_gpart;
+    DevBuf<unsigned long long> mk_acc;       // [F][M][ns][2] fixed-point contour-gradient sums (MaskIO::acc)
     // SMPL+D stage (smplify.py:228-247)
     DevBuf<float> disp, disp_m, disp_v, disp_base, disp_P, disp_fn, disp_vn, disp_dv, disp_dPf;
     DevBuf<const float *> scan_fn;

@@ -192,6 +192,22 @@ struct MaskIO {
     const int *contour_start;             // [F*M] offsets into contour_xy
     const int *contour_count;             // [F*M]
     const float *contour_xy;              // [sum][2] (x, y) contour points (loss.py:73-83)
+    // Round 5: the contour term's gradient per (view, sampled vertex) summed as 64-bit FIXED-POINT numbers by atomic adds of the contour
+    // scan itself (exact sums: the order of the additions does not matter, so the result is reproducible without the ordered walk of
+    // bf_mask_gather_kernel - a 13 us launch of the dense iteration).  [F][M][ns][2] (du, dv) scaled by 2^BF_ACC_SHIFT; zeroed by the
+    // projection of the same iteration; null = off (the contour scan then only writes choice / cgrad for the gather kernel).
+    unsigned long long *acc;
+};
+#define BF_ACC_SHIFT 40       // |du|, |dv| <= weight x eps x contour points < 2^18: 2^58 at most, steps of 2^-40
+__device__ __forceinline__ unsigned long long bf_acc_fixed(float x) { return (unsigned long long)__double2ll_rn((double)x * (double)(1ull << BF_ACC_SHIFT)); }
+__device__ __forceinline__ float bf_acc_float(unsigned long long a) { return (float)((double)(long long)a * (1.0 / (double)(1ull << BF_ACC_SHIFT))); }
+
+// What the reverse mesh pass needs to turn those sums into dL/dvertex itself (bf_mask_gather_kernel's closing step, per view, views in order)
+struct MaskFold {
+    const unsigned long long *acc;        // null = off
+    const float *uvi, *duvb, *proj;       // bf_mask_project_one's records; [F][V][12]
+    const int *view_index;                // [M]
+    int n_views;                          // V
 };
 
 // What the forward mesh pass needs to project its sampled vertices into the mask views (on = 0: nothing to do).

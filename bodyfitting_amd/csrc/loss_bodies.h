@@ -41,6 +41,7 @@ __device__ __forceinline__ float bf_mask_project_one(const MaskIO &K, float X0, 
     ((float4 *)uvi)[o] = rec;
     duvb[o * 2] = K.weight * K.eps * gx;
     duvb[o * 2 + 1] = K.weight * K.eps * gy;
+    if (K.acc) { K.acc[o * 2] = 0ull; K.acc[o * 2 + 1] = 0ull; }      // (this iteration's contour sums start here)
     return lval;
 }
 
@@ -366,9 +367,13 @@ __device__ __forceinline__ void bf_mask_contour_body(int bx, int m, int f, float
             float coeff = mval < 0.1f ? K.eps : 1.f;                            // (eps - 1) * outside + 1
             lval = coeff * d;
             if (d > 0.f) { gx = K.weight * coeff * (bu - cx) / d; gy = K.weight * coeff * (bv - cy) / d; }
+            if (K.acc && d > 0.f) {
+                unsigned long long *a = K.acc + ((size_t)vm * K.ns + bidx) * 2;
+                (void)__hip_atomic_fetch_add(a, bf_acc_fixed(gx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                (void)__hip_atomic_fetch_add(a + 1, bf_acc_fixed(gy), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        choice[o] = bidx;
-        cgrad[o * 2] = gx; cgrad[o * 2 + 1] = gy;
+        if (!K.acc) { choice[o] = bidx; cgrad[o * 2] = gx; cgrad[o * 2 + 1] = gy; }      // (the gather kernel's inputs: not in sums mode)
     }
     lval = lb_wave_sum(lval);
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = lval;

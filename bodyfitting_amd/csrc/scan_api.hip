@@ -11,7 +11,7 @@ extern "C" void bf_nearest_launch(dim3 grid, hipStream_t stream, const ScanDev *
 extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
 extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const float *, int, const float *, const float *, const float *, float *, hipStream_t,
-                                        const float *, int, int, int, int, int *);
+                                        const float *, int, int, int, int, int *, const MaskFold *);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int, int *, int);
 extern "C" int bf_mesh_use_multi(int npf, int n);
 extern "C" __global__ void bf_door_probe_kernel(int *);
@@ -427,9 +427,12 @@ static int launch_kp(bf_batch *b, const bf_hyper &h, const bf_model::Sub *sub = 
 
 // `with_kp`: the dense keypoint loss rides in the contour launch (bf_kp_contour_kernel) instead of a launch of its own
 static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss, bool sum_views = true, const bf_hyper *with_kp = nullptr,
-                               bool projected = false, const bf_model::Sub *sub = nullptr) {
+                               bool projected = false, const bf_model::Sub *sub = nullptr, bool fold_acc = false) {
+    // fold_acc: the contour scan adds its gradients into the fixed-point sums (MaskIO::acc) and the reverse mesh pass takes them from
+    // there (MaskFold): no gather launch
     MaskIO K = b->mask;
     K.weight = weight;
+    K.acc = fold_acc ? b->mk_acc.p : nullptr;
     if (sub) { K.nv = sub->mesh.nv; K.sstride = 1; }
     const int F = b->F;
     // (projected: the forward mesh pass already wrote uvi / duvb for its sampled vertices)
@@ -445,6 +448,7 @@ static int launch_mask_kernels(bf_batch *b, float weight, bool want_loss, bool s
     } else
     hipLaunchKernelGGL(bf_mask_contour_kernel, dim3((K.cmax * 16 + 255) / 256, K.n_masks, F), dim3(256), 0, b->stream, K,
                        (const float *)b->mk_uvi.p, b->mk_choice.p, b->mk_cgrad.p, b->mk_part.p);
+    if (!fold_acc)
     hipLaunchKernelGGL(bf_mask_gather_kernel, dim3((K.ns + 63) / 64, K.n_masks, F), dim3(256), 0, b->stream, K, (const float *)b->proj.p,
                        (const float *)b->mk_uvi.p, (const float *)b->mk_duvb.p, (const int *)b->mk_choice.p,
                        (const float *)b->mk_cgrad.p, b->mk_gpart.p);
@@ -470,6 +474,19 @@ static int launch_state_and_mesh(bf_batch *b, const HyperDev &hd) {
 // sub: run the mesh passes on a sub-model (bf_model::Sub): the sampled-first one for fit loops without scans, the keypoint-only one for
 // the iterations before the dense losses switch on; null = the full model
 // BF_DOOR_COHERENT=0: the kernels that wait for the resident fit launch read its pose states with plain loads (see bf_ld_state)
+// bf_mask_fold_set / BF_MASK_FOLD=gather: the silhouette's contour gradients through bf_mask_gather_kernel's ordered walk (rounds 2-4)
+// instead of the contour scan's fixed-point atomic sums (MaskIO::acc)
+static std::atomic<int> &mask_fold_cell() {
+    static std::atomic<int> cell([] { const char *e = std::getenv("BF_MASK_FOLD"); return (e && e[0] == 'g') ? BF_MASK_FOLD_GATHER : BF_MASK_FOLD_SUMS; }());
+    return cell;
+}
+extern "C" int bf_mask_fold_get(void) { return mask_fold_cell().load(std::memory_order_relaxed); }
+extern "C" int bf_mask_fold_set(int mode) {
+    if (mode != BF_MASK_FOLD_SUMS && mode != BF_MASK_FOLD_GATHER) return -1;
+    mask_fold_cell().store(mode, std::memory_order_relaxed);
+    return 0;
+}
+static bool fold_acc_on() { return bf_mask_fold_get() == BF_MASK_FOLD_SUMS; }
 static bool door_coherent() { const char *e = std::getenv("BF_DOOR_COHERENT"); return !(e && e[0] == '0'); }
 
 static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool late, float mask_weight, int *door = nullptr, int door_k = 0,
@@ -485,6 +502,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     const MeshTab &Q = sub ? sub->mesh : m->mesh;
     const int F = b->F, nv = Q.nv, nblk = (nv + 255) / 256;
     const bool scans = late && !b->scans.empty(), masks = late && b->has_masks, kp = m->kp_dense;
+    const bool acc_mode = fold_acc_on();          // (read once per pass)
     if (masks) { int rf = bf_masks_finalize(b); if (rf) return rf; }
     if (!door) {                     // (with the resident fit launch every state comes from it)
         hipLaunchKernelGGL(bf_pose_state_kernel, dim3(F), dim3(128), 0, b->stream, m->fit, (const float *)nullptr,
@@ -498,6 +516,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     bool projected = false;
     if (masks) {
         mp.on = 1; mp.K = b->mask; mp.K.weight = mask_weight; mp.proj = b->proj.p; mp.uvi = b->mk_uvi.p; mp.duvb = b->mk_duvb.p;
+        mp.K.acc = (acc_mode && !scans) ? b->mk_acc.p : nullptr;      // (zeroed by the projection that precedes the contour scan)
         if (sub) { mp.K.nv = nv; mp.K.sstride = 1; }
     }
     int rc = bf_launch_mesh(m, &b->scratch, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
@@ -526,7 +545,8 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     } else if (kp && !masks) { rc = launch_kp(b, h, sub); if (rc) return rc; }
     // with a scan as well, bf_pc_grad_kernel adds onto (keypoints + silhouette): keep that order of additions
     const bool fold_views = masks && !scans;
-    if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr, projected, sub); if (rc) return rc; }
+    const bool fold_acc = fold_views && acc_mode;
+    if (masks) { rc = launch_mask_kernels(b, mask_weight, false, !fold_views, kp ? &h : nullptr, projected, sub, fold_acc); if (rc) return rc; }
     HIP_TRY(mark(2));                         // [1,2] keypoint loss (on this stream) and / or the silhouette kernels
     if (scans) {
         bf_nearest_launch(dim3((nv + 3) / 4, F), b->stream, (const ScanDev *)b->scan_dev.p,
@@ -545,9 +565,11 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     const int EXT = m->npf + m->nj * 12 + m->nb + 4;
     int part_rows = Q.n_tiles;             // (two per tile when the reverse pass splits its tiles: one frame, a small grid)
     {
+        MaskFold fold = {};
+        if (fold_acc) { fold.acc = b->mk_acc.p; fold.uvi = b->mk_uvi.p; fold.duvb = b->mk_duvb.p; fold.proj = b->proj.p; fold.view_index = b->mask.view_index; fold.n_views = b->V; }
         const int e = bf_mesh_bwd_multi_launch(&Q, sub ? sub->posedirsT.p : m->posedirsT.p, b->state.p, F, b->dvout.p, b->vposed.p, b->vraw.p, b->ext_part.p,
-                                               b->stream, fold_views ? (const float *)b->mk_gpart.p : nullptr, b->mask.n_masks, b->mask.ns, sub ? 1 : 4,
-                                               (sub && sub == &m->sub_kp) ? Q.n_tiles : m->mesh.n_tiles, &part_rows);      // (keypoint-only sub-model: no tile split - a batch of 8 and its single frames keep the same partial sums)
+                                               b->stream, (fold_views && !fold_acc) ? (const float *)b->mk_gpart.p : nullptr, b->mask.n_masks, b->mask.ns, sub ? 1 : 4,
+                                               (sub && sub == &m->sub_kp) ? Q.n_tiles : m->mesh.n_tiles, &part_rows, fold_acc ? &fold : nullptr);      // (keypoint-only sub-model: no tile split - a batch of 8 and its single frames keep the same partial sums)
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_bwd_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     }
     HIP_TRY(mark(5));                         // [4,5] reverse mesh pass
@@ -870,7 +892,7 @@ int bf_batch_set_masks(bf_batch *b, int n_masks, const int32_t *view_index, int 
     HIP_TRY(hipMemcpy(b->mk_view.p, view_index, (size_t)n_masks * sizeof(int), hipMemcpyHostToDevice));
     b->mk_view_host.assign(view_index, view_index + n_masks);
     b->mk_stage.staged = false;                              // (masks set synchronously supersede staged ones)
-    HIP_TRY(ensure(b->mk_uvi, fm * ns * 4)); HIP_TRY(ensure(b->mk_duvb, fm * ns * 2)); HIP_TRY(ensure(b->mk_gpart, fm * ns * 3));
+    HIP_TRY(ensure(b->mk_uvi, fm * ns * 4)); HIP_TRY(ensure(b->mk_duvb, fm * ns * 2)); HIP_TRY(ensure(b->mk_gpart, fm * ns * 3)); HIP_TRY(ensure(b->mk_acc, fm * ns * 2));
     HIP_TRY(ensure(b->mk_loss, F));
     MaskIO &K0 = b->mask;
     K0.nv = nv; K0.ns = ns; K0.n_views = b->V; K0.n_masks = n_masks; K0.H = H; K0.W = W; K0.proj_blocks = pblocks;

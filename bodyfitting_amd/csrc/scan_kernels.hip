@@ -518,7 +518,7 @@ template <int FPW>
 __global__ void __launch_bounds__(512)
 bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const float *__restrict__ state, int n_frames,
                          const float *__restrict__ dvout, const float *__restrict__ vposed, const float *__restrict__ vraw,
-                         float *__restrict__ part, const float *__restrict__ gpart, int n_masks, int n_sampled, int samp_stride, int split) {
+                         float *__restrict__ part, const float *__restrict__ gpart, int n_masks, int n_sampled, int samp_stride, int split, MaskFold G) {
     // split = 2 (one frame per workgroup, the grid smaller than half the machine): TWO workgroups per tile, each streaming half of the
     // tile's posedirsT columns in (a) - that stream is a chain of dependent batches at ~1.3 us each (a kernel starts with cold caches),
     // and more loads in flight per CU made it slower, more CUs do not.  Each half leaves a partial row of its own (the reduction adds the
@@ -571,6 +571,21 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
             const int sidx = samp_stride == 4 ? (v0 + c / 3) >> 2 : v0 + c / 3;
             float gs = 0.f;
             for (int m = 0; m < n_masks; ++m) gs += gpart[(((size_t)(fbase + f) * n_masks + m) * n_sampled + sidx) * 3 + c % 3];
+            g += gs;
+        } else if (G.acc && ok && (samp_stride == 4 ? ((v0 + c / 3) & 3) == 0 : v0 + c / 3 < n_sampled)) {
+            // the same sum from the contour scan's fixed-point sums: bf_mask_gather_kernel's closing step per view (binary term + contour
+            // term back through the projection), the views added in view order
+            const int sidx = samp_stride == 4 ? (v0 + c / 3) >> 2 : v0 + c / 3, k = c % 3;
+            float gs = 0.f;
+            for (int m = 0; m < n_masks; ++m) {
+                const size_t o = ((size_t)(fbase + f) * n_masks + m) * n_sampled + sidx;
+                float tu = G.duvb[o * 2], tv = G.duvb[o * 2 + 1];
+                tu += bf_acc_float(G.acc[o * 2]); tv += bf_acc_float(G.acc[o * 2 + 1]);
+                const float4 r = ((const float4 *)G.uvi)[o];
+                const float *P = G.proj + ((size_t)(fbase + f) * G.n_views + G.view_index[m]) * 12;
+                const float q0 = tu * r.w, q1 = tv * r.w, q2 = -(tu * r.x + tv * r.y) * r.w;
+                gs += P[k] * q0 + P[4 + k] * q1 + P[8 + k] * q2;
+            }
             g += gs;
         }
         s_dv[i] = g * sc;
@@ -683,7 +698,10 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
 
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT, const float *state, int n, const float *dvout,
                                         const float *vposed, const float *vraw, float *part, hipStream_t stream,
-                                        const float *gpart, int n_masks, int n_sampled, int samp_stride, int part_rows, int *rows_out) {
+                                        const float *gpart, int n_masks, int n_sampled, int samp_stride, int part_rows, int *rows_out,
+                                        const MaskFold *fold) {
+    MaskFold G = {};
+    if (fold) G = *fold;
     // part_rows: rows per frame the partial buffer holds; *rows_out: rows per frame this launch wrote (n_tiles, or 2 n_tiles when split)
     constexpr int COLS = BF_MESH_TILE * 3;
     const int fpw = n <= 1 ? 1 : (n <= 2 ? 2 : (n <= 4 ? 4 : 8));
@@ -694,10 +712,10 @@ extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT
     const dim3 grid(M->n_tiles * split, (n + fpw - 1) / fpw), block(512);
     if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
     switch (fpw) {
-    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split); break;
-    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split); break;
-    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split); break;
-    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split); break;
+    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G); break;
+    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G); break;
+    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G); break;
+    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G); break;
     }
     return (int)hipGetLastError();
 }

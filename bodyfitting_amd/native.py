@@ -232,6 +232,17 @@ def set_nearest_rule(rule):
     return "fast" if before == _lib.NEAREST_FAST else "reference"
 
 
+def set_mask_fold(mode):
+    """How the silhouette loss's contour gradients reach dL/dvertices inside a fit: "sums" (default: fixed-point atomic sums by the
+    contour scan, bodyfit.h BF_MASK_FOLD_SUMS) or "gather" (the ordered float32 walk of rounds 2-4).  -> the mode that was active."""
+    names = {"sums": 0, "gather": 1}
+    lib = _lib.load()
+    before = lib.bf_mask_fold_get()
+    if lib.bf_mask_fold_set(names[mode] if isinstance(mode, str) else int(mode)) != 0:
+        raise ValueError("unknown mask fold mode %r" % (mode,))
+    return "gather" if before == 1 else "sums"
+
+
 def make_hyper(**kw):
     h = _lib.Hyper()
     _lib.load().bf_hyper_default(C.byref(h))

@@ -246,6 +246,17 @@ int bf_scan_nearest_hinted(bf_scan *s, int n, const float *points, const float *
 #define BF_NEAREST_FAST      1
 int bf_nearest_rule_set(int rule);                     /* 0 on success, -1 for an unknown rule */
 int bf_nearest_rule_get(void);
+/* How the silhouette loss's contour gradients (loss.py:110-119: every contour point pulls its nearest projected vertex) reach
+ * dL/dvertices inside bf_fit.  BF_MASK_FOLD_SUMS (default, round 5): the contour scan adds each point's pull onto its vertex as a
+ * 64-bit fixed-point number (steps of 2^-40, exact sums: the order of the atomic additions does not matter, so a fit is reproducible
+ * bit for bit) and the reverse mesh pass maps the sums back through the projection.  BF_MASK_FOLD_GATHER: the ordered walk of
+ * rounds 2-4 (bf_mask_gather_kernel: a vertex adds its contour points up in contour order, in float32) - one more launch per
+ * iteration, last bits of the sum differ.  bf_batch_mask_loss always takes the ordered walk.
+ * Also read once from the environment: BF_MASK_FOLD=sums|gather. */
+#define BF_MASK_FOLD_SUMS   0
+#define BF_MASK_FOLD_GATHER 1
+int bf_mask_fold_set(int mode);                        /* 0 on success, -1 for an unknown mode */
+int bf_mask_fold_get(void);
 /* Self-tests of the reference-arithmetic rule: out[i] = num[i] / den[i] through the kernel's division helper (exact IEEE division
  * for 1e-8 < |den| < 4, |num / den| < 2^90); the per-triangle rule itself on patches[n][9] = the corners relative to the query
  * (mesh_grid_kernel.cu:305-311) -> dist[n], coeff[n][3]; general = 0 evaluates the straight-line paths alone and returns -1 where

@@ -354,6 +354,47 @@ def test_staged_masks_equal_masks_set_between_the_fits(dev_model, smpl_model):
     assert not np.array_equal(plain[0], plain[1])
 
 
+def test_contour_gradient_sums_equal_the_ordered_walk(dev_model, smpl_model):
+    """Round 5: inside a fit the contour scan adds every contour point's pull onto its nearest vertex as a 64-bit fixed-point number
+    (atomic adds, exact sums) and the reverse mesh pass maps the sums back through the projection - no gather launch
+    (bodyfit.h: bf_mask_fold_set).  The sums are exact, the ordered float32 walk of rounds 2-4 rounds after every addition: after a
+    few iterations with the silhouette loss on the two paths agree to float32 round-off, the fixed-point path is reproducible bit for
+    bit (an atomic's arrival order must not show), whatever else is in the batch."""
+    from bodyfitting_amd import _lib
+    probs = [S.make_problem(smpl_model, frame=f, n_views=8, mask_frames=MASK_FRAMES) for f in (0, 1, 2)]
+    view_index = [probs[0]["use_frames"].index(f) for f in MASK_FRAMES]
+    hyper = N.make_hyper(dense_after=2)
+
+    def run(which, mode, iters=8, masks=True):
+        before = N.set_mask_fold(mode)
+        try:
+            c2w, K, kp, ndiv, betas, pose = N.pack_problem([probs[i] for i in which])
+            b = N.FrameBatch(dev_model, len(which), 8)
+            b.set_cameras(c2w, K); b.set_keypoints(kp, ndiv); b.set_init(betas, pose)
+            if masks:
+                b.set_masks(np.array([probs[i]["masks"] for i in which]), view_index, None)
+            b.fit(iters, hyper)
+            out = b.get_params().copy()
+            b.close()
+            return out
+        finally:
+            N.set_mask_fold(before)
+    assert N.set_mask_fold("sums") in ("sums", "gather")
+    # the first step that sees the silhouette gradient (Adam then turns round-off on a near-zero gradient into +-lr steps: later
+    # iterations of the two paths drift apart the way the reference drifts from itself, tests/ref_drift.py)
+    first = hyper.dense_after + 2 if hasattr(hyper, "dense_after") else 4
+    a, w, none = run([0, 1, 2], "sums", first), run([0, 1, 2], "gather", first), run([0, 1, 2], "sums", first, masks=False)
+    assert np.abs(a - none).max() > 1e-3                    # the silhouette term moves the step ...
+    np.testing.assert_allclose(a, w, rtol=0, atol=2e-6)     # ... and both paths make the same one
+    sums, again = run([0, 1, 2], "sums"), run([0, 1, 2], "sums")
+    np.testing.assert_array_equal(sums, again)
+    twice = run([0, 1, 0], "sums")
+    np.testing.assert_array_equal(twice[0], twice[2])      # the same frame twice in a batch: the same bits
+    np.testing.assert_array_equal(twice[:2], sums[:2])     # ... and a frame's bits do not depend on its neighbours
+    with pytest.raises(ValueError):
+        N.set_mask_fold(7)
+
+
 def test_stage_masks_refuses_what_it_cannot_take(dev_model, smpl_model):
     from bodyfitting_amd._lib import BodyfitError
     prob = S.make_problem(smpl_model, frame=0, n_views=8, mask_frames=MASK_FRAMES)
