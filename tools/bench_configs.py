@@ -64,7 +64,7 @@ def cfg3(reps, n_views=48, iters=200, mask_views=8):
                      "(%d mask views), %d iterations" % (n_views, len(mask_frames), iters),
            "frames_per_s": 1.0 / dt, "ms_per_fit": dt * 1e3, "ms_per_iteration": dt * 1e3 / iters,
            "ms_mask_upload_and_contours": t_masks * 1e3,
-           "roofline": nominal_roofline(BYTES_SMPLX_FWD * iters + BYTES_CFG3_MASK * (iters - iters // 3 - 1), dt, "config 3's dense iteration (forward mesh, keypoints + contours, gather, reverse mesh, reduce)"),
+           "roofline": nominal_roofline(BYTES_SMPLX_FWD * iters + BYTES_CFG3_MASK * (iters - iters // 3 - 1), dt, "config 3's dense iteration (forward mesh, keypoints + contours with fixed-point gradient sums, reverse mesh, reduce)"),
            "device_ms_last_iteration": per_class, "resident_fit_launch": b.dense_resident()}
     b.close(); dev.close()
     return out
