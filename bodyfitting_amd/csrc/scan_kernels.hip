@@ -514,7 +514,7 @@ bf_pc_grad_kernel(const float *__restrict__ P, const float *__restrict__ C, int 
 // feeds one fma per frame; the per-frame vectors it is dotted with sit frame-minor in LDS (one b128 read for four
 // frames).  shapedirs of the tile are staged in LDS, so the beta sums do not chase 96 dependent loads.  Every sum has a
 // fixed order that does not depend on FPW or on the frame's position in the batch.
-template <int FPW>
+template <int FPW, bool FOLD>
 __global__ void __launch_bounds__(512)
 bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const float *__restrict__ state, int n_frames,
                          const float *__restrict__ dvout, const float *__restrict__ vposed, const float *__restrict__ vraw,
@@ -572,7 +572,7 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
             float gs = 0.f;
             for (int m = 0; m < n_masks; ++m) gs += gpart[(((size_t)(fbase + f) * n_masks + m) * n_sampled + sidx) * 3 + c % 3];
             g += gs;
-        } else if (G.acc && ok && (samp_stride == 4 ? ((v0 + c / 3) & 3) == 0 : v0 + c / 3 < n_sampled)) {
+        } else if (FOLD && G.acc && ok && (samp_stride == 4 ? ((v0 + c / 3) & 3) == 0 : v0 + c / 3 < n_sampled)) {      // (FOLD: an instance of its own - with this path compiled into it the eight-frame instance of config 5 went from 27 to 35 us)
             // the same sum from the contour scan's fixed-point sums: bf_mask_gather_kernel's closing step per view (binary term + contour
             // term back through the projection), the views added in view order
             const int sidx = samp_stride == 4 ? (v0 + c / 3) >> 2 : v0 + c / 3, k = c % 3;
@@ -712,10 +712,18 @@ extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *M, const float *posedirsT
     const dim3 grid(M->n_tiles * split, (n + fpw - 1) / fpw), block(512);
     if (smem > 64 * 1024) return (int)hipErrorInvalidValue;
     switch (fpw) {
-    case 1: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<1>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G); break;
-    case 2: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<2>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G); break;
-    case 4: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<4>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G); break;
-    default: hipLaunchKernelGGL(bf_mesh_bwd_multi_kernel<8>, grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G); break;
+    case 1: if (G.acc) hipLaunchKernelGGL((bf_mesh_bwd_multi_kernel<1, true>), grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G);
+             else hipLaunchKernelGGL((bf_mesh_bwd_multi_kernel<1, false>), grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G);
+             break;
+    case 2: if (G.acc) hipLaunchKernelGGL((bf_mesh_bwd_multi_kernel<2, true>), grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G);
+             else hipLaunchKernelGGL((bf_mesh_bwd_multi_kernel<2, false>), grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G);
+             break;
+    case 4: if (G.acc) hipLaunchKernelGGL((bf_mesh_bwd_multi_kernel<4, true>), grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G);
+             else hipLaunchKernelGGL((bf_mesh_bwd_multi_kernel<4, false>), grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G);
+             break;
+    default: if (G.acc) hipLaunchKernelGGL((bf_mesh_bwd_multi_kernel<8, true>), grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G);
+             else hipLaunchKernelGGL((bf_mesh_bwd_multi_kernel<8, false>), grid, block, smem, stream, *M, posedirsT, state, n, dvout, vposed, vraw, part, gpart, n_masks, n_sampled, samp_stride, split, G);
+             break;
     }
     return (int)hipGetLastError();
 }
