@@ -747,6 +747,9 @@ extern "C" __global__ void bf_door_ring_kernel(int *door) {
 
 // A chunk lane adds its contiguous run of tiles in tile order (loads issued eight at a time: a plain serial loop costs
 // one memory latency per tile), then the eight chunk sums are added in chunk order: a fixed order, run to run.
+#ifndef BF_RED_UNROLL
+#define BF_RED_UNROLL 24
+#endif
 extern "C" __global__ void __launch_bounds__(256)
 bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float *__restrict__ ext, int ext_stride, int *door, int door_k) {
     __shared__ float s_c[8][32];
@@ -756,6 +759,13 @@ bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float
     if (i < EXT) {
         const float *p = part + (size_t)f * n_tiles * EXT + i;
         int t = t0;
+        for (; t + BF_RED_UNROLL <= t1; t += BF_RED_UNROLL) {          // (loads in flight per thread; the additions stay in row order)
+            float v[BF_RED_UNROLL];
+#pragma unroll
+            for (int q = 0; q < BF_RED_UNROLL; ++q) v[q] = p[(size_t)(t + q) * EXT];
+#pragma unroll
+            for (int q = 0; q < BF_RED_UNROLL; ++q) acc += v[q];
+        }
         for (; t + 8 <= t1; t += 8) {
             float v[8];
 #pragma unroll
