@@ -577,14 +577,32 @@ bf_mesh_bwd_multi_kernel(MeshTab M, const float *__restrict__ posedirsT, const f
             // term back through the projection), the views added in view order
             const int sidx = samp_stride == 4 ? (v0 + c / 3) >> 2 : v0 + c / 3, k = c % 3;
             float gs = 0.f;
-            for (int m = 0; m < n_masks; ++m) {
-                const size_t o = ((size_t)(fbase + f) * n_masks + m) * n_sampled + sidx;
-                float tu = G.duvb[o * 2], tv = G.duvb[o * 2 + 1];
-                tu += bf_acc_float(G.acc[o * 2]); tv += bf_acc_float(G.acc[o * 2 + 1]);
-                const float4 r = ((const float4 *)G.uvi)[o];
-                const float *P = G.proj + ((size_t)(fbase + f) * G.n_views + G.view_index[m]) * 12;
-                const float q0 = tu * r.w, q1 = tv * r.w, q2 = -(tu * r.x + tv * r.y) * r.w;
-                gs += P[k] * q0 + P[4 + k] * q1 + P[8 + k] * q2;
+            // (eight views at a time: every view's loads are requested before the first is used - a rolled loop paid one memory round trip
+            //  per view, ~3 us of this launch; the views are still added in view order)
+            constexpr int MB = 8;
+            for (int m0 = 0; m0 < n_masks; m0 += MB) {
+                unsigned long long au[MB], av[MB];
+                float bu[MB], bv[MB], pk[MB][3];
+                float4 rr[MB];
+#pragma unroll
+                for (int e = 0; e < MB; ++e) {
+                    const int m = min(m0 + e, n_masks - 1);
+                    const size_t o = ((size_t)(fbase + f) * n_masks + m) * n_sampled + sidx;
+                    au[e] = G.acc[o * 2]; av[e] = G.acc[o * 2 + 1];
+                    bu[e] = G.duvb[o * 2]; bv[e] = G.duvb[o * 2 + 1];
+                    rr[e] = ((const float4 *)G.uvi)[o];
+                    const float *P = G.proj + ((size_t)(fbase + f) * G.n_views + G.view_index[m]) * 12;
+                    pk[e][0] = P[k]; pk[e][1] = P[4 + k]; pk[e][2] = P[8 + k];
+                }
+#pragma unroll
+                for (int e = 0; e < MB; ++e) {
+                    if (m0 + e < n_masks) {
+                        const float tu = bu[e] + bf_acc_float(au[e]), tv = bv[e] + bf_acc_float(av[e]);
+                        const float4 r = rr[e];
+                        const float q0 = tu * r.w, q1 = tv * r.w, q2 = -(tu * r.x + tv * r.y) * r.w;
+                        gs += pk[e][0] * q0 + pk[e][1] * q1 + pk[e][2] * q2;
+                    }
+                }
             }
             g += gs;
         }
