@@ -397,28 +397,35 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
 // l / F of it.  Workgroups go to the eight XCDs round-robin by their linear id, so with F = 8 (config 5's shard; any F that divides 8 or
 // is a multiple of it) a frame's workgroups all land on one XCD and its scan's records (4 + 6 MB) are that XCD's L2 contents instead of
 // one eighth of every scan's.
+// Waves (= queries) per workgroup.  ONE since round 5: a workgroup's slots - its LDS above all - are held until its slowest wave is done,
+// and the queries of a workgroup take very different times (a cold or far query walks shells, a warm one a few cells).  Same box,
+// config 5 size, us per launch (exact hints / hints moved 5 mm / cold): 8 waves 125 / 179 / 240, 4 waves 113 / 158 / 222, 2 waves
+// 110 / 145 / 216, 1 wave 107 / 138 / 210.
+#ifndef NN_WAVES
+#define NN_WAVES 1
+#endif
 #define NN_FRAME(F) ((int)(blockIdx.x % (unsigned)(F)))
 #define NN_BLOCK(F) ((int)(blockIdx.x / (unsigned)(F)))
 #define NN_WAVE_LDS(RULE)                                                                                                               \
-    __shared__ float s_general[RULE == BF_NEAREST_REFERENCE ? 4 * 20 * nrule::LANES : 1];                                                \
-    __shared__ int s_queue[4 * NN_QCAP];                                                                                                 \
+    __shared__ float s_general[RULE == BF_NEAREST_REFERENCE ? NN_WAVES * 20 * nrule::LANES : 1];                                                \
+    __shared__ int s_queue[NN_WAVES * NN_QCAP];                                                                                                 \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* (told to the compiler as the wave-uniform value it is: the walk's bookkeeping then lives in scalar registers) */ \
     float *scr = s_general + (RULE == BF_NEAREST_REFERENCE ? wave * 20 * nrule::LANES + (threadIdx.x & 63) : 0);                          \
     int *queue = s_queue + wave * NN_QCAP;
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(64 * NN_WAVES)
 bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                   int *face, float *pts, float *__restrict__ bary, int warm, int n_frames) {
     NN_WAVE_LDS(BF_NEAREST_REFERENCE)
-    const int id = NN_BLOCK(n_frames) * 4 + wave;
+    const int id = NN_BLOCK(n_frames) * NN_WAVES + wave;
     if (id >= n) return;
     nearest_body<BF_NEAREST_REFERENCE>(scans, points, n, face, pts, bary, warm, id, NN_FRAME(n_frames), scr, queue);
 }
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(64 * NN_WAVES)
 bf_nearest_fast_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                        int *face, float *pts, float *__restrict__ bary, int warm, int n_frames) {
     NN_WAVE_LDS(BF_NEAREST_FAST)
-    const int id = NN_BLOCK(n_frames) * 4 + wave;
+    const int id = NN_BLOCK(n_frames) * NN_WAVES + wave;
     if (id >= n) return;
     nearest_body<BF_NEAREST_FAST>(scans, points, n, face, pts, bary, warm, id, NN_FRAME(n_frames), scr, queue);
 }
@@ -460,11 +467,11 @@ extern "C" void bf_nearest_launch(dim3 grid, hipStream_t stream, const ScanDev *
                                   float *bary, int warm) {
     // (grid = (ceil(n / 4), frames) as the callers think of it: one query per wave; launched one-dimensional and frame-minor, NN_FRAME)
     const int F = (int)grid.y;
-    const dim3 sgrid(grid.x * F);
+    const dim3 sgrid((unsigned)((n + NN_WAVES - 1) / NN_WAVES) * F);
     if (bf_nearest_rule_get() == BF_NEAREST_FAST)
-        hipLaunchKernelGGL(bf_nearest_fast_kernel, sgrid, dim3(256), 0, stream, scans, points, n, face, pts, bary, warm, F);
+        hipLaunchKernelGGL(bf_nearest_fast_kernel, sgrid, dim3(64 * NN_WAVES), 0, stream, scans, points, n, face, pts, bary, warm, F);
     else
-        hipLaunchKernelGGL(bf_nearest_kernel, sgrid, dim3(256), 0, stream, scans, points, n, face, pts, bary, warm, F);
+        hipLaunchKernelGGL(bf_nearest_kernel, sgrid, dim3(64 * NN_WAVES), 0, stream, scans, points, n, face, pts, bary, warm, F);
 }
 
 // grid (nblk, F): partial[f][blk] = sum over this block's vertices of |P - C|^2
