@@ -23,7 +23,7 @@ BYTES_CFG5_ITER = 136_600_000                                                   
 HBM_PEAK_GBS = 8000.0
 # bf_nearest_kernel (reference rule): VALU instructions per query-wave from the PMC pass of profiles/r04_rocprof_summary.md
 # (SQ_INSTS_VALU / queries; the kernel is unchanged since).  1,024 SIMDs issue one wave64 VALU instruction per 4 cycles at 2.4 GHz.
-NEAREST_VALU_PER_QUERY = 891
+NEAREST_VALU_PER_QUERY = 894
 SIMD_VALU_PER_S = 1024 * 2.4e9 / 4
 
 
@@ -135,7 +135,7 @@ def cfg5x(reps, frames=8, n_views=48, iters=300, disp_iters=300):
            "ms_per_displacement_iteration": dd * 1e3 / disp_iters,
            "roofline": nominal_roofline(BYTES_CFG5_ITER * iters * frames, dt, "config 5's dense iteration (forward mesh, closest-point search, point-cloud loss, reverse mesh, reduce)"),
            "device_ms_last_iteration": per_class, "resident_fit_launch": b.dense_resident(),
-           # the iteration's dominant kernel is not bound by bytes: one query per wave, ~891 VALU instructions per query
+           # the iteration's dominant kernel is not bound by bytes: one query per wave, ~894 VALU instructions per query
            "dominant_kernel": {"name": "bf_nearest_kernel", "bound": "valu_issue", "queries_per_launch": frames * nv,
                                "valu_per_query_wave": NEAREST_VALU_PER_QUERY, "ms_per_launch": search_s * 1e3,
                                "issue_bound_ms": frames * nv * NEAREST_VALU_PER_QUERY / SIMD_VALU_PER_S * 1e3,
