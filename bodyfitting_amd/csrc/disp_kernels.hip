@@ -10,6 +10,9 @@
 // Kernels per iteration: faces -> vertices(+P) -> [nearest, pc_partial from scan_kernels.hip] ->
 // vertex gradient -> face gradient -> vertex gather + Adam.
 #include "bf_internal.h"
+#ifndef BF_ADJ_BATCH
+#define BF_ADJ_BATCH 8        // incident faces of a vertex walked together (a closed triangle mesh averages six)
+#endif
 
 // grid (ceil(NF/256), F)
 extern "C" __global__ void __launch_bounds__(256)
@@ -42,9 +45,18 @@ bf_disp_vertex_kernel(const int *__restrict__ adj_start, const int *__restrict__
     const size_t o = ((size_t)fr * nv + v) * 3;
     P[o] = base[o] + disp[o]; P[o + 1] = base[o + 1] + disp[o + 1]; P[o + 2] = base[o + 2] + disp[o + 2];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int i = adj_start[v]; i < adj_start[v + 1]; ++i) {
-        float4 n = ((const float4 *)fnorm)[(size_t)fr * nf + (adj[i] >> 2)];
-        a0 += n.x; a1 += n.y; a2 += n.z;
+    // (the incident faces eight at a time: list entries, then normals, each level's loads in flight together - entry by entry the walk
+    //  was a chain of dependent round trips per face; the additions stay in list order)
+    const int i0 = adj_start[v], i1 = adj_start[v + 1];
+    for (int base = i0; base < i1; base += BF_ADJ_BATCH) {
+        int a[BF_ADJ_BATCH];
+        float4 n[BF_ADJ_BATCH];
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e) a[e] = base + e < i1 ? adj[base + e] : -1;
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e) n[e] = a[e] >= 0 ? ((const float4 *)fnorm)[(size_t)fr * nf + (a[e] >> 2)] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e) if (a[e] >= 0) { a0 += n[e].x; a1 += n[e].y; a2 += n[e].z; }
     }
     float len = sqrtf(a0 * a0 + a1 * a1 + a2 * a2), s = len + 1e-8f;
     float4 r = {a0 / s, a1 / s, a2 / s, len};
@@ -87,10 +99,22 @@ bf_disp_vgrad_kernel(const int *__restrict__ faces, const int *__restrict__ adj_
     }
     // laplacian: mean_f (|na-nb|^2 + |nc-na|^2 + |nb-nc|^2)  ->  d/dn_v = 2 (2 n_v - n_o1 - n_o2) / NF per incident face
     const float k2 = 2.f * w / (float)nf;
-    for (int i = adj_start[v]; i < adj_start[v + 1]; ++i) {
-        int f = adj[i] >> 2, c = adj[i] & 3;
-        float4 o1 = vn[faces[f * 3 + (c + 1) % 3]], o2 = vn[faces[f * 3 + (c + 2) % 3]];
-        g0 += k2 * (2.f * me.x - o1.x - o2.x); g1 += k2 * (2.f * me.y - o1.y - o2.y); g2 += k2 * (2.f * me.z - o1.z - o2.z);
+    const int i0 = adj_start[v], i1 = adj_start[v + 1];
+    for (int base = i0; base < i1; base += BF_ADJ_BATCH) {            // (eight incident faces at a time, level by level: see bf_disp_vertex_kernel)
+        int a[BF_ADJ_BATCH], v1[BF_ADJ_BATCH], v2[BF_ADJ_BATCH];
+        float4 o1[BF_ADJ_BATCH], o2[BF_ADJ_BATCH];
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e) a[e] = base + e < i1 ? adj[base + e] : -1;
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e) {
+            const int f = a[e] >> 2, c = a[e] & 3;
+            v1[e] = a[e] >= 0 ? faces[f * 3 + (c + 1) % 3] : 0; v2[e] = a[e] >= 0 ? faces[f * 3 + (c + 2) % 3] : 0;
+        }
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e) { o1[e] = vn[v1[e]]; o2[e] = vn[v2[e]]; }
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e)
+            if (a[e] >= 0) { g0 += k2 * (2.f * me.x - o1[e].x - o2[e].x); g1 += k2 * (2.f * me.y - o1[e].y - o2[e].y); g2 += k2 * (2.f * me.z - o1[e].z - o2[e].z); }
     }
     // through n = x / (|x| + 1e-8):  dx = dn / s - n (n . dn) / |x|
     float len = me.w, s = len + 1e-8f, dot = me.x * g0 + me.y * g1 + me.z * g2;
@@ -135,9 +159,19 @@ bf_disp_adam_kernel(const int *__restrict__ adj_start, const int *__restrict__ a
     const float inorm = 1.0f / sqrtf(tot);
     const size_t o = ((size_t)fr * nv + v) * 3;
     float g[3] = {(P[o] - C[o]) * inorm, (P[o + 1] - C[o + 1]) * inorm, (P[o + 2] - C[o + 2]) * inorm};
-    for (int i = adj_start[v]; i < adj_start[v + 1]; ++i) {
-        const float *q = dPf + ((size_t)fr * nf + (adj[i] >> 2)) * 9 + (adj[i] & 3) * 3;
-        g[0] += q[0]; g[1] += q[1]; g[2] += q[2];
+    const int i0 = adj_start[v], i1 = adj_start[v + 1];
+    for (int base = i0; base < i1; base += BF_ADJ_BATCH) {            // (eight incident faces at a time, level by level: see bf_disp_vertex_kernel)
+        int a[BF_ADJ_BATCH];
+        float q[BF_ADJ_BATCH][3];
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e) a[e] = base + e < i1 ? adj[base + e] : -1;
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e) {
+            const float *qp = dPf + ((size_t)fr * nf + (a[e] >= 0 ? a[e] >> 2 : 0)) * 9 + (a[e] >= 0 ? a[e] & 3 : 0) * 3;
+            q[e][0] = qp[0]; q[e][1] = qp[1]; q[e][2] = qp[2];
+        }
+#pragma unroll
+        for (int e = 0; e < BF_ADJ_BATCH; ++e) if (a[e] >= 0) { g[0] += q[e][0]; g[1] += q[e][1]; g[2] += q[e][2]; }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
