@@ -13,7 +13,7 @@ assert t != s, "patch did not change the source"
 open("_variant.hip", "w").write(t)
 PY
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on -mllvm -amdgpu-sched-strategy=max-ilp -c _variant.hip -o _variant.o 2>&1 | grep -E "error|Illegal|warning" && { echo "BUILD FAILED $TAG"; rm -f _variant.hip _variant.o; exit 1; }
-OBJ=$(ls *.o | grep -v "fit_kernels.o\|_variant.o" | tr '\n' ' ')
+OBJ=$(ls *.o | grep -v "fit_kernels.o\|_variant.o\|stamp" | tr '\n' ' ')
 /opt/rocm/bin/hipcc -shared --offload-arch=gfx950 -o ../libbodyfit_V_$TAG.so $OBJ _variant.o -ldl
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -mllvm -amdgpu-sched-strategy=max-ilp -Rpass-analysis=kernel-resource-usage -c _variant.hip -o /dev/null 2>&1 | grep -A5 "Function Name: _Z10fit_kernelILi24ELi10ELi11ELi25ELb0" | grep -E "Scratch|VGPRs" | sed 's/.*remark: *//; s/\[-Rpass.*//' | tr '\n' ' '; echo " <- $TAG"
 rm -f _variant.hip _variant.o
