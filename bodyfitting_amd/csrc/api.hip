@@ -1212,14 +1212,13 @@ static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t fl
         FrameIO io2 = bf_frame_io(b, false);
         io2.params0 = b->params0.p;                  // re-arm inside the fit kernel
         static const bool own_signal = [] { const char *e = getenv("BF_FIT_DONE_EVENT"); return !(e && e[0] == '0'); }();
-        const bool crowded_ = b->F >= [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
-        const bool signal_here = own_signal && !crowded_;       // (ev_done[k] completes with the fit's own dispatch: no marker packet between this fit and the next)
+        static const int n_cus = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+        const bool crowded = b->F >= n_cus;
+        const bool signal_here = own_signal && !crowded;       // (ev_done[k] completes with the fit's own dispatch: no marker packet between this fit and the next)
         HIP_TRY(bf_fit_launch(&m->fit, &io2, &hd, n_iters, 0, b->adam_tab.p, b->steps_done, b->fit_smem, b->stream, signal_here ? b->ev_done[k] : nullptr));
         // A batch that fills the machine (a frame's workgroup per CU, one workgroup fits per CU): under the NEXT fit the mesh kernels
         // would only get the CUs that fit's workgroups leave as they finish - measured 379 us for a 33 us GEMM at 256 frames.  The mesh
         // then goes on the fit's own stream, ahead of the next fit (0.462 + 0.074 ms instead of 0.601); only the copy stays aside.
-        static const int n_cus = [] { int v = 0, dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
-        const bool crowded = b->F >= n_cus;
         if (crowded) {
             rc = bf_launch_mesh(m, &b->scratch, b->F, b->state.p, b->vraw.p, b->vout.p, b->xpart.p, b->joints.p, nullptr, b->stream, nullptr, nullptr);
             if (rc) return rc;
