@@ -7,7 +7,7 @@ extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const flo
 extern "C" __global__ void bf_mesh_kernel(MeshTab, const float *, float *, float *, float *, float *, const float *, int *, int);
 extern "C" __global__ void bf_mesh_span_kernel(MeshTab, const float *, float *, float *, float *, unsigned long long *);
 extern "C" int bf_mesh_use_multi(int npf, int n);
-extern "C" int bf_mesh_multi_launch(const MeshTab *, const float *, int, float *, float *, float *, float *, float *, hipStream_t, const MaskProj *, int *, int);
+extern "C" int bf_mesh_multi_launch(const MeshTab *, const float *, int, float *, float *, float *, float *, float *, hipStream_t, const MaskProj *, int *, int, hipEvent_t);
 extern "C" __global__ void bf_mesh_epilogue_kernel(MeshTab, const float *, const float *, float *, float *, float *, float *);
 extern "C" hipError_t bf_poseblend_launch(const MeshTab *M, const float *state, int n, float *featT, int kpad, int fpad, float *pose_off, hipStream_t stream);
 extern "C" bool bf_mesh_batch32_fits(const MeshTab *M);
@@ -519,7 +519,8 @@ int bf_model_fit_instance(const bf_model *m) { return (m && bf_fit_is_sized_smpl
 int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev, float *vraw, float *vout, float *xpart, float *joints,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw, int *lmk_vid,
                    float *lmk_w, float *dvzero, bool *zeroed, bool want_xpart, const MaskProj *mproj, bool *projected, int *door, int door_target,
-                   const MeshTab *tab) {
+                   const MeshTab *tab, hipEvent_t mesh_done, bool *mesh_done_set) {
+    if (mesh_done_set) *mesh_done_set = false;
     if (zeroed) *zeroed = false;
     if (projected) *projected = false;
     const bool need_x = joints || joints_ori || jraw || want_xpart;
@@ -557,7 +558,8 @@ int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev,
                            need_x ? xpart : (float *)nullptr, vposed);
     } else if (bf_mesh_use_multi(m->npf, n)) {
         const int e = bf_mesh_multi_launch(&Q, state_dev, n, vraw, vout, need_x ? xpart : (float *)nullptr, vposed,
-                                           dvzero, stream, mproj, door, door_target);
+                                           dvzero, stream, mproj, door, door_target, mesh_done);
+        if (mesh_done && mesh_done_set) *mesh_done_set = true;          // (the event completes with the mesh dispatch: the caller records nothing)
         if (projected && mproj) *projected = true;
         if (zeroed && dvzero) *zeroed = true;
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_multi_kernel: ") + hipGetErrorString((hipError_t)e));

@@ -342,7 +342,7 @@ int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev,
                    float *joints_ori, hipStream_t stream, hipEvent_t after_mesh, float *vposed, float *jraw = nullptr,
                    int *lmk_vid = nullptr, float *lmk_w = nullptr, float *dvzero = nullptr, bool *zeroed = nullptr, bool want_xpart = false,
                    const MaskProj *mproj = nullptr, bool *projected = nullptr, int *door = nullptr, int door_target = 0,
-                   const MeshTab *tab = nullptr);
+                   const MeshTab *tab = nullptr, hipEvent_t mesh_done = nullptr, bool *mesh_done_set = nullptr);
 // (dvzero: a [n][NV][3] buffer the forward pass should zero while it is at it - only the 1..15-frame kernel does, *zeroed says so;
 //  want_xpart: fill xpart although no joints are asked for here - the caller forms them itself;
 //  mproj: project the sampled vertices into the mask views as well - only the 1..15-frame kernel does, *projected says so)

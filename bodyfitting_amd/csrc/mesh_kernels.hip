@@ -15,6 +15,7 @@
 // independent, the whole 17 MB matrix is in flight at once and all 256 CUs have work.  The 24 chain
 // matrices (1.1 KB) and the 207-float pose feature sit in LDS.
 #include "bf_internal.h"
+#include <hip/hip_ext.h>
 #include "pose_state_body.h"
 #include "joints_body.h"
 #include "loss_bodies.h"
@@ -458,7 +459,8 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
 }
 
 extern "C" int bf_mesh_multi_launch(const MeshTab *M, const float *state, int n, float *vraw, float *vout, float *xpart, float *vposed,
-                                    float *dvzero, hipStream_t stream, const MaskProj *mproj, int *door, int door_target) {
+                                    float *dvzero, hipStream_t stream, const MaskProj *mproj, int *door, int door_target, hipEvent_t done) {
+    // (`done`: an event that completes with this dispatch - its own completion signal instead of a marker packet behind it)
     MaskProj mp;
     if (mproj) mp = *mproj; else { std::memset(&mp, 0, sizeof mp); }
     constexpr int COLS = BF_MESH_TILE * 3;
@@ -474,10 +476,18 @@ extern "C" int bf_mesh_multi_launch(const MeshTab *M, const float *state, int n,
         if (e != hipSuccess) return (int)e;
     }
     switch (fpw) {
-    case 1: hipLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target); break;
-    case 2: hipLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target); break;
-    case 4: hipLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target); break;
-    default: hipLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target); break;
+    case 1: if (done) hipExtLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, nullptr, done, 0, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target);
+             else hipLaunchKernelGGL(bf_mesh_multi_kernel<1>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target);
+             break;
+    case 2: if (done) hipExtLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, nullptr, done, 0, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target);
+             else hipLaunchKernelGGL(bf_mesh_multi_kernel<2>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target);
+             break;
+    case 4: if (done) hipExtLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, nullptr, done, 0, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target);
+             else hipLaunchKernelGGL(bf_mesh_multi_kernel<4>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target);
+             break;
+    default: if (done) hipExtLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, nullptr, done, 0, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target);
+             else hipLaunchKernelGGL(bf_mesh_multi_kernel<8>, grid, block, smem, stream, *M, state, n, vraw, vout, xpart, vposed, dvzero, mp, door, door_target);
+             break;
     }
     return (int)hipGetLastError();
 }

@@ -519,9 +519,16 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         mp.K.acc = (acc_mode && !scans) ? b->mk_acc.p : nullptr;      // (zeroed by the projection that precedes the contour scan)
         if (sub) { mp.K.nv = nv; mp.K.sstride = 1; }
     }
+    const bool kp_aside = kp && !masks && scans && b->copy_stream;       // (see below)
+    bool forked = false;                                                  // ev_aux[0] completes with the mesh dispatch itself
+    if (kp_aside && !b->ev_aux[0]) {
+        HIP_TRY(hipEventCreateWithFlags(&b->ev_aux[0], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b->ev_aux[1], hipEventDisableTiming));
+    }
     int rc = bf_launch_mesh(m, &b->scratch, F, b->state.p, b->vraw.p, b->vout.p, kp ? b->xpart.p : nullptr, nullptr, nullptr, b->stream, nullptr,
                             b->vposed.p, nullptr, nullptr, nullptr, (kp || masks) ? b->dvout.p : nullptr, &zeroed, kp, masks ? &mp : nullptr,
-                            &projected, door, (F * door_k) | (door_coherent() ? 0x40000000 : 0), sub ? &Q : nullptr);
+                            &projected, door, (F * door_k) | (door_coherent() ? 0x40000000 : 0), sub ? &Q : nullptr,
+                            kp_aside ? b->ev_aux[0] : nullptr, &forked);
     if (rc) return rc;
     if ((kp || masks) && !zeroed) HIP_TRY(hipMemsetAsync(b->dvout.p, 0, b->dvout.n * sizeof(float), b->stream));
     HIP_TRY(mark(1));                         // [0,1] pose state (when not resident) + forward mesh pass
@@ -531,13 +538,10 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
     // dL/dvertices.
     // (With a silhouette loss instead the keypoint workgroups ride in the contour launch: taking them out onto the second stream was
     //  measured slower - 0.093 vs 0.085 ms per iteration - the fork / join costs more than the 7 us the merged launch waits for them.)
-    const bool kp_aside = kp && !masks && scans && b->copy_stream;
     if (kp_aside) {
-        if (!b->ev_aux[0]) {
-            HIP_TRY(hipEventCreateWithFlags(&b->ev_aux[0], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&b->ev_aux[1], hipEventDisableTiming));
-        }
-        HIP_TRY(hipEventRecord(b->ev_aux[0], b->stream));
+        // (the fork: the mesh dispatch's own completion signal when it could carry one - a record here is a marker packet between the
+        //  mesh pass and the search, ~4 us of the batch stream's time per iteration)
+        if (!forked || !zeroed) HIP_TRY(hipEventRecord(b->ev_aux[0], b->stream));
         HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_aux[0], 0));
         rc = launch_kp(b, h, sub, b->copy_stream);
         if (rc) return rc;
