@@ -252,6 +252,7 @@ struct bf_batch {
     hipEvent_t ev_door[2] = {nullptr, nullptr};
     DevBuf<int> door;
     int *h_resident = nullptr;          // pinned, device-visible: workgroups of the persistent launch that have started (this call)
+    int kp_tickets = 0;                 // keypoint workgroups launched beside the search since the doors were last zeroed (BF_DOOR_KP's target)
     int *h_door_err = nullptr;          // pinned; copied from door[BF_DOOR_ERR] at the end of a call, read by bf_sync_all
     hipEvent_t ev_done[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
     bool copy_pending[2] = {false, false};

@@ -234,6 +234,7 @@ struct MaskProj {
 #define BF_DOOR_EXT 0
 #define BF_DOOR_TICKET 1
 #define BF_DOOR_ERR 2
+#define BF_DOOR_KP 3            // running count of finished keypoint workgroups that ran beside the closest-point search (F per dense iteration): bf_pc_grad_kernel waits for F x k
 #define BF_DOOR_STATE 64
 #define BF_DOOR_FEAT 96          // (+ c * BF_DOOR_COPY_STRIDE) like BF_DOOR_STATE, one cache line further: the pose FEATURES of that many (frame,
                                  // iteration) states are published - rung early in the fit launch's phase A, as soon as the rotations exist, so a

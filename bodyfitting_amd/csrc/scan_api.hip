@@ -9,7 +9,7 @@ extern "C" __global__ void bf_pose_state_kernel(FitTab, const float *, const flo
 extern "C" void bf_nearest_launch(dim3 grid, hipStream_t stream, const ScanDev *scans, const float *points, int n, int *face, float *pts,
                                   float *bary, int warm);        // scan_kernels.hip: the rule selected by bf_nearest_rule_set / BF_NEAREST_RULE
 extern "C" __global__ void bf_pc_partial_kernel(const float *, const float *, int, float *);
-extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int);
+extern "C" __global__ void bf_pc_grad_kernel(const float *, const float *, int, const float *, const float *, float *, float *, int, int *, int);
 extern "C" int bf_mesh_bwd_multi_launch(const MeshTab *, const float *, const float *, int, const float *, const float *, const float *, float *, hipStream_t,
                                         const float *, int, int, int, int, int *, const MaskFold *);
 extern "C" __global__ void bf_ext_reduce_kernel(const float *, int, int, float *, int, int *, int);
@@ -17,7 +17,7 @@ extern "C" int bf_mesh_use_multi(int npf, int n);
 extern "C" __global__ void bf_door_probe_kernel(int *);
 extern "C" __global__ void bf_door_ring_kernel(int *);
 extern "C" __global__ void bf_kp_loss_kernel(KpIO, const float *, const float *, const float *, const float *, const int *, const int *,
-                                             const float *, float *, float *, float *, MeshTab, const float *, const float *);
+                                             const float *, float *, float *, float *, MeshTab, const float *, const float *, int *);
 extern "C" __global__ void bf_grid_count_kernel(ScanDev, int *);
 extern "C" __global__ void bf_grid_scan_kernel(int *, int *, int);
 extern "C" __global__ void bf_grid_fill_kernel(ScanDev, int *, int *);
@@ -415,12 +415,12 @@ static KpIO kp_io(bf_batch *b, const bf_hyper &h, const bf_model::Sub *sub = nul
     return K;
 }
 // (the keypoint workgroup computes the joints itself from the mesh pass's vraw / xpart: no bf_joints_kernel launch)
-static int launch_kp(bf_batch *b, const bf_hyper &h, const bf_model::Sub *sub = nullptr, hipStream_t on = nullptr) {
+static int launch_kp(bf_batch *b, const bf_hyper &h, const bf_model::Sub *sub = nullptr, hipStream_t on = nullptr, int *door = nullptr) {
     const KpIO K = kp_io(b, h, sub);
     hipLaunchKernelGGL(bf_kp_loss_kernel, dim3(b->F), dim3(512), kp_smem(K), on ? on : b->stream, K, (const float *)b->jraw.p, (const float *)b->state.p,
                        (const float *)b->proj.p, (const float *)b->keypoints.p, (const int *)b->ndiv.p, (const int *)b->lmk_vid.p,
                        (const float *)b->lmk_w.p, b->ext.p, b->dvout.p, b->terms.p, sub ? sub->mesh : b->m->mesh, (const float *)b->vraw.p,
-                       (const float *)b->xpart.p);
+                       (const float *)b->xpart.p, door);
     HIP_TRY(hipGetLastError());
     return BF_OK;
 }
@@ -543,9 +543,12 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         //  mesh pass and the search, ~4 us of the batch stream's time per iteration)
         if (!forked || !zeroed) HIP_TRY(hipEventRecord(b->ev_aux[0], b->stream));
         HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_aux[0], 0));
-        rc = launch_kp(b, h, sub, b->copy_stream);
+        // (the join: with the resident launch's doorbells at hand the keypoint workgroups count themselves off there and
+        //  bf_pc_grad_kernel waits for the count - BF_DOOR_KP; without them an event on the second stream and a wait on this one)
+        rc = launch_kp(b, h, sub, b->copy_stream, door);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(b->ev_aux[1], b->copy_stream));
+        if (door) b->kp_tickets += F;
+        else HIP_TRY(hipEventRecord(b->ev_aux[1], b->copy_stream));
     } else if (kp && !masks) { rc = launch_kp(b, h, sub); if (rc) return rc; }
     // with a scan as well, bf_pc_grad_kernel adds onto (keypoints + silhouette): keep that order of additions
     const bool fold_views = masks && !scans;
@@ -559,10 +562,10 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         HIP_TRY(mark(3));                     // [2,3] closest-point search
         hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, b->pc_partial.p);
-        if (kp_aside) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_aux[1], 0));
+        if (kp_aside && !door) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_aux[1], 0));
         hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, (const float *)b->pc_partial.p, (const float *)b->pc_weight.p,
-                           b->dvout.p, b->pc_loss.p, (kp || masks) ? 1 : 0);
+                           b->dvout.p, b->pc_loss.p, (kp || masks) ? 1 : 0, (kp_aside && door) ? door : (int *)nullptr, b->kp_tickets);
     }
     if (!scans) HIP_TRY(mark(3));
     HIP_TRY(mark(4));                         // [3,4] point-cloud loss + gradient (+ the join with the keypoint workgroups of the second stream)
@@ -702,6 +705,7 @@ int bf_fit_with_scans(bf_batch *b, int n_iters, const bf_hyper &h, const HyperDe
     if (door_ok && n_dense >= 1 && F < BF_MFMA_MIN_FRAMES && b->door_usable) {
         *(volatile int *)b->h_resident = 0;
         HIP_TRY(hipMemsetAsync(b->door.p, 0, BF_DOOR_INTS * sizeof(int), b->stream));
+        b->kp_tickets = 0;
         HIP_TRY(hipEventRecord(b->ev_door[0], b->stream));              // parameters / Adam state / doorbells as the loop finds them
         HIP_TRY(hipStreamWaitEvent(b->fit_stream, b->ev_door[0], 0));
         FrameIO io2 = io;

@@ -495,12 +495,21 @@ bf_pc_partial_kernel(const float *__restrict__ P, const float *__restrict__ C, i
 // `accumulate` != 0 adds to dvout instead of overwriting it.  loss[f] = weight[f] * norm (block 0 writes it).
 extern "C" __global__ void __launch_bounds__(256)
 bf_pc_grad_kernel(const float *__restrict__ P, const float *__restrict__ C, int n, const float *__restrict__ partial,
-                  const float *__restrict__ weight, float *__restrict__ dvout, float *__restrict__ loss, int accumulate) {
+                  const float *__restrict__ weight, float *__restrict__ dvout, float *__restrict__ loss, int accumulate,
+                  int *door, int door_target) {
     const int id = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
     float tot = 0.f;
     for (int b = 0; b < (int)gridDim.x; ++b) tot += partial[(size_t)f * gridDim.x + b];      // fixed order
     const float norm = sqrtf(tot), w = weight[f];
     if (blockIdx.x == 0 && threadIdx.x == 0 && loss) loss[f] = w * norm;
+    // (door: the keypoint workgroups whose dL/dvertices this kernel adds onto ran on the second stream beside the search and count
+    //  themselves off in door[BF_DOOR_KP] - they are done ~100 us before this kernel starts; the stream-level join that used to sit
+    //  in front of this launch was a wait packet of ~7 us per iteration.  A wait that runs into its time limit raises the door's
+    //  error flag and the call fails, as for the other doorbells.)
+    if (door) {
+        if (threadIdx.x == 0) (void)bf_door_wait(door, BF_DOOR_KP, door_target);
+        __syncthreads();
+    }
     if (id >= n) return;
     const size_t o = ((size_t)f * n + id) * 3;
     const float k = w / norm;
@@ -826,7 +835,7 @@ extern "C" __global__ void __launch_bounds__(512)
 bf_kp_loss_kernel(KpIO Q, const float *__restrict__ jraw, const float *__restrict__ state, const float *__restrict__ proj_all,
                   const float *__restrict__ keypoints, const int *__restrict__ ndiv, const int *__restrict__ lmk_vid,
                   const float *__restrict__ lmk_w, float *__restrict__ ext, float *__restrict__ dvout, float *__restrict__ terms,
-                  MeshTab M, const float *__restrict__ vraw, const float *__restrict__ xpart) {
+                  MeshTab M, const float *__restrict__ vraw, const float *__restrict__ xpart, int *door) {
     extern __shared__ __align__(16) float sm[];
     if (vraw) {           // the joints first (bf_joints_kernel's body: jraw / lmk_vid / lmk_w are then OUTPUTS of this workgroup)
         bf_joints_body<512>(M, state, vraw, xpart, nullptr, nullptr, const_cast<float *>(jraw), const_cast<int *>(lmk_vid), const_cast<float *>(lmk_w),
@@ -834,6 +843,13 @@ bf_kp_loss_kernel(KpIO Q, const float *__restrict__ jraw, const float *__restric
         __syncthreads();
     }
     bf_kp_loss_body(blockIdx.x, sm, Q, jraw, state, proj_all, keypoints, ndiv, lmk_vid, lmk_w, ext, dvout, terms);
+    if (door) {           // (on the second stream beside the search: count this workgroup off for bf_pc_grad_kernel - one device-scope release, then the ticket)
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            (void)__hip_atomic_fetch_add(door + BF_DOOR_KP, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // The dense keypoint loss and the silhouette loss's contour scan in ONE launch.  grid (contour blocks + 1, M, F), 512 threads:
