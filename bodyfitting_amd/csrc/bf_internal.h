@@ -8,6 +8,9 @@
 #define BF_GMM_LD 72        // padded row length of the d / y vectors in LDS
 #define BF_FIT_THREADS 512  // one workgroup (8 wave64, two per SIMD) per frame
 #define BF_VSUB 16          // view lanes per loss-joint pair in the projection phase (one DPP row)
+#ifndef BF_RED_COLS
+#define BF_RED_COLS 64       // outputs per workgroup of bf_ext_reduce_kernel (x 8 chunks of partial rows = its threads)
+#endif
 #define BF_KP_ROUNDS 3      // keypoint records staged in LDS for V <= 16*3 = 48 views
 #define BF_SEL_NNZ 8         // compacted skinning weights per selector vertex (real SMPL has <= 4)
 #define BF_SKIN_PER_WAVE 5   // selector vertices a geometry wave can skin in one pass (12 lanes each) in the merged skin + projection phase

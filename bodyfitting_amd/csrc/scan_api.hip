@@ -580,7 +580,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_bwd_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     }
     HIP_TRY(mark(5));                         // [4,5] reverse mesh pass
-    hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + 31) / 32, F), dim3(256), 0, b->stream,
+    hipLaunchKernelGGL(bf_ext_reduce_kernel, dim3((EXT + BF_RED_COLS - 1) / BF_RED_COLS, F), dim3(8 * BF_RED_COLS), 0, b->stream,
                        (const float *)b->ext_part.p, part_rows, EXT, b->ext.p, EXT + m->nj * 3 + 4, door, door_k);
     HIP_TRY(hipGetLastError());
     HIP_TRY(mark(6));                         // [5,6] reduction of the partial blocks (rings the resident fit launch)

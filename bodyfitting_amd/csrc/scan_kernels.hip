@@ -784,10 +784,12 @@ extern "C" __global__ void bf_door_ring_kernel(int *door) {
 #ifndef BF_RED_UNROLL
 #define BF_RED_UNROLL 24
 #endif
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(8 * BF_RED_COLS)
 bf_ext_reduce_kernel(const float *__restrict__ part, int n_tiles, int EXT, float *__restrict__ ext, int ext_stride, int *door, int door_k) {
-    __shared__ float s_c[8][32];
-    const int li = threadIdx.x & 31, ch = threadIdx.x >> 5, i = blockIdx.x * 32 + li, f = blockIdx.y;
+    // (BF_RED_COLS outputs per workgroup: 64 since the end of round 5 - half as many workgroups ring the door, each behind a device-scope
+    //  release that writes its XCD's L2 back, and a wave reads 256 contiguous bytes of a partial row instead of two rows' 128)
+    __shared__ float s_c[8][BF_RED_COLS];
+    const int li = threadIdx.x % BF_RED_COLS, ch = threadIdx.x / BF_RED_COLS, i = blockIdx.x * BF_RED_COLS + li, f = blockIdx.y;
     const int per = (n_tiles + 7) / 8, t0 = ch * per, t1 = min(n_tiles, t0 + per);
     float acc = 0.f;
     if (i < EXT) {
