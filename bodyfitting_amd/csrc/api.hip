@@ -559,10 +559,10 @@ int bf_launch_mesh(bf_model *m, MeshScratch *scr, int n, const float *state_dev,
     } else if (bf_mesh_use_multi(m->npf, n)) {
         const int e = bf_mesh_multi_launch(&Q, state_dev, n, vraw, vout, need_x ? xpart : (float *)nullptr, vposed,
                                            dvzero, stream, mproj, door, door_target, mesh_done);
+        if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_multi_kernel: ") + hipGetErrorString((hipError_t)e));
         if (mesh_done && mesh_done_set) *mesh_done_set = true;          // (the event completes with the mesh dispatch: the caller records nothing)
         if (projected && mproj) *projected = true;
         if (zeroed && dvzero) *zeroed = true;
-        if (e) return fail(BF_ERR_HIP, std::string("bf_mesh_multi_kernel: ") + hipGetErrorString((hipError_t)e));
     } else
     hipLaunchKernelGGL(bf_mesh_kernel, grid, dim3(BF_MESH_TILE * 3 * BF_MESH_RG), m->mesh_smem, stream, Q,
                        state_dev, vraw, vout, need_x ? xpart : (float *)nullptr, vposed, pose_off, door, door_target);
@@ -642,10 +642,7 @@ static hipError_t write_input(bf_batch *b, void *dst, const void *src, size_t by
 // the deferred part of a frame-after-frame call (fit_impl, `tail_aside`): mesh + joints + hand-over of result arena tail_k on the
 // second stream, behind the fit that filled it.  Every entry point that looks at results, events of the second stream or starts
 // another fit comes through here first (bf_sync_all, bf_fit, bf_batch_get_previous, bf_batch_stage_inputs, bf_batch_destroy).
-int bf_flush_tail(bf_batch *b) {
-    const int k = b->tail_k;
-    if (k < 0) return BF_OK;
-    b->tail_k = -1;
+static int flush_tail_body(bf_batch *b, int k) {
     bf_model *m = b->m;
     HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_done[k], 0));
     float *d = k ? b->res_b.p : b->res.p;            // (arena k's slices by address: the views may already have moved on)
@@ -661,6 +658,23 @@ int bf_flush_tail(bf_batch *b) {
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(b->ev_copied[k], b->copy_stream));
+    return BF_OK;
+}
+int bf_flush_tail(bf_batch *b) {
+    const int k = b->tail_k;
+    if (k < 0) return BF_OK;
+    b->tail_k = -1;
+    const int rc = flush_tail_body(b, k);
+    if (rc) {
+        // the mesh / copy / event of arena k did not all go out: ev_copied[k] still carries its previous (completed) record, so a
+        // wait on it would pass and hand out the pinned buffer's OLD contents.  Nothing of this arena may be read any more:
+        // bf_batch_get_previous (arena_fetched) and bf_batch_get_result (have_result) then fail instead.
+        b->arena_fetched[k] = false;
+        b->arena_has_v[k] = false;
+        b->copy_pending[k] = false;
+        if (k == b->cur) b->have_result = false;
+        return rc;
+    }
     b->tail_seq = b->arena_seq[k];
     return BF_OK;
 }
@@ -1075,6 +1089,8 @@ static int fit_impl(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t fl
 
 int bf_fit(bf_batch *b, int n_iters, const bf_hyper *hyper, uint32_t flags) {
     if (!b || n_iters <= 0) return fail(BF_ERR_INVALID, "bf_fit: bad argument");
+    if (b->scans_lost)
+        return fail(BF_ERR_INVALID, "bf_fit: a scan this batch held was destroyed (bf_scan_destroy) - call bf_batch_set_scans again (NULL: go on without scans)");
     if (b->staged && !(flags & BF_FIT_RESET))
         return fail(BF_ERR_INVALID, "bf_fit: inputs were staged with bf_batch_stage_inputs - the fit of a new frame starts from its initial estimate (BF_FIT_RESET)");
     bf_masks_commit(b);                       // (silhouettes staged with bf_batch_stage_masks become this fit's)

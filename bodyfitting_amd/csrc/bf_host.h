@@ -248,6 +248,8 @@ struct bf_batch {
     bool dense_timing = false, dense_timed = false;
     hipEvent_t ev_dense[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool door_usable = false;           // the self-test at first use found the fit stream running beside the batch stream
+    bool scans_lost = false;            // a scan this batch held was destroyed under it: fits fail until bf_batch_set_scans is called again
+    bool kp_door_ok = false;            // ... and the second stream beside the batch stream (the doorbell join of config 5's keypoint workgroups)
     int dense_resident = -1;            // bf_batch_dense_resident: how the last dense fit ran
     hipEvent_t ev_door[2] = {nullptr, nullptr};
     DevBuf<int> door;

@@ -60,7 +60,18 @@ constexpr float SAFE = 1e-8f;
 // Storage: element i of A at A[i * LANES], of b at b[i * LANES] - the caller's slot in an LDS array shared by the wave's lanes (a
 // private array indexed by the pivot lives in scratch memory: ~100 dependent round trips of ~600 cycles per call, measured as 64 us
 // for ONE pending query; LDS is ~10x closer).
-constexpr int LANES = 64;
+// Round 6: LANES slots per wave, not 64 - the lanes of a wave that need the general routines (a handful per launch) take turns in
+// rounds of LANES (lane l uses slot l % LANES in round l / LANES): 1.25 KB of LDS per wave instead of 5, which was what held the
+// closest-point kernel to six waves per SIMD.
+#ifndef BF_NRULE_LANES
+#define BF_NRULE_LANES 16
+#endif
+constexpr int LANES = BF_NRULE_LANES;
+#ifdef __HIPCC__
+__device__ __forceinline__ int general_round() { return (int)(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) / LANES); }
+#else
+inline int general_round() { return 0; }
+#endif
 template <int N>
 __device__ __noinline__ bool elim_general(float *A_, float *b_) {
     int rank = N, pivot;
@@ -306,7 +317,7 @@ __device__ __forceinline__ float nearest_proj_regular(const float *p, float *coe
 
 // search_nearest_proj (kernel.cu:12-109) with everything: the regular paths where they apply, the general routines of matrix.h where
 // the reference takes a rank decision (or a Gram entry reaches 1).  Used by the second kernel only.
-// scr: this lane's slot of a [20][LANES] float array in LDS (the systems the general routines work on).
+// scr: this lane's slot (lane % LANES) of a [20][LANES] float array in LDS (the systems the general routines work on).
 __device__ __forceinline__ float nearest_proj_general(const float *p, float *coeff, float *scr) {
     float G[9];
 #pragma unroll
@@ -322,12 +333,17 @@ __device__ __forceinline__ float nearest_proj_general(const float *p, float *coe
     bool solved;
     if (!kkt_regular(G[0], G[1], G[2], G[4], G[5], G[8], x)) {
         const float A[16] = {G[0], G[1], G[2], 1.f, G[3], G[4], G[5], 1.f, G[6], G[7], G[8], 1.f, 1.f, 1.f, 1.f, 0.f};
+        solved = false;
+        const int turn = general_round();
+        for (int round = 0; round < 64 / LANES; ++round)
+            if (round == turn) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) scr[e * LANES] = A[e];
-        scr[16 * LANES] = 0.f; scr[17 * LANES] = 0.f; scr[18 * LANES] = 0.f; scr[19 * LANES] = 1.f;
-        solved = elim_general<4>(scr, scr + 16 * LANES);
+                for (int e = 0; e < 16; ++e) scr[e * LANES] = A[e];
+                scr[16 * LANES] = 0.f; scr[17 * LANES] = 0.f; scr[18 * LANES] = 0.f; scr[19 * LANES] = 1.f;
+                solved = elim_general<4>(scr, scr + 16 * LANES);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = scr[(16 + e) * LANES];
+                for (int e = 0; e < 4; ++e) x[e] = scr[(16 + e) * LANES];
+            }
     } else solved = true;
     int i;
     bool longest = false;
@@ -354,11 +370,15 @@ __device__ __forceinline__ float nearest_proj_general(const float *p, float *coe
     if (!edge_regular(gjj, gjk, gkk, ej, ek, lam)) {
         const float gkj = i0 ? G[7] : (i1 ? G[2] : G[3]);                   // G[3 k + j] (the same bits; kept as the reference writes it)
         const float A[9] = {gjj, gjk, 1.f, gkj, gkk, 1.f, 1.f, 1.f, 0.f};
+        const int turn = general_round();
+        for (int round = 0; round < 64 / LANES; ++round)
+            if (round == turn) {
 #pragma unroll
-        for (int e = 0; e < 9; ++e) scr[e * LANES] = A[e];
-        scr[16 * LANES] = 0.f; scr[17 * LANES] = 0.f; scr[18 * LANES] = 1.f;
-        ok3 = elim_general<3>(scr, scr + 16 * LANES);
-        ej = scr[16 * LANES]; ek = scr[17 * LANES]; lam = scr[18 * LANES];
+                for (int e = 0; e < 9; ++e) scr[e * LANES] = A[e];
+                scr[16 * LANES] = 0.f; scr[17 * LANES] = 0.f; scr[18 * LANES] = 1.f;
+                ok3 = elim_general<3>(scr, scr + 16 * LANES);
+                ej = scr[16 * LANES]; ek = scr[17 * LANES]; lam = scr[18 * LANES];
+            }
     }
     float cj, ck, dist;
     if (longest && !ok3) { cj = .5f; ck = .5f; dist = op_div(op_add(gjj, gkk), 2.f); }       // kernel.cu:53-58

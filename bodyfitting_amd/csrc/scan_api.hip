@@ -138,15 +138,24 @@ int bf_scan_create(int device, int n_verts, const float *verts, int n_faces, con
 void bf_scan_destroy(bf_scan *s) {
     if (!s) return;
     // the scan's blocks go back to the cache without the device-wide wait a hipFree implies; a scan that a batch still holds may
-    // be in use by queued work: wait for the device then, as hipFree would have
-    // ... and those batches forget ALL their scans (the same state as bf_batch_set_scans(b, NULL)): a later fit runs without the
-    // closest-point loss instead of reading freed grids, and bf_batch_set_scans / bf_batch_destroy never touch this pointer again
+    // be in use by queued work: wait for the device then, as hipFree would have - BEFORE the links' lock is taken (other threads'
+    // bf_batch_set_scans / bf_batch_destroy do not queue up behind a device-wide wait)
+    // ... and those batches forget ALL their scans and are marked `scans_lost`: their next bf_fit / bf_fit_displacement FAILS
+    // (BF_ERR_INVALID) until bf_batch_set_scans is called again - with NULL to go on without scans.  (Rounds 4-5 let the fit run
+    // silently without the closest-point loss: a lifetime bug in the caller - Python's GC closing a Scan early - then showed up as
+    // quietly different results.)  bf_batch_set_scans / bf_batch_destroy never touch this pointer again.
+    bool held;
+    { std::lock_guard<std::mutex> lk(bf_scan_links()); held = !s->holders.empty(); }
+    if (held) {
+        (void)hipSetDevice(s->device);
+        (void)hipDeviceSynchronize();
+    }
     {
         std::lock_guard<std::mutex> lk(bf_scan_links());
-        if (!s->holders.empty()) {
-            (void)hipSetDevice(s->device);
-            (void)hipDeviceSynchronize();
-            while (!s->holders.empty()) bf_batch_unlink_scans(s->holders.back());
+        while (!s->holders.empty()) {
+            bf_batch *b = s->holders.back();
+            bf_batch_unlink_scans(b);
+            b->scans_lost = true;
         }
     }
     delete s;
@@ -365,6 +374,7 @@ int bf_batch_set_scans(bf_batch *b, bf_scan *const *scans) {
     if (!b) return fail(BF_ERR_INVALID, "bf_batch_set_scans: null batch");
     HIP_TRY(hipSetDevice(b->m->device));
     { int rs_ = bf_sync_all(b); if (rs_) return rs_; }
+    b->scans_lost = false;                         // (either way the caller has said what this batch's scans are now)
     if (!scans) {                                  // detach
         std::lock_guard<std::mutex> lk(bf_scan_links());
         bf_batch_unlink_scans(b);
@@ -520,6 +530,7 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         if (sub) { mp.K.nv = nv; mp.K.sstride = 1; }
     }
     const bool kp_aside = kp && !masks && scans && b->copy_stream;       // (see below)
+    const bool kp_door = kp_aside && door && b->kp_door_ok;              // the join of the second stream's keypoint workgroups: doorbell or event
     bool forked = false;                                                  // ev_aux[0] completes with the mesh dispatch itself
     if (kp_aside && !b->ev_aux[0]) {
         HIP_TRY(hipEventCreateWithFlags(&b->ev_aux[0], hipEventDisableTiming));
@@ -545,9 +556,12 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         HIP_TRY(hipStreamWaitEvent(b->copy_stream, b->ev_aux[0], 0));
         // (the join: with the resident launch's doorbells at hand the keypoint workgroups count themselves off there and
         //  bf_pc_grad_kernel waits for the count - BF_DOOR_KP; without them an event on the second stream and a wait on this one)
-        rc = launch_kp(b, h, sub, b->copy_stream, door);
+        //  The doorbell join needs the second stream's kernels to RUN while bf_pc_grad_kernel's workgroups spin on the batch stream: it is
+        //  used only when ensure_fit_stream's second probe has shown that pair of streams side by side (kp_door_ok; BF_KP_JOIN=event
+        //  forces the stream-level join) - the event join cannot fail that way.
+        rc = launch_kp(b, h, sub, b->copy_stream, kp_door ? door : nullptr);
         if (rc) return rc;
-        if (door) b->kp_tickets += F;
+        if (kp_door) b->kp_tickets += F;
         else HIP_TRY(hipEventRecord(b->ev_aux[1], b->copy_stream));
     } else if (kp && !masks) { rc = launch_kp(b, h, sub); if (rc) return rc; }
     // with a scan as well, bf_pc_grad_kernel adds onto (keypoints + silhouette): keep that order of additions
@@ -562,10 +576,10 @@ static int dense_pass(bf_batch *b, const bf_hyper &h, const HyperDev &hd, bool l
         HIP_TRY(mark(3));                     // [2,3] closest-point search
         hipLaunchKernelGGL(bf_pc_partial_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, b->pc_partial.p);
-        if (kp_aside && !door) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_aux[1], 0));
+        if (kp_aside && !kp_door) HIP_TRY(hipStreamWaitEvent(b->stream, b->ev_aux[1], 0));
         hipLaunchKernelGGL(bf_pc_grad_kernel, dim3(nblk, F), dim3(256), 0, b->stream, (const float *)b->vout.p,
                            (const float *)b->cpts.p, nv, (const float *)b->pc_partial.p, (const float *)b->pc_weight.p,
-                           b->dvout.p, b->pc_loss.p, (kp || masks) ? 1 : 0, (kp_aside && door) ? door : (int *)nullptr, b->kp_tickets);
+                           b->dvout.p, b->pc_loss.p, (kp || masks) ? 1 : 0, kp_door ? door : (int *)nullptr, b->kp_tickets);
     }
     if (!scans) HIP_TRY(mark(3));
     HIP_TRY(mark(4));                         // [3,4] point-cloud loss + gradient (+ the join with the keypoint workgroups of the second stream)
@@ -645,6 +659,22 @@ static int ensure_fit_stream(bf_batch *b, const FrameIO &io, const HyperDev &hd)
     int verdict = 0;
     HIP_TRY(hipMemcpy(&verdict, b->door.p + BF_DOOR_TICKET, sizeof(int), hipMemcpyDeviceToHost));
     b->door_usable = verdict == 1;
+    // the same question for the pair (batch stream, second stream): config 5's keypoint workgroups run on the second stream and are
+    // joined by a doorbell that bf_pc_grad_kernel's workgroups wait on (BF_DOOR_KP) - only if that stream's kernels run beside them
+    b->kp_door_ok = false;
+    const char *kj = getenv("BF_KP_JOIN");
+    if (b->door_usable && b->copy_stream && !(kj && kj[0] == 'e')) {
+        HIP_TRY(hipStreamSynchronize(b->copy_stream));
+        HIP_TRY(bf_memset_sync(b->door.p, 0, BF_DOOR_STATE * sizeof(int)));
+        hipLaunchKernelGGL(bf_door_probe_kernel, dim3(1), dim3(64), 0, b->stream, b->door.p);
+        hipLaunchKernelGGL(bf_door_ring_kernel, dim3(1), dim3(64), 0, b->copy_stream, b->door.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        HIP_TRY(hipStreamSynchronize(b->copy_stream));
+        int v2 = 0;
+        HIP_TRY(hipMemcpy(&v2, b->door.p + BF_DOOR_TICKET, sizeof(int), hipMemcpyDeviceToHost));
+        b->kp_door_ok = v2 == 1;
+    }
     if (!b->door_usable) {
         // said once per process: the dense loops still give the same results, about three times slower (one fit launch per iteration)
         static std::atomic<bool> told{false};
@@ -1122,6 +1152,8 @@ int bf_batch_mask_loss(bf_batch *b, const bf_hyper *hyper, float *loss, float *d
 int bf_fit_displacement(bf_batch *b, int n_iters, const bf_hyper *hyper) {
     if (!b || n_iters <= 0) return fail(BF_ERR_INVALID, "bf_fit_displacement: bad argument");
     bf_model *m = b->m;
+    if (b->scans_lost)
+        return fail(BF_ERR_INVALID, "bf_fit_displacement: a scan this batch held was destroyed (bf_scan_destroy) - call bf_batch_set_scans again");
     if (b->scans.empty()) return fail(BF_ERR_INVALID, "bf_fit_displacement: no scans attached (bf_batch_set_scans)");
     if (!b->have_result) return fail(BF_ERR_INVALID, "bf_fit_displacement: run bf_fit first (the stage starts from its vertices)");
     if (m->faces_host.empty()) return fail(BF_ERR_INVALID, "bf_fit_displacement: the model was created without faces");

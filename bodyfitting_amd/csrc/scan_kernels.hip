@@ -155,6 +155,16 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
     const size_t o = (size_t)f * n + id;
     const float *q = points + o * 3;
     const float qx = q[0], qy = q[1], qz = q[2];
+    // The query is wave-uniform and lives in scalar registers - and a vector instruction with a scalar operand issues at 4 cycles per
+    // SIMD where the same instruction on vector registers issues at 2 beside the other waves' work (profiles/r06_issue_rate.md).
+    // -DBF_NN_QVGPR subtracts it from a copy in vector registers in the per-lane arithmetic (box distances, the screen, the rule's
+    // corners; what steers the walk stays scalar): 37 fewer slow-pipe instructions of 524 in the ISA - and 3 more registers, 82, one
+    // more than six waves per SIMD allow.  Measured round 6, same box, exact hints / hints moved 5 mm: off 109.4 / 139.0 us, on at five
+    // waves 119.1 / 152.4, on and held to 80 registers 114.8 / 147.1, on with two screen passes per trip (73 registers) 111.6 / 140.4.  Off.
+    float qvx = qx, qvy = qy, qvz = qz;
+#ifdef BF_NN_QVGPR
+    asm volatile("" : "+v"(qvx), "+v"(qvy), "+v"(qvz));
+#endif
     int cx = (int)floorf((qx - S.ox) / S.step), cy = (int)floorf((qy - S.oy) / S.step), cz = (int)floorf((qz - S.oz) / S.step);
     cx = min(max(cx, 0), S.nx - 1); cy = min(max(cy, 0), S.ny - 1); cz = min(max(cz, 0), S.nz - 1);
     // the reference's shell limit (mesh_grid_kernel.cu:254-257, 262): per axis x > size - x ? x : size - x, shells L < that - on the
@@ -190,9 +200,9 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
             st = S.cell_start[cell];
             cnt = S.cell_start[cell + 1] - st;
             float lo, e;
-            lo = S.ox + S.step * x; e = qx < lo ? lo - qx : (qx > lo + S.step ? qx - lo - S.step : 0.f); d2 += e * e;
-            lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); d2 += e * e;
-            lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); d2 += e * e;
+            lo = S.ox + S.step * x; e = qvx < lo ? lo - qvx : (qvx > lo + S.step ? qvx - lo - S.step : 0.f); d2 += e * e;
+            lo = S.oy + S.step * y; e = qvy < lo ? lo - qvy : (qvy > lo + S.step ? qvy - lo - S.step : 0.f); d2 += e * e;
+            lo = S.oz + S.step * z; e = qvz < lo ? lo - qvz : (qvz > lo + S.step ? qvz - lo - S.step : 0.f); d2 += e * e;
         }
         cell_ok = cell_ok && cnt > 0;
     }
@@ -233,9 +243,9 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
                 st = 0; cnt = 0;
                 if (use) {
                     float lo, e, dd = 0.f;
-                    lo = S.ox + S.step * x; e = qx < lo ? lo - qx : (qx > lo + S.step ? qx - lo - S.step : 0.f); dd += e * e;
-                    lo = S.oy + S.step * y; e = qy < lo ? lo - qy : (qy > lo + S.step ? qy - lo - S.step : 0.f); dd += e * e;
-                    lo = S.oz + S.step * z; e = qz < lo ? lo - qz : (qz > lo + S.step ? qz - lo - S.step : 0.f); dd += e * e;
+                    lo = S.ox + S.step * x; e = qvx < lo ? lo - qvx : (qvx > lo + S.step ? qvx - lo - S.step : 0.f); dd += e * e;
+                    lo = S.oy + S.step * y; e = qvy < lo ? lo - qvy : (qvy > lo + S.step ? qvy - lo - S.step : 0.f); dd += e * e;
+                    lo = S.oz + S.step * z; e = qvz < lo ? lo - qvz : (qvz > lo + S.step ? qvz - lo - S.step : 0.f); dd += e * e;
                     use = !(B < dd);
                     if (use) {
                         const int cell = (x * S.ny + y) * S.nz + z;
@@ -294,7 +304,7 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
 #pragma unroll
                         for (int k = 0; k < PASSES; ++k)
                             if (k < npass) {
-                                const float lx = lo[k].x - qx, ly = lo[k].y - qy, lz = lo[k].z - qz, hx = hi[k].x - qx, hy = hi[k].y - qy, hz = hi[k].z - qz;
+                                const float lx = lo[k].x - qvx, ly = lo[k].y - qvy, lz = lo[k].z - qvz, hx = hi[k].x - qvx, hy = hi[k].y - qvy, hz = hi[k].z - qvz;
                                 const float ex = fmaxf(fmaxf(lx, -hx), 0.f), ey = fmaxf(fmaxf(ly, -hy), 0.f), ez = fmaxf(fmaxf(lz, -hz), 0.f);
                                 const float lb2 = ex * ex + ey * ey + ez * ez;
                                 const bool pass = rec[k] >= 0 && !(lb2 * 0.998f - lo[k].w > B);
@@ -313,7 +323,7 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
                             const int rq = queue[lane];
                             const size_t r = (size_t)rq * 3;
                             const float4 q0 = S.cell_pack[r], q1 = S.cell_pack[r + 1], q2 = S.cell_pack[r + 2];
-                            const float p[9] = {q0.x - qx, q0.y - qy, q0.z - qz, q0.w - qx, q1.x - qy, q1.y - qz, q1.z - qx, q1.w - qy, q2.x - qz};
+                            const float p[9] = {q0.x - qvx, q0.y - qvy, q0.z - qvz, q0.w - qvx, q1.x - qvy, q1.y - qvz, q1.z - qvx, q1.w - qvy, q2.x - qvz};
                             const int t = __float_as_int(q2.y);
                             float co[3];
                             float dist;
@@ -410,10 +420,15 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
     __shared__ float s_general[RULE == BF_NEAREST_REFERENCE ? NN_WAVES * 20 * nrule::LANES : 1];                                                \
     __shared__ int s_queue[NN_WAVES * NN_QCAP];                                                                                                 \
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   /* (told to the compiler as the wave-uniform value it is: the walk's bookkeeping then lives in scalar registers) */ \
-    float *scr = s_general + (RULE == BF_NEAREST_REFERENCE ? wave * 20 * nrule::LANES + (threadIdx.x & 63) : 0);                          \
+    float *scr = s_general + (RULE == BF_NEAREST_REFERENCE ? wave * 20 * nrule::LANES + (threadIdx.x & 63) % nrule::LANES : 0);                          \
     int *queue = s_queue + wave * NN_QCAP;
 
-extern "C" __global__ void __launch_bounds__(64 * NN_WAVES)
+#ifdef BF_NN_WPE
+#define NN_OCC __attribute__((amdgpu_waves_per_eu(BF_NN_WPE, BF_NN_WPE)))
+#else
+#define NN_OCC
+#endif
+extern "C" __global__ void __launch_bounds__(64 * NN_WAVES) NN_OCC
 bf_nearest_kernel(const ScanDev *__restrict__ scans, const float *__restrict__ points, int n,
                   int *face, float *pts, float *__restrict__ bary, int warm, int n_frames) {
     NN_WAVE_LDS(BF_NEAREST_REFERENCE)
@@ -444,7 +459,7 @@ extern "C" __global__ void bf_nearest_rule_kernel(int n, const float *__restrict
     float p[9], c[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 9; ++k) p[k] = patches[(size_t)i * 9 + k];
-    dist[i] = general ? nrule::nearest_proj_general(p, c, s_general + threadIdx.x) : nrule::nearest_proj_regular(p, c);
+    dist[i] = general ? nrule::nearest_proj_general(p, c, s_general + threadIdx.x % nrule::LANES) : nrule::nearest_proj_regular(p, c);
     coeff[i * 3] = c[0]; coeff[i * 3 + 1] = c[1]; coeff[i * 3 + 2] = c[2];
 }
 

@@ -179,9 +179,18 @@ class SMPLify:
         batch.set_cameras(c2w, K)
         batch._cams = None
         nl = self._dev.n_loss_joints
-        if mask_frames is None:
-            raise ValueError("stream(): mask_frames=None - name the views the frames' masks belong to (default [0], like __call__)")
-        mk_idx = [list(use_frames if use_frames is not None else range(V)).index(f) for f in mask_frames]
+        # (the reference looks a mask view up in use_frames only when use_mask is on, smplify.py:141: a keypoint-only or scan-only
+        #  stream whose use_frames does not hold view 0 - or that passes mask_frames=None / [] - is fine; the lookup happens at the
+        #  first frame that carries masks)
+        _mk_idx = []
+
+        def mk_index():
+            if not _mk_idx:
+                if not mask_frames:
+                    raise ValueError("stream(): a frame carries masks but mask_frames is empty - name the views they belong to (default [0], like __call__)")
+                views = list(use_frames if use_frames is not None else range(V))
+                _mk_idx.append([views.index(f) for f in mask_frames])
+            return _mk_idx[0]
 
         def pack(keypoints):
             kp = np.zeros((1, V, nl, 3), np.float32)
@@ -249,7 +258,7 @@ class SMPLify:
                 mk = None if masks is None else np.stack([np.asarray(m) for m in masks]).astype(np.uint8)[None]
                 staged = False
                 if mk is not None and in_flight is not None and batch._had_masks and mask_shape == mk.shape:
-                    batch.stage_masks(mk, mk_idx)      # (binarised, uploaded and border-followed under the previous frame's fit)
+                    batch.stage_masks(mk, mk_index())      # (binarised, uploaded and border-followed under the previous frame's fit)
                     staged = True
                 if in_flight is not None:
                     yield collect(in_flight)
@@ -259,7 +268,7 @@ class SMPLify:
                 if staged:
                     pass
                 elif mk is not None:
-                    batch.set_masks(mk, mk_idx, None); batch._had_masks = True
+                    batch.set_masks(mk, mk_index(), None); batch._had_masks = True
                     mask_shape = mk.shape
                 elif batch._had_masks:
                     batch.clear_masks(); batch._had_masks = False

@@ -208,8 +208,9 @@ int bf_batch_export_params_dev(bf_batch *b, void *dst_dev);
  * MeshGridSearcher(verts, faces) (utils/mesh_grid_searcher.py:51-79 -> insert_grid_surface,
  * thirdparty/mesh_grid/mesh_grid.cpp:31-52): verts[n_verts,3], faces[n_faces,3] int32. */
 /* ORDER OF DESTRUCTION: a scan may be destroyed while batches still hold it (bf_batch_set_scans): bf_scan_destroy then waits for
- * the device and DETACHES every scan from those batches - the state bf_batch_set_scans(b, NULL) leaves: a later bf_fit runs
- * without the closest-point loss, bf_fit_displacement reports "no scans attached" - and a batch may be destroyed before its scans.
+ * the device and DETACHES every scan from those batches, which are marked: their next bf_fit / bf_fit_displacement returns
+ * BF_ERR_INVALID ("a scan this batch held was destroyed") until bf_batch_set_scans is called again - with NULL to go on without
+ * scans (rounds 4-5 let the fit run silently without the closest-point loss).  A batch may be destroyed before its scans.
  * Not thread-safe against a bf_fit / bf_batch_set_scans of a holding batch running at the same moment on another thread.
  * bf_scan_create builds the grid on the NULL stream and waits for that stream only (the library's streams are non-blocking):
  * a fit in flight on a batch's stream keeps running. */

@@ -374,10 +374,37 @@ def smplx_goldens():
         print(tag, "done")
 
 
-def _nudge(problem):
-    """the same problem with every entry of the initial pose moved to the next float32 (1 ulp)"""
+# Perturbations that change no mathematics: (tag, torch intra-op threads, what is moved by one float32 ulp).  tests/ref_drift.py builds
+# the parity bands of the round-off-amplifying loops from how far the IMPORTED reference moves from itself under them.  The first two
+# are the ones of rounds 3-5 (their keys in the committed files are unchanged); round 6 added the other eight - a band built on two
+# draws of a chaotic system was weak in both directions.
+PERTURBATIONS = (("threads8", 8, None), ("ulp", 1, "pose+"), ("threads2", 2, None), ("threads4", 4, None), ("ulp_down", 1, "pose-"),
+                 ("ulp_kp", 1, "kp+"), ("ulp_cam", 1, "cam+"), ("ulp_ext", 1, "ext+"), ("t4_ulp_down", 4, "pose-"), ("t2_ulp_kp", 2, "kp+"))
+NEW_PERTURBATIONS = PERTURBATIONS[2:]
+
+
+def _ulp(a, up=True):
+    a = np.asarray(a)
+    return np.nextafter(a.astype(np.float32), np.float32(np.inf if up else -np.inf)).astype(a.dtype)
+
+
+def _nudge(problem, what="pose+"):
+    """the same problem with every entry of one input moved to the next float32 (1 ulp): the initial pose (up / down), the keypoints'
+    pixel coordinates, the intrinsics, or the camera-to-world matrices; None: the problem itself"""
+    if what is None:
+        return problem
     q = dict(problem)
-    q["init_pose"] = np.nextafter(problem["init_pose"].astype(np.float32), np.float32(np.inf)).astype(np.float32)
+    if what in ("pose+", "pose-"):
+        q["init_pose"] = _ulp(problem["init_pose"], what == "pose+")
+    elif what == "ext+":
+        q["c2ws"] = [_ulp(c) for c in problem["c2ws"]]
+    elif what == "kp+":
+        q["keypoints"] = [{k: np.concatenate([_ulp(v[:, :2]), v[:, 2:]], axis=1) for k, v in d.items()} if isinstance(d, dict) else d
+                          for d in problem["keypoints"]]
+    elif what == "cam+":
+        q["Ks"] = [_ulp(K) for K in problem["Ks"]]
+    else:
+        raise ValueError(what)
     return q
 
 
@@ -397,9 +424,9 @@ def sensitivity_cfg2_goldens():
     out = {}
     for frame in (0, 1, 2, 3):
         base = S.make_problem(model, frame=frame, n_views=48)
-        for tag, threads, nudge in (("threads8", 8, False), ("ulp", 1, True)):
+        for tag, threads, what in PERTURBATIONS:
             torch.set_num_threads(threads)
-            res, snaps, _ = run_reference_fit(_nudge(base) if nudge else base, 100, snapshots=(100,))
+            res, snaps, _ = run_reference_fit(_nudge(base, what), 100, snapshots=(100,))
             out[f"{tag}_f{frame}_final_global_transl"] = res["global_transl"]
             out[f"{tag}_f{frame}_joints"] = res["joints"]
             out.update({f"{tag}_f{frame}_{k}": v for k, v in flat_snaps(snaps).items()})
@@ -417,7 +444,7 @@ def sensitivity_scan_goldens():
     from bodyfitting_amd import synthetic as S
     from bodyfitting_amd.io import save_obj_mesh
 
-    variants = (("threads8", 8, False, False), ("ulp", 1, True, False), ("fused", 1, False, True))
+    variants = tuple((tag, threads, what, False) for tag, threads, what in PERTURBATIONS) + (("fused", 1, None, True),)
     gmm = S.make_gmm(seed=0)
     # ---- scan loop 300 + SMPL+D 300 on the reduced model (scan_goldens_long) -----------------------------------------
     model = S.make_model("smpl", seed=0, nv=690)
@@ -429,10 +456,10 @@ def sensitivity_scan_goldens():
     meshfile = os.path.join(tmp, "scan.obj")
     save_obj_mesh(meshfile, sv, sf)
     out = {}
-    for tag, threads, nudge, fused in variants:
+    for tag, threads, what, fused in variants:
         torch.set_num_threads(threads)
         StandInMeshGridSearcher.FUSED = fused
-        prob = _nudge(base) if nudge else base
+        prob = _nudge(base, what)
         res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 300, snapshots=(100, 101, 300), displacement=True)
         out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
         out[f"{tag}_vertices"], out[f"{tag}_joints"], out[f"{tag}_displacement"] = res["vertices"], res["joints"], res["displacement"]
@@ -440,10 +467,10 @@ def sensitivity_scan_goldens():
     np.savez_compressed(os.path.join(GOLDEN, "sens_scan_nv690_300it.npz"), model_digest=S.model_digest(model), **out)
     print("sensitivity: scan loop done")
     out = {}
-    for tag, threads, nudge, fused in variants:       # the 30 + 30-iteration run of scan_goldens, with its displacement snapshots
+    for tag, threads, what, fused in variants:       # the 30 + 30-iteration run of scan_goldens, with its displacement snapshots
         torch.set_num_threads(threads)
         StandInMeshGridSearcher.FUSED = fused
-        prob = _nudge(base) if nudge else base
+        prob = _nudge(base, what)
         res, snaps, dsn = run_reference_scan_fit(prob, meshfile, 30, snapshots=(1, 11, 12, 20, 30), displacement=True)
         out.update({f"{tag}_{k}": v for k, v in flat_snaps(snaps).items()})
         out.update({f"{tag}_disp{k}": v for k, v in dsn.items()})
@@ -465,7 +492,7 @@ def sensitivity_goldens():
     from bodyfitting_amd import synthetic as S
     from bodyfitting_amd.io import save_obj_mesh
 
-    variants = (("threads8", 8, False), ("ulp", 1, True))
+    variants = PERTURBATIONS
     gmm = S.make_gmm(seed=0)
 
     def capture(names, want, run):
@@ -501,9 +528,9 @@ def sensitivity_goldens():
     mask_frames = [1, 3, 5, 7]
     base = S.make_problem(model, frame=0, n_views=8, mask_frames=mask_frames)
     out = {}
-    for tag, threads, nudge in variants:
+    for tag, threads, what in variants:
         torch.set_num_threads(threads)
-        prob = _nudge(base) if nudge else base
+        prob = _nudge(base, what)
         fitter = SMPLify(smpl_type="smpl", num_iters=30, gender="neutral", device=torch.device("cpu"), debug=False)
         res, snaps = capture(smpl_names, (1, 11, 12, 20, 30), lambda: fitter(
             (torch.from_numpy(prob["init_betas"].copy()), torch.from_numpy(prob["init_pose"].copy())), prob["c2ws"], prob["Ks"],
@@ -527,9 +554,9 @@ def sensitivity_goldens():
     os.chdir(tmp)
     base = S.make_problem_smplx(model, frame=0, n_views=8, mask_frames=mask_frames)
     out = {}
-    for tag, threads, nudge in variants:
+    for tag, threads, what in variants:
         torch.set_num_threads(threads)
-        prob = _nudge(base) if nudge else base
+        prob = _nudge(base, what)
         fitter = SMPLify(smpl_type="smplx", num_iters=15, gender="neutral", device=torch.device("cpu"), debug=False)
         res, snaps = capture(smplx_names, (1, 2, 6, 10, 15), lambda: fitter(
             (torch.from_numpy(prob["init_betas"].copy()), torch.from_numpy(prob["init_pose"].copy())), prob["c2ws"], prob["Ks"],
@@ -542,7 +569,7 @@ def sensitivity_goldens():
     print("sensitivity: smplx mask loop done")
 
 
-def cfg3_goldens(variants=(("base", 1, False), ("threads8", 8, False), ("ulp", 1, True))):
+def cfg3_goldens(variants=(("base", 1, None),) + PERTURBATIONS):
     """BASELINE config 3 AS STATED, run by the imported reference: SMPL-X (10,475 vertices, 55 joints, 135 output joints),
     48 views with body + hands + face keypoints, 8 silhouette views at 512 x 512, 200 iterations (the silhouette loss is active
     for i > 66, smplify.py:197).  Snapshots of the optimised parameters after iterations 1 / 66 / 67 / 68 / 200 and the loss values
@@ -567,9 +594,9 @@ def cfg3_goldens(variants=(("base", 1, False), ("threads8", 8, False), ("ulp", 1
     mask_frames = list(range(0, 48, 6))
     base = S.make_problem_smplx(model, frame=0, n_views=48, mask_frames=mask_frames)
     want = (1, 66, 67, 68, 200)
-    for tag, threads, nudge in variants:
+    for tag, threads, what in variants:
         torch.set_num_threads(threads)
-        prob = _nudge(base) if nudge else base
+        prob = _nudge(base, what)
         snaps, losses, counter = {}, {}, {"n": 0}
         orig_step, orig_kp, orig_mask = torch.optim.Adam.step, RS.multiview_keypoint_loss, RS.multview_mask_loss
 
@@ -806,6 +833,9 @@ if __name__ == "__main__":
     elif "--cfg3-only" in sys.argv:
         install_reference_imports()
         cfg3_goldens()
+    elif "--cfg3-new-only" in sys.argv:                      # only the perturbations round 6 added (the other files stay as committed)
+        install_reference_imports()
+        cfg3_goldens(variants=NEW_PERTURBATIONS)
     elif "--timing-only" in sys.argv:
         install_reference_imports()
         reference_timing()

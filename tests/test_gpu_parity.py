@@ -554,4 +554,16 @@ def test_smplify_stream_yields_the_frames_of_the_call_path(smpl_model, gmm):
     b = fitter((p["init_betas"], p["init_pose"]), p["c2ws"], p["Ks"], p["keypoints"], use_frames=p["use_frames"], imsize=512)
     assert not np.array_equal(a["pose"], b["pose"])
     assert np.array_equal(b["pose"], streamed[0]["pose"])
+    # a keypoint-only stream never looks its mask views up (smplify.py:141 does so only under use_mask): use_frames without view 0, and
+    # mask_frames None / [] as older callers pass them, are fine; a frame WITH masks and no mask_frames is the error
+    sub = [1, 7, 13]
+    p = probs[1]
+    args = ([p["c2ws"][i] for i in sub], [p["Ks"][i] for i in sub])
+    kps = [p["keypoints"][i] for i in sub]
+    for mf in ((0,), None, []):
+        got = list(fitter.stream([((p["init_betas"], p["init_pose"]), kps)], *args, use_frames=sub, mask_frames=mf))
+        one = fitter((p["init_betas"], p["init_pose"]), *args, kps, use_frames=sub, imsize=512)
+        assert len(got) == 1 and np.array_equal(got[0]["pose"], one["pose"])
+    with pytest.raises(ValueError):
+        list(fitter.stream([((p["init_betas"], p["init_pose"]), kps, [np.zeros((64, 64), np.uint8)] * 1)], *args, use_frames=sub, mask_frames=None))
     fitter.close()

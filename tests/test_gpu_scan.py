@@ -636,9 +636,10 @@ def test_displacement_stage_first_steps(small, gmm_bufs):
 
 
 def test_scan_and_batch_may_be_destroyed_in_any_order(small):
-    """bodyfit.h "ORDER OF DESTRUCTION": a scan destroyed while a batch still holds it detaches that batch's scans (the later
-    fit then equals a fit that never had scans, bit for bit; the SMPL+D stage reports that nothing is attached), re-attaching and
-    detaching afterwards never touch the freed scan, and a batch may go before its scans."""
+    """bodyfit.h "ORDER OF DESTRUCTION": a scan destroyed while a batch still holds it detaches that batch's scans and the batch's
+    next fit FAILS until bf_batch_set_scans is called again (with None: the fit then equals a fit that never had scans, bit for
+    bit; the SMPL+D stage reports that nothing is attached); re-attaching and detaching afterwards never touch the freed scan, and
+    a batch may go before its scans."""
     from bodyfitting_amd import _lib
     model, dev = small
     items = [S.make_scan_problem(model, frame=f, n_views=8) for f in (0, 1)]
@@ -658,11 +659,16 @@ def test_scan_and_batch_may_be_destroyed_in_any_order(small):
     b.fit(3)                                   # queued work that reads the scans
     scans[0].close()                           # destroy-then-detach: waits for the device, detaches BOTH frames' scans
     b.reset()
+    with pytest.raises(_lib.BodyfitError, match="was destroyed"):      # ... and the batch says so instead of fitting without them
+        b.fit(12)
+    with pytest.raises(_lib.BodyfitError, match="was destroyed"):
+        b.fit_displacement(2)
+    b.set_scans(None)                          # detach after the destroy: nothing to touch; the batch goes on without scans
+    b.reset()
     b.fit(12)
     np.testing.assert_array_equal(b.get_params(), want)
     with pytest.raises(_lib.BodyfitError, match="no scans attached"):
         b.fit_displacement(2)
-    b.set_scans(None)                          # detach after the destroy: nothing to touch
     fresh = N.Scan(items[0][1], items[0][2])
     b.set_scans([fresh, scans[1]])             # replace after the destroy
     b.fit(2)

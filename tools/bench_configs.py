@@ -21,8 +21,8 @@ BYTES_SMPLX_FWD = 61_090_200 + 2_514_000 + 2_304_500 + 2_304_500 + 125_700      
 BYTES_CFG3_MASK = 15_270_000                                                       # + the sampled vertices' posedirs columns when the silhouette loss is on
 BYTES_CFG5_ITER = 136_600_000                                                      # forward + full reverse pass
 HBM_PEAK_GBS = 8000.0
-# bf_nearest_kernel (reference rule): VALU instructions per query-wave from the PMC pass of profiles/r04_rocprof_summary.md
-# (SQ_INSTS_VALU / queries; the kernel is unchanged since).  1,024 SIMDs issue one wave64 VALU instruction per 4 cycles at 2.4 GHz.
+# bf_nearest_kernel (reference rule): VALU instructions per query-wave from the PMC pass of profiles/r05_rocprof_summary.md, re-measured
+# in round 6 (SQ_INSTS_VALU / queries; profiles/r06_rocprof_summary.md).  1,024 SIMDs issue one wave64 VALU instruction per 4 cycles at 2.4 GHz.
 NEAREST_VALU_PER_QUERY = 894
 SIMD_VALU_PER_S = 1024 * 2.4e9 / 4
 

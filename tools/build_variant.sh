@@ -1,19 +1,19 @@
 #!/bin/bash
-# build libbodyfit_V_<tag>.so from a patched copy of fit_kernels.hip.  usage: tools/build_variant.sh <tag> <python-patch-file>
-# the patch file defines patch(s) -> s on the source text.
+# build bodyfitting_amd/libbodyfit_V_<tag>.so from a patched copy of ONE kernel source, with the product's own flags for that file
+# (the Makefile's `variant` target: nothing is duplicated here).   usage: tools/build_variant.sh <tag> <python-patch-file> [source-stem]
+# The patch file defines patch(s) -> s on the source text; source-stem defaults to fit_kernels.  The build fails on any warning.
 set -e
-TAG=$1; PATCH=$2
-cd /root/repo/bodyfitting_amd/csrc
-python3 - "$PATCH" <<'PY'
+TAG=$1; PATCH=$2; STEM=${3:-fit_kernels}
+ROOT=${GRAFT_REPO_ROOT:-$(git -C "$(dirname "$0")" rev-parse --show-toplevel)}
+cd "$ROOT/bodyfitting_amd/csrc"
+python3 - "$PATCH" "$STEM" <<'PY'
 import sys, importlib.util
 spec = importlib.util.spec_from_file_location("p", sys.argv[1]); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-s = open("fit_kernels.hip").read()
+s = open(sys.argv[2] + ".hip").read()
 t = m.patch(s)
 assert t != s, "patch did not change the source"
-open("_variant.hip", "w").write(t)
+open("_variant_" + sys.argv[2] + ".hip", "w").write(t)
 PY
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -ffp-contract=on -mllvm -amdgpu-sched-strategy=max-ilp -c _variant.hip -o _variant.o 2>&1 | grep -E "error|Illegal|warning" && { echo "BUILD FAILED $TAG"; rm -f _variant.hip _variant.o; exit 1; }
-OBJ=$(ls *.o | grep -v "fit_kernels.o\|_variant.o\|stamp" | tr '\n' ' ')
-/opt/rocm/bin/hipcc -shared --offload-arch=gfx950 -o ../libbodyfit_V_$TAG.so $OBJ _variant.o -ldl
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=on -mllvm -amdgpu-sched-strategy=max-ilp -Rpass-analysis=kernel-resource-usage -c _variant.hip -o /dev/null 2>&1 | grep -A5 "Function Name: _Z10fit_kernelILi24ELi10ELi11ELi25ELb0" | grep -E "Scratch|VGPRs" | sed 's/.*remark: *//; s/\[-Rpass.*//' | tr '\n' ' '; echo " <- $TAG"
-rm -f _variant.hip _variant.o
+make variant TAG=$TAG VSRC=$STEM VFILE=_variant_$STEM.hip 2>&1 | grep -E "error|Illegal|warning:" && { echo "BUILD FAILED $TAG"; rm -f _variant_$STEM.hip; exit 1; }
+rm -f _variant_$STEM.hip
+echo "built bodyfitting_amd/libbodyfit_V_$TAG.so"
