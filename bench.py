@@ -258,7 +258,7 @@ def pmc_traffic():
 # SURVEY.md 8(d), SMPL-X: posedirs 61,090,200 + shapedirs 2,514,000 + lbs_weights 2,304,500 + J_regressor 2,304,500 + v_template 125,700
 BYTES_SMPLX_FWD = 68_338_900
 BYTES_CFG3_MASK = 15_270_000          # + the every-4th-vertex posedirs columns of the reverse pass while the silhouette loss is active
-BYTES_CFG5_ITER = 136_600_000         # forward + full reverse pass (every vertex carries gradient)
+BYTES_CFG5_ITER = 136_600_000         # forward + full reverse pass (every vertex carries gradient): the iterations with the scan loss on
 
 
 def main_dense(a):
@@ -395,7 +395,15 @@ def main_dense(a):
         per_class = batch.dense_timing(False, read=True)
     except Exception as exc:                                   # (a diagnostic: never take the line down)
         per_class = {"error": repr(exc)}
-    bytes_iter = (BYTES_SMPLX_FWD * iters + BYTES_CFG3_MASK * (iters - iters // 3 - 1)) if cfg == 3 else BYTES_CFG5_ITER * iters
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import bench_configs as BC
+    # SURVEY 8(d) by iteration kind, per frame: config 3 = forward every iteration + the sampled vertices' posedirs columns while the
+    # silhouette is on; config 5 = the keypoint-only forward for i <= iters // 3, forward + full reverse pass after that
+    bytes_iter = (BYTES_SMPLX_FWD * iters + BYTES_CFG3_MASK * (iters - iters // 3 - 1)) if cfg == 3 else BC.cfg5_bytes_per_frame(iters)
+    # counter traffic of one fit (FETCH_SIZE doubled + WRITE_SIZE over the fit's kernels, profiles/pmc_traffic.json "dense"), when the
+    # committed passes were taken at this shard size
+    dense_pmc = ((pmc_traffic() or {}).get("dense") or {}).get(f"cfg{cfg}")
+    traffic = dense_pmc["bytes_per_fit"] if dense_pmc and dense_pmc.get("frames_per_fit") == F and dense_pmc.get("iters") == iters else None
     fit_s = per["fit_s"] * 1e-3
     what = {3: f"{F} frame(s) per GPU per step x {a.views} views (+ 8 silhouettes at 512 x 512), SMPL-X-shaped synthetic model (10,475 v, 55 joints, "
                f"135 output joints, body + hands + face keypoints), keypoint + silhouette loss, {iters} Adam iterations = BASELINE config 3; "
@@ -416,20 +424,19 @@ def main_dense(a):
                                        "ms_per_displacement_iteration": per["disp_s"] / iters if cfg == 5 else None},
            "roofline": {"bound": "hbm", "kernel": "the dense iteration's launch sequence (no single dominant kernel: see profiles/)",
                         "achieved": bytes_iter * F / fit_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": bytes_iter * F / fit_s / 1e9 / HBM_PEAK_GBS,
-                        "traffic": None, "algorithmic_bytes_per_fit": bytes_iter * F,
-                        "note": "nominal SURVEY 8(d) bytes per frame-iteration x iterations x frames over the fit's wall time on rank 0 "
-                                "(the resident fit launch and 5 kernels per iteration; frames of a shard share one model stream)"}}
+                        "traffic": traffic, "algorithmic_bytes_per_fit": bytes_iter * F,
+                        "real_hbm_gbs": traffic / fit_s / 1e9 if traffic else None,
+                        "note": "NOMINAL: SURVEY 8(d) bytes per frame-iteration, by iteration kind, x frames over the fit's wall time on rank 0 - every "
+                                "frame charged its own stream of the model tensors.  `traffic` = memory-side bytes of one fit by counters "
+                                "(profiles/pmc_traffic.json: FETCH_SIZE doubled + WRITE_SIZE, all its kernels): the frames of a shard share ONE "
+                                "stream per launch, so the real rate (`real_hbm_gbs`) is what HBM sees; the configuration is bound by "
+                                + ("its launch chain's latencies" if cfg == 3 else "the closest-point search's instruction issue (`dominant_kernel`)")
+                                + ", not by bytes"}}
     out["device_ms_last_iteration"] = per_class
     out["resident_fit_launch"] = batch.dense_resident()
     if cfg == 5 and per_class and per_class.get("closest_point_search"):
-        sys.path.insert(0, os.path.join(REPO, "tools"))
-        import bench_configs as BC
         nvx, s_search = dev.n_verts, per_class["closest_point_search"] * 1e-3
-        out["dominant_kernel"] = {"name": "bf_nearest_kernel", "bound": "valu_issue", "queries_per_launch": F * nvx,
-                                  "valu_per_query_wave": BC.NEAREST_VALU_PER_QUERY, "ms_per_launch": s_search * 1e3,
-                                  "issue_bound_ms": F * nvx * BC.NEAREST_VALU_PER_QUERY / BC.SIMD_VALU_PER_S * 1e3,
-                                  "frac": F * nvx * BC.NEAREST_VALU_PER_QUERY / BC.SIMD_VALU_PER_S / s_search,
-                                  "note": "queries x VALU instructions per query-wave (PMC, profiles/) / (1,024 SIMDs x 2.4 GHz / 4) / the search's device time"}
+        out["dominant_kernel"] = BC.nearest_dominant(F * nvx, s_search)
     if rank == 0:
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if live["scans"]:

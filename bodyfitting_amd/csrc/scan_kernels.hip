@@ -285,9 +285,14 @@ __device__ __forceinline__ void nearest_body(const ScanDev *__restrict__ scans, 
                             if (k < npass) {                // (wave-uniform; every lane loads: one without an entry reads the group's first record)
                                 const int e = e0 + k * 64 + lane;
                                 int d = base[0];
-#pragma unroll
-                                for (int c = 1; c < 6; ++c)
-                                    if (c < nlists) d = e >= off[c] ? base[c] : d;       // (wave-uniform: most groups are two or three lists)
+                                // (wave-uniform BRANCHES, not selects - round 6: flattened by the compiler, the chain was a compare, two
+                                //  selects and a move for each of the five possible further lists in every pass, whatever the group holds;
+                                //  the empty asm keeps the blocks from being if-converted again.  Same box, exact hints 110.5 -> 107.4 us)
+                                if (nlists > 1) { asm volatile(""); d = e >= off[1] ? base[1] : d;
+                                    if (nlists > 2) { asm volatile(""); d = e >= off[2] ? base[2] : d;
+                                        if (nlists > 3) { asm volatile(""); d = e >= off[3] ? base[3] : d;
+                                            if (nlists > 4) { asm volatile(""); d = e >= off[4] ? base[4] : d;
+                                                if (nlists > 5) { asm volatile(""); d = e >= off[5] ? base[5] : d; } } } } }
                                 rec[k] = e < total ? e + d : -1;
                                 const size_t r = (size_t)(e < total ? e + d : base[0]) * 2;
                                 lo[k] = S.cell_box[r]; hi[k] = S.cell_box[r + 1];

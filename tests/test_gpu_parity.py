@@ -103,17 +103,20 @@ def test_cfg2_fit_matches_reference(dev_model, smpl_model, frame):
     np.testing.assert_allclose(full_pose[0], g["full_pose"], atol=FIT_TOL)
     p = N.split_params(b.get_params()[0])
     # rtn_dict's global_transl = t * s (smplify.py:223), a field of the result: 1e-4 like everything else on the well-conditioned
-    # frames.  Frame 3's translation is the ill-conditioned one of the four: the imported reference itself ends 1.6e-4 from its own
-    # answer in this field when the initial pose moves by one float32 ulp (6e-5 with 8 threads; 3e-6 on frame 0) -
+    # frames.  Frame 3's translation is the ill-conditioned one of the four: the imported reference itself ends between 1.6e-5 and
+    # 1.9e-4 from its own answer in this field under the ten perturbations of tests/ref_drift.py (2 / 4 / 8 threads, one-ulp nudges of
+    # the initial pose, the keypoints, the cameras; at most 1.5e-5 / 3.7e-5 / 1.1e-6 on frames 0 / 1 / 2) -
     # tests/golden/sens_cfg2_48view_100it.npz, oracle/gen_golden.py: sensitivity_cfg2_goldens - and the band for that frame is the
-    # one of the other round-off-amplifying loops: 3 x the reference's own drift (tests/ref_drift.py)
+    # one of the other round-off-amplifying loops: K x the reference's own largest drift
     band = FIT_TOL
     if frame == 3:
         import ref_drift as RD
         sens = load_golden("sens_cfg2_48view_100it.npz")
-        own = max(float(np.abs(sens[f"{v}_f3_final_global_transl"] - g["final_global_transl"]).max()) for v in RD.VARIANTS)
+        owns = [float(np.abs(sens[f"{v}_f3_final_global_transl"] - g["final_global_transl"]).max()) for v in RD.VARIANTS]
+        own = max(owns)
         assert 1e-4 < own < 3e-4, own
         band = max(FIT_TOL, RD.K * own)
+        print("cfg2 frame 3 global_transl:", RD.position(float(np.abs(p["global_transl"] * p["scale"] - g["final_global_transl"]).max()), owns))
     np.testing.assert_allclose(p["global_transl"] * p["scale"], g["final_global_transl"], atol=band)
     b.close()
 

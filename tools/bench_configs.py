@@ -21,10 +21,48 @@ BYTES_SMPLX_FWD = 61_090_200 + 2_514_000 + 2_304_500 + 2_304_500 + 125_700      
 BYTES_CFG3_MASK = 15_270_000                                                       # + the sampled vertices' posedirs columns when the silhouette loss is on
 BYTES_CFG5_ITER = 136_600_000                                                      # forward + full reverse pass
 HBM_PEAK_GBS = 8000.0
-# bf_nearest_kernel (reference rule): VALU instructions per query-wave from the PMC pass of profiles/r05_rocprof_summary.md, re-measured
-# in round 6 (SQ_INSTS_VALU / queries; profiles/r06_rocprof_summary.md).  1,024 SIMDs issue one wave64 VALU instruction per 4 cycles at 2.4 GHz.
+# bf_nearest_kernel (reference rule): instructions per query-wave from the PMC pass of profiles/r05_rocprof_summary.md, re-measured in
+# round 6 (SQ_INSTS_VALU, SQ_INSTS_SALU / queries; profiles/r06_rocprof_summary.md).
 NEAREST_VALU_PER_QUERY = 894
-SIMD_VALU_PER_S = 1024 * 2.4e9 / 4
+NEAREST_SALU_PER_QUERY = 502
+# What a gfx950 SIMD issues (profiles/r06_issue_rate.md, tools/ubench/issue.hip): cycles per wave64 instruction per SIMD at two or more
+# waves, by class - the FAST class (fma / add / mul / mov / logic on vector registers) beside the SLOW class (compares, selects, max / min,
+# DPP, anything with a scalar operand, ...; transcendentals and v_readlane 8.1), the scalar unit a third pipe.  Rounds 3-5 priced every
+# vector instruction at 4.
+ISSUE_FAST, ISSUE_SLOW, ISSUE_TRANS, ISSUE_VCCRUN, ISSUE_SALU = 2.1, 4.1, 8.1, 16.0, 4.3
+SIMDS, CLOCK_HZ = 1024, 2.4e9
+# the kernel's static ISA mix (tools/isa_issue_classes.py on the product build): fractions of its vector instructions
+NEAREST_MIX = {"fast": 344 / 947, "slow": 540 / 947, "trans": 59 / 947, "vccrun": 4 / 947}
+
+
+def nearest_issue_bound(queries):
+    """-> (seconds, which pipe): the longest of the three issue pipes over a launch's queries spread evenly over the SIMDs"""
+    m = NEAREST_MIX
+    pipes = {"slow vector pipe": NEAREST_VALU_PER_QUERY * (m["slow"] * ISSUE_SLOW + m["trans"] * ISSUE_TRANS + m["vccrun"] * ISSUE_VCCRUN),
+             "fast vector pipe": NEAREST_VALU_PER_QUERY * m["fast"] * ISSUE_FAST,
+             "scalar pipe": NEAREST_SALU_PER_QUERY * ISSUE_SALU}
+    which = max(pipes, key=pipes.get)
+    return queries * pipes[which] / SIMDS / CLOCK_HZ, which, {k: round(v) for k, v in pipes.items()}
+
+
+def nearest_dominant(queries, search_s):
+    bound_s, which, pipes = nearest_issue_bound(queries)
+    return {"name": "bf_nearest_kernel", "bound": "issue: " + which, "queries_per_launch": queries,
+            "valu_per_query_wave": NEAREST_VALU_PER_QUERY, "salu_per_query_wave": NEAREST_SALU_PER_QUERY,
+            "cycles_per_query_by_pipe": pipes, "ms_per_launch": search_s * 1e3, "issue_bound_ms": bound_s * 1e3,
+            "frac": bound_s / search_s if search_s > 0 else None,
+            "issue_cycles_per_instruction": {"fast": ISSUE_FAST, "slow": ISSUE_SLOW, "transcendental": ISSUE_TRANS, "salu": ISSUE_SALU},
+            "note": "one query per wave, 6 waves per SIMD: frac = queries x the busiest issue pipe's cycles per query (instruction counts by PMC, "
+                    "class mix from the ISA, cycles per class MEASURED at this occupancy: profiles/r06_issue_rate.md) / (1,024 SIMDs x 2.4 GHz) / "
+                    "the search's device time in the last dense iteration (HIP events).  Rounds 3-5 charged 4 cycles for every vector instruction "
+                    "(122 us, '0.84-0.90'); at 2 for every one it would be 61 us"}
+
+
+# config 5, SURVEY 8(d) by iteration KIND: the scan loss is on for i > iters // 3 (smplify.py:205); before that an iteration is the
+# keypoint-only SMPL-X forward
+def cfg5_bytes_per_frame(iters):
+    kp_only = iters // 3 + 1
+    return kp_only * BYTES_SMPLX_FWD + (iters - kp_only) * BYTES_CFG5_ITER
 
 
 def nominal_roofline(bytes_per_fit, fit_s, what):
@@ -133,15 +171,10 @@ def cfg5x(reps, frames=8, n_views=48, iters=300, disp_iters=300):
            "frames_per_s_end_to_end": frames / total, "ms_scan_upload_and_grid": t_scan * 1e3, "ms_per_fit": dt * 1e3,
            "ms_per_iteration": dt * 1e3 / iters, "ms_displacement_stage": dd * 1e3,
            "ms_per_displacement_iteration": dd * 1e3 / disp_iters,
-           "roofline": nominal_roofline(BYTES_CFG5_ITER * iters * frames, dt, "config 5's dense iteration (forward mesh, closest-point search, point-cloud loss, reverse mesh, reduce)"),
+           "roofline": nominal_roofline(cfg5_bytes_per_frame(iters) * frames, dt, "config 5's fit (keypoint-only iterations, then forward mesh, closest-point search, point-cloud loss, reverse mesh, reduce)"),
            "device_ms_last_iteration": per_class, "resident_fit_launch": b.dense_resident(),
-           # the iteration's dominant kernel is not bound by bytes: one query per wave, ~894 VALU instructions per query
-           "dominant_kernel": {"name": "bf_nearest_kernel", "bound": "valu_issue", "queries_per_launch": frames * nv,
-                               "valu_per_query_wave": NEAREST_VALU_PER_QUERY, "ms_per_launch": search_s * 1e3,
-                               "issue_bound_ms": frames * nv * NEAREST_VALU_PER_QUERY / SIMD_VALU_PER_S * 1e3,
-                               "frac": frames * nv * NEAREST_VALU_PER_QUERY / SIMD_VALU_PER_S / search_s if search_s > 0 else None,
-                               "note": "frac = queries x VALU instructions per query-wave / (1,024 SIMDs x 2.4 GHz / 4) / the search's device time in "
-                                       "the last dense iteration (HIP events); instructions per query from the PMC pass in profiles/"}}
+           # the iteration's dominant kernel is not bound by bytes: one query per wave, ~894 vector + ~502 scalar instructions per query
+           "dominant_kernel": nearest_dominant(frames * nv, search_s)}
     b.close()
     for s in scans:
         s.close()
