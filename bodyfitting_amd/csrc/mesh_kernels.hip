@@ -221,9 +221,20 @@ bf_mesh_span_kernel(MeshTab M, const float *__restrict__ state, float *__restric
 // Arithmetic and its order per frame are those of bf_mesh_kernel (rows ascending inside a row group, row groups
 // ascending, template + shape offset first, pose offset added to it), so a frame's result does not depend on the
 // batch it was in.
-#define BF_MM_CH 64
+// Round 6: the eight-frame instance asks for its rows in chunks of 8 (two chunks in flight) instead of 64 and for six waves per SIMD:
+// 66 registers instead of 154, so TWO workgroups fit a CU and config 5's 328 tiles are all resident at once - at one workgroup per CU
+// the last 72 ran as a second round with nothing to hide their stream behind (forward pass 37.6 -> 31 us per dense iteration, config 5's
+// fit 54.9 -> 53.5 ms, same box; chunks of 12: the same; chunks of 16 need 90 registers - held to 80 they spill and the pass takes 44 us).
+// The bytes in flight per CU are what they were (24 waves x 16 rows instead of 12 x 64); the one-, two- and four-frame instances keep 64.
+#ifndef BF_MM_CH8
+#define BF_MM_CH8 8
+#endif
+#ifndef BF_MM_OCC8
+#define BF_MM_OCC8 6
+#endif
+#define BF_MM_CH (FPW == 8 ? BF_MM_CH8 : 64)
 template <int FPW>
-__global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG)
+__global__ void __launch_bounds__(BF_MESH_TILE * 3 * BF_MESH_RG, FPW == 8 ? BF_MM_OCC8 : 1)
 bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, float *__restrict__ vraw, float *__restrict__ vout,
                      float *__restrict__ xpart, float *__restrict__ vposed, float *__restrict__ dvzero, MaskProj mp, int *door, int door_target) {
     static_assert(FPW == 1 || FPW == 2 || FPW == 4 || FPW == 8, "frames per workgroup");
@@ -248,9 +259,10 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
     const int p0 = rg * rows, p1 = min(npf, p0 + rows);
     const int pdp = M.pd_pitch;
     const float *pd = M.posedirs + (size_t)p0 * pdp + (ok ? gcol : 0);
-    float pv[BF_MM_CH];
+    constexpr int CH = BF_MM_CH;
+    float pv[CH];
 #pragma unroll
-    for (int i = 0; i < BF_MM_CH; ++i) pv[i] = p0 + i < p1 ? pd[(size_t)i * pdp] : 0.f;
+    for (int i = 0; i < CH; ++i) pv[i] = p0 + i < p1 ? pd[(size_t)i * pdp] : 0.f;
     const bool coh = door && (door_target & BF_DOOR_COHERENT_BIT);
     // ... and so are the model rows the epilogue needs for this thread's vertex coordinate (shape directions, template, the sparse
     // skinning row): they depend on nothing that is waited for below, and requested here their two memory round trips are over
@@ -305,15 +317,15 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
     float acc[FPW];
 #pragma unroll
     for (int f = 0; f < FPW; ++f) acc[f] = 0.f;
-    for (int c0 = 0; c0 < rows; c0 += BF_MM_CH) {
-        float nx[BF_MM_CH];
-        const bool more = c0 + BF_MM_CH < rows;
+    for (int c0 = 0; c0 < rows; c0 += CH) {
+        float nx[CH];
+        const bool more = c0 + CH < rows;
         if (more) {
 #pragma unroll
-            for (int i = 0; i < BF_MM_CH; ++i) nx[i] = p0 + c0 + BF_MM_CH + i < p1 ? pd[(size_t)(c0 + BF_MM_CH + i) * pdp] : 0.f;
+            for (int i = 0; i < CH; ++i) nx[i] = p0 + c0 + CH + i < p1 ? pd[(size_t)(c0 + CH + i) * pdp] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < BF_MM_CH; ++i) {
+        for (int i = 0; i < CH; ++i) {
             if (c0 + i < rows) {                             // (s_feat rows up to npad exist and are zero beyond npf)
                 const float *fr = s_feat + (size_t)(p0 + c0 + i) * FPW;
                 if constexpr (FPW >= 4) {
@@ -330,7 +342,7 @@ bf_mesh_multi_kernel(MeshTab M, const float *__restrict__ state, int n_frames, f
         }
         if (more) {
 #pragma unroll
-            for (int i = 0; i < BF_MM_CH; ++i) pv[i] = nx[i];
+            for (int i = 0; i < CH; ++i) pv[i] = nx[i];
         }
     }
 #pragma unroll

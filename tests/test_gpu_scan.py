@@ -496,7 +496,7 @@ def test_config5_iteration_counts_end_state_against_the_reference(small):
     # closest-point search built with fused multiply-adds)
     sens = load_golden("sens_scan_nv690_300it.npz")
     band = {k: RD.band(g, sens, [f"it{k}_{n}" for n in PARAMS], variants=RD.SCAN_VARIANTS) for k in (100, 101, 300)}
-    print("bands = 3 x the reference's own drift:", band)
+    print("bands = K x the reference's largest drift under ten perturbations + the fused search (tests/ref_drift.py):", band)
 
     def rel_band(metric_of, ref_value, floor=0.05):
         """K x how far the reference's perturbed runs end from the reference in this metric (relative), at least `floor`"""

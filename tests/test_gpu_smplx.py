@@ -114,7 +114,7 @@ def test_smplx_with_masks_runs_and_improves(sx):
     worst = max(float(np.abs(got[n] - g[f"it15_{n}"]).max()) for n in O.SMPLX_PARAMS)
     print("smplx mask loop: max |param - reference| after 15 steps =", worst)
     band = RD.band(g, load_golden("sens_smplx_mask_8view_15it.npz"), [f"it15_{n}" for n in O.SMPLX_PARAMS])
-    print("band = 3 x the reference's own drift over the same 15 steps (8 threads / 1 ulp):", band)
+    print("band = K x the reference's largest drift over the same 15 steps (ten perturbations, tests/ref_drift.py):", band)
     assert worst < band
     b.close()
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the whole -m gpu suite, smoke, the default bench line, configs 3 / 5
-TAG=${1:-r5mid}
+TAG=${1:-validate}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/$TAG
 python -m pytest tests -m gpu -q -s > gpurun_out/$TAG/pytest_all.log 2>&1; echo "all rc=$?" >> gpurun_out/$TAG/pytest_all.log

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box (through gpurun): round-6 evidence (tools/profile_round5.sh + FETCH / WRITE passes over configs 3 and 5 and the closest-point kernel's wave-cycle breakdown).   usage: tools/profile_round5.sh <tag>
+# Run on the GPU box (through gpurun): round-6 evidence - kernel traces, PMC passes (MFMA, FETCH / WRITE of config 2, the batched mesh path, configs 3 and 5), the closest-point kernel's wave-cycle breakdown.   usage: tools/profile_round6.sh <tag>
 #   1. kernel trace + stats of the headline bench command (config 2) and of the 32- / 256-frame batches (config 4 shard / whole)
 #   2. PMC passes (each on its own, no trace domains): MFMA instruction / busy counters of the batched mesh kernels,
 #      FETCH_SIZE and WRITE_SIZE of the same launches, and of the headline fit kernel
@@ -35,6 +35,15 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_
 timeout 500 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD --output-format csv -d "$OUT/pmc_nearest_fast_rule" -- python3 $ROOT/tools/bench_configs.py --cfg5x --reps 1 --iters 120 > "$OUT/pmc_nearest_fast_rule.log" 2>&1; echo "pmc_nearest_fast_rule rc=$?"
 unset BF_NEAREST_RULE
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_texfit" -- python3 $ROOT/tools/bench_texfit.py > "$OUT/trace_texfit.log" 2>&1; echo "trace_texfit rc=$?"
+# the dense kernels WITHOUT the resident fit launch (BF_DENSE_PERSISTENT=0: one fit launch per iteration, no doorbells): in the product
+# schedule the forward mesh kernels request their posedirs slice and then WAIT for the fit launch's bell inside the kernel, so their
+# durations in trace_cfg35 include that wait (~16-20 us); here they are the kernels' own
+export BF_DENSE_PERSISTENT=0
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_cfg35_nodoor" -- python3 $ROOT/tools/bench_configs.py --cfg3 --cfg5x --reps 1 > "$OUT/trace_cfg35_nodoor.log" 2>&1; echo "trace_cfg35_nodoor rc=$?"
+unset BF_DENSE_PERSISTENT
+# the closest-point kernel's wave-cycle breakdown, cache hit rates and traffic on config 5's scan and query count (tools/bench_nearest.py)
+BODYFIT_LIB=$ROOT/bodyfitting_amd/libbodyfit.so bash $ROOT/tools/gpu_pmc_nearest6.sh $TAG libbodyfit.so > "$OUT/nearest_pmc.txt" 2>&1; echo "nearest pmc rc=$?"
+cd /tmp
 # memory-side traffic of the dense kernels (config 3 and config 5 apart: bf_mesh_multi_kernel<1> / <8>), one counter per pass
 for c in 3 5; do
   A=$([ $c = 3 ] && echo "--cfg3" || echo "--cfg5x")
@@ -44,5 +53,5 @@ done
 cd "$ROOT"
 find "$OUT" -name "*.db" -delete
 python3 tools/summarize_dense_traffic.py "$OUT" "$OUT/pmc_traffic_dense.json" > "$OUT/summary_dense_traffic.md" 2> "$OUT/summary_dense_traffic.err"; echo "dense traffic rc=$?"
-python3 tools/summarize_round4.py "$OUT" > "$OUT/summary.md" 2> "$OUT/summary.err"; echo "summary rc=$?"
+python3 tools/summarize_profile.py "$OUT" > "$OUT/summary.md" 2> "$OUT/summary.err"; echo "summary rc=$?"
 du -sh "$OUT"
