@@ -53,7 +53,13 @@
 #define BF_T(k) do { } while (0)
 #define BF_SYNC() __syncthreads()
 #endif
+#if defined(BF_STAMP) && defined(BF_STAMP_MARKS)
+// (make stamp STAMPFLAGS=-DBF_STAMP_MARKS: the marks 50 .. 54 inside the Adam phase - wave 0's Rodrigues reverse / Adam, wave 3's
+//  geometric d(beta) / Adam / beta-dependent tables - go to the free slots 12 .. 16; they perturb the build a little)
+#define BF_MARK(k, who, itv, t0v) do { (void)(itv); (void)(t0v); if ((k) >= 50 && (k) <= 54) BF_T(12 + (k) - 50); } while (0)
+#else
 #define BF_MARK(k, who, itv, t0v) do { (void)(itv); (void)(t0v); } while (0)
+#endif
 // (stamp build) cycles since kernel entry at a few points of a dense-schedule launch: thread `who` of frame 0 -> io.debug[4160 + k]
 #ifdef BF_STAMP
 #define BF_KMARK(k, who) do { if (EXT && tid == (who) && frame == 0 && io.debug) io.debug[4160 + (k)] = (float)(long long)(clock64() - bf_k0); } while (0)
