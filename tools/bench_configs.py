@@ -65,12 +65,25 @@ def cfg5_bytes_per_frame(iters):
     return kp_only * BYTES_SMPLX_FWD + (iters - kp_only) * BYTES_CFG5_ITER
 
 
-def nominal_roofline(bytes_per_fit, fit_s, what):
+def dense_traffic(cfg, frames, iters):
+    """memory-side bytes of one fit by counters (profiles/pmc_traffic.json "dense": FETCH_SIZE doubled + WRITE_SIZE over the fit's kernels,
+    tools/profile_round6.sh), if the committed passes were taken at this shard size; else None"""
+    try:
+        with open(os.path.join(REPO, "profiles", "pmc_traffic.json")) as f:
+            d = (json.load(f).get("dense") or {}).get(cfg)
+    except (OSError, ValueError):
+        return None
+    return d["bytes_per_fit"] if d and d.get("frames_per_fit") == frames and d.get("iters") == iters else None
+
+
+def nominal_roofline(bytes_per_fit, fit_s, what, traffic=None):
     gbs = bytes_per_fit / fit_s / 1e9
-    return {"bound": "hbm", "kernel": what, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes_per_fit": bytes_per_fit,
-            "note": "nominal SURVEY 8(d) bytes per frame-iteration x iterations x frames over the fit's wall time (the resident fit launch and "
-                    "4-5 kernels per iteration: no single dominant kernel for the byte figure; device_ms_last_iteration has the split)"}
+    return {"bound": "hbm", "kernel": what, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "real_hbm_gbs": traffic / fit_s / 1e9 if traffic else None, "algorithmic_bytes_per_fit": bytes_per_fit,
+            "note": "NOMINAL: SURVEY 8(d) bytes per frame-iteration, by iteration kind, x frames over the fit's wall time (every frame charged its own "
+                    "stream of the model tensors); `traffic` = the fit's memory-side bytes by counters (profiles/pmc_traffic.json), `real_hbm_gbs` = "
+                    "traffic / time: what HBM sees.  The dense configurations are bound by their launch chain's latencies (config 3) and the "
+                    "closest-point search's instruction issue (config 5), not by bytes; device_ms_last_iteration has the split"}
 
 
 def timed(fn, reps):
@@ -102,7 +115,7 @@ def cfg3(reps, n_views=48, iters=200, mask_views=8):
                      "(%d mask views), %d iterations" % (n_views, len(mask_frames), iters),
            "frames_per_s": 1.0 / dt, "ms_per_fit": dt * 1e3, "ms_per_iteration": dt * 1e3 / iters,
            "ms_mask_upload_and_contours": t_masks * 1e3,
-           "roofline": nominal_roofline(BYTES_SMPLX_FWD * iters + BYTES_CFG3_MASK * (iters - iters // 3 - 1), dt, "config 3's dense iteration (forward mesh, keypoints + contours with fixed-point gradient sums, reverse mesh, reduce)"),
+           "roofline": nominal_roofline(BYTES_SMPLX_FWD * iters + BYTES_CFG3_MASK * (iters - iters // 3 - 1), dt, "config 3's dense iteration (forward mesh, keypoints + contours with fixed-point gradient sums, reverse mesh, reduce)", dense_traffic("cfg3", 1, iters)),
            "device_ms_last_iteration": per_class, "resident_fit_launch": b.dense_resident()}
     b.close(); dev.close()
     return out
@@ -171,7 +184,7 @@ def cfg5x(reps, frames=8, n_views=48, iters=300, disp_iters=300):
            "frames_per_s_end_to_end": frames / total, "ms_scan_upload_and_grid": t_scan * 1e3, "ms_per_fit": dt * 1e3,
            "ms_per_iteration": dt * 1e3 / iters, "ms_displacement_stage": dd * 1e3,
            "ms_per_displacement_iteration": dd * 1e3 / disp_iters,
-           "roofline": nominal_roofline(cfg5_bytes_per_frame(iters) * frames, dt, "config 5's fit (keypoint-only iterations, then forward mesh, closest-point search, point-cloud loss, reverse mesh, reduce)"),
+           "roofline": nominal_roofline(cfg5_bytes_per_frame(iters) * frames, dt, "config 5's fit (keypoint-only iterations, then forward mesh, closest-point search, point-cloud loss, reverse mesh, reduce)", dense_traffic("cfg5", frames, iters)),
            "device_ms_last_iteration": per_class, "resident_fit_launch": b.dense_resident(),
            # the iteration's dominant kernel is not bound by bytes: one query per wave, ~894 vector + ~502 scalar instructions per query
            "dominant_kernel": nearest_dominant(frames * nv, search_s)}

@@ -36,10 +36,14 @@ for cfg in ("cfg3", "cfg5"):
     for k in sorted(fe, key=lambda k: -sum(fe[k]["FETCH_SIZE"])):
         if "grid_" in k or "rocclr" in k or "contour_kernel" in k and "kp_" not in k:
             continue            # (per-frame input work: scan grids, mask upload, contour extraction - not part of a fit)
+        if any(x in k for x in ("bf_disp_", "bf_face_normal", "bf_transpose", "bf_joints")):
+            continue            # (the SMPL+D stage, one-off model tables, the result's joints: not the fit either)
         f = fe[k]["FETCH_SIZE"]
         w = wr.get(k, {}).get("WRITE_SIZE", [0.0])
         rd, wt = 2 * sum(f) / len(f) * 1024, sum(w) / max(len(w), 1) * 1024
         per_fit = len(f) / fits
+        if "bf_nearest" in k:   # (the SMPL+D stage launches it too: a FIT runs it in its iterations past n // 3 only)
+            per_fit = ITERS[cfg] - ITERS[cfg] // 3 - 1
         if per_fit < 0.5:
             continue
         rows[short(k)] = {"launches_per_fit": per_fit, "read_bytes_per_launch": rd, "write_bytes_per_launch": wt}
