@@ -21,10 +21,10 @@ BYTES_SMPLX_FWD = 61_090_200 + 2_514_000 + 2_304_500 + 2_304_500 + 125_700      
 BYTES_CFG3_MASK = 15_270_000                                                       # + the sampled vertices' posedirs columns when the silhouette loss is on
 BYTES_CFG5_ITER = 136_600_000                                                      # forward + full reverse pass
 HBM_PEAK_GBS = 8000.0
-# bf_nearest_kernel (reference rule): instructions per query-wave from the PMC pass of profiles/r05_rocprof_summary.md, re-measured in
-# round 6 (SQ_INSTS_VALU, SQ_INSTS_SALU / queries; profiles/r06_rocprof_summary.md).
-NEAREST_VALU_PER_QUERY = 894
-NEAREST_SALU_PER_QUERY = 502
+# bf_nearest_kernel (reference rule): instructions per query-wave in config 5's loop by PMC (SQ_INSTS_VALU, SQ_INSTS_SALU / queries over
+# 120 fit + 120 SMPL+D iterations; profiles/r06_rocprof_summary.md.  Round 5: 894 / 502; the list map's uniform branches moved 42 to the scalar side).
+NEAREST_VALU_PER_QUERY = 852
+NEAREST_SALU_PER_QUERY = 519
 # What a gfx950 SIMD issues (profiles/r06_issue_rate.md, tools/ubench/issue.hip): cycles per wave64 instruction per SIMD at two or more
 # waves, by class - the FAST class (fma / add / mul / mov / logic on vector registers) beside the SLOW class (compares, selects, max / min,
 # DPP, anything with a scalar operand, ...; transcendentals and v_readlane 8.1), the scalar unit a third pipe.  Rounds 3-5 priced every
@@ -55,7 +55,7 @@ def nearest_dominant(queries, search_s):
             "note": "one query per wave, 6 waves per SIMD: frac = queries x the busiest issue pipe's cycles per query (instruction counts by PMC, "
                     "class mix from the ISA, cycles per class MEASURED at this occupancy: profiles/r06_issue_rate.md) / (1,024 SIMDs x 2.4 GHz) / "
                     "the search's device time in the last dense iteration (HIP events).  Rounds 3-5 charged 4 cycles for every vector instruction "
-                    "(122 us, '0.84-0.90'); at 2 for every one it would be 61 us"}
+                    "('0.84-0.90'); at 2 for every one it would be half of that"}
 
 
 # config 5, SURVEY 8(d) by iteration KIND: the scan loss is on for i > iters // 3 (smplify.py:205); before that an iteration is the
